@@ -1,0 +1,30 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_case(name):
+    d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    n = int(d["n"])
+    d["snps"] = np.unpackbits(d["snps_packed"], axis=1)[:, :n].astype(np.int8)
+    d["cof"] = list(d["cofactors"]) if len(d["cofactors"]) else None
+    return d
+
+
+CASE_NAMES = ["struct_n150_s0", "struct_n150_s1", "struct_n300_s2", "struct_n300_s3", "bern_n200_s4"]
+
+
+@pytest.fixture(params=CASE_NAMES)
+def case(request):
+    return load_case(request.param)

@@ -1,0 +1,157 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (/root/reference) in this container.
+
+Run once in the build container:  python tests/golden/make_golden.py
+The reference is imported through refshim.py (2to3 on the fly, nothing copied); this script is
+a no-op where /root/reference is absent (e.g. the GPU box).  Fixtures hold DATA only: seeded
+inputs and the reference's outputs, in two modes -- 'lit' (the reference as written, fp32
+where it says 'single') and 'dbl' ('single' -> 'double', the oracle the 1e-6 target refers to).
+"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import refshim  # noqa: E402
+
+
+def structured_genotypes(rng, n, m, npop=3, fst=0.1):
+    """Balding-Nichols style sub-populations so that the REML optimum is interior."""
+    anc = rng.uniform(0.1, 0.9, size=m)
+    a = anc * (1 - fst) / fst
+    b = (1 - anc) * (1 - fst) / fst
+    pop_p = rng.beta(a[:, None], b[:, None], size=(m, npop))
+    pops = rng.randint(0, npop, size=n)
+    snps = (rng.random_sample((m, n)) < pop_p[:, pops]).astype(np.int8)
+    keep = (snps.sum(1) > 0) & (snps.sum(1) < n)
+    return snps[keep]
+
+
+def bernoulli_genotypes(rng, n, m):
+    """simulations.py:21-24."""
+    snps = np.round(rng.random_sample((m, n))).astype(np.int8)
+    return snps[snps.sum(1) > 0]
+
+
+def phenotype(rng, snps, h2=0.6, ncausal=10):
+    m, n = snps.shape
+    idx = rng.choice(m, ncausal, replace=False)
+    eff = rng.exponential(1.0, size=ncausal)
+    g = eff @ snps[idx].astype(np.float64)
+    e = rng.randn(n)
+    y = g + e * np.sqrt((1 - h2) / h2 * g.var(ddof=1) / e.var(ddof=1))
+    return (y - y.mean()) / y.std()
+
+
+def quiet(fn, *a, **kw):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **kw)
+
+
+def run_case(mods, snps, y, cof, nperm, perm_seed):
+    lm, kin = mods['linear_models'], mods['kinship']
+    out = {}
+    snp_list = list(snps)
+    k_unscaled = np.asarray(quiet(kin.calc_ibs_kinship, snp_list, scaled=False))
+    k_ibs = np.asarray(quiet(kin.calc_ibs_kinship, snp_list))
+    out['ibs_unscaled'] = k_unscaled
+    out['ibs_scaled'] = k_ibs
+    out['ibd_scaled'] = np.asarray(quiet(kin.calc_ibd_kinship, snp_list))
+    out['scale_k_of_ibs_unscaled'] = np.asarray(kin.scale_k(k_unscaled))
+    res = quiet(lm.emmax, snp_list, list(y), k_ibs, cofactors=cof)
+    for k in ('ps', 'f_stats', 'rss', 'var_perc'):
+        out['emmax_' + k] = np.asarray(res[k], dtype=np.float64).reshape(-1)
+    out['emmax_h0_rss'] = np.asarray(res['h0_rss'], dtype=np.float64).reshape(-1)
+    out['emmax_h0_betas'] = np.asarray(res['h0_betas'], dtype=np.float64).reshape(-1)
+    for k in ('pseudo_heritability', 've', 'vg', 'max_ll'):
+        out['emmax_' + k] = np.float64(res[k])
+    reml = quiet(lm.get_emma_reml_estimates, list(y), k_ibs, cofactors=cof)
+    for k in ('max_ll', 'delta', 've', 'vg', 'pseudo_heritability'):
+        out['reml_' + k] = np.float64(reml[k])
+    out['reml_beta'] = np.asarray(reml['beta'], dtype=np.float64).reshape(-1)
+    out['reml_mahalanobis_rss'] = np.asarray(reml['mahalanobis_rss'], dtype=np.float64).reshape(-1)
+    out['eig_L_values'] = np.asarray(reml['eig_L']['values'], dtype=np.float64)
+    lmm = reml['lmm']
+    out['eig_R_values'] = np.asarray(lmm._get_eigen_R_(X=lmm.X)['values'], dtype=np.float64)
+    H = np.asarray(reml['H_sqrt_inv'], dtype=np.float64)
+    probe = np.random.RandomState(99).randn(H.shape[0], 3)
+    out['HtH_probe'] = H.T @ (H @ probe)
+    # with_betas variant of the scan
+    lmm2 = lm.LinearMixedModel(list(y))
+    lmm2.add_random_effect(k_ibs)
+    if cof is not None:
+        for c in cof:
+            lmm2.add_factor(c)
+    wb = quiet(lmm2.emmax_f_test, snp_list[:200], with_betas=True, emma_num=0)
+    out['wb_ps'] = np.asarray(wb['ps'], dtype=np.float64)
+    out['wb_betas'] = np.asarray(wb['betas'], dtype=np.float64)
+    # permutations (intercept only in the reference: h0_X * list-of-floats needs q == 1)
+    if cof is None and nperm:
+        lmm3 = lm.LinearMixedModel(list(y))
+        lmm3.add_random_effect(k_ibs)
+        n = len(y)
+        np.random.seed(perm_seed)
+        idx = np.asmatrix(np.arange(n).reshape(n, 1))
+        perm_idx = []
+        for _ in range(nperm):
+            np.random.shuffle(idx)
+            perm_idx.append(np.asarray(idx).reshape(-1).copy())
+        np.random.seed(perm_seed)
+        pr = quiet(lmm3._emmax_permutations_, [s.astype(np.float64) for s in snps], k_ibs,
+                   reml['H_sqrt_inv'], num_perm=nperm)
+        out['perm_idx'] = np.asarray(perm_idx, dtype=np.int32)
+        out['perm_min_ps'] = np.asarray(pr['min_ps'], dtype=np.float64).reshape(-1)
+        out['perm_max_f_stats'] = np.asarray(pr['max_f_stats'], dtype=np.float64).reshape(-1)
+    return out
+
+
+CASES = [
+    # name, kind, N, M, seed, n_cofactors, nperm
+    ('struct_n150_s0', 'struct', 150, 600, 0, 0, 20),
+    ('struct_n150_s1', 'struct', 150, 600, 1, 1, 0),
+    ('struct_n300_s2', 'struct', 300, 3000, 2, 0, 25),
+    ('struct_n300_s3', 'struct', 300, 3000, 3, 2, 0),
+    ('bern_n200_s4', 'bern', 200, 1000, 4, 0, 10),
+]
+
+
+def main():
+    if not refshim.available():
+        print('reference not mounted; nothing to do')
+        return
+    mods = {'lit': refshim.load('literal'), 'dbl': refshim.load('double')}
+    for name, kind, n, m, seed, ncof, nperm in CASES:
+        rng = np.random.RandomState(seed)
+        snps = structured_genotypes(rng, n, m) if kind == 'struct' else bernoulli_genotypes(rng, n, m)
+        y = phenotype(rng, snps)
+        cof = [rng.randn(n) + 0.5 * snps[7 + i] for i in range(ncof)] if ncof else None
+        data = {'snps_packed': np.packbits(snps.astype(np.uint8), axis=1), 'n': np.int64(n),
+                'y': y, 'cofactors': np.asarray(cof) if cof is not None else np.zeros((0, n))}
+        for mode, mm in mods.items():
+            for k, v in run_case(mm, snps, y, cof, nperm, 1000 + seed).items():
+                if mode == 'lit' and k.startswith(('ibs_', 'scale_k_')):
+                    continue          # float64 in both modes and bit-identical (checked below)
+                if k == 'ibs_unscaled':   # store the exact integer counts C = (K - 0.5) * 2M
+                    c = (v - 0.5) * 2 * len(snps)
+                    assert np.abs(c - np.rint(c)).max() < 1e-6
+                    k, v = 'ibs_counts', np.rint(c).astype(np.int32)
+                if mode == 'lit' and k == 'ibd_scaled':
+                    v = v.astype(np.float32)
+                data['%s_%s' % (mode, k)] = v
+        # p-value known-answer grid (scipy.stats.f.sf as the reference calls it)
+        path = os.path.join(HERE, name + '.npz')
+        np.savez_compressed(path, **data)
+        print(name, snps.shape, '%.0f KB' % (os.path.getsize(path) / 1024.0))
+    from scipy import stats
+    F = np.logspace(-8, np.log10(3e3), 400)
+    kat = {'F': F}
+    for nu in (197, 998, 4998, 49998):
+        kat['sf_%d' % nu] = stats.f.sf(F, 1, nu)
+    np.savez_compressed(os.path.join(HERE, 'f_sf_kat.npz'), **kat)
+
+
+if __name__ == '__main__':
+    main()
