@@ -1,0 +1,156 @@
+/* mixmogam_hip.h -- C ABI of libmixmogam_hip.so, the MI355X (gfx950) implementation of the
+ * mixmogam EMMAX hot path.
+ *
+ * The reference (bvilhjal/mixmogam) is pure Python and has NO FFI layer; its boundary for this
+ * path is its Python call surface.  Each entry point below names the reference interface whose
+ * arithmetic it replaces (file:line into /root/reference).  The reference-side binding a
+ * maintainer would add (a ctypes stub inside kinship.py / linear_models.py) is shown in
+ * INTEGRATION.md; the build's own host mirror of that call surface is mixmogam_amd/.
+ *
+ * Conventions
+ *   - every call returns int: 0 = ok, <0 = error (MMG_E_*); text via mmg_last_error(ctx).
+ *   - the caller owns every host buffer; the library never frees or retains one past return.
+ *   - the library owns device memory inside the opaque ctx / geno / model handles.
+ *   - calls are blocking unless named *_async; a ctx is single-threaded (one ctx per device
+ *     per host thread); no callbacks into the host language.
+ *   - genotypes are SNP-major: int8 [M x N] C-contiguous, M SNPs, N individuals
+ *     (simulations.py:21-23, snpsdata.py:2579-2597).
+ *   - no torch / numpy types in any signature: plain pointers and sizes.
+ */
+#ifndef MIXMOGAM_HIP_H
+#define MIXMOGAM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMG_OK 0
+#define MMG_E_ARG (-1)      /* bad argument / shape */
+#define MMG_E_HIP (-2)      /* HIP runtime error */
+#define MMG_E_STATE (-3)    /* call order (e.g. scan before model) */
+#define MMG_E_LIB (-4)      /* rocSOLVER / rocBLAS / RCCL error */
+#define MMG_E_NOMEM (-5)
+
+typedef struct mmg_ctx mmg_ctx;
+typedef struct mmg_geno mmg_geno;    /* device-resident padded genotype store */
+typedef struct mmg_comm mmg_comm;    /* RCCL communicator, one rank per process */
+
+/* ---- library / context -------------------------------------------------------------- */
+int mmg_version(void);
+int mmg_device_count(int* n);
+int mmg_ctx_create(int device, mmg_ctx** ctx);
+int mmg_ctx_destroy(mmg_ctx* ctx);
+const char* mmg_last_error(mmg_ctx* ctx);    /* ctx may be NULL: last global error */
+int mmg_device_info(mmg_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
+/* milliseconds the dominant kernel of the last call took, from hipEvents recorded on the
+ * ctx stream around it.  which: 0 = kinship GEMM, 1 = scan quadratic-form GEMM,
+ * 2 = scan finalize (per-SNP dot + F + p), 3 = permutation GEMM, 4 = eigh, 5 = transpose/pack */
+int mmg_last_kernel_ms(mmg_ctx* ctx, int which, double* ms);
+
+/* ---- genotype store ----------------------------------------------------------------- */
+/* Allocates an [Mpad x Npad] zero-filled int8 store (Npad = N rounded up to 256, Mpad = M
+ * rounded up to 256) in HBM. */
+int mmg_geno_create(mmg_ctx* ctx, int64_t M, int32_t N, mmg_geno** g);
+int mmg_geno_destroy(mmg_ctx* ctx, mmg_geno* g);
+/* Copy SNP rows [m0, m0+rows) from a host [rows x N] int8 C-contiguous buffer. */
+int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, int64_t rows);
+/* Same from a host float32 / float64 [rows x N] buffer holding small integers (the C3 config's
+ * "fp32 genotypes", hdf5_data.py:294 float64 copies); values are rounded to int8 on the device. */
+int mmg_geno_upload_f32(mmg_ctx* ctx, mmg_geno* g, const float* snps, int64_t m0, int64_t rows);
+int mmg_geno_upload_f64(mmg_ctx* ctx, mmg_geno* g, const double* snps, int64_t m0, int64_t rows);
+int mmg_geno_download(mmg_ctx* ctx, mmg_geno* g, int8_t* snps, int64_t m0, int64_t rows);
+/* Synthetic Bernoulli genotypes generated on the device (restates simulations.py:21-23 with a
+ * counter-based hash so that any SNP range can be regenerated on any rank or on the CPU):
+ * s[m][i] = hash64(seed, m_global0 + m, i) >> 48 < thr16 (thr16 = 32768 -> p = 0.5). */
+int mmg_geno_fill_hash(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_global0, uint32_t thr16);
+/* Per-SNP mean and population std (kinship.py:66, hdf5_data.py:99-104). Host outputs, length M. */
+int mmg_geno_snp_stats(mmg_ctx* ctx, mmg_geno* g, double* mean, double* std);
+
+/* out[k][m] = s_m . V[k] for nv host fp64 vectors V [nv x N] (row-major); out host [nv x M].
+ * The per-SNP linear functionals of the scan: X_j = H s regressors of linear_models.py:1323
+ * (with_betas) reduce to such dot products. */
+int mmg_geno_matvec(mmg_ctx* ctx, mmg_geno* g, const double* V, int32_t nv, double* out);
+
+/* ---- kinship (replaces the GEMMs of kinship.py:29-44 and kinship.py:63-69) ----------------- */
+/* IBS counts C = sum_m (2 s_m - 1)(2 s_m - 1)^T as an exact int8-MFMA GEMM (int32 accumulate).
+ * C_out: host int64 [N x N].  Bit-exact with kinship.py:43-44 (whose entries are exact
+ * integers carried in float64). */
+int mmg_kinship_ibs_i8(mmg_ctx* ctx, mmg_geno* g, int64_t* C_out);
+/* General per-SNP affine kinship C = sum_m x_m x_m^T, x_m = scale[m]*s_m + shift[m], as a dense
+ * fp32 MFMA GEMM with the int8 genotypes expanded to fp32 from the LDS tile.  scale/shift: host
+ * float arrays of length M, or NULL for scale=2, shift=-1 (the IBS expansion of kinship.py:43;
+ * exact while M < 2^24).  GRM (kinship.py:66): scale = 1/std, shift = -mean/std.
+ * C_out: host double [N x N] (fp32 partial tiles per K-split, summed in fp64 in fixed order). */
+int mmg_kinship_affine_f32(mmg_ctx* ctx, mmg_geno* g, const float* scale, const float* shift,
+                           double* C_out);
+/* One-shot twin taking host genotypes: upload + mmg_kinship_affine_f32 / _ibs_i8. */
+int mmg_kinship_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N,
+                   const float* scale, const float* shift, double* C_out);
+
+/* ---- eigendecomposition (replaces scipy.linalg.eigh at linear_models.py:594,613) ---------- */
+/* Symmetric eigendecomposition on the device (rocSOLVER dsyevd). A: host [N x N] (symmetric,
+ * both triangles present).  evals ascending; evecs (may be NULL) host [N x N] row-major whose
+ * ROWS are the eigenvectors -- the layout the reference keeps after its transpose at :596
+ * (scipy's evecs.T). */
+int mmg_eigh_f64(mmg_ctx* ctx, const double* A, int32_t N, double* evals, double* evecs);
+/* C[MxN] = op(A) op(B) in fp64 on the device (rocBLAS dgemm; row-major host buffers); used for
+ * the O(N^3) products of linear_models.py:610,898,1303.  ta/tb: 0 = as is, 1 = transposed. */
+int mmg_dgemm_f64(mmg_ctx* ctx, int ta, int tb, int32_t M, int32_t N, int32_t K,
+                  const double* A, const double* B, double* C);
+
+/* ---- EMMAX scan (replaces the loop of linear_models.py:1316-1349) ------------------------- */
+/* Loads the SNP-independent model onto the device:
+ *   A [N x N] symmetric (= Mp Mp^T with Mp = H^T (I - QQ^T), linear_models.py:1300-1303),
+ *   w [N]              (= Mp r, r the residualised transformed phenotype, :1293).
+ * The off-diagonal of A is quantised to `ndigits` balanced base-256 digits (exact integer
+ * GEMM on the int8 matrix cores; 4 digits = 2^-30 of max|A_ij| per entry); the diagonal and w
+ * stay fp64.  ndigits in [2, 6]; 0 = default (4). */
+int mmg_scan_set_model(mmg_ctx* ctx, int32_t N, const double* A, const double* w, int ndigits);
+/* Scan all M SNPs of g:  num = (s.w)^2, den = s'As, rss = h0_rss - num/den,
+ * F = (h0_rss/rss - 1) * df2, p = f.sf(F, 1, df2) (:1345-1349).  Host outputs of length M
+ * (any may be NULL).  den == 0 leaves rss = h0_rss, F = 0, p = 1 (:1308,1329). */
+int mmg_emmax_scan(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2,
+                   double* rss, double* F, double* p);
+/* Same, leaving results in device memory (for RCCL gathers / benchmarking); fetch with
+ * mmg_scan_fetch.  Blocks until the kernels finish. */
+int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2);
+int mmg_scan_fetch(mmg_ctx* ctx, int64_t M, double* rss, double* F, double* p);
+/* Raw per-SNP sufficient statistics of the last scan (length M each; any may be NULL):
+ * dot = s.w, den = s'As, sum = s.1 -- used by the with_betas / cofactor host paths and tests. */
+int mmg_scan_fetch_stats(mmg_ctx* ctx, int64_t M, double* dot, double* den, double* sum);
+/* One-shot twin taking host genotypes. */
+int mmg_emmax_scan_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N,
+                      const double* A, const double* w, double h0_rss, int32_t df2,
+                      double* rss, double* F, double* p);
+
+/* ---- EMMAX permutation test (replaces linear_models.py:1157-1164) ------------------------- */
+/* Ht: host [N x N] = H_sqrt_inv (row-major, as the reference holds it), Ys: host [N x P]
+ * permuted residual columns (:1150-1154).  For every permutation p returns
+ * min_rss[p] = min(h0_rss, min_m ( Ys_p.Ys_p - (t_m.Ys_p)^2 / (t_m.t_m) )), t_m = H (s_m - mean(s_m))
+ * (:1159-1164).  min_rss: host [P]. */
+int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const double* Ys,
+                   int32_t P, double h0_rss, int ndigits, double* min_rss);
+
+/* ---- p-values (replaces scipy.stats.f.sf at linear_models.py:1349,1172) ------------------- */
+/* Upper tail of F(1, df2) evaluated on the device for n values (host in/out). */
+int mmg_f_sf(mmg_ctx* ctx, const double* F, int64_t n, int32_t df2, double* p);
+
+/* ---- multi-GPU (RCCL over xGMI; one process per GPU) -------------------------------------- */
+/* id: 128-byte ncclUniqueId produced by rank 0 and distributed by the host launcher. */
+int mmg_comm_unique_id(unsigned char id[128]);
+int mmg_comm_create(mmg_ctx* ctx, const unsigned char id[128], int rank, int world, mmg_comm** c);
+int mmg_comm_destroy(mmg_ctx* ctx, mmg_comm* c);
+/* all-gather of equal-sized per-rank SNP result blocks that live on the device after
+ * mmg_emmax_scan_device: recv_* are host buffers of world*count doubles (rank-major). */
+int mmg_comm_allgather_scan(mmg_ctx* ctx, mmg_comm* c, int64_t count,
+                            double* rss, double* F, double* p);
+/* in-place all-reduce of host double buffers through device staging (SUM: partial kinship;
+ * MIN: permutation minima).  op: 0 = sum, 1 = min, 2 = max. */
+int mmg_comm_allreduce_f64(mmg_ctx* ctx, mmg_comm* c, double* buf, int64_t count, int op);
+int mmg_comm_allreduce_i64(mmg_ctx* ctx, mmg_comm* c, int64_t* buf, int64_t count, int op);
+int mmg_comm_barrier(mmg_ctx* ctx, mmg_comm* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,288 @@
+"""ctypes binding of libmixmogam_hip.so (include/mixmogam_hip.h).
+
+There is NO CPU fallback: if the library has not been built, cannot be loaded, or no HIP
+device is present, every product entry point raises.  (The CPU oracle lives in oracle/ and is
+test infrastructure only; nothing in this package imports it.)
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmixmogam_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mixmogam_hip.h")
+
+_lib = None
+_lock = threading.Lock()
+
+c_i8p = C.POINTER(C.c_int8)
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+c_i64p = C.POINTER(C.c_int64)
+c_vp = C.c_void_p
+
+# name -> (restype, argtypes); kept in sync with include/mixmogam_hip.h (tests check it)
+PROTOTYPES = {
+    "mmg_version": (C.c_int, []),
+    "mmg_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "mmg_ctx_create": (C.c_int, [C.c_int, C.POINTER(c_vp)]),
+    "mmg_ctx_destroy": (C.c_int, [c_vp]),
+    "mmg_last_error": (C.c_char_p, [c_vp]),
+    "mmg_device_info": (C.c_int, [c_vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), c_i64p]),
+    "mmg_last_kernel_ms": (C.c_int, [c_vp, C.c_int, c_f64p]),
+    "mmg_geno_create": (C.c_int, [c_vp, C.c_int64, C.c_int32, C.POINTER(c_vp)]),
+    "mmg_geno_destroy": (C.c_int, [c_vp, c_vp]),
+    "mmg_geno_upload": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64]),
+    "mmg_geno_upload_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64]),
+    "mmg_geno_upload_f64": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64]),
+    "mmg_geno_download": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64]),
+    "mmg_geno_fill_hash": (C.c_int, [c_vp, c_vp, C.c_uint64, C.c_int64, C.c_uint32]),
+    "mmg_geno_snp_stats": (C.c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "mmg_geno_matvec": (C.c_int, [c_vp, c_vp, c_vp, C.c_int32, c_vp]),
+    "mmg_kinship_ibs_i8": (C.c_int, [c_vp, c_vp, c_vp]),
+    "mmg_kinship_affine_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mmg_kinship_i8": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp, c_vp, c_vp]),
+    "mmg_eigh_f64": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp]),
+    "mmg_dgemm_f64": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_int32, c_vp, c_vp, c_vp]),
+    "mmg_scan_set_model": (C.c_int, [c_vp, C.c_int32, c_vp, c_vp, C.c_int]),
+    "mmg_emmax_scan": (C.c_int, [c_vp, c_vp, C.c_double, C.c_int32, c_vp, c_vp, c_vp]),
+    "mmg_emmax_scan_device": (C.c_int, [c_vp, c_vp, C.c_double, C.c_int32]),
+    "mmg_scan_fetch": (C.c_int, [c_vp, C.c_int64, c_vp, c_vp, c_vp]),
+    "mmg_scan_fetch_stats": (C.c_int, [c_vp, C.c_int64, c_vp, c_vp, c_vp]),
+    "mmg_emmax_scan_i8": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp, c_vp, C.c_double, C.c_int32,
+                                    c_vp, c_vp, c_vp]),
+    "mmg_emmax_perm": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, C.c_int, c_vp]),
+    "mmg_f_sf": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp]),
+    "mmg_comm_unique_id": (C.c_int, [c_vp]),
+    "mmg_comm_create": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.POINTER(c_vp)]),
+    "mmg_comm_destroy": (C.c_int, [c_vp, c_vp]),
+    "mmg_comm_allgather_scan": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, c_vp, c_vp]),
+    "mmg_comm_allreduce_f64": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int]),
+    "mmg_comm_allreduce_i64": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int]),
+    "mmg_comm_barrier": (C.c_int, [c_vp, c_vp]),
+}
+
+
+class MixmogamHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and bind every prototype.  Raises if it is missing."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.isfile(LIB_PATH):
+            raise MixmogamHipError(
+                "libmixmogam_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C mixmogam_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(c_vp)
+
+
+def _arr(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class Geno(object):
+    """Device-resident genotype store ([M x N] int8, SNP-major, padded in HBM)."""
+
+    def __init__(self, ctx, M, N):
+        self.ctx, self.M, self.N = ctx, int(M), int(N)
+        h = c_vp()
+        ctx._check(ctx.lib.mmg_geno_create(ctx.h, self.M, self.N, C.byref(h)))
+        self.h = h
+
+    def upload(self, snps, m0=0):
+        a = np.asarray(snps)
+        if a.ndim != 2 or a.shape[1] != self.N:
+            raise ValueError("expected [rows x %d] genotypes, got %r" % (self.N, a.shape))
+        if a.dtype == np.float32:
+            a = _arr(a, np.float32)
+            fn = self.ctx.lib.mmg_geno_upload_f32
+        elif a.dtype == np.float64:
+            a = _arr(a, np.float64)
+            fn = self.ctx.lib.mmg_geno_upload_f64
+        else:
+            a = _arr(a, np.int8)
+            fn = self.ctx.lib.mmg_geno_upload
+        self.ctx._check(fn(self.ctx.h, self.h, _ptr(a), int(m0), a.shape[0]))
+        return self
+
+    def download(self, m0=0, rows=None):
+        rows = self.M - m0 if rows is None else rows
+        out = np.empty((rows, self.N), dtype=np.int8)
+        self.ctx._check(self.ctx.lib.mmg_geno_download(self.ctx.h, self.h, _ptr(out), int(m0), int(rows)))
+        return out
+
+    def fill_hash(self, seed, m_global0=0, thr16=32768):
+        self.ctx._check(self.ctx.lib.mmg_geno_fill_hash(self.ctx.h, self.h, int(seed), int(m_global0), int(thr16)))
+        return self
+
+    def snp_stats(self):
+        mean = np.empty(self.M)
+        sd = np.empty(self.M)
+        self.ctx._check(self.ctx.lib.mmg_geno_snp_stats(self.ctx.h, self.h, _ptr(mean), _ptr(sd)))
+        return mean, sd
+
+    def matvec(self, V):
+        V = _arr(np.atleast_2d(V), np.float64)
+        assert V.shape[1] == self.N
+        out = np.empty((V.shape[0], self.M))
+        self.ctx._check(self.ctx.lib.mmg_geno_matvec(self.ctx.h, self.h, _ptr(V), V.shape[0], _ptr(out)))
+        return out
+
+    def close(self):
+        if self.h is not None:
+            self.ctx.lib.mmg_geno_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Context(object):
+    """One HIP device context (stream, scan model, result buffers)."""
+
+    KERNEL_SLOTS = {"kinship": 0, "scan_quad": 1, "scan_finalize": 2, "perm": 3, "eigh": 4, "pack": 5}
+
+    def __init__(self, device=0):
+        self.lib = load()
+        n = C.c_int(0)
+        rc = self.lib.mmg_device_count(C.byref(n))
+        if rc != 0 or n.value <= 0:
+            raise MixmogamHipError("no HIP device available (mmg_device_count -> %d devices): %s; "
+                                   "this package has no CPU path" %
+                                   (n.value, (self.lib.mmg_last_error(None) or b"").decode()))
+        h = c_vp()
+        rc = self.lib.mmg_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise MixmogamHipError("mmg_ctx_create(%d) failed: %s" %
+                                   (device, (self.lib.mmg_last_error(None) or b"").decode()))
+        self.h = h
+        self.device = int(device)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MixmogamHipError("libmixmogam_hip error %d: %s" %
+                                   (rc, (self.lib.mmg_last_error(self.h) or b"").decode()))
+
+    def device_info(self):
+        name = C.create_string_buffer(64)
+        ncu = C.c_int(0)
+        mem = C.c_int64(0)
+        self._check(self.lib.mmg_device_info(self.h, name, 64, C.byref(ncu), C.byref(mem)))
+        return {"arch": name.value.decode(), "n_cu": ncu.value, "hbm_bytes": mem.value}
+
+    def kernel_ms(self, which):
+        ms = C.c_double(0.0)
+        self._check(self.lib.mmg_last_kernel_ms(self.h, self.KERNEL_SLOTS[which], C.byref(ms)))
+        return ms.value
+
+    # --- genotype store
+    def geno(self, snps=None, M=None, N=None):
+        if snps is not None:
+            a = np.asarray(snps)
+            g = Geno(self, a.shape[0], a.shape[1])
+            if a.shape[0]:
+                g.upload(a)
+            return g
+        return Geno(self, M, N)
+
+    # --- kinship
+    def kinship_ibs_counts(self, g):
+        out = np.empty((g.N, g.N), dtype=np.int64)
+        self._check(self.lib.mmg_kinship_ibs_i8(self.h, g.h, _ptr(out)))
+        return out
+
+    def kinship_affine(self, g, scale=None, shift=None):
+        out = np.empty((g.N, g.N), dtype=np.float64)
+        sc = None if scale is None else _arr(scale, np.float32)
+        sh = None if shift is None else _arr(shift, np.float32)
+        self._check(self.lib.mmg_kinship_affine_f32(self.h, g.h, _ptr(sc), _ptr(sh), _ptr(out)))
+        return out
+
+    # --- dense fp64 helpers
+    def eigh(self, A, vectors=True):
+        A = _arr(A, np.float64)
+        n = A.shape[0]
+        vals = np.empty(n)
+        vecs = np.empty((n, n)) if vectors else None
+        self._check(self.lib.mmg_eigh_f64(self.h, _ptr(A), n, _ptr(vals), _ptr(vecs)))
+        return vals, vecs          # rows of vecs are eigenvectors
+
+    def dgemm(self, A, B, ta=False, tb=False):
+        A = _arr(A, np.float64)
+        B = _arr(B, np.float64)
+        m, k = (A.shape[1], A.shape[0]) if ta else A.shape
+        k2, n = (B.shape[1], B.shape[0]) if tb else B.shape
+        assert k == k2, (A.shape, B.shape, ta, tb)
+        out = np.empty((m, n))
+        self._check(self.lib.mmg_dgemm_f64(self.h, int(ta), int(tb), m, n, k, _ptr(A), _ptr(B), _ptr(out)))
+        return out
+
+    # --- scan
+    def scan_set_model(self, A, w, ndigits=0):
+        A = _arr(A, np.float64)
+        w = _arr(np.asarray(w).reshape(-1), np.float64)
+        assert A.shape == (len(w), len(w))
+        self._check(self.lib.mmg_scan_set_model(self.h, len(w), _ptr(A), _ptr(w), int(ndigits)))
+
+    def scan(self, g, h0_rss, df2, fetch=True, stats=False):
+        self._check(self.lib.mmg_emmax_scan_device(self.h, g.h, float(h0_rss), int(df2)))
+        if not fetch:
+            return None
+        rss, F, p = np.empty(g.M), np.empty(g.M), np.empty(g.M)
+        self._check(self.lib.mmg_scan_fetch(self.h, g.M, _ptr(rss), _ptr(F), _ptr(p)))
+        out = {"rss": rss, "f_stats": F, "ps": p}
+        if stats:
+            dot, den, sm = np.empty(g.M), np.empty(g.M), np.empty(g.M)
+            self._check(self.lib.mmg_scan_fetch_stats(self.h, g.M, _ptr(dot), _ptr(den), _ptr(sm)))
+            out.update(dot=dot, den=den, sum=sm)
+        return out
+
+    def f_sf(self, F, df2):
+        F = _arr(np.asarray(F).reshape(-1), np.float64)
+        p = np.empty_like(F)
+        self._check(self.lib.mmg_f_sf(self.h, _ptr(F), len(F), int(df2), _ptr(p)))
+        return p
+
+    def perm(self, g, H, Ys, h0_rss, ndigits=0):
+        H = _arr(H, np.float64)
+        Ys = _arr(Ys, np.float64)
+        P = Ys.shape[1]
+        out = np.empty(P)
+        self._check(self.lib.mmg_emmax_perm(self.h, g.h, g.N, _ptr(H), _ptr(Ys), P, float(h0_rss), int(ndigits),
+                                            _ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None) is not None:
+            self.lib.mmg_ctx_destroy(self.h)
+            self.h = None
+
+
+_default_ctx = None
+
+
+def get_context():
+    """Process-wide default context on device LOCAL_RANK (one process per GPU)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get("MMG_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    return _default_ctx

@@ -1,0 +1,686 @@
+// api.hip -- the extern "C" entry points of libmixmogam_hip.so (see include/mixmogam_hip.h).
+#include <rccl/rccl.h>
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+#include "gemm_i8_core.h"
+#include "mmg_internal.h"
+
+static std::string g_last_error;
+
+namespace mmg {
+int set_err(mmg_ctx* ctx, int code, const std::string& msg) {
+  g_last_error = msg;
+  if (ctx) ctx->err = msg;
+  return code;
+}
+}  // namespace mmg
+using namespace mmg;
+
+#define MMG_CHECK_ARG(ctx, cond)                                                   \
+  do {                                                                             \
+    if (!(cond)) return set_err(ctx, MMG_E_ARG, std::string("bad argument: ") + #cond); \
+  } while (0)
+#define MMG_RB(ctx, call)                                                                      \
+  do {                                                                                         \
+    rocblas_status s__ = (call);                                                               \
+    if (s__ != rocblas_status_success)                                                         \
+      return set_err(ctx, MMG_E_LIB, std::string(#call) + ": rocblas status " + std::to_string((int)s__)); \
+  } while (0)
+#define MMG_NCCL(ctx, call)                                                                    \
+  do {                                                                                         \
+    ncclResult_t r__ = (call);                                                                 \
+    if (r__ != ncclSuccess)                                                                    \
+      return set_err(ctx, MMG_E_LIB, std::string(#call) + ": " + ncclGetErrorString(r__));     \
+  } while (0)
+
+struct mmg_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+};
+
+extern "C" {
+
+int mmg_version(void) { return 100; }
+
+int mmg_device_count(int* n) {
+  if (!n) return MMG_E_ARG;
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { *n = 0; return set_err(nullptr, MMG_E_HIP, hipGetErrorString(e)); }
+  *n = c;
+  return MMG_OK;
+}
+
+const char* mmg_last_error(mmg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int mmg_ctx_create(int device, mmg_ctx** out) {
+  if (!out) return MMG_E_ARG;
+  *out = nullptr;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) return set_err(nullptr, MMG_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  mmg_ctx* ctx = new mmg_ctx();
+  ctx->device = device;
+  MMG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  for (int i = 0; i < EV_COUNT; ++i) {
+    MMG_HIP(ctx, hipEventCreate(&ctx->ev[i][0]));
+    MMG_HIP(ctx, hipEventCreate(&ctx->ev[i][1]));
+    ctx->ev_set[i] = false;
+  }
+  hipDeviceProp_t prop;
+  MMG_HIP(ctx, hipGetDeviceProperties(&prop, device));
+  ctx->n_cu = prop.multiProcessorCount;
+  *out = ctx;
+  return MMG_OK;
+}
+
+static void free_model(mmg_scan_model& m) {
+  hipFree(m.Bq); hipFree(m.diag); hipFree(m.w); hipFree(m.job_off); hipFree(m.jobs);
+  m = mmg_scan_model();
+}
+static void free_result(mmg_scan_result& r) {
+  hipFree(r.q); hipFree(r.rss); hipFree(r.F); hipFree(r.p); hipFree(r.dot); hipFree(r.den); hipFree(r.sum);
+  r = mmg_scan_result();
+}
+
+int mmg_ctx_destroy(mmg_ctx* ctx) {
+  if (!ctx) return MMG_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  free_model(ctx->model);
+  free_result(ctx->res);
+  if (ctx->rocblas) rocblas_destroy_handle((rocblas_handle)ctx->rocblas);
+  for (int i = 0; i < EV_COUNT; ++i) { hipEventDestroy(ctx->ev[i][0]); hipEventDestroy(ctx->ev[i][1]); }
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return MMG_OK;
+}
+
+int mmg_device_info(mmg_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* hbm_bytes) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  hipDeviceProp_t prop;
+  MMG_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  if (name && name_len > 0) { std::strncpy(name, prop.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
+  if (n_cu) *n_cu = prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+  return MMG_OK;
+}
+
+int mmg_last_kernel_ms(mmg_ctx* ctx, int which, double* ms) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, which >= 0 && which < EV_COUNT && ms != nullptr);
+  if (!ctx->ev_set[which]) return set_err(ctx, MMG_E_STATE, "no kernel of that kind has run");
+  float f = 0.f;
+  MMG_HIP(ctx, hipEventSynchronize(ctx->ev[which][1]));
+  MMG_HIP(ctx, hipEventElapsedTime(&f, ctx->ev[which][0], ctx->ev[which][1]));
+  *ms = (double)f;
+  return MMG_OK;
+}
+
+// ------------------------------------------------------------------------- genotype store
+int mmg_geno_create(mmg_ctx* ctx, int64_t M, int32_t N, mmg_geno** out) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, out != nullptr && M >= 0 && N > 0);
+  *out = nullptr;
+  mmg_geno* g = new mmg_geno();
+  g->M = M; g->N = N;
+  g->Mpad = std::max<int64_t>(round_up(M, 256), 256);
+  g->Npad = (int32_t)round_up(N, 256);
+  hipError_t e = hipMalloc(&g->d, (size_t)g->Mpad * g->Npad);
+  if (e != hipSuccess) { delete g; return set_err(ctx, MMG_E_NOMEM, std::string("hipMalloc genotype store: ") + hipGetErrorString(e)); }
+  MMG_HIP(ctx, hipMemsetAsync(g->d, 0, (size_t)g->Mpad * g->Npad, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out = g;
+  return MMG_OK;
+}
+
+int mmg_geno_destroy(mmg_ctx* ctx, mmg_geno* g) {
+  if (!g) return MMG_OK;
+  if (ctx) hipStreamSynchronize(ctx->stream);
+  hipFree(g->d);
+  delete g;
+  return MMG_OK;
+}
+
+int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, int64_t rows) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, g && snps && m0 >= 0 && rows >= 0 && m0 + rows <= g->M);
+  if (rows == 0) return MMG_OK;
+  MMG_HIP(ctx, hipMemcpy2DAsync(g->d + m0 * (int64_t)g->Npad, g->Npad, snps, g->N, g->N, rows,
+                                hipMemcpyHostToDevice, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MMG_OK;
+}
+
+extern "C++" {
+template <typename T>
+static int upload_cvt(mmg_ctx* ctx, mmg_geno* g, const T* snps, int64_t m0, int64_t rows) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, g && snps && m0 >= 0 && rows >= 0 && m0 + rows <= g->M);
+  const int64_t chunk = std::max<int64_t>(1, (int64_t)(256 << 20) / ((int64_t)g->N * sizeof(T)));
+  T* tmp = nullptr;
+  MMG_HIP(ctx, hipMalloc(&tmp, (size_t)std::min(chunk, rows) * g->N * sizeof(T)));
+  for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
+    const int64_t nr = std::min(chunk, rows - r0);
+    MMG_HIP(ctx, hipMemcpyAsync(tmp, snps + r0 * g->N, (size_t)nr * g->N * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    if (sizeof(T) == 4) launch_cvt_f32(ctx, (const float*)tmp, g->d + (m0 + r0) * (int64_t)g->Npad, nr, g->N, g->Npad);
+    else launch_cvt_f64(ctx, (const double*)tmp, g->d + (m0 + r0) * (int64_t)g->Npad, nr, g->N, g->Npad);
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  MMG_HIP(ctx, hipFree(tmp));
+  return MMG_OK;
+}
+}  // extern C++
+int mmg_geno_upload_f32(mmg_ctx* ctx, mmg_geno* g, const float* snps, int64_t m0, int64_t rows) {
+  return upload_cvt<float>(ctx, g, snps, m0, rows);
+}
+int mmg_geno_upload_f64(mmg_ctx* ctx, mmg_geno* g, const double* snps, int64_t m0, int64_t rows) {
+  return upload_cvt<double>(ctx, g, snps, m0, rows);
+}
+
+int mmg_geno_download(mmg_ctx* ctx, mmg_geno* g, int8_t* snps, int64_t m0, int64_t rows) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, g && snps && m0 >= 0 && rows >= 0 && m0 + rows <= g->M);
+  if (rows == 0) return MMG_OK;
+  MMG_HIP(ctx, hipMemcpy2DAsync(snps, g->N, g->d + m0 * (int64_t)g->Npad, g->Npad, g->N, rows,
+                                hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MMG_OK;
+}
+
+int mmg_geno_fill_hash(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_global0, uint32_t thr16) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, g != nullptr && thr16 <= 65536);
+  if (g->M == 0) return MMG_OK;
+  {
+    EvScope ev(ctx, EV_PACK);
+    launch_fill_hash(ctx, g, seed, m_global0, thr16);
+  }
+  MMG_HIP(ctx, hipGetLastError());
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MMG_OK;
+}
+
+int mmg_geno_snp_stats(mmg_ctx* ctx, mmg_geno* g, double* mean, double* sd) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, g && mean && sd);
+  if (g->M == 0) return MMG_OK;
+  double *dm = nullptr, *ds = nullptr;
+  MMG_HIP(ctx, hipMalloc(&dm, g->M * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&ds, g->M * sizeof(double)));
+  launch_snp_stats(ctx, g, dm, ds);
+  MMG_HIP(ctx, hipGetLastError());
+  MMG_HIP(ctx, hipMemcpyAsync(mean, dm, g->M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipMemcpyAsync(sd, ds, g->M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipFree(dm); hipFree(ds);
+  return MMG_OK;
+}
+
+// ------------------------------------------------------------------------- kinship
+int mmg_kinship_ibs_i8(mmg_ctx* ctx, mmg_geno* g, int64_t* C_out) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, g && C_out && g->M > 0);
+  // |2s-1| <= 255 would overflow int8 for |s| > 63; genotypes are 0/1/2 (binary or diploid counts)
+  const int64_t Mk = round_up(g->M, BK);
+  int8_t* Xt = nullptr;
+  int* C32 = nullptr;
+  int64_t* C64 = nullptr;
+  hipError_t e = hipMalloc(&Xt, (size_t)g->Npad * Mk);
+  if (e != hipSuccess) return set_err(ctx, MMG_E_NOMEM, "hipMalloc transposed genotype image");
+  MMG_HIP(ctx, hipMalloc(&C32, (size_t)g->Npad * g->Npad * sizeof(int)));
+  MMG_HIP(ctx, hipMalloc(&C64, (size_t)g->N * g->N * sizeof(int64_t)));
+  {
+    EvScope ev(ctx, EV_PACK);
+    launch_transpose(ctx, g, Xt, Mk, 2, -1);
+  }
+  MMG_HIP(ctx, hipGetLastError());
+  int rc = run_kinship_i8(ctx, Xt, g->Npad, Mk, C32);
+  if (rc == MMG_OK) {
+    launch_mirror_i32_to_i64(ctx, C32, g->Npad, g->N, C64);
+    hipError_t e2 = hipMemcpyAsync(C_out, C64, (size_t)g->N * g->N * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
+    if (e2 != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e2));
+  }
+  hipFree(Xt); hipFree(C32); hipFree(C64);
+  return rc;
+}
+
+int mmg_kinship_affine_f32(mmg_ctx* ctx, mmg_geno* g, const float* scale, const float* shift, double* C_out) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, g && C_out && g->M > 0);
+  MMG_CHECK_ARG(ctx, (scale == nullptr) == (shift == nullptr));
+  const int64_t Mk = round_up(g->M, BK);
+  const int ksplit = kinship_pick_ksplit(g->Npad, Mk, true);
+  int8_t* Xt = nullptr;
+  float *dsc = nullptr, *dsh = nullptr, *slabs = nullptr;
+  double* dC = nullptr;
+  hipError_t e = hipMalloc(&Xt, (size_t)g->Npad * Mk);
+  if (e != hipSuccess) return set_err(ctx, MMG_E_NOMEM, "hipMalloc transposed genotype image");
+  MMG_HIP(ctx, hipMalloc(&dsc, Mk * sizeof(float)));
+  MMG_HIP(ctx, hipMalloc(&dsh, Mk * sizeof(float)));
+  MMG_HIP(ctx, hipMalloc(&slabs, (size_t)ksplit * g->Npad * g->Npad * sizeof(float)));
+  MMG_HIP(ctx, hipMalloc(&dC, (size_t)g->N * g->N * sizeof(double)));
+  MMG_HIP(ctx, hipMemsetAsync(dsc, 0, Mk * sizeof(float), ctx->stream));
+  MMG_HIP(ctx, hipMemsetAsync(dsh, 0, Mk * sizeof(float), ctx->stream));
+  if (scale) {
+    MMG_HIP(ctx, hipMemcpyAsync(dsc, scale, g->M * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    MMG_HIP(ctx, hipMemcpyAsync(dsh, shift, g->M * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    std::vector<float> two((size_t)g->M, 2.0f), neg((size_t)g->M, -1.0f);
+    MMG_HIP(ctx, hipMemcpyAsync(dsc, two.data(), g->M * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    MMG_HIP(ctx, hipMemcpyAsync(dsh, neg.data(), g->M * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  {
+    EvScope ev(ctx, EV_PACK);
+    launch_transpose(ctx, g, Xt, Mk, 1, 0);
+  }
+  MMG_HIP(ctx, hipGetLastError());
+  int rc = run_kinship_f32(ctx, Xt, g->Npad, Mk, dsc, dsh, slabs, ksplit);
+  if (rc == MMG_OK) {
+    launch_reduce_slabs(ctx, slabs, ksplit, g->Npad, g->N, dC);
+    hipError_t e2 = hipMemcpyAsync(C_out, dC, (size_t)g->N * g->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
+    if (e2 != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e2));
+  }
+  hipFree(Xt); hipFree(dsc); hipFree(dsh); hipFree(slabs); hipFree(dC);
+  return rc;
+}
+
+int mmg_kinship_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N, const float* scale, const float* shift,
+                   double* C_out) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, snps && C_out && M > 0 && N > 0);
+  mmg_geno* g = nullptr;
+  int rc = mmg_geno_create(ctx, M, N, &g);
+  if (rc) return rc;
+  rc = mmg_geno_upload(ctx, g, snps, 0, M);
+  if (rc == MMG_OK) {
+    if (!scale) {
+      std::vector<int64_t> c64((size_t)N * N);
+      rc = mmg_kinship_ibs_i8(ctx, g, c64.data());
+      if (rc == MMG_OK) for (size_t i = 0; i < c64.size(); ++i) C_out[i] = (double)c64[i];
+    } else {
+      rc = mmg_kinship_affine_f32(ctx, g, scale, shift, C_out);
+    }
+  }
+  mmg_geno_destroy(ctx, g);
+  return rc;
+}
+
+// ------------------------------------------------------------------------- eigh / dgemm
+static int get_rocblas(mmg_ctx* ctx, rocblas_handle* h) {
+  if (!ctx->rocblas) {
+    rocblas_handle hh;
+    MMG_RB(ctx, rocblas_create_handle(&hh));
+    MMG_RB(ctx, rocblas_set_stream(hh, ctx->stream));
+    ctx->rocblas = hh;
+  }
+  *h = (rocblas_handle)ctx->rocblas;
+  return MMG_OK;
+}
+
+int mmg_eigh_f64(mmg_ctx* ctx, const double* A, int32_t N, double* evals, double* evecs) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, A && evals && N > 0);
+  rocblas_handle h;
+  int rc = get_rocblas(ctx, &h);
+  if (rc) return rc;
+  double *dA = nullptr, *dD = nullptr, *dE = nullptr;
+  rocblas_int* dinfo = nullptr;
+  MMG_HIP(ctx, hipMalloc(&dA, (size_t)N * N * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dD, N * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dE, N * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dinfo, sizeof(rocblas_int)));
+  MMG_HIP(ctx, hipMemcpyAsync(dA, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  rocblas_status st;
+  {
+    EvScope ev(ctx, EV_EIGH);
+    // row-major symmetric input == column-major symmetric input; use the lower triangle of the
+    // column-major view (= upper triangle of the row-major matrix).
+    st = rocsolver_dsyevd(h, evecs ? rocblas_evect_original : rocblas_evect_none, rocblas_fill_lower, N, dA, N, dD,
+                          dE, dinfo);
+  }
+  rocblas_int info = 0;
+  hipError_t e = hipMemcpyAsync(&info, dinfo, sizeof(info), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(evals, dD, N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  // column-major eigenvector matrix V read as row-major is V^T: ROWS are the eigenvectors,
+  // which is the layout the reference keeps (linear_models.py:596).
+  if (e == hipSuccess && evecs)
+    e = hipMemcpyAsync(evecs, dA, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(dA); hipFree(dD); hipFree(dE); hipFree(dinfo);
+  if (st != rocblas_status_success) return set_err(ctx, MMG_E_LIB, "rocsolver_dsyevd failed: status " + std::to_string((int)st));
+  if (e != hipSuccess) return set_err(ctx, MMG_E_HIP, hipGetErrorString(e));
+  if (info != 0) return set_err(ctx, MMG_E_LIB, "rocsolver_dsyevd did not converge: info " + std::to_string((int)info));
+  return MMG_OK;
+}
+
+int mmg_dgemm_f64(mmg_ctx* ctx, int ta, int tb, int32_t M, int32_t N, int32_t K, const double* A, const double* B,
+                  double* C) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, A && B && C && M > 0 && N > 0 && K > 0);
+  rocblas_handle h;
+  int rc = get_rocblas(ctx, &h);
+  if (rc) return rc;
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  MMG_HIP(ctx, hipMalloc(&dA, (size_t)M * K * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dB, (size_t)K * N * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dC, (size_t)M * N * sizeof(double)));
+  MMG_HIP(ctx, hipMemcpyAsync(dA, A, (size_t)M * K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  MMG_HIP(ctx, hipMemcpyAsync(dB, B, (size_t)K * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const double one = 1.0, zero = 0.0;
+  // row-major C = op(A) op(B)  <=>  column-major C^T = op(B)^T op(A)^T
+  rocblas_status st = rocblas_dgemm(h, tb ? rocblas_operation_transpose : rocblas_operation_none,
+                                    ta ? rocblas_operation_transpose : rocblas_operation_none, N, M, K, &one, dB,
+                                    tb ? K : N, dA, ta ? M : K, &zero, dC, N);
+  hipError_t e = hipMemcpyAsync(C, dC, (size_t)M * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(dA); hipFree(dB); hipFree(dC);
+  if (st != rocblas_status_success) return set_err(ctx, MMG_E_LIB, "rocblas_dgemm failed");
+  if (e != hipSuccess) return set_err(ctx, MMG_E_HIP, hipGetErrorString(e));
+  return MMG_OK;
+}
+
+// ------------------------------------------------------------------------- scan
+static double ln_beta_half(double a) {  // ln B(a, 1/2)
+  const double half_ln_pi = 0.57236494292470008707;
+  if (a < 30.0) return std::lgamma(a) + std::lgamma(0.5) - std::lgamma(a + 0.5);
+  // ln Gamma(a+1/2) - ln Gamma(a) = 1/2 ln a - 1/(8a) + 1/(192 a^3) - 1/(640 a^5) + 17/(14336 a^7)
+  const double i = 1.0 / a, i2 = i * i;
+  const double diff = 0.5 * std::log(a) + i * (-1.0 / 8 + i2 * (1.0 / 192 + i2 * (-1.0 / 640 + i2 * (17.0 / 14336))));
+  return half_ln_pi - diff;
+}
+
+static int build_schedule(mmg_ctx* ctx, mmg_scan_model& md) {
+  const int nJ = md.Npad / TM;
+  int AS = 2;
+  if (const char* s = std::getenv("MMG_SCAN_AS")) AS = std::atoi(s);
+  if (AS != 1 && AS != 2 && AS != 4 && AS != 8 && AS != 16 && AS != 32) AS = 2;
+  const int G = 32 / AS;
+  md.AS = AS; md.G = G;
+  std::vector<std::pair<int, int>> all;  // (weight = J + 1 k-blocks, id)
+  for (int d = 0; d < md.D; ++d)
+    for (int J = 0; J < nJ; ++J) all.push_back({J + 1, d * nJ + J});
+  std::sort(all.begin(), all.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) {
+    return a.first != b.first ? a.first > b.first : a.second < b.second;
+  });
+  std::vector<std::vector<int>> bins(G);
+  std::vector<long> load(G, 0);
+  for (auto& it : all) {
+    int best = 0;
+    for (int gI = 1; gI < G; ++gI) if (load[gI] < load[best]) best = gI;
+    bins[best].push_back(it.second);
+    load[best] += it.first;
+  }
+  std::vector<int> off(G + 1, 0);
+  std::vector<int2> jobs;
+  for (int gI = 0; gI < G; ++gI) {
+    for (int id : bins[gI]) jobs.push_back(make_int2(id / nJ, id % nJ));
+    off[gI + 1] = (int)jobs.size();
+  }
+  md.njobs = (int)jobs.size();
+  MMG_HIP(ctx, hipMalloc(&md.job_off, (G + 1) * sizeof(int)));
+  MMG_HIP(ctx, hipMalloc(&md.jobs, std::max<size_t>(1, jobs.size()) * sizeof(int2)));
+  MMG_HIP(ctx, hipMemcpy(md.job_off, off.data(), (G + 1) * sizeof(int), hipMemcpyHostToDevice));
+  if (!jobs.empty()) MMG_HIP(ctx, hipMemcpy(md.jobs, jobs.data(), jobs.size() * sizeof(int2), hipMemcpyHostToDevice));
+  return MMG_OK;
+}
+
+int mmg_scan_set_model(mmg_ctx* ctx, int32_t N, const double* A, const double* w, int ndigits) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, A && w && N > 0);
+  if (ndigits == 0) ndigits = 4;
+  MMG_CHECK_ARG(ctx, ndigits >= 2 && ndigits <= 6);
+  free_model(ctx->model);
+  mmg_scan_model& md = ctx->model;
+  md.N = N; md.Npad = (int32_t)round_up(N, 256); md.D = ndigits;
+  double* dA = nullptr;
+  unsigned long long* dmax = nullptr;
+  MMG_HIP(ctx, hipMalloc(&dA, (size_t)N * N * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dmax, sizeof(unsigned long long)));
+  MMG_HIP(ctx, hipMalloc(&md.Bq, (size_t)md.D * md.Npad * md.Npad));
+  MMG_HIP(ctx, hipMalloc(&md.diag, md.Npad * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&md.w, md.Npad * sizeof(double)));
+  MMG_HIP(ctx, hipMemsetAsync(md.w, 0, md.Npad * sizeof(double), ctx->stream));
+  MMG_HIP(ctx, hipMemsetAsync(dmax, 0, sizeof(unsigned long long), ctx->stream));
+  MMG_HIP(ctx, hipMemcpyAsync(dA, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  MMG_HIP(ctx, hipMemcpyAsync(md.w, w, N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  launch_absmax_offdiag(ctx, dA, N, dmax);
+  unsigned long long bits = 0;
+  MMG_HIP(ctx, hipMemcpyAsync(&bits, dmax, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double maxoff;
+  std::memcpy(&maxoff, &bits, sizeof(double));
+  if (!(maxoff > 0.0) || !std::isfinite(maxoff)) maxoff = 1.0;   // diagonal matrix: all digits are zero
+  // |rint(2 A_jk / step)| <= 2^(8D-2): the top balanced digit stays within int8
+  md.step = 2.0 * maxoff / std::ldexp(1.0, 8 * md.D - 2);
+  launch_quantize(ctx, dA, N, md.Npad, md.D, 1.0 / md.step, md.Bq, md.diag);
+  MMG_HIP(ctx, hipGetLastError());
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipFree(dA); hipFree(dmax);
+  return build_schedule(ctx, md);
+}
+
+static int ensure_result(mmg_ctx* ctx, int64_t Mpad) {
+  mmg_scan_result& r = ctx->res;
+  if (r.cap >= Mpad) return MMG_OK;
+  free_result(r);
+  MMG_HIP(ctx, hipMalloc(&r.q, Mpad * sizeof(unsigned long long)));
+  MMG_HIP(ctx, hipMalloc(&r.rss, Mpad * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&r.F, Mpad * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&r.p, Mpad * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&r.dot, Mpad * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&r.den, Mpad * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&r.sum, Mpad * sizeof(double)));
+  r.cap = Mpad;
+  return MMG_OK;
+}
+
+int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, g != nullptr && df2 > 0);
+  if (!ctx->model.Bq) return set_err(ctx, MMG_E_STATE, "mmg_scan_set_model has not been called");
+  if (ctx->model.N != g->N) return set_err(ctx, MMG_E_ARG, "model N does not match the genotype store");
+  int rc = ensure_result(ctx, g->Mpad);
+  if (rc) return rc;
+  ctx->res.M = g->M;
+  if (g->M == 0) return MMG_OK;
+  MMG_HIP(ctx, hipMemsetAsync(ctx->res.q, 0, g->Mpad * sizeof(unsigned long long), ctx->stream));
+  {
+    EvScope ev(ctx, EV_QUAD);
+    launch_scan_quad(ctx, g, ctx->model, ctx->res.q);
+  }
+  MMG_HIP(ctx, hipGetLastError());
+  {
+    EvScope ev(ctx, EV_FIN);
+    launch_scan_finalize(ctx, g, ctx->model, ctx->res, h0_rss, df2, ln_beta_half(0.5 * df2));
+  }
+  MMG_HIP(ctx, hipGetLastError());
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MMG_OK;
+}
+
+static int fetch(mmg_ctx* ctx, double* dst, const double* src, int64_t M) {
+  if (!dst || M == 0) return MMG_OK;
+  MMG_HIP(ctx, hipMemcpyAsync(dst, src, M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  return MMG_OK;
+}
+
+int mmg_scan_fetch(mmg_ctx* ctx, int64_t M, double* rss, double* F, double* p) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, M == ctx->res.M);
+  int rc;
+  if ((rc = fetch(ctx, rss, ctx->res.rss, M))) return rc;
+  if ((rc = fetch(ctx, F, ctx->res.F, M))) return rc;
+  if ((rc = fetch(ctx, p, ctx->res.p, M))) return rc;
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MMG_OK;
+}
+
+int mmg_scan_fetch_stats(mmg_ctx* ctx, int64_t M, double* dot, double* den, double* sum) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, M == ctx->res.M);
+  int rc;
+  if ((rc = fetch(ctx, dot, ctx->res.dot, M))) return rc;
+  if ((rc = fetch(ctx, den, ctx->res.den, M))) return rc;
+  if ((rc = fetch(ctx, sum, ctx->res.sum, M))) return rc;
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MMG_OK;
+}
+
+int mmg_emmax_scan(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2, double* rss, double* F, double* p) {
+  int rc = mmg_emmax_scan_device(ctx, g, h0_rss, df2);
+  if (rc) return rc;
+  return mmg_scan_fetch(ctx, g->M, rss, F, p);
+}
+
+int mmg_emmax_scan_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N, const double* A, const double* w,
+                      double h0_rss, int32_t df2, double* rss, double* F, double* p) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, snps && M >= 0 && N > 0);
+  int rc = mmg_scan_set_model(ctx, N, A, w, 0);
+  if (rc) return rc;
+  mmg_geno* g = nullptr;
+  rc = mmg_geno_create(ctx, M, N, &g);
+  if (rc) return rc;
+  rc = mmg_geno_upload(ctx, g, snps, 0, M);
+  if (rc == MMG_OK) rc = mmg_emmax_scan(ctx, g, h0_rss, df2, rss, F, p);
+  mmg_geno_destroy(ctx, g);
+  return rc;
+}
+
+int mmg_geno_matvec(mmg_ctx* ctx, mmg_geno* g, const double* V, int32_t nv, double* out) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, g && V && out && nv > 0);
+  if (g->M == 0) return MMG_OK;
+  double *dv = nullptr, *dout = nullptr;
+  MMG_HIP(ctx, hipMalloc(&dv, g->Npad * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dout, g->M * sizeof(double)));
+  for (int k = 0; k < nv; ++k) {
+    MMG_HIP(ctx, hipMemsetAsync(dv, 0, g->Npad * sizeof(double), ctx->stream));
+    MMG_HIP(ctx, hipMemcpyAsync(dv, V + (int64_t)k * g->N, g->N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    launch_snp_dot(ctx, g, dv, dout);
+    MMG_HIP(ctx, hipGetLastError());
+    MMG_HIP(ctx, hipMemcpyAsync(out + (int64_t)k * g->M, dout, g->M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  hipFree(dv); hipFree(dout);
+  return MMG_OK;
+}
+
+int mmg_f_sf(mmg_ctx* ctx, const double* F, int64_t n, int32_t df2, double* p) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, F && p && n >= 0 && df2 > 0);
+  if (n == 0) return MMG_OK;
+  double *dF = nullptr, *dp = nullptr;
+  MMG_HIP(ctx, hipMalloc(&dF, n * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dp, n * sizeof(double)));
+  MMG_HIP(ctx, hipMemcpyAsync(dF, F, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  launch_f_sf(ctx, dF, n, df2, ln_beta_half(0.5 * df2), dp);
+  MMG_HIP(ctx, hipGetLastError());
+  MMG_HIP(ctx, hipMemcpyAsync(p, dp, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipFree(dF); hipFree(dp);
+  return MMG_OK;
+}
+
+// ------------------------------------------------------------------------- permutations
+int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const double* Ys, int32_t P, double h0_rss,
+                   int ndigits, double* min_rss) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  (void)g; (void)N; (void)Ht; (void)Ys; (void)P; (void)h0_rss; (void)ndigits; (void)min_rss;
+  return set_err(ctx, MMG_E_STATE, "mmg_emmax_perm: not built yet");
+}
+
+// ------------------------------------------------------------------------- RCCL
+int mmg_comm_unique_id(unsigned char id[128]) {
+  ncclUniqueId uid;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  ncclResult_t r = ncclGetUniqueId(&uid);
+  if (r != ncclSuccess) return set_err(nullptr, MMG_E_LIB, ncclGetErrorString(r));
+  std::memcpy(id, &uid, 128);
+  return MMG_OK;
+}
+
+int mmg_comm_create(mmg_ctx* ctx, const unsigned char id[128], int rank, int world, mmg_comm** out) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, id && out && world >= 1 && rank >= 0 && rank < world);
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, 128);
+  mmg_comm* c = new mmg_comm();
+  c->rank = rank; c->world = world;
+  MMG_HIP(ctx, hipSetDevice(ctx->device));
+  ncclResult_t r = ncclCommInitRank(&c->comm, world, uid, rank);
+  if (r != ncclSuccess) { delete c; return set_err(ctx, MMG_E_LIB, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+  *out = c;
+  return MMG_OK;
+}
+
+int mmg_comm_destroy(mmg_ctx* ctx, mmg_comm* c) {
+  if (!c) return MMG_OK;
+  if (ctx) hipStreamSynchronize(ctx->stream);
+  if (c->comm) ncclCommDestroy(c->comm);
+  delete c;
+  return MMG_OK;
+}
+
+int mmg_comm_allgather_scan(mmg_ctx* ctx, mmg_comm* c, int64_t count, double* rss, double* F, double* p) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, c && count >= 0 && count <= ctx->res.cap);
+  if (count == 0) return MMG_OK;
+  double* stage = nullptr;
+  MMG_HIP(ctx, hipMalloc(&stage, (size_t)c->world * count * sizeof(double)));
+  const double* srcs[3] = {ctx->res.rss, ctx->res.F, ctx->res.p};
+  double* dsts[3] = {rss, F, p};
+  int rc = MMG_OK;
+  for (int k = 0; k < 3 && rc == MMG_OK; ++k) {
+    if (!dsts[k]) continue;
+    ncclResult_t r = ncclAllGather(srcs[k], stage, count, ncclDouble, c->comm, ctx->stream);
+    if (r != ncclSuccess) { rc = set_err(ctx, MMG_E_LIB, std::string("ncclAllGather: ") + ncclGetErrorString(r)); break; }
+    hipError_t e = hipMemcpyAsync(dsts[k], stage, (size_t)c->world * count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e));
+  }
+  hipFree(stage);
+  return rc;
+}
+
+extern "C++" {
+template <typename T>
+static int allreduce_host(mmg_ctx* ctx, mmg_comm* c, T* buf, int64_t count, int op, ncclDataType_t dt) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, c && buf && count >= 0 && op >= 0 && op <= 2);
+  if (count == 0) return MMG_OK;
+  T* d = nullptr;
+  MMG_HIP(ctx, hipMalloc(&d, count * sizeof(T)));
+  MMG_HIP(ctx, hipMemcpyAsync(d, buf, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  const ncclRedOp_t ops[3] = {ncclSum, ncclMin, ncclMax};
+  ncclResult_t r = ncclAllReduce(d, d, count, dt, ops[op], c->comm, ctx->stream);
+  if (r != ncclSuccess) { hipFree(d); return set_err(ctx, MMG_E_LIB, std::string("ncclAllReduce: ") + ncclGetErrorString(r)); }
+  MMG_HIP(ctx, hipMemcpyAsync(buf, d, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipFree(d);
+  return MMG_OK;
+}
+
+}  // extern C++
+int mmg_comm_allreduce_f64(mmg_ctx* ctx, mmg_comm* c, double* buf, int64_t count, int op) {
+  return allreduce_host<double>(ctx, c, buf, count, op, ncclDouble);
+}
+int mmg_comm_allreduce_i64(mmg_ctx* ctx, mmg_comm* c, int64_t* buf, int64_t count, int op) {
+  return allreduce_host<int64_t>(ctx, c, buf, count, op, ncclInt64);
+}
+int mmg_comm_barrier(mmg_ctx* ctx, mmg_comm* c) {
+  int64_t one = 1;
+  return mmg_comm_allreduce_i64(ctx, c, &one, 1, 0);
+}
+
+}  // extern "C"

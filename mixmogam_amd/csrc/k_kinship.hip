@@ -1,0 +1,249 @@
+// k_kinship.hip -- the kinship GEMMs K = X X^T over the individual-major genotype image
+// Xt [Npad x Mk] (k = SNP index contiguous).  Replaces kinship.py:29-44 (IBS) and
+// kinship.py:63-69 / hdf5_data.py:99-106 (GRM).
+//
+//  * kinship_i8_kernel : exact IBS counts on the int8 matrix cores (v_mfma_i32_32x32x32_i8),
+//                        split-K over SNPs, int32 atomics (order independent -> bit reproducible).
+//  * kinship_f32_kernel: dense fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32) with the int8 genotypes
+//                        expanded to fp32 from the LDS tile through a per-SNP affine
+//                        x = scale*s + shift; per-(tile, K-split) fp32 slabs, reduced in fp64 in
+//                        fixed order (deterministic).
+// Only upper-triangular tiles (I <= J) are computed.
+#include <algorithm>
+#include "gemm_i8_core.h"
+#include "mmg_internal.h"
+
+namespace mmg {
+
+struct KinJob { int I, J, ks0, ks1, slab, pad0, pad1, pad2; };
+
+__device__ __forceinline__ int xcd_job_index(int b) {
+  // blocks b and b+8 share an XCD (observed round-robin placement; speed only).  Give each XCD
+  // 32 consecutive jobs of every chunk of 256 so that neighbouring tiles share an L2.
+  return (b & ~255) + (b & 7) * 32 + ((b >> 3) & 31);
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void kinship_i8_kernel(const int8_t* __restrict__ Xt, int64_t Mk,
+                                                                 int32_t Npad, const KinJob* __restrict__ jobs,
+                                                                 int* __restrict__ C32) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const KinJob job = jobs[xcd_job_index(blockIdx.x)];
+  if (job.ks1 <= job.ks0) return;
+  v16i acc[4][2];
+  gemm_tile_i8(Xt + (int64_t)job.I * TM * Mk, Mk, Xt + (int64_t)job.J * TN * Mk, Mk, job.ks0, job.ks1, lds,
+               acc);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3, h = lane >> 5, r = lane & 31;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int col = job.J * TN + wn * 64 + n * 32 + r;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = job.I * TM + wm * 128 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        atomicAdd(C32 + (int64_t)row * Npad + col, acc[m][n][i]);
+      }
+    }
+}
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float byte_to_f32(int word, int j) {
+  return (float)(int)(int8_t)((word >> (8 * j)) & 0xff);
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void kinship_f32_kernel(const int8_t* __restrict__ Xt, int64_t Mk,
+                                                                  int32_t Npad, const KinJob* __restrict__ jobs,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift,
+                                                                  float* __restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const KinJob job = jobs[xcd_job_index(blockIdx.x)];
+  if (job.ks1 <= job.ks0) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3, h = lane >> 5, r = lane & 31;
+  const int8_t* P = Xt + (int64_t)job.I * TM * Mk;
+  const int8_t* Q = Xt + (int64_t)job.J * TN * Mk;
+  v16f acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+  stage_tile(P, Mk, (int64_t)job.ks0 * BK, lds, wave, lane);
+  stage_tile(Q, Mk, (int64_t)job.ks0 * BK, lds + TILE_BYTES, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int ks = job.ks0; ks < job.ks1; ++ks) {
+    if (ks + 1 < job.ks1) {
+      char* nb = lds + (cur ^ 1) * BUF_BYTES;
+      stage_tile(P, Mk, (int64_t)(ks + 1) * BK, nb, wave, lane);
+      stage_tile(Q, Mk, (int64_t)(ks + 1) * BK, nb + TILE_BYTES, wave, lane);
+    }
+    const char* pt = lds + cur * BUF_BYTES;
+    const char* qt = pt + TILE_BYTES;
+#pragma unroll 1
+    for (int kk = 0; kk < 4; ++kk) {
+      // this lane's 16 contraction indices of the sub-step: k = ks*128 + kk*32 + h*16 + j
+      const int64_t kbase = (int64_t)ks * BK + kk * 32 + h * 16;
+      v4i ab[4], bb[2];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) ab[m] = lds_frag(pt, wm * 128 + m * 32 + r, 2 * kk + h);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) bb[n] = lds_frag(qt, wn * 64 + n * 32 + r, 2 * kk + h);
+      float sc[16], sh[16];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const float4 s4 = *(const float4*)(scale + kbase + q4 * 4);
+        const float4 t4 = *(const float4*)(shift + kbase + q4 * 4);
+        sc[q4 * 4 + 0] = s4.x; sc[q4 * 4 + 1] = s4.y; sc[q4 * 4 + 2] = s4.z; sc[q4 * 4 + 3] = s4.w;
+        sh[q4 * 4 + 0] = t4.x; sh[q4 * 4 + 1] = t4.y; sh[q4 * 4 + 2] = t4.z; sh[q4 * 4 + 3] = t4.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float af[4], bf[2];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) af[m] = fmaf(byte_to_f32(ab[m][j >> 2], j & 3), sc[j], sh[j]);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bf[n] = fmaf(byte_to_f32(bb[n][j >> 2], j & 3), sc[j], sh[j]);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf[n], acc[m][n], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+  float* slab = slabs + (int64_t)job.slab * Npad * Npad;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int col = job.J * TN + wn * 64 + n * 32 + r;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = job.I * TM + wm * 128 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        slab[(int64_t)row * Npad + col] = acc[m][n][i];
+      }
+    }
+}
+
+// C[i][j] (i,j < N) = sum over slabs in fixed order of the upper-triangular tile entry, in fp64.
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int ksplit, int32_t Npad, int32_t N,
+                                    double* __restrict__ C) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)N * N) return;
+  const int i = (int)(gid / N), j = (int)(gid % N);
+  // tile (I,J) with I<=J was computed; inside a diagonal tile both halves are present
+  int a = i, b = j;
+  if ((i / TM) > (j / TN)) { a = j; b = i; }
+  double s = 0.0;
+  for (int k = 0; k < ksplit; ++k) s += (double)slabs[(int64_t)k * Npad * Npad + (int64_t)a * Npad + b];
+  C[gid] = s;
+}
+
+__global__ void mirror_i32_kernel(const int* __restrict__ C32, int32_t Npad, int32_t N, int64_t* __restrict__ C) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)N * N) return;
+  const int i = (int)(gid / N), j = (int)(gid % N);
+  int a = i, b = j;
+  if ((i / TM) > (j / TN)) { a = j; b = i; }
+  C[gid] = (int64_t)C32[(int64_t)a * Npad + b];
+}
+
+void launch_reduce_slabs(mmg_ctx* ctx, const float* slabs, int ksplit, int32_t Npad, int32_t N, double* C) {
+  const int64_t total = (int64_t)N * N;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                     slabs, ksplit, Npad, N, C);
+}
+void launch_mirror_i32_to_i64(mmg_ctx* ctx, const int* C32, int32_t Npad, int32_t N, int64_t* C) {
+  const int64_t total = (int64_t)N * N;
+  hipLaunchKernelGGL(mirror_i32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, C32,
+                     Npad, N, C);
+}
+
+// Upper-triangular tiles in 4 x 8 patches (neighbouring jobs share operand panels), K-split
+// chosen so that the job count fills whole cohorts of 256 workgroups.
+static int choose_ksplit(int ntiles, int nk, int min_steps, int max_split) {
+  int best = 1;
+  double best_score = -1.0;
+  for (int ks = 1; ks <= max_split && ks <= nk; ++ks) {
+    if (ks > 1 && nk / ks < min_steps) break;
+    const int64_t jobs = (int64_t)ntiles * ks;
+    if (jobs > 4096 && ks > 1) break;
+    const double score = (double)jobs / (double)round_up(jobs, 256);
+    if (score > best_score + 1e-9) { best_score = score; best = ks; }
+  }
+  return best;
+}
+
+static std::vector<KinJob> build_jobs(int nT, int nk, int ksplit) {
+  std::vector<std::pair<int, int>> tiles;
+  for (int Ib = 0; Ib < nT; Ib += 4)
+    for (int Jb = 0; Jb < nT; Jb += 8)
+      for (int I = Ib; I < std::min(Ib + 4, nT); ++I)
+        for (int J = Jb; J < std::min(Jb + 8, nT); ++J)
+          if (I <= J) tiles.push_back({I, J});
+  std::vector<KinJob> jobs;
+  for (int s = 0; s < ksplit; ++s) {
+    const int k0 = (int)((int64_t)nk * s / ksplit), k1 = (int)((int64_t)nk * (s + 1) / ksplit);
+    for (auto& t : tiles) jobs.push_back(KinJob{t.first, t.second, k0, k1, s, 0, 0, 0});
+  }
+  while (jobs.size() % 256) jobs.push_back(KinJob{0, 0, 0, 0, 0, 0, 0, 0});
+  return jobs;
+}
+
+int kinship_pick_ksplit(int32_t Npad, int64_t Mk, bool f32) {
+  const int nT = Npad / TM;
+  const int nk = (int)(Mk / BK);
+  return choose_ksplit(nT * (nT + 1) / 2, nk, f32 ? 2 : 8, f32 ? 16 : 64);
+}
+
+int run_kinship_i8(mmg_ctx* ctx, const int8_t* Xt, int32_t Npad, int64_t Mk, int* C32) {
+  const int nT = Npad / TM, nk = (int)(Mk / BK);
+  const int ksplit = kinship_pick_ksplit(Npad, Mk, false);
+  std::vector<KinJob> jobs = build_jobs(nT, nk, ksplit);
+  KinJob* djobs = nullptr;
+  MMG_HIP(ctx, hipMalloc(&djobs, jobs.size() * sizeof(KinJob)));
+  MMG_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(KinJob), hipMemcpyHostToDevice, ctx->stream));
+  MMG_HIP(ctx, hipMemsetAsync(C32, 0, (size_t)Npad * Npad * sizeof(int), ctx->stream));
+  MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  {
+    EvScope ev(ctx, EV_KIN);
+    hipLaunchKernelGGL(kinship_i8_kernel, dim3((unsigned)jobs.size()), dim3(NTHREADS), LDS_BYTES, ctx->stream, Xt,
+                       Mk, Npad, djobs, C32);
+  }
+  MMG_HIP(ctx, hipGetLastError());
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MMG_HIP(ctx, hipFree(djobs));
+  return MMG_OK;
+}
+
+int run_kinship_f32(mmg_ctx* ctx, const int8_t* Xt, int32_t Npad, int64_t Mk, const float* scale,
+                    const float* shift, float* slabs, int ksplit) {
+  const int nT = Npad / TM, nk = (int)(Mk / BK);
+  std::vector<KinJob> jobs = build_jobs(nT, nk, ksplit);
+  KinJob* djobs = nullptr;
+  MMG_HIP(ctx, hipMalloc(&djobs, jobs.size() * sizeof(KinJob)));
+  MMG_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(KinJob), hipMemcpyHostToDevice, ctx->stream));
+  MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  {
+    EvScope ev(ctx, EV_KIN);
+    hipLaunchKernelGGL(kinship_f32_kernel, dim3((unsigned)jobs.size()), dim3(NTHREADS), LDS_BYTES, ctx->stream, Xt,
+                       Mk, Npad, djobs, scale, shift, slabs);
+  }
+  MMG_HIP(ctx, hipGetLastError());
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MMG_HIP(ctx, hipFree(djobs));
+  return MMG_OK;
+}
+
+}  // namespace mmg

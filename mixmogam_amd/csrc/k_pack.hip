@@ -1,0 +1,135 @@
+// k_pack.hip -- HBM-bound byte kernels around the genotype store: synthetic fill, dtype
+// conversion on ingest, SNP-major -> individual-major transposition for the kinship GEMM, and
+// per-SNP mean / std (kinship.py:66).  All are streaming kernels with 16-byte accesses.
+#include "mmg_internal.h"
+
+namespace mmg {
+
+__device__ __forceinline__ uint64_t hash3(uint64_t seed, uint64_t snp, uint64_t ind) {
+  uint64_t x = (snp * 0x9E3779B97F4A7C15ull) ^ (ind * 0xBF58476D1CE4E5B9ull) ^ (seed * 0x94D049BB133111EBull);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+
+// grid.x = Npad/16 chunks (x 256 threads -> rows), one thread = 16 individuals of one SNP.
+__global__ void fill_hash_kernel(int8_t* __restrict__ S, int64_t M, int32_t N, int32_t Npad,
+                                 uint64_t seed, int64_t m0g, uint32_t thr16) {
+  const int chunks = Npad >> 4;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t m = gid / chunks;
+  const int c = (int)(gid % chunks);
+  if (m >= M) return;
+  uint32_t wds[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int i = c * 16 + j;
+    uint32_t bit = 0;
+    if (i < N) bit = ((uint32_t)(hash3(seed, (uint64_t)(m0g + m), (uint64_t)i) >> 48) < thr16) ? 1u : 0u;
+    wds[j >> 2] |= bit << (8 * (j & 3));
+  }
+  uint4 v = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+  *(uint4*)(S + m * (int64_t)Npad + c * 16) = v;
+}
+
+void launch_fill_hash(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_global0, uint32_t thr16) {
+  const int64_t total = g->M * (int64_t)(g->Npad >> 4);
+  const int bs = 256;
+  const int64_t nb = (total + bs - 1) / bs;
+  hipLaunchKernelGGL(fill_hash_kernel, dim3((unsigned)nb), dim3(bs), 0, ctx->stream, g->d, g->M, g->N,
+                     g->Npad, seed, m_global0, thr16);
+}
+
+template <typename T>
+__global__ void cvt_kernel(const T* __restrict__ src, int8_t* __restrict__ dst, int64_t rows, int32_t N,
+                           int64_t ld) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = rows * (int64_t)N;
+  if (gid >= total) return;
+  const int64_t r = gid / N;
+  const int c = (int)(gid % N);
+  dst[r * ld + c] = (int8_t)__double2int_rn((double)src[gid]);
+}
+
+void launch_cvt_f32(mmg_ctx* ctx, const float* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld) {
+  const int64_t total = rows * (int64_t)N;
+  hipLaunchKernelGGL(cvt_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                     src, dst, rows, N, ld);
+}
+void launch_cvt_f64(mmg_ctx* ctx, const double* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld) {
+  const int64_t total = rows * (int64_t)N;
+  hipLaunchKernelGGL(cvt_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                     src, dst, rows, N, ld);
+}
+
+// 64 SNPs x 64 individuals per block; out[i][m] = valid ? mul * s + add : 0.
+__global__ __launch_bounds__(256) void transpose_kernel(const int8_t* __restrict__ S, int64_t M, int32_t N,
+                                                        int32_t Npad, int8_t* __restrict__ Xt, int64_t Mk,
+                                                        int mul, int add) {
+  __shared__ int8_t tile[64][64 + 4];
+  const int t = threadIdx.x;
+  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  const int i0 = blockIdx.y * 64;
+  {
+    const int r = t >> 2, c = t & 3;
+    const uint4 v = *(const uint4*)(S + (m0 + r) * (int64_t)Npad + i0 + c * 16);
+    uint32_t* dstw = (uint32_t*)&tile[r][c * 16];
+    dstw[0] = v.x; dstw[1] = v.y; dstw[2] = v.z; dstw[3] = v.w;
+  }
+  __syncthreads();
+  const int i = t >> 2, mc = t & 3;
+  uint32_t wds[4] = {0, 0, 0, 0};
+  const bool ivalid = (i0 + i) < N;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int64_t m = m0 + mc * 16 + j;
+    int v = 0;
+    if (ivalid && m < M) v = mul * (int)tile[mc * 16 + j][i] + add;
+    wds[j >> 2] |= ((uint32_t)(v & 0xff)) << (8 * (j & 3));
+  }
+  *(uint4*)(Xt + (int64_t)(i0 + i) * Mk + m0 + mc * 16) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+}
+
+void launch_transpose(mmg_ctx* ctx, const mmg_geno* g, int8_t* Xt, int64_t Mk, int mul, int add) {
+  dim3 grid((unsigned)(Mk / 64), (unsigned)(g->Npad / 64));
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, g->d, g->M, g->N, g->Npad, Xt, Mk,
+                     mul, add);
+}
+
+// one wave per SNP: exact integer sum and sum of squares -> mean, population std
+__global__ __launch_bounds__(256) void snp_stats_kernel(const int8_t* __restrict__ S, int64_t M, int32_t N,
+                                                        int32_t Npad, double* __restrict__ mean,
+                                                        double* __restrict__ sd) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  long long s1 = 0, s2 = 0;
+  for (int c = lane; c < (Npad >> 4); c += 64) {
+    const uint4 v = *(const uint4*)(S + m * (int64_t)Npad + c * 16);
+    const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int x = (int)(int8_t)((wds[j >> 2] >> (8 * (j & 3))) & 0xff);
+      s1 += x; s2 += x * x;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o);
+    s2 += __shfl_xor(s2, o);
+  }
+  if (lane == 0) {
+    const double mu = (double)s1 / (double)N;
+    const double var = (double)s2 / (double)N - mu * mu;
+    mean[m] = mu;
+    sd[m] = sqrt(var > 0.0 ? var : 0.0);
+  }
+}
+
+void launch_snp_stats(mmg_ctx* ctx, const mmg_geno* g, double* mean, double* sd) {
+  hipLaunchKernelGGL(snp_stats_kernel, dim3((unsigned)((g->M + 3) / 4)), dim3(256), 0, ctx->stream, g->d,
+                     g->M, g->N, g->Npad, mean, sd);
+}
+
+}  // namespace mmg

@@ -1,0 +1,314 @@
+// k_scan.hip -- the EMMAX per-SNP scan (replaces the chunked GEMM + per-SNP lstsq loop of
+// linear_models.py:1316-1349 with its closed form):
+//     num_m = (s_m . w)^2,  den_m = s_m' A s_m,  rss_m = h0_rss - num_m/den_m,
+//     F_m = (h0_rss/rss_m - 1) * df2,  p_m = f.sf(F_m, 1, df2).
+//
+// den is the hot part (2 N^2 flop per SNP).  Genotypes are small integers, so the product
+// S . A is computed EXACTLY on the int8 matrix cores after writing the (fp64) matrix as D
+// balanced base-256 digits ("Ozaki" splitting):  2*A_jk = step * sum_d 256^d z_d[j][k], k < j.
+// Only the strictly lower triangle is stored (A symmetric: s'As = sum_i A_ii s_i^2 +
+// sum_{k<j} 2 A_jk s_j s_k), which halves the MFMA work; the diagonal term and s.w are
+// evaluated in fp64 by the HBM-bound finalize kernel (one wave per 8 SNP rows, coalesced
+// 16-byte genotype reads), which also evaluates F and the p-value.
+//
+// All integer partial sums are exact and accumulated with 64-bit integer atomics, so results
+// are bitwise reproducible from run to run and independent of the tile schedule.
+#include <algorithm>
+#include <cmath>
+#include "gemm_i8_core.h"
+#include "mmg_internal.h"
+
+namespace mmg {
+
+// ------------------------------------------------------------------ model quantisation
+__global__ void absmax_offdiag_kernel(const double* __restrict__ A, int32_t N, unsigned long long* out) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double v = 0.0;
+  if (gid < (int64_t)N * N) {
+    const int i = (int)(gid / N), j = (int)(gid % N);
+    if (j < i) v = fabs(A[gid]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  if ((threadIdx.x & 63) == 0 && v > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(v));
+}
+
+void launch_absmax_offdiag(mmg_ctx* ctx, const double* A, int32_t N, unsigned long long* out_bits) {
+  const int64_t total = (int64_t)N * N;
+  hipLaunchKernelGGL(absmax_offdiag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, A,
+                     N, out_bits);
+}
+
+// one thread = 16 consecutive k of row j; Bq[d][j][k] = digit d of rint(2 A[j][k] / step), k < j
+__global__ void quantize_kernel(const double* __restrict__ A, int32_t N, int32_t Npad, int D, double inv_step,
+                                int8_t* __restrict__ Bq, double* __restrict__ diag) {
+  const int chunks = Npad >> 4;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)Npad * chunks) return;
+  const int j = (int)(gid / chunks), c = (int)(gid % chunks);
+  uint32_t out[6][4];
+#pragma unroll
+  for (int d = 0; d < 6; ++d)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[d][e] = 0;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int k = c * 16 + e;
+    long long Z = 0;
+    if (j < N && k < j) Z = __double2ll_rn(2.0 * A[(int64_t)j * N + k] * inv_step);
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      if (d < D) {
+        const long long z = ((Z + 128) & 255) - 128;
+        Z = (Z - z) >> 8;
+        out[d][e >> 2] |= ((uint32_t)(z & 0xff)) << (8 * (e & 3));
+      }
+    }
+  }
+  for (int d = 0; d < D; ++d)
+    *(uint4*)(Bq + ((int64_t)d * Npad + j) * Npad + c * 16) = make_uint4(out[d][0], out[d][1], out[d][2], out[d][3]);
+  if (c == 0) diag[j] = (j < N) ? A[(int64_t)j * N + j] : 0.0;
+}
+
+void launch_quantize(mmg_ctx* ctx, const double* A, int32_t N, int32_t Npad, int D, double inv_step, int8_t* Bq,
+                     double* diag) {
+  const int64_t total = (int64_t)Npad * (Npad >> 4);
+  hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, A, N, Npad,
+                     D, inv_step, Bq, diag);
+}
+
+// ------------------------------------------------------------------ quadratic-form GEMM
+// Workgroup -> (SNP block of 256, job group).  Blocks b, b+8, ... share an XCD (observed
+// placement, speed only): a cohort of 32 consecutive such blocks works on AS SNP blocks x G
+// job groups, so the S rows are L2 hits for G workgroups and the digit tiles for AS.
+__global__ __launch_bounds__(NTHREADS, 2) void scan_quad_kernel(
+    const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Bq, int64_t ldB,
+    int64_t digit_stride, const int* __restrict__ job_off, const int2* __restrict__ jobs, int AS,
+    unsigned long long* __restrict__ q) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int b = blockIdx.x;
+  const int x = b & 7, i = b >> 3;
+  const int cohort = i >> 5, within = i & 31;
+  const int a = within % AS, grp = within / AS;
+  const int sb = (cohort * 8 + x) * AS + a;
+  if (sb >= nSb) return;
+  const int j0 = job_off[grp], j1 = job_off[grp + 1];
+  if (j1 <= j0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3, h = lane >> 5, r = lane & 31;
+  const int8_t* Q = S + (int64_t)sb * TN * ldS;
+  unsigned long long qacc[2] = {0ull, 0ull};
+  for (int jj = j0; jj < j1; ++jj) {
+    const int2 jb = jobs[jj];
+    const int d = jb.x, J = jb.y;
+    const int8_t* P = Bq + (int64_t)d * digit_stride + (int64_t)J * TM * ldB;
+    v16i acc[4][2];
+    gemm_tile_i8(P, ldB, Q, ldS, 0, 2 * (J + 1), lds, acc);
+    // epilogue: lane holds SNP column n = wn*64 + nn*32 + r and rows j = wm*128 + m*32 +
+    // (reg&3) + 8*(reg>>2) + 4*h of T = Z_d(J-tile rows) . S^T; multiply by s[snp][256J + j].
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+      const int8_t* srow = Q + (int64_t)(wn * 64 + nn * 32 + r) * ldS + J * TM + wm * 128 + 4 * h;
+      long long part = 0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int wd = *(const int*)(srow + m * 32 + 8 * g4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            part += (long long)acc[m][nn][g4 * 4 + e] * (long long)(int)(int8_t)((wd >> (8 * e)) & 0xff);
+        }
+      qacc[nn] += ((unsigned long long)part) << (8 * d);
+    }
+  }
+#pragma unroll
+  for (int nn = 0; nn < 2; ++nn) {
+    unsigned long long v = qacc[nn];
+    v += __shfl_xor(v, 32);
+    if (h == 0) atomicAdd(q + (int64_t)sb * TN + wn * 64 + nn * 32 + r, v);
+  }
+}
+
+void launch_scan_quad(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, unsigned long long* q) {
+  const int nSb = (int)(g->Mpad / TN);
+  const int per = 8 * md.AS;
+  const int ncoh = (nSb + per - 1) / per;
+  hipFuncSetAttribute((const void*)scan_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  hipLaunchKernelGGL(scan_quad_kernel, dim3((unsigned)(ncoh * 256)), dim3(NTHREADS), LDS_BYTES, ctx->stream, g->d,
+                     (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad, (int64_t)md.Npad * md.Npad, md.job_off,
+                     md.jobs, md.AS, q);
+}
+
+// ------------------------------------------------------------------ p-value
+// Upper tail of F(1, nu) = I_x(nu/2, 1/2), x = nu/(nu+F)  (scipy.stats.f.sf, :1349).
+// Continued fraction (modified Lentz); the tail 1-x = F/(nu+F) is formed directly.
+__device__ double betacf(double a, double b, double x) {
+  const double EPS = 1e-16, FPMIN = 1e-300;
+  const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+  double c = 1.0, d = 1.0 - qab * x / qap;
+  if (fabs(d) < FPMIN) d = FPMIN;
+  d = 1.0 / d;
+  double hh = d;
+  for (int m = 1; m <= 2000; ++m) {
+    const double m2 = 2.0 * m;
+    double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+    d = 1.0 + aa * d; if (fabs(d) < FPMIN) d = FPMIN;
+    c = 1.0 + aa / c; if (fabs(c) < FPMIN) c = FPMIN;
+    d = 1.0 / d; hh *= d * c;
+    aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+    d = 1.0 + aa * d; if (fabs(d) < FPMIN) d = FPMIN;
+    c = 1.0 + aa / c; if (fabs(c) < FPMIN) c = FPMIN;
+    d = 1.0 / d;
+    const double del = d * c;
+    hh *= del;
+    if (fabs(del - 1.0) < EPS) break;
+  }
+  return hh;
+}
+
+__device__ double f_sf_1(double F, double nu, double lnbeta) {
+  if (!(F > 0.0)) return (F != F) ? F : 1.0;
+  if (isinf(F)) return 0.0;
+  const double a = 0.5 * nu, b = 0.5;
+  const double y = F / (nu + F), x = nu / (nu + F);
+  const double bt = exp(a * log1p(-y) + b * log(y) - lnbeta);
+  if (x < (a + 1.0) / (a + b + 2.0)) return bt * betacf(a, b, x) / a;
+  return 1.0 - bt * betacf(b, a, y) / b;
+}
+
+__global__ void f_sf_kernel(const double* __restrict__ F, int64_t n, double nu, double lnbeta, double* __restrict__ p) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < n) p[gid] = f_sf_1(F[gid], nu, lnbeta);
+}
+
+void launch_f_sf(mmg_ctx* ctx, const double* F, int64_t n, int32_t df2, double lnbeta, double* p) {
+  hipLaunchKernelGGL(f_sf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, F, n, (double)df2,
+                     lnbeta, p);
+}
+
+// ------------------------------------------------------------------ finalize
+// One wave handles FR SNP rows: streams their genotype bytes once (16 B per lane per row),
+// keeping the matching 16 entries of w and diag(A) in registers for all 8 rows.
+constexpr int FR = 4;   // SNP rows per wave
+__global__ __launch_bounds__(256, 2) void scan_finalize_kernel(
+    const int8_t* __restrict__ S, int64_t ldS, int64_t M, int32_t Npad, const double* __restrict__ w,
+    const double* __restrict__ diag, const unsigned long long* __restrict__ q, double step, double h0_rss, double nu,
+    double lnbeta, double* __restrict__ rss, double* __restrict__ Fst, double* __restrict__ pv,
+    double* __restrict__ dotv, double* __restrict__ denv, double* __restrict__ sumv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * FR;
+  if (m0 >= M) return;
+  double dw[FR], dd[FR];
+  int sm[FR];
+#pragma unroll
+  for (int rr = 0; rr < FR; ++rr) { dw[rr] = 0.0; dd[rr] = 0.0; sm[rr] = 0; }
+  for (int c = lane; c < (Npad >> 4); c += 64) {
+    double wv[16], dv[16];
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) {
+      const double2 t = *(const double2*)(w + c * 16 + e);
+      const double2 u = *(const double2*)(diag + c * 16 + e);
+      wv[e] = t.x; wv[e + 1] = t.y; dv[e] = u.x; dv[e + 1] = u.y;
+    }
+#pragma unroll
+    for (int rr = 0; rr < FR; ++rr) {
+      // rows beyond M are inside the padded store (Mpad is a multiple of 256) and hold zeros
+      const uint4 v = *(const uint4*)(S + (m0 + rr) * ldS + c * 16);
+      const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int xi = (int)(int8_t)((wds[e >> 2] >> (8 * (e & 3))) & 0xff);
+        const double xd = (double)xi;
+        dw[rr] = fma(xd, wv[e], dw[rr]);
+        dd[rr] = fma(xd * xd, dv[e], dd[rr]);
+        sm[rr] += xi;
+      }
+    }
+  }
+  double my_dw = 0.0, my_dd = 0.0;
+  int my_sm = 0;
+#pragma unroll
+  for (int rr = 0; rr < FR; ++rr) {
+    double a = dw[rr], b = dd[rr];
+    int s = sm[rr];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o);
+      b += __shfl_xor(b, o);
+      s += __shfl_xor(s, o);
+    }
+    if (lane == rr) { my_dw = a; my_dd = b; my_sm = s; }
+  }
+  const int64_t m = m0 + lane;
+  if (lane < FR && m < M) {
+    const double qd = (double)(long long)q[m];
+    const double den = fma(step, qd, my_dd);
+    const double num = my_dw * my_dw;
+    double r = h0_rss;
+    // den ~ 0: monomorphic after projection; the reference's lstsq returns no residual and rss
+    // stays h0_rss (linear_models.py:1308,1329)
+    if (den > 1e-7 * my_dd && den > 0.0) r = h0_rss - num / den;
+    const double ratio = h0_rss / r;
+    const double F = (ratio - 1.0) * nu;
+    if (rss) rss[m] = r;
+    if (Fst) Fst[m] = F;
+    if (pv) pv[m] = f_sf_1(F, nu, lnbeta);
+    if (dotv) dotv[m] = my_dw;
+    if (denv) denv[m] = den;
+    if (sumv) sumv[m] = (double)my_sm;
+  }
+}
+
+// out[m] = s_m . v for an arbitrary fp64 vector v (zero padded to Npad); same streaming shape.
+__global__ __launch_bounds__(256, 2) void snp_dot_kernel(const int8_t* __restrict__ S, int64_t ldS, int64_t M,
+                                                         int32_t Npad, const double* __restrict__ v,
+                                                         double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t m0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * FR;
+  if (m0 >= M) return;
+  double dw[FR];
+#pragma unroll
+  for (int rr = 0; rr < FR; ++rr) dw[rr] = 0.0;
+  for (int c = lane; c < (Npad >> 4); c += 64) {
+    double wv[16];
+#pragma unroll
+    for (int e = 0; e < 16; e += 2) {
+      const double2 t = *(const double2*)(v + c * 16 + e);
+      wv[e] = t.x; wv[e + 1] = t.y;
+    }
+#pragma unroll
+    for (int rr = 0; rr < FR; ++rr) {
+      const uint4 u = *(const uint4*)(S + (m0 + rr) * ldS + c * 16);
+      const uint32_t wds[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        dw[rr] = fma((double)(int)(int8_t)((wds[e >> 2] >> (8 * (e & 3))) & 0xff), wv[e], dw[rr]);
+    }
+  }
+  double mine = 0.0;
+#pragma unroll
+  for (int rr = 0; rr < FR; ++rr) {
+    double a = dw[rr];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == rr) mine = a;
+  }
+  if (lane < FR && m0 + lane < M) out[m0 + lane] = mine;
+}
+
+void launch_snp_dot(mmg_ctx* ctx, const mmg_geno* g, const double* v, double* out) {
+  const int64_t nwaves = (g->M + FR - 1) / FR;
+  hipLaunchKernelGGL(snp_dot_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, ctx->stream, g->d,
+                     (int64_t)g->Npad, g->M, g->Npad, v, out);
+}
+
+void launch_scan_finalize(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, mmg_scan_result& res,
+                          double h0_rss, int32_t df2, double lnbeta) {
+  const int64_t nwaves = (g->M + FR - 1) / FR;
+  hipLaunchKernelGGL(scan_finalize_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, ctx->stream, g->d,
+                     (int64_t)g->Npad, g->M, g->Npad, md.w, md.diag, res.q, md.step, h0_rss, (double)df2, lnbeta,
+                     res.rss, res.F, res.p, res.dot, res.den, res.sum);
+}
+
+}  // namespace mmg

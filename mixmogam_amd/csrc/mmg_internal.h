@@ -1,0 +1,99 @@
+// mmg_internal.h -- shared declarations of libmixmogam_hip (not part of the public ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/mixmogam_hip.h"
+
+struct mmg_geno {
+  int64_t M = 0, Mpad = 0;      // SNPs, padded to 256
+  int32_t N = 0, Npad = 0;      // individuals, padded to 256
+  int8_t* d = nullptr;          // [Mpad x Npad] SNP-major, zero padded
+};
+
+enum { EV_KIN = 0, EV_QUAD = 1, EV_FIN = 2, EV_PERM = 3, EV_EIGH = 4, EV_PACK = 5, EV_COUNT = 6 };
+
+struct mmg_scan_model {
+  int32_t N = 0, Npad = 0, D = 0;
+  int8_t* Bq = nullptr;         // [D][Npad][Npad] digits of the strictly-lower triangle of 2A
+  double* diag = nullptr;       // [Npad] diagonal of A (0 padded)
+  double* w = nullptr;          // [Npad] (0 padded)
+  double step = 0.0;            // den = step * q + sum_i diag_i s_i^2
+  // tile schedule
+  int AS = 2, G = 16;           // sub-blocks per cohort, job groups per cohort (AS * G = 32)
+  int* job_off = nullptr;       // [G + 1]
+  int2* jobs = nullptr;         // (digit, J)
+  int njobs = 0;
+};
+
+struct mmg_scan_result {
+  int64_t cap = 0;              // capacity in SNPs (padded)
+  int64_t M = 0;
+  unsigned long long* q = nullptr;
+  double *rss = nullptr, *F = nullptr, *p = nullptr, *dot = nullptr, *den = nullptr, *sum = nullptr;
+};
+
+struct mmg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  hipEvent_t ev[EV_COUNT][2];
+  bool ev_set[EV_COUNT];
+  int n_cu = 0;
+  mmg_scan_model model;
+  mmg_scan_result res;
+  void* rocblas = nullptr;      // rocblas_handle, created lazily
+};
+
+namespace mmg {
+
+int set_err(mmg_ctx* ctx, int code, const std::string& msg);
+#define MMG_HIP(ctx, call)                                                                  \
+  do {                                                                                      \
+    hipError_t e__ = (call);                                                                \
+    if (e__ != hipSuccess)                                                                  \
+      return mmg::set_err(ctx, MMG_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+struct EvScope {  // records the two events of slot `which` around a region on ctx->stream
+  mmg_ctx* c; int w;
+  EvScope(mmg_ctx* ctx, int which) : c(ctx), w(which) { hipEventRecord(c->ev[w][0], c->stream); }
+  ~EvScope() { hipEventRecord(c->ev[w][1], c->stream); c->ev_set[w] = true; }
+};
+
+// ---- k_pack.hip
+void launch_fill_hash(mmg_ctx*, mmg_geno*, uint64_t seed, int64_t m_global0, uint32_t thr16);
+void launch_cvt_f32(mmg_ctx*, const float* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld);
+void launch_cvt_f64(mmg_ctx*, const double* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld);
+// Xt [Npad x Mk] = transpose of S with value map v -> mul*v + add for valid cells, 0 elsewhere.
+void launch_transpose(mmg_ctx*, const mmg_geno*, int8_t* Xt, int64_t Mk, int mul, int add);
+void launch_snp_stats(mmg_ctx*, const mmg_geno*, double* mean, double* sd);
+
+// ---- k_kinship.hip
+int kinship_pick_ksplit(int32_t Npad, int64_t Mk, bool f32);
+// C32 [Npad x Npad] int32 += Xt Xt^T (upper-triangular tiles only, mirrored by the caller).
+int run_kinship_i8(mmg_ctx*, const int8_t* Xt, int32_t Npad, int64_t Mk, int* C32);
+// slabs [ksplit][Npad x Npad] fp32; returns ksplit through *ksplit_out.
+int run_kinship_f32(mmg_ctx*, const int8_t* Xt, int32_t Npad, int64_t Mk, const float* scale,
+                    const float* shift, float* slabs, int ksplit);
+void launch_reduce_slabs(mmg_ctx*, const float* slabs, int ksplit, int32_t Npad, int32_t N, double* C);
+void launch_mirror_i32_to_i64(mmg_ctx*, const int* C32, int32_t Npad, int32_t N, int64_t* C);
+
+// ---- k_scan.hip
+void launch_absmax_offdiag(mmg_ctx*, const double* A, int32_t N, unsigned long long* out_bits);
+void launch_quantize(mmg_ctx*, const double* A, int32_t N, int32_t Npad, int D, double inv_step,
+                     int8_t* Bq, double* diag);
+void launch_scan_quad(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
+void launch_scan_finalize(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, mmg_scan_result&,
+                          double h0_rss, int32_t df2, double lnbeta);
+void launch_snp_dot(mmg_ctx*, const mmg_geno*, const double* v /*[Npad] dev*/, double* out /*[M] dev*/);
+void launch_f_sf(mmg_ctx*, const double* F, int64_t n, int32_t df2, double lnbeta, double* p);
+
+// ---- k_perm.hip
+int run_perm(mmg_ctx*, const mmg_geno*, int32_t N, const double* dW /*[Npad x P] dev*/, int32_t P,
+             const double* d_invden, const double* d_mu, int ndigits, double* d_maxstat);
+
+}  // namespace mmg

@@ -1,0 +1,114 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, SNP blocks partitioned across ranks.
+
+SURVEY 8e: kinship shards the contraction (SNP) axis -> all-reduce SUM of the N x N integer
+count matrix; eigh + REML are replicas; the EMMAX scan shards independent SNP blocks -> all-gather
+of (rss, F, p); the permutation test shards SNP blocks -> all-reduce MIN over the P minima.
+
+The collectives are behind a two-method interface so that the same sharding logic runs over
+RCCL on GPUs (RcclCollectives: libmixmogam_hip's mmg_comm_* over xGMI) and over gloo on CPU in
+the world_size-2 tests (TorchCollectives).
+"""
+import numpy as np
+
+
+def shard_range(total, rank, world):
+    """Contiguous block [m0, m1) of `total` units owned by `rank` (sizes differ by at most 1)."""
+    base, rem = divmod(int(total), int(world))
+    m0 = rank * base + min(rank, rem)
+    return m0, m0 + base + (1 if rank < rem else 0)
+
+
+class RcclCollectives(object):
+    """RCCL through the C ABI.  `bootstrap_bcast(bytes_or_None) -> bytes` distributes rank 0's
+    ncclUniqueId (e.g. over torch.distributed gloo, a file, or MPI)."""
+
+    def __init__(self, ctx, rank, world, bootstrap_bcast):
+        import ctypes as C
+        self.ctx, self.rank, self.world = ctx, rank, world
+        uid = (C.c_ubyte * 128)()
+        if rank == 0:
+            ctx._check(ctx.lib.mmg_comm_unique_id(uid))
+        raw = bootstrap_bcast(bytes(uid) if rank == 0 else None)
+        uid = (C.c_ubyte * 128).from_buffer_copy(raw)
+        h = C.c_void_p()
+        ctx._check(ctx.lib.mmg_comm_create(ctx.h, uid, rank, world, C.byref(h)))
+        self.h = h
+
+    def allreduce(self, arr, op="sum"):
+        from . import _lib
+        code = {"sum": 0, "min": 1, "max": 2}[op]
+        a = np.ascontiguousarray(arr)
+        if a.dtype == np.int64:
+            self.ctx._check(self.ctx.lib.mmg_comm_allreduce_i64(self.ctx.h, self.h, _lib._ptr(a), a.size, code))
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            self.ctx._check(self.ctx.lib.mmg_comm_allreduce_f64(self.ctx.h, self.h, _lib._ptr(a), a.size, code))
+        return a
+
+    def allgather_scan(self, count):
+        """all-gather the device-resident (rss, F, p) of the last scan; equal `count` per rank."""
+        from . import _lib
+        outs = [np.empty(self.world * count) for _ in range(3)]
+        self.ctx._check(self.ctx.lib.mmg_comm_allgather_scan(self.ctx.h, self.h, count, *[_lib._ptr(o) for o in outs]))
+        return outs
+
+    def barrier(self):
+        self.ctx._check(self.ctx.lib.mmg_comm_barrier(self.ctx.h, self.h))
+
+    def close(self):
+        if self.h is not None:
+            self.ctx.lib.mmg_comm_destroy(self.ctx.h, self.h)
+            self.h = None
+
+
+class TorchCollectives(object):
+    """torch.distributed (gloo on CPU) stand-in with the same interface, for tests."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def allreduce(self, arr, op="sum"):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(arr).copy())
+        self.dist.all_reduce(t, op={"sum": self.dist.ReduceOp.SUM, "min": self.dist.ReduceOp.MIN,
+                                    "max": self.dist.ReduceOp.MAX}[op])
+        return t.numpy()
+
+    def allgather_host(self, arr):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        return np.concatenate([o.numpy() for o in outs])
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def sharded_ibs_counts(local_counts, coll):
+    """Partial IBS count matrices (one per rank, over that rank's SNP block) -> global counts.
+    Integer all-reduce: exact and order independent."""
+    return coll.allreduce(np.asarray(local_counts, dtype=np.int64), "sum")
+
+
+def sharded_perm_min(local_min_rss, coll):
+    return coll.allreduce(np.asarray(local_min_rss, dtype=np.float64), "min")
+
+
+def pad_block(x, count):
+    """Pad a per-rank result block to the common `count` (ragged last shard) with NaN."""
+    out = np.full(count, np.nan)
+    out[:len(x)] = x
+    return out
+
+
+def unpad_gathered(gathered, total, world):
+    """Inverse of the rank-major gather of equal-sized padded blocks."""
+    count = len(gathered) // world
+    parts = []
+    for r in range(world):
+        m0, m1 = shard_range(total, r, world)
+        parts.append(gathered[r * count:r * count + (m1 - m0)])
+    return np.concatenate(parts)

@@ -1,0 +1,93 @@
+"""Kinship matrices -- same call surface as the reference's kinship.py, GEMMs on the MI355X.
+
+calc_ibs_kinship / calc_ibd_kinship / scale_k / prepare_k follow /root/reference/kinship.py
+(:14-56, :59-75, :94-100, :79-90).  Results are float64 ndarrays (the reference's IBS result is
+a float64 numpy.matrix; ndarray supports the same indexing the callers use).
+"""
+import numpy as np
+
+from . import _lib
+
+
+def _as_snp_matrix(snps, dtype=np.int8):
+    """list of M int8 arrays of length N, or 2-D array -> C-contiguous [M x N]."""
+    a = np.asarray(snps)
+    if a.ndim != 2:
+        raise ValueError("snps must be [num_snps x num_individuals]")
+    if a.dtype in (np.float32, np.float64):
+        return np.ascontiguousarray(a)
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def scale_k(k, verbose=False):
+    """kinship.py:94-100 -- c = tr(K) - sum(K)/n, K * (n-1)/c.  Host fp64, O(N^2)."""
+    k = np.asarray(k, dtype=np.float64)
+    n = len(k)
+    c = np.sum((np.eye(n) - (1.0 / n) * np.ones(k.shape)) * k)
+    scalar = (n - 1) / c
+    if verbose:
+        print('Kinship scaled by: %0.4f' % scalar)
+    return scalar * k
+
+
+def calc_ibs_kinship(snps, snps_data_format='binary', snp_dtype='int8', dtype='single',
+                     chunk_size=None, scaled=True, ctx=None, geno=None):
+    """kinship.py:14-56 ('binary'): K = sum_m (2s-1)(2s-1)^T / (2M) + 0.5, then scale_k.
+
+    The count matrix is an exact int8-MFMA GEMM on the device (bit-exact with the reference's
+    float64 accumulator); chunk_size is accepted for signature compatibility (the device kernel
+    tiles the SNP axis itself).  `geno` may pass an already-resident device genotype store."""
+    if snps_data_format != 'binary':
+        raise NotImplementedError("only snps_data_format='binary' is on the device path "
+                                  "(diploid_int: SURVEY 8f N4)")
+    ctx = ctx or _lib.get_context()
+    own = geno is None
+    g = ctx.geno(_as_snp_matrix(snps)) if own else geno
+    try:
+        counts = ctx.kinship_ibs_counts(g)
+        num_snps = g.M
+    finally:
+        if own:
+            g.close()
+    k_mat = counts.astype(np.float64) / (2 * float(num_snps)) + 0.5
+    if scaled:
+        k_mat = scale_k(k_mat)
+    return k_mat
+
+
+def calc_ibd_kinship(snps, dtype='single', scaled=True, ctx=None, geno=None):
+    """kinship.py:59-75: z = (s - mean)/std per SNP (population std), K = sum z z^T / M, scale_k.
+
+    fp32 MFMA GEMM with the standardisation applied while expanding int8 -> fp32 from LDS
+    (scale = 1/std, shift = -mean/std).  A monomorphic SNP has std = 0: the reference divides by
+    zero there and asserts (:67); here it raises ValueError."""
+    ctx = ctx or _lib.get_context()
+    own = geno is None
+    g = ctx.geno(_as_snp_matrix(snps)) if own else geno
+    try:
+        mean, sd = g.snp_stats()
+        if np.any(sd == 0):
+            raise ValueError("monomorphic SNP (std == 0) in calc_ibd_kinship")
+        k_mat = ctx.kinship_affine(g, 1.0 / sd, -mean / sd)
+        num_snps = g.M
+    finally:
+        if own:
+            g.close()
+    k_mat = k_mat / float(num_snps)
+    if scaled:
+        k_mat = scale_k(k_mat)
+    return k_mat
+
+
+def prepare_k(k, k_accessions, accessions):
+    """kinship.py:79-90."""
+    if k_accessions == accessions:
+        return np.asarray(k)
+    indices_to_keep = []
+    for acc in accessions:
+        try:
+            indices_to_keep.append(k_accessions.index(acc))
+        except ValueError:
+            continue
+    k = np.asarray(k)
+    return k[indices_to_keep, :][:, indices_to_keep]

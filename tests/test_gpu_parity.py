@@ -1,0 +1,292 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (ctypes) and through the
+reference-shaped Python surface, against the CPU oracle and the committed golden vectors.
+
+Bars: integer work (IBS counts, genotype store, hash fill) bit-exact; floating point within the
+tolerance written next to each assert (north star: p-values 1e-6 relative vs the double-promoted
+reference)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_case
+
+pytestmark = pytest.mark.gpu
+
+orc = pytest.importorskip("oracle.emmax_oracle")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from mixmogam_amd import _lib
+    return _lib.get_context()          # raises (does not skip) when the .so or the GPU is missing
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))) if len(a) else 0.0
+
+
+def struct_snps(rng, n, m, npop=3):
+    pops = rng.randint(0, npop, size=n)
+    freqs = rng.uniform(0.05, 0.95, size=(m, npop))
+    return (rng.random_sample((m, n)) < freqs[:, pops]).astype(np.int8)
+
+
+# ------------------------------------------------------------------ genotype store
+@pytest.mark.parametrize("n,m", [(150, 600), (257, 1000), (16, 3), (1000, 5)])
+def test_geno_roundtrip(ctx, n, m):
+    rng = np.random.RandomState(n + m)
+    snps = rng.randint(0, 3, size=(m, n)).astype(np.int8)
+    g = ctx.geno(snps)
+    assert np.array_equal(g.download(), snps)
+    assert np.array_equal(g.download(1, m - 1), snps[1:])
+    g2 = ctx.geno(M=m, N=n)
+    g2.upload(snps.astype(np.float32))
+    assert np.array_equal(g2.download(), snps)
+    g2.upload(snps[::-1].astype(np.float64))
+    assert np.array_equal(g2.download(), snps[::-1])
+    mean, sd = g.snp_stats()
+    assert rel(mean, snps.mean(1)) < 1e-14
+    assert np.max(np.abs(sd - snps.std(1))) < 1e-12
+
+
+def test_fill_hash_matches_oracle(ctx):
+    g = ctx.geno(M=777, N=333)
+    g.fill_hash(20240, m_global0=1000, thr16=32768)
+    assert np.array_equal(g.download(), orc.hash_genotypes(1000, 1777, 333, 20240))
+    g.fill_hash(7, m_global0=0, thr16=9000)
+    ref = orc.hash_genotypes(0, 777, 333, 7, maf_q16=np.full(777, 9000))
+    assert np.array_equal(g.download(), ref)
+
+
+# ------------------------------------------------------------------ kinship
+def test_ibs_counts_bit_exact_golden(ctx, case):
+    g = ctx.geno(case["snps"])
+    c = ctx.kinship_ibs_counts(g)
+    assert c.dtype == np.int64
+    assert np.array_equal(c, case["dbl_ibs_counts"].astype(np.int64))
+
+
+@pytest.mark.parametrize("n,m,seed", [(700, 5000, 0), (513, 12345, 1), (64, 100, 2), (1030, 257, 3)])
+def test_ibs_counts_bit_exact_random(ctx, n, m, seed):
+    rng = np.random.RandomState(seed)
+    snps = struct_snps(rng, n, m)
+    g = ctx.geno(snps)
+    c = ctx.kinship_ibs_counts(g)
+    ref = orc.ibs_counts(snps)
+    bad = np.argwhere(c != ref)
+    assert len(bad) == 0, "first mismatches %r got %r want %r" % (bad[:5], c[tuple(bad[0])], ref[tuple(bad[0])])
+    # same counts through the fp32-MFMA affine kernel (exact: integers < 2^24)
+    cf = ctx.kinship_affine(g)
+    assert np.array_equal(cf, ref.astype(np.float64))
+
+
+def test_ibs_kinship_property_large(ctx):
+    """size-independent properties at a size the CPU oracle would take minutes for:
+    diagonal == M exactly, symmetry, and linearity in the SNP axis (counts of two halves add)."""
+    n, m = 2000, 60000
+    g = ctx.geno(M=m, N=n).fill_hash(11)
+    c = ctx.kinship_ibs_counts(g)
+    assert np.all(np.diag(c) == m)
+    assert np.array_equal(c, c.T)
+    g1 = ctx.geno(M=m // 2, N=n).fill_hash(11, m_global0=0)
+    g2 = ctx.geno(M=m - m // 2, N=n).fill_hash(11, m_global0=m // 2)
+    assert np.array_equal(ctx.kinship_ibs_counts(g1) + ctx.kinship_ibs_counts(g2), c)
+    sub = orc.ibs_counts(g.download()[:, :64])
+    assert np.array_equal(c[:64, :64], sub)
+
+
+def test_kinship_module_golden(ctx, case):
+    from mixmogam_amd import kinship
+    k = kinship.calc_ibs_kinship(list(case["snps"]))
+    assert rel(k, case["dbl_ibs_scaled"]) < 1e-13           # exact counts -> fp64 affine + scale_k
+    ku = kinship.calc_ibs_kinship(case["snps"], scaled=False)
+    assert np.array_equal(np.rint((ku - 0.5) * 2 * len(case["snps"])).astype(np.int64),
+                          case["dbl_ibs_counts"].astype(np.int64))
+    kd = kinship.calc_ibd_kinship(case["snps"])
+    # fp32 MFMA accumulation of standardised genotypes: the reference's own fp32 accumulator
+    # differs from its fp64 one by up to ~2e-7 absolute (golden lit vs dbl)
+    assert np.max(np.abs(kd - case["dbl_ibd_scaled"])) < 2e-5
+    assert rel(kinship.scale_k(ku), case["dbl_scale_k_of_ibs_unscaled"]) < 1e-13
+
+
+# ------------------------------------------------------------------ dense fp64 helpers
+def test_eigh_and_dgemm(ctx):
+    rng = np.random.RandomState(3)
+    n = 301
+    a = rng.randn(n, n)
+    a = a @ a.T / n + np.eye(n)
+    vals, vecs = ctx.eigh(a)
+    ref = np.linalg.eigvalsh(a)
+    assert np.all(np.diff(vals) >= 0)                      # ascending: eigenvalue ORDER is exact
+    assert np.max(np.abs(vals - ref)) < 1e-11
+    assert np.max(np.abs(vecs @ vecs.T - np.eye(n))) < 1e-11
+    assert np.max(np.abs((vecs.T * vals) @ vecs - a)) < 1e-10
+    b = rng.randn(n, 77)
+    c = rng.randn(55, n)
+    assert rel(ctx.dgemm(a, b), a @ b) < 1e-12
+    assert rel(ctx.dgemm(b, a, ta=True), b.T @ a) < 1e-12
+    assert rel(ctx.dgemm(a, c, tb=True), a @ c.T) < 1e-12
+    assert rel(ctx.dgemm(b, c, ta=True, tb=True), b.T @ c.T) < 1e-11
+
+
+def test_f_sf_known_answers(ctx):
+    kat = np.load(os.path.join(GOLDEN, "f_sf_kat.npz"))
+    for nu in (197, 998, 4998, 49998):
+        p = ctx.f_sf(kat["F"], nu)
+        ref = kat["sf_%d" % nu]
+        ok = ref > 1e-300
+        # scipy itself loses ~1e-8 for F < 1e-3 (forms x = nu/(nu+F) before 1-x); 1e-7 covers it
+        assert rel(p[ok], ref[ok]) < 1e-7, nu
+        big = ok & (kat["F"] > 1e-3)
+        assert rel(p[big], ref[big]) < 1e-9, nu
+    assert ctx.f_sf([0.0, -1.0], 100).tolist() == [1.0, 1.0]
+
+
+# ------------------------------------------------------------------ EMMAX scan
+def _prep(case):
+    y = case["y"]
+    n = len(y)
+    X = np.ones((n, 1))
+    if case["cof"] is not None:
+        X = np.hstack([X] + [c.reshape(n, 1) for c in case["cof"]])
+    K = orc.scale_k(case["dbl_ibs_scaled"])
+    est = orc.get_estimates(y, X, K)
+    return orc.scan_prepare(y, X, est["H_sqrt_inv"])
+
+
+@pytest.mark.parametrize("ndigits", [3, 4, 5])
+def test_scan_c_abi_vs_oracle(ctx, case, ndigits):
+    prep = _prep(case)
+    ref = orc.scan_closed(case["snps"], prep)
+    g = ctx.geno(case["snps"])
+    ctx.scan_set_model(prep["A"], prep["w"], ndigits)
+    out = ctx.scan(g, prep["h0_rss"], prep["n"] - prep["q"] - 1, stats=True)
+    tol = {3: 2e-5, 4: 1e-6, 5: 1e-6}[ndigits]
+    assert rel(out["dot"], case["snps"].astype(float) @ prep["w"]) < 1e-10
+    assert rel(out["den"], ref["den"]) < tol * 1e-1
+    assert rel(out["rss"], ref["rss"]) < tol * 1e-1
+    assert rel(out["ps"], ref["ps"]) < tol, "min p %g" % ref["ps"].min()
+    assert np.array_equal(out["sum"], case["snps"].sum(1).astype(float))
+
+
+def test_scan_bitwise_reproducible_and_schedule_independent(ctx):
+    case = load_case("struct_n300_s2")
+    prep = _prep(case)
+    g = ctx.geno(case["snps"])
+    ctx.scan_set_model(prep["A"], prep["w"], 4)
+    a = ctx.scan(g, prep["h0_rss"], 298)
+    b = ctx.scan(g, prep["h0_rss"], 298)
+    for k in ("rss", "f_stats", "ps"):
+        assert np.array_equal(a[k], b[k])
+
+
+def test_emmax_python_surface_vs_golden(ctx, case):
+    from mixmogam_amd import linear_models as lm
+    res = lm.emmax(list(case["snps"]), list(case["y"]), case["dbl_ibs_scaled"], cofactors=case["cof"])
+    assert rel(res["ps"], case["dbl_emmax_ps"]) < 1e-6          # the north-star tolerance
+    assert rel(res["rss"], case["dbl_emmax_rss"]) < 1e-8
+    assert rel(res["h0_rss"], case["dbl_emmax_h0_rss"]) < 1e-9
+    big = case["dbl_emmax_f_stats"] > 1e-6
+    assert rel(res["f_stats"][big], case["dbl_emmax_f_stats"][big]) < 1e-6
+    for k in ("pseudo_heritability", "ve", "vg", "max_ll"):
+        assert rel(res[k], case["dbl_emmax_" + k]) < 1e-7, k
+    assert np.argmin(res["ps"]) == np.argmin(case["dbl_emmax_ps"])
+
+
+def test_reml_python_surface_vs_golden(ctx, case):
+    from mixmogam_amd import linear_models as lm
+    res = lm.get_emma_reml_estimates(list(case["y"]), case["dbl_ibs_scaled"], cofactors=case["cof"])
+    for k in ("max_ll", "delta", "ve", "vg", "pseudo_heritability"):
+        assert rel(res[k], case["dbl_reml_" + k]) < 1e-7, k
+    assert rel(res["beta"], case["dbl_reml_beta"]) < 1e-6
+    ev = res["eig_L"]["values"]
+    assert np.all(np.diff(ev) >= 0)
+    assert np.max(np.abs(ev - case["dbl_eig_L_values"])) < 1e-9
+    H = res["H_sqrt_inv"]
+    probe = np.random.RandomState(99).randn(len(case["y"]), 3)
+    assert rel(H.T @ (H @ probe), case["dbl_HtH_probe"]) < 1e-6
+
+
+def test_with_betas_vs_golden(ctx, case):
+    from mixmogam_amd import linear_models as lm
+    lmm = lm.LinearMixedModel(list(case["y"]))
+    lmm.add_random_effect(case["dbl_ibs_scaled"])
+    if case["cof"] is not None:
+        for c in case["cof"]:
+            lmm.add_factor(c)
+    wb = lmm.emmax_f_test(case["snps"][:200], with_betas=True, emma_num=0)
+    assert rel(wb["ps"], case["dbl_wb_ps"]) < 1e-6
+    got = np.asarray(wb["betas"])
+    want = case["dbl_wb_betas"]
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) < 1e-6 * max(1.0, np.abs(want).max())
+
+
+def test_scan_edge_cases(ctx):
+    case = load_case("struct_n150_s0")
+    prep = _prep(case)
+    n = 150
+    ctx.scan_set_model(prep["A"], prep["w"], 4)
+    # monomorphic SNPs (all 0 / all 1): rss stays h0_rss, F = 0, p = 1 (linear_models.py:1308,1329)
+    snps = np.vstack([np.zeros((1, n)), np.ones((1, n)), case["snps"][:3]]).astype(np.int8)
+    out = ctx.scan(ctx.geno(snps), prep["h0_rss"], n - 2)
+    assert out["rss"][0] == prep["h0_rss"] and out["rss"][1] == prep["h0_rss"]
+    assert out["ps"][0] == 1.0 and out["ps"][1] == 1.0 and out["f_stats"][0] == 0.0
+    ref = orc.scan_closed(case["snps"][:3], prep)
+    assert rel(out["ps"][2:], ref["ps"]) < 1e-6
+    # a single SNP and an empty store
+    one = ctx.scan(ctx.geno(case["snps"][5:6]), prep["h0_rss"], n - 2)
+    assert rel(one["ps"], orc.scan_closed(case["snps"][5:6], prep)["ps"]) < 1e-6
+    empty = ctx.scan(ctx.geno(M=0, N=n), prep["h0_rss"], n - 2)
+    assert len(empty["ps"]) == 0
+    # allele-coding flip s -> 1 - s leaves F unchanged (the intercept is projected out)
+    a = ctx.scan(ctx.geno(case["snps"]), prep["h0_rss"], n - 2)
+    b = ctx.scan(ctx.geno(1 - case["snps"]), prep["h0_rss"], n - 2)
+    assert rel(b["ps"], a["ps"]) < 1e-6
+    # diploid-style 0/1/2 coding
+    s2 = (case["snps"][:100] + case["snps"][100:200]).astype(np.int8)
+    c = ctx.scan(ctx.geno(s2), prep["h0_rss"], n - 2)
+    assert rel(c["ps"], orc.scan_closed(s2, prep)["ps"]) < 1e-6
+
+
+def test_scan_midsize_vs_oracle(ctx):
+    """N = 1100 (5 column tiles, ragged), M = 3000: full pipeline through the Python surface."""
+    from mixmogam_amd import kinship, linear_models as lm
+    rng = np.random.RandomState(42)
+    n, m = 1100, 3000
+    snps = struct_snps(rng, n, m)
+    snps = snps[(snps.sum(1) > 0) & (snps.sum(1) < n)]
+    y = snps[:8].astype(float).T @ rng.exponential(1.0, 8) + 2.0 * rng.randn(n)
+    K = kinship.calc_ibs_kinship(snps)
+    assert rel(K, orc.calc_ibs_kinship(snps)) < 1e-13
+    res = lm.emmax(snps, y, K)
+    ref = orc.emmax(snps, y, K)
+    assert rel(res["ps"], ref["ps"]) < 1e-6, (res["ps"].min(), ref["ps"].min())
+    assert rel(res["pseudo_heritability"], ref["pseudo_heritability"]) < 1e-6
+
+
+def test_one_shot_c_abi(ctx):
+    import ctypes as C
+    from mixmogam_amd import _lib
+    case = load_case("struct_n150_s0")
+    prep = _prep(case)
+    snps = np.ascontiguousarray(case["snps"])
+    m, n = snps.shape
+    rss, F, p = np.empty(m), np.empty(m), np.empty(m)
+    A = np.ascontiguousarray(prep["A"])
+    w = np.ascontiguousarray(prep["w"])
+    rc = ctx.lib.mmg_emmax_scan_i8(ctx.h, _lib._ptr(snps), m, n, _lib._ptr(A), _lib._ptr(w),
+                                   C.c_double(prep["h0_rss"]), n - 2, _lib._ptr(rss), _lib._ptr(F), _lib._ptr(p))
+    assert rc == 0
+    assert rel(p, orc.scan_closed(snps, prep)["ps"]) < 1e-6
+    Cout = np.empty((n, n))
+    rc = ctx.lib.mmg_kinship_i8(ctx.h, _lib._ptr(snps), m, n, None, None, _lib._ptr(Cout))
+    assert rc == 0
+    assert np.array_equal(Cout, orc.ibs_counts(snps).astype(float))
+    # error behaviour: scan before a model of matching N -> error code + message, no crash
+    g = ctx.geno(M=4, N=n + 1)
+    rc = ctx.lib.mmg_emmax_scan_device(ctx.h, g.h, C.c_double(1.0), 10)
+    assert rc != 0 and b"N" in ctx.lib.mmg_last_error(ctx.h)

@@ -1,0 +1,155 @@
+"""CPU-side tests (-m "not gpu"): the C-ABI library builds, loads and exports every symbol the
+header declares; the host package fails loudly without a GPU; sharding logic; simulations."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    from mixmogam_amd import _lib
+    return _lib
+
+
+def test_header_symbols_exported_and_bound(built):
+    lib = built.load()
+    header = open(built.HEADER_PATH).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(mmg_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    assert len(declared) >= 30
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(built.PROTOTYPES), declared ^ set(built.PROTOTYPES)
+    out = subprocess.run(["nm", "-D", "--defined-only", built.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (mmg_[a-z0-9_]+)", out))
+    assert declared <= exported, declared - exported
+    assert lib.mmg_version() >= 100
+
+
+def test_code_object_targets_gfx950(built):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", built.LIB_PATH],
+                         capture_output=True, text=True)
+    txt = out.stdout + out.stderr
+    if "gfx" in txt:
+        assert "gfx950" in txt
+
+
+def test_no_silent_cpu_fallback(built):
+    import ctypes as C
+    lib = built.load()
+    n = C.c_int(-1)
+    lib.mmg_device_count(C.byref(n))
+    if n.value > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(built.MixmogamHipError):
+        built.Context(0)
+    from mixmogam_amd import kinship
+    with pytest.raises(built.MixmogamHipError):
+        kinship.calc_ibs_kinship(np.zeros((4, 8), dtype=np.int8))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "mixmogam_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no CPU oracle", "").replace("The CPU oracle lives in oracle/", "") \
+                    or f == "_lib.py", f
+
+
+def test_shard_range_partitions():
+    from mixmogam_amd.dist import shard_range, pad_block, unpad_gathered
+    for total in (0, 1, 7, 8, 1000003):
+        for world in (1, 2, 3, 8):
+            edges = [shard_range(total, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == total
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+    total, world = 11, 3
+    x = np.arange(total, dtype=float)
+    count = max(b - a for a, b in (shard_range(total, r, world) for r in range(world)))
+    gathered = np.concatenate([pad_block(x[slice(*shard_range(total, r, world))], count) for r in range(world)])
+    assert np.array_equal(unpad_gathered(gathered, total, world), x)
+
+
+def test_scale_k_and_prepare_k_host():
+    from mixmogam_amd import kinship
+    from oracle import emmax_oracle as orc
+    rng = np.random.RandomState(0)
+    a = rng.rand(20, 20)
+    k = a @ a.T
+    assert np.allclose(kinship.scale_k(k), orc.scale_k(k), rtol=1e-14)
+    acc = list("abcdefghijklmnopqrst")
+    sub = kinship.prepare_k(k, acc, ["c", "a", "zz", "t"])
+    assert np.array_equal(sub, k[[2, 0, 19]][:, [2, 0, 19]])
+
+
+def test_simulations_restate_reference_shapes():
+    from mixmogam_amd import simulations
+    sd = simulations.simulate_genotypes(num_indivs=50, num_snps=200, seed=1)
+    snps = sd['snps']
+    assert snps.dtype == np.int8 and snps.shape[1] == 50 and set(np.unique(snps)) <= {0, 1}
+    assert np.all(snps.sum(1) > 0)
+    assert len(sd['positions']) == len(snps) == len(sd['chromosomes'])
+    y = simulations.simulate_phenotype(snps, seed=2)
+    assert abs(y.mean()) < 1e-12 and abs(y.std() - 1) < 1e-12
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch.distributed as dist
+from mixmogam_amd import dist as mdist
+from oracle import emmax_oracle as orc
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+coll = mdist.TorchCollectives()
+rng = np.random.RandomState(0)
+n, m = 60, 501
+snps = (rng.random_sample((m, n)) < rng.uniform(0.1, 0.9, size=(m, 1))).astype(np.int8)
+y = rng.randn(n) + snps[3]
+m0, m1 = mdist.shard_range(m, rank, world)
+# kinship: partial exact counts + integer all-reduce
+counts = mdist.sharded_ibs_counts(orc.ibs_counts(snps[m0:m1]), coll)
+assert np.array_equal(counts, orc.ibs_counts(snps))
+K = orc.scale_k(counts / (2.0 * m) + 0.5)
+# replicas: eigh + REML; scan: SNP shards + gather
+X = np.ones((n, 1))
+est = orc.get_estimates(y, X, orc.scale_k(K))
+prep = orc.scan_prepare(y, X, est["H_sqrt_inv"])
+local = orc.scan_closed(snps[m0:m1], prep)["ps"]
+count = max(b - a for a, b in (mdist.shard_range(m, r, world) for r in range(world)))
+gathered = coll.allgather_host(mdist.pad_block(local, count))
+ps = mdist.unpad_gathered(gathered, m, world)
+assert np.array_equal(ps, orc.scan_closed(snps, prep)["ps"])
+# permutations: SNP shards + MIN all-reduce
+idx = np.array([np.random.RandomState(5 + p).permutation(n) for p in range(6)])
+pp = orc.perm_prepare(y, X, est["H_sqrt_inv"], idx)
+mn = mdist.sharded_perm_min(orc.perm_closed(snps[m0:m1], pp)["min_rss"], coll)
+assert np.allclose(mn, orc.perm_closed(snps, pp)["min_rss"], rtol=1e-12)
+coll.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_sharding_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % r in o
