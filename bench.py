@@ -56,21 +56,16 @@ def main():
 
     from mixmogam_amd import _lib, dist as mdist, kinship, linear_models as lm
 
-    tdist = None
-    if world > 1:
-        import torch.distributed as tdist_mod
-        tdist = tdist_mod
-        tdist.init_process_group("gloo", rank=rank, world_size=world)   # rendezvous + host barriers only
-
+    # No torch in this process: libmixmogam_hip links the system ROCm runtime and importing
+    # torch's bundled one beside it segfaults.  Rendezvous = rank 0's ncclUniqueId through a
+    # /tmp file keyed by the launcher's MASTER_PORT; barriers and the max-over-ranks time go
+    # over RCCL itself.
     ctx = _lib.Context(local_rank)
     info = ctx.device_info()
     coll = None
-    if world > 1:
-        def bcast(raw):
-            obj = [raw]
-            tdist.broadcast_object_list(obj, src=0)
-            return obj[0]
-        coll = mdist.RcclCollectives(ctx, rank, world, bcast)
+    if world > 1 or os.environ.get("MMG_BENCH_FORCE_COLL"):   # the env knob exercises the RCCL path on 1 GPU
+        boot = mdist.file_bootstrap(rank, world)
+        coll = mdist.RcclCollectives(ctx, rank, world, boot)
 
     N, M, D = args.n, args.m, args.digits
     Mtot = M * world
@@ -119,14 +114,10 @@ def main():
     t_setup = time.time() - t_setup
 
     def barrier():
-        if tdist is not None:
-            tdist.barrier()
-        try:
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
-        except Exception:
-            pass
+        # every library call above blocks on its HIP stream (hipStreamSynchronize), so the device
+        # is idle here; across ranks: an RCCL all-reduce.
+        if coll is not None:
+            coll.barrier()
 
     def step():
         ctx.scan(g, prep["h0_rss"], n_p, fetch=False)           # blocks until the kernels finish
@@ -147,11 +138,8 @@ def main():
         fin_ms.append(ctx.kernel_ms("scan_finalize"))
     barrier()
     elapsed = time.time() - t0
-    if tdist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    if coll is not None:
+        elapsed = float(coll.allreduce(np.array([elapsed]), "max")[0])
 
     ps = out[2]
     if rank == 0:
@@ -193,9 +181,14 @@ def main():
             res["cpu_baseline"] = cpu_baseline(N, args.cpu_sample or N, lmm, est, prep, ps[:min(M, args.cpu_sample or N)])
         print(json.dumps(res))
         sys.stdout.flush()
-    if tdist is not None:
-        tdist.barrier()
-        tdist.destroy_process_group()
+    if coll is not None:
+        coll.barrier()
+        if rank == 0:
+            try:
+                os.remove(boot.path)
+            except OSError:
+                pass
+        coll.close()
 
 
 def _device_rows(ctx, rows, n, seed):

@@ -79,7 +79,7 @@ def load():
             raise MixmogamHipError(
                 "libmixmogam_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C mixmogam_amd/csrc`. There is no CPU fallback." % LIB_PATH)
-        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        lib = C.CDLL(LIB_PATH)   # RTLD_LOCAL: keep the system ROCm libraries it links out of other modules' way
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res

@@ -18,6 +18,41 @@ def shard_range(total, rank, world):
     return m0, m0 + base + (1 if rank < rem else 0)
 
 
+def file_bootstrap(rank, world, timeout_s=120.0):
+    """Single-node bootstrap of rank 0's 128-byte ncclUniqueId through a file in /tmp, keyed by
+    the launcher's MASTER_PORT / run id (torchrun exports them).  Returns a `bcast(raw)`
+    callable for RcclCollectives.  No torch in the GPU process: the HIP library links the
+    system ROCm runtime, and importing torch's bundled runtime beside it is not safe."""
+    import os
+    import time
+    key = "%s_%s_%s_%d" % (os.environ.get("MASTER_ADDR", "local"), os.environ.get("MASTER_PORT", "0"),
+                           os.environ.get("TORCHELASTIC_RUN_ID", "none"), world)
+    path = os.path.join("/tmp", "mmg_rdzv_" + "".join(c if c.isalnum() else "_" for c in key) + ".bin")
+    t_start = time.time()
+
+    def bcast(raw):
+        if rank == 0:
+            tmp = path + ".%d" % os.getpid()
+            with open(tmp, "wb") as f:
+                f.write(raw)
+            os.replace(tmp, path)
+            return raw
+        while True:
+            try:
+                st = os.stat(path)
+                if st.st_size == 128 and st.st_mtime > t_start - 30.0:
+                    with open(path, "rb") as f:
+                        return f.read()
+            except OSError:
+                pass
+            if time.time() - t_start > timeout_s:
+                raise RuntimeError("timed out waiting for rank 0's RCCL id at %s" % path)
+            time.sleep(0.05)
+
+    bcast.path = path
+    return bcast
+
+
 class RcclCollectives(object):
     """RCCL through the C ABI.  `bootstrap_bcast(bytes_or_None) -> bytes` distributes rank 0's
     ncclUniqueId (e.g. over torch.distributed gloo, a file, or MPI)."""
