@@ -73,6 +73,9 @@ __device__ __forceinline__ void mma_kstep(const char* buf, int wm, int wn, int l
 
 // Full K loop over k-steps [ks0, ks1) (units of BK bytes).  P / Q point at row 0 of the tile's
 // row range.  On return every wave has passed the final barrier (LDS free for reuse).
+// ABLATE (timing experiments only; results are wrong unless 0): 1 = no staging inside the loop,
+// 2 = staging only (no LDS reads, no MFMA), 3 = MFMA on registers only (no LDS reads in loop).
+template <int ABLATE = 0>
 __device__ __forceinline__ void gemm_tile_i8(const int8_t* __restrict__ P, int64_t ldP,
                                              const int8_t* __restrict__ Q, int64_t ldQ,
                                              int ks0, int ks1, char* lds, v16i (&acc)[4][2]) {
@@ -91,13 +94,30 @@ __device__ __forceinline__ void gemm_tile_i8(const int8_t* __restrict__ P, int64
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
+  v4i fa[4], fb[2];
+  if (ABLATE == 3) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) fa[m] = lds_frag(lds, wm * 128 + m * 32 + (lane & 31), lane >> 5);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) fb[n] = lds_frag(lds + TILE_BYTES, wn * 64 + n * 32 + (lane & 31), lane >> 5);
+  }
   for (int ks = ks0; ks < ks1; ++ks) {
-    if (ks + 1 < ks1) {
+    if (ks + 1 < ks1 && ABLATE != 1 && ABLATE != 3) {
       char* nb = lds + (cur ^ 1) * BUF_BYTES;
       stage_tile(P, ldP, (int64_t)(ks + 1) * BK, nb, wave, lane);
       stage_tile(Q, ldQ, (int64_t)(ks + 1) * BK, nb + TILE_BYTES, wave, lane);
     }
-    mma_kstep(lds + cur * BUF_BYTES, wm, wn, lane, acc);
+    if (ABLATE == 3) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
+    } else if (ABLATE != 2) {
+      mma_kstep(lds + cur * BUF_BYTES, wm, wn, lane, acc);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;

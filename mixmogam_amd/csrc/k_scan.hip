@@ -15,6 +15,7 @@
 // are bitwise reproducible from run to run and independent of the tile schedule.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include "gemm_i8_core.h"
 #include "mmg_internal.h"
 
@@ -81,6 +82,7 @@ void launch_quantize(mmg_ctx* ctx, const double* A, int32_t N, int32_t Npad, int
 // Workgroup -> (SNP block of 256, job group).  Blocks b, b+8, ... share an XCD (observed
 // placement, speed only): a cohort of 32 consecutive such blocks works on AS SNP blocks x G
 // job groups, so the S rows are L2 hits for G workgroups and the digit tiles for AS.
+template <int ABLATE>
 __global__ __launch_bounds__(NTHREADS, 2) void scan_quad_kernel(
     const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Bq, int64_t ldB,
     int64_t digit_stride, const int* __restrict__ job_off, const int2* __restrict__ jobs, int AS,
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void scan_quad_kernel(
     const int d = jb.x, J = jb.y;
     const int8_t* P = Bq + (int64_t)d * digit_stride + (int64_t)J * TM * ldB;
     v16i acc[4][2];
-    gemm_tile_i8(P, ldB, Q, ldS, 0, 2 * (J + 1), lds, acc);
+    gemm_tile_i8<ABLATE>(P, ldB, Q, ldS, 0, 2 * (J + 1), lds, acc);
     // epilogue: lane holds SNP column n = wn*64 + nn*32 + r and rows j = wm*128 + m*32 +
     // (reg&3) + 8*(reg>>2) + 4*h of T = Z_d(J-tile rows) . S^T; multiply by s[snp][256J + j].
 #pragma unroll
@@ -134,10 +136,22 @@ void launch_scan_quad(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md,
   const int nSb = (int)(g->Mpad / TN);
   const int per = 8 * md.AS;
   const int ncoh = (nSb + per - 1) / per;
-  hipFuncSetAttribute((const void*)scan_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-  hipLaunchKernelGGL(scan_quad_kernel, dim3((unsigned)(ncoh * 256)), dim3(NTHREADS), LDS_BYTES, ctx->stream, g->d,
-                     (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad, (int64_t)md.Npad * md.Npad, md.job_off,
-                     md.jobs, md.AS, q);
+  int ablate = 0;
+  if (const char* e = std::getenv("MMG_ABLATE")) ablate = std::atoi(e);   // timing experiments only
+#define MMG_LAUNCH_QUAD(AB)                                                                                       \
+  do {                                                                                                            \
+    hipFuncSetAttribute((const void*)scan_quad_kernel<AB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
+    hipLaunchKernelGGL(scan_quad_kernel<AB>, dim3((unsigned)(ncoh * 256)), dim3(NTHREADS), LDS_BYTES, ctx->stream, \
+                       g->d, (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad, (int64_t)md.Npad * md.Npad,         \
+                       md.job_off, md.jobs, md.AS, q);                                                            \
+  } while (0)
+  switch (ablate) {
+    case 1: MMG_LAUNCH_QUAD(1); break;
+    case 2: MMG_LAUNCH_QUAD(2); break;
+    case 3: MMG_LAUNCH_QUAD(3); break;
+    default: MMG_LAUNCH_QUAD(0); break;
+  }
+#undef MMG_LAUNCH_QUAD
 }
 
 // ------------------------------------------------------------------ p-value
