@@ -434,25 +434,19 @@ static int build_schedule(mmg_ctx* ctx, mmg_scan_model& md) {
   return MMG_OK;
 }
 
-int mmg_scan_set_model(mmg_ctx* ctx, int32_t N, const double* A, const double* w, int ndigits) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
-  MMG_CHECK_ARG(ctx, A && w && N > 0);
-  if (ndigits == 0) ndigits = 4;
-  MMG_CHECK_ARG(ctx, ndigits >= 2 && ndigits <= 6);
-  free_model(ctx->model);
-  mmg_scan_model& md = ctx->model;
+// Build a scan model from a DEVICE-resident fp64 matrix dA [N x N] and device vector dw [N].
+static int model_from_device(mmg_ctx* ctx, mmg_scan_model& md, int32_t N, const double* dA, const double* dw,
+                             int ndigits) {
+  free_model(md);
   md.N = N; md.Npad = (int32_t)round_up(N, 256); md.D = ndigits;
-  double* dA = nullptr;
   unsigned long long* dmax = nullptr;
-  MMG_HIP(ctx, hipMalloc(&dA, (size_t)N * N * sizeof(double)));
   MMG_HIP(ctx, hipMalloc(&dmax, sizeof(unsigned long long)));
   MMG_HIP(ctx, hipMalloc(&md.Bq, (size_t)md.D * md.Npad * md.Npad));
   MMG_HIP(ctx, hipMalloc(&md.diag, md.Npad * sizeof(double)));
   MMG_HIP(ctx, hipMalloc(&md.w, md.Npad * sizeof(double)));
   MMG_HIP(ctx, hipMemsetAsync(md.w, 0, md.Npad * sizeof(double), ctx->stream));
   MMG_HIP(ctx, hipMemsetAsync(dmax, 0, sizeof(unsigned long long), ctx->stream));
-  MMG_HIP(ctx, hipMemcpyAsync(dA, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  MMG_HIP(ctx, hipMemcpyAsync(md.w, w, N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  MMG_HIP(ctx, hipMemcpyAsync(md.w, dw, N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   launch_absmax_offdiag(ctx, dA, N, dmax);
   unsigned long long bits = 0;
   MMG_HIP(ctx, hipMemcpyAsync(&bits, dmax, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
@@ -465,12 +459,26 @@ int mmg_scan_set_model(mmg_ctx* ctx, int32_t N, const double* A, const double* w
   launch_quantize(ctx, dA, N, md.Npad, md.D, 1.0 / md.step, md.Bq, md.diag);
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  hipFree(dA); hipFree(dmax);
+  hipFree(dmax);
   return build_schedule(ctx, md);
 }
 
-static int ensure_result(mmg_ctx* ctx, int64_t Mpad) {
-  mmg_scan_result& r = ctx->res;
+int mmg_scan_set_model(mmg_ctx* ctx, int32_t N, const double* A, const double* w, int ndigits) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, A && w && N > 0);
+  if (ndigits == 0) ndigits = 4;
+  MMG_CHECK_ARG(ctx, ndigits >= 2 && ndigits <= 6);
+  double *dA = nullptr, *dw = nullptr;
+  MMG_HIP(ctx, hipMalloc(&dA, (size_t)N * N * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dw, N * sizeof(double)));
+  MMG_HIP(ctx, hipMemcpyAsync(dA, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  MMG_HIP(ctx, hipMemcpyAsync(dw, w, N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  int rc = model_from_device(ctx, ctx->model, N, dA, dw, ndigits);
+  hipFree(dA); hipFree(dw);
+  return rc;
+}
+
+static int ensure_result(mmg_ctx* ctx, mmg_scan_result& r, int64_t Mpad) {
   if (r.cap >= Mpad) return MMG_OK;
   free_result(r);
   MMG_HIP(ctx, hipMalloc(&r.q, Mpad * sizeof(unsigned long long)));
@@ -489,7 +497,7 @@ int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2)
   MMG_CHECK_ARG(ctx, g != nullptr && df2 > 0);
   if (!ctx->model.Bq) return set_err(ctx, MMG_E_STATE, "mmg_scan_set_model has not been called");
   if (ctx->model.N != g->N) return set_err(ctx, MMG_E_ARG, "model N does not match the genotype store");
-  int rc = ensure_result(ctx, g->Mpad);
+  int rc = ensure_result(ctx, ctx->res, g->Mpad);
   if (rc) return rc;
   ctx->res.M = g->M;
   if (g->M == 0) return MMG_OK;
@@ -593,11 +601,81 @@ int mmg_f_sf(mmg_ctx* ctx, const double* F, int64_t n, int32_t df2, double* p) {
 }
 
 // ------------------------------------------------------------------------- permutations
+// row-major C[M x N] = op(A) op(B) on device pointers
+static int dgemm_dev(mmg_ctx* ctx, int ta, int tb, int M, int N, int K, const double* dA, const double* dB, double* dC) {
+  rocblas_handle h;
+  int rc = get_rocblas(ctx, &h);
+  if (rc) return rc;
+  const double one = 1.0, zero = 0.0;
+  MMG_RB(ctx, rocblas_dgemm(h, tb ? rocblas_operation_transpose : rocblas_operation_none,
+                            ta ? rocblas_operation_transpose : rocblas_operation_none, N, M, K, &one, dB,
+                            tb ? K : N, dA, ta ? M : K, &zero, dC, N));
+  return MMG_OK;
+}
+
 int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const double* Ys, int32_t P, double h0_rss,
                    int ndigits, double* min_rss) {
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
-  (void)g; (void)N; (void)Ht; (void)Ys; (void)P; (void)h0_rss; (void)ndigits; (void)min_rss;
-  return set_err(ctx, MMG_E_STATE, "mmg_emmax_perm: not built yet");
+  MMG_CHECK_ARG(ctx, g && Ht && Ys && min_rss && P > 0 && N == g->N);
+  MMG_CHECK_ARG(ctx, ndigits == 0 || ndigits == 4);
+  std::vector<double> yy((size_t)P, 0.0);
+  for (int i = 0; i < N; ++i)
+    for (int p = 0; p < P; ++p) yy[p] += Ys[(size_t)i * P + p] * Ys[(size_t)i * P + p];
+  if (g->M == 0) {
+    for (int p = 0; p < P; ++p) min_rss[p] = h0_rss;
+    return MMG_OK;
+  }
+  double *dH = nullptr, *dYs = nullptr, *dA = nullptr, *dWt = nullptr, *dv = nullptr, *dones = nullptr;
+  double *dmu = nullptr, *dinv = nullptr, *dmax = nullptr;
+  const int Npad = g->Npad;
+  const int Ppad = (int)round_up(P, 64);
+  MMG_HIP(ctx, hipMalloc(&dH, (size_t)N * N * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dYs, (size_t)N * P * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dA, (size_t)N * N * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dWt, (size_t)P * N * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dv, N * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dones, N * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dmu, g->Mpad * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dinv, g->Mpad * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dmax, Ppad * sizeof(double)));
+  MMG_HIP(ctx, hipMemcpyAsync(dH, Ht, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  MMG_HIP(ctx, hipMemcpyAsync(dYs, Ys, (size_t)N * P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  std::vector<double> ones((size_t)N, 1.0);
+  MMG_HIP(ctx, hipMemcpyAsync(dones, ones.data(), N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  int rc = dgemm_dev(ctx, 1, 0, N, N, N, dH, dH, dA);               // A' = H'H         (t.t = s~' A' s~, :1160,1163)
+  if (rc == MMG_OK) rc = dgemm_dev(ctx, 1, 0, P, N, N, dYs, dH, dWt);  // W' = Ys'H  [P x N] (t.Ys_p = s~ . W_p)
+  if (rc == MMG_OK) rc = dgemm_dev(ctx, 0, 0, N, 1, N, dA, dones, dv); // v = A' 1
+  std::vector<double> v((size_t)N);
+  if (rc == MMG_OK) {
+    hipError_t e = hipMemcpyAsync(v.data(), dv, N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e));
+  }
+  mmg_scan_model pm;
+  mmg_scan_result pr;
+  if (rc == MMG_OK) rc = model_from_device(ctx, pm, N, dA, dv, 4);
+  if (rc == MMG_OK) rc = ensure_result(ctx, pr, g->Mpad);
+  if (rc == MMG_OK) {
+    double c0 = 0.0;
+    for (int i = 0; i < N; ++i) c0 += v[i];
+    hipMemsetAsync(pr.q, 0, g->Mpad * sizeof(unsigned long long), ctx->stream);
+    launch_scan_quad(ctx, g, pm, pr.q);
+    launch_scan_finalize(ctx, g, pm, pr, 1.0, 1, 0.0);              // den = s'A's, dot = s.v, sum = s.1
+    launch_perm_center(ctx, g, pr, c0, dmu, dinv);                  // mu, 1/(s~'A's~)   (:1159)
+    rc = run_perm(ctx, g, N, dWt, P, dinv, dmu, 4, dmax);
+  }
+  std::vector<double> mx((size_t)Ppad, 0.0);
+  if (rc == MMG_OK) {
+    hipError_t e = hipMemcpyAsync(mx.data(), dmax, Ppad * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e));
+  }
+  if (rc == MMG_OK)
+    for (int p = 0; p < P; ++p) min_rss[p] = std::min(h0_rss, yy[p] - mx[p]);   // :1164 running min from h0_rss (:1156)
+  hipStreamSynchronize(ctx->stream);
+  free_model(pm); free_result(pr);
+  hipFree(dH); hipFree(dYs); hipFree(dA); hipFree(dWt); hipFree(dv); hipFree(dones); hipFree(dmu); hipFree(dinv); hipFree(dmax);
+  return rc;
 }
 
 // ------------------------------------------------------------------------- RCCL

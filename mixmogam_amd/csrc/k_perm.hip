@@ -1,8 +1,200 @@
-// k_perm.hip -- EMMAX permutation test GEMM (placeholder until the scan path is parity-green).
+// k_perm.hip -- EMMAX permutation test (replaces the per-SNP multi-RHS lstsq loop of
+// linear_models.py:1157-1164).  For permutation p and SNP m
+//     rss_{m,p} = Ys_p.Ys_p - (t_m.Ys_p)^2 / (t_m.t_m),   t_m = H (s_m - mean(s_m))      (:1159-1163)
+// so  min_m rss_{m,p} = Ys_p.Ys_p - max_m G_{m,p}^2 / tt_m  with
+//     G_{m,p} = s_m.W_p - mu_m * sum(W_p),  W = H'Ys  [N x P],   tt_m = s~' (H'H) s~.
+// tt comes from the scan's quadratic-form GEMM (model H'H); G is the GEMM S . W computed exactly
+// on the int8 matrix cores with W written as 4 balanced base-256 digits per permutation column
+// (per-column scale).  The four digit rows of one permutation sit in the four 32-row MFMA tiles
+// of ONE wave, so the digits are recombined in registers (exact int64), squared, scaled by
+// 1/tt_m and max-reduced over SNPs without ever leaving the chip; one 64-bit atomicMax per
+// (permutation, workgroup) at the end (order independent -> reproducible).
+#include <algorithm>
+#include "gemm_i8_core.h"
 #include "mmg_internal.h"
+
 namespace mmg {
-int run_perm(mmg_ctx* ctx, const mmg_geno*, int32_t, const double*, int32_t, const double*, const double*, int,
-             double*) {
-  return set_err(ctx, MMG_E_STATE, "perm kernel not built yet");
+
+constexpr int PERM_TILE = 64;                       // permutations per workgroup tile
+constexpr int PERM_LDS_EXTRA = PERM_TILE * 16;      // step + csum per permutation (fp64)
+
+__global__ void perm_center_kernel(const double* __restrict__ den, const double* __restrict__ dot,
+                                   const double* __restrict__ sum, int64_t M, int64_t Mpad, double invN, double c0,
+                                   double* __restrict__ mu, double* __restrict__ inv) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= Mpad) return;
+  double u = 0.0, iv = 0.0;
+  if (m < M) {
+    u = sum[m] * invN;
+    const double tt = den[m] - 2.0 * u * dot[m] + u * u * c0;
+    if (tt > 1e-7 * fabs(den[m]) && tt > 0.0) iv = 1.0 / tt;
+  }
+  mu[m] = u;
+  inv[m] = iv;
 }
+
+void launch_perm_center(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_result& r, double c0, double* d_mu,
+                        double* d_inv) {
+  hipLaunchKernelGGL(perm_center_kernel, dim3((unsigned)((g->Mpad + 255) / 256)), dim3(256), 0, ctx->stream, r.den,
+                     r.dot, r.sum, g->M, g->Mpad, 1.0 / (double)g->N, c0, d_mu, d_inv);
+}
+
+// one wave per permutation row: max |W_p|, sum W_p
+__global__ __launch_bounds__(256) void perm_rowstat_kernel(const double* __restrict__ Wt, int32_t N, int32_t P,
+                                                           double* __restrict__ step, double* __restrict__ csum) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= P) return;
+  double mx = 0.0, s = 0.0;
+  for (int k = lane; k < N; k += 64) {
+    const double v = Wt[(int64_t)p * N + k];
+    mx = fmax(mx, fabs(v));
+    s += v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = fmax(mx, __shfl_xor(mx, o));
+    s += __shfl_xor(s, o);
+  }
+  if (lane == 0) {
+    if (!(mx > 0.0)) mx = 1.0;
+    step[p] = mx / 1073741824.0;       // |rint(W/step)| <= 2^30: four balanced digits fit int8
+    csum[p] = s;
+  }
+}
+
+// Wq [nPT][256][Npad]: row wmi*128 + d*32 + pl of tile pt holds digit d of permutation pt*64 + wmi*32 + pl
+__global__ void perm_quantize_kernel(const double* __restrict__ Wt, int32_t N, int32_t Npad, int32_t P,
+                                     const double* __restrict__ step, int8_t* __restrict__ Wq) {
+  const int chunks = Npad >> 4;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Ppad = (P + PERM_TILE - 1) / PERM_TILE * PERM_TILE;
+  if (gid >= (int64_t)Ppad * chunks) return;
+  const int p = (int)(gid / chunks), c = (int)(gid % chunks);
+  uint32_t out[4][4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[d][e] = 0;
+  if (p < P) {
+    const double inv = 1.0 / step[p];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int k = c * 16 + e;
+      long long Z = 0;
+      if (k < N) Z = __double2ll_rn(Wt[(int64_t)p * N + k] * inv);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const long long z = ((Z + 128) & 255) - 128;
+        Z = (Z - z) >> 8;
+        out[d][e >> 2] |= ((uint32_t)(z & 0xff)) << (8 * (e & 3));
+      }
+    }
+  }
+  const int pt = p / PERM_TILE, wmi = (p % PERM_TILE) / 32, pl = p % 32;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const int row = wmi * 128 + d * 32 + pl;
+    *(uint4*)(Wq + ((int64_t)pt * TM + row) * Npad + c * 16) = make_uint4(out[d][0], out[d][1], out[d][2], out[d][3]);
+  }
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void perm_gemm_kernel(
+    const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Wq, int64_t ldW, int nPT,
+    int nch, int sb_per_chunk, int nks, const double* __restrict__ step, const double* __restrict__ csum,
+    const double* __restrict__ mu, const double* __restrict__ inv, unsigned long long* __restrict__ maxstat) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int b = blockIdx.x;
+  const int x = b & 7, i = b >> 3;
+  const int pt = x + 8 * (i / nch), chunk = i % nch;
+  if (pt >= nPT) return;
+  const int sb0 = chunk * sb_per_chunk;
+  const int sb1 = min(sb0 + sb_per_chunk, nSb);
+  if (sb0 >= sb1) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3, h = lane >> 5, r = lane & 31;
+  // per-permutation scale and column sum for this tile -> LDS (behind the staging buffers)
+  double* ex = (double*)(lds + LDS_BYTES);
+  if (threadIdx.x < PERM_TILE) {
+    ex[threadIdx.x] = step[pt * PERM_TILE + threadIdx.x];
+    ex[PERM_TILE + threadIdx.x] = csum[pt * PERM_TILE + threadIdx.x];
+  }
+  __syncthreads();
+  const int8_t* P = Wq + (int64_t)pt * TM * ldW;
+  double maxv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) maxv[e] = 0.0;
+  for (int sb = sb0; sb < sb1; ++sb) {
+    const int8_t* Q = S + (int64_t)sb * TN * ldS;
+    v16i acc[4][2];
+    gemm_tile_i8(P, ldW, Q, ldS, 0, nks, lds, acc);
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+      const int64_t snp = (int64_t)sb * TN + wn * 64 + nn * 32 + r;
+      const double u = mu[snp], iv = inv[snp];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int pl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const long long gi = (long long)acc[0][nn][e] + ((long long)acc[1][nn][e] << 8) +
+                             ((long long)acc[2][nn][e] << 16) + ((long long)acc[3][nn][e] << 24);
+        const double G = fma((double)gi, ex[pl], -u * ex[PERM_TILE + pl]);
+        maxv[e] = fmax(maxv[e], G * G * iv);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    double v = maxv[e];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    if (r == 0) {
+      const int p = pt * PERM_TILE + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      atomicMax(maxstat + p, (unsigned long long)__double_as_longlong(v));   // v >= 0: bit order == value order
+    }
+  }
+}
+
+int run_perm(mmg_ctx* ctx, const mmg_geno* g, int32_t N, const double* dWt, int32_t P, const double* d_inv,
+             const double* d_mu, int ndigits, double* d_maxstat) {
+  (void)ndigits;
+  const int Npad = g->Npad;
+  const int nPT = (P + PERM_TILE - 1) / PERM_TILE;
+  const int Ppad = nPT * PERM_TILE;
+  const int nSb = (int)(g->Mpad / TN);
+  double *dstep = nullptr, *dcsum = nullptr;
+  int8_t* Wq = nullptr;
+  MMG_HIP(ctx, hipMalloc(&dstep, Ppad * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&dcsum, Ppad * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&Wq, (size_t)nPT * TM * Npad));
+  MMG_HIP(ctx, hipMemsetAsync(dstep, 0, Ppad * sizeof(double), ctx->stream));
+  MMG_HIP(ctx, hipMemsetAsync(dcsum, 0, Ppad * sizeof(double), ctx->stream));
+  MMG_HIP(ctx, hipMemsetAsync(d_maxstat, 0, Ppad * sizeof(double), ctx->stream));
+  hipLaunchKernelGGL(perm_rowstat_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, ctx->stream, dWt, N, P, dstep,
+                     dcsum);
+  {
+    const int64_t total = (int64_t)Ppad * (Npad >> 4);
+    hipLaunchKernelGGL(perm_quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dWt, N,
+                       Npad, P, dstep, Wq);
+  }
+  MMG_HIP(ctx, hipGetLastError());
+  // grid: permutation tiles x SNP-block chunks, ~4 workgroups per CU in flight over the launch
+  const int rounds = (nPT + 7) / 8;
+  int nch = std::max(1, (4 * 256) / (8 * rounds));
+  nch = std::min(nch, nSb);
+  const int per = (nSb + nch - 1) / nch;
+  nch = (nSb + per - 1) / per;
+  MMG_HIP(ctx, hipFuncSetAttribute((const void*)perm_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   LDS_BYTES + PERM_LDS_EXTRA));
+  {
+    EvScope ev(ctx, EV_PERM);
+    hipLaunchKernelGGL(perm_gemm_kernel, dim3((unsigned)(8 * rounds * nch)), dim3(NTHREADS), LDS_BYTES + PERM_LDS_EXTRA,
+                       ctx->stream, g->d, (int64_t)Npad, nSb, Wq, (int64_t)Npad, nPT, nch, per, Npad / BK, dstep, dcsum,
+                       d_mu, d_inv, (unsigned long long*)d_maxstat);
+  }
+  MMG_HIP(ctx, hipGetLastError());
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipFree(dstep); hipFree(dcsum); hipFree(Wq);
+  return MMG_OK;
+}
+
 }  // namespace mmg

@@ -93,7 +93,10 @@ void launch_snp_dot(mmg_ctx*, const mmg_geno*, const double* v /*[Npad] dev*/, d
 void launch_f_sf(mmg_ctx*, const double* F, int64_t n, int32_t df2, double lnbeta, double* p);
 
 // ---- k_perm.hip
-int run_perm(mmg_ctx*, const mmg_geno*, int32_t N, const double* dW /*[Npad x P] dev*/, int32_t P,
-             const double* d_invden, const double* d_mu, int ndigits, double* d_maxstat);
+// mu[m] = sum/N, inv[m] = 1/(den - 2 mu dot + mu^2 c0) (0 for SNPs that are constant after centring)
+void launch_perm_center(mmg_ctx*, const mmg_geno*, const mmg_scan_result&, double c0, double* d_mu, double* d_inv);
+// d_maxstat[p] = max_m (s~_m . W_p)^2 * inv[m];  dWt: device [P x N] row-major fp64
+int run_perm(mmg_ctx*, const mmg_geno*, int32_t N, const double* dWt, int32_t P, const double* d_inv,
+             const double* d_mu, int ndigits, double* d_maxstat);
 
 }  // namespace mmg

@@ -103,6 +103,8 @@ def run_case(mods, snps, y, cof, nperm, perm_seed):
         pr = quiet(lmm3._emmax_permutations_, [s.astype(np.float64) for s in snps], k_ibs,
                    reml['H_sqrt_inv'], num_perm=nperm)
         out['perm_idx'] = np.asarray(perm_idx, dtype=np.int32)
+        # H_sqrt_inv is an INPUT of _emmax_permutations_ (:1125) and its row signs are LAPACK's choice
+        out['perm_H'] = np.asarray(reml['H_sqrt_inv'], dtype=np.float64)
         out['perm_min_ps'] = np.asarray(pr['min_ps'], dtype=np.float64).reshape(-1)
         out['perm_max_f_stats'] = np.asarray(pr['max_f_stats'], dtype=np.float64).reshape(-1)
     return out
@@ -138,7 +140,7 @@ def main():
                     c = (v - 0.5) * 2 * len(snps)
                     assert np.abs(c - np.rint(c)).max() < 1e-6
                     k, v = 'ibs_counts', np.rint(c).astype(np.int32)
-                if mode == 'lit' and k == 'ibd_scaled':
+                if mode == 'lit' and k in ('ibd_scaled', 'perm_H'):
                     v = v.astype(np.float32)
                 data['%s_%s' % (mode, k)] = v
         # p-value known-answer grid (scipy.stats.f.sf as the reference calls it)

@@ -33,9 +33,9 @@ def test_header_symbols_exported_and_bound(built):
     assert lib.mmg_version() >= 100
 
 
-def test_code_object_targets_gfx950(built):
+def test_code_object_targets_gfx950(built, tmp_path):
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", built.LIB_PATH],
-                         capture_output=True, text=True)
+                         capture_output=True, text=True, cwd=str(tmp_path))
     txt = out.stdout + out.stderr
     if "gfx" in txt:
         assert "gfx950" in txt
