@@ -7,13 +7,18 @@
 //   waves        2 (M) x 4 (N); wave tile 128 x 64 = 4 x 2 MFMA tiles of 32x32
 //   MFMA         v_mfma_i32_32x32x32_i8 (16 B of k per lane per operand)
 //   K step       BK = 128 bytes; LDS: 2 buffers x (P tile 32 KiB + Q tile 32 KiB) = 128 KiB
-//   staging      global_load_lds_dwordx4 (LDS-DMA, 1 KiB = 8 rows x 128 B per wave-instruction);
-//                the LDS image is lane-linear, the 16-B chunk swizzle c ^ ((row>>1)&7) is applied
-//                to the per-lane SOURCE address and again on the ds_read_b128 side
+//   staging      buffer_load_dwordx4 ... lds (LDS-DMA, 1 KiB = 8 rows x 128 B per wave-instruction):
+//                wave-uniform descriptor + SGPR offset (k, row group) + ONE per-lane VGPR offset that
+//                is constant for the whole tile, so a piece costs two SALU ops and one VMEM issue.
+//                The LDS image is lane-linear; the 16-B chunk swizzle c ^ ((row>>1)&7) is applied
+//                to the per-lane SOURCE offset and again on the ds_read_b128 side
 //                (conflict-free for the 16-lane ds_read_b128 groups: rows distinct mod 16).
 //
 // C/D layout of the 32x32 MFMA (dtype independent): lane l holds column n = l & 31 and rows
 // m = (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5), reg = 0..15.
+//
+// Addressing limit: 256 * ld < 2^31 bytes per operand tile (32-bit buffer offsets); callers chunk
+// the contraction axis accordingly (kinship: <= 4M SNPs per pass).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,23 +33,39 @@ constexpr int TILE_BYTES = TM * BK;            // 32 KiB per operand tile
 constexpr int BUF_BYTES = 2 * TILE_BYTES;      // P + Q
 constexpr int LDS_BYTES = 2 * BUF_BYTES;       // double buffered: 128 KiB
 constexpr int NTHREADS = 512;
+constexpr int64_t MAX_LD = (int64_t(1) << 31) / 256 - 1;
 
 #define MMG_AS1 __attribute__((address_space(1)))
 #define MMG_AS3 __attribute__((address_space(3)))
 
-// Stage rows [0,256) x bytes [k0, k0+128) of a row-major int8 operand (leading dimension ld
-// bytes, 16-B aligned rows) into a 32 KiB LDS tile.  Each wave moves 4 groups of 8 rows.
-__device__ __forceinline__ void stage_tile(const int8_t* __restrict__ g, int64_t ld, int64_t k0,
-                                           char* lds_tile, int wave, int lane) {
+// Per-operand staging state of one wave: buffer descriptor of the tile's 256 rows and the two
+// per-lane byte offsets (even / odd 8-row group: the swizzle differs by chunk ^ 4).
+struct StageOp {
+  __amdgpu_buffer_rsrc_t rs;
+  int v_even, v_odd;   // lane offsets (bytes) for row groups wave*4 + {0,2} / {1,3}
+  int ld8;             // 8 * ld
+};
+
+__device__ __forceinline__ StageOp make_stage_op(const int8_t* base, int64_t ld, int wave, int lane) {
+  StageOp s;
+  s.rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+  const int base_row = wave * 32 + (lane >> 3);
+  const int c0 = (lane & 7) ^ ((base_row >> 1) & 7);
+  s.v_even = base_row * (int)ld + c0 * 16;
+  s.v_odd = base_row * (int)ld + (c0 ^ 4) * 16;
+  s.ld8 = 8 * (int)ld;
+  return s;
+}
+
+// piece i in 0..3: rows (wave*4 + i)*8 .. +8 of the operand tile, bytes [k0, k0+128)
+__device__ __forceinline__ void stage_piece(const StageOp& s, int k0, char* lds_tile, int wave, int i) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rs, (MMG_AS3 void*)(lds_tile + (wave * 4 + i) * 1024), 16,
+                                           (i & 1) ? s.v_odd : s.v_even, k0 + i * s.ld8, 0, 0);
+}
+
+__device__ __forceinline__ void stage_tile(const StageOp& s, int k0, char* lds_tile, int wave) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int grp = wave * 4 + i;
-    const int row = grp * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    const int8_t* src = g + (int64_t)row * ld + k0 + c * 16;
-    __builtin_amdgcn_global_load_lds((const MMG_AS1 void*)src, (MMG_AS3 void*)(lds_tile + grp * 1024),
-                                     16, 0, 0);
-  }
+  for (int i = 0; i < 4; ++i) stage_piece(s, k0, lds_tile, wave, i);
 }
 
 __device__ __forceinline__ v4i lds_frag(const char* tile, int row, int chunk) {
@@ -71,10 +92,64 @@ __device__ __forceinline__ void mma_kstep(const char* buf, int wm, int wn, int l
   }
 }
 
+// ---- 16x16x64 MFMA flavour of the same wave tile (128 x 64 = 8 x 4 tiles of 16 x 16) ----------
+// A/B: lane l holds row l&15, k = 16*(l>>4) + j (j < 16) of a 64-byte k slice; C/D: column l&15,
+// rows 4*(l>>4) + reg (reg < 4).  Same LDS bytes per K step as the 32x32x32 form.
+__device__ __forceinline__ void mma_kstep_16(const char* buf, int wm, int wn, int lane, v4i (&acc)[8][4]) {
+  const char* pt = buf;
+  const char* qt = buf + TILE_BYTES;
+  const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    v4i b[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) b[n] = lds_frag(qt, wn * 64 + n * 16 + r, 4 * kk + g);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const v4i a = lds_frag(pt, wm * 128 + m * 16 + r, 4 * kk + g);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b[n], acc[m][n], 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ void gemm_tile_i8_16(const int8_t* __restrict__ P, int64_t ldP,
+                                                const int8_t* __restrict__ Q, int64_t ldQ, int ks0, int ks1,
+                                                char* lds, v4i (&acc)[8][4]) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[m][n][i] = 0;
+  if (ks1 <= ks0) return;
+  const StageOp sp = make_stage_op(P, ldP, wave, lane);
+  const StageOp sq = make_stage_op(Q, ldQ, wave, lane);
+  stage_tile(sp, ks0 * BK, lds, wave);
+  stage_tile(sq, ks0 * BK, lds + TILE_BYTES, wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int ks = ks0; ks < ks1; ++ks) {
+    char* nb = lds + (cur ^ 1) * BUF_BYTES;
+    if (ks + 1 < ks1) {
+      stage_tile(sp, (ks + 1) * BK, nb, wave);
+      stage_tile(sq, (ks + 1) * BK, nb + TILE_BYTES, wave);
+    }
+    mma_kstep_16(lds + cur * BUF_BYTES, wm, wn, lane, acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
 // Full K loop over k-steps [ks0, ks1) (units of BK bytes).  P / Q point at row 0 of the tile's
 // row range.  On return every wave has passed the final barrier (LDS free for reuse).
 // ABLATE (timing experiments only; results are wrong unless 0): 1 = no staging inside the loop,
-// 2 = staging only (no LDS reads, no MFMA), 3 = MFMA on registers only (no LDS reads in loop).
+// 2 = staging only (no LDS reads, no MFMA), 3 = MFMA on registers only.
 template <int ABLATE = 0>
 __device__ __forceinline__ void gemm_tile_i8(const int8_t* __restrict__ P, int64_t ldP,
                                              const int8_t* __restrict__ Q, int64_t ldQ,
@@ -89,8 +164,10 @@ __device__ __forceinline__ void gemm_tile_i8(const int8_t* __restrict__ P, int64
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][n][i] = 0;
   if (ks1 <= ks0) return;
-  stage_tile(P, ldP, (int64_t)ks0 * BK, lds, wave, lane);
-  stage_tile(Q, ldQ, (int64_t)ks0 * BK, lds + TILE_BYTES, wave, lane);
+  const StageOp sp = make_stage_op(P, ldP, wave, lane);
+  const StageOp sq = make_stage_op(Q, ldQ, wave, lane);
+  stage_tile(sp, ks0 * BK, lds, wave);
+  stage_tile(sq, ks0 * BK, lds + TILE_BYTES, wave);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
@@ -102,10 +179,10 @@ __device__ __forceinline__ void gemm_tile_i8(const int8_t* __restrict__ P, int64
     for (int n = 0; n < 2; ++n) fb[n] = lds_frag(lds + TILE_BYTES, wn * 64 + n * 32 + (lane & 31), lane >> 5);
   }
   for (int ks = ks0; ks < ks1; ++ks) {
+    char* nb = lds + (cur ^ 1) * BUF_BYTES;
     if (ks + 1 < ks1 && ABLATE != 1 && ABLATE != 3) {
-      char* nb = lds + (cur ^ 1) * BUF_BYTES;
-      stage_tile(P, ldP, (int64_t)(ks + 1) * BK, nb, wave, lane);
-      stage_tile(Q, ldQ, (int64_t)(ks + 1) * BK, nb + TILE_BYTES, wave, lane);
+      stage_tile(sp, (ks + 1) * BK, nb, wave);
+      stage_tile(sq, (ks + 1) * BK, nb + TILE_BYTES, wave);
     }
     if (ABLATE == 3) {
 #pragma unroll

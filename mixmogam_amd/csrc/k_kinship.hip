@@ -74,16 +74,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void kinship_f32_kernel(const int8_t* 
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
-  stage_tile(P, Mk, (int64_t)job.ks0 * BK, lds, wave, lane);
-  stage_tile(Q, Mk, (int64_t)job.ks0 * BK, lds + TILE_BYTES, wave, lane);
+  const StageOp sp = make_stage_op(P, Mk, wave, lane);
+  const StageOp sq = make_stage_op(Q, Mk, wave, lane);
+  stage_tile(sp, job.ks0 * BK, lds, wave);
+  stage_tile(sq, job.ks0 * BK, lds + TILE_BYTES, wave);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
   for (int ks = job.ks0; ks < job.ks1; ++ks) {
     if (ks + 1 < job.ks1) {
       char* nb = lds + (cur ^ 1) * BUF_BYTES;
-      stage_tile(P, Mk, (int64_t)(ks + 1) * BK, nb, wave, lane);
-      stage_tile(Q, Mk, (int64_t)(ks + 1) * BK, nb + TILE_BYTES, wave, lane);
+      stage_tile(sp, (ks + 1) * BK, nb, wave);
+      stage_tile(sq, (ks + 1) * BK, nb + TILE_BYTES, wave);
     }
     const char* pt = lds + cur * BUF_BYTES;
     const char* qt = pt + TILE_BYTES;

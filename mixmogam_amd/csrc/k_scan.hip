@@ -16,7 +16,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <string>
 #include "gemm_i8_core.h"
+#include "gemm_i8_ring.h"
+#include "gemm_i8_w4.h"
 #include "mmg_internal.h"
 
 namespace mmg {
@@ -132,6 +135,173 @@ __global__ __launch_bounds__(NTHREADS, 2) void scan_quad_kernel(
   }
 }
 
+// 16x16x64-MFMA flavour of scan_quad_kernel (same tiles, same exact integers).
+__global__ __launch_bounds__(NTHREADS, 2) void scan_quad16_kernel(
+    const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Bq, int64_t ldB,
+    int64_t digit_stride, const int* __restrict__ job_off, const int2* __restrict__ jobs, int AS,
+    unsigned long long* __restrict__ q) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int b = blockIdx.x;
+  const int x = b & 7, i = b >> 3;
+  const int cohort = i >> 5, within = i & 31;
+  const int a = within % AS, grp = within / AS;
+  const int sb = (cohort * 8 + x) * AS + a;
+  if (sb >= nSb) return;
+  const int j0 = job_off[grp], j1 = job_off[grp + 1];
+  if (j1 <= j0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3, g = lane >> 4, r = lane & 15;
+  const int8_t* Q = S + (int64_t)sb * TN * ldS;
+  unsigned long long qacc[4] = {0ull, 0ull, 0ull, 0ull};
+  for (int jj = j0; jj < j1; ++jj) {
+    const int2 jb = jobs[jj];
+    const int d = jb.x, J = jb.y;
+    const int8_t* P = Bq + (int64_t)d * digit_stride + (int64_t)J * TM * ldB;
+    v4i acc[8][4];
+    gemm_tile_i8_16(P, ldB, Q, ldS, 0, 2 * (J + 1), lds, acc);
+    // lane holds SNP column wn*64 + nn*16 + r and rows j = wm*128 + m*16 + 4*g + reg
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) {
+      const int8_t* srow = Q + (int64_t)(wn * 64 + nn * 16 + r) * ldS + J * TM + wm * 128 + 4 * g;
+      long long part = 0;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int wd = *(const int*)(srow + m * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          part += (long long)acc[m][nn][e] * (long long)(int)(int8_t)((wd >> (8 * e)) & 0xff);
+      }
+      qacc[nn] += ((unsigned long long)part) << (8 * d);
+    }
+  }
+#pragma unroll
+  for (int nn = 0; nn < 4; ++nn) {
+    unsigned long long v = qacc[nn];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (g == 0) atomicAdd(q + (int64_t)sb * TN + wn * 64 + nn * 16 + r, v);
+  }
+}
+
+// Second-generation mainloop: the workgroup's jobs form one flattened K-step pipeline over a
+// 4-slot LDS ring (gemm_i8_ring.h).  Same arithmetic, same exact integer results.
+template <int PINGPONG>
+__global__ __launch_bounds__(NTHREADS, 2) void scan_quad_ring_kernel(
+    const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Bq, int64_t ldB,
+    int64_t digit_stride, const int* __restrict__ job_off, const int2* __restrict__ jobs, int AS,
+    unsigned long long* __restrict__ q) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int b = blockIdx.x;
+  const int x = b & 7, i = b >> 3;
+  const int cohort = i >> 5, within = i & 31;
+  const int a = within % AS, grp = within / AS;
+  const int sb = (cohort * 8 + x) * AS + a;
+  if (sb >= nSb) return;
+  const int j0 = job_off[grp], j1 = job_off[grp + 1];
+  if (j1 <= j0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3, h = lane >> 5, r = lane & 31;
+  const int8_t* Q = S + (int64_t)sb * TN * ldS;
+  unsigned long long qacc[2] = {0ull, 0ull};
+  // job descriptors -> LDS (behind the ring) so that the pipeline never waits on a VMEM load for them
+  int2* jl = (int2*)(lds + LDS_BYTES);
+  for (int t = threadIdx.x; t < j1 - j0; t += NTHREADS) jl[t] = jobs[j0 + t];
+  __syncthreads();
+  auto tile = [&](int t) {
+    const int2 jb = jl[t];
+    TileDesc d;
+    d.P = Bq + (int64_t)jb.x * digit_stride + (int64_t)jb.y * TM * ldB;
+    d.Q = Q;
+    d.nks = (PINGPONG == 2 ? 2 : 4) * (jb.y + 1);
+    return d;
+  };
+  auto epi = [&](int t, v16i (&acc)[4][2]) {
+    const int2 jb = jl[t];
+    const int d = jb.x, J = jb.y;
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+      const int8_t* srow = Q + (int64_t)(wn * 64 + nn * 32 + r) * ldS + J * TM + wm * 128 + 4 * h;
+      long long part = 0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int wd = *(const int*)(srow + m * 32 + 8 * g4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            part += (long long)acc[m][nn][g4 * 4 + e] * (long long)(int)(int8_t)((wd >> (8 * e)) & 0xff);
+        }
+      qacc[nn] += ((unsigned long long)part) << (8 * d);
+    }
+  };
+  if (PINGPONG == 1) run_tiles_pingpong(j1 - j0, ldB, ldS, lds, tile, epi);
+  else if (PINGPONG == 2) run_tiles_flat2(j1 - j0, ldB, ldS, lds, tile, epi);
+  else run_tiles_ring(j1 - j0, ldB, ldS, lds, tile, epi);
+#pragma unroll
+  for (int nn = 0; nn < 2; ++nn) {
+    unsigned long long v = qacc[nn];
+    v += __shfl_xor(v, 32);
+    if (h == 0) atomicAdd(q + (int64_t)sb * TN + wn * 64 + nn * 32 + r, v);
+  }
+}
+
+// Experiment: 4 waves per workgroup, 128 x 128 wave tiles (gemm_i8_w4.h).
+__global__ __launch_bounds__(W4_THREADS, 1) void scan_quad_w4_kernel(
+    const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Bq, int64_t ldB,
+    int64_t digit_stride, const int* __restrict__ job_off, const int2* __restrict__ jobs, int AS,
+    unsigned long long* __restrict__ q) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int b = blockIdx.x;
+  const int x = b & 7, i = b >> 3;
+  const int cohort = i >> 5, within = i & 31;
+  const int a = within % AS, grp = within / AS;
+  const int sb = (cohort * 8 + x) * AS + a;
+  if (sb >= nSb) return;
+  const int j0 = job_off[grp], j1 = job_off[grp + 1];
+  if (j1 <= j0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;
+  const int8_t* Q = S + (int64_t)sb * TN * ldS;
+  unsigned long long qacc[4] = {0ull, 0ull, 0ull, 0ull};
+  int2* jl = (int2*)(lds + LDS_BYTES);
+  for (int t = threadIdx.x; t < j1 - j0; t += W4_THREADS) jl[t] = jobs[j0 + t];
+  __syncthreads();
+  auto tile = [&](int t) {
+    const int2 jb = jl[t];
+    TileDesc d;
+    d.P = Bq + (int64_t)jb.x * digit_stride + (int64_t)jb.y * TM * ldB;
+    d.Q = Q;
+    d.nks = 2 * (jb.y + 1);
+    return d;
+  };
+  auto epi = [&](int t, v16i (&acc)[4][4]) {
+    const int2 jb = jl[t];
+    const int d = jb.x, J = jb.y;
+#pragma unroll
+    for (int nn = 0; nn < 4; ++nn) {
+      const int8_t* srow = Q + (int64_t)(wn * 128 + nn * 32 + r) * ldS + J * TM + wm * 128 + 4 * h;
+      long long part = 0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int wd = *(const int*)(srow + m * 32 + 8 * g4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            part += (long long)acc[m][nn][g4 * 4 + e] * (long long)(int)(int8_t)((wd >> (8 * e)) & 0xff);
+        }
+      qacc[nn] += ((unsigned long long)part) << (8 * d);
+    }
+  };
+  run_tiles_w4(j1 - j0, ldB, ldS, lds, tile, epi);
+#pragma unroll
+  for (int nn = 0; nn < 4; ++nn) {
+    unsigned long long v = qacc[nn];
+    v += __shfl_xor(v, 32);
+    if (h == 0) atomicAdd(q + (int64_t)sb * TN + wn * 128 + nn * 32 + r, v);
+  }
+}
+
 void launch_scan_quad(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, unsigned long long* q) {
   const int nSb = (int)(g->Mpad / TN);
   const int per = 8 * md.AS;
@@ -145,6 +315,45 @@ void launch_scan_quad(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md,
                        g->d, (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad, (int64_t)md.Npad * md.Npad,         \
                        md.job_off, md.jobs, md.AS, q);                                                            \
   } while (0)
+  const char* kv = std::getenv("MMG_SCAN_KERNEL");
+  if (ablate == 0 && kv && std::string(kv) == "w4") {
+    const int lds_bytes = LDS_BYTES + 8 * std::max(1, md.njobs);
+    hipFuncSetAttribute((const void*)scan_quad_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(scan_quad_w4_kernel, dim3((unsigned)(ncoh * 256)), dim3(W4_THREADS), lds_bytes, ctx->stream,
+                       g->d, (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad, (int64_t)md.Npad * md.Npad,
+                       md.job_off, md.jobs, md.AS, q);
+    return;
+  }
+  if (ablate == 0 && kv && std::string(kv) == "m16") {
+    hipFuncSetAttribute((const void*)scan_quad16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipLaunchKernelGGL(scan_quad16_kernel, dim3((unsigned)(ncoh * 256)), dim3(NTHREADS), LDS_BYTES, ctx->stream,
+                       g->d, (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad, (int64_t)md.Npad * md.Npad,
+                       md.job_off, md.jobs, md.AS, q);
+    return;
+  }
+  if (ablate == 0 && kv && std::string(kv) == "flat") {
+    const int lds_bytes = LDS_BYTES + 8 * std::max(1, md.njobs);
+    hipFuncSetAttribute((const void*)scan_quad_ring_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(scan_quad_ring_kernel<2>, dim3((unsigned)(ncoh * 256)), dim3(NTHREADS), lds_bytes, ctx->stream,
+                       g->d, (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad, (int64_t)md.Npad * md.Npad,
+                       md.job_off, md.jobs, md.AS, q);
+    return;
+  }
+  if (ablate == 0 && kv && (std::string(kv) == "ring" || std::string(kv) == "pp")) {
+    const int lds_bytes = LDS_BYTES + 8 * std::max(1, md.njobs);
+    if (std::string(kv) == "ring") {
+      hipFuncSetAttribute((const void*)scan_quad_ring_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      hipLaunchKernelGGL(scan_quad_ring_kernel<0>, dim3((unsigned)(ncoh * 256)), dim3(NTHREADS), lds_bytes, ctx->stream,
+                         g->d, (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad, (int64_t)md.Npad * md.Npad,
+                         md.job_off, md.jobs, md.AS, q);
+    } else {
+      hipFuncSetAttribute((const void*)scan_quad_ring_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+      hipLaunchKernelGGL(scan_quad_ring_kernel<1>, dim3((unsigned)(ncoh * 256)), dim3(NTHREADS), lds_bytes, ctx->stream,
+                         g->d, (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad, (int64_t)md.Npad * md.Npad,
+                         md.job_off, md.jobs, md.AS, q);
+    }
+    return;
+  }
   switch (ablate) {
     case 1: MMG_LAUNCH_QUAD(1); break;
     case 2: MMG_LAUNCH_QUAD(2); break;
@@ -202,41 +411,59 @@ void launch_f_sf(mmg_ctx* ctx, const double* F, int64_t n, int32_t df2, double l
 }
 
 // ------------------------------------------------------------------ finalize
-// One wave handles FR SNP rows: streams their genotype bytes once (16 B per lane per row),
-// keeping the matching 16 entries of w and diag(A) in registers for all 8 rows.
-constexpr int FR = 4;   // SNP rows per wave
+// HBM-bound.  A block of 4 waves handles 32 SNP rows (8 per wave).  Per 1024-column chunk the block
+// stages w and diag(A) once into LDS (lane-interleaved 16-byte units: conflict-free ds_read_b128)
+// and every lane streams its 16 genotype bytes of each of its wave's 8 rows with one 16-byte load.
+constexpr int FR = 8;                      // SNP rows per wave
+constexpr int FIN_ROWS = 4 * FR;           // per block
 __global__ __launch_bounds__(256, 2) void scan_finalize_kernel(
     const int8_t* __restrict__ S, int64_t ldS, int64_t M, int32_t Npad, const double* __restrict__ w,
     const double* __restrict__ diag, const unsigned long long* __restrict__ q, double step, double h0_rss, double nu,
     double lnbeta, double* __restrict__ rss, double* __restrict__ Fst, double* __restrict__ pv,
     double* __restrict__ dotv, double* __restrict__ denv, double* __restrict__ sumv) {
-  const int lane = threadIdx.x & 63;
-  const int64_t m0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * FR;
-  if (m0 >= M) return;
+  __shared__ double2 lw[8 * 64], ldg[8 * 64];          // [unit e>>1][lane]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int64_t m0 = (int64_t)blockIdx.x * FIN_ROWS + (tid >> 6) * FR;
   double dw[FR], dd[FR];
   int sm[FR];
 #pragma unroll
   for (int rr = 0; rr < FR; ++rr) { dw[rr] = 0.0; dd[rr] = 0.0; sm[rr] = 0; }
-  for (int c = lane; c < (Npad >> 4); c += 64) {
-    double wv[16], dv[16];
-#pragma unroll
-    for (int e = 0; e < 16; e += 2) {
-      const double2 t = *(const double2*)(w + c * 16 + e);
-      const double2 u = *(const double2*)(diag + c * 16 + e);
-      wv[e] = t.x; wv[e + 1] = t.y; dv[e] = u.x; dv[e + 1] = u.y;
+  const int nchunks = Npad >> 4;
+  for (int c0 = 0; c0 < nchunks; c0 += 64) {
+    __syncthreads();
+    {
+      const int k = c0 * 16 + tid * 4;                  // 4 consecutive columns per thread
+      double2 w0 = make_double2(0, 0), w1 = w0, d0 = w0, d1 = w0;
+      if (k < Npad) {
+        w0 = *(const double2*)(w + k); w1 = *(const double2*)(w + k + 2);
+        d0 = *(const double2*)(diag + k); d1 = *(const double2*)(diag + k + 2);
+      }
+      const int l = tid >> 2, u = (tid & 3) * 2;        // owning lane, first 16-byte unit
+      lw[u * 64 + l] = w0; lw[(u + 1) * 64 + l] = w1;
+      ldg[u * 64 + l] = d0; ldg[(u + 1) * 64 + l] = d1;
     }
+    __syncthreads();
+    const int c = c0 + lane;
+    if (c < nchunks) {
+      double wv[16], dv[16];
 #pragma unroll
-    for (int rr = 0; rr < FR; ++rr) {
-      // rows beyond M are inside the padded store (Mpad is a multiple of 256) and hold zeros
-      const uint4 v = *(const uint4*)(S + (m0 + rr) * ldS + c * 16);
-      const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+      for (int u = 0; u < 8; ++u) {
+        const double2 t = lw[u * 64 + lane], x = ldg[u * 64 + lane];
+        wv[2 * u] = t.x; wv[2 * u + 1] = t.y; dv[2 * u] = x.x; dv[2 * u + 1] = x.y;
+      }
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int xi = (int)(int8_t)((wds[e >> 2] >> (8 * (e & 3))) & 0xff);
-        const double xd = (double)xi;
-        dw[rr] = fma(xd, wv[e], dw[rr]);
-        dd[rr] = fma(xd * xd, dv[e], dd[rr]);
-        sm[rr] += xi;
+      for (int rr = 0; rr < FR; ++rr) {
+        // rows beyond M are inside the padded store (Mpad is a multiple of 256) and hold zeros
+        const uint4 v = *(const uint4*)(S + (m0 + rr) * ldS + c * 16);
+        const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int xi = (int)(int8_t)((wds[e >> 2] >> (8 * (e & 3))) & 0xff);
+          const double xd = (double)xi;
+          dw[rr] = fma(xd, wv[e], dw[rr]);
+          dd[rr] = fma(xd * xd, dv[e], dd[rr]);
+          sm[rr] += xi;
+        }
       }
     }
   }
@@ -279,11 +506,12 @@ __global__ __launch_bounds__(256, 2) void snp_dot_kernel(const int8_t* __restric
                                                          int32_t Npad, const double* __restrict__ v,
                                                          double* __restrict__ out) {
   const int lane = threadIdx.x & 63;
-  const int64_t m0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * FR;
+  constexpr int DR = 4;
+  const int64_t m0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * DR;
   if (m0 >= M) return;
-  double dw[FR];
+  double dw[DR];
 #pragma unroll
-  for (int rr = 0; rr < FR; ++rr) dw[rr] = 0.0;
+  for (int rr = 0; rr < DR; ++rr) dw[rr] = 0.0;
   for (int c = lane; c < (Npad >> 4); c += 64) {
     double wv[16];
 #pragma unroll
@@ -292,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void snp_dot_kernel(const int8_t* __restric
       wv[e] = t.x; wv[e + 1] = t.y;
     }
 #pragma unroll
-    for (int rr = 0; rr < FR; ++rr) {
+    for (int rr = 0; rr < DR; ++rr) {
       const uint4 u = *(const uint4*)(S + (m0 + rr) * ldS + c * 16);
       const uint32_t wds[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
@@ -302,25 +530,24 @@ __global__ __launch_bounds__(256, 2) void snp_dot_kernel(const int8_t* __restric
   }
   double mine = 0.0;
 #pragma unroll
-  for (int rr = 0; rr < FR; ++rr) {
+  for (int rr = 0; rr < DR; ++rr) {
     double a = dw[rr];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
     if (lane == rr) mine = a;
   }
-  if (lane < FR && m0 + lane < M) out[m0 + lane] = mine;
+  if (lane < DR && m0 + lane < M) out[m0 + lane] = mine;
 }
 
 void launch_snp_dot(mmg_ctx* ctx, const mmg_geno* g, const double* v, double* out) {
-  const int64_t nwaves = (g->M + FR - 1) / FR;
+  const int64_t nwaves = (g->M + 3) / 4;
   hipLaunchKernelGGL(snp_dot_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, ctx->stream, g->d,
                      (int64_t)g->Npad, g->M, g->Npad, v, out);
 }
 
 void launch_scan_finalize(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, mmg_scan_result& res,
                           double h0_rss, int32_t df2, double lnbeta) {
-  const int64_t nwaves = (g->M + FR - 1) / FR;
-  hipLaunchKernelGGL(scan_finalize_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, ctx->stream, g->d,
+  hipLaunchKernelGGL(scan_finalize_kernel, dim3((unsigned)(g->Mpad / FIN_ROWS)), dim3(256), 0, ctx->stream, g->d,
                      (int64_t)g->Npad, g->M, g->Npad, md.w, md.diag, res.q, md.step, h0_rss, (double)df2, lnbeta,
                      res.rss, res.F, res.p, res.dot, res.den, res.sum);
 }
