@@ -152,6 +152,13 @@ def main():
         Npad = -(-N // 256) * 256
         nJ = Npad // 256
         exec_ops = 2.0 * D * 256.0 * 256.0 * 256.0 * (nJ * (nJ + 1) / 2) * (-(-M // 256))
+        traffic = None
+        try:   # HBM bytes per launch measured with rocprofv3 PMC passes of this same command (profiles/)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_c3.json")))
+            if tj["config"] == {"n": N, "m": M, "digits": D}:
+                traffic = tj["kernels"]["scan_quad_kernel"]["hbm_bytes_corrected"]
+        except Exception:
+            pass
         res = {
             "metric": "SNPs/sec EMMAX scan", "value": value, "unit": "SNPs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -163,7 +170,8 @@ def main():
                        "parallelism": "snp-block x%d" % world},
             "roofline": {"bound": "mfma", "kernel": "scan_quad_kernel", "achieved": achieved,
                          "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s", "frac": achieved / I8_MFMA_PEAK_TOPS,
-                         "traffic": None, "ms": qms,
+                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/traffic_c3.json)",
+                         "algorithmic_bytes": float(-(-M // 256) * 256 * Npad + D * Npad * Npad), "ms": qms,
                          "executed_int8_tops": exec_ops / (qms * 1e-3) / 1e12,
                          "executed_frac": exec_ops / (qms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS},
             "finalize_kernel": {"ms": float(np.mean(fin_ms)),

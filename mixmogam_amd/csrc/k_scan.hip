@@ -494,7 +494,6 @@ __global__ __launch_bounds__(256, 2) void scan_finalize_kernel(
     const double F = (ratio - 1.0) * nu;
     if (rss) rss[m] = r;
     if (Fst) Fst[m] = F;
-    if (pv) pv[m] = f_sf_1(F, nu, lnbeta);
     if (dotv) dotv[m] = my_dw;
     if (denv) denv[m] = den;
     if (sumv) sumv[m] = (double)my_sm;
@@ -550,6 +549,9 @@ void launch_scan_finalize(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model&
   hipLaunchKernelGGL(scan_finalize_kernel, dim3((unsigned)(g->Mpad / FIN_ROWS)), dim3(256), 0, ctx->stream, g->d,
                      (int64_t)g->Npad, g->M, g->Npad, md.w, md.diag, res.q, md.step, h0_rss, (double)df2, lnbeta,
                      res.rss, res.F, res.p, res.dot, res.den, res.sum);
+  // p-values in their own launch: one lane per SNP (in the finalize kernel only 8 of 64 lanes hold a
+  // finished SNP, and the continued fraction is ~100 dependent fp64 divisions long)
+  if (res.p && g->M > 0) launch_f_sf(ctx, res.F, g->M, df2, lnbeta, res.p);
 }
 
 }  // namespace mmg
