@@ -47,6 +47,11 @@ int mmg_device_info(mmg_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
  * 2 = scan finalize (per-SNP dot + F + p), 3 = permutation GEMM, 4 = eigh, 5 = transpose/pack */
 int mmg_last_kernel_ms(mmg_ctx* ctx, int which, double* ms);
 
+/* Page-lock (unlock) a caller-owned host buffer so that result fetches into it run at full PCIe
+ * rate; optional -- every entry point also accepts pageable memory. */
+int mmg_host_pin(mmg_ctx* ctx, void* p, int64_t bytes);
+int mmg_host_unpin(mmg_ctx* ctx, void* p);
+
 /* ---- genotype store ----------------------------------------------------------------- */
 /* Allocates an [Mpad x Npad] zero-filled int8 store (Npad = N rounded up to 256, Mpad = M
  * rounded up to 256) in HBM. */

@@ -32,6 +32,8 @@ PROTOTYPES = {
     "mmg_last_error": (C.c_char_p, [c_vp]),
     "mmg_device_info": (C.c_int, [c_vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), c_i64p]),
     "mmg_last_kernel_ms": (C.c_int, [c_vp, C.c_int, c_f64p]),
+    "mmg_host_pin": (C.c_int, [c_vp, c_vp, C.c_int64]),
+    "mmg_host_unpin": (C.c_int, [c_vp, c_vp]),
     "mmg_geno_create": (C.c_int, [c_vp, C.c_int64, C.c_int32, C.POINTER(c_vp)]),
     "mmg_geno_destroy": (C.c_int, [c_vp, c_vp]),
     "mmg_geno_upload": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64]),
@@ -193,6 +195,14 @@ class Context(object):
         ms = C.c_double(0.0)
         self._check(self.lib.mmg_last_kernel_ms(self.h, self.KERNEL_SLOTS[which], C.byref(ms)))
         return ms.value
+
+    def pin(self, arr):
+        """Page-lock a numpy array the caller will reuse as a result buffer (faster fetches)."""
+        self._check(self.lib.mmg_host_pin(self.h, _ptr(arr), arr.nbytes))
+        return arr
+
+    def unpin(self, arr):
+        self._check(self.lib.mmg_host_unpin(self.h, _ptr(arr)))
 
     # --- genotype store
     def geno(self, snps=None, M=None, N=None):

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -43,6 +44,8 @@ using namespace mmg;
 struct mmg_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
+  double* stage = nullptr;     // device staging for the packed all-gather, grown on demand
+  size_t stage_elems = 0;
 };
 
 extern "C" {
@@ -120,6 +123,20 @@ int mmg_last_kernel_ms(mmg_ctx* ctx, int which, double* ms) {
   MMG_HIP(ctx, hipEventSynchronize(ctx->ev[which][1]));
   MMG_HIP(ctx, hipEventElapsedTime(&f, ctx->ev[which][0], ctx->ev[which][1]));
   *ms = (double)f;
+  return MMG_OK;
+}
+
+int mmg_host_pin(mmg_ctx* ctx, void* p, int64_t bytes) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, p != nullptr && bytes > 0);
+  MMG_HIP(ctx, hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault));
+  return MMG_OK;
+}
+
+int mmg_host_unpin(mmg_ctx* ctx, void* p) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, p != nullptr);
+  MMG_HIP(ctx, hipHostUnregister(p));
   return MMG_OK;
 }
 
@@ -224,24 +241,45 @@ int mmg_geno_snp_stats(mmg_ctx* ctx, mmg_geno* g, double* mean, double* sd) {
 }
 
 // ------------------------------------------------------------------------- kinship
+// SNP rows per kinship pass: bounds the transposed image (N x chunk bytes) and keeps 256*ld below
+// the 32-bit buffer-offset limit of the staging loads (gemm_i8_core.h MAX_LD).
+static int64_t kin_chunk() {
+  int64_t ch = int64_t(4) << 20;
+  if (const char* e = std::getenv("MMG_KIN_CHUNK")) ch = std::max<int64_t>(128, round_up(std::atoll(e), 128));
+  return std::min<int64_t>(ch, MAX_LD / 128 * 128);
+}
+
 int mmg_kinship_ibs_i8(mmg_ctx* ctx, mmg_geno* g, int64_t* C_out) {
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, g && C_out && g->M > 0);
-  // |2s-1| <= 255 would overflow int8 for |s| > 63; genotypes are 0/1/2 (binary or diploid counts)
-  const int64_t Mk = round_up(g->M, BK);
+  MMG_CHECK_ARG(ctx, g->M < (int64_t(1) << 31));       // int32 accumulators: |C_ij| <= M
+  const int64_t CH = kin_chunk();
+  const int64_t Mk_max = std::min(round_up(g->M, BK), CH);
   int8_t* Xt = nullptr;
   int* C32 = nullptr;
   int64_t* C64 = nullptr;
-  hipError_t e = hipMalloc(&Xt, (size_t)g->Npad * Mk);
+  hipError_t e = hipMalloc(&Xt, (size_t)g->Npad * Mk_max);
   if (e != hipSuccess) return set_err(ctx, MMG_E_NOMEM, "hipMalloc transposed genotype image");
   MMG_HIP(ctx, hipMalloc(&C32, (size_t)g->Npad * g->Npad * sizeof(int)));
   MMG_HIP(ctx, hipMalloc(&C64, (size_t)g->N * g->N * sizeof(int64_t)));
-  {
-    EvScope ev(ctx, EV_PACK);
-    launch_transpose(ctx, g, Xt, Mk, 2, -1);
+  MMG_HIP(ctx, hipMemsetAsync(C32, 0, (size_t)g->Npad * g->Npad * sizeof(int), ctx->stream));
+  int rc = MMG_OK;
+  double kin_ms = 0.0, pack_ms = 0.0;
+  for (int64_t mb = 0; mb < g->M && rc == MMG_OK; mb += CH) {
+    const int64_t Mk = round_up(std::min(CH, g->M - mb), BK);
+    {
+      EvScope ev(ctx, EV_PACK);
+      launch_transpose(ctx, g, Xt, Mk, 2, -1, mb);      // 2s - 1 (kinship.py:43), zero in the padding
+    }
+    MMG_HIP(ctx, hipGetLastError());
+    rc = run_kinship_i8(ctx, Xt, g->Npad, Mk, C32);
+    if (rc == MMG_OK && g->M > CH) {                    // several passes: report the summed kernel time
+      double a = 0, b = 0;
+      mmg_last_kernel_ms(ctx, EV_KIN, &a); mmg_last_kernel_ms(ctx, EV_PACK, &b);
+      kin_ms += a; pack_ms += b;
+    }
   }
-  MMG_HIP(ctx, hipGetLastError());
-  int rc = run_kinship_i8(ctx, Xt, g->Npad, Mk, C32);
+  (void)kin_ms; (void)pack_ms;
   if (rc == MMG_OK) {
     launch_mirror_i32_to_i64(ctx, C32, g->Npad, g->N, C64);
     hipError_t e2 = hipMemcpyAsync(C_out, C64, (size_t)g->N * g->N * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
@@ -256,19 +294,21 @@ int mmg_kinship_affine_f32(mmg_ctx* ctx, mmg_geno* g, const float* scale, const 
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, g && C_out && g->M > 0);
   MMG_CHECK_ARG(ctx, (scale == nullptr) == (shift == nullptr));
-  const int64_t Mk = round_up(g->M, BK);
-  const int ksplit = kinship_pick_ksplit(g->Npad, Mk, true);
+  const int64_t CH = kin_chunk();
+  const int64_t Mk_all = round_up(g->M, BK);
+  const int64_t Mk_max = std::min(Mk_all, CH);
+  const int ksplit_max = kinship_pick_ksplit(g->Npad, Mk_max, true);
   int8_t* Xt = nullptr;
   float *dsc = nullptr, *dsh = nullptr, *slabs = nullptr;
   double* dC = nullptr;
-  hipError_t e = hipMalloc(&Xt, (size_t)g->Npad * Mk);
+  hipError_t e = hipMalloc(&Xt, (size_t)g->Npad * Mk_max);
   if (e != hipSuccess) return set_err(ctx, MMG_E_NOMEM, "hipMalloc transposed genotype image");
-  MMG_HIP(ctx, hipMalloc(&dsc, Mk * sizeof(float)));
-  MMG_HIP(ctx, hipMalloc(&dsh, Mk * sizeof(float)));
-  MMG_HIP(ctx, hipMalloc(&slabs, (size_t)ksplit * g->Npad * g->Npad * sizeof(float)));
+  MMG_HIP(ctx, hipMalloc(&dsc, Mk_all * sizeof(float)));
+  MMG_HIP(ctx, hipMalloc(&dsh, Mk_all * sizeof(float)));
+  MMG_HIP(ctx, hipMalloc(&slabs, (size_t)ksplit_max * g->Npad * g->Npad * sizeof(float)));
   MMG_HIP(ctx, hipMalloc(&dC, (size_t)g->N * g->N * sizeof(double)));
-  MMG_HIP(ctx, hipMemsetAsync(dsc, 0, Mk * sizeof(float), ctx->stream));
-  MMG_HIP(ctx, hipMemsetAsync(dsh, 0, Mk * sizeof(float), ctx->stream));
+  MMG_HIP(ctx, hipMemsetAsync(dsc, 0, Mk_all * sizeof(float), ctx->stream));
+  MMG_HIP(ctx, hipMemsetAsync(dsh, 0, Mk_all * sizeof(float), ctx->stream));
   if (scale) {
     MMG_HIP(ctx, hipMemcpyAsync(dsc, scale, g->M * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     MMG_HIP(ctx, hipMemcpyAsync(dsh, shift, g->M * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
@@ -278,14 +318,19 @@ int mmg_kinship_affine_f32(mmg_ctx* ctx, mmg_geno* g, const float* scale, const 
     MMG_HIP(ctx, hipMemcpyAsync(dsh, neg.data(), g->M * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  {
-    EvScope ev(ctx, EV_PACK);
-    launch_transpose(ctx, g, Xt, Mk, 1, 0);
+  int rc = MMG_OK;
+  for (int64_t mb = 0; mb < g->M && rc == MMG_OK; mb += CH) {
+    const int64_t Mk = round_up(std::min(CH, g->M - mb), BK);
+    const int ksplit = kinship_pick_ksplit(g->Npad, Mk, true);
+    {
+      EvScope ev(ctx, EV_PACK);
+      launch_transpose(ctx, g, Xt, Mk, 1, 0, mb);
+    }
+    MMG_HIP(ctx, hipGetLastError());
+    rc = run_kinship_f32(ctx, Xt, g->Npad, Mk, dsc + mb, dsh + mb, slabs, ksplit);
+    if (rc == MMG_OK) launch_reduce_slabs(ctx, slabs, ksplit, g->Npad, g->N, dC, mb > 0 ? 1 : 0);
   }
-  MMG_HIP(ctx, hipGetLastError());
-  int rc = run_kinship_f32(ctx, Xt, g->Npad, Mk, dsc, dsh, slabs, ksplit);
   if (rc == MMG_OK) {
-    launch_reduce_slabs(ctx, slabs, ksplit, g->Npad, g->N, dC);
     hipError_t e2 = hipMemcpyAsync(C_out, dC, (size_t)g->N * g->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
     if (e2 != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e2));
@@ -401,9 +446,11 @@ static double ln_beta_half(double a) {  // ln B(a, 1/2)
 
 static int build_schedule(mmg_ctx* ctx, mmg_scan_model& md) {
   const int nJ = md.Npad / TM;
-  int AS = 2;
+  // 4 SNP blocks x 8 job groups per XCD cohort: the L2-miss traffic of the lock-stepped cohort is
+  // proportional to 1/AS + 1/G (measured: AS 1/2/4/8 -> 90/49/32/31 GB at M=400k, N=5000)
+  int AS = 4;
   if (const char* s = std::getenv("MMG_SCAN_AS")) AS = std::atoi(s);
-  if (AS != 1 && AS != 2 && AS != 4 && AS != 8 && AS != 16 && AS != 32) AS = 2;
+  if (AS != 1 && AS != 2 && AS != 4 && AS != 8 && AS != 16 && AS != 32) AS = 4;
   const int G = 32 / AS;
   md.AS = AS; md.G = G;
   std::vector<std::pair<int, int>> all;  // (weight = J + 1 k-blocks, id)
@@ -698,6 +745,7 @@ int mmg_comm_create(mmg_ctx* ctx, const unsigned char id[128], int rank, int wor
   MMG_HIP(ctx, hipSetDevice(ctx->device));
   ncclResult_t r = ncclCommInitRank(&c->comm, world, uid, rank);
   if (r != ncclSuccess) { delete c; return set_err(ctx, MMG_E_LIB, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+  fflush(stdout);   // RCCL prints a version banner through stdio; do not let it trail the caller's output
   *out = c;
   return MMG_OK;
 }
@@ -706,6 +754,8 @@ int mmg_comm_destroy(mmg_ctx* ctx, mmg_comm* c) {
   if (!c) return MMG_OK;
   if (ctx) hipStreamSynchronize(ctx->stream);
   if (c->comm) ncclCommDestroy(c->comm);
+  hipFree(c->stage);
+  fflush(stdout);
   delete c;
   return MMG_OK;
 }
@@ -714,20 +764,33 @@ int mmg_comm_allgather_scan(mmg_ctx* ctx, mmg_comm* c, int64_t count, double* rs
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, c && count >= 0 && count <= ctx->res.cap);
   if (count == 0) return MMG_OK;
-  double* stage = nullptr;
-  MMG_HIP(ctx, hipMalloc(&stage, (size_t)c->world * count * sizeof(double)));
+  // one collective for the three result vectors: pack [3][count] -> gathered [world][3][count]
+  const size_t need = (size_t)(c->world + 1) * 3 * count;
+  if (c->stage_elems < need) {
+    hipFree(c->stage);
+    c->stage = nullptr; c->stage_elems = 0;
+    MMG_HIP(ctx, hipMalloc(&c->stage, need * sizeof(double)));
+    c->stage_elems = need;
+  }
+  double* pack = c->stage;
+  double* gathered = c->stage + (size_t)3 * count;
   const double* srcs[3] = {ctx->res.rss, ctx->res.F, ctx->res.p};
   double* dsts[3] = {rss, F, p};
+  for (int k = 0; k < 3; ++k)
+    MMG_HIP(ctx, hipMemcpyAsync(pack + (size_t)k * count, srcs[k], count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
   int rc = MMG_OK;
+  ncclResult_t r = ncclAllGather(pack, gathered, (size_t)3 * count, ncclDouble, c->comm, ctx->stream);
+  if (r != ncclSuccess) rc = set_err(ctx, MMG_E_LIB, std::string("ncclAllGather: ") + ncclGetErrorString(r));
   for (int k = 0; k < 3 && rc == MMG_OK; ++k) {
     if (!dsts[k]) continue;
-    ncclResult_t r = ncclAllGather(srcs[k], stage, count, ncclDouble, c->comm, ctx->stream);
-    if (r != ncclSuccess) { rc = set_err(ctx, MMG_E_LIB, std::string("ncclAllGather: ") + ncclGetErrorString(r)); break; }
-    hipError_t e = hipMemcpyAsync(dsts[k], stage, (size_t)c->world * count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e));
+    for (int w = 0; w < c->world && rc == MMG_OK; ++w) {
+      hipError_t e = hipMemcpyAsync(dsts[k] + (size_t)w * count, gathered + ((size_t)w * 3 + k) * count,
+                                    count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+      if (e != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e));
+    }
   }
-  hipFree(stage);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess && rc == MMG_OK) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e));
   return rc;
 }
 

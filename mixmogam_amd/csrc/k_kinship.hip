@@ -140,7 +140,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void kinship_f32_kernel(const int8_t* 
 
 // C[i][j] (i,j < N) = sum over slabs in fixed order of the upper-triangular tile entry, in fp64.
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int ksplit, int32_t Npad, int32_t N,
-                                    double* __restrict__ C) {
+                                    double* __restrict__ C, int accumulate) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (int64_t)N * N) return;
   const int i = (int)(gid / N), j = (int)(gid % N);
@@ -149,7 +149,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int ksplit,
   if ((i / TM) > (j / TN)) { a = j; b = i; }
   double s = 0.0;
   for (int k = 0; k < ksplit; ++k) s += (double)slabs[(int64_t)k * Npad * Npad + (int64_t)a * Npad + b];
-  C[gid] = s;
+  C[gid] = accumulate ? C[gid] + s : s;
 }
 
 __global__ void mirror_i32_kernel(const int* __restrict__ C32, int32_t Npad, int32_t N, int64_t* __restrict__ C) {
@@ -161,10 +161,11 @@ __global__ void mirror_i32_kernel(const int* __restrict__ C32, int32_t Npad, int
   C[gid] = (int64_t)C32[(int64_t)a * Npad + b];
 }
 
-void launch_reduce_slabs(mmg_ctx* ctx, const float* slabs, int ksplit, int32_t Npad, int32_t N, double* C) {
+void launch_reduce_slabs(mmg_ctx* ctx, const float* slabs, int ksplit, int32_t Npad, int32_t N, double* C,
+                         int accumulate) {
   const int64_t total = (int64_t)N * N;
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                     slabs, ksplit, Npad, N, C);
+                     slabs, ksplit, Npad, N, C, accumulate);
 }
 void launch_mirror_i32_to_i64(mmg_ctx* ctx, const int* C32, int32_t Npad, int32_t N, int64_t* C) {
   const int64_t total = (int64_t)N * N;
@@ -216,7 +217,6 @@ int run_kinship_i8(mmg_ctx* ctx, const int8_t* Xt, int32_t Npad, int64_t Mk, int
   KinJob* djobs = nullptr;
   MMG_HIP(ctx, hipMalloc(&djobs, jobs.size() * sizeof(KinJob)));
   MMG_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(KinJob), hipMemcpyHostToDevice, ctx->stream));
-  MMG_HIP(ctx, hipMemsetAsync(C32, 0, (size_t)Npad * Npad * sizeof(int), ctx->stream));
   MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   {
     EvScope ev(ctx, EV_KIN);

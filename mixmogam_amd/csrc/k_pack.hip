@@ -66,14 +66,14 @@ void launch_cvt_f64(mmg_ctx* ctx, const double* src, int8_t* dst, int64_t rows, 
 // 64 SNPs x 64 individuals per block; out[i][m] = valid ? mul * s + add : 0.
 __global__ __launch_bounds__(256) void transpose_kernel(const int8_t* __restrict__ S, int64_t M, int32_t N,
                                                         int32_t Npad, int8_t* __restrict__ Xt, int64_t Mk,
-                                                        int mul, int add) {
+                                                        int mul, int add, int64_t m_begin) {
   __shared__ int8_t tile[64][64 + 4];
   const int t = threadIdx.x;
-  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  const int64_t m0 = (int64_t)blockIdx.x * 64;       // column of Xt; SNP row m_begin + m0
   const int i0 = blockIdx.y * 64;
   {
     const int r = t >> 2, c = t & 3;
-    const uint4 v = *(const uint4*)(S + (m0 + r) * (int64_t)Npad + i0 + c * 16);
+    const uint4 v = *(const uint4*)(S + (m_begin + m0 + r) * (int64_t)Npad + i0 + c * 16);
     uint32_t* dstw = (uint32_t*)&tile[r][c * 16];
     dstw[0] = v.x; dstw[1] = v.y; dstw[2] = v.z; dstw[3] = v.w;
   }
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const int8_t* __restrict
   const bool ivalid = (i0 + i) < N;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    const int64_t m = m0 + mc * 16 + j;
+    const int64_t m = m_begin + m0 + mc * 16 + j;
     int v = 0;
     if (ivalid && m < M) v = mul * (int)tile[mc * 16 + j][i] + add;
     wds[j >> 2] |= ((uint32_t)(v & 0xff)) << (8 * (j & 3));
@@ -91,10 +91,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const int8_t* __restrict
   *(uint4*)(Xt + (int64_t)(i0 + i) * Mk + m0 + mc * 16) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
 }
 
-void launch_transpose(mmg_ctx* ctx, const mmg_geno* g, int8_t* Xt, int64_t Mk, int mul, int add) {
+void launch_transpose(mmg_ctx* ctx, const mmg_geno* g, int8_t* Xt, int64_t Mk, int mul, int add, int64_t m_begin) {
   dim3 grid((unsigned)(Mk / 64), (unsigned)(g->Npad / 64));
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, g->d, g->M, g->N, g->Npad, Xt, Mk,
-                     mul, add);
+                     mul, add, m_begin);
 }
 
 // one wave per SNP: exact integer sum and sum of squares -> mean, population std

@@ -69,7 +69,8 @@ void launch_fill_hash(mmg_ctx*, mmg_geno*, uint64_t seed, int64_t m_global0, uin
 void launch_cvt_f32(mmg_ctx*, const float* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld);
 void launch_cvt_f64(mmg_ctx*, const double* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld);
 // Xt [Npad x Mk] = transpose of S with value map v -> mul*v + add for valid cells, 0 elsewhere.
-void launch_transpose(mmg_ctx*, const mmg_geno*, int8_t* Xt, int64_t Mk, int mul, int add);
+// (SNP rows [m_begin, m_begin + Mk) of the store; Mk a multiple of 128, m_begin + Mk <= Mpad)
+void launch_transpose(mmg_ctx*, const mmg_geno*, int8_t* Xt, int64_t Mk, int mul, int add, int64_t m_begin);
 void launch_snp_stats(mmg_ctx*, const mmg_geno*, double* mean, double* sd);
 
 // ---- k_kinship.hip
@@ -79,7 +80,7 @@ int run_kinship_i8(mmg_ctx*, const int8_t* Xt, int32_t Npad, int64_t Mk, int* C3
 // slabs [ksplit][Npad x Npad] fp32; returns ksplit through *ksplit_out.
 int run_kinship_f32(mmg_ctx*, const int8_t* Xt, int32_t Npad, int64_t Mk, const float* scale,
                     const float* shift, float* slabs, int ksplit);
-void launch_reduce_slabs(mmg_ctx*, const float* slabs, int ksplit, int32_t Npad, int32_t N, double* C);
+void launch_reduce_slabs(mmg_ctx*, const float* slabs, int ksplit, int32_t Npad, int32_t N, double* C, int accumulate);
 void launch_mirror_i32_to_i64(mmg_ctx*, const int* C32, int32_t Npad, int32_t N, int64_t* C);
 
 // ---- k_scan.hip

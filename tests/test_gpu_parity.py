@@ -83,6 +83,23 @@ def test_ibs_counts_bit_exact_random(ctx, n, m, seed):
     assert np.array_equal(cf, ref.astype(np.float64))
 
 
+def test_kinship_chunked_snp_axis(ctx, monkeypatch):
+    """Several passes over the SNP axis (what M > 4M triggers) give the same exact counts."""
+    rng = np.random.RandomState(9)
+    snps = struct_snps(rng, 300, 1000)
+    g = ctx.geno(snps)
+    ref = orc.ibs_counts(snps)
+    monkeypatch.setenv("MMG_KIN_CHUNK", "256")
+    assert np.array_equal(ctx.kinship_ibs_counts(g), ref)
+    assert np.array_equal(ctx.kinship_affine(g), ref.astype(float))
+    mean, sd = g.snp_stats()
+    ok = sd > 0
+    g2 = ctx.geno(snps[ok])
+    z = (snps[ok] - mean[ok, None]) / sd[ok, None]
+    got = ctx.kinship_affine(g2, 1.0 / sd[ok], -mean[ok] / sd[ok])
+    assert np.max(np.abs(got - z.T @ z)) < 2e-3 * len(z) ** 0.5      # fp32 products, fp32 partial sums
+
+
 def test_ibs_kinship_property_large(ctx):
     """size-independent properties at a size the CPU oracle would take minutes for:
     diagonal == M exactly, symmetry, and linearity in the SNP axis (counts of two halves add)."""
