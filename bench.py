@@ -120,8 +120,8 @@ def main():
         if coll is not None:
             coll.barrier()
 
-    # result buffers are allocated once and page-locked (mmg_host_pin) so the fetch runs at PCIe rate
-    outs = [ctx.pin(np.empty(M * world)) for _ in range(3)]
+    # result buffers are allocated once and page-locked (mmg_host_alloc) so the fetch runs at PCIe rate
+    outs = [ctx.pinned_empty(M * world) for _ in range(3)]
 
     def step():
         ctx.scan(g, prep["h0_rss"], n_p, fetch=False)           # blocks until the kernels finish

@@ -50,7 +50,10 @@ int mmg_last_kernel_ms(mmg_ctx* ctx, int which, double* ms);
 /* Page-lock (unlock) a caller-owned host buffer so that result fetches into it run at full PCIe
  * rate; optional -- every entry point also accepts pageable memory. */
 int mmg_host_pin(mmg_ctx* ctx, void* p, int64_t bytes);
-int mmg_host_unpin(mmg_ctx* ctx, void* p);
+int mmg_host_unpin(mmg_ctx* ctx, void* p);   /* MUST precede freeing a pinned buffer */
+/* Page-locked host memory owned by the library until mmg_host_free. */
+int mmg_host_alloc(mmg_ctx* ctx, int64_t bytes, void** p);
+int mmg_host_free(mmg_ctx* ctx, void* p);
 
 /* ---- genotype store ----------------------------------------------------------------- */
 /* Allocates an [Mpad x Npad] zero-filled int8 store (Npad = N rounded up to 256, Mpad = M

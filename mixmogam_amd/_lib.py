@@ -34,6 +34,8 @@ PROTOTYPES = {
     "mmg_last_kernel_ms": (C.c_int, [c_vp, C.c_int, c_f64p]),
     "mmg_host_pin": (C.c_int, [c_vp, c_vp, C.c_int64]),
     "mmg_host_unpin": (C.c_int, [c_vp, c_vp]),
+    "mmg_host_alloc": (C.c_int, [c_vp, C.c_int64, C.POINTER(c_vp)]),
+    "mmg_host_free": (C.c_int, [c_vp, c_vp]),
     "mmg_geno_create": (C.c_int, [c_vp, C.c_int64, C.c_int32, C.POINTER(c_vp)]),
     "mmg_geno_destroy": (C.c_int, [c_vp, c_vp]),
     "mmg_geno_upload": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64]),
@@ -196,13 +198,18 @@ class Context(object):
         self._check(self.lib.mmg_last_kernel_ms(self.h, self.KERNEL_SLOTS[which], C.byref(ms)))
         return ms.value
 
-    def pin(self, arr):
-        """Page-lock a numpy array the caller will reuse as a result buffer (faster fetches)."""
-        self._check(self.lib.mmg_host_pin(self.h, _ptr(arr), arr.nbytes))
+    def pinned_empty(self, n, dtype=np.float64):
+        """1-D numpy array in page-locked host memory owned by the library (result fetches into it
+        run at PCIe rate).  Freed when the array is garbage collected."""
+        import weakref
+        nbytes = int(n) * np.dtype(dtype).itemsize
+        p = c_vp()
+        self._check(self.lib.mmg_host_alloc(self.h, max(nbytes, 1), C.byref(p)))
+        buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(n))
+        lib, h, addr = self.lib, self.h, p.value
+        weakref.finalize(buf, lambda: lib.mmg_host_free(h, c_vp(addr)))
         return arr
-
-    def unpin(self, arr):
-        self._check(self.lib.mmg_host_unpin(self.h, _ptr(arr)))
 
     # --- genotype store
     def geno(self, snps=None, M=None, N=None):
@@ -253,11 +260,12 @@ class Context(object):
         assert A.shape == (len(w), len(w))
         self._check(self.lib.mmg_scan_set_model(self.h, len(w), _ptr(A), _ptr(w), int(ndigits)))
 
-    def scan(self, g, h0_rss, df2, fetch=True, stats=False):
+    def scan(self, g, h0_rss, df2, fetch=True, stats=False, out=None):
+        """out: optional (rss, F, p) arrays of length M to fetch into (e.g. page-locked with pin())."""
         self._check(self.lib.mmg_emmax_scan_device(self.h, g.h, float(h0_rss), int(df2)))
         if not fetch:
             return None
-        rss, F, p = np.empty(g.M), np.empty(g.M), np.empty(g.M)
+        rss, F, p = out if out is not None else (np.empty(g.M), np.empty(g.M), np.empty(g.M))
         self._check(self.lib.mmg_scan_fetch(self.h, g.M, _ptr(rss), _ptr(F), _ptr(p)))
         out = {"rss": rss, "f_stats": F, "ps": p}
         if stats:

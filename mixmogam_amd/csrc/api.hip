@@ -133,6 +133,22 @@ int mmg_host_pin(mmg_ctx* ctx, void* p, int64_t bytes) {
   return MMG_OK;
 }
 
+int mmg_host_alloc(mmg_ctx* ctx, int64_t bytes, void** p) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, p != nullptr && bytes > 0);
+  *p = nullptr;
+  MMG_HIP(ctx, hipHostMalloc(p, (size_t)bytes, hipHostMallocDefault));
+  return MMG_OK;
+}
+
+int mmg_host_free(mmg_ctx* ctx, void* p) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  if (!p) return MMG_OK;
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MMG_HIP(ctx, hipHostFree(p));
+  return MMG_OK;
+}
+
 int mmg_host_unpin(mmg_ctx* ctx, void* p) {
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, p != nullptr);
