@@ -84,6 +84,10 @@ int mmg_geno_matvec(mmg_ctx* ctx, mmg_geno* g, const double* V, int32_t nv, doub
  * C_out: host int64 [N x N].  Bit-exact with kinship.py:43-44 (whose entries are exact
  * integers carried in float64). */
 int mmg_kinship_ibs_i8(mmg_ctx* ctx, mmg_geno* g, int64_t* C_out);
+/* Indicator co-occurrence counts C = U U^T, U = [s >= thr] (exact, same kernel).  Two calls
+ * (thr = 1, 2) give the 'diploid_int' IBS kinship of kinship.py:33-41:
+ * sum_m |a_m - b_m| = r_a + r_b - 2 (C1_ab + C2_ab), r = diag(C1 + C2). */
+int mmg_kinship_indicator_i8(mmg_ctx* ctx, mmg_geno* g, int32_t thr, int64_t* C_out);
 /* General per-SNP affine kinship C = sum_m x_m x_m^T, x_m = scale[m]*s_m + shift[m], as a dense
  * fp32 MFMA GEMM with the int8 genotypes expanded to fp32 from the LDS tile.  scale/shift: host
  * float arrays of length M, or NULL for scale=2, shift=-1 (the IBS expansion of kinship.py:43;

@@ -46,6 +46,7 @@ PROTOTYPES = {
     "mmg_geno_snp_stats": (C.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "mmg_geno_matvec": (C.c_int, [c_vp, c_vp, c_vp, C.c_int32, c_vp]),
     "mmg_kinship_ibs_i8": (C.c_int, [c_vp, c_vp, c_vp]),
+    "mmg_kinship_indicator_i8": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp]),
     "mmg_kinship_affine_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mmg_kinship_i8": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp, c_vp, c_vp]),
     "mmg_eigh_f64": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp]),
@@ -225,6 +226,11 @@ class Context(object):
     def kinship_ibs_counts(self, g):
         out = np.empty((g.N, g.N), dtype=np.int64)
         self._check(self.lib.mmg_kinship_ibs_i8(self.h, g.h, _ptr(out)))
+        return out
+
+    def kinship_indicator_counts(self, g, thr):
+        out = np.empty((g.N, g.N), dtype=np.int64)
+        self._check(self.lib.mmg_kinship_indicator_i8(self.h, g.h, int(thr), _ptr(out)))
         return out
 
     def kinship_affine(self, g, scale=None, shift=None):

@@ -265,7 +265,19 @@ static int64_t kin_chunk() {
   return std::min<int64_t>(ch, MAX_LD / 128 * 128);
 }
 
+static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int thr, int64_t* C_out);
+
 int mmg_kinship_ibs_i8(mmg_ctx* ctx, mmg_geno* g, int64_t* C_out) {
+  return kinship_counts_i8(ctx, g, 2, -1, 0, C_out);    // X = 2S - 1 (kinship.py:43)
+}
+
+int mmg_kinship_indicator_i8(mmg_ctx* ctx, mmg_geno* g, int32_t thr, int64_t* C_out) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, thr >= 1 && thr <= 127);
+  return kinship_counts_i8(ctx, g, 0, 0, thr, C_out);   // X = [S >= thr]
+}
+
+static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int thr, int64_t* C_out) {
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, g && C_out && g->M > 0);
   MMG_CHECK_ARG(ctx, g->M < (int64_t(1) << 31));       // int32 accumulators: |C_ij| <= M
@@ -285,7 +297,7 @@ int mmg_kinship_ibs_i8(mmg_ctx* ctx, mmg_geno* g, int64_t* C_out) {
     const int64_t Mk = round_up(std::min(CH, g->M - mb), BK);
     {
       EvScope ev(ctx, EV_PACK);
-      launch_transpose(ctx, g, Xt, Mk, 2, -1, mb);      // 2s - 1 (kinship.py:43), zero in the padding
+      launch_transpose(ctx, g, Xt, Mk, mul, add, mb, thr);   // zero in the padding
     }
     MMG_HIP(ctx, hipGetLastError());
     rc = run_kinship_i8(ctx, Xt, g->Npad, Mk, C32);

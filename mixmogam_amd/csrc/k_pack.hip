@@ -66,7 +66,7 @@ void launch_cvt_f64(mmg_ctx* ctx, const double* src, int8_t* dst, int64_t rows, 
 // 64 SNPs x 64 individuals per block; out[i][m] = valid ? mul * s + add : 0.
 __global__ __launch_bounds__(256) void transpose_kernel(const int8_t* __restrict__ S, int64_t M, int32_t N,
                                                         int32_t Npad, int8_t* __restrict__ Xt, int64_t Mk,
-                                                        int mul, int add, int64_t m_begin) {
+                                                        int mul, int add, int64_t m_begin, int thr) {
   __shared__ int8_t tile[64][64 + 4];
   const int t = threadIdx.x;
   const int64_t m0 = (int64_t)blockIdx.x * 64;       // column of Xt; SNP row m_begin + m0
@@ -85,16 +85,20 @@ __global__ __launch_bounds__(256) void transpose_kernel(const int8_t* __restrict
   for (int j = 0; j < 16; ++j) {
     const int64_t m = m_begin + m0 + mc * 16 + j;
     int v = 0;
-    if (ivalid && m < M) v = mul * (int)tile[mc * 16 + j][i] + add;
+    if (ivalid && m < M) {
+      const int sv = (int)tile[mc * 16 + j][i];
+      v = thr > 0 ? (sv >= thr ? 1 : 0) : mul * sv + add;     // indicator [s >= thr] or affine
+    }
     wds[j >> 2] |= ((uint32_t)(v & 0xff)) << (8 * (j & 3));
   }
   *(uint4*)(Xt + (int64_t)(i0 + i) * Mk + m0 + mc * 16) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
 }
 
-void launch_transpose(mmg_ctx* ctx, const mmg_geno* g, int8_t* Xt, int64_t Mk, int mul, int add, int64_t m_begin) {
+void launch_transpose(mmg_ctx* ctx, const mmg_geno* g, int8_t* Xt, int64_t Mk, int mul, int add, int64_t m_begin,
+                      int thr) {
   dim3 grid((unsigned)(Mk / 64), (unsigned)(g->Npad / 64));
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, ctx->stream, g->d, g->M, g->N, g->Npad, Xt, Mk,
-                     mul, add, m_begin);
+                     mul, add, m_begin, thr);
 }
 
 // one wave per SNP: exact integer sum and sum of squares -> mean, population std

@@ -70,7 +70,9 @@ void launch_cvt_f32(mmg_ctx*, const float* src, int8_t* dst, int64_t rows, int32
 void launch_cvt_f64(mmg_ctx*, const double* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld);
 // Xt [Npad x Mk] = transpose of S with value map v -> mul*v + add for valid cells, 0 elsewhere.
 // (SNP rows [m_begin, m_begin + Mk) of the store; Mk a multiple of 128, m_begin + Mk <= Mpad)
-void launch_transpose(mmg_ctx*, const mmg_geno*, int8_t* Xt, int64_t Mk, int mul, int add, int64_t m_begin);
+// thr > 0: indicator image [s >= thr] instead of the affine map
+void launch_transpose(mmg_ctx*, const mmg_geno*, int8_t* Xt, int64_t Mk, int mul, int add, int64_t m_begin,
+                      int thr = 0);
 void launch_snp_stats(mmg_ctx*, const mmg_geno*, double* mean, double* sd);
 
 // ---- k_kinship.hip

@@ -37,15 +37,25 @@ def calc_ibs_kinship(snps, snps_data_format='binary', snp_dtype='int8', dtype='s
     The count matrix is an exact int8-MFMA GEMM on the device (bit-exact with the reference's
     float64 accumulator); chunk_size is accepted for signature compatibility (the device kernel
     tiles the SNP axis itself).  `geno` may pass an already-resident device genotype store."""
-    if snps_data_format != 'binary':
-        raise NotImplementedError("only snps_data_format='binary' is on the device path "
-                                  "(diploid_int: SURVEY 8f N4)")
+    if snps_data_format not in ('binary', 'diploid_int'):
+        raise NotImplementedError(snps_data_format)
     ctx = ctx or _lib.get_context()
     own = geno is None
     g = ctx.geno(_as_snp_matrix(snps)) if own else geno
     try:
-        counts = ctx.kinship_ibs_counts(g)
         num_snps = g.M
+        if snps_data_format == 'diploid_int':
+            # kinship.py:33-41: k_ij = #(|a-b| = 0) + 0.5 #(|a-b| = 1) = M - 0.5 sum_m |a_m - b_m| for
+            # 0/1/2 genotypes; |a-b| = a + b - 2 min(a,b) and min(a,b) = [a>=1][b>=1] + [a>=2][b>=2]:
+            # two exact indicator GEMMs on the int8 matrix cores replace the O(N^2 M) bincount loop.
+            c12 = ctx.kinship_indicator_counts(g, 1) + ctx.kinship_indicator_counts(g, 2)
+            r = np.diag(c12).astype(np.float64)
+            absdiff = r[:, None] + r[None, :] - 2.0 * c12
+            k_mat = float(num_snps) - 0.5 * absdiff
+            np.fill_diagonal(k_mat, 0.0)                   # the reference only fills i != j (:34-41)
+            k_mat = k_mat / float(num_snps) + np.eye(g.N)  # :51
+            return scale_k(k_mat) if scaled else k_mat
+        counts = ctx.kinship_ibs_counts(g)
     finally:
         if own:
             g.close()

@@ -26,6 +26,74 @@ def _col(x, n=None):
     return a
 
 
+class LinearModel(object):
+    """linear_models.py:81 -- the K-free twin of the EMMAX scan: fast_f_test is the same
+    device scan with H = I, i.e. A = I - QQ' and w = (I - QQ') y."""
+
+    def __init__(self, Y=None, ctx=None):
+        self.n = len(Y)
+        self.Y = _col(Y).reshape(self.n, 1)
+        self.X = np.ones((self.n, 1))
+        self.p = 1
+        self.beta_est = None
+        self.cofactors = []
+        self._ctx = ctx
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = _lib.get_context()
+        return self._ctx
+
+    def add_factor(self, x, lin_depend_thres=1e-8):
+        """:98-113."""
+        new_x = _col(x, self.n)
+        (beta, rss, rank, sigma) = linalg.lstsq(self.X, new_x)
+        if float(np.sum((new_x - self.X @ beta) ** 2)) < lin_depend_thres:
+            warnings.warn('A factor was found to be linearly dependent on the factors already in the X '
+                          'matrix.  Hence skipping it!')
+            return False
+        self.X = np.hstack([self.X, new_x.reshape(self.n, 1)])
+        self.cofactors.append(x)
+        self.p += 1
+        return True
+
+    def get_rss(self, dtype='double'):
+        """:178-184."""
+        (betas, _r, r, s) = linalg.lstsq(self.X, self.Y.reshape(-1))
+        return float(np.sum((self.Y.reshape(-1) - self.X @ betas) ** 2))
+
+    def get_ll(self, rss=None, dtype='double'):
+        """:187-193."""
+        if not rss:
+            rss = self.get_rss(dtype)
+        return (-self.n / 2) * (1 + np.log(2 * np.pi) + rss / self.n)
+
+    def fast_f_test(self, snps, verbose=True, Z=None, with_betas=False, ndigits=0):
+        """:196-257 -- per-SNP F test of y ~ X + snp.  M = I - QQ' (:215-218) is idempotent, so
+        the closed form of the scan applies with A = M and w = M y."""
+        if with_betas or Z is not None:
+            raise NotImplementedError("fast_f_test(with_betas / Z) is not on the device path")
+        ctx = self.ctx
+        y = self.Y.reshape(-1)
+        (h0_betas, _r, h0_rank, h0_s) = linalg.lstsq(self.X, y)          # :210
+        r = y - self.X @ h0_betas
+        h0_rss = float(r @ r)
+        (Q, R) = linalg.qr(self.X, mode='economic')                       # :214
+        A = np.eye(self.n) - Q @ Q.T                                      # :218
+        n_p = self.n - (self.X.shape[1] + 1)
+        own = not isinstance(snps, _lib.Geno)
+        g = ctx.geno(kinship._as_snp_matrix(snps)) if own else snps
+        try:
+            ctx.scan_set_model(A, r, ndigits)
+            out = ctx.scan(g, h0_rss, n_p)
+        finally:
+            if own:
+                g.close()
+        return {'ps': out['ps'], 'f_stats': out['f_stats'], 'rss': out['rss'], 'var_perc': 1 - out['rss'] / h0_rss,
+                'h0_rss': np.array([h0_rss]), 'h0_betas': [float(b) for b in h0_betas]}
+
+
 class LinearMixedModel(object):
     """linear_models.py:554 (and the parts of LinearModel :81 it inherits on this path)."""
 
@@ -478,6 +546,15 @@ def emma(snps, phenotypes, K, cofactors=None, ctx=None):
         for cofactor in cofactors:
             lmm.add_factor(cofactor)
     return lmm.expedited_REML_t_test(list(np.asarray(snps)))
+
+
+def linear_model(snps, phenotypes, cofactors=None, ctx=None):
+    """:3168-3183 -- standard linear model GWAS (no kinship)."""
+    lm_ = LinearModel(phenotypes, ctx=ctx)
+    if cofactors:
+        for cofactor in cofactors:
+            lm_.add_factor(cofactor)
+    return lm_.fast_f_test(snps)
 
 
 def emmax_perm_test(snps, phenotypes, K, num_perm=100, perm_idx=None, ctx=None):

@@ -270,6 +270,75 @@ def emmax(snps, y, K, cofactors=None):
     return res
 
 
+def linear_model(snps, y, cofactors=None):
+    """linear_models.py:3168-3183 -> LinearModel.fast_f_test (:196-257): the scan with H = I."""
+    y = np.asarray(y, dtype=np.float64)
+    n = len(y)
+    X = np.ones((n, 1))
+    if cofactors is not None:
+        for c in cofactors:
+            X = np.hstack([X, np.asarray(c, dtype=np.float64).reshape(n, 1)])
+    prep = scan_prepare(y, X, np.eye(n))
+    return scan_closed(snps, prep)
+
+
+def ibs_diploid_unscaled(snps):
+    """kinship.py:33-41,51 ('diploid_int', scaled=False): k_ij = #(|a-b|=0) + 0.5 #(|a-b|=1) for
+    i != j, divided by M, plus the identity."""
+    S = np.asarray(snps, dtype=np.int64)
+    m, n = S.shape
+    k = np.zeros((n, n))
+    for i in range(n):
+        d = np.abs(S[:, i:i + 1] - S)                       # M x N
+        k[i] = (d == 0).sum(0) + 0.5 * (d == 1).sum(0)
+    np.fill_diagonal(k, 0.0)
+    return k / float(m) + np.eye(n)
+
+
+def exact_emma(snps, y, X, K, eigL=None, ngrids=50, llim=-4, ulim=10, esp=1e-6):
+    """expedited_REML_t_test (linear_models.py:931-968): get_estimates with xs = snp per SNP
+    (:782-788, :914-926).  K must already be scaled as the model holds it."""
+    y = np.asarray(y, dtype=np.float64)
+    X = np.asarray(X, dtype=np.float64)
+    n = len(y)
+    if eigL is None:
+        eigL = eig_L(K)
+    out = {k: [] for k in ('ps', 'f_stats', 'rss', 'var_perc')}
+    for s in np.asarray(snps, dtype=np.float64):
+        Xf = np.hstack([X, s.reshape(n, 1)])
+        est = get_estimates(y, Xf, K, eigL=eigL, eigR=None, ngrids=ngrids, llim=llim, ulim=ulim, esp=esp)
+        H = est['H_sqrt_inv']
+        h0_X = H @ X
+        Yt = H @ y
+        b0, _, _, _ = linalg.lstsq(h0_X, Yt)
+        h0_rss = float(np.sum((Yt - h0_X @ b0) ** 2))
+        p = n - Xf.shape[1]
+        f = (h0_rss / est['mahalanobis_rss'] - 1) * p            # :921 (one SNP column)
+        out['f_stats'].append(f)
+        out['ps'].append(float(stats.f.sf(f, 1, p)))
+        out['rss'].append(est['rss'])
+        out['var_perc'].append(1.0 - est['mahalanobis_rss'] / h0_rss)
+    return {k: np.asarray(v) for k, v in out.items()}
+
+
+def emmax_with_emma(snps, y, K, cofactors=None, emma_num=15):
+    """emmax(..., emma_num > 0): EMMAX scan, then the emma_num smallest p-values are replaced by the
+    exact-EMMA values (linear_models.py:1365-1377)."""
+    res = emmax(snps, y, K, cofactors=cofactors)
+    y = np.asarray(y, dtype=np.float64)
+    n = len(y)
+    X = np.ones((n, 1))
+    if cofactors is not None:
+        for c in cofactors:
+            X = np.hstack([X, np.asarray(c, dtype=np.float64).reshape(n, 1)])
+    order = np.argsort(res['ps'], kind='stable')[:emma_num]
+    top = exact_emma(np.asarray(snps)[order], y, X, scale_k(K))
+    for k in ('ps', 'f_stats', 'rss', 'var_perc'):
+        res[k] = np.array(res[k], dtype=np.float64)
+        res[k][order] = top[k]
+    return res
+
+
 # ----------------------------------------------------------------------------- permutations
 def perm_prepare(y, X, H_sqrt_inv, perm_idx):
     """SNP-independent part of _emmax_permutations_ (linear_models.py:1135-1156).

@@ -88,6 +88,21 @@ def run_case(mods, snps, y, cof, nperm, perm_seed):
     wb = quiet(lmm2.emmax_f_test, snp_list[:200], with_betas=True, emma_num=0)
     out['wb_ps'] = np.asarray(wb['ps'], dtype=np.float64)
     out['wb_betas'] = np.asarray(wb['betas'], dtype=np.float64)
+    # plain linear model (LinearModel.fast_f_test through linear_model(), linear_models.py:3168, :196)
+    lres = quiet(lm.linear_model, snp_list, list(y), cofactors=cof)
+    for k in ('ps', 'f_stats', 'rss'):
+        out['lm_' + k] = np.asarray(lres[k], dtype=np.float64).reshape(-1)
+    out['lm_h0_rss'] = np.asarray(lres['h0_rss'], dtype=np.float64).reshape(-1)
+    # exact-EMMA refinement of the top hits (emma_num > 0, linear_models.py:1365-1377)
+    if len(y) <= 160:
+        eres = quiet(lm.emmax, snp_list, list(y), k_ibs, cofactors=cof, emma_num=15)
+        for k in ('ps', 'f_stats', 'rss', 'var_perc'):
+            out['emma15_' + k] = np.asarray(eres[k], dtype=np.float64).reshape(-1)
+        # 'diploid_int' IBS kinship (kinship.py:33-41) on 0/1/2 genotypes
+        half = len(snps) // 2
+        dip = (snps[:half] + snps[half:2 * half]).astype(np.int8)
+        out['dip_ibs_unscaled'] = np.asarray(quiet(kin.calc_ibs_kinship, list(dip), snps_data_format='diploid_int',
+                                                   scaled=False), dtype=np.float64)
     # permutations (intercept only in the reference: h0_X * list-of-floats needs q == 1)
     if cof is None and nperm:
         lmm3 = lm.LinearMixedModel(list(y))
@@ -134,7 +149,7 @@ def main():
                 'y': y, 'cofactors': np.asarray(cof) if cof is not None else np.zeros((0, n))}
         for mode, mm in mods.items():
             for k, v in run_case(mm, snps, y, cof, nperm, 1000 + seed).items():
-                if mode == 'lit' and k.startswith(('ibs_', 'scale_k_')):
+                if mode == 'lit' and k.startswith(('ibs_', 'scale_k_', 'dip_')):
                     continue          # float64 in both modes and bit-identical (checked below)
                 if k == 'ibs_unscaled':   # store the exact integer counts C = (K - 0.5) * 2M
                     c = (v - 0.5) * 2 * len(snps)

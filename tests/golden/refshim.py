@@ -47,6 +47,9 @@ def _install_aliases():
             sys.modules["h5py"] = types.ModuleType("h5py")
     import pickle
     sys.modules.setdefault("cPickle", pickle)
+    import itertools
+    if not hasattr(itertools, "izip"):      # `import itertools as it; it.izip(...)` escapes lib2to3
+        itertools.izip = zip
     try:
         import matplotlib
         matplotlib.use("Agg")

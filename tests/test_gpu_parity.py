@@ -366,3 +366,56 @@ def test_emmax_perm_test_surface(ctx):
                              perm_idx=[np.random.RandomState(p).permutation(150) for p in range(40)])
     assert len(res["min_ps"]) == 40 and np.all(res["min_ps"] > 0) and np.all(res["min_ps"] <= 1)
     assert res["threshold_05"] == sorted(zip(res["min_ps"], res["max_f_stats"]))[2]
+
+
+# ------------------------------------------------------------------ "next" rows
+def test_linear_model_fast_f_test_vs_golden(ctx, case):
+    """N4: LinearModel.fast_f_test / linear_model() = the scan with H = I."""
+    from mixmogam_amd import linear_models as lm
+    res = lm.linear_model(list(case["snps"]), list(case["y"]), cofactors=case["cof"])
+    assert rel(res["h0_rss"], case["dbl_lm_h0_rss"]) < 1e-9
+    assert rel(res["rss"], case["dbl_lm_rss"]) < 1e-8
+    assert rel(res["ps"], case["dbl_lm_ps"]) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["struct_n150_s0", "struct_n150_s1"])
+def test_diploid_int_kinship_bit_exact(ctx, name):
+    """N4: 'diploid_int' IBS kinship from two exact indicator GEMMs (kinship.py:33-41)."""
+    from mixmogam_amd import kinship
+    case = load_case(name)
+    half = len(case["snps"]) // 2
+    dip = (case["snps"][:half] + case["snps"][half:2 * half]).astype(np.int8)
+    k = kinship.calc_ibs_kinship(list(dip), snps_data_format='diploid_int', scaled=False)
+    assert np.array_equal(k, case["dbl_dip_ibs_unscaled"])
+    g = ctx.geno(dip)
+    for thr in (1, 2):
+        u = (dip >= thr).astype(np.int64)
+        assert np.array_equal(ctx.kinship_indicator_counts(g, thr), u.T @ u)
+
+
+@pytest.mark.parametrize("name", ["struct_n150_s0", "struct_n150_s1"])
+def test_exact_emma_refinement_vs_golden(ctx, name):
+    """N2: emma_num > 0 -- the top hits are re-estimated with one device eigh per SNP."""
+    from mixmogam_amd import linear_models as lm
+    case = load_case(name)
+    res = lm.emmax(case["snps"], list(case["y"]), case["dbl_ibs_scaled"], cofactors=case["cof"], emma_num=15)
+    assert rel(res["ps"], case["dbl_emma15_ps"]) < 1e-5
+    changed = np.argsort(case["dbl_emmax_ps"], kind="stable")[:15]
+    assert rel(res["rss"][changed], case["dbl_emma15_rss"][changed]) < 1e-6
+    assert rel(res["f_stats"][changed], case["dbl_emma15_f_stats"][changed]) < 1e-5
+
+
+def test_snp_priors_bayes_factors(ctx):
+    """N1 ingredient: snp_priors -> bfs / pos / ppas (linear_models.py:1311-1314,1357-1363)."""
+    from mixmogam_amd import linear_models as lm
+    case = load_case("struct_n150_s0")
+    m = len(case["snps"])
+    lmm = lm.LinearMixedModel(list(case["y"]))
+    lmm.add_random_effect(case["dbl_ibs_scaled"])
+    pri = np.full(m, 1.0 / m)
+    res = lmm.emmax_f_test(case["snps"], snp_priors=pri, emma_num=0)
+    n = 150
+    h0 = float(res["h0_rss"][0])
+    bfs = np.exp(((np.log(h0) - np.log(res["rss"])) * n - np.log(n)) / 2)
+    assert rel(res["bfs"], bfs) < 1e-12
+    assert rel(res["ppas"], (bfs * pri / (1 - pri)) / (1 + bfs * pri / (1 - pri))) < 1e-12
