@@ -137,11 +137,12 @@ __device__ __forceinline__ void run_tiles_ring(int ntiles, int64_t ldP, int64_t 
 
 // ---------------------------------------------------------------------------------------------
 // Flattened tile stream over the 2-slot / 128-byte K-step layout of gemm_i8_core.h: one barrier per
-// 32 MFMA per wave, the first stage of the next tile is already in flight while the epilogue of the
-// current tile runs.
-template <class TileFn, class EpiFn>
+// 32 MFMA per wave; the first stage of the next tile is already in flight while the epilogue of the
+// current tile runs.  hook(ct, ks, nks, stage_ptr) is called once per K step while that step's
+// stage is readable in LDS (the scan captures its epilogue operands from the Q tile there).
+template <class TileFn, class HookFn, class EpiFn>
 __device__ __forceinline__ void run_tiles_flat2(int ntiles, int64_t ldP, int64_t ldQ, char* lds, TileFn tile,
-                                                EpiFn epi) {
+                                                HookFn hook, EpiFn epi) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -185,7 +186,9 @@ __device__ __forceinline__ void run_tiles_flat2(int ntiles, int64_t ldP, int64_t
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       issue_one();                                        // stage t+1 -> the slot step t-1 used
-      mma_kstep(lds + (t & 1) * BUF_BYTES, wm, wn, lane, acc);
+      const char* cur = lds + (t & 1) * BUF_BYTES;
+      hook(ct, ks, cd.nks, cur);
+      mma_kstep(cur, wm, wn, lane, acc);
     }
     epi(ct, acc);
   }

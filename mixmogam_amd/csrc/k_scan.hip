@@ -109,24 +109,108 @@ __global__ __launch_bounds__(NTHREADS, 2) void scan_quad_kernel(
     const int8_t* P = Bq + (int64_t)d * digit_stride + (int64_t)J * TM * ldB;
     v16i acc[4][2];
     gemm_tile_i8<ABLATE>(P, ldB, Q, ldS, 0, 2 * (J + 1), lds, acc);
-    // epilogue: lane holds SNP column n = wn*64 + nn*32 + r and rows j = wm*128 + m*32 +
+    // Epilogue: lane holds SNP column n = wn*64 + nn*32 + r and rows j = wm*128 + m*32 +
     // (reg&3) + 8*(reg>>2) + 4*h of T = Z_d(J-tile rows) . S^T; multiply by s[snp][256J + j].
+    // Those genotype bytes are the Q tiles of the job's last two K steps (k = 256J .. 256J+255),
+    // which are still in LDS: K step 2J sits in buffer 0, 2J+1 in buffer 1 (stage parity), and
+    // no stage was issued during the last step.  Wave row half wm reads buffer wm: 8 conflict-free
+    // ds_read_b128 per SNP instead of 16 scattered global dword loads.
+    const char* qbuf = lds + wm * BUF_BYTES + TILE_BYTES;
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
-      const int8_t* srow = Q + (int64_t)(wn * 64 + nn * 32 + r) * ldS + J * TM + wm * 128 + 4 * h;
+      const int qrow = wn * 64 + nn * 32 + r;
+      long long part = 0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const v4i ch = lds_frag(qbuf, qrow, 2 * m + cc);       // bytes m*32 + cc*16 .. +16 of the row
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp) {                        // g4 = 2*cc + gp; dword (gp*2 + h)
+            const int wd = h ? ch[gp * 2 + 1] : ch[gp * 2];
+            const int g4 = 2 * cc + gp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              part += (long long)acc[m][nn][g4 * 4 + e] * (long long)(int)(int8_t)((wd >> (8 * e)) & 0xff);
+          }
+        }
+      qacc[nn] += ((unsigned long long)part) << (8 * d);
+    }
+    __syncthreads();   // the next job's prologue refills buffer 0
+  }
+#pragma unroll
+  for (int nn = 0; nn < 2; ++nn) {
+    unsigned long long v = qacc[nn];
+    v += __shfl_xor(v, 32);
+    if (h == 0) atomicAdd(q + (int64_t)sb * TN + wn * 64 + nn * 32 + r, v);
+  }
+}
+
+// Flattened-pipeline flavour: the workgroup's jobs form one K-step stream (gemm_i8_ring.h
+// run_tiles_flat2); the epilogue operands (genotype bytes of the job's diagonal block) are captured
+// from the Q tile in LDS while the matching K step is resident, so the next job's first stage can be
+// in flight during the epilogue.
+__global__ __launch_bounds__(NTHREADS, 2) void scan_quad_flat_kernel(
+    const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Bq, int64_t ldB,
+    int64_t digit_stride, const int* __restrict__ job_off, const int2* __restrict__ jobs, int AS,
+    unsigned long long* __restrict__ q) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int b = blockIdx.x;
+  const int x = b & 7, i = b >> 3;
+  const int cohort = i >> 5, within = i & 31;
+  const int a = within % AS, grp = within / AS;
+  const int sb = (cohort * 8 + x) * AS + a;
+  if (sb >= nSb) return;
+  const int j0 = job_off[grp], j1 = job_off[grp + 1];
+  if (j1 <= j0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 2, wn = wave & 3, h = lane >> 5, r = lane & 31;
+  const int8_t* Q = S + (int64_t)sb * TN * ldS;
+  unsigned long long qacc[2] = {0ull, 0ull};
+  int2* jl = (int2*)(lds + LDS_BYTES);
+  for (int t = threadIdx.x; t < j1 - j0; t += NTHREADS) jl[t] = jobs[j0 + t];
+  __syncthreads();
+  int sv[2][16];                       // this lane's 64 genotype bytes per SNP column for the epilogue
+  auto tile = [&](int t) {
+    const int2 jb = jl[t];
+    TileDesc d;
+    d.P = Bq + (int64_t)jb.x * digit_stride + (int64_t)jb.y * TM * ldB;
+    d.Q = Q;
+    d.nks = 2 * (jb.y + 1);
+    return d;
+  };
+  auto hook = [&](int t, int ks, int nks, const char* stage) {
+    if (ks != nks - 2 + wm) return;    // K step 2J + wm holds columns 256J + wm*128 .. +127
+    const char* qt = stage + TILE_BYTES;
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
+      const int qrow = wn * 64 + nn * 32 + r;
+#pragma unroll
+      for (int c8 = 0; c8 < 8; ++c8) {
+        const v4i ch = lds_frag(qt, qrow, c8);
+        sv[nn][c8 * 2 + 0] = h ? ch[1] : ch[0];
+        sv[nn][c8 * 2 + 1] = h ? ch[3] : ch[2];
+      }
+    }
+  };
+  auto epi = [&](int t, v16i (&acc)[4][2]) {
+    const int d = jl[t].x;
+#pragma unroll
+    for (int nn = 0; nn < 2; ++nn) {
       long long part = 0;
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          const int wd = *(const int*)(srow + m * 32 + 8 * g4);
+          const int wd = sv[nn][(2 * m + (g4 >> 1)) * 2 + (g4 & 1)];
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             part += (long long)acc[m][nn][g4 * 4 + e] * (long long)(int)(int8_t)((wd >> (8 * e)) & 0xff);
         }
       qacc[nn] += ((unsigned long long)part) << (8 * d);
     }
-  }
+  };
+  run_tiles_flat2(j1 - j0, ldB, ldS, lds, tile, hook, epi);
 #pragma unroll
   for (int nn = 0; nn < 2; ++nn) {
     unsigned long long v = qacc[nn];
@@ -212,7 +296,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void scan_quad_ring_kernel(
     TileDesc d;
     d.P = Bq + (int64_t)jb.x * digit_stride + (int64_t)jb.y * TM * ldB;
     d.Q = Q;
-    d.nks = (PINGPONG == 2 ? 2 : 4) * (jb.y + 1);
+    d.nks = 4 * (jb.y + 1);
     return d;
   };
   auto epi = [&](int t, v16i (&acc)[4][2]) {
@@ -235,7 +319,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void scan_quad_ring_kernel(
     }
   };
   if (PINGPONG == 1) run_tiles_pingpong(j1 - j0, ldB, ldS, lds, tile, epi);
-  else if (PINGPONG == 2) run_tiles_flat2(j1 - j0, ldB, ldS, lds, tile, epi);
   else run_tiles_ring(j1 - j0, ldB, ldS, lds, tile, epi);
 #pragma unroll
   for (int nn = 0; nn < 2; ++nn) {
@@ -333,8 +416,8 @@ void launch_scan_quad(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md,
   }
   if (ablate == 0 && kv && std::string(kv) == "flat") {
     const int lds_bytes = LDS_BYTES + 8 * std::max(1, md.njobs);
-    hipFuncSetAttribute((const void*)scan_quad_ring_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    hipLaunchKernelGGL(scan_quad_ring_kernel<2>, dim3((unsigned)(ncoh * 256)), dim3(NTHREADS), lds_bytes, ctx->stream,
+    hipFuncSetAttribute((const void*)scan_quad_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(scan_quad_flat_kernel, dim3((unsigned)(ncoh * 256)), dim3(NTHREADS), lds_bytes, ctx->stream,
                        g->d, (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad, (int64_t)md.Npad * md.Npad,
                        md.job_off, md.jobs, md.AS, q);
     return;
