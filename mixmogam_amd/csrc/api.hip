@@ -177,6 +177,7 @@ int mmg_geno_destroy(mmg_ctx* ctx, mmg_geno* g) {
   if (!g) return MMG_OK;
   if (ctx) hipStreamSynchronize(ctx->stream);
   hipFree(g->d);
+  hipFree(g->bits);
   delete g;
   return MMG_OK;
 }
@@ -185,6 +186,7 @@ int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, i
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, g && snps && m0 >= 0 && rows >= 0 && m0 + rows <= g->M);
   if (rows == 0) return MMG_OK;
+  g->bits_valid = false;
   MMG_HIP(ctx, hipMemcpy2DAsync(g->d + m0 * (int64_t)g->Npad, g->Npad, snps, g->N, g->N, rows,
                                 hipMemcpyHostToDevice, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -196,6 +198,7 @@ template <typename T>
 static int upload_cvt(mmg_ctx* ctx, mmg_geno* g, const T* snps, int64_t m0, int64_t rows) {
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, g && snps && m0 >= 0 && rows >= 0 && m0 + rows <= g->M);
+  g->bits_valid = false;
   const int64_t chunk = std::max<int64_t>(1, (int64_t)(256 << 20) / ((int64_t)g->N * sizeof(T)));
   T* tmp = nullptr;
   MMG_HIP(ctx, hipMalloc(&tmp, (size_t)std::min(chunk, rows) * g->N * sizeof(T)));
@@ -231,6 +234,7 @@ int mmg_geno_fill_hash(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_globa
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, g != nullptr && thr16 <= 65536);
   if (g->M == 0) return MMG_OK;
+  g->bits_valid = false;
   {
     EvScope ev(ctx, EV_PACK);
     launch_fill_hash(ctx, g, seed, m_global0, thr16);
@@ -577,10 +581,8 @@ int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2)
   ctx->res.M = g->M;
   if (g->M == 0) return MMG_OK;
   MMG_HIP(ctx, hipMemsetAsync(ctx->res.q, 0, g->Mpad * sizeof(unsigned long long), ctx->stream));
-  {
-    EvScope ev(ctx, EV_QUAD);
-    launch_scan_quad(ctx, g, ctx->model, ctx->res.q);
-  }
+  rc = run_scan_quad(ctx, g, ctx->model, ctx->res.q);
+  if (rc) return rc;
   MMG_HIP(ctx, hipGetLastError());
   {
     EvScope ev(ctx, EV_FIN);
@@ -734,7 +736,7 @@ int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const
     double c0 = 0.0;
     for (int i = 0; i < N; ++i) c0 += v[i];
     hipMemsetAsync(pr.q, 0, g->Mpad * sizeof(unsigned long long), ctx->stream);
-    launch_scan_quad(ctx, g, pm, pr.q);
+    rc = run_scan_quad(ctx, g, pm, pr.q);
     launch_scan_finalize(ctx, g, pm, pr, 1.0, 1, 0.0);              // den = s'A's, dot = s.v, sum = s.1
     launch_perm_center(ctx, g, pr, c0, dmu, dinv);                  // mu, 1/(s~'A's~)   (:1159)
     rc = run_perm(ctx, g, N, dWt, P, dinv, dmu, 4, dmax);

@@ -146,6 +146,62 @@ __device__ __forceinline__ void gemm_tile_i8_16(const int8_t* __restrict__ P, in
   }
 }
 
+// In-kernel stamp (diagnostic builds only): shader clock, with the lgkmcnt(0) the guide prescribes.
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+
+// Diagnostic twin of gemm_tile_i8: same loop, accumulates per-wave cycle sums of the four segments
+// of a K step into seg[0..3] = {issue DMA, LDS reads + MFMA issue, vmcnt(0) wait, barrier wait}.
+__device__ __forceinline__ void gemm_tile_i8_timed(const int8_t* __restrict__ P, int64_t ldP,
+                                                   const int8_t* __restrict__ Q, int64_t ldQ, int ks0, int ks1,
+                                                   char* lds, v16i (&acc)[4][2], unsigned long long (&seg)[5]) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0;
+  if (ks1 <= ks0) return;
+  const StageOp sp = make_stage_op(P, ldP, wave, lane);
+  const StageOp sq = make_stage_op(Q, ldQ, wave, lane);
+  unsigned long long tp = stamp();
+  stage_tile(sp, ks0 * BK, lds, wave);
+  stage_tile(sq, ks0 * BK, lds + TILE_BYTES, wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  seg[4] += stamp() - tp;                      // prologue
+  int cur = 0;
+  for (int ks = ks0; ks < ks1; ++ks) {
+    char* nb = lds + (cur ^ 1) * BUF_BYTES;
+    const unsigned long long t0 = stamp();
+    if (ks + 1 < ks1) {
+      stage_tile(sp, (ks + 1) * BK, nb, wave);
+      stage_tile(sq, (ks + 1) * BK, nb + TILE_BYTES, wave);
+    }
+    const unsigned long long t1 = stamp();
+    mma_kstep(lds + cur * BUF_BYTES, wm, wn, lane, acc);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) asm volatile("" : "+v"(acc[m][n]));   // pin the MFMAs before the stamp
+    const unsigned long long t2 = stamp();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t3 = stamp();
+    __syncthreads();
+    const unsigned long long t4 = stamp();
+    seg[0] += t1 - t0; seg[1] += t2 - t1; seg[2] += t3 - t2; seg[3] += t4 - t3;
+    cur ^= 1;
+  }
+}
+
 // Full K loop over k-steps [ks0, ks1) (units of BK bytes).  P / Q point at row 0 of the tile's
 // row range.  On return every wave has passed the final barrier (LDS free for reuse).
 // ABLATE (timing experiments only; results are wrong unless 0): 1 = no staging inside the loop,

@@ -17,6 +17,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <string>
+#include <vector>
+#include <cstdio>
 #include "gemm_i8_core.h"
 #include "gemm_i8_ring.h"
 #include "gemm_i8_w4.h"
@@ -143,6 +145,52 @@ __global__ __launch_bounds__(NTHREADS, 2) void scan_quad_kernel(
     unsigned long long v = qacc[nn];
     v += __shfl_xor(v, 32);
     if (h == 0) atomicAdd(q + (int64_t)sb * TN + wn * 64 + nn * 32 + r, v);
+  }
+}
+
+// Diagnostic build of scan_quad_kernel with in-kernel stamps (tools/prof_scan.py, MMG_SCAN_KERNEL=timed).
+// Stamps go to a buffer of their own (dbg); the q outputs are still produced but the run time of this
+// build is not quoted anywhere.
+__global__ __launch_bounds__(NTHREADS, 2) void scan_quad_timed_kernel(
+    const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Bq, int64_t ldB,
+    int64_t digit_stride, const int* __restrict__ job_off, const int2* __restrict__ jobs, int AS,
+    unsigned long long* __restrict__ q, unsigned long long* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int b = blockIdx.x;
+  const int x = b & 7, i = b >> 3;
+  const int cohort = i >> 5, within = i & 31;
+  const int a = within % AS, grp = within / AS;
+  const int sb = (cohort * 8 + x) * AS + a;
+  if (sb >= nSb) return;
+  const int j0 = job_off[grp], j1 = job_off[grp + 1];
+  if (j1 <= j0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int8_t* Q = S + (int64_t)sb * TN * ldS;
+  unsigned long long seg[5] = {0, 0, 0, 0, 0};
+  unsigned long long tepi = 0, ksteps = 0;
+  const unsigned long long tstart = stamp();
+  for (int jj = j0; jj < j1; ++jj) {
+    const int2 jb = jobs[jj];
+    const int8_t* P = Bq + (int64_t)jb.x * digit_stride + (int64_t)jb.y * TM * ldB;
+    v16i acc[4][2];
+    gemm_tile_i8_timed(P, ldB, Q, ldS, 0, 2 * (jb.y + 1), lds, acc, seg);
+    ksteps += 2 * (jb.y + 1);
+    const unsigned long long te = stamp();
+    long long part = 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) part += acc[m][n][e];
+    if (part == 0x7fffffffffffll) q[0] = 1;      // keep the accumulators alive
+    __syncthreads();
+    tepi += stamp() - te;
+  }
+  const unsigned long long ttot = stamp() - tstart;
+  if (lane == 0 && b < 2048) {
+    unsigned long long* o = dbg + ((size_t)b * 8 + wave) * 8;
+    o[0] = seg[0]; o[1] = seg[1]; o[2] = seg[2]; o[3] = seg[3]; o[4] = seg[4]; o[5] = tepi; o[6] = ttot; o[7] = ksteps;
   }
 }
 
@@ -405,6 +453,32 @@ void launch_scan_quad(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md,
     hipLaunchKernelGGL(scan_quad_w4_kernel, dim3((unsigned)(ncoh * 256)), dim3(W4_THREADS), lds_bytes, ctx->stream,
                        g->d, (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad, (int64_t)md.Npad * md.Npad,
                        md.job_off, md.jobs, md.AS, q);
+    return;
+  }
+  if (ablate == 0 && kv && std::string(kv) == "timed") {
+    static unsigned long long* dbg = nullptr;
+    if (!dbg) hipMalloc(&dbg, (size_t)2048 * 8 * 8 * sizeof(unsigned long long));
+    hipMemsetAsync(dbg, 0, (size_t)2048 * 8 * 8 * sizeof(unsigned long long), ctx->stream);
+    hipFuncSetAttribute((const void*)scan_quad_timed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipLaunchKernelGGL(scan_quad_timed_kernel, dim3((unsigned)(ncoh * 256)), dim3(NTHREADS), LDS_BYTES, ctx->stream,
+                       g->d, (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad, (int64_t)md.Npad * md.Npad,
+                       md.job_off, md.jobs, md.AS, q, dbg);
+    std::vector<unsigned long long> h((size_t)2048 * 64);
+    hipMemcpyAsync(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+    hipStreamSynchronize(ctx->stream);
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long cnt = 0;
+    for (size_t w = 0; w < (size_t)2048 * 8; ++w) {
+      if (h[w * 8 + 7] == 0) continue;
+      for (int k = 0; k < 8; ++k) s[k] += (double)h[w * 8 + k];
+      ++cnt;
+    }
+    if (cnt) {
+      const double ks = s[7] / cnt;
+      fprintf(stderr, "[timed] waves %ld  K-steps/wave %.0f  per K-step cycles: issueDMA %.0f  lds+mfma %.0f  vmcnt %.0f  barrier %.0f | "
+                      "per wave: prologues %.0f  epilogues %.0f  total %.0f cycles\n",
+              cnt, ks, s[0] / s[7], s[1] / s[7], s[2] / s[7], s[3] / s[7], s[4] / cnt, s[5] / cnt, s[6] / cnt);
+    }
     return;
   }
   if (ablate == 0 && kv && std::string(kv) == "m16") {

@@ -10,6 +10,9 @@ struct mmg_geno {
   int64_t M = 0, Mpad = 0;      // SNPs, padded to 256
   int32_t N = 0, Npad = 0;      // individuals, padded to 256
   int8_t* d = nullptr;          // [Mpad x Npad] SNP-major, zero padded
+  // lazily built bit-packed twin [Mpad x Npad/8] (k_scan_bits.hip); invalidated by every write
+  uint8_t* bits = nullptr;
+  bool bits_valid = false, binary = false;
 };
 
 enum { EV_KIN = 0, EV_QUAD = 1, EV_FIN = 2, EV_PERM = 3, EV_EIGH = 4, EV_PACK = 5, EV_COUNT = 6 };
@@ -90,6 +93,11 @@ void launch_absmax_offdiag(mmg_ctx*, const double* A, int32_t N, unsigned long l
 void launch_quantize(mmg_ctx*, const double* A, int32_t N, int32_t Npad, int D, double inv_step,
                      int8_t* Bq, double* diag);
 void launch_scan_quad(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
+// ---- k_scan_bits.hip (binary genotypes staged as bits)
+int ensure_bits(mmg_ctx*, mmg_geno*);
+void launch_scan_quad_bits(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
+// picks the bit-packed kernel for 0/1 genotypes unless MMG_SCAN_KERNEL names another variant
+int run_scan_quad(mmg_ctx*, mmg_geno*, const mmg_scan_model&, unsigned long long* q);
 void launch_scan_finalize(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, mmg_scan_result&,
                           double h0_rss, int32_t df2, double lnbeta);
 void launch_snp_dot(mmg_ctx*, const mmg_geno*, const double* v /*[Npad] dev*/, double* out /*[M] dev*/);
