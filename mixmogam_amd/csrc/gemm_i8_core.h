@@ -68,6 +68,17 @@ __device__ __forceinline__ void stage_tile(const StageOp& s, int k0, char* lds_t
   for (int i = 0; i < 4; ++i) stage_piece(s, k0, lds_tile, wave, i);
 }
 
+// Loader-wave form: wave w < 4 moves its own 32 rows AND the 32 rows of wave w+4 (rows +128: same
+// per-lane offsets, the row displacement goes into the scalar offset), so that waves 4-7 issue no DMA.
+__device__ __forceinline__ void stage_tile_pair(const StageOp& s, int k0, char* lds_tile, int wave) {
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rs, (MMG_AS3 void*)(lds_tile + ((wave + 4 * half) * 4 + i) * 1024), 16,
+                                               (i & 1) ? s.v_odd : s.v_even, k0 + (i + 16 * half) * s.ld8, 0, 0);
+}
+
 __device__ __forceinline__ v4i lds_frag(const char* tile, int row, int chunk) {
   return *(const v4i*)(tile + row * BK + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
@@ -204,9 +215,15 @@ __device__ __forceinline__ void gemm_tile_i8_timed(const int8_t* __restrict__ P,
 
 // Full K loop over k-steps [ks0, ks1) (units of BK bytes).  P / Q point at row 0 of the tile's
 // row range.  On return every wave has passed the final barrier (LDS free for reuse).
-// ABLATE (timing experiments only; results are wrong unless 0): 1 = no staging inside the loop,
-// 2 = staging only (no LDS reads, no MFMA), 3 = MFMA on registers only.
-template <int ABLATE = 0>
+// MODE 5 (default): only waves 0-3 issue the LDS-DMA of the next stage -- for their own rows and
+//   for the rows of their SIMD partner (wave w+4) -- so that waves 4-7 start their MFMAs right after
+//   the barrier while the loader waves are still queueing pieces behind the CU's single address
+//   path (in-kernel stamps: with all 8 waves loading, every wave spent ~650 of ~3000 cycles per
+//   K step issuing DMA with the MFMA pipe idle).  -4...5 % kernel time.
+// MODE 0: every wave stages its own rows (first version).
+// MODE 1/2/3 are timing ablations with WRONG results: 1 = no staging inside the loop, 2 = staging
+//   only (no LDS reads, no MFMA), 3 = MFMA on registers only.
+template <int ABLATE = 5>
 __device__ __forceinline__ void gemm_tile_i8(const int8_t* __restrict__ P, int64_t ldP,
                                              const int8_t* __restrict__ Q, int64_t ldQ,
                                              int ks0, int ks1, char* lds, v16i (&acc)[4][2]) {
@@ -236,7 +253,12 @@ __device__ __forceinline__ void gemm_tile_i8(const int8_t* __restrict__ P, int64
   }
   for (int ks = ks0; ks < ks1; ++ks) {
     char* nb = lds + (cur ^ 1) * BUF_BYTES;
-    if (ks + 1 < ks1 && ABLATE != 1 && ABLATE != 3) {
+    if (ABLATE == 5) {
+      if (ks + 1 < ks1 && wave < 4) {
+        stage_tile_pair(sp, (ks + 1) * BK, nb, wave);
+        stage_tile_pair(sq, (ks + 1) * BK, nb + TILE_BYTES, wave);
+      }
+    } else if (ks + 1 < ks1 && ABLATE != 1 && ABLATE != 3) {
       stage_tile(sp, (ks + 1) * BK, nb, wave);
       stage_tile(sq, (ks + 1) * BK, nb + TILE_BYTES, wave);
     }

@@ -437,8 +437,8 @@ void launch_scan_quad(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md,
   const int nSb = (int)(g->Mpad / TN);
   const int per = 8 * md.AS;
   const int ncoh = (nSb + per - 1) / per;
-  int ablate = 0;
-  if (const char* e = std::getenv("MMG_ABLATE")) ablate = std::atoi(e);   // timing experiments only
+  int ablate = 5;   // 5 = production (loader waves); 0 = symmetric staging; 1-3 timing ablations
+  if (const char* e = std::getenv("MMG_ABLATE")) ablate = std::atoi(e);
 #define MMG_LAUNCH_QUAD(AB)                                                                                       \
   do {                                                                                                            \
     hipFuncSetAttribute((const void*)scan_quad_kernel<AB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
@@ -447,7 +447,7 @@ void launch_scan_quad(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md,
                        md.job_off, md.jobs, md.AS, q);                                                            \
   } while (0)
   const char* kv = std::getenv("MMG_SCAN_KERNEL");
-  if (ablate == 0 && kv && std::string(kv) == "w4") {
+  if (ablate == 5 && kv && std::string(kv) == "w4") {
     const int lds_bytes = LDS_BYTES + 8 * std::max(1, md.njobs);
     hipFuncSetAttribute((const void*)scan_quad_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipLaunchKernelGGL(scan_quad_w4_kernel, dim3((unsigned)(ncoh * 256)), dim3(W4_THREADS), lds_bytes, ctx->stream,
@@ -455,7 +455,7 @@ void launch_scan_quad(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md,
                        md.job_off, md.jobs, md.AS, q);
     return;
   }
-  if (ablate == 0 && kv && std::string(kv) == "timed") {
+  if (ablate == 5 && kv && std::string(kv) == "timed") {
     static unsigned long long* dbg = nullptr;
     if (!dbg) hipMalloc(&dbg, (size_t)2048 * 8 * 8 * sizeof(unsigned long long));
     hipMemsetAsync(dbg, 0, (size_t)2048 * 8 * 8 * sizeof(unsigned long long), ctx->stream);
@@ -481,14 +481,14 @@ void launch_scan_quad(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md,
     }
     return;
   }
-  if (ablate == 0 && kv && std::string(kv) == "m16") {
+  if (ablate == 5 && kv && std::string(kv) == "m16") {
     hipFuncSetAttribute((const void*)scan_quad16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipLaunchKernelGGL(scan_quad16_kernel, dim3((unsigned)(ncoh * 256)), dim3(NTHREADS), LDS_BYTES, ctx->stream,
                        g->d, (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad, (int64_t)md.Npad * md.Npad,
                        md.job_off, md.jobs, md.AS, q);
     return;
   }
-  if (ablate == 0 && kv && std::string(kv) == "flat") {
+  if (ablate == 5 && kv && std::string(kv) == "flat") {
     const int lds_bytes = LDS_BYTES + 8 * std::max(1, md.njobs);
     hipFuncSetAttribute((const void*)scan_quad_flat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipLaunchKernelGGL(scan_quad_flat_kernel, dim3((unsigned)(ncoh * 256)), dim3(NTHREADS), lds_bytes, ctx->stream,
@@ -496,7 +496,7 @@ void launch_scan_quad(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md,
                        md.job_off, md.jobs, md.AS, q);
     return;
   }
-  if (ablate == 0 && kv && (std::string(kv) == "ring" || std::string(kv) == "pp")) {
+  if (ablate == 5 && kv && (std::string(kv) == "ring" || std::string(kv) == "pp")) {
     const int lds_bytes = LDS_BYTES + 8 * std::max(1, md.njobs);
     if (std::string(kv) == "ring") {
       hipFuncSetAttribute((const void*)scan_quad_ring_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -515,7 +515,8 @@ void launch_scan_quad(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md,
     case 1: MMG_LAUNCH_QUAD(1); break;
     case 2: MMG_LAUNCH_QUAD(2); break;
     case 3: MMG_LAUNCH_QUAD(3); break;
-    default: MMG_LAUNCH_QUAD(0); break;
+    case 0: MMG_LAUNCH_QUAD(0); break;
+    default: MMG_LAUNCH_QUAD(5); break;
   }
 #undef MMG_LAUNCH_QUAD
 }

@@ -31,9 +31,12 @@ w = rng.standard_normal(n)
 ctx.scan_set_model(A, w, 4)
 g = ctx.geno(snps)
 var = os.environ.pop("MMG_SCAN_KERNEL", None)
+abl = os.environ.pop("MMG_ABLATE", None)
 base = ctx.scan(g, 1e6, n - 2, stats=True)
 if var:
     os.environ["MMG_SCAN_KERNEL"] = var
+if abl:
+    os.environ["MMG_ABLATE"] = abl
 alt = ctx.scan(g, 1e6, n - 2, stats=True)
 same = all(np.array_equal(base[k], alt[k]) for k in ("rss", "den", "ps"))
 S = snps.astype(float)
