@@ -419,3 +419,19 @@ def test_snp_priors_bayes_factors(ctx):
     bfs = np.exp(((np.log(h0) - np.log(res["rss"])) * n - np.log(n)) / 2)
     assert rel(res["bfs"], bfs) < 1e-12
     assert rel(res["ppas"], (bfs * pri / (1 - pri)) / (1 + bfs * pri / (1 - pri))) < 1e-12
+
+
+def test_examples_mixed_model_gwas_call_sequence(ctx, tmp_path):
+    """BASELINE configs[0]: the examples.py:65-102 call sequence on the real FT10 phenotype (198 accessions)
+    with synthetic genotypes, against the oracle."""
+    import examples
+    out = str(tmp_path / "mm.pvals")
+    res, sd, phend, K = examples.mixed_model_gwas(pvalue_file=out, num_snps=20000)
+    snps = np.asarray(sd.get_snps())
+    y = np.asarray(phend.get_values(5))
+    assert snps.shape[1] == 198 == len(y)
+    assert rel(K, orc.calc_ibs_kinship(snps)) < 1e-13
+    ref = orc.emmax(snps, y, K)
+    assert rel(res["ps"], ref["ps"]) < 1e-6
+    lines = open(out).read().splitlines()
+    assert lines[0] == "chromosomes,positions,scores" and len(lines) == len(snps) + 1
