@@ -34,6 +34,7 @@ extern "C" {
 typedef struct mmg_ctx mmg_ctx;
 typedef struct mmg_geno mmg_geno;    /* device-resident padded genotype store */
 typedef struct mmg_comm mmg_comm;    /* RCCL communicator, one rank per process */
+typedef struct mmg_kin_acc mmg_kin_acc;  /* device-resident N x N kinship accumulator */
 
 /* ---- library / context -------------------------------------------------------------- */
 int mmg_version(void);
@@ -95,6 +96,13 @@ int mmg_kinship_indicator_i8(mmg_ctx* ctx, mmg_geno* g, int32_t thr, int64_t* C_
  * C_out: host double [N x N] (fp32 partial tiles per K-split, summed in fp64 in fixed order). */
 int mmg_kinship_affine_f32(mmg_ctx* ctx, mmg_geno* g, const float* scale, const float* shift,
                            double* C_out);
+/* Chunked / streamed genotypes: the `k_mat += x'x` loop of hdf5_data.py:99-106 / kinship.py:63-69 with the
+ * N x N sum kept in HBM between chunks.  add: acc += sum_m x_m x_m' over the SNPs of g (same affine map as
+ * mmg_kinship_affine_f32; NULL/NULL = 2s-1); fetch: host double [N x N] and the SNP count so far. */
+int mmg_kin_acc_create(mmg_ctx* ctx, int32_t N, mmg_kin_acc** acc);
+int mmg_kin_acc_add(mmg_ctx* ctx, mmg_kin_acc* acc, mmg_geno* g, const float* scale, const float* shift);
+int mmg_kin_acc_fetch(mmg_ctx* ctx, mmg_kin_acc* acc, double* C_out, int64_t* n_snps);
+int mmg_kin_acc_destroy(mmg_ctx* ctx, mmg_kin_acc* acc);
 /* One-shot twin taking host genotypes: upload + mmg_kinship_affine_f32 / _ibs_i8. */
 int mmg_kinship_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N,
                    const float* scale, const float* shift, double* C_out);

@@ -48,6 +48,10 @@ PROTOTYPES = {
     "mmg_kinship_ibs_i8": (C.c_int, [c_vp, c_vp, c_vp]),
     "mmg_kinship_indicator_i8": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp]),
     "mmg_kinship_affine_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mmg_kin_acc_create": (C.c_int, [c_vp, C.c_int32, C.POINTER(c_vp)]),
+    "mmg_kin_acc_add": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mmg_kin_acc_fetch": (C.c_int, [c_vp, c_vp, c_vp, c_i64p]),
+    "mmg_kin_acc_destroy": (C.c_int, [c_vp, c_vp]),
     "mmg_kinship_i8": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp, c_vp, c_vp]),
     "mmg_eigh_f64": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp]),
     "mmg_dgemm_f64": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_int32, c_vp, c_vp, c_vp]),
@@ -161,6 +165,38 @@ class Geno(object):
             pass
 
 
+class KinshipAccumulator(object):
+    """Device-resident sum of x x' over successive genotype chunks (mmg_kin_acc_*)."""
+
+    def __init__(self, ctx, N):
+        self.ctx, self.N = ctx, int(N)
+        h = c_vp()
+        ctx._check(ctx.lib.mmg_kin_acc_create(ctx.h, self.N, C.byref(h)))
+        self.h = h
+
+    def add(self, g, scale=None, shift=None):
+        sc = None if scale is None else _arr(scale, np.float32)
+        sh = None if shift is None else _arr(shift, np.float32)
+        self.ctx._check(self.ctx.lib.mmg_kin_acc_add(self.ctx.h, self.h, g.h, _ptr(sc), _ptr(sh)))
+
+    def fetch(self):
+        out = np.empty((self.N, self.N))
+        n = C.c_int64(0)
+        self.ctx._check(self.ctx.lib.mmg_kin_acc_fetch(self.ctx.h, self.h, _ptr(out), C.byref(n)))
+        return out, n.value
+
+    def close(self):
+        if self.h is not None:
+            self.ctx.lib.mmg_kin_acc_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context(object):
     """One HIP device context (stream, scan model, result buffers)."""
 
@@ -239,6 +275,9 @@ class Context(object):
         sh = None if shift is None else _arr(shift, np.float32)
         self._check(self.lib.mmg_kinship_affine_f32(self.h, g.h, _ptr(sc), _ptr(sh), _ptr(out)))
         return out
+
+    def kinship_accumulator(self, N):
+        return KinshipAccumulator(self, N)
 
     # --- dense fp64 helpers
     def eigh(self, A, vectors=True):

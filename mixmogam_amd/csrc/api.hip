@@ -322,28 +322,26 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
   return rc;
 }
 
-int mmg_kinship_affine_f32(mmg_ctx* ctx, mmg_geno* g, const float* scale, const float* shift, double* C_out) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
-  MMG_CHECK_ARG(ctx, g && C_out && g->M > 0);
-  MMG_CHECK_ARG(ctx, (scale == nullptr) == (shift == nullptr));
+// dC [N x N] (device, fp64) (+)= sum_m x_m x_m', x_m = scale[m] s_m + shift[m]
+static int kinship_affine_into(mmg_ctx* ctx, mmg_geno* g, const float* scale, const float* shift, double* dC,
+                               bool accumulate) {
   const int64_t CH = kin_chunk();
   const int64_t Mk_all = round_up(g->M, BK);
   const int64_t Mk_max = std::min(Mk_all, CH);
   const int ksplit_max = kinship_pick_ksplit(g->Npad, Mk_max, true);
   int8_t* Xt = nullptr;
   float *dsc = nullptr, *dsh = nullptr, *slabs = nullptr;
-  double* dC = nullptr;
   hipError_t e = hipMalloc(&Xt, (size_t)g->Npad * Mk_max);
   if (e != hipSuccess) return set_err(ctx, MMG_E_NOMEM, "hipMalloc transposed genotype image");
   MMG_HIP(ctx, hipMalloc(&dsc, Mk_all * sizeof(float)));
   MMG_HIP(ctx, hipMalloc(&dsh, Mk_all * sizeof(float)));
   MMG_HIP(ctx, hipMalloc(&slabs, (size_t)ksplit_max * g->Npad * g->Npad * sizeof(float)));
-  MMG_HIP(ctx, hipMalloc(&dC, (size_t)g->N * g->N * sizeof(double)));
   MMG_HIP(ctx, hipMemsetAsync(dsc, 0, Mk_all * sizeof(float), ctx->stream));
   MMG_HIP(ctx, hipMemsetAsync(dsh, 0, Mk_all * sizeof(float), ctx->stream));
   if (scale) {
     MMG_HIP(ctx, hipMemcpyAsync(dsc, scale, g->M * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     MMG_HIP(ctx, hipMemcpyAsync(dsh, shift, g->M * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   } else {
     std::vector<float> two((size_t)g->M, 2.0f), neg((size_t)g->M, -1.0f);
     MMG_HIP(ctx, hipMemcpyAsync(dsc, two.data(), g->M * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
@@ -360,15 +358,70 @@ int mmg_kinship_affine_f32(mmg_ctx* ctx, mmg_geno* g, const float* scale, const 
     }
     MMG_HIP(ctx, hipGetLastError());
     rc = run_kinship_f32(ctx, Xt, g->Npad, Mk, dsc + mb, dsh + mb, slabs, ksplit);
-    if (rc == MMG_OK) launch_reduce_slabs(ctx, slabs, ksplit, g->Npad, g->N, dC, mb > 0 ? 1 : 0);
+    if (rc == MMG_OK) launch_reduce_slabs(ctx, slabs, ksplit, g->Npad, g->N, dC, (accumulate || mb > 0) ? 1 : 0);
   }
+  hipStreamSynchronize(ctx->stream);
+  hipFree(Xt); hipFree(dsc); hipFree(dsh); hipFree(slabs);
+  return rc;
+}
+
+int mmg_kinship_affine_f32(mmg_ctx* ctx, mmg_geno* g, const float* scale, const float* shift, double* C_out) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, g && C_out && g->M > 0);
+  MMG_CHECK_ARG(ctx, (scale == nullptr) == (shift == nullptr));
+  double* dC = nullptr;
+  MMG_HIP(ctx, hipMalloc(&dC, (size_t)g->N * g->N * sizeof(double)));
+  int rc = kinship_affine_into(ctx, g, scale, shift, dC, false);
   if (rc == MMG_OK) {
     hipError_t e2 = hipMemcpyAsync(C_out, dC, (size_t)g->N * g->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
     if (e2 != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e2));
   }
-  hipFree(Xt); hipFree(dsc); hipFree(dsh); hipFree(slabs); hipFree(dC);
+  hipFree(dC);
   return rc;
+}
+
+// Device-resident kinship accumulator for chunked / streamed genotypes (the `k_mat += x'x` loop of
+// hdf5_data.py:99-106 and kinship.py:63-69): the N x N sum stays in HBM between chunks.
+struct mmg_kin_acc { int32_t N = 0; double* dC = nullptr; int64_t n_snps = 0; };
+
+int mmg_kin_acc_create(mmg_ctx* ctx, int32_t N, mmg_kin_acc** out) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, out && N > 0);
+  mmg_kin_acc* a = new mmg_kin_acc();
+  a->N = N;
+  hipError_t e = hipMalloc(&a->dC, (size_t)N * N * sizeof(double));
+  if (e != hipSuccess) { delete a; return set_err(ctx, MMG_E_NOMEM, "hipMalloc kinship accumulator"); }
+  MMG_HIP(ctx, hipMemsetAsync(a->dC, 0, (size_t)N * N * sizeof(double), ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out = a;
+  return MMG_OK;
+}
+
+int mmg_kin_acc_add(mmg_ctx* ctx, mmg_kin_acc* a, mmg_geno* g, const float* scale, const float* shift) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, a && g && g->N == a->N && (scale == nullptr) == (shift == nullptr));
+  if (g->M == 0) return MMG_OK;
+  int rc = kinship_affine_into(ctx, g, scale, shift, a->dC, true);
+  if (rc == MMG_OK) a->n_snps += g->M;
+  return rc;
+}
+
+int mmg_kin_acc_fetch(mmg_ctx* ctx, mmg_kin_acc* a, double* C_out, int64_t* n_snps) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, a && C_out);
+  MMG_HIP(ctx, hipMemcpyAsync(C_out, a->dC, (size_t)a->N * a->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (n_snps) *n_snps = a->n_snps;
+  return MMG_OK;
+}
+
+int mmg_kin_acc_destroy(mmg_ctx* ctx, mmg_kin_acc* a) {
+  if (!a) return MMG_OK;
+  if (ctx) hipStreamSynchronize(ctx->stream);
+  hipFree(a->dC);
+  delete a;
+  return MMG_OK;
 }
 
 int mmg_kinship_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N, const float* scale, const float* shift,

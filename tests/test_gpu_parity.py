@@ -435,3 +435,60 @@ def test_examples_mixed_model_gwas_call_sequence(ctx, tmp_path):
     assert rel(res["ps"], ref["ps"]) < 1e-6
     lines = open(out).read().splitlines()
     assert lines[0] == "chromosomes,positions,scores" and len(lines) == len(snps) + 1
+
+
+def _chunk_source(rng, n, sizes):
+    src, allsnps = {}, []
+    for ci, m in enumerate(sizes):
+        snps = struct_snps(rng, n, m)
+        snps = snps[(snps.sum(1) > 0) & (snps.sum(1) < n)]
+        src["chr%d" % (ci + 1)] = {"raw_snps": snps, "freqs": snps.mean(1), "positions": np.arange(len(snps)) * 10}
+        allsnps.append(snps)
+    return src, allsnps
+
+
+def test_chunked_run_emmax_vs_oracle(ctx):
+    """hdf5_data.run_emmax compute (MAF filter, GRM kinship over chunks, REML once, scan per chromosome)."""
+    from mixmogam_amd import hdf5_data
+    rng = np.random.RandomState(21)
+    n = 260
+    src, allsnps = _chunk_source(rng, n, [900, 700])
+    y = allsnps[0][:6].astype(float).T @ rng.exponential(1.0, 6) + 2.0 * rng.randn(n)
+    out = hdf5_data.run_emmax(src, y, min_maf=0.1, chunk_size=256, ctx=ctx)
+    keep = [np.minimum(s.mean(1), 1 - s.mean(1)) > 0.1 for s in allsnps]
+    filt = np.vstack([s[k] for s, k in zip(allsnps, keep)])
+    assert out["num_snps"] == len(filt)
+    kref = orc.calc_ibd_kinship(filt)
+    assert np.max(np.abs(out["kinship"] - kref)) < 2e-5          # fp32 MFMA products
+    ref = orc.emmax(filt, y, out["kinship"])                     # same K: isolates the chunked scan
+    got = np.concatenate([out["chrom_results"][c]["ps"] for c in ("chr1", "chr2")])
+    assert rel(got, ref["ps"]) < 1e-6
+    assert rel(out["pseudo_heritability"], ref["pseudo_heritability"]) < 1e-6
+    assert np.array_equal(out["chrom_results"]["chr2"]["positions"], src["chr2"]["positions"][keep[1]])
+    # chunking is invisible: one big chunk gives the same p-values bit for bit given the same kinship
+    out1 = hdf5_data.run_emmax(src, y, min_maf=0.1, chunk_size=10 ** 6, k=out["kinship"], ctx=ctx)
+    got1 = np.concatenate([out1["chrom_results"][c]["ps"] for c in ("chr1", "chr2")])
+    assert np.array_equal(got1, got)
+
+
+def test_chunked_run_emmax_perm(ctx):
+    from mixmogam_amd import hdf5_data, linear_models as lm
+    rng = np.random.RandomState(22)
+    n = 200
+    src, allsnps = _chunk_source(rng, n, [500, 400])
+    y = rng.randn(n) + allsnps[1][5]
+    idx = [np.random.RandomState(p).permutation(n) for p in range(30)]
+    a = hdf5_data.run_emmax_perm(src, y, min_maf=0.05, chunk_size=128, num_perm=30, perm_idx=idx, ctx=ctx)
+    b = hdf5_data.run_emmax_perm(src, y, min_maf=0.05, chunk_size=10 ** 6, num_perm=30, perm_idx=idx,
+                                 k=a["kinship"], ctx=ctx)
+    assert rel(a["perm_min_ps"], b["perm_min_ps"]) < 1e-9        # min over chunks == min over all SNPs
+    keep = [np.minimum(s.mean(1), 1 - s.mean(1)) > 0.05 for s in allsnps]
+    filt = np.vstack([s[k] for s, k in zip(allsnps, keep)])
+    lmm = lm.LinearMixedModel(y, ctx=ctx)
+    lmm.add_random_effect(a["kinship"])
+    eL, eR = lmm._get_eigen_L_(), lmm._get_eigen_R_(X=lmm.X)
+    H = lmm._get_estimates_with(eL, eR, "REML")["H_sqrt_inv"]    # the same (deterministic) device eigenbasis
+    pp = orc.perm_prepare(y, np.ones((n, 1)), H, np.asarray(idx))
+    ref = orc.perm_closed(filt, pp)
+    assert rel(a["perm_max_f_stats"], ref["max_f_stats"]) < 1e-6
+    assert a["threshold_05"][0] == np.sort(a["perm_min_ps"])[1]
