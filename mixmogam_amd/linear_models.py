@@ -370,13 +370,13 @@ class LinearMixedModel(object):
             print('EMMAX timings (s):', t)
         return r
 
-    def _get_estimates_with(self, eig_L, eig_R, method):
+    def _get_estimates_with(self, eig_L, eig_R, method, ngrids=50):
         # get_estimates' `not (eig_R and xs != None)` recomputes eig_R when xs is None; pass the
         # precomputed one through a tiny shim instead of paying a third N^3 eigh for equal values.
         saved = self._get_eigen_R_
         try:
             self._get_eigen_R_ = lambda X=None, K=None, **kw: eig_R
-            return self.get_estimates(eig_L, method=method, eig_R=eig_R)
+            return self.get_estimates(eig_L, method=method, eig_R=eig_R, ngrids=ngrids)
         finally:
             self._get_eigen_R_ = saved
 
@@ -555,6 +555,228 @@ def linear_model(snps, phenotypes, cofactors=None, ctx=None):
         for cofactor in cofactors:
             lm_.add_factor(cofactor)
     return lm_.fast_f_test(snps)
+
+
+# ---------------------------------------------------------------------- MLMM
+def _log_choose_(n, k):
+    """:1885-1892."""
+    if k == 0 or n == k:
+        return 0
+    if n < k:
+        raise Exception('Out of range.')
+    return np.sum(np.log(np.arange(n, n - k, -1))) - np.sum(np.log(np.arange(k, 0, -1)))
+
+
+def _calc_bic_(ll, num_snps, num_par, n):
+    """:1895-1901."""
+    bic = -2 * ll + num_par * np.log(n)
+    extended_bic = bic + 2 * _log_choose_(num_snps, num_par - 2)
+    modified_bic = bic + 2 * num_par * np.log(num_snps / 2.2 - 1)
+    return (bic, extended_bic, modified_bic)
+
+
+def _opt_fw_bw_(vals, max_num_cofactors, good):
+    """The forward/backward optimum search shared by 'mbonf' and 'min_cof_ppa' (:2002-2051)."""
+    fw = np.arange(max_num_cofactors + 1)
+    for i in range(max_num_cofactors + 1):
+        if not good(vals[i]):
+            fw[i] = -1
+    fw_i = int(fw.argmax())
+    if max_num_cofactors > 1 and len(vals) > max_num_cofactors + 1:
+        shift = max_num_cofactors + 1
+        bw = np.arange(max_num_cofactors - 1, 0, -1)
+        for i in range(len(bw)):
+            if not good(vals[i + shift]):
+                bw[i] = -1
+        bw_max = bw[int(bw.argmax())]
+        bw_i = int(bw.argmax()) + shift
+        if bw_max == fw[fw_i]:
+            return bw_i if vals[fw_i] > vals[bw_i] else fw_i
+        return bw_i if bw_max > fw[fw_i] else fw_i
+    return fw_i
+
+
+def _analyze_opt_criterias_(criterias, sign_threshold, max_num_cofactors, ppa_threshold=0.5):
+    """:1984-2066 without the plotting: optimal step index per criterion."""
+    ret = {}
+    for c in criterias:
+        if c == 'bonf':
+            opt_list = np.arange(max_num_cofactors + 1)
+            for i, pval in enumerate(criterias['bonf'][:max_num_cofactors + 1]):
+                if pval > sign_threshold:
+                    opt_list[i] = -1
+            ret[c] = int(opt_list.argmax())
+        elif c == 'mbonf':
+            ret[c] = _opt_fw_bw_(criterias[c], max_num_cofactors, lambda v: not v > sign_threshold)
+        elif c == 'min_cof_ppa':
+            ret[c] = _opt_fw_bw_(criterias[c], max_num_cofactors, lambda v: not v < ppa_threshold)
+        else:
+            ret[c] = int(np.argmin(criterias[c]))                        # first minimum (:2054-2063)
+    return ret
+
+
+def mlmm(phenotypes, K, sd=None, num_steps=10, forward_backwards=True, sign_threshold=None, snp_priors=None,
+         snp_choose_criteria='pval', emma_num=0, save_pvals=False, ctx=None, **kwargs):
+    """:2543-2923 -- multi-locus mixed model: forward inclusion of the most significant SNP as a cofactor,
+    then backward elimination; every step is one full EMMAX scan with q fixed-effect columns.  The
+    genotypes are uploaded once and stay in HBM for all steps (the reference re-converts its Python
+    list every step).  Plotting, K2 and file output are out of scope.  kwargs: snps, positions,
+    chromosomes (or `sd` providing get_snps / get_positions / get_chr_list)."""
+    import math
+    if sd is not None:
+        kwargs['snps'] = sd.get_snps()
+        kwargs['positions'] = sd.get_positions()
+        kwargs['chromosomes'] = sd.get_chr_list()
+    all_snps = kinship._as_snp_matrix(kwargs['snps'])
+    positions = list(kwargs['positions'])
+    chromosomes = list(kwargs['chromosomes'])
+    lmm = LinearMixedModel(phenotypes, ctx=ctx)
+    lmm.add_random_effect(K)
+    ctx = lmm.ctx
+    num_snps = len(all_snps)
+    all_priors = np.asarray(snp_priors, dtype=np.float64) if snp_priors is not None \
+        else np.full(num_snps, 1.0 / num_snps)                           # :2579-2581
+    if not sign_threshold:
+        sign_threshold = 1.0 / (num_snps * 20.0)                         # :2583-2584
+    active = list(range(num_snps))                                       # global ids still in the scan
+    geno = ctx.geno(all_snps)                                            # resident for every step
+
+    def scan_active():
+        r = lmm._emmax_f_test_(geno, H_sqrt_inv, snp_priors=all_priors, emma_num=0, verbose=False)
+        idx = np.asarray(active)
+        out = {k: np.asarray(r[k])[idx] for k in ('ps', 'rss', 'var_perc', 'ppas', 'f_stats')}
+        if emma_num > 0:                                                 # :1365-1377 on the active list
+            order = np.argsort(out['ps'], kind='stable')[:emma_num]
+            top = lmm.expedited_REML_t_test(list(all_snps[idx[order]]), eig_L=eig_L)
+            for k2, pi in enumerate(order):
+                for key in ('ps', 'f_stats', 'rss', 'var_perc'):
+                    out[key][pi] = top[key][k2]
+        return out
+
+    def reestimate():
+        eig_R = lmm._get_eigen_R_(X=lmm.X, K=None)
+        reml = lmm._get_estimates_with(eig_L, eig_R, 'REML', ngrids=100)   # get_REML / get_ML use 100 grid points
+        ml = lmm._get_estimates_with(eig_L, eig_R, 'ML', ngrids=100)
+        return reml, ml
+
+    def cofactor_stats():
+        pvals, ppas, fstats = [], [], []
+        for i, gid in enumerate(cofactor_ids):
+            t = [all_snps[j] for k2, j in enumerate(cofactor_ids) if k2 != i]
+            lmm.set_factors(t)
+            r = lmm._emmax_f_test_(all_snps[gid:gid + 1], H_sqrt_inv, snp_priors=[cof_snp_priors[i]], emma_num=0,
+                                   verbose=False)
+            pvals.append(float(r['ps'][0])); ppas.append(float(r['ppas'][0])); fstats.append(float(r['f_stats'][0]))
+        lmm.set_factors([all_snps[j] for j in cofactor_ids])
+        return pvals, ppas, fstats
+
+    try:
+        step_info_list, cofactors, cofactor_ids, cof_snp_priors, ppa_cofactors = [], [], [], [], []
+        num_par = 2
+        num_pher_0 = 0
+        eig_L = lmm._get_eigen_L_()
+        reml_res, ml_res = reestimate()
+        H_sqrt_inv = reml_res['H_sqrt_inv']
+        ll, rss = ml_res['max_ll'], float(reml_res['rss'])
+        criterias = {'ebics': [], 'mbics': [], 'bonf': [], 'mbonf': []}
+        bic, extended_bic, modified_bic = _calc_bic_(ll, num_snps, num_par, lmm.n)
+        criterias['ebics'].append(extended_bic); criterias['mbics'].append(modified_bic)
+        max_cofactor_pval = 0
+        criterias['mbonf'].append(max_cofactor_pval); criterias['bonf'].append(0)
+        criterias['min_cof_ppa'] = [1]
+        pherit = reml_res['pseudo_heritability']
+        first_emmax_res = None
+
+        def info(em):
+            min_i, ppa_i = int(np.argmin(em['ps'])), int(np.argmax(em['ppas']))
+            d = {'pseudo_heritability': pherit, 'rss': rss, 'reml_mahalanobis_rss': reml_res['mahalanobis_rss'],
+                 'mahalanobis_rss': float(em['rss'][min_i]), 'll': ll, 'bic': bic, 'e_bic': extended_bic,
+                 'm_bic': modified_bic, 'mbonf': max_cofactor_pval, 'cofactors': [tuple(c) for c in cofactors],
+                 'cofactor_snps': [all_snps[j] for j in cofactor_ids], 'min_pval': float(em['ps'][min_i]),
+                 'min_pval_chr_pos': (chromosomes[active[min_i]], positions[active[min_i]]),
+                 'max_ppa': float(em['ppas'][ppa_i]), 'max_ppa_pval': float(em['ps'][ppa_i]),
+                 'max_ppa_chr_pos': (chromosomes[active[ppa_i]], positions[active[ppa_i]]),
+                 'ppa_cofactors': [tuple(c) for c in ppa_cofactors]}
+            if save_pvals:
+                d['ps'] = em['ps'].tolist()
+            return d, min_i, ppa_i
+
+        for step_i in range(1, num_steps + 1):                           # :2631
+            em = scan_active()
+            if step_i == 1:
+                first_emmax_res = em
+            step_info, min_i, ppa_i = info(em)
+            criterias['bonf'].append(step_info['min_pval'])
+            step_info_list.append(step_info)
+            snp_i = min_i if snp_choose_criteria == 'pval' else ppa_i
+            gid = active[snp_i]
+            lmm.add_factor(all_snps[gid])                                # :2686
+            cofactor_ids.append(gid)
+            reml_res, ml_res = reestimate()
+            H_sqrt_inv = reml_res['H_sqrt_inv']
+            ll, rss = ml_res['max_ll'], float(reml_res['rss'])
+            num_par += 1
+            cof_snp_priors.append(all_priors[gid])
+            ppa_cofactors.append([chromosomes[gid], positions[gid], step_info['max_ppa']])
+            cofactors.append([chromosomes[gid], positions[gid], step_info['min_pval']])
+            pvals, ppas, _f = cofactor_stats()                           # :2712-2730
+            for i, pv in enumerate(pvals):
+                cofactors[i][2] = -math.log10(pv)
+                ppa_cofactors[i][2] = ppas[i]
+            max_cofactor_pval = max(pvals)
+            criterias['mbonf'].append(max_cofactor_pval)
+            criterias['min_cof_ppa'].append(min(ppas))
+            del active[snp_i]                                            # :2734-2741
+            num_snps -= 1
+            bic, extended_bic, modified_bic = _calc_bic_(ll, num_snps, num_par, lmm.n)
+            criterias['ebics'].append(extended_bic); criterias['mbics'].append(modified_bic)
+            pherit = reml_res['pseudo_heritability']
+            if pherit < 0.001:                                           # :2760-2765
+                if num_pher_0 < 1:
+                    num_pher_0 += 1
+                else:
+                    break
+        em = scan_active()                                               # :2767
+        step_info, _, _ = info(em)
+        step_info_list.append(step_info)
+        max_num_cofactors = len(cofactors)
+
+        if forward_backwards:                                            # :2814-2897
+            while len(cofactor_ids) > 1:
+                pvals, ppas, fstats = cofactor_stats()
+                for i, pv in enumerate(pvals):
+                    cofactors[i][2] = -math.log10(pv)
+                i_rm = int(np.argmin(fstats)) if snp_choose_criteria == 'pval' else int(np.argmin(ppas))
+                # (the reference leaves cof_snp_priors untouched here, :2837-2839; kept for identical ppas)
+                del ppa_cofactors[i_rm], cofactor_ids[i_rm], cofactors[i_rm]
+                lmm.set_factors([all_snps[j] for j in cofactor_ids])
+                num_snps += 1
+                reml_res, ml_res = reestimate()
+                ll, rss = ml_res['max_ll'], float(reml_res['rss'])
+                H_sqrt_inv = reml_res['H_sqrt_inv']
+                num_par -= 1
+                pvals, ppas, _f = cofactor_stats()
+                for i, pv in enumerate(pvals):
+                    cofactors[i][2] = -math.log10(pv)
+                    ppa_cofactors[i][2] = ppas[i]
+                max_cofactor_pval = max(pvals)
+                criterias['mbonf'].append(max_cofactor_pval)
+                criterias['min_cof_ppa'].append(min(ppas))
+                bic, extended_bic, modified_bic = _calc_bic_(ll, num_snps, num_par, lmm.n)
+                criterias['ebics'].append(extended_bic); criterias['mbics'].append(modified_bic)
+                pherit = reml_res['pseudo_heritability']
+                step_info_list.append({'pseudo_heritability': pherit, 'rss': rss,
+                                       'reml_mahalanobis_rss': reml_res['mahalanobis_rss'], 'll': ll, 'bic': bic,
+                                       'e_bic': extended_bic, 'm_bic': modified_bic, 'mbonf': max_cofactor_pval,
+                                       'cofactors': [tuple(c) for c in cofactors],
+                                       'cofactor_snps': [all_snps[j] for j in cofactor_ids],
+                                       'mahalanobis_rss': None, 'min_pval': None, 'min_pval_chr_pos': None,
+                                       'ppa_cofactors': [tuple(c) for c in ppa_cofactors]})
+        opt_dict = _analyze_opt_criterias_(criterias, sign_threshold, max_num_cofactors)
+    finally:
+        geno.close()
+    return {'step_info_list': step_info_list, 'first_emmax_res': first_emmax_res, 'opt_dict': opt_dict,
+            'criterias': criterias}
 
 
 def emmax_perm_test(snps, phenotypes, K, num_perm=100, perm_idx=None, ctx=None):

@@ -103,6 +103,28 @@ def run_case(mods, snps, y, cof, nperm, perm_seed):
         dip = (snps[:half] + snps[half:2 * half]).astype(np.int8)
         out['dip_ibs_unscaled'] = np.asarray(quiet(kin.calc_ibs_kinship, list(dip), snps_data_format='diploid_int',
                                                    scaled=False), dtype=np.float64)
+    # MLMM forward/backward (linear_models.py:2543-2923); plotting/reporting helpers are not exercised
+    if cof is None and len(y) <= 160:
+        import sys as _sys
+        _sys.modules['gwaResults'] = mods['gwaResults']
+        lm.agr.calc_median = lambda ps, exp_median=0.5: float(np.median(ps) - exp_median)   # py2 int division inside
+        lm.agr.calc_ks_stats = lambda ps, exp_dist=None: {'D': 0.0, 'p_val': 1.0}
+        m_all = len(snp_list)
+        mres = quiet(lm.mlmm, list(y), k_ibs, num_steps=3, forward_backwards=True, file_prefix=None,
+                     snps=list(snp_list), positions=list(range(m_all)), chromosomes=[1] * m_all,
+                     mafs=[0.3] * m_all, macs=[30] * m_all)
+        keys = ('pseudo_heritability', 'll', 'bic', 'e_bic', 'm_bic', 'mbonf', 'min_pval', 'rss',
+                'reml_mahalanobis_rss', 'mahalanobis_rss')
+        tab = [[np.nan if si[k] is None else float(np.asarray(si[k]).reshape(-1)[0]) for k in keys]
+               for si in mres['step_info_list']]
+        out['mlmm_steps'] = np.asarray(tab)
+        out['mlmm_cof_pos'] = np.asarray([[c[1] for c in si['cofactors']] + [-1] * (3 - len(si['cofactors']))
+                                          for si in mres['step_info_list']])
+        out['mlmm_cof_mlogp'] = np.asarray([[c[2] for c in si['cofactors']] + [np.nan] * (3 - len(si['cofactors']))
+                                            for si in mres['step_info_list']])
+        for c in ('ebics', 'mbics', 'bonf', 'mbonf', 'min_cof_ppa'):
+            out['mlmm_opt_' + c] = np.int64(mres['opt_dict'][c])
+        out['mlmm_first_ps'] = np.asarray(mres['first_emmax_res']['ps'], dtype=np.float64)
     # permutations (intercept only in the reference: h0_X * list-of-floats needs q == 1)
     if cof is None and nperm:
         lmm3 = lm.LinearMixedModel(list(y))

@@ -19,7 +19,7 @@ import types
 
 REF = os.environ.get("MIXMOGAM_REFERENCE", "/root/reference")
 _MODS = ["kinship", "linear_models", "simulations", "snpsdata", "analyze_gwas_results",
-         "phenotypeData"]
+         "phenotypeData", "gwaResults"]
 
 
 def available():

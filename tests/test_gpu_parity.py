@@ -492,3 +492,31 @@ def test_chunked_run_emmax_perm(ctx):
     ref = orc.perm_closed(filt, pp)
     assert rel(a["perm_max_f_stats"], ref["max_f_stats"]) < 1e-6
     assert a["threshold_05"][0] == np.sort(a["perm_min_ps"])[1]
+
+
+def test_mlmm_forward_backward_vs_golden(ctx):
+    """N1: multi-locus mixed model (forward inclusion + backward elimination), every step one device scan
+    over the resident genotypes; step statistics vs the reference's own mlmm run (golden)."""
+    from mixmogam_amd import linear_models as lm
+    case = load_case("struct_n150_s0")
+    m = len(case["snps"])
+    res = lm.mlmm(list(case["y"]), case["dbl_ibs_scaled"], num_steps=3, forward_backwards=True,
+                  snps=case["snps"], positions=list(range(m)), chromosomes=[1] * m, ctx=ctx)
+    keys = ("pseudo_heritability", "ll", "bic", "e_bic", "m_bic", "mbonf", "min_pval", "rss",
+            "reml_mahalanobis_rss", "mahalanobis_rss")
+    want = case["dbl_mlmm_steps"]
+    assert len(res["step_info_list"]) == len(want)
+    for si, row, pos, mlogp in zip(res["step_info_list"], want, case["dbl_mlmm_cof_pos"], case["dbl_mlmm_cof_mlogp"]):
+        for k, w in zip(keys, row):
+            if np.isnan(w):
+                assert si[k] is None, k
+            elif w == 0:
+                assert float(np.asarray(si[k]).reshape(-1)[0]) == 0
+            else:
+                assert abs(float(np.asarray(si[k]).reshape(-1)[0]) / w - 1) < 2e-6, (k, si[k], w)
+        assert [c[1] for c in si["cofactors"]] == [p for p in pos if p >= 0]
+        for c, w in zip(si["cofactors"], mlogp):
+            assert abs(c[2] / w - 1) < 1e-6
+    for c in ("ebics", "mbics", "bonf", "mbonf", "min_cof_ppa"):
+        assert res["opt_dict"][c] == int(case["dbl_mlmm_opt_" + c]), c
+    assert rel(res["first_emmax_res"]["ps"], case["dbl_mlmm_first_ps"]) < 1e-6
