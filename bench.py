@@ -189,7 +189,7 @@ def main():
             "eigh_ms": eigh_ms, "model_setup_s": model_s, "setup_s": t_setup,
             "delta": float(est["delta"]), "min_p": float(np.nanmin(ps)), "device": info,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
             sample = min(M, args.cpu_sample or 40 * N)
             res["cpu_baseline"] = cpu_baseline(N, sample, lmm, est, prep, ps[:sample])
     if coll is not None:
