@@ -28,6 +28,9 @@ def open_hdf5(filename):
     return {'genot_data': f['genot_data'], 'phenotypes': f['indiv_data']['phenotypes'][...], 'file': f}
 
 
+_UPLOAD_CTX = {}
+
+
 def _maf_filter(cg, min_maf):
     freqs = np.asarray(cg['freqs'][...], dtype=np.float64)
     return np.minimum(freqs, 1 - freqs) > min_maf                       # hdf5_data.py:91-93
@@ -44,8 +47,40 @@ def _chunks(genot_data, min_maf, chunk_size):
         for i in range(0, len(idx), chunk_size):
             sel = idx[i:i + chunk_size]
             lo, hi = int(sel[0]), int(sel[-1]) + 1
-            block = np.asarray(raw[lo:hi])[sel - lo]                     # contiguous read, then the MAF subset
+            block = np.asarray(raw[lo:hi])                               # one contiguous read ...
+            if len(sel) != hi - lo:
+                block = block[sel - lo]                                  # ... then the MAF subset
             yield chrom, np.ascontiguousarray(block, dtype=np.int8), positions[i:i + chunk_size]
+
+
+def _resident_chunks(ctx, genot_data, min_maf, chunk_size, rank=0, world=1, prefetch=True):
+    """Yield (chunk index, chrom, Geno or None, block rows, positions) for every chunk; chunks owned by
+    other ranks come with Geno = None.  With prefetch the NEXT owned chunk is read from the source and
+    uploaded by a helper thread on a second context/stream of the same device while the caller computes
+    on the current one (the C ABI is blocking; ctypes releases the GIL): PCIe ingest overlaps the kernels."""
+    items = enumerate(_chunks(genot_data, min_maf, chunk_size))
+    if not prefetch:
+        for ci, (chrom, block, pos) in items:
+            yield ci, chrom, (ctx.geno(block) if ci % world == rank else None), len(block), pos
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    up = _UPLOAD_CTX.get(ctx.device)
+    if up is None:
+        up = _UPLOAD_CTX[ctx.device] = _lib.Context(ctx.device)     # second stream of the same device, kept
+
+    def load_next():
+        for ci, (chrom, block, pos) in items:
+            return ci, chrom, (up.geno(block) if ci % world == rank else None), len(block), pos
+        return None
+
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        fut = pool.submit(load_next)
+        while True:
+            cur = fut.result()
+            if cur is None:
+                break
+            fut = pool.submit(load_next)
+            yield cur
 
 
 def calculate_ibd_kinship(genot_data, n_indivs, min_maf=0.0, chunk_size=100000, ctx=None, coll=None):
@@ -55,11 +90,10 @@ def calculate_ibd_kinship(genot_data, n_indivs, min_maf=0.0, chunk_size=100000, 
     acc = ctx.kinship_accumulator(n_indivs)
     n_snps = 0
     rank, world = (coll.rank, coll.world) if coll is not None else (0, 1)
-    for ci, (chrom, block, _pos) in enumerate(_chunks(genot_data, min_maf, chunk_size)):
-        n_snps += len(block)
-        if ci % world != rank:
+    for ci, chrom, g, nrows, _pos in _resident_chunks(ctx, genot_data, min_maf, chunk_size, rank, world):
+        n_snps += nrows
+        if g is None:
             continue
-        g = ctx.geno(block)
         mean, sd = g.snp_stats()
         if np.any(sd == 0):
             raise ValueError("monomorphic SNP passed the MAF filter on chromosome %s" % chrom)
@@ -97,10 +131,9 @@ def run_emmax(genot_data, phenotypes, min_maf=0.1, chunk_size=100000, k=None, ct
     ctx.scan_set_model(prep['A'], prep['w'], 0)
     per_chrom = {}
     kept = []                                                            # chunk genotype stores for the permutations
-    for ci, (chrom, block, pos) in enumerate(_chunks(genot_data, min_maf, chunk_size)):
-        ps = np.full(len(block), np.nan)
-        if ci % world == rank:
-            g = ctx.geno(block)
+    for ci, chrom, g, nrows, pos in _resident_chunks(ctx, genot_data, min_maf, chunk_size, rank, world):
+        ps = np.full(nrows, np.nan)
+        if g is not None:
             ps = ctx.scan(g, prep['h0_rss'], prep['n_p'])['ps']          # :174 _emmax_f_test_(emma_num=0)
             if num_perm:
                 kept.append(g)
