@@ -193,9 +193,9 @@ __device__ __forceinline__ void gemm_tile_i8_timed(const int8_t* __restrict__ P,
   for (int ks = ks0; ks < ks1; ++ks) {
     char* nb = lds + (cur ^ 1) * BUF_BYTES;
     const unsigned long long t0 = stamp();
-    if (ks + 1 < ks1) {
-      stage_tile(sp, (ks + 1) * BK, nb, wave);
-      stage_tile(sq, (ks + 1) * BK, nb + TILE_BYTES, wave);
+    if (ks + 1 < ks1 && wave < 4) {                 // production staging: loader waves only
+      stage_tile_pair(sp, (ks + 1) * BK, nb, wave);
+      stage_tile_pair(sq, (ks + 1) * BK, nb + TILE_BYTES, wave);
     }
     const unsigned long long t1 = stamp();
     mma_kstep(lds + cur * BUF_BYTES, wm, wn, lane, acc);

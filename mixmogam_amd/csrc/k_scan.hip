@@ -466,18 +466,20 @@ void launch_scan_quad(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md,
     std::vector<unsigned long long> h((size_t)2048 * 64);
     hipMemcpyAsync(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
     hipStreamSynchronize(ctx->stream);
-    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long cnt = 0;
-    for (size_t w = 0; w < (size_t)2048 * 8; ++w) {
-      if (h[w * 8 + 7] == 0) continue;
-      for (int k = 0; k < 8; ++k) s[k] += (double)h[w * 8 + k];
-      ++cnt;
-    }
-    if (cnt) {
-      const double ks = s[7] / cnt;
-      fprintf(stderr, "[timed] waves %ld  K-steps/wave %.0f  per K-step cycles: issueDMA %.0f  lds+mfma %.0f  vmcnt %.0f  barrier %.0f | "
-                      "per wave: prologues %.0f  epilogues %.0f  total %.0f cycles\n",
-              cnt, ks, s[0] / s[7], s[1] / s[7], s[2] / s[7], s[3] / s[7], s[4] / cnt, s[5] / cnt, s[6] / cnt);
+    for (int role = 0; role < 2; ++role) {           // loader waves (0-3) and their SIMD partners (4-7)
+      double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      long cnt = 0;
+      for (size_t w = 0; w < (size_t)2048 * 8; ++w) {
+        if (h[w * 8 + 7] == 0 || (int)((w & 7) >> 2) != role) continue;
+        for (int k = 0; k < 8; ++k) s[k] += (double)h[w * 8 + k];
+        ++cnt;
+      }
+      if (cnt) {
+        const double ks = s[7] / cnt;
+        fprintf(stderr, "[timed] %s waves %ld  K-steps/wave %.0f  per K-step cycles: issueDMA %.0f  lds+mfma %.0f  vmcnt %.0f  barrier %.0f | "
+                        "per wave: prologues %.0f  epilogues %.0f  total %.0f cycles\n", role ? "partner" : "loader ",
+                cnt, ks, s[0] / s[7], s[1] / s[7], s[2] / s[7], s[3] / s[7], s[4] / cnt, s[5] / cnt, s[6] / cnt);
+      }
     }
     return;
   }

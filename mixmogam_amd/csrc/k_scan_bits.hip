@@ -70,17 +70,12 @@ __device__ __forceinline__ v4i expand16(uint32_t x16) {
   return o;
 }
 
-template <int NW>   // loads per stage of this wave: 4 (waves 4-7) or 5 (waves 0-3 also move a Q piece)
+// Only waves 0-3 issue DMA (loader waves, as in gemm_i8_core.h MODE 5): 8 P pieces (own rows and the
+// SIMD partner's) + 1 Q piece = 9 loads per stage; waves 4-7 have nothing in flight.
 __device__ __forceinline__ void wait_stages(int keep) {
-  if (NW == 5) {
-    if (keep >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (keep == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
-    if (keep >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (keep == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  if (keep >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else if (keep == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 __global__ __launch_bounds__(NTHREADS, 2) void scan_quad_bits_kernel(
@@ -120,11 +115,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void scan_quad_bits_kernel(
         for (int e = 0; e < 16; ++e) acc[m][n][e] = 0;
 
     auto issue = [&](int ks) {
+      if (!qloader) return;
       char* slot = lds + (ks & (BSLOTS - 1)) * BSLOT;
-      stage_tile(sp, ks * BK, slot, wave);
-      if (qloader)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (MMG_AS3 void*)(slot + TILE_BYTES + wave * 1024), 16, vq,
-                                                 ks * 16, 0, 0);
+      stage_tile_pair(sp, ks * BK, slot, wave);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (MMG_AS3 void*)(slot + TILE_BYTES + wave * 1024), 16, vq,
+                                               ks * 16, 0, 0);
     };
 #pragma unroll 1
     for (int ks = 0; ks < 3 && ks < nks; ++ks) issue(ks);
@@ -132,7 +127,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void scan_quad_bits_kernel(
 #pragma unroll 1
     for (int ks = 0; ks < nks; ++ks) {
       const int keep = min(2, nks - 1 - ks);         // younger stages allowed to stay in flight
-      if (qloader) wait_stages<5>(keep); else wait_stages<4>(keep);
+      if (qloader) wait_stages(keep);
       __builtin_amdgcn_s_barrier();                   // stage ks landed for every wave; slot (ks-1)&3 is free
       asm volatile("" ::: "memory");
       if (ks + 3 < nks) issue(ks + 3);   // (spreading the pieces between the MFMA groups measured 4 % slower)
