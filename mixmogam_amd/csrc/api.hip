@@ -196,12 +196,13 @@ int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, i
 extern "C++" {
 template <typename T>
 static int upload_cvt(mmg_ctx* ctx, mmg_geno* g, const T* snps, int64_t m0, int64_t rows) {
+  Scratch sc;
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, g && snps && m0 >= 0 && rows >= 0 && m0 + rows <= g->M);
   g->bits_valid = false;
   const int64_t chunk = std::max<int64_t>(1, (int64_t)(256 << 20) / ((int64_t)g->N * sizeof(T)));
   T* tmp = nullptr;
-  MMG_HIP(ctx, hipMalloc(&tmp, (size_t)std::min(chunk, rows) * g->N * sizeof(T)));
+  MMG_HIP(ctx, sc.alloc(&tmp, (size_t)std::min(chunk, rows) * g->N * sizeof(T)));
   for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
     const int64_t nr = std::min(chunk, rows - r0);
     MMG_HIP(ctx, hipMemcpyAsync(tmp, snps + r0 * g->N, (size_t)nr * g->N * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
@@ -209,7 +210,6 @@ static int upload_cvt(mmg_ctx* ctx, mmg_geno* g, const T* snps, int64_t m0, int6
     else launch_cvt_f64(ctx, (const double*)tmp, g->d + (m0 + r0) * (int64_t)g->Npad, nr, g->N, g->Npad);
     MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  MMG_HIP(ctx, hipFree(tmp));
   return MMG_OK;
 }
 }  // extern C++
@@ -245,18 +245,18 @@ int mmg_geno_fill_hash(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_globa
 }
 
 int mmg_geno_snp_stats(mmg_ctx* ctx, mmg_geno* g, double* mean, double* sd) {
+  Scratch sc;
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, g && mean && sd);
   if (g->M == 0) return MMG_OK;
   double *dm = nullptr, *ds = nullptr;
-  MMG_HIP(ctx, hipMalloc(&dm, g->M * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&ds, g->M * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dm, g->M * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&ds, g->M * sizeof(double)));
   launch_snp_stats(ctx, g, dm, ds);
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipMemcpyAsync(mean, dm, g->M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MMG_HIP(ctx, hipMemcpyAsync(sd, ds, g->M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  hipFree(dm); hipFree(ds);
   return MMG_OK;
 }
 
@@ -282,6 +282,7 @@ int mmg_kinship_indicator_i8(mmg_ctx* ctx, mmg_geno* g, int32_t thr, int64_t* C_
 }
 
 static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int thr, int64_t* C_out) {
+  Scratch sc;
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, g && C_out && g->M > 0);
   MMG_CHECK_ARG(ctx, g->M < (int64_t(1) << 31));       // int32 accumulators: |C_ij| <= M
@@ -290,10 +291,10 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
   int8_t* Xt = nullptr;
   int* C32 = nullptr;
   int64_t* C64 = nullptr;
-  hipError_t e = hipMalloc(&Xt, (size_t)g->Npad * Mk_max);
+  hipError_t e = sc.alloc(&Xt, (size_t)g->Npad * Mk_max);
   if (e != hipSuccess) return set_err(ctx, MMG_E_NOMEM, "hipMalloc transposed genotype image");
-  MMG_HIP(ctx, hipMalloc(&C32, (size_t)g->Npad * g->Npad * sizeof(int)));
-  MMG_HIP(ctx, hipMalloc(&C64, (size_t)g->N * g->N * sizeof(int64_t)));
+  MMG_HIP(ctx, sc.alloc(&C32, (size_t)g->Npad * g->Npad * sizeof(int)));
+  MMG_HIP(ctx, sc.alloc(&C64, (size_t)g->N * g->N * sizeof(int64_t)));
   MMG_HIP(ctx, hipMemsetAsync(C32, 0, (size_t)g->Npad * g->Npad * sizeof(int), ctx->stream));
   int rc = MMG_OK;
   double kin_ms = 0.0, pack_ms = 0.0;
@@ -318,24 +319,24 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
     if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
     if (e2 != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e2));
   }
-  hipFree(Xt); hipFree(C32); hipFree(C64);
   return rc;
 }
 
 // dC [N x N] (device, fp64) (+)= sum_m x_m x_m', x_m = scale[m] s_m + shift[m]
 static int kinship_affine_into(mmg_ctx* ctx, mmg_geno* g, const float* scale, const float* shift, double* dC,
                                bool accumulate) {
+  Scratch sc;
   const int64_t CH = kin_chunk();
   const int64_t Mk_all = round_up(g->M, BK);
   const int64_t Mk_max = std::min(Mk_all, CH);
   const int ksplit_max = kinship_pick_ksplit(g->Npad, Mk_max, true);
   int8_t* Xt = nullptr;
   float *dsc = nullptr, *dsh = nullptr, *slabs = nullptr;
-  hipError_t e = hipMalloc(&Xt, (size_t)g->Npad * Mk_max);
+  hipError_t e = sc.alloc(&Xt, (size_t)g->Npad * Mk_max);
   if (e != hipSuccess) return set_err(ctx, MMG_E_NOMEM, "hipMalloc transposed genotype image");
-  MMG_HIP(ctx, hipMalloc(&dsc, Mk_all * sizeof(float)));
-  MMG_HIP(ctx, hipMalloc(&dsh, Mk_all * sizeof(float)));
-  MMG_HIP(ctx, hipMalloc(&slabs, (size_t)ksplit_max * g->Npad * g->Npad * sizeof(float)));
+  MMG_HIP(ctx, sc.alloc(&dsc, Mk_all * sizeof(float)));
+  MMG_HIP(ctx, sc.alloc(&dsh, Mk_all * sizeof(float)));
+  MMG_HIP(ctx, sc.alloc(&slabs, (size_t)ksplit_max * g->Npad * g->Npad * sizeof(float)));
   MMG_HIP(ctx, hipMemsetAsync(dsc, 0, Mk_all * sizeof(float), ctx->stream));
   MMG_HIP(ctx, hipMemsetAsync(dsh, 0, Mk_all * sizeof(float), ctx->stream));
   if (scale) {
@@ -361,23 +362,22 @@ static int kinship_affine_into(mmg_ctx* ctx, mmg_geno* g, const float* scale, co
     if (rc == MMG_OK) launch_reduce_slabs(ctx, slabs, ksplit, g->Npad, g->N, dC, (accumulate || mb > 0) ? 1 : 0);
   }
   hipStreamSynchronize(ctx->stream);
-  hipFree(Xt); hipFree(dsc); hipFree(dsh); hipFree(slabs);
   return rc;
 }
 
 int mmg_kinship_affine_f32(mmg_ctx* ctx, mmg_geno* g, const float* scale, const float* shift, double* C_out) {
+  Scratch sc;
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, g && C_out && g->M > 0);
   MMG_CHECK_ARG(ctx, (scale == nullptr) == (shift == nullptr));
   double* dC = nullptr;
-  MMG_HIP(ctx, hipMalloc(&dC, (size_t)g->N * g->N * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dC, (size_t)g->N * g->N * sizeof(double)));
   int rc = kinship_affine_into(ctx, g, scale, shift, dC, false);
   if (rc == MMG_OK) {
     hipError_t e2 = hipMemcpyAsync(C_out, dC, (size_t)g->N * g->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
     if (e2 != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e2));
   }
-  hipFree(dC);
   return rc;
 }
 
@@ -458,6 +458,7 @@ static int get_rocblas(mmg_ctx* ctx, rocblas_handle* h) {
 }
 
 int mmg_eigh_f64(mmg_ctx* ctx, const double* A, int32_t N, double* evals, double* evecs) {
+  Scratch sc;
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, A && evals && N > 0);
   rocblas_handle h;
@@ -465,10 +466,10 @@ int mmg_eigh_f64(mmg_ctx* ctx, const double* A, int32_t N, double* evals, double
   if (rc) return rc;
   double *dA = nullptr, *dD = nullptr, *dE = nullptr;
   rocblas_int* dinfo = nullptr;
-  MMG_HIP(ctx, hipMalloc(&dA, (size_t)N * N * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&dD, N * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&dE, N * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&dinfo, sizeof(rocblas_int)));
+  MMG_HIP(ctx, sc.alloc(&dA, (size_t)N * N * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dD, N * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dE, N * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dinfo, sizeof(rocblas_int)));
   MMG_HIP(ctx, hipMemcpyAsync(dA, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   rocblas_status st;
   {
@@ -486,7 +487,6 @@ int mmg_eigh_f64(mmg_ctx* ctx, const double* A, int32_t N, double* evals, double
   if (e == hipSuccess && evecs)
     e = hipMemcpyAsync(evecs, dA, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  hipFree(dA); hipFree(dD); hipFree(dE); hipFree(dinfo);
   if (st != rocblas_status_success) return set_err(ctx, MMG_E_LIB, "rocsolver_dsyevd failed: status " + std::to_string((int)st));
   if (e != hipSuccess) return set_err(ctx, MMG_E_HIP, hipGetErrorString(e));
   if (info != 0) return set_err(ctx, MMG_E_LIB, "rocsolver_dsyevd did not converge: info " + std::to_string((int)info));
@@ -495,15 +495,16 @@ int mmg_eigh_f64(mmg_ctx* ctx, const double* A, int32_t N, double* evals, double
 
 int mmg_dgemm_f64(mmg_ctx* ctx, int ta, int tb, int32_t M, int32_t N, int32_t K, const double* A, const double* B,
                   double* C) {
+  Scratch sc;
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, A && B && C && M > 0 && N > 0 && K > 0);
   rocblas_handle h;
   int rc = get_rocblas(ctx, &h);
   if (rc) return rc;
   double *dA = nullptr, *dB = nullptr, *dC = nullptr;
-  MMG_HIP(ctx, hipMalloc(&dA, (size_t)M * K * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&dB, (size_t)K * N * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&dC, (size_t)M * N * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dA, (size_t)M * K * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dB, (size_t)K * N * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dC, (size_t)M * N * sizeof(double)));
   MMG_HIP(ctx, hipMemcpyAsync(dA, A, (size_t)M * K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   MMG_HIP(ctx, hipMemcpyAsync(dB, B, (size_t)K * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   const double one = 1.0, zero = 0.0;
@@ -513,7 +514,6 @@ int mmg_dgemm_f64(mmg_ctx* ctx, int ta, int tb, int32_t M, int32_t N, int32_t K,
                                     tb ? K : N, dA, ta ? M : K, &zero, dC, N);
   hipError_t e = hipMemcpyAsync(C, dC, (size_t)M * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  hipFree(dA); hipFree(dB); hipFree(dC);
   if (st != rocblas_status_success) return set_err(ctx, MMG_E_LIB, "rocblas_dgemm failed");
   if (e != hipSuccess) return set_err(ctx, MMG_E_HIP, hipGetErrorString(e));
   return MMG_OK;
@@ -569,10 +569,11 @@ static int build_schedule(mmg_ctx* ctx, mmg_scan_model& md) {
 // Build a scan model from a DEVICE-resident fp64 matrix dA [N x N] and device vector dw [N].
 static int model_from_device(mmg_ctx* ctx, mmg_scan_model& md, int32_t N, const double* dA, const double* dw,
                              int ndigits) {
+  Scratch sc;
   free_model(md);
   md.N = N; md.Npad = (int32_t)round_up(N, 256); md.D = ndigits;
   unsigned long long* dmax = nullptr;
-  MMG_HIP(ctx, hipMalloc(&dmax, sizeof(unsigned long long)));
+  MMG_HIP(ctx, sc.alloc(&dmax, sizeof(unsigned long long)));
   MMG_HIP(ctx, hipMalloc(&md.Bq, (size_t)md.D * md.Npad * md.Npad));
   MMG_HIP(ctx, hipMalloc(&md.diag, md.Npad * sizeof(double)));
   MMG_HIP(ctx, hipMalloc(&md.w, md.Npad * sizeof(double)));
@@ -591,22 +592,21 @@ static int model_from_device(mmg_ctx* ctx, mmg_scan_model& md, int32_t N, const 
   launch_quantize(ctx, dA, N, md.Npad, md.D, 1.0 / md.step, md.Bq, md.diag);
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  hipFree(dmax);
   return build_schedule(ctx, md);
 }
 
 int mmg_scan_set_model(mmg_ctx* ctx, int32_t N, const double* A, const double* w, int ndigits) {
+  Scratch sc;
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, A && w && N > 0);
   if (ndigits == 0) ndigits = 4;
   MMG_CHECK_ARG(ctx, ndigits >= 2 && ndigits <= 6);
   double *dA = nullptr, *dw = nullptr;
-  MMG_HIP(ctx, hipMalloc(&dA, (size_t)N * N * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&dw, N * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dA, (size_t)N * N * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dw, N * sizeof(double)));
   MMG_HIP(ctx, hipMemcpyAsync(dA, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   MMG_HIP(ctx, hipMemcpyAsync(dw, w, N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   int rc = model_from_device(ctx, ctx->model, N, dA, dw, ndigits);
-  hipFree(dA); hipFree(dw);
   return rc;
 }
 
@@ -696,12 +696,13 @@ int mmg_emmax_scan_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N, co
 }
 
 int mmg_geno_matvec(mmg_ctx* ctx, mmg_geno* g, const double* V, int32_t nv, double* out) {
+  Scratch sc;
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, g && V && out && nv > 0);
   if (g->M == 0) return MMG_OK;
   double *dv = nullptr, *dout = nullptr;
-  MMG_HIP(ctx, hipMalloc(&dv, g->Npad * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&dout, g->M * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dv, g->Npad * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dout, g->M * sizeof(double)));
   for (int k = 0; k < nv; ++k) {
     MMG_HIP(ctx, hipMemsetAsync(dv, 0, g->Npad * sizeof(double), ctx->stream));
     MMG_HIP(ctx, hipMemcpyAsync(dv, V + (int64_t)k * g->N, g->N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -710,23 +711,22 @@ int mmg_geno_matvec(mmg_ctx* ctx, mmg_geno* g, const double* V, int32_t nv, doub
     MMG_HIP(ctx, hipMemcpyAsync(out + (int64_t)k * g->M, dout, g->M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  hipFree(dv); hipFree(dout);
   return MMG_OK;
 }
 
 int mmg_f_sf(mmg_ctx* ctx, const double* F, int64_t n, int32_t df2, double* p) {
+  Scratch sc;
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, F && p && n >= 0 && df2 > 0);
   if (n == 0) return MMG_OK;
   double *dF = nullptr, *dp = nullptr;
-  MMG_HIP(ctx, hipMalloc(&dF, n * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&dp, n * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dF, n * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dp, n * sizeof(double)));
   MMG_HIP(ctx, hipMemcpyAsync(dF, F, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   launch_f_sf(ctx, dF, n, df2, ln_beta_half(0.5 * df2), dp);
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipMemcpyAsync(p, dp, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  hipFree(dF); hipFree(dp);
   return MMG_OK;
 }
 
@@ -745,6 +745,7 @@ static int dgemm_dev(mmg_ctx* ctx, int ta, int tb, int M, int N, int K, const do
 
 int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const double* Ys, int32_t P, double h0_rss,
                    int ndigits, double* min_rss) {
+  Scratch sc;
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, g && Ht && Ys && min_rss && P > 0 && N == g->N);
   MMG_CHECK_ARG(ctx, ndigits == 0 || ndigits == 4);
@@ -757,17 +758,16 @@ int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const
   }
   double *dH = nullptr, *dYs = nullptr, *dA = nullptr, *dWt = nullptr, *dv = nullptr, *dones = nullptr;
   double *dmu = nullptr, *dinv = nullptr, *dmax = nullptr;
-  const int Npad = g->Npad;
   const int Ppad = (int)round_up(P, 64);
-  MMG_HIP(ctx, hipMalloc(&dH, (size_t)N * N * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&dYs, (size_t)N * P * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&dA, (size_t)N * N * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&dWt, (size_t)P * N * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&dv, N * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&dones, N * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&dmu, g->Mpad * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&dinv, g->Mpad * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&dmax, Ppad * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dH, (size_t)N * N * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dYs, (size_t)N * P * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dA, (size_t)N * N * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dWt, (size_t)P * N * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dv, N * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dones, N * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dmu, g->Mpad * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dinv, g->Mpad * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dmax, Ppad * sizeof(double)));
   MMG_HIP(ctx, hipMemcpyAsync(dH, Ht, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   MMG_HIP(ctx, hipMemcpyAsync(dYs, Ys, (size_t)N * P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   std::vector<double> ones((size_t)N, 1.0);
@@ -804,7 +804,6 @@ int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const
     for (int p = 0; p < P; ++p) min_rss[p] = std::min(h0_rss, yy[p] - mx[p]);   // :1164 running min from h0_rss (:1156)
   hipStreamSynchronize(ctx->stream);
   free_model(pm); free_result(pr);
-  hipFree(dH); hipFree(dYs); hipFree(dA); hipFree(dWt); hipFree(dv); hipFree(dones); hipFree(dmu); hipFree(dinv); hipFree(dmax);
   return rc;
 }
 
@@ -880,18 +879,18 @@ int mmg_comm_allgather_scan(mmg_ctx* ctx, mmg_comm* c, int64_t count, double* rs
 extern "C++" {
 template <typename T>
 static int allreduce_host(mmg_ctx* ctx, mmg_comm* c, T* buf, int64_t count, int op, ncclDataType_t dt) {
+  Scratch sc;
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, c && buf && count >= 0 && op >= 0 && op <= 2);
   if (count == 0) return MMG_OK;
   T* d = nullptr;
-  MMG_HIP(ctx, hipMalloc(&d, count * sizeof(T)));
+  MMG_HIP(ctx, sc.alloc(&d, count * sizeof(T)));
   MMG_HIP(ctx, hipMemcpyAsync(d, buf, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
   const ncclRedOp_t ops[3] = {ncclSum, ncclMin, ncclMax};
   ncclResult_t r = ncclAllReduce(d, d, count, dt, ops[op], c->comm, ctx->stream);
-  if (r != ncclSuccess) { hipFree(d); return set_err(ctx, MMG_E_LIB, std::string("ncclAllReduce: ") + ncclGetErrorString(r)); }
+  if (r != ncclSuccess) { return set_err(ctx, MMG_E_LIB, std::string("ncclAllReduce: ") + ncclGetErrorString(r)); }
   MMG_HIP(ctx, hipMemcpyAsync(buf, d, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  hipFree(d);
   return MMG_OK;
 }
 

@@ -61,6 +61,21 @@ int set_err(mmg_ctx* ctx, int code, const std::string& msg);
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// Call-scoped device scratch: everything allocated through it is freed when the entry point returns,
+// on every path (the MMG_HIP early returns included).
+struct Scratch {
+  std::vector<void*> ptrs;
+  template <typename T>
+  hipError_t alloc(T** out, size_t bytes) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    *out = (T*)p;
+    if (e == hipSuccess) ptrs.push_back(p);
+    return e;
+  }
+  ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+};
+
 struct EvScope {  // records the two events of slot `which` around a region on ctx->stream
   mmg_ctx* c; int w;
   EvScope(mmg_ctx* ctx, int which) : c(ctx), w(which) { hipEventRecord(c->ev[w][0], c->stream); }
