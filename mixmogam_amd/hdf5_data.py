@@ -59,7 +59,7 @@ def _resident_chunks(ctx, genot_data, min_maf, chunk_size, rank=0, world=1, pref
     uploaded by a helper thread on a second context/stream of the same device while the caller computes
     on the current one (the C ABI is blocking; ctypes releases the GIL): PCIe ingest overlaps the kernels."""
     items = enumerate(_chunks(genot_data, min_maf, chunk_size))
-    if not prefetch:
+    if not (prefetch and isinstance(ctx, _lib.Context)):
         for ci, (chrom, block, pos) in items:
             yield ci, chrom, (ctx.geno(block) if ci % world == rank else None), len(block), pos
         return

@@ -1,0 +1,104 @@
+"""CPU stand-in for mixmogam_amd._lib.Context, for the -m "not gpu" tests of the HOST logic only
+(REML grid/secant search, scan preparation, MLMM stepping, chunked drivers).  Test infrastructure:
+every method is a few lines of numpy/scipy; nothing in the product imports this."""
+import numpy as np
+from scipy import linalg, stats
+
+from mixmogam_amd import _lib
+
+
+class FakeGeno(_lib.Geno):
+    def __init__(self, ctx, snps):
+        self.ctx = ctx
+        self.data = np.ascontiguousarray(snps, dtype=np.int8)
+        self.M, self.N = self.data.shape
+        self.h = None
+
+    def download(self, m0=0, rows=None):
+        rows = self.M - m0 if rows is None else rows
+        return self.data[m0:m0 + rows].copy()
+
+    def snp_stats(self):
+        return self.data.mean(1), self.data.std(1)
+
+    def matvec(self, V):
+        return np.atleast_2d(V) @ self.data.T.astype(np.float64)
+
+    def close(self):
+        pass
+
+
+class FakeAcc(object):
+    def __init__(self, n):
+        self.c, self.n = np.zeros((n, n)), 0
+
+    def add(self, g, scale=None, shift=None):
+        s = g.data.astype(np.float64)
+        x = 2 * s - 1 if scale is None else s * np.asarray(scale)[:, None] + np.asarray(shift)[:, None]
+        self.c += x.T @ x
+        self.n += g.M
+
+    def fetch(self):
+        return self.c.copy(), self.n
+
+    def close(self):
+        pass
+
+
+class FakeContext(object):
+    device = 0
+
+    def geno(self, snps=None, M=None, N=None):
+        return FakeGeno(self, snps if snps is not None else np.zeros((M, N), dtype=np.int8))
+
+    def kinship_ibs_counts(self, g):
+        x = 2 * g.data.astype(np.int64) - 1
+        return x.T @ x
+
+    def kinship_indicator_counts(self, g, thr):
+        u = (g.data >= thr).astype(np.int64)
+        return u.T @ u
+
+    def kinship_affine(self, g, scale=None, shift=None):
+        a = FakeAcc(g.N)
+        a.add(g, scale, shift)
+        return a.c
+
+    def kinship_accumulator(self, n):
+        return FakeAcc(n)
+
+    def eigh(self, A, vectors=True):
+        vals, vecs = linalg.eigh(np.asarray(A, dtype=np.float64))
+        return vals, (vecs.T.copy() if vectors else None)
+
+    def dgemm(self, A, B, ta=False, tb=False):
+        return (A.T if ta else A) @ (B.T if tb else B)
+
+    def scan_set_model(self, A, w, ndigits=0):
+        self.A, self.w = np.asarray(A, dtype=np.float64), np.asarray(w, dtype=np.float64).reshape(-1)
+
+    def scan(self, g, h0_rss, df2, fetch=True, stats=False, out=None):
+        S = g.data.astype(np.float64)
+        dot = S @ self.w
+        den = np.einsum('ij,ij->i', S @ self.A, S)
+        dd = (S * S) @ np.diag(self.A)
+        ok = (den > 1e-7 * dd) & (den > 0)
+        rss = np.where(ok, h0_rss - dot * dot / np.where(ok, den, 1.0), h0_rss)
+        F = (h0_rss / rss - 1.0) * df2
+        res = {"rss": rss, "f_stats": F, "ps": self.f_sf(F, df2)}
+        if stats:
+            res.update(dot=dot, den=den, sum=S.sum(1))
+        return res
+
+    def f_sf(self, F, df2):
+        return stats.f.sf(np.asarray(F, dtype=np.float64), 1, df2)
+
+    def perm(self, g, H, Ys, h0_rss, ndigits=0):
+        S = g.data.astype(np.float64)
+        S = S - S.mean(1, keepdims=True)
+        T = S @ np.asarray(H).T
+        tt = np.einsum('ij,ij->i', T, T)
+        G = T @ np.asarray(Ys)
+        ok = tt > 1e-12 * max(tt.max(), 1e-300)
+        stat = np.where(ok[:, None], G * G / np.where(ok, tt, 1.0)[:, None], 0.0)
+        return np.minimum(h0_rss, np.einsum('ij,ij->j', Ys, Ys) - stat.max(0))

@@ -1,0 +1,89 @@
+"""-m "not gpu": the HOST side of the product (mixmogam_amd.linear_models / kinship / hdf5_data) driven
+through a numpy stand-in for the device context (tests/fake_ctx.py), against the reference's golden
+vectors.  Covers what runs on the host in production: model building, REML grid + secant search, the
+closed-form scan preparation, with_betas algebra, MLMM stepping and the chunked drivers."""
+import numpy as np
+import pytest
+
+from conftest import load_case
+from fake_ctx import FakeContext
+from mixmogam_amd import hdf5_data, kinship
+from mixmogam_amd import linear_models as lm
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+@pytest.fixture
+def ctx():
+    return FakeContext()
+
+
+def test_emmax_and_reml_host_logic_vs_golden(case, ctx):
+    res = lm.emmax(list(case["snps"]), list(case["y"]), case["dbl_ibs_scaled"], cofactors=case["cof"], ctx=ctx)
+    assert rel(res["ps"], case["dbl_emmax_ps"]) < 1e-7
+    assert rel(res["h0_rss"], case["dbl_emmax_h0_rss"]) < 1e-9
+    for k in ("pseudo_heritability", "ve", "vg", "max_ll"):
+        assert rel(res[k], case["dbl_emmax_" + k]) < 1e-8, k
+    reml = lm.get_emma_reml_estimates(list(case["y"]), case["dbl_ibs_scaled"], cofactors=case["cof"], ctx=ctx)
+    for k in ("max_ll", "delta", "ve", "vg", "pseudo_heritability"):
+        assert rel(reml[k], case["dbl_reml_" + k]) < 1e-8, k
+    assert np.max(np.abs(reml["eig_L"]["values"] - case["dbl_eig_L_values"])) < 1e-10
+
+
+def test_with_betas_and_kinship_host_logic(case, ctx):
+    lmm = lm.LinearMixedModel(list(case["y"]), ctx=ctx)
+    lmm.add_random_effect(case["dbl_ibs_scaled"])
+    if case["cof"] is not None:
+        for c in case["cof"]:
+            lmm.add_factor(c)
+    wb = lmm.emmax_f_test(case["snps"][:200], with_betas=True, emma_num=0)
+    assert np.max(np.abs(np.asarray(wb["betas"]) - case["dbl_wb_betas"])) < 1e-7 * max(1, np.abs(case["dbl_wb_betas"]).max())
+    assert rel(kinship.calc_ibs_kinship(list(case["snps"]), ctx=ctx), case["dbl_ibs_scaled"]) < 1e-13
+    assert np.max(np.abs(kinship.calc_ibd_kinship(case["snps"], ctx=ctx) - case["dbl_ibd_scaled"])) < 1e-11
+
+
+def test_add_factor_rejects_dependent_cofactor(ctx):
+    case = load_case("struct_n150_s0")
+    lmm = lm.LinearMixedModel(list(case["y"]), ctx=ctx)
+    with pytest.warns(UserWarning):
+        assert lmm.add_factor(np.full(150, 3.0)) is False          # collinear with the intercept (:105-108)
+    assert lmm.add_factor(case["snps"][0]) is True and lmm.X.shape == (150, 2)
+
+
+def test_mlmm_host_logic_vs_golden(ctx):
+    case = load_case("struct_n150_s0")
+    m = len(case["snps"])
+    res = lm.mlmm(list(case["y"]), case["dbl_ibs_scaled"], num_steps=3, forward_backwards=True,
+                  snps=case["snps"], positions=list(range(m)), chromosomes=[1] * m, ctx=ctx)
+    want = case["dbl_mlmm_steps"]
+    got = np.array([[np.nan if si[k] is None else float(np.asarray(si[k]).reshape(-1)[0])
+                     for k in ("pseudo_heritability", "ll", "bic", "e_bic", "m_bic")] for si in res["step_info_list"]])
+    assert np.allclose(got, want[:, :5], rtol=1e-6)
+    assert [[c[1] for c in si["cofactors"]] for si in res["step_info_list"]] == \
+        [[p for p in row if p >= 0] for row in case["dbl_mlmm_cof_pos"]]
+    for c in ("ebics", "mbics", "bonf", "mbonf", "min_cof_ppa"):
+        assert res["opt_dict"][c] == int(case["dbl_mlmm_opt_" + c])
+
+
+def test_chunked_driver_host_logic(ctx):
+    rng = np.random.RandomState(3)
+    n = 120
+    snps = (rng.random_sample((700, n)) < rng.uniform(0.05, 0.95, size=(700, 1))).astype(np.int8)
+    snps = snps[(snps.sum(1) > 0) & (snps.sum(1) < n)]
+    src = {"c1": {"raw_snps": snps[:400], "freqs": snps[:400].mean(1), "positions": np.arange(400)},
+           "c2": {"raw_snps": snps[400:], "freqs": snps[400:].mean(1), "positions": np.arange(len(snps) - 400)}}
+    y = rng.randn(n) + snps[3]
+    a = hdf5_data.run_emmax(src, y, min_maf=0.1, chunk_size=64, ctx=ctx)
+    b = hdf5_data.run_emmax(src, y, min_maf=0.1, chunk_size=10 ** 6, ctx=ctx)
+    for c in ("c1", "c2"):
+        assert rel(a["chrom_results"][c]["ps"], b["chrom_results"][c]["ps"]) < 1e-9
+    keep = np.minimum(snps.mean(1), 1 - snps.mean(1)) > 0.1
+    assert a["num_snps"] == int(keep.sum())
+    from oracle import emmax_oracle as orc
+    ref = orc.emmax(snps[keep], y, a["kinship"])
+    got = np.concatenate([a["chrom_results"][c]["ps"] for c in ("c1", "c2")])
+    assert rel(got, ref["ps"]) < 1e-7
