@@ -1,0 +1,105 @@
+"""GPU tests at BASELINE.json's full sizes (configs[1]: N=1000 x M=500k, configs[2]: N=5000 x M=1M).
+
+The CPU oracle cannot run these sizes end to end in seconds, so parity is shown through
+  * the oracle on SAMPLES of the full problem (SNP rows regenerated on the host by the oracle's own
+    counter-based generator, i.e. independent of the device store), p-values within 1e-6 relative;
+  * size-independent properties: diag(IBS counts) == M exactly, symmetry, additivity of counts over
+    the SNP axis, bit-identical scan results wherever a SNP sits in the launch (second half of the
+    launch == a launch of the second half), exact per-SNP genotype sums, NaN-free outputs.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+orc = pytest.importorskip("oracle.emmax_oracle")
+
+SEED = 4242
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from mixmogam_amd import _lib
+    return _lib.get_context()
+
+
+def _phenotype(n, m, seed):
+    """simulations.py:64-85 shape: a few causal SNPs + noise, h2 = 0.8 (rows from the oracle generator)."""
+    rng = np.random.RandomState(seed)
+    causal = np.sort(rng.choice(m, 20, replace=False))
+    rows = np.vstack([orc.hash_genotypes(int(c), int(c) + 1, n, SEED) for c in causal]).astype(np.float64)
+    gen = rng.exponential(1.0, size=20) @ rows
+    err = rng.normal(0, 1, size=n)
+    y = gen + err * np.sqrt(0.25 * np.var(gen, ddof=1) / np.var(err, ddof=1))
+    return (y - y.mean()) / y.std(), causal
+
+
+def _full_size(ctx, n, m):
+    from mixmogam_amd import kinship, linear_models as lm
+    g = ctx.geno(M=m, N=n).fill_hash(SEED)
+
+    # ---- kinship: exact integer properties at full size
+    counts = ctx.kinship_ibs_counts(g)
+    assert counts.shape == (n, n)
+    assert np.all(np.diag(counts) == m)
+    assert np.array_equal(counts, counts.T)
+    half = m // 2
+    g_hi = ctx.geno(M=m - half, N=n).fill_hash(SEED, m_global0=half)
+    g_lo = ctx.geno(M=half, N=n).fill_hash(SEED, m_global0=0)
+    assert np.array_equal(ctx.kinship_ibs_counts(g_lo) + ctx.kinship_ibs_counts(g_hi), counts)
+    g_lo.close()
+    # a 48-individual corner against the oracle over ALL m SNPs (oracle generator, oracle counts)
+    corner = np.zeros((48, 48), dtype=np.int64)
+    for m0 in range(0, m, 250000):
+        corner += orc.ibs_counts(orc.hash_genotypes(m0, min(m, m0 + 250000), 48, SEED))
+    assert np.array_equal(counts[:48, :48], corner)
+
+    # ---- model through the product's Python surface (host logic is pinned on golden vectors elsewhere)
+    y, causal = _phenotype(n, m, 7)
+    K = kinship.scale_k(counts.astype(np.float64) / (2.0 * m) + 0.5)
+    lmm = lm.LinearMixedModel(y, ctx=ctx)
+    lmm.add_random_effect(K)
+    est = lmm._get_estimates_with(lmm._get_eigen_L_(), lmm._get_eigen_R_(X=lmm.X), "REML")
+    prep = lmm.scan_prepare(est["H_sqrt_inv"])
+    ctx.scan_set_model(prep["A"], prep["w"], 0)
+    out = ctx.scan(g, prep["h0_rss"], prep["n_p"], stats=True)
+    ps = out["ps"]
+    assert ps.shape == (m,) and not np.any(np.isnan(ps))
+    assert np.all((ps >= 0) & (ps <= 1))            # the strongest causal SNPs underflow to 0 at N=5000, as f.sf does
+
+    # ---- oracle on samples of the full launch: the strongest hits, the causal SNPs, blocks at the ends
+    # and in the middle of the launch.  Rows come from the oracle's generator, not from the device.
+    top = np.argsort(ps)[:64]
+    pick = np.unique(np.concatenate([top, causal, np.arange(0, 300), np.arange(m // 2 - 150, m // 2 + 150),
+                                     np.arange(m - 300, m)]))
+    rows = np.vstack([orc.hash_genotypes(int(i), int(i) + 1, n, SEED) for i in pick])
+    oprep = orc.scan_prepare(y, np.ones((n, 1)), est["H_sqrt_inv"])        # A, w, h0_rss rebuilt in numpy float64
+    assert abs(oprep["h0_rss"] / prep["h0_rss"] - 1) < 1e-10
+    ref = orc.scan_closed(rows, oprep)
+    normal = ref["ps"] > 1e-290                                            # below: denormal / 0 in scipy as well
+    assert np.all(ps[pick][~normal] < 1e-289)
+    err = np.abs(ps[pick][normal] / ref["ps"][normal] - 1)
+    assert err.max() < 1e-6, "max rel p err %.3g at p=%.3g" % (err.max(), ref["ps"][normal][err.argmax()])
+    assert np.max(np.abs(out["f_stats"][pick] / ref["f_stats"] - 1)) < 1e-7
+    assert np.max(np.abs(out["rss"][pick] / ref["rss"] - 1)) < 1e-9
+    assert np.array_equal(out["sum"][pick], rows.sum(1).astype(np.float64))      # exact integers
+    # the device store itself, spot-checked against the oracle generator
+    assert np.array_equal(g.download(m - 300, 300), rows[-300:])
+
+    # ---- position independence, bit for bit: scanning the second half alone reproduces its slice
+    out_hi = ctx.scan(g_hi, prep["h0_rss"], prep["n_p"])
+    for k in ("ps", "rss", "f_stats"):
+        assert np.array_equal(out_hi[k], out[k][half:]), k
+    g_hi.close()
+    g.close()
+    return float(ps.min())
+
+
+def test_c2_n1000_m500k(ctx):
+    """BASELINE configs[1]: N=1,000 x M=500,000, IBS kinship + single-phenotype EMMAX scan."""
+    assert _full_size(ctx, 1000, 500000) < 1e-8
+
+
+def test_c3_n5000_m1M(ctx):
+    """BASELINE configs[2], the headline shape: N=5,000 x M=1,000,000."""
+    assert _full_size(ctx, 5000, 1000000) < 1e-8
