@@ -103,3 +103,39 @@ def test_c2_n1000_m500k(ctx):
 def test_c3_n5000_m1M(ctx):
     """BASELINE configs[2], the headline shape: N=5,000 x M=1,000,000."""
     assert _full_size(ctx, 5000, 1000000) < 1e-8
+
+
+def test_c4_perm_n5000_m1M_p1000(ctx):
+    """BASELINE configs[3] on one GPU: N=5,000 x M=1,000,000, 1,000 phenotype permutations.
+    Oracle: the first 1,536 SNPs of the launch against perm_closed for all 1,000 permutations;
+    properties: min over the launch == min(min over halves) bit for bit (what the 8-GPU MIN
+    all-reduce relies on), full-launch minimum <= sample minimum."""
+    n, m, P, ms = 5000, 1000000, 1000, 1536
+    g = ctx.geno(M=m, N=n).fill_hash(SEED)
+    y, _ = _phenotype(n, m, 9)
+    # any symmetric positive definite H_sqrt_inv is a valid argument of _emmax_permutations_ (:1125)
+    rng = np.random.RandomState(3)
+    B = rng.standard_normal((n, 30)) / np.sqrt(n)
+    H = np.eye(n) * 0.9 + 0.3 * (B @ B.T)
+    X = np.ones((n, 1))
+    idx = np.array([np.arange(n)] + [np.random.RandomState(50 + p).permutation(n) for p in range(1, P)])
+    pp = orc.perm_prepare(y, X, H, idx)
+    got = ctx.perm(g, H, pp["Ys"], pp["h0_rss"])
+    assert got.shape == (P,) and np.all(got > 0) and np.all(got <= pp["h0_rss"])
+
+    g_s = ctx.geno(M=ms, N=n).fill_hash(SEED)
+    ref = orc.perm_closed(orc.hash_genotypes(0, ms, n, SEED), pp)
+    got_s = ctx.perm(g_s, H, pp["Ys"], pp["h0_rss"])
+    assert np.max(np.abs(got_s / ref["min_rss"] - 1)) < 1e-9
+    assert np.all(got <= got_s)
+    g_s.close()
+
+    half = m // 2
+    g_lo = ctx.geno(M=half, N=n).fill_hash(SEED, m_global0=0)
+    a = ctx.perm(g_lo, H, pp["Ys"], pp["h0_rss"])
+    g_lo.close()
+    g_hi = ctx.geno(M=m - half, N=n).fill_hash(SEED, m_global0=half)
+    b = ctx.perm(g_hi, H, pp["Ys"], pp["h0_rss"])
+    g_hi.close()
+    assert np.array_equal(np.minimum(a, b), got)
+    g.close()
