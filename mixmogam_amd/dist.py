@@ -27,6 +27,10 @@ def file_bootstrap(rank, world, timeout_s=120.0):
     import time
     key = "%s_%s_%s_%d" % (os.environ.get("MASTER_ADDR", "local"), os.environ.get("MASTER_PORT", "0"),
                            os.environ.get("TORCHELASTIC_RUN_ID", "none"), world)
+    if "TORCHELASTIC_RUN_ID" in os.environ:
+        # the ranks of one torch.distributed.run launch are children of the same agent process: its pid
+        # separates back-to-back launches that reuse a port (a stale file of a crashed run is never read)
+        key += "_%d" % os.getppid()
     path = os.path.join("/tmp", "mmg_rdzv_" + "".join(c if c.isalnum() else "_" for c in key) + ".bin")
     t_start = time.time()
 
