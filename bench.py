@@ -234,12 +234,18 @@ def cpu_baseline(N, sample, lmm, est, prep, gpu_ps):
     out = orc.scan_loop(snps, p, dtype=np.float32)
     dt = time.time() - t0
     agree = float(np.nanmax(np.abs(out["ps"][:len(gpu_ps)] / gpu_ps[:len(out["ps"])] - 1)))
+    blas, blas4 = "unknown", None
     try:
         import threadpoolctl
         blas = ";".join("%s:%s" % (d.get("internal_api"), d.get("num_threads")) for d in threadpoolctl.threadpool_info())
+        # the reference pins its BLAS to 4 threads (linear_models.py:37): the same loop on a quarter of the sample
+        with threadpoolctl.threadpool_limits(limits=4):
+            t0 = time.time()
+            orc.scan_loop(snps[:max(N, sample // 4)], p, dtype=np.float32)
+            blas4 = max(N, sample // 4) / (time.time() - t0)
     except Exception:
-        blas = "unknown"
-    return {"value": sample / dt, "unit": "SNPs/s", "cores": os.cpu_count(), "kind": "port",
+        pass
+    return {"value": sample / dt, "value_blas_4_threads": blas4, "unit": "SNPs/s", "cores": os.cpu_count(), "kind": "port",
             "sample": "first %d SNPs of the same workload (chunks of N), fp32 reference loop, %.1f s; BLAS %s"
                       % (sample, dt, blas),
             "max_rel_p_diff_vs_gpu": agree}
