@@ -167,6 +167,9 @@ int mmg_geno_create(mmg_ctx* ctx, int64_t M, int32_t N, mmg_geno** out) {
   g->Npad = (int32_t)round_up(N, 256);
   hipError_t e = hipMalloc(&g->d, (size_t)g->Mpad * g->Npad);
   if (e != hipSuccess) { delete g; return set_err(ctx, MMG_E_NOMEM, std::string("hipMalloc genotype store: ") + hipGetErrorString(e)); }
+  e = hipMalloc(&g->d_smax, sizeof(int));
+  if (e != hipSuccess) { hipFree(g->d); delete g; return set_err(ctx, MMG_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+  MMG_HIP(ctx, hipMemsetAsync(g->d_smax, 0, sizeof(int), ctx->stream));
   MMG_HIP(ctx, hipMemsetAsync(g->d, 0, (size_t)g->Mpad * g->Npad, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *out = g;
@@ -178,7 +181,19 @@ int mmg_geno_destroy(mmg_ctx* ctx, mmg_geno* g) {
   if (ctx) hipStreamSynchronize(ctx->stream);
   hipFree(g->d);
   hipFree(g->bits);
+  hipFree(g->d_smax);
   delete g;
+  return MMG_OK;
+}
+
+// every write path ends here: fold max |s| of the written rows into the store's running bound
+static int refresh_smax(mmg_ctx* ctx, mmg_geno* g, int64_t m0, int64_t rows) {
+  launch_absmax_i8(ctx, g->d + m0 * (int64_t)g->Npad, rows * (int64_t)g->Npad, g->d_smax);
+  MMG_HIP(ctx, hipGetLastError());
+  int v = 0;
+  MMG_HIP(ctx, hipMemcpyAsync(&v, g->d_smax, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  g->smax = std::max(g->smax, v);
   return MMG_OK;
 }
 
@@ -189,8 +204,7 @@ int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, i
   g->bits_valid = false;
   MMG_HIP(ctx, hipMemcpy2DAsync(g->d + m0 * (int64_t)g->Npad, g->Npad, snps, g->N, g->N, rows,
                                 hipMemcpyHostToDevice, ctx->stream));
-  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return MMG_OK;
+  return refresh_smax(ctx, g, m0, rows);
 }
 
 extern "C++" {
@@ -210,7 +224,7 @@ static int upload_cvt(mmg_ctx* ctx, mmg_geno* g, const T* snps, int64_t m0, int6
     else launch_cvt_f64(ctx, (const double*)tmp, g->d + (m0 + r0) * (int64_t)g->Npad, nr, g->N, g->Npad);
     MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  return MMG_OK;
+  return refresh_smax(ctx, g, m0, rows);
 }
 }  // extern C++
 int mmg_geno_upload_f32(mmg_ctx* ctx, mmg_geno* g, const float* snps, int64_t m0, int64_t rows) {
@@ -241,6 +255,7 @@ int mmg_geno_fill_hash(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_globa
   }
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  g->smax = std::max(g->smax, 1);                     // the generator writes 0 / 1
   return MMG_OK;
 }
 
@@ -461,6 +476,11 @@ int mmg_eigh_f64(mmg_ctx* ctx, const double* A, int32_t N, double* evals, double
   Scratch sc;
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, A && evals && N > 0);
+  // rocSOLVER 7.2 has no 64-bit-index syevd: element offsets lda*N wrap at N*N >= 2^31 and the
+  // solver faults on the device (seen at N = 50000).  Refuse instead.
+  if ((int64_t)N * N >= (int64_t)1 << 31)
+    return set_err(ctx, MMG_E_ARG, "mmg_eigh_f64: N = " + std::to_string(N) +
+                                       " exceeds the 32-bit index range of rocsolver_dsyevd (N <= 46340)");
   rocblas_handle h;
   int rc = get_rocblas(ctx, &h);
   if (rc) return rc;

@@ -1,6 +1,7 @@
 // k_pack.hip -- HBM-bound byte kernels around the genotype store: synthetic fill, dtype
 // conversion on ingest, SNP-major -> individual-major transposition for the kinship GEMM, and
 // per-SNP mean / std (kinship.py:66).  All are streaming kernels with 16-byte accesses.
+#include <algorithm>
 #include "mmg_internal.h"
 
 namespace mmg {
@@ -134,6 +135,30 @@ __global__ __launch_bounds__(256) void snp_stats_kernel(const int8_t* __restrict
 void launch_snp_stats(mmg_ctx* ctx, const mmg_geno* g, double* mean, double* sd) {
   hipLaunchKernelGGL(snp_stats_kernel, dim3((unsigned)((g->M + 3) / 4)), dim3(256), 0, ctx->stream, g->d,
                      g->M, g->N, g->Npad, mean, sd);
+}
+
+// max |s| over a 16-byte aligned range (write paths of the genotype store keep an upper bound of it)
+__global__ __launch_bounds__(256) void absmax_i8_kernel(const int8_t* __restrict__ p, int64_t n16, int* __restrict__ out) {
+  int mx = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 v = *(const uint4*)(p + i * 16);
+    const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int x = (int)(int8_t)((wds[j >> 2] >> (8 * (j & 3))) & 0xff);
+      mx = max(mx, x < 0 ? -x : x);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(out, mx);
+}
+
+void launch_absmax_i8(mmg_ctx* ctx, const int8_t* p, int64_t bytes, int* d_out) {
+  const int64_t n16 = bytes >> 4;
+  if (n16 <= 0) return;
+  const int64_t nb = std::min<int64_t>((n16 + 255) / 256, 4096);
+  hipLaunchKernelGGL(absmax_i8_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, p, n16, d_out);
 }
 
 }  // namespace mmg

@@ -201,7 +201,9 @@ int run_scan_quad(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, unsigned 
     if (rc) return rc;
   }
   EvScope ev(ctx, EV_QUAD);
+  const bool want_w4s = kv && std::string(kv) == "w4s" && !std::getenv("MMG_ABLATE");
   if (want_bits && g->binary) launch_scan_quad_bits(ctx, g, md, q);
+  else if (want_w4s) launch_scan_quad_w4s(ctx, g, md, q);
   else launch_scan_quad(ctx, g, md, q);
   return MMG_OK;
 }

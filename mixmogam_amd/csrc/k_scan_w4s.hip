@@ -1,0 +1,319 @@
+// k_scan_w4s.hip -- quadratic-form GEMM of the EMMAX scan, third generation: 4 waves per workgroup
+// (one per SIMD, the whole 512-entry register file), wave tile 128 x 128, and a software pipeline
+// that is written out slice by slice instead of being left to the compiler:
+//
+//   K step = 128 bytes = 4 slices of 32 bytes; per wave and slice: 16 MFMA (4 x 4 tiles of
+//   v_mfma_i32_32x32x32_i8), 8 ds_read_b128 that fetch the NEXT slice's fragments into the other half
+//   of a register double buffer, and (slices 0 and 3 only) 8 LDS-DMA pieces -- interleaved
+//   MFMA / ds_read / MFMA / DMA, so that the matrix pipe never waits for an address-path burst.
+//
+//   LDS: the 2-slot, 128-byte-row image of gemm_i8_core.h (same swizzle).  Stage u = K step u of the
+//   workgroup's flattened job stream (the prefetch never drains at a job boundary):
+//       step t, slice 0:  Q half of stage t+1  -> slot (t+1)&1
+//       step t, slices 0-2: MFMA on slot t&1 (fragments one slice ahead)
+//       s_waitcnt vmcnt(0) lgkmcnt(0) ; s_barrier        <- the only barrier of the step
+//       step t, slice 3:  MFMA on registers; fragments of step t+1 slice 0 from slot (t+1)&1;
+//                         P half of stage t+2 -> slot t&1
+//     RAW: stage t+1 (P half issued in step t-1, Q half in slice 0 of step t) is complete on every wave
+//          at that wave's vmcnt(0) before the barrier; it is first read after the barrier.
+//     WAR: slot t&1 is rewritten (P: slice 3 of step t, Q: slice 0 of step t+1) only after the barrier,
+//          which every wave reaches with lgkmcnt(0), i.e. with all its reads of slot t&1 returned.
+//   The barrier sits before the LAST slice, whose fragments are already in registers, so no wave waits
+//   for LDS latency after it.  Beyond the end of the stream the cursor re-issues the last stage into
+//   slots nobody reads (branch-free step body); the kernel drains vmcnt before it exits.
+//
+//   Epilogue operands (the genotype bytes s[snp][256J + j] that multiply row j of the accumulators) are
+//   the Q tiles of the job's last two K steps: wave row-half wm captures its 64 dwords from LDS during
+//   step nks-2+wm (before that step's barrier) and keeps them in registers.
+//
+// Results are bit-identical to scan_quad_kernel (exact integers, 64-bit integer atomics).
+#include <algorithm>
+#include <cstdlib>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include "gemm_i8_core.h"
+#include "gemm_i8_w4.h"
+#include "mmg_internal.h"
+
+namespace mmg {
+
+struct Frag4 {
+  v4i a[4], b[4];
+};
+
+__device__ __forceinline__ v16i mfma8(v4i a, v4i b, v16i c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
+
+// interleave hint for one slice: (MFMA, ds_read, MFMA, [DMA]) x 8
+template <int NDMA>
+__device__ __forceinline__ void sched_slice() {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if (i < NDMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+  }
+}
+
+// Fragments are fetched in the order a0 b0 a1 b1 a2 b2 a3 b3 (one per two MFMAs) and the MFMAs of the next
+// slice consume them in the order of their arrival (ORD), so every fragment has at least 12 MFMA slots
+// (~400 cycles) between its ds_read and its first use.
+__device__ constexpr int ORD_M[16] = {0, 1, 0, 1, 2, 2, 0, 1, 2, 3, 3, 3, 0, 1, 2, 3};
+__device__ constexpr int ORD_N[16] = {0, 0, 1, 1, 0, 1, 2, 2, 2, 0, 1, 2, 3, 3, 3, 3};
+
+// One slice: 16 MFMA on `cur`; fragment reads of (slot `src`, chunk) into `nxt`; DMA pieces [P0, P1) of the
+// cursor's stage (pieces 0-7: P rows, 8-15: Q rows of this wave) into slot `dst`.
+template <bool LOAD, int P0, int P1, bool ZERO = false>
+__device__ __forceinline__ void slice(v16i (&acc)[4][4], const Frag4& cur, Frag4& nxt, const char* src, int arow,
+                                      int brow, int chunk, const StageOp4& sp, const StageOp4& sq, int k0, char* dst,
+                                      int wave) {
+  static_assert(P1 - P0 <= 8, "at most one DMA piece per MFMA pair");
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m0 = ORD_M[2 * i], n0 = ORD_N[2 * i], m1 = ORD_M[2 * i + 1], n1 = ORD_N[2 * i + 1];
+    if (ZERO) acc[m0][n0] = mfma8(cur.a[m0], cur.b[n0], v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0});
+    else acc[m0][n0] = mfma8(cur.a[m0], cur.b[n0], acc[m0][n0]);
+    if (LOAD) {
+      if ((i & 1) == 0) nxt.a[i >> 1] = lds_frag(src, arow + (i >> 1) * 32, chunk);
+      else nxt.b[i >> 1] = lds_frag(src + TILE_BYTES, brow + (i >> 1) * 32, chunk);
+    }
+    if (ZERO) acc[m1][n1] = mfma8(cur.a[m1], cur.b[n1], v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0});
+    else acc[m1][n1] = mfma8(cur.a[m1], cur.b[n1], acc[m1][n1]);
+    if (P0 + i < P1) {
+      const int pc = P0 + i;
+      if (pc < 8) stage_piece4(sp, k0, dst, wave, pc);
+      else stage_piece4(sq, k0, dst + TILE_BYTES, wave, pc - 8);
+    }
+  }
+  sched_slice<(P1 > P0 ? P1 - P0 : 0)>();
+}
+
+// ABL: 0 = production; timing ablations with WRONG results: 1 = no DMA in the loop, 2 = no fragment reads in
+// the loop, 3 = trivial epilogue.
+// N3/N0/N1: DMA pieces of a stage issued in slice 3 (right after the barrier that frees the slot) and in slices
+// 0 / 1 of the following step; the remaining 16 - N3 - N0 - N1 go into slice 2.
+// FAST: |s| * Npad < 2^16 and s^2 * Npad < 2^18 (checked on the host from the store's tracked max |s|): every
+// accumulator fits 24 bits and a lane's 64 products per SNP fit 32 bits, so the epilogue runs on v_mad_i32_i24.
+template <int ABL, int N3, int N0, int N1, bool FAST>
+__global__ __launch_bounds__(W4_THREADS) void scan_quad_w4s_kernel(
+    const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Bq, int64_t ldB,
+    int64_t digit_stride, const int* __restrict__ job_off, const int2* __restrict__ jobs, int AS,
+    unsigned long long* __restrict__ q, unsigned long long* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr bool LD = ABL != 2;
+  unsigned long long seg[4] = {0, 0, 0, 0};              // ABL 4: cycles in {vmcnt+lgkm wait, barrier, epilogue, total}
+  const unsigned long long T0 = ABL == 4 ? stamp() : 0;
+  constexpr int E3 = ABL == 1 ? 0 : N3, E0 = ABL == 1 ? 0 : N3 + N0, E1 = ABL == 1 ? 0 : N3 + N0 + N1,
+                E2 = ABL == 1 ? 0 : 16;
+  const int b = blockIdx.x;
+  const int x = b & 7, bi = b >> 3;
+  const int cohort = bi >> 5, within = bi & 31;
+  const int a_ = within % AS, grp = within / AS;
+  const int sb = (cohort * 8 + x) * AS + a_;
+  if (sb >= nSb) return;
+  const int j0 = job_off[grp], j1 = job_off[grp + 1];
+  if (j1 <= j0) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1, r = lane & 31, h = lane >> 5;
+  const int8_t* Q = S + (int64_t)sb * TN * ldS;
+  const int arow = wm * 128 + r, brow = wn * 128 + r;
+
+  // ---- issue cursor over the flattened stage stream (wave-uniform scalars)
+  int cj = j0;                                           // job of the stage the cursor points at
+  int2 cjb = jobs[cj];
+  int cks = 0, cnks = 2 * (cjb.y + 1);
+  StageOp4 sp = make_stage_op4(Bq + (int64_t)cjb.x * digit_stride + (int64_t)cjb.y * TM * ldB, ldB, wave, lane);
+  const StageOp4 sq = make_stage_op4(Q, ldS, wave, lane);
+  auto advance = [&]() {
+    if (cks + 1 < cnks) { ++cks; return; }
+    if (cj + 1 < j1) {
+      ++cj;
+      cjb = jobs[cj];
+      cks = 0;
+      cnks = 2 * (cjb.y + 1);
+      sp.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(Bq + (int64_t)cjb.x * digit_stride + (int64_t)cjb.y * TM * ldB),
+                                                0, 0x7fffffff, 0x00020000);
+    }                                                    // else: stay on the last stage (harmless re-issue)
+  };
+
+  // ---- prologue: stage 0 complete, the first N3 pieces of stage 1 in flight, fragments of step 0 slice 0
+#pragma unroll
+  for (int i = 0; i < 8; ++i) stage_piece4(sp, 0, lds, wave, i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) stage_piece4(sq, 0, lds + TILE_BYTES, wave, i);
+  advance();                                             // -> stage 1
+#pragma unroll
+  for (int i = 0; i < N3; ++i) {
+    if (i < 8) stage_piece4(sp, cks * BK, lds + BUF_BYTES, wave, i);
+    else stage_piece4(sq, cks * BK, lds + BUF_BYTES + TILE_BYTES, wave, i - 8);
+  }
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N3) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  Frag4 f0, f1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f0.a[i] = lds_frag(lds, arow + i * 32, h);
+    f0.b[i] = lds_frag(lds + TILE_BYTES, brow + i * 32, h);
+  }
+
+  v16i acc[4][4];                                        // written (not accumulated) by the first slice of every job
+  unsigned long long qacc[4] = {0ull, 0ull, 0ull, 0ull};
+  int cap[4][4][2][2];                                   // [n][m][chunk of the 32-byte group][dword pair]
+
+  int t = 0;
+  // capture: dwords (4h + 8q) / 4 of every 32-byte row group of this wave's 4 x 32 SNP rows, from the Q tile
+  // of the step about to run (must be issued before that step's barrier)
+  auto capture = [&]() {
+    const char* qt = lds + (t & 1) * BUF_BYTES + TILE_BYTES;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const int row = brow + n * 32;
+          const int* p = (const int*)(qt + row * BK + (((2 * m + cc) ^ ((row >> 1) & 7)) << 4)) + h;
+          cap[n][m][cc][0] = p[0];
+          cap[n][m][cc][1] = p[2];
+        }
+  };
+  auto step = [&](int ks) {
+    char* cur = lds + (t & 1) * BUF_BYTES;
+    char* oth = lds + ((t + 1) & 1) * BUF_BYTES;
+    // slices 0-2: MFMA on slot t&1; the rest of stage t+1 (the cursor's stage) -> the other slot
+    const int k1 = cks * BK;
+    if (ks == 0) slice<LD, E3, E0, true>(acc, f0, f1, cur, arow, brow, 2 + h, sp, sq, k1, oth, wave);
+    else slice<LD, E3, E0>(acc, f0, f1, cur, arow, brow, 2 + h, sp, sq, k1, oth, wave);
+    slice<LD, E0, E1>(acc, f1, f0, cur, arow, brow, 4 + h, sp, sq, k1, oth, wave);
+    slice<LD, E1, E2>(acc, f0, f1, cur, arow, brow, 6 + h, sp, sq, k1, oth, wave);
+    const unsigned long long tb0 = ABL == 4 ? stamp() : 0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long tb1 = ABL == 4 ? stamp() : 0;
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ABL == 4) { const unsigned long long tb2 = stamp(); seg[0] += tb1 - tb0; seg[1] += tb2 - tb1; }
+    advance();                                           // -> stage t+2
+    // slice 3: MFMA on registers; fragments of step t+1 slice 0; first pieces of stage t+2 -> the slot just retired
+    slice<LD, 0, E3>(acc, f1, f0, oth, arow, brow, h, sp, sq, cks * BK, cur, wave);
+    ++t;
+  };
+  for (int jj = j0; jj < j1; ++jj) {
+    const int2 jb = jobs[jj];
+    const int d = jb.x, nks = 2 * (jb.y + 1);
+    for (int ks = 0; ks < nks - 2; ++ks) step(ks);
+    capture();                                           // step nks-2 holds the operands of row half wm = 0 ...
+    step(nks - 2);
+    if (wm == 1) capture();                              // ... and step nks-1 those of row half wm = 1
+    step(nks - 1);
+    // ---- epilogue of job jj: qacc[n] += (sum_j T[j][snp] * s[snp][256J + j]) << 8d, then clear
+    const unsigned long long te0 = ABL == 4 ? stamp() : 0;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      long long part = 0;
+      if (ABL == 3) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) part += acc[m][n][0] + cap[n][m][0][0];
+      } else if (FAST) {
+        int p32 = 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+              const int wd = cap[n][m][cc][gp];
+              const int g4 = 2 * cc + gp;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) p32 += __mul24(acc[m][n][g4 * 4 + e], (int)(int8_t)((wd >> (8 * e)) & 0xff));
+              __builtin_amdgcn_sched_barrier(0);           // keep the AGPR reads next to their use (register pressure)
+            }
+        part = p32;
+      } else {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+              const int wd = cap[n][m][cc][gp];
+              const int g4 = 2 * cc + gp;
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                part += (long long)acc[m][n][g4 * 4 + e] * (long long)(int)(int8_t)((wd >> (8 * e)) & 0xff);
+            }
+      }
+      qacc[n] += ((unsigned long long)part) << (8 * d);
+    }
+    if (ABL == 4) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) asm volatile("" : "+v"(qacc[n]));
+      seg[2] += stamp() - te0;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the re-issued tail stages must land before LDS is released
+  if (ABL == 4 && lane == 0 && blockIdx.x < 16384) {
+    seg[3] = stamp() - T0;
+    unsigned long long* o = dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+    o[0] = seg[0]; o[1] = seg[1]; o[2] = seg[2]; o[3] = seg[3]; o[4] = (unsigned long long)t;
+  }
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    unsigned long long v = qacc[n];
+    v += __shfl_xor(v, 32);
+    if (h == 0) atomicAdd(q + (int64_t)sb * TN + wn * 128 + n * 32 + r, v);
+  }
+}
+
+void launch_scan_quad_w4s(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, unsigned long long* q) {
+  const int nSb = (int)(g->Mpad / TN);
+  const int per = 8 * md.AS;
+  const int ncoh = (nSb + per - 1) / per;
+  int abl = 0, dist = 0;
+  const int64_t smax = g->smax;
+  bool fast = smax * md.Npad < (1 << 16) && smax * smax * md.Npad < (1 << 18);
+  if (std::getenv("MMG_W4S_SLOW_EPI")) fast = false;
+  if (const char* e = std::getenv("MMG_W4S_ABL")) abl = std::atoi(e);
+  if (const char* e = std::getenv("MMG_W4S_DIST")) dist = std::atoi(e);
+#define MMG_LAUNCH_W4S(...)                                                                                             \
+  do {                                                                                                                  \
+    hipFuncSetAttribute((const void*)scan_quad_w4s_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                        LDS_BYTES);                                                                                     \
+    hipLaunchKernelGGL((scan_quad_w4s_kernel<__VA_ARGS__>), dim3((unsigned)(ncoh * 256)), dim3(W4_THREADS), LDS_BYTES, \
+                       ctx->stream, g->d, (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad,                               \
+                       (int64_t)md.Npad * md.Npad, md.job_off, md.jobs, md.AS, q, dbg);                                 \
+  } while (0)
+  static unsigned long long* dbg = nullptr;
+  if (abl == 4) {
+    const size_t n = (size_t)16384 * 4 * 8;
+    if (!dbg) hipMalloc(&dbg, n * sizeof(unsigned long long));
+    hipMemsetAsync(dbg, 0, n * sizeof(unsigned long long), ctx->stream);
+    if (fast) MMG_LAUNCH_W4S(4, 8, 8, 0, true); else MMG_LAUNCH_W4S(4, 8, 8, 0, false);
+    std::vector<unsigned long long> hbuf(n);
+    hipMemcpyAsync(hbuf.data(), dbg, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+    hipStreamSynchronize(ctx->stream);
+    double sm[5] = {0, 0, 0, 0, 0};
+    long cnt = 0;
+    for (size_t w = 0; w < (size_t)16384 * 4; ++w) {
+      if (hbuf[w * 8 + 4] == 0) continue;
+      for (int k = 0; k < 5; ++k) sm[k] += (double)hbuf[w * 8 + k];
+      ++cnt;
+    }
+    if (cnt)
+      fprintf(stderr, "[w4s stamps] waves %ld  K-steps/wave %.0f  per K-step cycles: total %.0f  mem wait %.0f  barrier %.0f  "
+                      "epilogue (amortised) %.0f\n", cnt, sm[4] / cnt, sm[3] / sm[4], sm[0] / sm[4], sm[1] / sm[4], sm[2] / sm[4]);
+    return;
+  }
+  if (abl == 1) MMG_LAUNCH_W4S(1, 8, 8, 0, true);
+  else if (abl == 2) MMG_LAUNCH_W4S(2, 8, 8, 0, true);
+  else if (abl == 3) MMG_LAUNCH_W4S(3, 8, 8, 0, true);
+  else if (dist == 1 && fast) MMG_LAUNCH_W4S(0, 6, 5, 5, true);
+  else if (fast) MMG_LAUNCH_W4S(0, 8, 8, 0, true);
+  else MMG_LAUNCH_W4S(0, 8, 8, 0, false);
+#undef MMG_LAUNCH_W4S
+}
+
+}  // namespace mmg

@@ -13,6 +13,10 @@ struct mmg_geno {
   // lazily built bit-packed twin [Mpad x Npad/8] (k_scan_bits.hip); invalidated by every write
   uint8_t* bits = nullptr;
   bool bits_valid = false, binary = false;
+  // upper bound of |s| over everything ever written to the store (updated by every write path); the scan uses
+  // it to prove that its 32-bit epilogue cannot overflow
+  int smax = 0;
+  int* d_smax = nullptr;
 };
 
 enum { EV_KIN = 0, EV_QUAD = 1, EV_FIN = 2, EV_PERM = 3, EV_EIGH = 4, EV_PACK = 5, EV_COUNT = 6 };
@@ -91,7 +95,9 @@ void launch_cvt_f64(mmg_ctx*, const double* src, int8_t* dst, int64_t rows, int3
 // thr > 0: indicator image [s >= thr] instead of the affine map
 void launch_transpose(mmg_ctx*, const mmg_geno*, int8_t* Xt, int64_t Mk, int mul, int add, int64_t m_begin,
                       int thr = 0);
+void launch_absmax_i8(mmg_ctx*, const int8_t* p, int64_t bytes, int* d_out);
 void launch_snp_stats(mmg_ctx*, const mmg_geno*, double* mean, double* sd);
+void launch_absmax_i8(mmg_ctx*, const int8_t* p, int64_t bytes, int* d_out);   // *d_out = max(*d_out, max |p[i]|); bytes % 16 == 0
 
 // ---- k_kinship.hip
 int kinship_pick_ksplit(int32_t Npad, int64_t Mk, bool f32);
@@ -111,6 +117,7 @@ void launch_scan_quad(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned
 // ---- k_scan_bits.hip (binary genotypes staged as bits)
 int ensure_bits(mmg_ctx*, mmg_geno*);
 void launch_scan_quad_bits(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
+void launch_scan_quad_w4s(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
 // picks the bit-packed kernel for 0/1 genotypes unless MMG_SCAN_KERNEL names another variant
 int run_scan_quad(mmg_ctx*, mmg_geno*, const mmg_scan_model&, unsigned long long* q);
 void launch_scan_finalize(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, mmg_scan_result&,

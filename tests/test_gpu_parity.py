@@ -520,3 +520,12 @@ def test_mlmm_forward_backward_vs_golden(ctx):
     for c in ("ebics", "mbics", "bonf", "mbonf", "min_cof_ppa"):
         assert res["opt_dict"][c] == int(case["dbl_mlmm_opt_" + c]), c
     assert rel(res["first_emmax_res"]["ps"], case["dbl_mlmm_first_ps"]) < 1e-6
+
+
+def test_eigh_refuses_sizes_beyond_rocsolver_index_range(ctx):
+    """N*N >= 2^31 overflows rocsolver_dsyevd's 32-bit element offsets (device fault at N = 50000):
+    the ABI returns an error before touching the buffers."""
+    from mixmogam_amd import _lib
+    dummy = np.zeros(4)
+    rc = ctx.lib.mmg_eigh_f64(ctx.h, _lib._ptr(dummy), 46341, _lib._ptr(dummy), None)
+    assert rc != 0 and b"46340" in ctx.lib.mmg_last_error(ctx.h)
