@@ -192,18 +192,25 @@ void launch_scan_quad_bits(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model
 }
 
 int run_scan_quad(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, unsigned long long* q) {
+  // MMG_SCAN_KERNEL selects a generation of the quadratic-form GEMM (all bit-identical):
+  //   (unset) / w4s   4 waves x 128x128, hand-laid pipeline (k_scan_w4s.hip)            -- production
+  //   q8              8 waves x 128x64, loader waves (k_scan.hip; also what MMG_ABLATE instruments)
+  //   w4b / bits      bit-packed genotype operand for binary stores (k_scan_w4b.hip / this file): fewer bytes
+  //                   through L2 and LDS, but the fragment expansion costs more than it saves (+5...8 %)
+  //   timed, w4, m16, flat, ring, pp    earlier experiments kept for A/B runs (k_scan.hip)
   const char* kv = std::getenv("MMG_SCAN_KERNEL");
-  // The bit-packed kernel is bit-identical and moves 44 % fewer bytes per K step, but the fragment
-  // expansion puts it at the SIMD's VALU issue limit: 16.3 ms vs 15.6 ms (M=400k, N=5000).  Opt-in.
-  const bool want_bits = kv && std::string(kv) == "bits" && !std::getenv("MMG_ABLATE");
+  const std::string k = kv ? kv : "";
+  const bool ablate = std::getenv("MMG_ABLATE") != nullptr;
+  const bool want_w4b = k == "w4b" && !ablate;
+  const bool want_bits = (k == "bits" || want_w4b) && !ablate;
   if (want_bits) {
     int rc = ensure_bits(ctx, g);                     // once per store content
     if (rc) return rc;
   }
   EvScope ev(ctx, EV_QUAD);
-  const bool want_w4s = kv && std::string(kv) == "w4s" && !std::getenv("MMG_ABLATE");
-  if (want_bits && g->binary) launch_scan_quad_bits(ctx, g, md, q);
-  else if (want_w4s) launch_scan_quad_w4s(ctx, g, md, q);
+  if (want_w4b && g->binary) launch_scan_quad_w4b(ctx, g, md, q);
+  else if (want_bits && g->binary) launch_scan_quad_bits(ctx, g, md, q);
+  else if (!ablate && (k.empty() || k == "w4s" || k == "w4b" || k == "bits")) launch_scan_quad_w4s(ctx, g, md, q);
   else launch_scan_quad(ctx, g, md, q);
   return MMG_OK;
 }

@@ -529,3 +529,43 @@ def test_eigh_refuses_sizes_beyond_rocsolver_index_range(ctx):
     dummy = np.zeros(4)
     rc = ctx.lib.mmg_eigh_f64(ctx.h, _lib._ptr(dummy), 46341, _lib._ptr(dummy), None)
     assert rc != 0 and b"46340" in ctx.lib.mmg_last_error(ctx.h)
+
+
+@pytest.mark.parametrize("variant", ["q8", "w4b", "bits", "flat", "ring"])
+def test_scan_kernel_generations_agree_bit_for_bit(ctx, monkeypatch, variant):
+    """Every generation of the quadratic-form GEMM (MMG_SCAN_KERNEL) accumulates the same exact integers:
+    den / rss / p are bit-identical to the production kernel on a ragged multi-tile problem, for binary
+    genotypes (all kernels) and for 0/1/2 genotypes (where the bit-packed ones fall back)."""
+    rng = np.random.RandomState(5)
+    n, m = 1100, 2500
+    B = rng.standard_normal((n, 30)) / 6
+    A = np.eye(n) + B @ B.T / n
+    w = rng.standard_normal(n)
+    ctx.scan_set_model(A, w, 4)
+    for hi in (2, 3):                                   # genotype alphabet {0,1} / {0,1,2}
+        snps = rng.randint(0, hi, size=(m, n)).astype(np.int8)
+        g = ctx.geno(snps)
+        monkeypatch.delenv("MMG_SCAN_KERNEL", raising=False)
+        base = ctx.scan(g, 1e6, n - 2, stats=True)
+        monkeypatch.setenv("MMG_SCAN_KERNEL", variant)
+        alt = ctx.scan(g, 1e6, n - 2, stats=True)
+        monkeypatch.delenv("MMG_SCAN_KERNEL", raising=False)
+        for k in ("den", "rss", "ps"):
+            assert np.array_equal(base[k], alt[k]), (variant, hi, k)
+        S = snps[:64].astype(np.float64)
+        assert rel(base["den"][:64], np.einsum("ij,ij->i", S @ A, S)) < 1e-8
+        g.close()
+
+
+def test_scan_wide_genotype_values_use_the_64bit_epilogue(ctx):
+    """|s| up to 100: the store's tracked max |s| sends the scan down the 64-bit epilogue (the 24-bit one
+    would overflow); den still matches float64."""
+    rng = np.random.RandomState(6)
+    n, m = 700, 600
+    B = rng.standard_normal((n, 10)) / 4
+    A = np.eye(n) + B @ B.T / n
+    ctx.scan_set_model(A, rng.standard_normal(n), 4)
+    snps = rng.randint(-100, 101, size=(m, n)).astype(np.int8)
+    out = ctx.scan(ctx.geno(snps), 1e12, n - 2, stats=True)
+    S = snps.astype(np.float64)
+    assert rel(out["den"], np.einsum("ij,ij->i", S @ A, S)) < 1e-8
