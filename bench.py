@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+QUAD_KERNEL = "scan_quad_w4s_kernel"   # the dominant kernel (k_scan_w4s.hip); its name in rocprofv3 / profiles/
 I8_MFMA_PEAK_TOPS = 5000.0     # dense int8 MFMA: 2x the ~2.5 PF bf16 rate (MI355X_MICROARCH.md, Matrix cores)
 F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 (same guide)
 
@@ -160,7 +161,7 @@ def main():
         try:   # HBM bytes per launch measured with rocprofv3 PMC passes of this same command (profiles/)
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_c3.json")))
             if tj["config"] == {"n": N, "m": M, "digits": D}:
-                traffic = tj["kernels"]["scan_quad_kernel"]["hbm_bytes_corrected"]
+                traffic = tj["kernels"][QUAD_KERNEL]["hbm_bytes_corrected"]
         except Exception:
             pass
         res = {
@@ -172,7 +173,7 @@ def main():
                                    "Bernoulli(0.5) hash genotypes resident in HBM, q=1" % (N, M),
                        "n_individuals": N, "snps_per_gpu": M, "snps_total": Mtot, "digits": D,
                        "parallelism": "snp-block x%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "scan_quad_kernel", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": QUAD_KERNEL, "achieved": achieved,
                          "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s", "frac": achieved / I8_MFMA_PEAK_TOPS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/traffic_c3.json)",
                          "algorithmic_bytes": float(-(-M // 256) * 256 * Npad + D * Npad * Npad), "ms": qms,

@@ -64,7 +64,7 @@ __device__ constexpr int ORD_N[16] = {0, 0, 1, 1, 0, 1, 2, 2, 2, 0, 1, 2, 3, 3, 
 
 // One slice: 16 MFMA on `cur`; fragment reads of (slot `src`, chunk) into `nxt`; DMA pieces [P0, P1) of the
 // cursor's stage (pieces 0-7: P rows, 8-15: Q rows of this wave) into slot `dst`.
-template <bool LOAD, int P0, int P1, bool ZERO = false>
+template <bool LOAD, int P0, int P1, bool ZERO = false, bool HOT = false>
 __device__ __forceinline__ void slice(v16i (&acc)[4][4], const Frag4& cur, Frag4& nxt, const char* src, int arow,
                                       int brow, int chunk, const StageOp4& sp, const StageOp4& sq, int k0, char* dst,
                                       int wave) {
@@ -82,6 +82,11 @@ __device__ __forceinline__ void slice(v16i (&acc)[4][4], const Frag4& cur, Frag4
     else acc[m1][n1] = mfma8(cur.a[m1], cur.b[n1], acc[m1][n1]);
     if (P0 + i < P1) {
       const int pc = P0 + i;
+      if (HOT) {                                       // ablation: same LDS-DMA traffic, source always the same 2 KiB
+        if (pc < 8) stage_piece4(sq, 0, dst, wave, pc & 1);
+        else stage_piece4(sq, 0, dst + TILE_BYTES, wave, pc & 1);
+        continue;
+      }
       if (pc < 8) stage_piece4(sp, k0, dst, wave, pc);
       else stage_piece4(sq, k0, dst + TILE_BYTES, wave, pc - 8);
     }
@@ -90,7 +95,7 @@ __device__ __forceinline__ void slice(v16i (&acc)[4][4], const Frag4& cur, Frag4
 }
 
 // ABL: 0 = production; timing ablations with WRONG results: 1 = no DMA in the loop, 2 = no fragment reads in
-// the loop, 3 = trivial epilogue.
+// the loop, 3 = trivial epilogue, 4 = in-kernel stamps, 5 = all DMA pieces read the same 2 KiB (L1-resident).
 // N3/N0/N1: DMA pieces of a stage issued in slice 3 (right after the barrier that frees the slot) and in slices
 // 0 / 1 of the following step; the remaining 16 - N3 - N0 - N1 go into slice 2.
 // FAST: |s| * Npad < 2^16 and s^2 * Npad < 2^18 (checked on the host from the store's tracked max |s|): every
@@ -175,10 +180,11 @@ __global__ __launch_bounds__(W4_THREADS) void scan_quad_w4s_kernel(
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
-          const int row = brow + n * 32;
-          const int* p = (const int*)(qt + row * BK + (((2 * m + cc) ^ ((row >> 1) & 7)) << 4)) + h;
-          cap[n][m][cc][0] = p[0];
-          cap[n][m][cc][1] = p[2];
+          // whole 16-byte chunks (conflict-free like the fragment reads; ds_read2_b32 of just the two dwords
+          // cost 17 % LDS bank-conflict cycles), then the lane's half: dwords h and h + 2
+          const v4i ch = lds_frag(qt, brow + n * 32, 2 * m + cc);
+          cap[n][m][cc][0] = h ? ch[1] : ch[0];
+          cap[n][m][cc][1] = h ? ch[3] : ch[2];
         }
   };
   auto step = [&](int ks) {
@@ -186,10 +192,11 @@ __global__ __launch_bounds__(W4_THREADS) void scan_quad_w4s_kernel(
     char* oth = lds + ((t + 1) & 1) * BUF_BYTES;
     // slices 0-2: MFMA on slot t&1; the rest of stage t+1 (the cursor's stage) -> the other slot
     const int k1 = cks * BK;
-    if (ks == 0) slice<LD, E3, E0, true>(acc, f0, f1, cur, arow, brow, 2 + h, sp, sq, k1, oth, wave);
-    else slice<LD, E3, E0>(acc, f0, f1, cur, arow, brow, 2 + h, sp, sq, k1, oth, wave);
-    slice<LD, E0, E1>(acc, f1, f0, cur, arow, brow, 4 + h, sp, sq, k1, oth, wave);
-    slice<LD, E1, E2>(acc, f0, f1, cur, arow, brow, 6 + h, sp, sq, k1, oth, wave);
+    constexpr bool HOT = ABL == 5;
+    if (ks == 0) slice<LD, E3, E0, true, HOT>(acc, f0, f1, cur, arow, brow, 2 + h, sp, sq, k1, oth, wave);
+    else slice<LD, E3, E0, false, HOT>(acc, f0, f1, cur, arow, brow, 2 + h, sp, sq, k1, oth, wave);
+    slice<LD, E0, E1, false, HOT>(acc, f1, f0, cur, arow, brow, 4 + h, sp, sq, k1, oth, wave);
+    slice<LD, E1, E2, false, HOT>(acc, f0, f1, cur, arow, brow, 6 + h, sp, sq, k1, oth, wave);
     const unsigned long long tb0 = ABL == 4 ? stamp() : 0;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long tb1 = ABL == 4 ? stamp() : 0;
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(W4_THREADS) void scan_quad_w4s_kernel(
     if (ABL == 4) { const unsigned long long tb2 = stamp(); seg[0] += tb1 - tb0; seg[1] += tb2 - tb1; }
     advance();                                           // -> stage t+2
     // slice 3: MFMA on registers; fragments of step t+1 slice 0; first pieces of stage t+2 -> the slot just retired
-    slice<LD, 0, E3>(acc, f1, f0, oth, arow, brow, h, sp, sq, cks * BK, cur, wave);
+    slice<LD, 0, E3, false, HOT>(acc, f1, f0, oth, arow, brow, h, sp, sq, cks * BK, cur, wave);
     ++t;
   };
   for (int jj = j0; jj < j1; ++jj) {
@@ -310,6 +317,7 @@ void launch_scan_quad_w4s(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model&
   if (abl == 1) MMG_LAUNCH_W4S(1, 8, 8, 0, true);
   else if (abl == 2) MMG_LAUNCH_W4S(2, 8, 8, 0, true);
   else if (abl == 3) MMG_LAUNCH_W4S(3, 8, 8, 0, true);
+  else if (abl == 5) MMG_LAUNCH_W4S(5, 8, 8, 0, true);
   else if (dist == 1 && fast) MMG_LAUNCH_W4S(0, 6, 5, 5, true);
   else if (fast) MMG_LAUNCH_W4S(0, 8, 8, 0, true);
   else MMG_LAUNCH_W4S(0, 8, 8, 0, false);
