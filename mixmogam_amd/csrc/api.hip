@@ -461,6 +461,12 @@ int mmg_kinship_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N, const
 }
 
 // ------------------------------------------------------------------------- eigh / dgemm
+}  // extern "C" (reopened below)
+namespace mmg {
+int eigh_block_jacobi(mmg_ctx* ctx, rocblas_handle h, double* dA, int32_t N, int32_t block, double* evals, double* evecs,
+                      std::string& err);
+}
+extern "C" {
 static int get_rocblas(mmg_ctx* ctx, rocblas_handle* h) {
   if (!ctx->rocblas) {
     rocblas_handle hh;
@@ -476,11 +482,30 @@ int mmg_eigh_f64(mmg_ctx* ctx, const double* A, int32_t N, double* evals, double
   Scratch sc;
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, A && evals && N > 0);
-  // rocSOLVER 7.2 has no 64-bit-index syevd: element offsets lda*N wrap at N*N >= 2^31 and the
-  // solver faults on the device (seen at N = 50000).  Refuse instead.
-  if ((int64_t)N * N >= (int64_t)1 << 31)
-    return set_err(ctx, MMG_E_ARG, "mmg_eigh_f64: N = " + std::to_string(N) +
-                                       " exceeds the 32-bit index range of rocsolver_dsyevd (N <= 46340)");
+  // rocSOLVER 7.2 has no 64-bit-index syevd: element offsets lda*N wrap at N*N >= 2^31 and the solver faults
+  // on the device (seen at N = 50000).  Beyond that range -- or when MMG_EIGH_BLOCK=<rows> asks for it (tests) --
+  // the block-Jacobi solver of eigh_block.hip runs dsyevd on block pairs that stay inside the range.
+  {
+    int block = 0;
+    if (const char* e = std::getenv("MMG_EIGH_BLOCK")) block = std::atoi(e);
+    if ((int64_t)N * N >= (int64_t)1 << 31 && (block <= 0 || block > 23168)) block = 23168;
+    if (block > 0 && N > block) {
+      rocblas_handle hb;
+      int rcb = get_rocblas(ctx, &hb);
+      if (rcb) return rcb;
+      double* dAb = nullptr;
+      MMG_HIP(ctx, sc.alloc(&dAb, (size_t)N * N * sizeof(double)));
+      MMG_HIP(ctx, hipMemcpyAsync(dAb, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      std::string err;
+      int rce;
+      {
+        EvScope ev(ctx, EV_EIGH);
+        rce = eigh_block_jacobi(ctx, hb, dAb, N, block, evals, evecs, err);
+      }
+      if (rce) return set_err(ctx, rce, err);
+      return MMG_OK;
+    }
+  }
   rocblas_handle h;
   int rc = get_rocblas(ctx, &h);
   if (rc) return rc;
@@ -529,7 +554,7 @@ int mmg_dgemm_f64(mmg_ctx* ctx, int ta, int tb, int32_t M, int32_t N, int32_t K,
   MMG_HIP(ctx, hipMemcpyAsync(dB, B, (size_t)K * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   const double one = 1.0, zero = 0.0;
   // row-major C = op(A) op(B)  <=>  column-major C^T = op(B)^T op(A)^T
-  rocblas_status st = rocblas_dgemm(h, tb ? rocblas_operation_transpose : rocblas_operation_none,
+  rocblas_status st = rocblas_dgemm_64(h, tb ? rocblas_operation_transpose : rocblas_operation_none,
                                     ta ? rocblas_operation_transpose : rocblas_operation_none, N, M, K, &one, dB,
                                     tb ? K : N, dA, ta ? M : K, &zero, dC, N);
   hipError_t e = hipMemcpyAsync(C, dC, (size_t)M * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
@@ -757,7 +782,7 @@ static int dgemm_dev(mmg_ctx* ctx, int ta, int tb, int M, int N, int K, const do
   int rc = get_rocblas(ctx, &h);
   if (rc) return rc;
   const double one = 1.0, zero = 0.0;
-  MMG_RB(ctx, rocblas_dgemm(h, tb ? rocblas_operation_transpose : rocblas_operation_none,
+  MMG_RB(ctx, rocblas_dgemm_64(h, tb ? rocblas_operation_transpose : rocblas_operation_none,
                             ta ? rocblas_operation_transpose : rocblas_operation_none, N, M, K, &one, dB,
                             tb ? K : N, dA, ta ? M : K, &zero, dC, N));
   return MMG_OK;

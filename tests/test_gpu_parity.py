@@ -522,15 +522,6 @@ def test_mlmm_forward_backward_vs_golden(ctx):
     assert rel(res["first_emmax_res"]["ps"], case["dbl_mlmm_first_ps"]) < 1e-6
 
 
-def test_eigh_refuses_sizes_beyond_rocsolver_index_range(ctx):
-    """N*N >= 2^31 overflows rocsolver_dsyevd's 32-bit element offsets (device fault at N = 50000):
-    the ABI returns an error before touching the buffers."""
-    from mixmogam_amd import _lib
-    dummy = np.zeros(4)
-    rc = ctx.lib.mmg_eigh_f64(ctx.h, _lib._ptr(dummy), 46341, _lib._ptr(dummy), None)
-    assert rc != 0 and b"46340" in ctx.lib.mmg_last_error(ctx.h)
-
-
 @pytest.mark.parametrize("variant", ["q8", "w4b", "bits", "flat", "ring"])
 def test_scan_kernel_generations_agree_bit_for_bit(ctx, monkeypatch, variant):
     """Every generation of the quadratic-form GEMM (MMG_SCAN_KERNEL) accumulates the same exact integers:
@@ -569,3 +560,27 @@ def test_scan_wide_genotype_values_use_the_64bit_epilogue(ctx):
     out = ctx.scan(ctx.geno(snps), 1e12, n - 2, stats=True)
     S = snps.astype(np.float64)
     assert rel(out["den"], np.einsum("ij,ij->i", S @ A, S)) < 1e-8
+
+
+def test_eigh_block_jacobi_matches_direct(ctx, monkeypatch):
+    """The solver used beyond rocSOLVER's index range (block Jacobi over dsyevd pair problems), forced at a
+    small size with ragged blocks: eigenvalues equal the direct solver's to 1e-12 relative to the spectral
+    norm, eigenvectors are orthonormal and satisfy K v = lambda v; a kinship-like spectrum (a few large
+    eigenvalues + bulk) and a clustered one."""
+    rng = np.random.RandomState(12)
+    n = 1111
+    X = (rng.random_sample((n, 3000)) < 0.4).astype(np.float64)
+    K1 = X @ X.T / 3000.0
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    K2 = (Q * np.repeat([1.0, 1.0 + 1e-9, 2.0, 5.0], [400, 300, 400, 11])) @ Q.T
+    for K in (K1, 0.5 * (K2 + K2.T)):
+        monkeypatch.delenv("MMG_EIGH_BLOCK", raising=False)
+        v0, _ = ctx.eigh(K)
+        monkeypatch.setenv("MMG_EIGH_BLOCK", "320")          # 4 blocks: 320, 320, 320, 151
+        v1, U = ctx.eigh(K)
+        monkeypatch.delenv("MMG_EIGH_BLOCK", raising=False)
+        scale = np.abs(v0).max()
+        assert np.max(np.abs(v1 - v0)) < 1e-12 * scale
+        assert np.all(np.diff(v1) >= 0)
+        assert np.max(np.abs(U @ U.T - np.eye(n))) < 1e-11     # rows are the eigenvectors
+        assert np.max(np.abs(K @ U.T - U.T * v1)) < 1e-10 * scale
