@@ -376,62 +376,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void scan_quad_ring_kernel(
   }
 }
 
-// Experiment: 4 waves per workgroup, 128 x 128 wave tiles (gemm_i8_w4.h).
-__global__ __launch_bounds__(W4_THREADS, 1) void scan_quad_w4_kernel(
-    const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Bq, int64_t ldB,
-    int64_t digit_stride, const int* __restrict__ job_off, const int2* __restrict__ jobs, int AS,
-    unsigned long long* __restrict__ q) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int b = blockIdx.x;
-  const int x = b & 7, i = b >> 3;
-  const int cohort = i >> 5, within = i & 31;
-  const int a = within % AS, grp = within / AS;
-  const int sb = (cohort * 8 + x) * AS + a;
-  if (sb >= nSb) return;
-  const int j0 = job_off[grp], j1 = job_off[grp + 1];
-  if (j1 <= j0) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;
-  const int8_t* Q = S + (int64_t)sb * TN * ldS;
-  unsigned long long qacc[4] = {0ull, 0ull, 0ull, 0ull};
-  int2* jl = (int2*)(lds + LDS_BYTES);
-  for (int t = threadIdx.x; t < j1 - j0; t += W4_THREADS) jl[t] = jobs[j0 + t];
-  __syncthreads();
-  auto tile = [&](int t) {
-    const int2 jb = jl[t];
-    TileDesc d;
-    d.P = Bq + (int64_t)jb.x * digit_stride + (int64_t)jb.y * TM * ldB;
-    d.Q = Q;
-    d.nks = 2 * (jb.y + 1);
-    return d;
-  };
-  auto epi = [&](int t, v16i (&acc)[4][4]) {
-    const int2 jb = jl[t];
-    const int d = jb.x, J = jb.y;
-#pragma unroll
-    for (int nn = 0; nn < 4; ++nn) {
-      const int8_t* srow = Q + (int64_t)(wn * 128 + nn * 32 + r) * ldS + J * TM + wm * 128 + 4 * h;
-      long long part = 0;
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int wd = *(const int*)(srow + m * 32 + 8 * g4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            part += (long long)acc[m][nn][g4 * 4 + e] * (long long)(int)(int8_t)((wd >> (8 * e)) & 0xff);
-        }
-      qacc[nn] += ((unsigned long long)part) << (8 * d);
-    }
-  };
-  run_tiles_w4(j1 - j0, ldB, ldS, lds, tile, epi);
-#pragma unroll
-  for (int nn = 0; nn < 4; ++nn) {
-    unsigned long long v = qacc[nn];
-    v += __shfl_xor(v, 32);
-    if (h == 0) atomicAdd(q + (int64_t)sb * TN + wn * 128 + nn * 32 + r, v);
-  }
-}
 
 void launch_scan_quad(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, unsigned long long* q) {
   const int nSb = (int)(g->Mpad / TN);
@@ -447,14 +391,6 @@ void launch_scan_quad(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md,
                        md.job_off, md.jobs, md.AS, q);                                                            \
   } while (0)
   const char* kv = std::getenv("MMG_SCAN_KERNEL");
-  if (ablate == 5 && kv && std::string(kv) == "w4") {
-    const int lds_bytes = LDS_BYTES + 8 * std::max(1, md.njobs);
-    hipFuncSetAttribute((const void*)scan_quad_w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    hipLaunchKernelGGL(scan_quad_w4_kernel, dim3((unsigned)(ncoh * 256)), dim3(W4_THREADS), lds_bytes, ctx->stream,
-                       g->d, (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad, (int64_t)md.Npad * md.Npad,
-                       md.job_off, md.jobs, md.AS, q);
-    return;
-  }
   if (ablate == 5 && kv && std::string(kv) == "timed") {
     static unsigned long long* dbg = nullptr;
     if (!dbg) hipMalloc(&dbg, (size_t)2048 * 8 * 8 * sizeof(unsigned long long));

@@ -197,7 +197,7 @@ int run_scan_quad(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, unsigned 
   //   q8              8 waves x 128x64, loader waves (k_scan.hip; also what MMG_ABLATE instruments)
   //   w4b / bits      bit-packed genotype operand for binary stores (k_scan_w4b.hip / this file): fewer bytes
   //                   through L2 and LDS, but the fragment expansion costs more than it saves (+5...8 %)
-  //   timed, w4, m16, flat, ring, pp    earlier experiments kept for A/B runs (k_scan.hip)
+  //   timed, m16, flat, ring, pp    earlier experiments kept for A/B runs (k_scan.hip)
   const char* kv = std::getenv("MMG_SCAN_KERNEL");
   const std::string k = kv ? kv : "";
   const bool ablate = std::getenv("MMG_ABLATE") != nullptr;
