@@ -121,26 +121,29 @@ def main():
         if coll is not None:
             coll.barrier()
 
-    # result buffers are allocated once and page-locked (mmg_host_alloc) so the fetch runs at PCIe rate
-    outs = [ctx.pinned_empty(M * world) for _ in range(3)]
+    # Result buffers are allocated once and page-locked (mmg_host_alloc).  Delivery is double buffered: the
+    # (rss, F, p) of step i are snapshotted on the device and all-gathered over RCCL / downloaded on a second
+    # HIP stream (mmg_scan_deliver_begin) while step i+1 scans; the last delivery is awaited inside the timed
+    # region, so every step's results are on the host of every rank before the closing barrier.
+    outs2 = [[ctx.pinned_empty(M * world) for _ in range(3)] for _ in range(2)]
+    comm_h = coll.h if coll is not None else None
 
-    def step():
+    def step(i):
         ctx.scan(g, prep["h0_rss"], n_p, fetch=False)           # blocks until the kernels finish
-        if coll is not None:
-            ctx._check(ctx.lib.mmg_comm_allgather_scan(ctx.h, coll.h, M, *[_lib._ptr(o) for o in outs]))
-        else:
-            ctx._check(ctx.lib.mmg_scan_fetch(ctx.h, M, *[_lib._ptr(o) for o in outs]))
-        return outs
+        ctx.scan_deliver_begin(outs2[i & 1], count=M, comm=comm_h)
+        return outs2[i & 1]
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
+    ctx.scan_deliver_wait()
     quad_ms, fin_ms = [], []
     barrier()
     t0 = time.time()
-    for _ in range(args.steps):
-        out = step()
+    for i in range(args.steps):
+        out = step(i)
         quad_ms.append(ctx.kernel_ms("scan_quad"))
         fin_ms.append(ctx.kernel_ms("scan_finalize"))
+    ctx.scan_deliver_wait()
     barrier()
     elapsed = time.time() - t0
     if coll is not None:
@@ -172,7 +175,9 @@ def main():
             "config": {"workload": "EMMAX scan N=%d individuals x M=%d SNPs per GPU (BASELINE configs[2] shape), "
                                    "Bernoulli(0.5) hash genotypes resident in HBM, q=1" % (N, M),
                        "n_individuals": N, "snps_per_gpu": M, "snps_total": Mtot, "digits": D,
-                       "parallelism": "snp-block x%d" % world},
+                       "parallelism": "snp-block x%d" % world,
+                       "delivery": "double buffered: step i's results are gathered (RCCL) / downloaded on a second "
+                                   "stream while step i+1 scans; the last one is awaited inside the timed region"},
             "roofline": {"bound": "mfma", "kernel": QUAD_KERNEL, "achieved": achieved,
                          "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s", "frac": achieved / I8_MFMA_PEAK_TOPS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/traffic_c3.json)",

@@ -164,6 +164,15 @@ int mmg_comm_destroy(mmg_ctx* ctx, mmg_comm* c);
  * mmg_emmax_scan_device: recv_* are host buffers of world*count doubles (rank-major). */
 int mmg_comm_allgather_scan(mmg_ctx* ctx, mmg_comm* c, int64_t count,
                             double* rss, double* F, double* p);
+/* The same delivery in the background (what the all-gather row of SURVEY 8e becomes when scans are
+ * issued back to back, e.g. per chromosome / per phenotype): snapshots the device-resident
+ * (rss, F, p) of the last scan, then on a second HIP stream all-gathers them over RCCL (c != NULL;
+ * host buffers of world*count doubles) or just downloads this rank's block (c == NULL; count
+ * doubles), so that the next mmg_emmax_scan_device overlaps the gather and the PCIe transfer.
+ * Host buffers must stay valid -- and should be page-locked (mmg_host_alloc) -- until
+ * mmg_scan_deliver_wait returns.  One delivery in flight per context: begin waits for the previous. */
+int mmg_scan_deliver_begin(mmg_ctx* ctx, mmg_comm* c, int64_t count, double* rss, double* F, double* p);
+int mmg_scan_deliver_wait(mmg_ctx* ctx);
 /* in-place all-reduce of host double buffers through device staging (SUM: partial kinship;
  * MIN: permutation minima).  op: 0 = sum, 1 = min, 2 = max. */
 int mmg_comm_allreduce_f64(mmg_ctx* ctx, mmg_comm* c, double* buf, int64_t count, int op);

@@ -53,6 +53,8 @@ PROTOTYPES = {
     "mmg_kin_acc_fetch": (C.c_int, [c_vp, c_vp, c_vp, c_i64p]),
     "mmg_kin_acc_destroy": (C.c_int, [c_vp, c_vp]),
     "mmg_kinship_i8": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp, c_vp, c_vp]),
+    "mmg_scan_deliver_begin": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, c_vp, c_vp]),
+    "mmg_scan_deliver_wait": (C.c_int, [c_vp]),
     "mmg_eigh_f64": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp]),
     "mmg_dgemm_f64": (C.c_int, [c_vp, C.c_int, C.c_int, C.c_int32, C.c_int32, C.c_int32, c_vp, c_vp, c_vp]),
     "mmg_scan_set_model": (C.c_int, [c_vp, C.c_int32, c_vp, c_vp, C.c_int]),
@@ -318,6 +320,15 @@ class Context(object):
             self._check(self.lib.mmg_scan_fetch_stats(self.h, g.M, _ptr(dot), _ptr(den), _ptr(sm)))
             out.update(dot=dot, den=den, sum=sm)
         return out
+
+    def scan_deliver_begin(self, outs, count=None, comm=None):
+        """Background delivery of the last scan's (rss, F, p) into the three host arrays `outs`
+        (page-locked for overlap): this rank's `count` values, or the RCCL all-gather over `comm`."""
+        self._check(self.lib.mmg_scan_deliver_begin(self.h, comm, int(count if count is not None else len(outs[0])),
+                                                    *[_ptr(o) for o in outs]))
+
+    def scan_deliver_wait(self):
+        self._check(self.lib.mmg_scan_deliver_wait(self.h))
 
     def f_sf(self, F, df2):
         F = _arr(np.asarray(F).reshape(-1), np.float64)

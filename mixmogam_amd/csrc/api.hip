@@ -44,8 +44,6 @@ using namespace mmg;
 struct mmg_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
-  double* stage = nullptr;     // device staging for the packed all-gather, grown on demand
-  size_t stage_elems = 0;
 };
 
 extern "C" {
@@ -71,6 +69,9 @@ int mmg_ctx_create(int device, mmg_ctx** out) {
   mmg_ctx* ctx = new mmg_ctx();
   ctx->device = device;
   MMG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  MMG_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  MMG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_snap, hipEventDisableTiming));
+  MMG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_deliver, hipEventDisableTiming));
   for (int i = 0; i < EV_COUNT; ++i) {
     MMG_HIP(ctx, hipEventCreate(&ctx->ev[i][0]));
     MMG_HIP(ctx, hipEventCreate(&ctx->ev[i][1]));
@@ -96,10 +97,15 @@ int mmg_ctx_destroy(mmg_ctx* ctx) {
   if (!ctx) return MMG_OK;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  hipStreamSynchronize(ctx->stream2);
   free_model(ctx->model);
   free_result(ctx->res);
+  hipFree(ctx->dstage);
   if (ctx->rocblas) rocblas_destroy_handle((rocblas_handle)ctx->rocblas);
   for (int i = 0; i < EV_COUNT; ++i) { hipEventDestroy(ctx->ev[i][0]); hipEventDestroy(ctx->ev[i][1]); }
+  hipEventDestroy(ctx->ev_snap);
+  hipEventDestroy(ctx->ev_deliver);
+  hipStreamDestroy(ctx->stream2);
   hipStreamDestroy(ctx->stream);
   delete ctx;
   return MMG_OK;
@@ -879,46 +885,66 @@ int mmg_comm_create(mmg_ctx* ctx, const unsigned char id[128], int rank, int wor
 
 int mmg_comm_destroy(mmg_ctx* ctx, mmg_comm* c) {
   if (!c) return MMG_OK;
-  if (ctx) hipStreamSynchronize(ctx->stream);
+  if (ctx) { hipStreamSynchronize(ctx->stream); hipStreamSynchronize(ctx->stream2); ctx->deliver_pending = false; }
   if (c->comm) ncclCommDestroy(c->comm);
-  hipFree(c->stage);
   fflush(stdout);
   delete c;
   return MMG_OK;
 }
 
-int mmg_comm_allgather_scan(mmg_ctx* ctx, mmg_comm* c, int64_t count, double* rss, double* F, double* p) {
+int mmg_scan_deliver_wait(mmg_ctx* ctx) {
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
-  MMG_CHECK_ARG(ctx, c && count >= 0 && count <= ctx->res.cap);
+  if (!ctx->deliver_pending) return MMG_OK;
+  ctx->deliver_pending = false;
+  MMG_HIP(ctx, hipEventSynchronize(ctx->ev_deliver));
+  return MMG_OK;
+}
+
+int mmg_scan_deliver_begin(mmg_ctx* ctx, mmg_comm* c, int64_t count, double* rss, double* F, double* p) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, count >= 0 && count <= ctx->res.cap);
+  int rc = mmg_scan_deliver_wait(ctx);              // one delivery in flight: the staging is reused
+  if (rc) return rc;
   if (count == 0) return MMG_OK;
-  // one collective for the three result vectors: pack [3][count] -> gathered [world][3][count]
-  const size_t need = (size_t)(c->world + 1) * 3 * count;
-  if (c->stage_elems < need) {
-    hipFree(c->stage);
-    c->stage = nullptr; c->stage_elems = 0;
-    MMG_HIP(ctx, hipMalloc(&c->stage, need * sizeof(double)));
-    c->stage_elems = need;
+  const int world = c ? c->world : 1;
+  // snapshot [3][count] (so the next scan may overwrite the result arrays) + gathered [world][3][count]
+  const size_t need = (size_t)(world + 1) * 3 * count;
+  if (ctx->dstage_elems < need) {
+    hipFree(ctx->dstage);
+    ctx->dstage = nullptr; ctx->dstage_elems = 0;
+    MMG_HIP(ctx, hipMalloc(&ctx->dstage, need * sizeof(double)));
+    ctx->dstage_elems = need;
   }
-  double* pack = c->stage;
-  double* gathered = c->stage + (size_t)3 * count;
+  double* pack = ctx->dstage;
+  double* gathered = c ? ctx->dstage + (size_t)3 * count : pack;
   const double* srcs[3] = {ctx->res.rss, ctx->res.F, ctx->res.p};
   double* dsts[3] = {rss, F, p};
   for (int k = 0; k < 3; ++k)
     MMG_HIP(ctx, hipMemcpyAsync(pack + (size_t)k * count, srcs[k], count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-  int rc = MMG_OK;
-  ncclResult_t r = ncclAllGather(pack, gathered, (size_t)3 * count, ncclDouble, c->comm, ctx->stream);
-  if (r != ncclSuccess) rc = set_err(ctx, MMG_E_LIB, std::string("ncclAllGather: ") + ncclGetErrorString(r));
-  for (int k = 0; k < 3 && rc == MMG_OK; ++k) {
-    if (!dsts[k]) continue;
-    for (int w = 0; w < c->world && rc == MMG_OK; ++w) {
-      hipError_t e = hipMemcpyAsync(dsts[k] + (size_t)w * count, gathered + ((size_t)w * 3 + k) * count,
-                                    count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-      if (e != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e));
-    }
+  MMG_HIP(ctx, hipEventRecord(ctx->ev_snap, ctx->stream));
+  MMG_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_snap, 0));
+  if (c) {
+    // one collective for the three result vectors: [3][count] -> [world][3][count]
+    ncclResult_t r = ncclAllGather(pack, gathered, (size_t)3 * count, ncclDouble, c->comm, ctx->stream2);
+    if (r != ncclSuccess) return set_err(ctx, MMG_E_LIB, std::string("ncclAllGather: ") + ncclGetErrorString(r));
   }
-  hipError_t e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess && rc == MMG_OK) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e));
-  return rc;
+  for (int k = 0; k < 3; ++k) {
+    if (!dsts[k]) continue;
+    for (int w = 0; w < world; ++w)
+      MMG_HIP(ctx, hipMemcpyAsync(dsts[k] + (size_t)w * count, gathered + ((size_t)w * 3 + k) * count,
+                                  count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream2));
+  }
+  MMG_HIP(ctx, hipEventRecord(ctx->ev_deliver, ctx->stream2));
+  ctx->deliver_pending = true;
+  return MMG_OK;
+}
+
+int mmg_comm_allgather_scan(mmg_ctx* ctx, mmg_comm* c, int64_t count, double* rss, double* F, double* p) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_CHECK_ARG(ctx, c != nullptr);
+  int rc = mmg_scan_deliver_begin(ctx, c, count, rss, F, p);
+  if (rc) return rc;
+  return mmg_scan_deliver_wait(ctx);
 }
 
 extern "C++" {

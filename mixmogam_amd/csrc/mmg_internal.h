@@ -51,6 +51,12 @@ struct mmg_ctx {
   mmg_scan_model model;
   mmg_scan_result res;
   void* rocblas = nullptr;      // rocblas_handle, created lazily
+  // background delivery of scan results (mmg_scan_deliver_*): second stream, snapshot staging, one in flight
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_snap = nullptr, ev_deliver = nullptr;
+  double* dstage = nullptr;
+  size_t dstage_elems = 0;
+  bool deliver_pending = false;
 };
 
 namespace mmg {
