@@ -137,6 +137,31 @@ idx = np.array([np.random.RandomState(5 + p).permutation(n) for p in range(6)])
 pp = orc.perm_prepare(y, X, est["H_sqrt_inv"], idx)
 mn = mdist.sharded_perm_min(orc.perm_closed(snps[m0:m1], pp)["min_rss"], coll)
 assert np.allclose(mn, orc.perm_closed(snps, pp)["min_rss"], rtol=1e-12)
+# the product's chunked driver (hdf5_data.run_emmax / run_emmax_perm) with chunks dealt to the two ranks,
+# through the numpy stand-in context: kinship partial sums all-reduced, per-chunk p-values and permutation
+# minima combined -- equal to the single-rank run
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from fake_ctx import FakeContext
+from mixmogam_amd import hdf5_data
+src = {"chr%%d" %% c: {"raw_snps": snps[c * 167:(c + 1) * 167], "freqs": snps[c * 167:(c + 1) * 167].mean(1),
+                     "positions": np.arange(167) + 1000 * c} for c in range(3)}
+pidx = [np.random.RandomState(9 + p).permutation(n) for p in range(5)]
+both = hdf5_data.run_emmax(src, y, min_maf=0.05, chunk_size=50, ctx=FakeContext(), coll=coll)
+solo = hdf5_data.run_emmax(src, y, min_maf=0.05, chunk_size=50, ctx=FakeContext(), coll=None)
+assert both["num_snps"] == solo["num_snps"]
+assert np.allclose(both["kinship"], solo["kinship"], rtol=1e-12, atol=1e-12)
+assert abs(both["pseudo_heritability"] - solo["pseudo_heritability"]) < 1e-9
+for c in solo["chrom_results"]:
+    assert np.allclose(both["chrom_results"][c]["ps"], solo["chrom_results"][c]["ps"], rtol=1e-9)
+# permutations shuffle the elements of the ROTATED residual, so they depend on the sign LAPACK gives each
+# eigenvector (a 1e-16 difference in K can flip one): compare on the same kinship matrix
+bothp = hdf5_data.run_emmax(src, y, min_maf=0.05, chunk_size=50, ctx=FakeContext(), coll=coll, num_perm=5,
+                            perm_idx=pidx, k=solo["kinship"])
+solop = hdf5_data.run_emmax(src, y, min_maf=0.05, chunk_size=50, ctx=FakeContext(), coll=None, num_perm=5,
+                            perm_idx=pidx, k=solo["kinship"])
+assert np.allclose(bothp["perm_min_ps"], solop["perm_min_ps"], rtol=1e-9)
+assert np.allclose(bothp["perm_max_f_stats"], solop["perm_max_f_stats"], rtol=1e-9)
+assert bothp["threshold_05"] == solop["threshold_05"] or np.allclose(bothp["threshold_05"], solop["threshold_05"], rtol=1e-9)
 coll.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
