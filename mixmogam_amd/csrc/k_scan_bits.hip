@@ -194,10 +194,10 @@ void launch_scan_quad_bits(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model
 int run_scan_quad(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, unsigned long long* q) {
   // MMG_SCAN_KERNEL selects a generation of the quadratic-form GEMM (all bit-identical):
   //   (unset) / w4s   4 waves x 128x128, hand-laid pipeline (k_scan_w4s.hip)            -- production
-  //   q8              8 waves x 128x64, loader waves (k_scan.hip; also what MMG_ABLATE instruments)
+  //   q8              8 waves x 128x64, loader waves (k_scan_q8.hip; also what MMG_ABLATE instruments)
   //   w4b / bits      bit-packed genotype operand for binary stores (k_scan_w4b.hip / this file): fewer bytes
   //                   through L2 and LDS, but the fragment expansion costs more than it saves (+5...8 %)
-  //   timed, m16, flat, ring, pp    earlier experiments kept for A/B runs (k_scan.hip)
+  //   timed, m16, flat, ring, pp    earlier experiments kept for A/B runs (k_scan_q8.hip)
   const char* kv = std::getenv("MMG_SCAN_KERNEL");
   const std::string k = kv ? kv : "";
   const bool ablate = std::getenv("MMG_ABLATE") != nullptr;
