@@ -124,6 +124,7 @@ void launch_scan_quad(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned
 int ensure_bits(mmg_ctx*, mmg_geno*);
 void launch_scan_quad_bits(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
 void launch_scan_quad_w4s(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
+void launch_scan_quad_w4m(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
 void launch_scan_quad_w4b(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
 // picks the bit-packed kernel for 0/1 genotypes unless MMG_SCAN_KERNEL names another variant
 int run_scan_quad(mmg_ctx*, mmg_geno*, const mmg_scan_model&, unsigned long long* q);

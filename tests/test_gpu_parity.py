@@ -522,7 +522,7 @@ def test_mlmm_forward_backward_vs_golden(ctx):
     assert rel(res["first_emmax_res"]["ps"], case["dbl_mlmm_first_ps"]) < 1e-6
 
 
-@pytest.mark.parametrize("variant", ["q8", "w4b", "bits", "flat", "ring"])
+@pytest.mark.parametrize("variant", ["q8", "w4m", "w4b", "bits", "flat", "ring"])
 def test_scan_kernel_generations_agree_bit_for_bit(ctx, monkeypatch, variant):
     """Every generation of the quadratic-form GEMM (MMG_SCAN_KERNEL) accumulates the same exact integers:
     den / rss / p are bit-identical to the production kernel on a ragged multi-tile problem, for binary
