@@ -29,6 +29,9 @@ if ROOT not in sys.path:
 
 QUAD_KERNEL = "scan_quad_w4s_kernel"   # the dominant kernel (k_scan_w4s.hip); its name in rocprofv3 / profiles/
 I8_MFMA_PEAK_TOPS = 5000.0     # dense int8 MFMA: 2x the ~2.5 PF bf16 rate (MI355X_MICROARCH.md, Matrix cores)
+# What a bare v_mfma_i32_32x32x32_i8 loop on random operands sustains on this chip (power-limited clock 2.07 GHz;
+# tools/probes/mfma_shape_probe.hip).  Reported beside the nominal peak, never instead of it.
+I8_MFMA_SUSTAINED_TOPS = 4230.0
 F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 (same guide)
 
 
@@ -183,7 +186,8 @@ def main():
                          "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/traffic_c3.json)",
                          "algorithmic_bytes": float(-(-M // 256) * 256 * Npad + D * Npad * Npad), "ms": qms,
                          "executed_int8_tops": exec_ops / (qms * 1e-3) / 1e12,
-                         "executed_frac": exec_ops / (qms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS},
+                         "executed_frac": exec_ops / (qms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
+                         "executed_frac_of_sustained_mfma_rate": exec_ops / (qms * 1e-3) / 1e12 / I8_MFMA_SUSTAINED_TOPS},
             "finalize_kernel": {"ms": float(np.mean(fin_ms)),
                                 "hbm_gbps": (M * (Npad + 56.0)) / (np.mean(fin_ms) * 1e-3) / 1e9},
             # "flop" is the full product the reference forms; only the lower triangle of 256^2
