@@ -64,7 +64,7 @@ __device__ constexpr int ORD_N[16] = {0, 0, 1, 1, 0, 1, 2, 2, 2, 0, 1, 2, 3, 3, 
 
 // One slice: 16 MFMA on `cur`; fragment reads of (slot `src`, chunk) into `nxt`; DMA pieces [P0, P1) of the
 // cursor's stage (pieces 0-7: P rows, 8-15: Q rows of this wave) into slot `dst`.
-template <bool LOAD, int P0, int P1, bool ZERO = false, bool HOT = false>
+template <bool LOAD, int P0, int P1, bool ZERO = false, int HOT = 0>   // HOT: 1 = all pieces, 2 = Q pieces, 3 = P pieces
 __device__ __forceinline__ void slice(v16i (&acc)[4][4], const Frag4& cur, Frag4& nxt, const char* src, int arow,
                                       int brow, int chunk, const StageOp4& sp, const StageOp4& sq, int k0, char* dst,
                                       int wave) {
@@ -82,7 +82,7 @@ __device__ __forceinline__ void slice(v16i (&acc)[4][4], const Frag4& cur, Frag4
     else acc[m1][n1] = mfma8(cur.a[m1], cur.b[n1], acc[m1][n1]);
     if (P0 + i < P1) {
       const int pc = P0 + i;
-      if (HOT) {                                       // ablation: same LDS-DMA traffic, source always the same 2 KiB
+      if (HOT == 1 || (HOT == 2 && pc >= 8) || (HOT == 3 && pc < 8)) {   // ablation: same LDS-DMA traffic, source always the same 2 KiB
         if (pc < 8) stage_piece4(sq, 0, dst, wave, pc & 1);
         else stage_piece4(sq, 0, dst + TILE_BYTES, wave, pc & 1);
         continue;
@@ -95,7 +95,7 @@ __device__ __forceinline__ void slice(v16i (&acc)[4][4], const Frag4& cur, Frag4
 }
 
 // ABL: 0 = production; timing ablations with WRONG results: 1 = no DMA in the loop, 2 = no fragment reads in
-// the loop, 3 = trivial epilogue, 4 = in-kernel stamps, 5 = all DMA pieces read the same 2 KiB (L1-resident).
+// the loop, 3 = trivial epilogue, 4 = in-kernel stamps, 5 = all DMA pieces read the same 2 KiB (L1-resident), 6 / 7 = only the genotype / only the digit pieces do.
 // N3/N0/N1: DMA pieces of a stage issued in slice 3 (right after the barrier that frees the slot) and in slices
 // 0 / 1 of the following step; the remaining 16 - N3 - N0 - N1 go into slice 2.
 // FAST: |s| * Npad < 2^16 and s^2 * Npad < 2^18 (checked on the host from the store's tracked max |s|): every
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(W4_THREADS) void scan_quad_w4s_kernel(
     char* oth = lds + ((t + 1) & 1) * BUF_BYTES;
     // slices 0-2: MFMA on slot t&1; the rest of stage t+1 (the cursor's stage) -> the other slot
     const int k1 = cks * BK;
-    constexpr bool HOT = ABL == 5;
+    constexpr int HOT = ABL == 5 ? 1 : ABL == 6 ? 2 : ABL == 7 ? 3 : 0;
     if (ks == 0) slice<LD, E3, E0, true, HOT>(acc, f0, f1, cur, arow, brow, 2 + h, sp, sq, k1, oth, wave);
     else slice<LD, E3, E0, false, HOT>(acc, f0, f1, cur, arow, brow, 2 + h, sp, sq, k1, oth, wave);
     slice<LD, E0, E1, false, HOT>(acc, f1, f0, cur, arow, brow, 4 + h, sp, sq, k1, oth, wave);
@@ -318,6 +318,8 @@ void launch_scan_quad_w4s(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model&
   else if (abl == 2) MMG_LAUNCH_W4S(2, 8, 8, 0, true);
   else if (abl == 3) MMG_LAUNCH_W4S(3, 8, 8, 0, true);
   else if (abl == 5) MMG_LAUNCH_W4S(5, 8, 8, 0, true);
+  else if (abl == 6) MMG_LAUNCH_W4S(6, 8, 8, 0, true);
+  else if (abl == 7) MMG_LAUNCH_W4S(7, 8, 8, 0, true);
   else if (dist == 1 && fast) MMG_LAUNCH_W4S(0, 6, 5, 5, true);
   else if (fast) MMG_LAUNCH_W4S(0, 8, 8, 0, true);
   else MMG_LAUNCH_W4S(0, 8, 8, 0, false);
