@@ -110,8 +110,7 @@ def main():
     t0 = time.time()
     eig_L = lmm._get_eigen_L_()
     eigh_ms = ctx.kernel_ms("eigh")
-    eig_R = lmm._get_eigen_R_(X=lmm.X)
-    est = lmm._get_estimates_with(eig_L, eig_R, "REML")
+    est = lmm.get_estimates(eig_L, method="REML")       # REML sums from eig_L alone: no second eigh
     prep = lmm.scan_prepare(est["H_sqrt_inv"])
     ctx.scan_set_model(prep["A"], prep["w"], D)
     model_s = time.time() - t0

@@ -123,8 +123,7 @@ def run_emmax(genot_data, phenotypes, min_maf=0.1, chunk_size=100000, k=None, ct
     lmm = lm.LinearMixedModel(phenotypes, ctx=ctx)                       # :121
     lmm.add_random_effect(k)
     eig_L = lmm._get_eigen_L_()                                          # :126
-    eig_R = lmm._get_eigen_R_(X=lmm.X)                                   # :131
-    res = lmm._get_estimates_with(eig_L, eig_R, 'REML')                  # :137
+    res = lmm.get_estimates(eig_L, method='REML')                        # :131-137 (no eig_R: linear_models._SpectralSumsL)
     out = {'pseudo_heritability': res['pseudo_heritability'], 've': res['ve'], 'vg': res['vg'],
            'max_ll': res['max_ll'], 'num_snps': n_snps, 'chrom_results': {}, 'kinship': k}
     prep = lmm.scan_prepare(res['H_sqrt_inv'])

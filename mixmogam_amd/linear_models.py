@@ -94,6 +94,56 @@ class LinearModel(object):
                 'h0_rss': np.array([h0_rss]), 'h0_betas': [float(b) for b in h0_betas]}
 
 
+# Where get_estimates would compute eig_R itself, take the spectral sums from eig_L instead (no second eigh).
+REML_SUMS_FROM_EIG_L = True
+
+
+class _SpectralSumsR(object):
+    """The four sums of the EMMA likelihood from the eigen-pairs of S(K+I)S (linear_models.py:794-810)."""
+
+    def __init__(self, eig_R, y, p):
+        self.eig_vals = np.asarray(eig_R['values'], dtype=np.float64)
+        assert len(self.eig_vals) == p, 'Number of eigenvalues is incorrect.'
+        etas = np.asarray(eig_R['vectors']) @ y                          # :794
+        self.sq_etas = etas * etas
+        self.sum_sq_etas = float(np.sum(self.sq_etas))
+
+    def at(self, deltas):
+        lambdas = self.eig_vals[:, None] + deltas[None, :]
+        s1 = np.sum(self.sq_etas[:, None] / lambdas, axis=0)
+        s3 = np.sum(self.sq_etas[:, None] / (lambdas * lambdas), axis=0)
+        return s1, np.sum(np.log(lambdas), axis=0), s3, np.sum(1 / lambdas, axis=0)
+
+
+class _SpectralSumsL(object):
+    """The same sums from eig_L alone: rotate y and X once (O(N^2 q)), then O(N q^2) per delta."""
+
+    def __init__(self, eig_L, X, y):
+        U = np.asarray(eig_L['vectors'], dtype=np.float64)               # rows are eigenvectors
+        self.lam = np.asarray(eig_L['values'], dtype=np.float64)
+        self.yt = U @ y
+        self.Xt = U @ X
+        XtX = X.T @ X
+        self.logdet_xtx = np.linalg.slogdet(XtX)[1]
+        xty = X.T @ y
+        self.sum_sq_etas = float(y @ y - xty @ np.linalg.solve(XtX, xty))   # |Sy|^2
+
+    def at(self, deltas):
+        d = 1.0 / (self.lam[:, None] + deltas[None, :])                  # N x m
+        Xt, yt = self.Xt, self.yt
+        a = np.einsum('ni,nj,nm->mij', Xt, Xt, d, optimize=True)         # X'H^-1 X
+        a2 = np.einsum('ni,nj,nm->mij', Xt, Xt, d * d, optimize=True)    # X'H^-2 X
+        b = np.einsum('ni,nm->mi', Xt, d * yt[:, None])                  # X'H^-1 y
+        c = (yt * yt) @ d                                                # y'H^-1 y
+        x = np.linalg.solve(a, b[:, :, None])[:, :, 0]                   # m x q
+        s1 = c - np.einsum('mi,mi->m', b, x)
+        z = d * (yt[:, None] - Xt @ x.T)                                 # P y in the eigenbasis
+        s3 = np.einsum('nm,nm->m', z, z)
+        s2 = np.sum(np.log(self.lam[:, None] + deltas[None, :]), axis=0) + np.linalg.slogdet(a)[1] - self.logdet_xtx
+        s4 = np.sum(d, axis=0) - np.trace(np.linalg.solve(a, a2), axis1=1, axis2=2)
+        return s1, s2, s3, s4
+
+
 class LinearMixedModel(object):
     """linear_models.py:554 (and the parts of LinearModel :81 it inherits on this path)."""
 
@@ -224,27 +274,30 @@ class LinearMixedModel(object):
             X = np.hstack([self.X, xs])
         else:
             X = self.X
-        if not (eig_R and xs is not None):                              # :787 (quirk kept)
-            eig_R = self._get_eigen_R_(X=X, K=K)
         q = X.shape[1]
         n = self.n
         p = n - q
         m = ngrids + 1
         y = self.Y.reshape(-1)
-        etas = eig_R['vectors'] @ y                                      # :794
-        sq_etas = etas * etas
         log_deltas = (np.arange(m, dtype=np.float64) / ngrids) * (ulim - llim) + llim
         deltas = np.exp(log_deltas)
-        eig_vals = np.asarray(eig_R['values'], dtype=np.float64)
-        assert len(eig_vals) == p, 'Number of eigenvalues is incorrect.'
-        lambdas = eig_vals[:, None] + deltas[None, :]
-        s1 = np.sum(sq_etas[:, None] / lambdas, axis=0)
-        s3 = np.sum(sq_etas[:, None] / (lambdas * lambdas), axis=0)
         eig_vals_L = np.asarray(eig_L['values'], dtype=np.float64)
+        # The likelihood only needs four sums over the spectrum of S(K+delta I)S -- s1 = sum eta^2/(xi+delta),
+        # s3 = sum eta^2/(xi+delta)^2, s2 = sum log(xi+delta), s4 = sum 1/(xi+delta) -- and sum eta^2.  The
+        # reference gets them from a second N^3 eigendecomposition (eig_R, :787-799); they are also
+        #   s1 = y'Py, s3 = |Py|^2, s2 = log|H| + log|X'H^-1 X| - log|X'X|, s4 = tr H^-1 - tr[(X'H^-1 X)^-1 X'H^-2 X]
+        # with H = K + delta I and P = H^-1 - H^-1 X (X'H^-1 X)^-1 X'H^-1, i.e. O(N q^2) per delta from eig_L alone
+        # (_SpectralSums).  Where the reference would compute eig_R itself (:787) the second eigh is skipped;
+        # a caller-supplied eig_R that the reference would use (xs given) is used as is.
+        if eig_R and xs is not None:
+            sums = _SpectralSumsR(eig_R, y, p)
+        elif K is not None or not REML_SUMS_FROM_EIG_L:
+            sums = _SpectralSumsR(self._get_eigen_R_(X=X, K=K), y, p)   # :787 (quirk kept)
+        else:
+            sums = _SpectralSumsL(eig_L, X, y)
+        s1, s2, s3, s4 = sums.at(deltas)
         if method == 'REML':
-            s2 = np.sum(np.log(lambdas), axis=0)
             lls = 0.5 * (p * (np.log(p / (2.0 * np.pi)) - 1 - np.log(s1)) - s2)        # :807
-            s4 = np.sum(1 / lambdas, axis=0)
             dlls = 0.5 * (p * s3 / s1 - s4)
         elif method == 'ML':
             xis = eig_vals_L[:, None] + deltas[None, :]
@@ -254,6 +307,24 @@ class LinearMixedModel(object):
             dlls = 0.5 * (n * s3 / s1 - s4)
         else:
             raise ValueError(method)
+
+        def redll(delta):                                                # _redll_ (:627-631)
+            a1, _a2, a3, a4 = sums.at(np.array([delta], dtype=np.float64))
+            return float(p * a3[0] / a1[0] - a4[0])
+
+        def rell(delta):                                                 # _rell_ (:618-623)
+            a1, a2, _a3, _a4 = sums.at(np.array([delta], dtype=np.float64))
+            return float(0.5 * p * (np.log(p / (2.0 * np.pi)) - 1) - 0.5 * (p * np.log(a1[0]) + a2[0]))
+
+        def dll(delta):                                                  # _dll_ (:643-649)
+            a1, _a2, a3, _a4 = sums.at(np.array([delta], dtype=np.float64))
+            return float(n * a3[0] / a1[0] - np.sum(1.0 / (eig_vals_L + delta)))
+
+        def ll(delta):                                                   # _ll_ (:634-640)
+            a1, _a2, _a3, _a4 = sums.at(np.array([delta], dtype=np.float64))
+            return float(0.5 * n * (np.log(n / (2.0 * np.pi)) - 1)
+                         - 0.5 * (n * np.log(a1[0]) + np.sum(np.log(eig_vals_L + delta))))
+
         max_ll_i = int(np.argmax(lls))
         max_ll = lls[max_ll_i]
         zero_intervals = []
@@ -268,12 +339,8 @@ class LinearMixedModel(object):
             try:
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
-                    if method == 'REML':
-                        new_opt_delta = optimize.newton(self._redll_, opt_delta, args=(eig_vals, sq_etas),
-                                                        tol=esp, maxiter=100)          # :847 (secant)
-                    else:
-                        new_opt_delta = optimize.newton(self._dll_, opt_delta,
-                                                        args=(eig_vals, eig_vals_L, sq_etas), tol=esp, maxiter=100)
+                    new_opt_delta = optimize.newton(redll if method == 'REML' else dll, opt_delta, tol=esp,
+                                                    maxiter=100)          # :847 (secant)
             except Exception:
                 new_opt_delta = opt_delta
             if opt_i > 1 and deltas[opt_i - 1] - esp < new_opt_delta < deltas[opt_i] + esp:
@@ -283,10 +350,7 @@ class LinearMixedModel(object):
             elif opt_i == len(deltas) - 1 and new_opt_delta > deltas[opt_i - 1] - esp \
                     and not np.isinf(new_opt_delta):
                 opt_delta = new_opt_delta
-            if method == 'REML':
-                opt_ll = self._rell_(opt_delta, eig_vals, sq_etas)       # :882
-            else:
-                opt_ll = self._ll_(opt_delta, eig_vals, eig_vals_L, sq_etas)
+            opt_ll = rell(opt_delta) if method == 'REML' else ll(opt_delta)   # :882
             if opt_ll < max_ll:
                 opt_delta = deltas[max_ll_i]                             # :886-887
         else:
@@ -295,7 +359,7 @@ class LinearMixedModel(object):
         # :894-896 -- the reference's (p,1)/(p,) broadcast makes vg = sum(sq_etas) *
         # sum(1/(lambda+delta)) / p ("BUG NEEDS TO BE FIXED HERE!!!" in its own words); the value
         # is reported as is so that results are identical; nothing on the scan path uses it.
-        opt_vg = np.sum(sq_etas) * np.sum(1.0 / (eig_vals + opt_delta)) / p
+        opt_vg = sums.sum_sq_etas * sums.at(np.array([opt_delta], dtype=np.float64))[3][0] / p
         opt_ve = opt_vg * opt_delta
         H_sqrt_inv = (1.0 / np.sqrt(eig_vals_L + opt_delta))[:, None] * np.asarray(eig_L['vectors'])   # :898
         X_t = H_sqrt_inv @ X
@@ -349,13 +413,12 @@ class LinearMixedModel(object):
         if not eig_L:
             eig_L = self._get_eigen_L_()
         t['eig_L'] = time.time() - s0
+        t['eig_R'] = 0.0
         s0 = time.time()
-        if not eig_R:
-            eig_R = self._get_eigen_R_(X=self.X)
-        t['eig_R'] = time.time() - s0
-        s0 = time.time()
-        # the reference passes eig_R but recomputes it (:787 quirk) -- same values, so reuse
-        res = self._get_estimates_with(eig_L, eig_R, method)
+        # The reference computes eig_R here (:1252) and again inside get_estimates (:787).  The likelihood sums
+        # come from eig_L alone (_SpectralSumsL), so neither N^3 eigendecomposition is needed; a caller-supplied
+        # eig_R is still honoured.
+        res = self._get_estimates_with(eig_L, eig_R, method) if eig_R else self.get_estimates(eig_L, method=method)
         t['reml'] = time.time() - s0
         s0 = time.time()
         r = self._emmax_f_test_(snps, res['H_sqrt_inv'], snp_priors=snp_priors, Z=Z, with_betas=with_betas,
@@ -371,14 +434,17 @@ class LinearMixedModel(object):
         return r
 
     def _get_estimates_with(self, eig_L, eig_R, method, ngrids=50):
-        # get_estimates' `not (eig_R and xs != None)` recomputes eig_R when xs is None; pass the
-        # precomputed one through a tiny shim instead of paying a third N^3 eigh for equal values.
-        saved = self._get_eigen_R_
+        """get_estimates on a PRECOMPUTED eig_R (the reference's own route, :787-799): its
+        `not (eig_R and xs != None)` would recompute eig_R when xs is None, so the given one is passed through a
+        tiny shim; used where a caller already holds eig_R and by the tests that compare the two routes."""
+        global REML_SUMS_FROM_EIG_L
+        saved, saved_flag = self._get_eigen_R_, REML_SUMS_FROM_EIG_L
         try:
+            REML_SUMS_FROM_EIG_L = False
             self._get_eigen_R_ = lambda X=None, K=None, **kw: eig_R
             return self.get_estimates(eig_L, method=method, eig_R=eig_R, ngrids=ngrids)
         finally:
-            self._get_eigen_R_ = saved
+            self._get_eigen_R_, REML_SUMS_FROM_EIG_L = saved, saved_flag
 
     def scan_prepare(self, H_sqrt_inv, Z=None, with_betas=False):
         """SNP-independent part of _emmax_f_test_ (:1290-1306) in closed form:
@@ -654,9 +720,9 @@ def mlmm(phenotypes, K, sd=None, num_steps=10, forward_backwards=True, sign_thre
         return out
 
     def reestimate():
-        eig_R = lmm._get_eigen_R_(X=lmm.X, K=None)
-        reml = lmm._get_estimates_with(eig_L, eig_R, 'REML', ngrids=100)   # get_REML / get_ML use 100 grid points
-        ml = lmm._get_estimates_with(eig_L, eig_R, 'ML', ngrids=100)
+        # get_REML / get_ML use 100 grid points; no eig_R: every step would need a fresh N^3 eigh for its X
+        reml = lmm.get_estimates(eig_L, method='REML', ngrids=100)
+        ml = lmm.get_estimates(eig_L, method='ML', ngrids=100)
         return reml, ml
 
     def cofactor_stats():

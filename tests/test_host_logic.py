@@ -87,3 +87,30 @@ def test_chunked_driver_host_logic(ctx):
     ref = orc.emmax(snps[keep], y, a["kinship"])
     got = np.concatenate([a["chrom_results"][c]["ps"] for c in ("c1", "c2")])
     assert rel(got, ref["ps"]) < 1e-7
+
+
+@pytest.mark.parametrize("name", ["struct_n150_s0", "struct_n300_s3", "bern_n200_s4"])
+def test_reml_sums_from_eig_L_equal_the_eig_R_route(name):
+    """get_estimates takes the four likelihood sums from eig_L alone (no second N^3 eigh); the reference's
+    own route through eig_R (kept as _get_estimates_with) gives the same delta, likelihood and variance
+    components to rounding, for REML and ML, with and without cofactors, also with an extra SNP column (xs)."""
+    from mixmogam_amd import linear_models as lm
+    case = load_case(name)
+    m = lm.LinearMixedModel(list(case["y"]), ctx=FakeContext())
+    m.add_random_effect(case["dbl_ibs_scaled"])
+    if case["cof"] is not None:
+        for c in case["cof"]:
+            m.add_factor(c)
+    eig_L = m._get_eigen_L_()
+    for method in ("REML", "ML"):
+        fast = m.get_estimates(eig_L, method=method)
+        ref = m._get_estimates_with(eig_L, m._get_eigen_R_(X=m.X), method)
+        for k in ("delta", "max_ll", "vg", "ve", "pseudo_heritability"):
+            assert abs(fast[k] / ref[k] - 1) < 1e-10, (method, k)
+        assert np.allclose(fast["H_sqrt_inv"], ref["H_sqrt_inv"], rtol=1e-10, atol=1e-12)
+    xs = case["snps"][7].astype(np.float64).reshape(-1, 1)
+    fast = m.get_estimates(eig_L, xs=xs, return_f_stat=True, return_pvalue=True)
+    X = np.hstack([m.X, xs])
+    ref = m.get_estimates(eig_L, xs=xs, return_f_stat=True, return_pvalue=True, eig_R=m._get_eigen_R_(X=X))
+    for k in ("delta", "max_ll", "f_stat", "p_val"):
+        assert abs(fast[k] / ref[k] - 1) < 1e-9, k

@@ -54,8 +54,7 @@ for i in (0, N // 2, N - 1):                                   # rows are eigenv
     v = np.asarray(vecs[i]).reshape(-1)
     r = np.asarray(Ks @ v).reshape(-1) - vals[i] * v
     assert np.linalg.norm(r) < 1e-8 * max(1.0, abs(vals).max()), ("eig residual", i, np.linalg.norm(r))
-eig_R = timed("eigh_R", lambda: lmm._get_eigen_R_(X=lmm.X))
-est = timed("reml", lambda: lmm._get_estimates_with(eig_L, eig_R, "REML"))
+est = timed("reml", lambda: lmm.get_estimates(eig_L, method="REML"))   # sums from eig_L alone: no second eigh
 prep = timed("scan_prepare", lambda: lmm.scan_prepare(est["H_sqrt_inv"]))
 timed("set_model", lambda: ctx.scan_set_model(prep["A"], prep["w"], 0))
 out = timed("scan", lambda: ctx.scan(g, prep["h0_rss"], prep["n_p"], stats=True))
