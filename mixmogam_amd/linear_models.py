@@ -118,11 +118,14 @@ class _SpectralSumsR(object):
 class _SpectralSumsL(object):
     """The same sums from eig_L alone: rotate y and X once (O(N^2 q)), then O(N q^2) per delta."""
 
-    def __init__(self, eig_L, X, y):
-        U = np.asarray(eig_L['vectors'], dtype=np.float64)               # rows are eigenvectors
+    def __init__(self, eig_L, X, y, rot=None):
         self.lam = np.asarray(eig_L['values'], dtype=np.float64)
-        self.yt = U @ y
-        self.Xt = U @ X
+        if rot is not None:                                              # (U y, U X) supplied by the caller
+            self.yt, self.Xt = rot
+        else:
+            U = np.asarray(eig_L['vectors'], dtype=np.float64)           # rows are eigenvectors
+            self.yt = U @ y
+            self.Xt = U @ X
         XtX = X.T @ X
         self.logdet_xtx = np.linalg.slogdet(XtX)[1]
         xty = X.T @ y
@@ -267,7 +270,7 @@ class LinearMixedModel(object):
 
     def get_estimates(self, eig_L, K=None, xs=None, ngrids=50, llim=-10, ulim=10, esp=1e-6,
                       return_pvalue=False, return_f_stat=False, method='REML', verbose=False,
-                      dtype='double', eig_R=None, rss_0=None):
+                      dtype='double', eig_R=None, rss_0=None, return_H=True, _rot=None):
         """:771-927 -- EMMA variance-component estimates (Kang et al. 2008)."""
         if xs is not None:
             xs = np.asarray(xs, dtype=np.float64).reshape(self.n, -1)
@@ -294,7 +297,7 @@ class LinearMixedModel(object):
         elif K is not None or not REML_SUMS_FROM_EIG_L:
             sums = _SpectralSumsR(self._get_eigen_R_(X=X, K=K), y, p)   # :787 (quirk kept)
         else:
-            sums = _SpectralSumsL(eig_L, X, y)
+            sums = _SpectralSumsL(eig_L, X, y, rot=_rot)
         s1, s2, s3, s4 = sums.at(deltas)
         if method == 'REML':
             lls = 0.5 * (p * (np.log(p / (2.0 * np.pi)) - 1 - np.log(s1)) - s2)        # :807
@@ -361,9 +364,19 @@ class LinearMixedModel(object):
         # is reported as is so that results are identical; nothing on the scan path uses it.
         opt_vg = sums.sum_sq_etas * sums.at(np.array([opt_delta], dtype=np.float64))[3][0] / p
         opt_ve = opt_vg * opt_delta
-        H_sqrt_inv = (1.0 / np.sqrt(eig_vals_L + opt_delta))[:, None] * np.asarray(eig_L['vectors'])   # :898
-        X_t = H_sqrt_inv @ X
-        Y_t = H_sqrt_inv @ y
+        # :898-907.  H_sqrt_inv = diag((lambda+delta)^-1/2) U'; its products with X and y are row scalings of the
+        # rotated U'X, U'y that _SpectralSumsL already holds (O(N q) instead of O(N^2 q)); the N x N matrix itself
+        # is only formed when the caller wants it (return_H; the exact-EMMA loop does not).
+        wts = 1.0 / np.sqrt(eig_vals_L + opt_delta)
+        H_sqrt_inv = wts[:, None] * np.asarray(eig_L['vectors']) if return_H else None
+        if isinstance(sums, _SpectralSumsL):
+            X_t = wts[:, None] * sums.Xt
+            Y_t = wts * sums.yt
+        else:
+            if H_sqrt_inv is None:
+                H_sqrt_inv = wts[:, None] * np.asarray(eig_L['vectors'])
+            X_t = H_sqrt_inv @ X
+            Y_t = H_sqrt_inv @ y
         (beta_est, _res, rank, sigma) = linalg.lstsq(X_t, Y_t)
         mahalanobis_rss = float(np.sum((Y_t - X_t @ beta_est) ** 2))
         residuals = y - X @ beta_est
@@ -372,7 +385,7 @@ class LinearMixedModel(object):
                     'vg': opt_vg, 'rss': rss, 'mahalanobis_rss': np.array([mahalanobis_rss]),
                     'H_sqrt_inv': H_sqrt_inv, 'pseudo_heritability': 1.0 / (1 + opt_delta)}
         if xs is not None and return_f_stat:                             # :914-923
-            h0_X = H_sqrt_inv @ self.X
+            h0_X = X_t[:, :self.X.shape[1]]                              # H_sqrt_inv @ self.X: the leading columns of X_t
             (h0_betas, _r, h0_rank, h0_s) = linalg.lstsq(h0_X, Y_t)
             h0_rss = float(np.sum((Y_t - h0_X @ h0_betas) ** 2))
             f_stat = (h0_rss / mahalanobis_rss - 1) * p / xs.shape[1]
@@ -394,10 +407,18 @@ class LinearMixedModel(object):
         keys = ('f_stat', 'vg', 've', 'max_ll', 'var_perc', 'rss', 'p_val')
         out = {k: np.empty(len(snps)) for k in keys}
         betas = []
+        # one rotation of y, X and ALL candidate SNPs into the eigenbasis (a single device GEMM) instead of an N x N
+        # eigendecomposition -- or even an O(N^2) product -- per SNP; each SNP then costs O(N q^2) per delta
+        U = np.asarray(eig_L['vectors'], dtype=np.float64)
+        snp_mat = np.ascontiguousarray(np.asarray([np.asarray(sn, dtype=np.float64).reshape(-1) for sn in snps]))
+        yt0 = U @ self.Y.reshape(-1)
+        Xt0 = U @ self.X
+        XSt = self.ctx.dgemm(U, snp_mat, tb=True) if len(snp_mat) else np.zeros((self.n, 0))    # N x k
         for i, snp in enumerate(snps):
             res = self.get_estimates(eig_L=eig_L, xs=np.asarray(snp, dtype=np.float64).reshape(-1, 1),
                                      ngrids=ngrids, llim=llim, ulim=ulim, esp=esp, return_pvalue=True,
-                                     return_f_stat=True)
+                                     return_f_stat=True, return_H=False,
+                                     _rot=(yt0, np.hstack([Xt0, XSt[:, i:i + 1]])))
             for k in keys:
                 out[k][i] = res[k]
             betas.append([float(b) for b in res['beta'].reshape(-1)])
