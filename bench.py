@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=5000, help="individuals")
     ap.add_argument("--m", type=int, default=1000000, help="SNPs per GPU")
-    ap.add_argument("--digits", type=int, default=4)
+    ap.add_argument("--digits", type=int, default=0,
+                    help="digit planes of the scan model; 0 = the library default (4 planes, adaptive schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-kinship", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0,
@@ -152,6 +153,7 @@ def main():
         elapsed = float(coll.allreduce(np.array([elapsed]), "max")[0])
 
     ps = out[2]
+    scan_stats = ctx.scan_last_stats()
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = Mtot * args.steps / elapsed
@@ -160,12 +162,17 @@ def main():
         achieved = alg_flop / (qms * 1e-3) / 1e12
         Npad = -(-N // 256) * 256
         nJ = Npad // 256
-        exec_ops = 2.0 * D * 256.0 * 256.0 * 256.0 * (nJ * (nJ + 1) / 2) * (-(-M // 256))
+        Dn = D if D else 4
+        plane_ops = 2.0 * 256.0 * 256.0 * 256.0 * (nJ * (nJ + 1) / 2)          # one digit plane over one 256-SNP block
+        if scan_stats["adaptive"] and not scan_stats["fell_back"]:            # 3 planes for all + 1 for the refined
+            exec_ops = plane_ops * ((Dn - 1) * (-(-M // 256)) + (-(-scan_stats["n_refined"] // 256)))
+        else:
+            exec_ops = plane_ops * Dn * (-(-M // 256)) * (2 if scan_stats["fell_back"] else 1)
         kin_exec = 2.0 * 256.0 * 256.0 * (nJ * (nJ + 1) / 2) * M     # lower-triangle tiles x contraction length
         traffic = None
         try:   # HBM bytes per launch measured with rocprofv3 PMC passes of this same command (profiles/)
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_c3.json")))
-            if tj["config"] == {"n": N, "m": M, "digits": D}:
+            if tj["config"] == {"n": N, "m": M, "digits": D} and tj.get("adaptive", False) == scan_stats["adaptive"]:
                 traffic = tj["kernels"][QUAD_KERNEL]["hbm_bytes_corrected"]
         except Exception:
             pass
@@ -176,14 +183,16 @@ def main():
             "dtype": "i8", "data": "synthetic",
             "config": {"workload": "EMMAX scan N=%d individuals x M=%d SNPs per GPU (BASELINE configs[2] shape), "
                                    "Bernoulli(0.5) hash genotypes resident in HBM, q=1" % (N, M),
-                       "n_individuals": N, "snps_per_gpu": M, "snps_total": Mtot, "digits": D,
+                       "n_individuals": N, "snps_per_gpu": M, "snps_total": Mtot, "digits": Dn,
+                       "digit_schedule": "adaptive (3 planes for every SNP, the 4th where p could move by 2.5e-7)"
+                                         if scan_stats["adaptive"] else "all planes for every SNP",
                        "parallelism": "snp-block x%d" % world,
                        "delivery": "double buffered: step i's results are gathered (RCCL) / downloaded on a second "
                                    "stream while step i+1 scans; the last one is awaited inside the timed region"},
             "roofline": {"bound": "mfma", "kernel": QUAD_KERNEL, "achieved": achieved,
                          "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s", "frac": achieved / I8_MFMA_PEAK_TOPS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/traffic_c3.json)",
-                         "algorithmic_bytes": float(-(-M // 256) * 256 * Npad + D * Npad * Npad), "ms": qms,
+                         "algorithmic_bytes": float(-(-M // 256) * 256 * Npad + Dn * Npad * Npad), "ms": qms,
                          "executed_int8_tops": exec_ops / (qms * 1e-3) / 1e12,
                          "executed_frac": exec_ops / (qms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
                          "executed_frac_of_sustained_mfma_rate": exec_ops / (qms * 1e-3) / 1e12 / I8_MFMA_SUSTAINED_TOPS},
@@ -203,6 +212,7 @@ def main():
                         "f32_tflops": None if kin_f32_ms is None else 2.0 * N * N * M / (kin_f32_ms * 1e-3) / 1e12,
                         "f32_frac_of_peak": None if kin_f32_ms is None else
                         2.0 * N * N * M / (kin_f32_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS},
+            "adaptive_scan": scan_stats,
             "eigh_ms": eigh_ms, "model_setup_s": model_s, "setup_s": t_setup,
             "delta": float(est["delta"]), "min_p": float(np.nanmin(ps)), "device": info,
         }

@@ -131,6 +131,16 @@ int mmg_scan_set_model(mmg_ctx* ctx, int32_t N, const double* A, const double* w
  * (any may be NULL).  den == 0 leaves rss = h0_rss, F = 0, p = 1 (:1308,1329). */
 int mmg_emmax_scan(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2,
                    double* rss, double* F, double* p);
+/* What the last mmg_emmax_scan_device did.  The default model (ndigits = 0 in mmg_scan_set_model) runs an ADAPTIVE
+ * schedule: the three upper digit planes of the matrix for every SNP (the matrix rounded to 22 bits: den to ~1e-8
+ * relative), then the lowest plane only for the SNPs whose p-value could move by more than 2.5e-7 relative at six
+ * sigma of that rounding noise (large F, or den small against the noise), which makes those bit-identical to a full
+ * 4-plane scan.  sigma_ratio_max = max over the refined SNPs of (observed change of den) / (its six-sigma
+ * prediction); if it exceeds 1 the error model is rejected and everything is redone with all planes (fell_back = 1).
+ * eps_max = max relative change of den over the refined SNPs.  adaptive = 0 for models with an explicit ndigits. */
+int mmg_scan_last_stats(mmg_ctx* ctx, int32_t* adaptive, int64_t* n_refined, double* eps_max,
+                        double* sigma_ratio_max, int32_t* fell_back);
+
 /* Same, leaving results in device memory (for RCCL gathers / benchmarking); fetch with
  * mmg_scan_fetch.  Blocks until the kernels finish. */
 int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2);

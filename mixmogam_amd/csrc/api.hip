@@ -86,10 +86,12 @@ int mmg_ctx_create(int device, mmg_ctx** out) {
 
 static void free_model(mmg_scan_model& m) {
   hipFree(m.Bq); hipFree(m.diag); hipFree(m.w); hipFree(m.job_off); hipFree(m.jobs);
+  hipFree(m.job_off_hi); hipFree(m.jobs_hi); hipFree(m.job_off_lo); hipFree(m.jobs_lo);
   m = mmg_scan_model();
 }
 static void free_result(mmg_scan_result& r) {
   hipFree(r.q); hipFree(r.rss); hipFree(r.F); hipFree(r.p); hipFree(r.dot); hipFree(r.den); hipFree(r.sum);
+  hipFree(r.dd); hipFree(r.ssq); hipFree(r.idx); hipFree(r.scal); hipFree(r.q2);
   r = mmg_scan_result();
 }
 
@@ -100,6 +102,7 @@ int mmg_ctx_destroy(mmg_ctx* ctx) {
   hipStreamSynchronize(ctx->stream2);
   free_model(ctx->model);
   free_result(ctx->res);
+  if (ctx->sel_geno) { hipFree(ctx->sel_geno->d); hipFree(ctx->sel_geno->bits); hipFree(ctx->sel_geno->d_smax); delete ctx->sel_geno; }
   hipFree(ctx->dstage);
   if (ctx->rocblas) rocblas_destroy_handle((rocblas_handle)ctx->rocblas);
   for (int i = 0; i < EV_COUNT; ++i) { hipEventDestroy(ctx->ev[i][0]); hipEventDestroy(ctx->ev[i][1]); }
@@ -129,6 +132,11 @@ int mmg_last_kernel_ms(mmg_ctx* ctx, int which, double* ms) {
   MMG_HIP(ctx, hipEventSynchronize(ctx->ev[which][1]));
   MMG_HIP(ctx, hipEventElapsedTime(&f, ctx->ev[which][0], ctx->ev[which][1]));
   *ms = (double)f;
+  if (which == EV_QUAD && ctx->ev_set[EV_QUAD2]) {       // adaptive scan: the refinement pass counts too
+    MMG_HIP(ctx, hipEventSynchronize(ctx->ev[EV_QUAD2][1]));
+    MMG_HIP(ctx, hipEventElapsedTime(&f, ctx->ev[EV_QUAD2][0], ctx->ev[EV_QUAD2][1]));
+    *ms += (double)f;
+  }
   return MMG_OK;
 }
 
@@ -580,17 +588,12 @@ static double ln_beta_half(double a) {  // ln B(a, 1/2)
   return half_ln_pi - diff;
 }
 
-static int build_schedule(mmg_ctx* ctx, mmg_scan_model& md) {
-  const int nJ = md.Npad / TM;
-  // 4 SNP blocks x 8 job groups per XCD cohort: the L2-miss traffic of the lock-stepped cohort is
-  // proportional to 1/AS + 1/G (measured: AS 1/2/4/8 -> 90/49/32/31 GB at M=400k, N=5000)
-  int AS = 4;
-  if (const char* s = std::getenv("MMG_SCAN_AS")) AS = std::atoi(s);
-  if (AS != 1 && AS != 2 && AS != 4 && AS != 8 && AS != 16 && AS != 32) AS = 4;
-  const int G = 32 / AS;
-  md.AS = AS; md.G = G;
+// LPT assignment of the (digit, J) jobs with digit in [d0, d1) to the G job groups of an XCD cohort
+static int build_schedule_range(mmg_ctx* ctx, const mmg_scan_model& md, int d0, int d1, int** job_off, int2** jobs_out,
+                                int* njobs) {
+  const int nJ = md.Npad / TM, G = md.G;
   std::vector<std::pair<int, int>> all;  // (weight = J + 1 k-blocks, id)
-  for (int d = 0; d < md.D; ++d)
+  for (int d = d0; d < d1; ++d)
     for (int J = 0; J < nJ; ++J) all.push_back({J + 1, d * nJ + J});
   std::sort(all.begin(), all.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) {
     return a.first != b.first ? a.first > b.first : a.second < b.second;
@@ -609,20 +612,34 @@ static int build_schedule(mmg_ctx* ctx, mmg_scan_model& md) {
     for (int id : bins[gI]) jobs.push_back(make_int2(id / nJ, id % nJ));
     off[gI + 1] = (int)jobs.size();
   }
-  md.njobs = (int)jobs.size();
-  MMG_HIP(ctx, hipMalloc(&md.job_off, (G + 1) * sizeof(int)));
-  MMG_HIP(ctx, hipMalloc(&md.jobs, std::max<size_t>(1, jobs.size()) * sizeof(int2)));
-  MMG_HIP(ctx, hipMemcpy(md.job_off, off.data(), (G + 1) * sizeof(int), hipMemcpyHostToDevice));
-  if (!jobs.empty()) MMG_HIP(ctx, hipMemcpy(md.jobs, jobs.data(), jobs.size() * sizeof(int2), hipMemcpyHostToDevice));
+  *njobs = (int)jobs.size();
+  MMG_HIP(ctx, hipMalloc(job_off, (G + 1) * sizeof(int)));
+  MMG_HIP(ctx, hipMalloc(jobs_out, std::max<size_t>(1, jobs.size()) * sizeof(int2)));
+  MMG_HIP(ctx, hipMemcpy(*job_off, off.data(), (G + 1) * sizeof(int), hipMemcpyHostToDevice));
+  if (!jobs.empty()) MMG_HIP(ctx, hipMemcpy(*jobs_out, jobs.data(), jobs.size() * sizeof(int2), hipMemcpyHostToDevice));
   return MMG_OK;
+}
+
+static int build_schedule(mmg_ctx* ctx, mmg_scan_model& md) {
+  // 4 SNP blocks x 8 job groups per XCD cohort: the L2-miss traffic of the lock-stepped cohort is
+  // proportional to 1/AS + 1/G (measured: AS 1/2/4/8 -> 90/49/32/31 GB at M=400k, N=5000)
+  int AS = 4;
+  if (const char* s = std::getenv("MMG_SCAN_AS")) AS = std::atoi(s);
+  if (AS != 1 && AS != 2 && AS != 4 && AS != 8 && AS != 16 && AS != 32) AS = 4;
+  md.AS = AS; md.G = 32 / AS;
+  int rc = build_schedule_range(ctx, md, 0, md.D, &md.job_off, &md.jobs, &md.njobs);
+  if (rc || !md.adaptive) return rc;
+  if ((rc = build_schedule_range(ctx, md, 1, md.D, &md.job_off_hi, &md.jobs_hi, &md.njobs_hi))) return rc;
+  return build_schedule_range(ctx, md, 0, 1, &md.job_off_lo, &md.jobs_lo, &md.njobs_lo);
 }
 
 // Build a scan model from a DEVICE-resident fp64 matrix dA [N x N] and device vector dw [N].
 static int model_from_device(mmg_ctx* ctx, mmg_scan_model& md, int32_t N, const double* dA, const double* dw,
-                             int ndigits) {
+                             int ndigits, bool adaptive = false) {
   Scratch sc;
   free_model(md);
   md.N = N; md.Npad = (int32_t)round_up(N, 256); md.D = ndigits;
+  md.adaptive = adaptive && ndigits == 4;
   unsigned long long* dmax = nullptr;
   MMG_HIP(ctx, sc.alloc(&dmax, sizeof(unsigned long long)));
   MMG_HIP(ctx, hipMalloc(&md.Bq, (size_t)md.D * md.Npad * md.Npad));
@@ -640,9 +657,15 @@ static int model_from_device(mmg_ctx* ctx, mmg_scan_model& md, int32_t N, const 
   if (!(maxoff > 0.0) || !std::isfinite(maxoff)) maxoff = 1.0;   // diagonal matrix: all digits are zero
   // |rint(2 A_jk / step)| <= 2^(8D-2): the top balanced digit stays within int8
   md.step = 2.0 * maxoff / std::ldexp(1.0, 8 * md.D - 2);
-  launch_quantize(ctx, dA, N, md.Npad, md.D, 1.0 / md.step, md.Bq, md.diag);
+  long long* dz0 = nullptr;
+  MMG_HIP(ctx, sc.alloc(&dz0, sizeof(long long)));
+  MMG_HIP(ctx, hipMemsetAsync(dz0, 0, sizeof(long long), ctx->stream));
+  launch_quantize(ctx, dA, N, md.Npad, md.D, 1.0 / md.step, md.Bq, md.diag, dz0);
   MMG_HIP(ctx, hipGetLastError());
+  long long z0 = 0;
+  MMG_HIP(ctx, hipMemcpyAsync(&z0, dz0, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  md.mu0 = N > 1 ? (double)z0 / (0.5 * (double)N * (double)(N - 1)) : 0.0;
   return build_schedule(ctx, md);
 }
 
@@ -650,14 +673,22 @@ int mmg_scan_set_model(mmg_ctx* ctx, int32_t N, const double* A, const double* w
   Scratch sc;
   MMG_CHECK_ARG(nullptr, ctx != nullptr);
   MMG_CHECK_ARG(ctx, A && w && N > 0);
-  if (ndigits == 0) ndigits = 4;
+  // ndigits = 0: the default model -- 4 digit planes with the adaptive schedule of mmg_emmax_scan_device (three
+  // planes for every SNP, the fourth for those whose F passes a threshold); an explicit count runs all its planes
+  // for every SNP.  MMG_SCAN_ADAPTIVE=0 turns the adaptive schedule off.
+  bool adaptive = false;
+  if (ndigits == 0) {
+    ndigits = 4;
+    const char* e = std::getenv("MMG_SCAN_ADAPTIVE");
+    adaptive = !(e && e[0] == '0');
+  }
   MMG_CHECK_ARG(ctx, ndigits >= 2 && ndigits <= 6);
   double *dA = nullptr, *dw = nullptr;
   MMG_HIP(ctx, sc.alloc(&dA, (size_t)N * N * sizeof(double)));
   MMG_HIP(ctx, sc.alloc(&dw, N * sizeof(double)));
   MMG_HIP(ctx, hipMemcpyAsync(dA, A, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   MMG_HIP(ctx, hipMemcpyAsync(dw, w, N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  int rc = model_from_device(ctx, ctx->model, N, dA, dw, ndigits);
+  int rc = model_from_device(ctx, ctx->model, N, dA, dw, ndigits, adaptive);
   return rc;
 }
 
@@ -671,6 +702,10 @@ static int ensure_result(mmg_ctx* ctx, mmg_scan_result& r, int64_t Mpad) {
   MMG_HIP(ctx, hipMalloc(&r.dot, Mpad * sizeof(double)));
   MMG_HIP(ctx, hipMalloc(&r.den, Mpad * sizeof(double)));
   MMG_HIP(ctx, hipMalloc(&r.sum, Mpad * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&r.dd, Mpad * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&r.ssq, Mpad * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&r.idx, Mpad * sizeof(int64_t)));
+  MMG_HIP(ctx, hipMalloc(&r.scal, 4 * sizeof(unsigned long long)));
   r.cap = Mpad;
   return MMG_OK;
 }
@@ -684,16 +719,107 @@ int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2)
   if (rc) return rc;
   ctx->res.M = g->M;
   if (g->M == 0) return MMG_OK;
-  MMG_HIP(ctx, hipMemsetAsync(ctx->res.q, 0, g->Mpad * sizeof(unsigned long long), ctx->stream));
-  rc = run_scan_quad(ctx, g, ctx->model, ctx->res.q);
+  mmg_scan_result& res = ctx->res;
+  const mmg_scan_model& md = ctx->model;
+  const double lnb = ln_beta_half(0.5 * df2);
+  res.n_refined = 0; res.eps_max = 0.0; res.sigma_ratio_max = 0.0; res.fell_back = 0; res.adaptive = md.adaptive ? 1 : 0;
+  ctx->ev_set[EV_QUAD2] = false;
+  MMG_HIP(ctx, hipMemsetAsync(res.q, 0, g->Mpad * sizeof(unsigned long long), ctx->stream));
+  if (!md.adaptive) {
+    rc = run_scan_quad(ctx, g, md, res.q);
+    if (rc) return rc;
+    MMG_HIP(ctx, hipGetLastError());
+    {
+      EvScope ev(ctx, EV_FIN);
+      launch_scan_finalize(ctx, g, md, res, h0_rss, df2, lnb);
+    }
+    MMG_HIP(ctx, hipGetLastError());
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MMG_OK;
+  }
+  // ---- adaptive precision.  Pass 1: the three upper digit planes for every SNP, i.e. the matrix rounded to 22
+  // bits (balanced digits: dropping the lowest one IS round-to-nearest).  That leaves den off by a sum of
+  // independent roundings whose sigma is known per SNP (k_scan.hip:scan_select_kernel); a SNP whose p could move
+  // by more than `target` at six sigma -- large F, or a den that is small against the rounding noise -- gets the
+  // lowest plane added to the same exact integer in pass 2, which makes it bit-identical to a full 4-plane scan.
+  // The refined SNPs double as a check of the error model: if any of them moved by more than its six-sigma
+  // prediction, everything is redone with all planes.
+  double target = 2.5e-7;                                  // a quarter of the 1e-6 bar on p
+  if (const char* e = std::getenv("MMG_SCAN_ADAPT_TARGET")) target = std::atof(e);
+  const double sig_unit = md.step * 256.0 / std::sqrt(12.0) / std::sqrt(2.0);   // sigma = sig_unit * sum s^2
+  mmg_scan_model hi = md, lo = md;                        // shallow copies with the schedule swapped
+  hi.job_off = md.job_off_hi; hi.jobs = md.jobs_hi; hi.njobs = md.njobs_hi;
+  lo.job_off = md.job_off_lo; lo.jobs = md.jobs_lo; lo.njobs = md.njobs_lo;
+  rc = run_scan_quad(ctx, g, hi, res.q);
   if (rc) return rc;
   MMG_HIP(ctx, hipGetLastError());
   {
     EvScope ev(ctx, EV_FIN);
-    launch_scan_finalize(ctx, g, ctx->model, ctx->res, h0_rss, df2, ln_beta_half(0.5 * df2));
+    launch_scan_finalize(ctx, g, md, res, h0_rss, df2, lnb, false, md.step * md.mu0);
   }
+  MMG_HIP(ctx, hipMemsetAsync(res.scal, 0, 4 * sizeof(unsigned long long), ctx->stream));
+  launch_scan_select(ctx, res, g->M, sig_unit, target, res.scal);
+  unsigned long long hs[3] = {0, 0, 0};
+  MMG_HIP(ctx, hipMemcpyAsync(hs, res.scal, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int64_t cnt = (int64_t)hs[0];
+  bool all = cnt > g->M / 2;                               // a selection this large is not worth compacting
+  if (!all && cnt > 0) {
+    const int64_t cpad = round_up(cnt, 256);
+    if (!ctx->sel_geno || ctx->sel_geno->Mpad < cpad || ctx->sel_geno->N != g->N) {
+      if (ctx->sel_geno) { mmg_geno_destroy(ctx, ctx->sel_geno); ctx->sel_geno = nullptr; }
+      rc = mmg_geno_create(ctx, cpad + cpad / 4, g->N, &ctx->sel_geno);
+      if (rc) return rc;
+    }
+    if (res.q2_cap < ctx->sel_geno->Mpad) {
+      hipFree(res.q2); res.q2 = nullptr; res.q2_cap = 0;
+      MMG_HIP(ctx, hipMalloc(&res.q2, ctx->sel_geno->Mpad * sizeof(unsigned long long)));
+      res.q2_cap = ctx->sel_geno->Mpad;
+    }
+    mmg_geno view = *ctx->sel_geno;                        // a cpad-row window of the compact store
+    view.M = cnt; view.Mpad = cpad; view.smax = g->smax; view.bits = nullptr; view.bits_valid = false;
+    launch_gather_rows(ctx, g, res.idx, cnt, view.d);
+    MMG_HIP(ctx, hipMemsetAsync(res.q2, 0, cpad * sizeof(unsigned long long), ctx->stream));
+    rc = run_scan_quad(ctx, &view, lo, res.q2, EV_QUAD2);
+    if (rc) return rc;
+    launch_scan_refine(ctx, res.idx, cnt, md, res, res.q2, sig_unit, h0_rss, df2, res.scal + 1);
+    MMG_HIP(ctx, hipGetLastError());
+    MMG_HIP(ctx, hipMemcpyAsync(hs, res.scal, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(&res.eps_max, &hs[1], sizeof(double));
+    std::memcpy(&res.sigma_ratio_max, &hs[2], sizeof(double));
+    res.n_refined = cnt;
+    if (res.sigma_ratio_max > 1.0) all = true;            // a rounding error beyond six sigma: the error model failed
+    if (all) {
+      // undo nothing: the refined SNPs already carry plane 0; run it for the others by running it for all rows of
+      // a store view whose refined rows are skipped -- simplest exact way: subtract is impossible on atomics, so
+      // zero q and redo both passes over everything
+      MMG_HIP(ctx, hipMemsetAsync(res.q, 0, g->Mpad * sizeof(unsigned long long), ctx->stream));
+      rc = run_scan_quad(ctx, g, md, res.q);
+      if (rc) return rc;
+    }
+  } else if (all) {
+    rc = run_scan_quad(ctx, g, lo, res.q, EV_QUAD2);       // plane 0 on top of planes 1-3: the full 4-plane integer
+    if (rc) return rc;
+  }
+  if (all) {
+    res.fell_back = 1;
+    launch_scan_finalize(ctx, g, md, res, h0_rss, df2, lnb, false);
+  }
+  if (res.p && g->M > 0) launch_f_sf(ctx, res.F, g->M, df2, lnb, res.p);
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MMG_OK;
+}
+
+int mmg_scan_last_stats(mmg_ctx* ctx, int32_t* adaptive, int64_t* n_refined, double* eps_max, double* sigma_ratio_max,
+                        int32_t* fell_back) {
+  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  if (adaptive) *adaptive = ctx->res.adaptive;
+  if (n_refined) *n_refined = ctx->res.n_refined;
+  if (eps_max) *eps_max = ctx->res.eps_max;
+  if (sigma_ratio_max) *sigma_ratio_max = ctx->res.sigma_ratio_max;
+  if (fell_back) *fell_back = ctx->res.fell_back;
   return MMG_OK;
 }
 

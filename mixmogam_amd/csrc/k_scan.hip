@@ -49,10 +49,12 @@ void launch_absmax_offdiag(mmg_ctx* ctx, const double* A, int32_t N, unsigned lo
 
 // one thread = 16 consecutive k of row j; Bq[d][j][k] = digit d of rint(2 A[j][k] / step), k < j
 __global__ void quantize_kernel(const double* __restrict__ A, int32_t N, int32_t Npad, int D, double inv_step,
-                                int8_t* __restrict__ Bq, double* __restrict__ diag) {
+                                int8_t* __restrict__ Bq, double* __restrict__ diag, long long* __restrict__ z0_sum) {
   const int chunks = Npad >> 4;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (int64_t)Npad * chunks) return;
+  long long z0acc = 0;                                   // sum of the lowest digits (adaptive scan: their mean is the
+                                                         // bias of a pass that leaves that plane out)
+  if (gid < (int64_t)Npad * chunks) {
   const int j = (int)(gid / chunks), c = (int)(gid % chunks);
   uint32_t out[6][4];
 #pragma unroll
@@ -69,6 +71,7 @@ __global__ void quantize_kernel(const double* __restrict__ A, int32_t N, int32_t
       if (d < D) {
         const long long z = ((Z + 128) & 255) - 128;
         Z = (Z - z) >> 8;
+        if (d == 0) z0acc += z;
         out[d][e >> 2] |= ((uint32_t)(z & 0xff)) << (8 * (e & 3));
       }
     }
@@ -76,13 +79,19 @@ __global__ void quantize_kernel(const double* __restrict__ A, int32_t N, int32_t
   for (int d = 0; d < D; ++d)
     *(uint4*)(Bq + ((int64_t)d * Npad + j) * Npad + c * 16) = make_uint4(out[d][0], out[d][1], out[d][2], out[d][3]);
   if (c == 0) diag[j] = (j < N) ? A[(int64_t)j * N + j] : 0.0;
+  }
+  if (z0_sum) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) z0acc += __shfl_xor(z0acc, o);
+    if ((threadIdx.x & 63) == 0 && z0acc != 0) atomicAdd((unsigned long long*)z0_sum, (unsigned long long)z0acc);
+  }
 }
 
 void launch_quantize(mmg_ctx* ctx, const double* A, int32_t N, int32_t Npad, int D, double inv_step, int8_t* Bq,
-                     double* diag) {
+                     double* diag, long long* z0_sum) {
   const int64_t total = (int64_t)Npad * (Npad >> 4);
   hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, A, N, Npad,
-                     D, inv_step, Bq, diag);
+                     D, inv_step, Bq, diag, z0_sum);
 }
 
 // ------------------------------------------------------------------ p-value
@@ -150,16 +159,17 @@ constexpr int FR = 8;                      // SNP rows per wave
 constexpr int FIN_ROWS = 4 * FR;           // per block
 __global__ __launch_bounds__(256, 2) void scan_finalize_kernel(
     const int8_t* __restrict__ S, int64_t ldS, int64_t M, int32_t Npad, const double* __restrict__ w,
-    const double* __restrict__ diag, const unsigned long long* __restrict__ q, double step, double h0_rss, double nu,
+    const double* __restrict__ diag, const unsigned long long* __restrict__ q, double step, double bias, double h0_rss, double nu,
     double lnbeta, double* __restrict__ rss, double* __restrict__ Fst, double* __restrict__ pv,
-    double* __restrict__ dotv, double* __restrict__ denv, double* __restrict__ sumv) {
+    double* __restrict__ dotv, double* __restrict__ denv, double* __restrict__ sumv, double* __restrict__ ddv,
+    double* __restrict__ ssqv) {
   __shared__ double2 lw[8 * 64], ldg[8 * 64];          // [unit e>>1][lane]
   const int tid = threadIdx.x, lane = tid & 63;
   const int64_t m0 = (int64_t)blockIdx.x * FIN_ROWS + (tid >> 6) * FR;
   double dw[FR], dd[FR];
-  int sm[FR];
+  int sm[FR], sq[FR];
 #pragma unroll
-  for (int rr = 0; rr < FR; ++rr) { dw[rr] = 0.0; dd[rr] = 0.0; sm[rr] = 0; }
+  for (int rr = 0; rr < FR; ++rr) { dw[rr] = 0.0; dd[rr] = 0.0; sm[rr] = 0; sq[rr] = 0; }
   const int nchunks = Npad >> 4;
   for (int c0 = 0; c0 < nchunks; c0 += 64) {
     __syncthreads();
@@ -195,28 +205,32 @@ __global__ __launch_bounds__(256, 2) void scan_finalize_kernel(
           dw[rr] = fma(xd, wv[e], dw[rr]);
           dd[rr] = fma(xd * xd, dv[e], dd[rr]);
           sm[rr] += xi;
+          sq[rr] += xi * xi;
         }
       }
     }
   }
   double my_dw = 0.0, my_dd = 0.0;
-  int my_sm = 0;
+  int my_sm = 0, my_sq = 0;
 #pragma unroll
   for (int rr = 0; rr < FR; ++rr) {
     double a = dw[rr], b = dd[rr];
-    int s = sm[rr];
+    int s = sm[rr], s2 = sq[rr];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       a += __shfl_xor(a, o);
       b += __shfl_xor(b, o);
       s += __shfl_xor(s, o);
+      s2 += __shfl_xor(s2, o);
     }
-    if (lane == rr) { my_dw = a; my_dd = b; my_sm = s; }
+    if (lane == rr) { my_dw = a; my_dd = b; my_sm = s; my_sq = s2; }
   }
   const int64_t m = m0 + lane;
   if (lane < FR && m < M) {
     const double qd = (double)(long long)q[m];
-    const double den = fma(step, qd, my_dd);
+    // bias: adaptive first pass only -- step * (mean of the digit plane that was left out), times the number of
+    // (j > k) products sum_{j>k} s_j s_k = ((sum s)^2 - sum s^2) / 2: removes the coherent part of the rounding error
+    const double den = fma(step, qd, my_dd) + bias * (0.5 * ((double)my_sm * (double)my_sm - (double)my_sq));
     const double num = my_dw * my_dw;
     double r = h0_rss;
     // den ~ 0: monomorphic after projection; the reference's lstsq returns no residual and rss
@@ -229,7 +243,94 @@ __global__ __launch_bounds__(256, 2) void scan_finalize_kernel(
     if (dotv) dotv[m] = my_dw;
     if (denv) denv[m] = den;
     if (sumv) sumv[m] = (double)my_sm;
+    if (ddv) ddv[m] = my_dd;
+    if (ssqv) ssqv[m] = (double)my_sq;
   }
+}
+
+// ---- adaptive precision (api.hip:mmg_emmax_scan_device): the first pass runs the three upper digit planes, i.e. the
+// matrix rounded to 22 bits.  Its error in den = s'As is a sum of ~(sum s^2)^2/2 independent roundings of +-step22/2:
+//     sigma_m = step22 / sqrt(12) * (sum_i s_i^2) / sqrt(2)          (absolute, 1 sigma)
+// and p moves by (F/2 + 1) * |d den| / den at most.  A SNP is refined (lowest plane added) when six sigma of that
+// could move p by more than `target`: large F, or a den that is small against its own rounding noise (a SNP nearly
+// collinear with the covariates).  idx[atomicAdd(cnt)] = m; order arbitrary, everything downstream is indexed.
+__global__ void scan_select_kernel(const double* __restrict__ F, const double* __restrict__ den,
+                                   const double* __restrict__ ssq, int64_t M, double sig_unit, double target,
+                                   int64_t* __restrict__ idx, unsigned long long* __restrict__ cnt) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const double d = den[m], six_sigma = 6.0 * sig_unit * ssq[m];
+  const bool refine = !(d > 0.0) ? six_sigma > 0.0 : (0.5 * F[m] + 1.0) * six_sigma > target * d;
+  if (refine) idx[atomicAdd(cnt, 1ull)] = m;
+}
+
+// compact store row i <- store row idx[i]; 16 bytes per thread
+__global__ void gather_rows_kernel(const int8_t* __restrict__ S, int32_t Npad, const int64_t* __restrict__ idx, int64_t cnt,
+                                   int8_t* __restrict__ Sc) {
+  const int chunks = Npad >> 4;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= cnt * chunks) return;
+  const int64_t i = gid / chunks;
+  const int c = (int)(gid % chunks);
+  *(uint4*)(Sc + i * (int64_t)Npad + c * 16) = *(const uint4*)(S + idx[i] * (int64_t)Npad + c * 16);
+}
+
+// q[idx[i]] += q2[i]; den / rss / F recomputed exactly as scan_finalize_kernel does from the full integer;
+// eps = max |den_before / den_after - 1| (what the 22-bit pass was off by on this sample)
+__global__ void scan_refine_kernel(const int64_t* __restrict__ idx, int64_t cnt, unsigned long long* __restrict__ q,
+                                   const unsigned long long* __restrict__ q2, const double* __restrict__ dd,
+                                   const double* __restrict__ dot, const double* __restrict__ ssq, double sig_unit,
+                                   double step, double h0_rss, double nu,
+                                   double* __restrict__ den, double* __restrict__ rss, double* __restrict__ Fst,
+                                   unsigned long long* __restrict__ eps_bits) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double eps = 0.0, ratio = 0.0;
+  if (i < cnt) {
+    const int64_t m = idx[i];
+    const unsigned long long qn = q[m] + q2[i];
+    q[m] = qn;
+    const double my_dd = dd[m], my_dw = dot[m];
+    const double d_old = den[m];
+    const double d_new = fma(step, (double)(long long)qn, my_dd);
+    const double num = my_dw * my_dw;
+    double r = h0_rss;
+    if (d_new > 1e-7 * my_dd && d_new > 0.0) r = h0_rss - num / d_new;
+    den[m] = d_new;
+    rss[m] = r;
+    Fst[m] = (h0_rss / r - 1.0) * nu;
+    if (d_new > 0.0) eps = fabs(d_old / d_new - 1.0);
+    const double six_sigma = 6.0 * sig_unit * ssq[m];
+    if (six_sigma > 0.0) ratio = fabs(d_old - d_new) / six_sigma;      // observed rounding error / its 6-sigma prediction
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    eps = fmax(eps, __shfl_xor(eps, o));
+    ratio = fmax(ratio, __shfl_xor(ratio, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (eps > 0.0) atomicMax(eps_bits, (unsigned long long)__double_as_longlong(eps));
+    if (ratio > 0.0) atomicMax(eps_bits + 1, (unsigned long long)__double_as_longlong(ratio));
+  }
+}
+
+void launch_scan_select(mmg_ctx* ctx, const mmg_scan_result& res, int64_t M, double sig_unit, double target,
+                        unsigned long long* cnt) {
+  hipLaunchKernelGGL(scan_select_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, res.F, res.den,
+                     res.ssq, M, sig_unit, target, res.idx, cnt);
+}
+void launch_gather_rows(mmg_ctx* ctx, const mmg_geno* g, const int64_t* idx, int64_t cnt, int8_t* Sc) {
+  const int64_t total = cnt * (g->Npad >> 4);
+  if (total <= 0) return;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, g->d, g->Npad,
+                     idx, cnt, Sc);
+}
+void launch_scan_refine(mmg_ctx* ctx, const int64_t* idx, int64_t cnt, const mmg_scan_model& md, mmg_scan_result& res,
+                        const unsigned long long* q2, double sig_unit, double h0_rss, int32_t df2,
+                        unsigned long long* eps_bits) {
+  if (cnt <= 0) return;
+  hipLaunchKernelGGL(scan_refine_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, idx, cnt, res.q,
+                     q2, res.dd, res.dot, res.ssq, sig_unit, md.step, h0_rss, (double)df2, res.den, res.rss, res.F,
+                     eps_bits);
 }
 
 // out[m] = s_m . v for an arbitrary fp64 vector v (zero padded to Npad); same streaming shape.
@@ -277,13 +378,13 @@ void launch_snp_dot(mmg_ctx* ctx, const mmg_geno* g, const double* v, double* ou
 }
 
 void launch_scan_finalize(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, mmg_scan_result& res,
-                          double h0_rss, int32_t df2, double lnbeta) {
+                          double h0_rss, int32_t df2, double lnbeta, bool with_p, double bias) {
   hipLaunchKernelGGL(scan_finalize_kernel, dim3((unsigned)(g->Mpad / FIN_ROWS)), dim3(256), 0, ctx->stream, g->d,
-                     (int64_t)g->Npad, g->M, g->Npad, md.w, md.diag, res.q, md.step, h0_rss, (double)df2, lnbeta,
-                     res.rss, res.F, res.p, res.dot, res.den, res.sum);
+                     (int64_t)g->Npad, g->M, g->Npad, md.w, md.diag, res.q, md.step, bias, h0_rss, (double)df2, lnbeta,
+                     res.rss, res.F, res.p, res.dot, res.den, res.sum, res.dd, res.ssq);
   // p-values in their own launch: one lane per SNP (in the finalize kernel only 8 of 64 lanes hold a
   // finished SNP, and the continued fraction is ~100 dependent fp64 divisions long)
-  if (res.p && g->M > 0) launch_f_sf(ctx, res.F, g->M, df2, lnbeta, res.p);
+  if (with_p && res.p && g->M > 0) launch_f_sf(ctx, res.F, g->M, df2, lnbeta, res.p);
 }
 
 }  // namespace mmg

@@ -191,7 +191,7 @@ void launch_scan_quad_bits(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model
                      md.job_off, md.jobs, md.AS, q);
 }
 
-int run_scan_quad(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, unsigned long long* q) {
+int run_scan_quad(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, unsigned long long* q, int ev_slot) {
   // MMG_SCAN_KERNEL selects a generation of the quadratic-form GEMM (all bit-identical):
   //   (unset) / w4s   4 waves x 128x128, hand-laid pipeline (k_scan_w4s.hip)            -- production
   //   q8              8 waves x 128x64, loader waves (k_scan_q8.hip; also what MMG_ABLATE instruments)
@@ -208,7 +208,7 @@ int run_scan_quad(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, unsigned 
     int rc = ensure_bits(ctx, g);                     // once per store content
     if (rc) return rc;
   }
-  EvScope ev(ctx, EV_QUAD);
+  EvScope ev(ctx, ev_slot);
   if (want_w4b && g->binary) launch_scan_quad_w4b(ctx, g, md, q);
   else if (want_bits && g->binary) launch_scan_quad_bits(ctx, g, md, q);
   else if (!ablate && k == "w4m") launch_scan_quad_w4m(ctx, g, md, q);

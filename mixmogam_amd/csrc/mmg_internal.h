@@ -19,7 +19,7 @@ struct mmg_geno {
   int* d_smax = nullptr;
 };
 
-enum { EV_KIN = 0, EV_QUAD = 1, EV_FIN = 2, EV_PERM = 3, EV_EIGH = 4, EV_PACK = 5, EV_COUNT = 6 };
+enum { EV_KIN = 0, EV_QUAD = 1, EV_FIN = 2, EV_PERM = 3, EV_EIGH = 4, EV_PACK = 5, EV_QUAD2 = 6, EV_COUNT = 7 };
 
 struct mmg_scan_model {
   int32_t N = 0, Npad = 0, D = 0;
@@ -32,6 +32,12 @@ struct mmg_scan_model {
   int* job_off = nullptr;       // [G + 1]
   int2* jobs = nullptr;         // (digit, J)
   int njobs = 0;
+  // adaptive precision (default model, D = 4): schedules over the upper planes d = 1..D-1 and over plane 0
+  bool adaptive = false;
+  double mu0 = 0.0;             // mean of the lowest digit over the stored (j > k) entries
+  int *job_off_hi = nullptr, *job_off_lo = nullptr;
+  int2 *jobs_hi = nullptr, *jobs_lo = nullptr;
+  int njobs_hi = 0, njobs_lo = 0;
 };
 
 struct mmg_scan_result {
@@ -39,6 +45,17 @@ struct mmg_scan_result {
   int64_t M = 0;
   unsigned long long* q = nullptr;
   double *rss = nullptr, *F = nullptr, *p = nullptr, *dot = nullptr, *den = nullptr, *sum = nullptr;
+  // adaptive precision: sum_i A_ii s_i^2 per SNP, the indices of the SNPs that get the lowest digit plane,
+  // their count / the observed max relative den change (device scalars), the quadratic forms of the compact store
+  double *dd = nullptr, *ssq = nullptr;   // sum_i A_ii s_i^2 and sum_i s_i^2 per SNP
+  int64_t* idx = nullptr;
+  unsigned long long* scal = nullptr;      // [0] = count, [1] = max eps bits, [2] = max (observed / 6 sigma) bits
+  unsigned long long* q2 = nullptr;
+  int64_t q2_cap = 0;
+  // what the last scan did (mmg_scan_last_stats)
+  int64_t n_refined = 0;
+  double eps_max = 0.0, sigma_ratio_max = 0.0;
+  int fell_back = 0, adaptive = 0;
 };
 
 struct mmg_ctx {
@@ -51,6 +68,7 @@ struct mmg_ctx {
   mmg_scan_model model;
   mmg_scan_result res;
   void* rocblas = nullptr;      // rocblas_handle, created lazily
+  mmg_geno* sel_geno = nullptr; // compact store of the SNPs refined by the adaptive scan (grown on demand)
   // background delivery of scan results (mmg_scan_deliver_*): second stream, snapshot staging, one in flight
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_snap = nullptr, ev_deliver = nullptr;
@@ -118,7 +136,7 @@ void launch_mirror_i32_to_i64(mmg_ctx*, const int* C32, int32_t Npad, int32_t N,
 // ---- k_scan.hip
 void launch_absmax_offdiag(mmg_ctx*, const double* A, int32_t N, unsigned long long* out_bits);
 void launch_quantize(mmg_ctx*, const double* A, int32_t N, int32_t Npad, int D, double inv_step,
-                     int8_t* Bq, double* diag);
+                     int8_t* Bq, double* diag, long long* z0_sum /*dev, accumulated; may be null*/);
 void launch_scan_quad(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
 // ---- k_scan_bits.hip (binary genotypes staged as bits)
 int ensure_bits(mmg_ctx*, mmg_geno*);
@@ -127,9 +145,15 @@ void launch_scan_quad_w4s(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsi
 void launch_scan_quad_w4m(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
 void launch_scan_quad_w4b(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
 // picks the bit-packed kernel for 0/1 genotypes unless MMG_SCAN_KERNEL names another variant
-int run_scan_quad(mmg_ctx*, mmg_geno*, const mmg_scan_model&, unsigned long long* q);
+// ev_slot: which event pair brackets the kernel (EV_QUAD, or EV_QUAD2 for the refinement pass)
+int run_scan_quad(mmg_ctx*, mmg_geno*, const mmg_scan_model&, unsigned long long* q, int ev_slot = EV_QUAD);
 void launch_scan_finalize(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, mmg_scan_result&,
-                          double h0_rss, int32_t df2, double lnbeta);
+                          double h0_rss, int32_t df2, double lnbeta, bool with_p = true, double bias = 0.0);
+void launch_scan_select(mmg_ctx*, const mmg_scan_result&, int64_t M, double sig_unit, double target, unsigned long long* cnt);
+void launch_gather_rows(mmg_ctx*, const mmg_geno*, const int64_t* idx, int64_t cnt, int8_t* Sc);
+void launch_scan_refine(mmg_ctx*, const int64_t* idx, int64_t cnt, const mmg_scan_model&, mmg_scan_result&,
+                        const unsigned long long* q2, double sig_unit, double h0_rss, int32_t df2,
+                        unsigned long long* eps_bits);
 void launch_snp_dot(mmg_ctx*, const mmg_geno*, const double* v /*[Npad] dev*/, double* out /*[M] dev*/);
 void launch_f_sf(mmg_ctx*, const double* F, int64_t n, int32_t df2, double lnbeta, double* p);
 

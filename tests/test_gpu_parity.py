@@ -374,7 +374,7 @@ def test_linear_model_fast_f_test_vs_golden(ctx, case):
     from mixmogam_amd import linear_models as lm
     res = lm.linear_model(list(case["snps"]), list(case["y"]), cofactors=case["cof"])
     assert rel(res["h0_rss"], case["dbl_lm_h0_rss"]) < 1e-9
-    assert rel(res["rss"], case["dbl_lm_rss"]) < 1e-8
+    assert rel(res["rss"], case["dbl_lm_rss"]) < 1e-7          # adaptive digit schedule: den to ~3e-8 below the F threshold
     assert rel(res["ps"], case["dbl_lm_ps"]) < 1e-6
 
 
@@ -617,3 +617,47 @@ def test_background_delivery_snapshots_and_overlaps(ctx):
                 assert np.array_equal(bufB[k], refB[name]), (comm, name)
     finally:
         coll.close()
+
+
+def test_adaptive_digit_schedule(ctx, monkeypatch):
+    """Default model (ndigits = 0): three digit planes for every SNP, the fourth only for the SNPs whose p could
+    move by more than 2.5e-7 at six sigma of the 22-bit rounding noise.  Those are bit-identical to the explicit
+    4-plane scan, the others agree to 1e-6 on p; the refined set validates the error model (sigma ratio < 1).  A
+    target of 0 refines everything and MMG_SCAN_ADAPTIVE=0 switches the schedule off -- both bit-identical to the
+    4-plane scan everywhere.  A SNP nearly collinear with a covariate (tiny den) must be among the refined."""
+    rng = np.random.RandomState(21)
+    n, m = 1300, 6000
+    snps = struct_snps(rng, n, m)
+    cof = snps[17].astype(np.float64)
+    snps[18] = snps[17]
+    snps[18, :3] ^= 1                                     # differs from the covariate in 3 individuals: den ~ 0
+    y = rng.randn(n) + 0.4 * snps[3] + 0.3 * snps[10]
+    X = np.hstack([np.ones((n, 1)), cof.reshape(n, 1)])
+    est = orc.get_estimates(y, X, orc.scale_k(orc.scale_k(orc.calc_ibs_kinship(snps))))
+    prep = orc.scan_prepare(y, X, est["H_sqrt_inv"])
+    ref = orc.scan_closed(snps, prep)
+    g = ctx.geno(snps)
+    ctx.scan_set_model(prep["A"], prep["w"], 4)
+    full = ctx.scan(g, prep["h0_rss"], n - 3, stats=True)
+    assert not ctx.scan_last_stats()["adaptive"]
+    ctx.scan_set_model(prep["A"], prep["w"], 0)
+    ada = ctx.scan(g, prep["h0_rss"], n - 3, stats=True)
+    st = ctx.scan_last_stats()
+    assert st["adaptive"] and not st["fell_back"] and 0 < st["n_refined"] < m // 2 and st["sigma_ratio_max"] < 1.0
+    same = ada["den"] == full["den"]
+    assert int(same.sum()) >= st["n_refined"] and same[18]
+    for k in ("rss", "f_stats", "ps"):
+        assert np.array_equal(ada[k][same], full[k][same]), k
+    ok = ref["den"] > 1e-6 * ref["den"].max()
+    assert rel(ada["ps"][ok], full["ps"][ok]) < 1e-6 and rel(ada["ps"][ok], ref["ps"][ok]) < 1e-6
+    monkeypatch.setenv("MMG_SCAN_ADAPT_TARGET", "0")
+    everything = ctx.scan(g, prep["h0_rss"], n - 3, stats=True)
+    assert ctx.scan_last_stats()["fell_back"]
+    monkeypatch.delenv("MMG_SCAN_ADAPT_TARGET")
+    monkeypatch.setenv("MMG_SCAN_ADAPTIVE", "0")
+    ctx.scan_set_model(prep["A"], prep["w"], 0)
+    off = ctx.scan(g, prep["h0_rss"], n - 3, stats=True)
+    monkeypatch.delenv("MMG_SCAN_ADAPTIVE")
+    for k in ("den", "rss", "f_stats", "ps"):
+        assert np.array_equal(everything[k], full[k]), k
+        assert np.array_equal(off[k], full[k]), k
