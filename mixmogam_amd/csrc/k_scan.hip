@@ -198,14 +198,18 @@ __global__ __launch_bounds__(256, 2) void scan_finalize_kernel(
         // rows beyond M are inside the padded store (Mpad is a multiple of 256) and hold zeros
         const uint4 v = *(const uint4*)(S + (m0 + rr) * ldS + c * 16);
         const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+        // sum s and sum s^2 four bytes at a time on the integer dot-product unit (v_dot4_i32_i8)
+#pragma unroll
+        for (int d4 = 0; d4 < 4; ++d4) {
+          sm[rr] = __builtin_amdgcn_sdot4((int)wds[d4], 0x01010101, sm[rr], false);
+          sq[rr] = __builtin_amdgcn_sdot4((int)wds[d4], (int)wds[d4], sq[rr], false);
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int xi = (int)(int8_t)((wds[e >> 2] >> (8 * (e & 3))) & 0xff);
           const double xd = (double)xi;
           dw[rr] = fma(xd, wv[e], dw[rr]);
           dd[rr] = fma(xd * xd, dv[e], dd[rr]);
-          sm[rr] += xi;
-          sq[rr] += xi * xi;
         }
       }
     }

@@ -7,11 +7,17 @@ import collections, csv, glob, json, os, sys
 root, tag = sys.argv[1], sys.argv[2]
 n, m, d = (int(x) for x in sys.argv[3:6]) if len(sys.argv) > 5 else (5000, 1000000, 4)
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(root + "/pmc_*SIZE*/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("mmg::", "")
-        vals[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"config": {"n": n, "m": m, "digits": d},
+rows = [r for f in glob.glob(root + "/pmc_*SIZE*/**/*counter_collection.csv", recursive=True) for r in csv.DictReader(open(f))]
+name = lambda r: r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").replace("mmg::", "")
+# a kernel may be launched with different grids in one step (adaptive scan: the full pass and the small
+# refinement pass): "per launch" means the launches with the largest grid
+biggest = collections.defaultdict(int)
+for r in rows:
+    biggest[name(r)] = max(biggest[name(r)], int(r["Grid_Size"]))
+for r in rows:
+    if int(r["Grid_Size"]) == biggest[name(r)]:
+        vals[name(r)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {"config": {"n": n, "m": m, "digits": d}, "adaptive": len(sys.argv) > 6 and sys.argv[6] == "adaptive",
        "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes on bench.py (tools/gpu_profile.sh %s); "
                "FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); "
                "WRITE_SIZE as is; counter unit KB" % tag,

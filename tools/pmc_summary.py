@@ -5,8 +5,14 @@ root = sys.argv[1]
 for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(list)
     dur = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
+    rows = list(csv.DictReader(open(f)))
+    big = collections.defaultdict(int)
+    for r in rows:
+        big[r["Kernel_Name"].split("(")[0]] = max(big[r["Kernel_Name"].split("(")[0]], int(r["Grid_Size"]))
+    for r in rows:
         k = r["Kernel_Name"].split("(")[0]
+        if int(r["Grid_Size"]) != big[k]:
+            continue                                   # only the launches with the kernel's largest grid
         agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
         dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     print("==", os.path.relpath(f, root))
