@@ -781,6 +781,7 @@ int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2)
     launch_gather_rows(ctx, g, res.idx, cnt, view.d);
     MMG_HIP(ctx, hipMemsetAsync(res.q2, 0, cpad * sizeof(unsigned long long), ctx->stream));
     rc = run_scan_quad(ctx, &view, lo, res.q2, EV_QUAD2);
+    if (view.bits) (void)hipFree(view.bits);               // only the bit-packed diagnostic kernels build this twin
     if (rc) return rc;
     launch_scan_refine(ctx, res.idx, cnt, md, res, res.q2, sig_unit, h0_rss, df2, res.scal + 1);
     MMG_HIP(ctx, hipGetLastError());
