@@ -59,6 +59,7 @@ prep = timed("scan_prepare", lambda: lmm.scan_prepare(est["H_sqrt_inv"]))
 timed("set_model", lambda: ctx.scan_set_model(prep["A"], prep["w"], 0))
 out = timed("scan", lambda: ctx.scan(g, prep["h0_rss"], prep["n_p"], stats=True))
 T["scan_quad_ms"] = ctx.kernel_ms("scan_quad"); T["scan_finalize_ms"] = ctx.kernel_ms("scan_finalize")
+T["adaptive_scan"] = ctx.scan_last_stats()
 
 idx = np.unique(np.r_[np.argsort(out["ps"])[:8], np.linspace(0, M - 1, 16).astype(int)])
 worst = 0.0
