@@ -152,8 +152,23 @@ def main():
     if coll is not None:
         elapsed = float(coll.allreduce(np.array([elapsed]), "max")[0])
 
-    ps = out[2]
+    ps = out[2].copy()
     scan_stats = ctx.scan_last_stats()
+    # For the record, outside the timed region: the same scan with all four digit planes for every SNP (what the
+    # adaptive schedule is measured against) -- its time and how far the two sets of p-values are apart.
+    all_planes = None
+    if scan_stats["adaptive"] and rank == 0:
+        ctx.scan_set_model(prep["A"], prep["w"], 4)
+        ctx.scan(g, prep["h0_rss"], n_p, fetch=False)
+        t1 = time.time()
+        for _ in range(2):
+            ctx.scan(g, prep["h0_rss"], n_p, fetch=False)
+        dt_all = (time.time() - t1) / 2
+        ref_out = ctx.scan(g, prep["h0_rss"], n_p)
+        mine = ps[rank * M:(rank + 1) * M]
+        ok = ref_out["ps"] > 1e-290
+        all_planes = {"ms_per_scan_kernels_only": 1e3 * dt_all, "scan_quad_ms": ctx.kernel_ms("scan_quad"),
+                      "max_rel_p_diff_adaptive_vs_all_planes": float(np.max(np.abs(mine[ok] / ref_out["ps"][ok] - 1)))}
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = Mtot * args.steps / elapsed
@@ -212,7 +227,7 @@ def main():
                         "f32_tflops": None if kin_f32_ms is None else 2.0 * N * N * M / (kin_f32_ms * 1e-3) / 1e12,
                         "f32_frac_of_peak": None if kin_f32_ms is None else
                         2.0 * N * N * M / (kin_f32_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS},
-            "adaptive_scan": scan_stats,
+            "adaptive_scan": scan_stats, "all_planes_reference": all_planes,
             "eigh_ms": eigh_ms, "model_setup_s": model_s, "setup_s": t_setup,
             "delta": float(est["delta"]), "min_p": float(np.nanmin(ps)), "device": info,
         }
