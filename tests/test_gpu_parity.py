@@ -661,3 +661,30 @@ def test_adaptive_digit_schedule(ctx, monkeypatch):
     for k in ("den", "rss", "f_stats", "ps"):
         assert np.array_equal(everything[k], full[k]), k
         assert np.array_equal(off[k], full[k]), k
+
+
+@pytest.mark.parametrize("alphabet", [(0, 3), (-1, 2), (0, 6)])
+def test_adaptive_digit_schedule_other_genotype_alphabets(ctx, alphabet):
+    """The bias and sigma terms of the adaptive schedule use sum s and sum s^2 (not allele counts): 0/1/2
+    genotypes, centred -1/0/1 ones and 0..5 dosages all stay within the 2.5e-7 design target of the full scan
+    and validate the error model (observed / six-sigma < 1, no fallback)."""
+    rng = np.random.RandomState(31)
+    n, m = 1500, 5000
+    lo, hi = alphabet
+    snps = rng.randint(lo, hi, size=(m, n)).astype(np.int8)
+    B = rng.standard_normal((n, 25)) / 5
+    A = np.eye(n) * 1.5 + B @ B.T / n
+    A[np.triu_indices(n, 1)] += 0.02 * rng.standard_normal(n * (n - 1) // 2)
+    A = 0.5 * (A + A.T)
+    w = rng.standard_normal(n)
+    g = ctx.geno(snps)
+    ctx.scan_set_model(A, w, 4)
+    full = ctx.scan(g, 1e7, n - 2, stats=True)
+    ctx.scan_set_model(A, w, 0)
+    ada = ctx.scan(g, 1e7, n - 2, stats=True)
+    st = ctx.scan_last_stats()
+    assert st["adaptive"] and not st["fell_back"] and st["sigma_ratio_max"] < 1.0 and st["n_refined"] > 0
+    ok = full["ps"] > 1e-290
+    assert rel(ada["ps"][ok], full["ps"][ok]) < 2.5e-7
+    S = snps[:32].astype(np.float64)
+    assert rel(full["den"][:32], np.einsum("ij,ij->i", S @ A, S)) < 1e-8
