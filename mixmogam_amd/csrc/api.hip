@@ -657,15 +657,36 @@ static int model_from_device(mmg_ctx* ctx, mmg_scan_model& md, int32_t N, const 
   if (!(maxoff > 0.0) || !std::isfinite(maxoff)) maxoff = 1.0;   // diagonal matrix: all digits are zero
   // |rint(2 A_jk / step)| <= 2^(8D-2): the top balanced digit stays within int8
   md.step = 2.0 * maxoff / std::ldexp(1.0, 8 * md.D - 2);
-  long long* dz0 = nullptr;
+  const int nT = md.Npad / 256;
+  long long *dz0 = nullptr, *dzt = nullptr;
   MMG_HIP(ctx, sc.alloc(&dz0, sizeof(long long)));
+  MMG_HIP(ctx, sc.alloc(&dzt, (size_t)nT * nT * sizeof(long long)));
   MMG_HIP(ctx, hipMemsetAsync(dz0, 0, sizeof(long long), ctx->stream));
-  launch_quantize(ctx, dA, N, md.Npad, md.D, 1.0 / md.step, md.Bq, md.diag, dz0);
+  MMG_HIP(ctx, hipMemsetAsync(dzt, 0, (size_t)nT * nT * sizeof(long long), ctx->stream));
+  launch_quantize(ctx, dA, N, md.Npad, md.D, 1.0 / md.step, md.Bq, md.diag, dz0, md.adaptive ? dzt : nullptr);
   MMG_HIP(ctx, hipGetLastError());
   long long z0 = 0;
+  std::vector<long long> zt((size_t)nT * nT, 0);
   MMG_HIP(ctx, hipMemcpyAsync(&z0, dz0, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+  if (md.adaptive)
+    MMG_HIP(ctx, hipMemcpyAsync(zt.data(), dzt, zt.size() * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   md.mu0 = N > 1 ? (double)z0 / (0.5 * (double)N * (double)(N - 1)) : 0.0;
+  if (md.adaptive) {
+    // The adaptive schedule treats the lowest digit plane as noise with mean mu0 around which nothing is
+    // structured.  Guard: the mean of every 256 x 256 tile of that plane must be within 8 sigma of mu0 (a uniform
+    // digit has sigma 73.9); a matrix with blocks that are constant to 22 bits would fail -- then every plane is
+    // run for every SNP.
+    for (int tj = 0; tj < nT && md.adaptive; ++tj)
+      for (int tk = 0; tk <= tj; ++tk) {
+        const int64_t rows = std::min<int64_t>(256, N - 256 * (int64_t)tj), cols = std::min<int64_t>(256, N - 256 * (int64_t)tk);
+        if (rows <= 0 || cols <= 0) continue;
+        const double cnt = tj == tk ? 0.5 * rows * (rows - 1) : (double)rows * cols;
+        if (cnt < 1024) continue;
+        const double dev = std::fabs((double)zt[(size_t)tj * nT + tk] - md.mu0 * cnt) / (73.9 * std::sqrt(cnt));
+        if (dev > 8.0) { md.adaptive = false; break; }
+      }
+  }
   return build_schedule(ctx, md);
 }
 

@@ -49,7 +49,8 @@ void launch_absmax_offdiag(mmg_ctx* ctx, const double* A, int32_t N, unsigned lo
 
 // one thread = 16 consecutive k of row j; Bq[d][j][k] = digit d of rint(2 A[j][k] / step), k < j
 __global__ void quantize_kernel(const double* __restrict__ A, int32_t N, int32_t Npad, int D, double inv_step,
-                                int8_t* __restrict__ Bq, double* __restrict__ diag, long long* __restrict__ z0_sum) {
+                                int8_t* __restrict__ Bq, double* __restrict__ diag, long long* __restrict__ z0_sum,
+                                long long* __restrict__ z0_tile /*[nJ][nJ] sums of the lowest digit per 256 x 256 tile*/) {
   const int chunks = Npad >> 4;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   long long z0acc = 0;                                   // sum of the lowest digits (adaptive scan: their mean is the
@@ -79,6 +80,8 @@ __global__ void quantize_kernel(const double* __restrict__ A, int32_t N, int32_t
   for (int d = 0; d < D; ++d)
     *(uint4*)(Bq + ((int64_t)d * Npad + j) * Npad + c * 16) = make_uint4(out[d][0], out[d][1], out[d][2], out[d][3]);
   if (c == 0) diag[j] = (j < N) ? A[(int64_t)j * N + j] : 0.0;
+  if (z0_tile && z0acc != 0)
+    atomicAdd((unsigned long long*)(z0_tile + (int64_t)(j >> 8) * (Npad >> 8) + (c >> 4)), (unsigned long long)z0acc);
   }
   if (z0_sum) {
 #pragma unroll
@@ -88,10 +91,10 @@ __global__ void quantize_kernel(const double* __restrict__ A, int32_t N, int32_t
 }
 
 void launch_quantize(mmg_ctx* ctx, const double* A, int32_t N, int32_t Npad, int D, double inv_step, int8_t* Bq,
-                     double* diag, long long* z0_sum) {
+                     double* diag, long long* z0_sum, long long* z0_tile) {
   const int64_t total = (int64_t)Npad * (Npad >> 4);
   hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, A, N, Npad,
-                     D, inv_step, Bq, diag, z0_sum);
+                     D, inv_step, Bq, diag, z0_sum, z0_tile);
 }
 
 // ------------------------------------------------------------------ p-value

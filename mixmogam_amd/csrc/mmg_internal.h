@@ -136,7 +136,8 @@ void launch_mirror_i32_to_i64(mmg_ctx*, const int* C32, int32_t Npad, int32_t N,
 // ---- k_scan.hip
 void launch_absmax_offdiag(mmg_ctx*, const double* A, int32_t N, unsigned long long* out_bits);
 void launch_quantize(mmg_ctx*, const double* A, int32_t N, int32_t Npad, int D, double inv_step,
-                     int8_t* Bq, double* diag, long long* z0_sum /*dev, accumulated; may be null*/);
+                     int8_t* Bq, double* diag, long long* z0_sum /*dev, accumulated; may be null*/,
+                     long long* z0_tile /*dev [Npad/256]^2, accumulated; may be null*/);
 void launch_scan_quad(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
 // ---- k_scan_bits.hip (binary genotypes staged as bits)
 int ensure_bits(mmg_ctx*, mmg_geno*);

@@ -688,3 +688,25 @@ def test_adaptive_digit_schedule_other_genotype_alphabets(ctx, alphabet):
     assert rel(ada["ps"][ok], full["ps"][ok]) < 2.5e-7
     S = snps[:32].astype(np.float64)
     assert rel(full["den"][:32], np.einsum("ij,ij->i", S @ A, S)) < 1e-8
+
+
+def test_adaptive_schedule_is_refused_for_matrices_with_flat_blocks(ctx):
+    """The error model of the adaptive schedule needs a lowest digit plane without structure.  A matrix whose
+    off-diagonal is constant over whole tiles (here: everywhere) has a constant lowest digit; the per-tile mean
+    check at quantisation time catches it and the default model then runs every plane for every SNP."""
+    rng = np.random.RandomState(41)
+    n, m = 900, 2000
+    A = np.full((n, n), 0.0123456789)                      # the maximum: its lowest digit is 0 ...
+    A[256:512, 0:256] = A[0:256, 256:512] = 0.00777777     # ... this block's is a constant that is not
+    A[512:768, 256:512] = A[256:512, 512:768] = 0.00313131
+    A += np.eye(n) * 2.0
+    w = rng.standard_normal(n)
+    snps = (rng.random_sample((m, n)) < 0.4).astype(np.int8)
+    g = ctx.geno(snps)
+    ctx.scan_set_model(A, w, 4)
+    full = ctx.scan(g, 1e7, n - 2, stats=True)
+    ctx.scan_set_model(A, w, 0)
+    dflt = ctx.scan(g, 1e7, n - 2, stats=True)
+    assert not ctx.scan_last_stats()["adaptive"]
+    for k in ("den", "rss", "ps"):
+        assert np.array_equal(dflt[k], full[k]), k
