@@ -23,9 +23,15 @@
 //   slots nobody reads (branch-free step body); the kernel drains vmcnt before it exits.
 //
 //   Epilogue operands (the genotype bytes s[snp][256J + j] that multiply row j of the accumulators) are
-//   the Q tiles of the job's last two K steps: wave row-half wm captures its 64 dwords from LDS during
-//   step nks-2+wm (before that step's barrier) and keeps them in registers.
+//   the Q tiles of the job's last two K steps: every wave captures 64 dwords from LDS before step nks-2 (row
+//   half wm = 0 keeps them, wm = 1 overwrites them before step nks-1 -- an unconditional first capture keeps the
+//   64 registers from being live across jobs) and holds them in registers.  The first slice of a job writes the
+//   accumulators with C = 0 instead of clearing them; the epilogue runs on v_mad_i32_i24 when the host can prove
+//   from the store's tracked max |s| that nothing overflows (FAST), on 64-bit multiply-adds otherwise.
 //
+// Which digit planes a launch covers is the caller's business (job list): the adaptive schedule of
+// api.hip:mmg_emmax_scan_device launches this kernel twice per scan (planes 1-3 on everything, plane 0 on the
+// compact store of the SNPs that need it).
 // Results are bit-identical to scan_quad_kernel (exact integers, 64-bit integer atomics).
 #include <algorithm>
 #include <cstdlib>
