@@ -34,7 +34,10 @@ def test_header_symbols_exported_and_bound(built):
 
 
 def test_code_object_targets_gfx950(built, tmp_path):
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", built.LIB_PATH],
+    import shutil
+    copy = str(tmp_path / "lib.so")          # --offloading drops the extracted code objects beside its input
+    shutil.copy(built.LIB_PATH, copy)
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", copy],
                          capture_output=True, text=True, cwd=str(tmp_path))
     txt = out.stdout + out.stderr
     if "gfx" in txt:
