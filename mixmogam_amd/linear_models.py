@@ -567,7 +567,7 @@ class LinearMixedModel(object):
                 np.random.shuffle(idx)
                 perm_idx.append(np.asarray(idx).reshape(-1).copy())
         perm_idx = np.asarray(perm_idx)
-        Ys = np.stack([r[ix] for ix in perm_idx], axis=1)                # n x P
+        Ys = np.ascontiguousarray(r[perm_idx].T)                          # n x P: column p = r[perm_idx[p]]
         own = not isinstance(snps, _lib.Geno)
         g = ctx.geno(kinship._as_snp_matrix(snps)) if own else snps
         try:
