@@ -38,6 +38,9 @@ typedef struct mmg_kin_acc mmg_kin_acc;  /* device-resident N x N kinship accumu
 
 /* ---- library / context -------------------------------------------------------------- */
 int mmg_version(void);
+/* 1 if the library was built with `make EXPERIMENTS=1` (superseded scan-GEMM generations selectable through
+ * MMG_SCAN_KERNEL for A/B runs); the shipped library returns 0 and ignores that variable. */
+int mmg_has_experiments(void);
 int mmg_device_count(int* n);
 int mmg_ctx_create(int device, mmg_ctx** ctx);
 int mmg_ctx_destroy(mmg_ctx* ctx);
@@ -64,7 +67,9 @@ int mmg_geno_destroy(mmg_ctx* ctx, mmg_geno* g);
 /* Copy SNP rows [m0, m0+rows) from a host [rows x N] int8 C-contiguous buffer. */
 int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, int64_t rows);
 /* Same from a host float32 / float64 [rows x N] buffer holding small integers (the C3 config's
- * "fp32 genotypes", hdf5_data.py:294 float64 copies); values are rounded to int8 on the device. */
+ * "fp32 genotypes", hdf5_data.py:294 float64 copies), converted to int8 on the device.  Values that are not
+ * integers in [-127, 127] (dosages, normalised SNPs, NaN) make the call fail with MMG_E_ARG -- the reference
+ * takes arbitrary numeric SNPs (linear_models.py:1317), this int8 store does not, and says so. */
 int mmg_geno_upload_f32(mmg_ctx* ctx, mmg_geno* g, const float* snps, int64_t m0, int64_t rows);
 int mmg_geno_upload_f64(mmg_ctx* ctx, mmg_geno* g, const double* snps, int64_t m0, int64_t rows);
 int mmg_geno_download(mmg_ctx* ctx, mmg_geno* g, int8_t* snps, int64_t m0, int64_t rows);

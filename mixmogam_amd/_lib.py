@@ -11,7 +11,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmixmogam_hip.so")
+# MMG_LIB: another build of the same ABI (e.g. the `make EXPERIMENTS=1` library for A/B runs of superseded kernels)
+LIB_PATH = os.environ.get("MMG_LIB") or os.path.join(_HERE, "lib", "libmixmogam_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mixmogam_hip.h")
 
 _lib = None
@@ -26,6 +27,7 @@ c_vp = C.c_void_p
 # name -> (restype, argtypes); kept in sync with include/mixmogam_hip.h (tests check it)
 PROTOTYPES = {
     "mmg_version": (C.c_int, []),
+    "mmg_has_experiments": (C.c_int, []),
     "mmg_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "mmg_ctx_create": (C.c_int, [C.c_int, C.POINTER(c_vp)]),
     "mmg_ctx_destroy": (C.c_int, [c_vp]),
@@ -108,6 +110,27 @@ def _arr(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
 
 
+def as_store_array(snps):
+    """[rows x N] genotypes in a dtype the store ingests without silent damage: int8 as is; wider integer / bool
+    dtypes are range-checked on the host and narrowed; float32 / float64 pass through (the device conversion
+    kernel rejects non-integral, out-of-range or NaN values); anything else goes through float64.  The reference
+    takes arbitrary numeric SNPs (sp.matrix(snps, dtype='single'), linear_models.py:1317); this store is int8, so
+    dosages or normalised SNPs raise instead of being rounded or wrapped."""
+    a = np.asarray(snps)
+    if a.ndim != 2:
+        raise ValueError("snps must be [num_snps x num_individuals]")
+    if a.dtype == np.int8 or a.dtype in (np.float32, np.float64):
+        return np.ascontiguousarray(a)
+    if a.dtype == np.bool_:
+        return np.ascontiguousarray(a, dtype=np.int8)
+    if np.issubdtype(a.dtype, np.integer):
+        if a.size and (int(a.min()) < -127 or int(a.max()) > 127):
+            raise ValueError("genotype values must lie in [-127, 127] (int8 store); got [%d, %d]"
+                             % (int(a.min()), int(a.max())))
+        return np.ascontiguousarray(a, dtype=np.int8)
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
 class Geno(object):
     """Device-resident genotype store ([M x N] int8, SNP-major, padded in HBM)."""
 
@@ -118,17 +141,14 @@ class Geno(object):
         self.h = h
 
     def upload(self, snps, m0=0):
-        a = np.asarray(snps)
-        if a.ndim != 2 or a.shape[1] != self.N:
+        a = as_store_array(snps)
+        if a.shape[1] != self.N:
             raise ValueError("expected [rows x %d] genotypes, got %r" % (self.N, a.shape))
         if a.dtype == np.float32:
-            a = _arr(a, np.float32)
             fn = self.ctx.lib.mmg_geno_upload_f32
         elif a.dtype == np.float64:
-            a = _arr(a, np.float64)
             fn = self.ctx.lib.mmg_geno_upload_f64
         else:
-            a = _arr(a, np.int8)
             fn = self.ctx.lib.mmg_geno_upload
         self.ctx._check(fn(self.ctx.h, self.h, _ptr(a), int(m0), a.shape[0]))
         return self
@@ -254,7 +274,7 @@ class Context(object):
     # --- genotype store
     def geno(self, snps=None, M=None, N=None):
         if snps is not None:
-            a = np.asarray(snps)
+            a = as_store_array(snps)
             g = Geno(self, a.shape[0], a.shape[1])
             if a.shape[0]:
                 g.upload(a)

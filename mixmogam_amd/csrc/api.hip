@@ -28,6 +28,16 @@ using namespace mmg;
   do {                                                                             \
     if (!(cond)) return set_err(ctx, MMG_E_ARG, std::string("bad argument: ") + #cond); \
   } while (0)
+// Every entry point that allocates, copies or launches binds the calling thread to the context's device first: HIP's
+// current device is per host thread (and defaults to 0), and a context may be driven from helper threads (the
+// chunk prefetcher of hdf5_data.py) or beside contexts of other devices in the same process.
+#define MMG_ENTER(ctx)                                                              \
+  do {                                                                              \
+    if (!(ctx)) return set_err(nullptr, MMG_E_ARG, "bad argument: ctx != nullptr"); \
+    hipError_t e_dev__ = hipSetDevice((ctx)->device);                               \
+    if (e_dev__ != hipSuccess)                                                      \
+      return set_err(ctx, MMG_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e_dev__)); \
+  } while (0)
 #define MMG_RB(ctx, call)                                                                      \
   do {                                                                                         \
     rocblas_status s__ = (call);                                                               \
@@ -115,7 +125,7 @@ int mmg_ctx_destroy(mmg_ctx* ctx) {
 }
 
 int mmg_device_info(mmg_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* hbm_bytes) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   hipDeviceProp_t prop;
   MMG_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
   if (name && name_len > 0) { std::strncpy(name, prop.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
@@ -125,7 +135,7 @@ int mmg_device_info(mmg_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
 }
 
 int mmg_last_kernel_ms(mmg_ctx* ctx, int which, double* ms) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, which >= 0 && which < EV_COUNT && ms != nullptr);
   if (!ctx->ev_set[which]) return set_err(ctx, MMG_E_STATE, "no kernel of that kind has run");
   float f = 0.f;
@@ -141,14 +151,14 @@ int mmg_last_kernel_ms(mmg_ctx* ctx, int which, double* ms) {
 }
 
 int mmg_host_pin(mmg_ctx* ctx, void* p, int64_t bytes) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, p != nullptr && bytes > 0);
   MMG_HIP(ctx, hipHostRegister(p, (size_t)bytes, hipHostRegisterDefault));
   return MMG_OK;
 }
 
 int mmg_host_alloc(mmg_ctx* ctx, int64_t bytes, void** p) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, p != nullptr && bytes > 0);
   *p = nullptr;
   MMG_HIP(ctx, hipHostMalloc(p, (size_t)bytes, hipHostMallocDefault));
@@ -156,7 +166,7 @@ int mmg_host_alloc(mmg_ctx* ctx, int64_t bytes, void** p) {
 }
 
 int mmg_host_free(mmg_ctx* ctx, void* p) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   if (!p) return MMG_OK;
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   MMG_HIP(ctx, hipHostFree(p));
@@ -164,7 +174,7 @@ int mmg_host_free(mmg_ctx* ctx, void* p) {
 }
 
 int mmg_host_unpin(mmg_ctx* ctx, void* p) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, p != nullptr);
   MMG_HIP(ctx, hipHostUnregister(p));
   return MMG_OK;
@@ -172,7 +182,7 @@ int mmg_host_unpin(mmg_ctx* ctx, void* p) {
 
 // ------------------------------------------------------------------------- genotype store
 int mmg_geno_create(mmg_ctx* ctx, int64_t M, int32_t N, mmg_geno** out) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, out != nullptr && M >= 0 && N > 0);
   *out = nullptr;
   mmg_geno* g = new mmg_geno();
@@ -192,7 +202,7 @@ int mmg_geno_create(mmg_ctx* ctx, int64_t M, int32_t N, mmg_geno** out) {
 
 int mmg_geno_destroy(mmg_ctx* ctx, mmg_geno* g) {
   if (!g) return MMG_OK;
-  if (ctx) hipStreamSynchronize(ctx->stream);
+  if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
   hipFree(g->d);
   hipFree(g->bits);
   hipFree(g->d_smax);
@@ -212,33 +222,47 @@ static int refresh_smax(mmg_ctx* ctx, mmg_geno* g, int64_t m0, int64_t rows) {
 }
 
 int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, int64_t rows) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g && snps && m0 >= 0 && rows >= 0 && m0 + rows <= g->M);
   if (rows == 0) return MMG_OK;
   g->bits_valid = false;
   MMG_HIP(ctx, hipMemcpy2DAsync(g->d + m0 * (int64_t)g->Npad, g->Npad, snps, g->N, g->N, rows,
                                 hipMemcpyHostToDevice, ctx->stream));
-  return refresh_smax(ctx, g, m0, rows);
+  int rc = refresh_smax(ctx, g, m0, rows);
+  if (rc) return rc;
+  if (g->smax > 127) return set_err(ctx, MMG_E_ARG, "genotype value -128 is outside the store's range [-127, 127]");
+  return MMG_OK;
 }
 
 extern "C++" {
 template <typename T>
 static int upload_cvt(mmg_ctx* ctx, mmg_geno* g, const T* snps, int64_t m0, int64_t rows) {
   Scratch sc;
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g && snps && m0 >= 0 && rows >= 0 && m0 + rows <= g->M);
   g->bits_valid = false;
   const int64_t chunk = std::max<int64_t>(1, (int64_t)(256 << 20) / ((int64_t)g->N * sizeof(T)));
   T* tmp = nullptr;
+  int* dbad = nullptr;
+  if (rows == 0) return MMG_OK;
   MMG_HIP(ctx, sc.alloc(&tmp, (size_t)std::min(chunk, rows) * g->N * sizeof(T)));
+  MMG_HIP(ctx, sc.alloc(&dbad, sizeof(int)));
+  MMG_HIP(ctx, hipMemsetAsync(dbad, 0, sizeof(int), ctx->stream));
   for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
     const int64_t nr = std::min(chunk, rows - r0);
     MMG_HIP(ctx, hipMemcpyAsync(tmp, snps + r0 * g->N, (size_t)nr * g->N * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    if (sizeof(T) == 4) launch_cvt_f32(ctx, (const float*)tmp, g->d + (m0 + r0) * (int64_t)g->Npad, nr, g->N, g->Npad);
-    else launch_cvt_f64(ctx, (const double*)tmp, g->d + (m0 + r0) * (int64_t)g->Npad, nr, g->N, g->Npad);
+    if (sizeof(T) == 4) launch_cvt_f32(ctx, (const float*)tmp, g->d + (m0 + r0) * (int64_t)g->Npad, nr, g->N, g->Npad, dbad);
+    else launch_cvt_f64(ctx, (const double*)tmp, g->d + (m0 + r0) * (int64_t)g->Npad, nr, g->N, g->Npad, dbad);
     MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  return refresh_smax(ctx, g, m0, rows);
+  int bad = 0;
+  MMG_HIP(ctx, hipMemcpy(&bad, dbad, sizeof(int), hipMemcpyDeviceToHost));
+  int rc = refresh_smax(ctx, g, m0, rows);
+  if (rc) return rc;
+  if (bad)
+    return set_err(ctx, MMG_E_ARG, "genotype values must be integers in [-127, 127] (the store is int8); "
+                                   "non-integral, out-of-range or NaN values were found and left unwritten");
+  return MMG_OK;
 }
 }  // extern C++
 int mmg_geno_upload_f32(mmg_ctx* ctx, mmg_geno* g, const float* snps, int64_t m0, int64_t rows) {
@@ -249,7 +273,7 @@ int mmg_geno_upload_f64(mmg_ctx* ctx, mmg_geno* g, const double* snps, int64_t m
 }
 
 int mmg_geno_download(mmg_ctx* ctx, mmg_geno* g, int8_t* snps, int64_t m0, int64_t rows) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g && snps && m0 >= 0 && rows >= 0 && m0 + rows <= g->M);
   if (rows == 0) return MMG_OK;
   MMG_HIP(ctx, hipMemcpy2DAsync(snps, g->N, g->d + m0 * (int64_t)g->Npad, g->Npad, g->N, rows,
@@ -259,7 +283,7 @@ int mmg_geno_download(mmg_ctx* ctx, mmg_geno* g, int8_t* snps, int64_t m0, int64
 }
 
 int mmg_geno_fill_hash(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_global0, uint32_t thr16) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g != nullptr && thr16 <= 65536);
   if (g->M == 0) return MMG_OK;
   g->bits_valid = false;
@@ -275,7 +299,7 @@ int mmg_geno_fill_hash(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_globa
 
 int mmg_geno_snp_stats(mmg_ctx* ctx, mmg_geno* g, double* mean, double* sd) {
   Scratch sc;
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g && mean && sd);
   if (g->M == 0) return MMG_OK;
   double *dm = nullptr, *ds = nullptr;
@@ -305,14 +329,14 @@ int mmg_kinship_ibs_i8(mmg_ctx* ctx, mmg_geno* g, int64_t* C_out) {
 }
 
 int mmg_kinship_indicator_i8(mmg_ctx* ctx, mmg_geno* g, int32_t thr, int64_t* C_out) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, thr >= 1 && thr <= 127);
   return kinship_counts_i8(ctx, g, 0, 0, thr, C_out);   // X = [S >= thr]
 }
 
 static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int thr, int64_t* C_out) {
   Scratch sc;
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g && C_out && g->M > 0);
   MMG_CHECK_ARG(ctx, g->M < (int64_t(1) << 31));       // int32 accumulators: |C_ij| <= M
   const int64_t CH = kin_chunk();
@@ -396,7 +420,7 @@ static int kinship_affine_into(mmg_ctx* ctx, mmg_geno* g, const float* scale, co
 
 int mmg_kinship_affine_f32(mmg_ctx* ctx, mmg_geno* g, const float* scale, const float* shift, double* C_out) {
   Scratch sc;
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g && C_out && g->M > 0);
   MMG_CHECK_ARG(ctx, (scale == nullptr) == (shift == nullptr));
   double* dC = nullptr;
@@ -415,7 +439,7 @@ int mmg_kinship_affine_f32(mmg_ctx* ctx, mmg_geno* g, const float* scale, const 
 struct mmg_kin_acc { int32_t N = 0; double* dC = nullptr; int64_t n_snps = 0; };
 
 int mmg_kin_acc_create(mmg_ctx* ctx, int32_t N, mmg_kin_acc** out) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, out && N > 0);
   mmg_kin_acc* a = new mmg_kin_acc();
   a->N = N;
@@ -428,7 +452,7 @@ int mmg_kin_acc_create(mmg_ctx* ctx, int32_t N, mmg_kin_acc** out) {
 }
 
 int mmg_kin_acc_add(mmg_ctx* ctx, mmg_kin_acc* a, mmg_geno* g, const float* scale, const float* shift) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, a && g && g->N == a->N && (scale == nullptr) == (shift == nullptr));
   if (g->M == 0) return MMG_OK;
   int rc = kinship_affine_into(ctx, g, scale, shift, a->dC, true);
@@ -437,7 +461,7 @@ int mmg_kin_acc_add(mmg_ctx* ctx, mmg_kin_acc* a, mmg_geno* g, const float* scal
 }
 
 int mmg_kin_acc_fetch(mmg_ctx* ctx, mmg_kin_acc* a, double* C_out, int64_t* n_snps) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, a && C_out);
   MMG_HIP(ctx, hipMemcpyAsync(C_out, a->dC, (size_t)a->N * a->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -447,7 +471,7 @@ int mmg_kin_acc_fetch(mmg_ctx* ctx, mmg_kin_acc* a, double* C_out, int64_t* n_sn
 
 int mmg_kin_acc_destroy(mmg_ctx* ctx, mmg_kin_acc* a) {
   if (!a) return MMG_OK;
-  if (ctx) hipStreamSynchronize(ctx->stream);
+  if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
   hipFree(a->dC);
   delete a;
   return MMG_OK;
@@ -455,7 +479,7 @@ int mmg_kin_acc_destroy(mmg_ctx* ctx, mmg_kin_acc* a) {
 
 int mmg_kinship_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N, const float* scale, const float* shift,
                    double* C_out) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, snps && C_out && M > 0 && N > 0);
   mmg_geno* g = nullptr;
   int rc = mmg_geno_create(ctx, M, N, &g);
@@ -494,7 +518,7 @@ static int get_rocblas(mmg_ctx* ctx, rocblas_handle* h) {
 
 int mmg_eigh_f64(mmg_ctx* ctx, const double* A, int32_t N, double* evals, double* evecs) {
   Scratch sc;
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, A && evals && N > 0);
   // rocSOLVER 7.2 has no 64-bit-index syevd: element offsets lda*N wrap at N*N >= 2^31 and the solver faults
   // on the device (seen at N = 50000).  Beyond that range -- or when MMG_EIGH_BLOCK=<rows> asks for it (tests) --
@@ -555,7 +579,7 @@ int mmg_eigh_f64(mmg_ctx* ctx, const double* A, int32_t N, double* evals, double
 int mmg_dgemm_f64(mmg_ctx* ctx, int ta, int tb, int32_t M, int32_t N, int32_t K, const double* A, const double* B,
                   double* C) {
   Scratch sc;
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, A && B && C && M > 0 && N > 0 && K > 0);
   rocblas_handle h;
   int rc = get_rocblas(ctx, &h);
@@ -692,7 +716,7 @@ static int model_from_device(mmg_ctx* ctx, mmg_scan_model& md, int32_t N, const 
 
 int mmg_scan_set_model(mmg_ctx* ctx, int32_t N, const double* A, const double* w, int ndigits) {
   Scratch sc;
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, A && w && N > 0);
   // ndigits = 0: the default model -- 4 digit planes with the adaptive schedule of mmg_emmax_scan_device (three
   // planes for every SNP, the fourth for those whose F passes a threshold); an explicit count runs all its planes
@@ -732,7 +756,7 @@ static int ensure_result(mmg_ctx* ctx, mmg_scan_result& r, int64_t Mpad) {
 }
 
 int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g != nullptr && df2 > 0);
   if (!ctx->model.Bq) return set_err(ctx, MMG_E_STATE, "mmg_scan_set_model has not been called");
   if (ctx->model.N != g->N) return set_err(ctx, MMG_E_ARG, "model N does not match the genotype store");
@@ -836,7 +860,7 @@ int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2)
 
 int mmg_scan_last_stats(mmg_ctx* ctx, int32_t* adaptive, int64_t* n_refined, double* eps_max, double* sigma_ratio_max,
                         int32_t* fell_back) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   if (adaptive) *adaptive = ctx->res.adaptive;
   if (n_refined) *n_refined = ctx->res.n_refined;
   if (eps_max) *eps_max = ctx->res.eps_max;
@@ -852,7 +876,7 @@ static int fetch(mmg_ctx* ctx, double* dst, const double* src, int64_t M) {
 }
 
 int mmg_scan_fetch(mmg_ctx* ctx, int64_t M, double* rss, double* F, double* p) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, M == ctx->res.M);
   int rc;
   if ((rc = fetch(ctx, rss, ctx->res.rss, M))) return rc;
@@ -863,7 +887,7 @@ int mmg_scan_fetch(mmg_ctx* ctx, int64_t M, double* rss, double* F, double* p) {
 }
 
 int mmg_scan_fetch_stats(mmg_ctx* ctx, int64_t M, double* dot, double* den, double* sum) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, M == ctx->res.M);
   int rc;
   if ((rc = fetch(ctx, dot, ctx->res.dot, M))) return rc;
@@ -881,7 +905,7 @@ int mmg_emmax_scan(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2, double
 
 int mmg_emmax_scan_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N, const double* A, const double* w,
                       double h0_rss, int32_t df2, double* rss, double* F, double* p) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, snps && M >= 0 && N > 0);
   int rc = mmg_scan_set_model(ctx, N, A, w, 0);
   if (rc) return rc;
@@ -896,7 +920,7 @@ int mmg_emmax_scan_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N, co
 
 int mmg_geno_matvec(mmg_ctx* ctx, mmg_geno* g, const double* V, int32_t nv, double* out) {
   Scratch sc;
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g && V && out && nv > 0);
   if (g->M == 0) return MMG_OK;
   double *dv = nullptr, *dout = nullptr;
@@ -915,7 +939,7 @@ int mmg_geno_matvec(mmg_ctx* ctx, mmg_geno* g, const double* V, int32_t nv, doub
 
 int mmg_f_sf(mmg_ctx* ctx, const double* F, int64_t n, int32_t df2, double* p) {
   Scratch sc;
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, F && p && n >= 0 && df2 > 0);
   if (n == 0) return MMG_OK;
   double *dF = nullptr, *dp = nullptr;
@@ -945,7 +969,7 @@ static int dgemm_dev(mmg_ctx* ctx, int ta, int tb, int M, int N, int K, const do
 int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const double* Ys, int32_t P, double h0_rss,
                    int ndigits, double* min_rss) {
   Scratch sc;
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g && Ht && Ys && min_rss && P > 0 && N == g->N);
   MMG_CHECK_ARG(ctx, ndigits == 0 || ndigits == 4);
   std::vector<double> yy((size_t)P, 0.0);
@@ -1017,7 +1041,7 @@ int mmg_comm_unique_id(unsigned char id[128]) {
 }
 
 int mmg_comm_create(mmg_ctx* ctx, const unsigned char id[128], int rank, int world, mmg_comm** out) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, id && out && world >= 1 && rank >= 0 && rank < world);
   ncclUniqueId uid;
   std::memcpy(&uid, id, 128);
@@ -1033,7 +1057,7 @@ int mmg_comm_create(mmg_ctx* ctx, const unsigned char id[128], int rank, int wor
 
 int mmg_comm_destroy(mmg_ctx* ctx, mmg_comm* c) {
   if (!c) return MMG_OK;
-  if (ctx) { hipStreamSynchronize(ctx->stream); hipStreamSynchronize(ctx->stream2); ctx->deliver_pending = false; }
+  if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); hipStreamSynchronize(ctx->stream2); ctx->deliver_pending = false; }
   if (c->comm) ncclCommDestroy(c->comm);
   fflush(stdout);
   delete c;
@@ -1041,7 +1065,7 @@ int mmg_comm_destroy(mmg_ctx* ctx, mmg_comm* c) {
 }
 
 int mmg_scan_deliver_wait(mmg_ctx* ctx) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   if (!ctx->deliver_pending) return MMG_OK;
   ctx->deliver_pending = false;
   MMG_HIP(ctx, hipEventSynchronize(ctx->ev_deliver));
@@ -1049,7 +1073,7 @@ int mmg_scan_deliver_wait(mmg_ctx* ctx) {
 }
 
 int mmg_scan_deliver_begin(mmg_ctx* ctx, mmg_comm* c, int64_t count, double* rss, double* F, double* p) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, count >= 0 && count <= ctx->res.cap);
   int rc = mmg_scan_deliver_wait(ctx);              // one delivery in flight: the staging is reused
   if (rc) return rc;
@@ -1088,7 +1112,7 @@ int mmg_scan_deliver_begin(mmg_ctx* ctx, mmg_comm* c, int64_t count, double* rss
 }
 
 int mmg_comm_allgather_scan(mmg_ctx* ctx, mmg_comm* c, int64_t count, double* rss, double* F, double* p) {
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, c != nullptr);
   int rc = mmg_scan_deliver_begin(ctx, c, count, rss, F, p);
   if (rc) return rc;
@@ -1099,7 +1123,7 @@ extern "C++" {
 template <typename T>
 static int allreduce_host(mmg_ctx* ctx, mmg_comm* c, T* buf, int64_t count, int op, ncclDataType_t dt) {
   Scratch sc;
-  MMG_CHECK_ARG(nullptr, ctx != nullptr);
+  MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, c && buf && count >= 0 && op >= 0 && op <= 2);
   if (count == 0) return MMG_OK;
   T* d = nullptr;

@@ -191,30 +191,4 @@ void launch_scan_quad_bits(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model
                      md.job_off, md.jobs, md.AS, q);
 }
 
-int run_scan_quad(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, unsigned long long* q, int ev_slot) {
-  // MMG_SCAN_KERNEL selects a generation of the quadratic-form GEMM (all bit-identical):
-  //   (unset) / w4s   4 waves x 128x128, hand-laid pipeline (k_scan_w4s.hip)            -- production
-  //   q8              8 waves x 128x64, loader waves (k_scan_q8.hip; also what MMG_ABLATE instruments)
-  //   w4m             the w4s pipeline on v_mfma_i32_16x16x64_i8 (k_scan_w4m.hip): higher clock, more cycles, +13 %
-  //   w4b / bits      bit-packed genotype operand for binary stores (k_scan_w4b.hip / this file): fewer bytes
-  //                   through L2 and LDS, but the fragment expansion costs more than it saves (+5...8 %)
-  //   timed, m16, flat, ring, pp    earlier experiments kept for A/B runs (k_scan_q8.hip)
-  const char* kv = std::getenv("MMG_SCAN_KERNEL");
-  const std::string k = kv ? kv : "";
-  const bool ablate = std::getenv("MMG_ABLATE") != nullptr;
-  const bool want_w4b = k == "w4b" && !ablate;
-  const bool want_bits = (k == "bits" || want_w4b) && !ablate;
-  if (want_bits) {
-    int rc = ensure_bits(ctx, g);                     // once per store content
-    if (rc) return rc;
-  }
-  EvScope ev(ctx, ev_slot);
-  if (want_w4b && g->binary) launch_scan_quad_w4b(ctx, g, md, q);
-  else if (want_bits && g->binary) launch_scan_quad_bits(ctx, g, md, q);
-  else if (!ablate && k == "w4m") launch_scan_quad_w4m(ctx, g, md, q);
-  else if (!ablate && (k.empty() || k == "w4s" || k == "w4b" || k == "bits")) launch_scan_quad_w4s(ctx, g, md, q);
-  else launch_scan_quad(ctx, g, md, q);
-  return MMG_OK;
-}
-
 }  // namespace mmg

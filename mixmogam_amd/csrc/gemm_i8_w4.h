@@ -3,7 +3,6 @@
 // an operand tile as 8 pieces of 8 rows x 128 B.
 #pragma once
 #include "gemm_i8_core.h"
-#include "gemm_i8_ring.h"
 
 namespace mmg {
 

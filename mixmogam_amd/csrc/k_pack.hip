@@ -44,24 +44,28 @@ void launch_fill_hash(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_global
 
 template <typename T>
 __global__ void cvt_kernel(const T* __restrict__ src, int8_t* __restrict__ dst, int64_t rows, int32_t N,
-                           int64_t ld) {
+                           int64_t ld, int* __restrict__ bad) {
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = rows * (int64_t)N;
   if (gid >= total) return;
   const int64_t r = gid / N;
   const int c = (int)(gid % N);
-  dst[r * ld + c] = (int8_t)__double2int_rn((double)src[gid]);
+  const double x = (double)src[gid];
+  // the store holds small integers: anything else (dosages, normalised SNPs, NaN, |x| > 127) would be silently
+  // rounded or wrapped -- flag it and let the entry point fail
+  if (!(x == rint(x)) || !(fabs(x) <= 127.0)) { atomicOr(bad, 1); return; }
+  dst[r * ld + c] = (int8_t)(int)x;
 }
 
-void launch_cvt_f32(mmg_ctx* ctx, const float* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld) {
+void launch_cvt_f32(mmg_ctx* ctx, const float* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld, int* d_bad) {
   const int64_t total = rows * (int64_t)N;
   hipLaunchKernelGGL(cvt_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                     src, dst, rows, N, ld);
+                     src, dst, rows, N, ld, d_bad);
 }
-void launch_cvt_f64(mmg_ctx* ctx, const double* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld) {
+void launch_cvt_f64(mmg_ctx* ctx, const double* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld, int* d_bad) {
   const int64_t total = rows * (int64_t)N;
   hipLaunchKernelGGL(cvt_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                     src, dst, rows, N, ld);
+                     src, dst, rows, N, ld, d_bad);
 }
 
 // 64 SNPs x 64 individuals per block; out[i][m] = valid ? mul * s + add : 0.

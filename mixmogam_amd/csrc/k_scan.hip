@@ -15,8 +15,8 @@
 // are bitwise reproducible from run to run and independent of the tile schedule.
 //
 // This file: model quantisation, the finalize kernel and the p-value function.  The quadratic-form GEMM itself
-// lives in k_scan_w4s.hip (production), k_scan_w4b.hip / k_scan_bits.hip (bit-packed variants) and k_scan_q8.hip
-// (8-wave generations); k_scan_bits.hip:run_scan_quad picks one.
+// lives in k_scan_w4s.hip; superseded generations (8-wave, bit-packed, 16x16x64) are kept under experiments/ and are
+// only compiled by `make EXPERIMENTS=1`.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>

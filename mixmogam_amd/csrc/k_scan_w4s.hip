@@ -332,4 +332,39 @@ void launch_scan_quad_w4s(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model&
 #undef MMG_LAUNCH_W4S
 }
 
+int run_scan_quad(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, unsigned long long* q, int ev_slot) {
+  // Production: the 4-wave x 128x128 hand-laid pipeline above.  A library built with `make EXPERIMENTS=1`
+  // (csrc/experiments/: the superseded generations q8 / w4m / w4b / bits / timed / m16 / flat / ring / pp, all
+  // bit-identical) honours MMG_SCAN_KERNEL / MMG_ABLATE for A/B runs; the shipped library ignores them.
+#ifdef MMG_EXPERIMENTS
+  const char* kv = std::getenv("MMG_SCAN_KERNEL");
+  const std::string k = kv ? kv : "";
+  const bool ablate = std::getenv("MMG_ABLATE") != nullptr;
+  const bool want_w4b = k == "w4b" && !ablate;
+  const bool want_bits = (k == "bits" || want_w4b) && !ablate;
+  if (want_bits) {
+    int rc = ensure_bits(ctx, g);                     // once per store content
+    if (rc) return rc;
+  }
+  EvScope ev(ctx, ev_slot);
+  if (want_w4b && g->binary) launch_scan_quad_w4b(ctx, g, md, q);
+  else if (want_bits && g->binary) launch_scan_quad_bits(ctx, g, md, q);
+  else if (!ablate && k == "w4m") launch_scan_quad_w4m(ctx, g, md, q);
+  else if (!ablate && (k.empty() || k == "w4s" || k == "w4b" || k == "bits")) launch_scan_quad_w4s(ctx, g, md, q);
+  else launch_scan_quad(ctx, g, md, q);
+#else
+  EvScope ev(ctx, ev_slot);
+  launch_scan_quad_w4s(ctx, g, md, q);
+#endif
+  return MMG_OK;
+}
+
 }  // namespace mmg
+
+extern "C" int mmg_has_experiments(void) {
+#ifdef MMG_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}

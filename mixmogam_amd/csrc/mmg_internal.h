@@ -112,14 +112,14 @@ struct EvScope {  // records the two events of slot `which` around a region on c
 
 // ---- k_pack.hip
 void launch_fill_hash(mmg_ctx*, mmg_geno*, uint64_t seed, int64_t m_global0, uint32_t thr16);
-void launch_cvt_f32(mmg_ctx*, const float* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld);
-void launch_cvt_f64(mmg_ctx*, const double* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld);
+// fp32 / fp64 genotype ingest -> int8; *d_bad |= 1 if any value is not an integer in [-127, 127]
+void launch_cvt_f32(mmg_ctx*, const float* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld, int* d_bad);
+void launch_cvt_f64(mmg_ctx*, const double* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld, int* d_bad);
 // Xt [Npad x Mk] = transpose of S with value map v -> mul*v + add for valid cells, 0 elsewhere.
 // (SNP rows [m_begin, m_begin + Mk) of the store; Mk a multiple of 128, m_begin + Mk <= Mpad)
 // thr > 0: indicator image [s >= thr] instead of the affine map
 void launch_transpose(mmg_ctx*, const mmg_geno*, int8_t* Xt, int64_t Mk, int mul, int add, int64_t m_begin,
                       int thr = 0);
-void launch_absmax_i8(mmg_ctx*, const int8_t* p, int64_t bytes, int* d_out);
 void launch_snp_stats(mmg_ctx*, const mmg_geno*, double* mean, double* sd);
 void launch_absmax_i8(mmg_ctx*, const int8_t* p, int64_t bytes, int* d_out);   // *d_out = max(*d_out, max |p[i]|); bytes % 16 == 0
 
@@ -138,14 +138,14 @@ void launch_absmax_offdiag(mmg_ctx*, const double* A, int32_t N, unsigned long l
 void launch_quantize(mmg_ctx*, const double* A, int32_t N, int32_t Npad, int D, double inv_step,
                      int8_t* Bq, double* diag, long long* z0_sum /*dev, accumulated; may be null*/,
                      long long* z0_tile /*dev [Npad/256]^2, accumulated; may be null*/);
-void launch_scan_quad(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
-// ---- k_scan_bits.hip (binary genotypes staged as bits)
+// ---- k_scan_w4s.hip: the production quadratic-form GEMM
+void launch_scan_quad_w4s(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
+// ---- experiments/ (only in a `make EXPERIMENTS=1` library): superseded generations, bit-identical
+void launch_scan_quad(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);   // 8-wave family
 int ensure_bits(mmg_ctx*, mmg_geno*);
 void launch_scan_quad_bits(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
-void launch_scan_quad_w4s(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
 void launch_scan_quad_w4m(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
 void launch_scan_quad_w4b(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
-// picks the bit-packed kernel for 0/1 genotypes unless MMG_SCAN_KERNEL names another variant
 // ev_slot: which event pair brackets the kernel (EV_QUAD, or EV_QUAD2 for the refinement pass)
 int run_scan_quad(mmg_ctx*, mmg_geno*, const mmg_scan_model&, unsigned long long* q, int ev_slot = EV_QUAD);
 void launch_scan_finalize(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, mmg_scan_result&,

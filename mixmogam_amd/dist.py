@@ -4,9 +4,9 @@ SURVEY 8e: kinship shards the contraction (SNP) axis -> all-reduce SUM of the N 
 count matrix; eigh + REML are replicas; the EMMAX scan shards independent SNP blocks -> all-gather
 of (rss, F, p); the permutation test shards SNP blocks -> all-reduce MIN over the P minima.
 
-The collectives are behind a two-method interface so that the same sharding logic runs over
-RCCL on GPUs (RcclCollectives: libmixmogam_hip's mmg_comm_* over xGMI) and over gloo on CPU in
-the world_size-2 tests (TorchCollectives).
+The collectives are behind a small interface (rank, world, allreduce, barrier) so that the same sharding
+logic runs over RCCL on GPUs (RcclCollectives: libmixmogam_hip's mmg_comm_* over xGMI) and over gloo on CPU
+in the world_size-2 tests (tests/torch_coll.py -- test infrastructure; nothing here imports torch).
 """
 import numpy as np
 
@@ -98,32 +98,6 @@ class RcclCollectives(object):
         if self.h is not None:
             self.ctx.lib.mmg_comm_destroy(self.ctx.h, self.h)
             self.h = None
-
-
-class TorchCollectives(object):
-    """torch.distributed (gloo on CPU) stand-in with the same interface, for tests."""
-
-    def __init__(self):
-        import torch.distributed as dist
-        self.dist = dist
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-
-    def allreduce(self, arr, op="sum"):
-        import torch
-        t = torch.from_numpy(np.ascontiguousarray(arr).copy())
-        self.dist.all_reduce(t, op={"sum": self.dist.ReduceOp.SUM, "min": self.dist.ReduceOp.MIN,
-                                    "max": self.dist.ReduceOp.MAX}[op])
-        return t.numpy()
-
-    def allgather_host(self, arr):
-        import torch
-        t = torch.from_numpy(np.ascontiguousarray(arr))
-        outs = [torch.empty_like(t) for _ in range(self.world)]
-        self.dist.all_gather(outs, t)
-        return np.concatenate([o.numpy() for o in outs])
-
-    def barrier(self):
-        self.dist.barrier()
 
 
 def sharded_ibs_counts(local_counts, coll):

@@ -11,12 +11,7 @@ from . import _lib
 
 def _as_snp_matrix(snps, dtype=np.int8):
     """list of M int8 arrays of length N, or 2-D array -> C-contiguous [M x N]."""
-    a = np.asarray(snps)
-    if a.ndim != 2:
-        raise ValueError("snps must be [num_snps x num_individuals]")
-    if a.dtype in (np.float32, np.float64):
-        return np.ascontiguousarray(a)
-    return np.ascontiguousarray(a, dtype=dtype)
+    return _lib.as_store_array(snps)
 
 
 def scale_k(k, verbose=False):

@@ -27,13 +27,9 @@ class phenotype_data(object):
 
     def get_incidence_matrix(self, pid):
         """:555-567 -- Z [n_values x n_unique_ecotypes] for replicated measurements."""
-        ets = self.phen_dict[pid]['ecotypes']
-        uniq = sorted(set(ets), key=ets.index)
-        col = {e: j for j, e in enumerate(uniq)}
-        Z = np.zeros((len(ets), len(uniq)), dtype=np.int8)
-        for i, e in enumerate(ets):
-            Z[i, col[e]] = 1
-        return Z
+        ets = [str(e) for e in self.phen_dict[pid]['ecotypes']]
+        uniq = [e for i, e in enumerate(ets) if i == 0 or ets[i - 1] != e]   # runs: "assumed to be sorted" (:561)
+        return (np.asarray(ets)[:, None] == np.asarray(uniq)[None, :]).astype(np.int8)
 
 
 def parse_phenotype_file(file_name=None, file_object=None, delim=',', file_format='guess', with_db_ids=True):

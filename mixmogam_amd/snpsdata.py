@@ -31,9 +31,13 @@ class SNPsDataSet(object):
         """:2221-2297 -- keep the accessions present in both (in this data set's order), drop SNPs that are
         no longer polymorphic, and filter the phenotype to the same accessions in the same order."""
         ets = [str(e) for e in phend.get_ecotypes(pid)]
-        pos = {e: i for i, e in reversed(list(enumerate(ets)))}
-        sd_keep = [i for i, a in enumerate(self.accessions) if a in pos]
-        pd_keep = [pos[self.accessions[i]] for i in sd_keep]
+        where = {}
+        for j, e in enumerate(ets):
+            where.setdefault(e, []).append(j)
+        sd_keep = [i for i, a in enumerate(self.accessions) if a in where]
+        # every matching phenotype entry, accession by accession in genotype order (:2236-2240): replicated
+        # measurements survive, so get_incidence_matrix / emmax(Z=...) see them
+        pd_keep = [j for i in sd_keep for j in where[self.accessions[i]]]
         self.snps = np.ascontiguousarray(self.snps[:, sd_keep])
         self.accessions = [self.accessions[i] for i in sd_keep]
         if coord_phen:

@@ -109,8 +109,23 @@ def _redll(delta, eig_vals, sq_etas):
     return p * np.sum(v2 / v1) / np.sum(v2) - np.sum(1.0 / v1)
 
 
-def get_estimates(y, X, K, eigL=None, eigR=None, ngrids=50, llim=-10, ulim=10, esp=1e-6):
-    """linear_models.py:771-912, method='REML', xs=None.
+def _ll(delta, eig_vals, eig_vals_L, sq_etas):
+    """linear_models.py:634-640."""
+    n = len(eig_vals_L)
+    c_1 = 0.5 * n * (np.log(n / (2.0 * np.pi)) - 1)
+    return c_1 - 0.5 * (n * np.log(np.sum(sq_etas / (eig_vals + delta))) + np.sum(np.log(eig_vals_L + delta)))
+
+
+def _dll(delta, eig_vals, eig_vals_L, sq_etas):
+    """linear_models.py:643-649."""
+    n = len(eig_vals_L)
+    v1 = eig_vals + delta
+    v2 = sq_etas / v1
+    return n * np.sum(v2 / v1) / np.sum(v2) - np.sum(1.0 / (eig_vals_L + delta))
+
+
+def get_estimates(y, X, K, eigL=None, eigR=None, ngrids=50, llim=-10, ulim=10, esp=1e-6, method='REML'):
+    """linear_models.py:771-912, xs=None; method 'REML' (:803-810) or 'ML' (:811-825).
 
     Returns dict(max_ll, delta, beta, ve, vg, rss, mahalanobis_rss, H_sqrt_inv,
     pseudo_heritability)."""
@@ -135,6 +150,12 @@ def get_estimates(y, X, K, eigL=None, eigR=None, ngrids=50, llim=-10, ulim=10, e
     s3 = np.sum(sq_etas[:, None] / (lambdas * lambdas), axis=0)
     s4 = np.sum(1 / lambdas, axis=0)
     dlls = 0.5 * (p * s3 / s1 - s4)                                                # :810
+    if method == 'ML':                                                             # :811-825
+        xis = eigL['values'][:, None] + deltas[None, :]
+        s2 = np.sum(np.log(xis), axis=0)
+        lls = 0.5 * (n * (np.log(n / (2.0 * np.pi)) - 1 - np.log(s1)) - s2)
+        s4 = np.sum(1 / xis, axis=0)
+        dlls = 0.5 * (n * s3 / s1 - s4)
     max_ll_i = int(np.argmax(lls))
     max_ll = lls[max_ll_i]
     zero_intervals = []
@@ -149,8 +170,12 @@ def get_estimates(y, X, K, eigL=None, eigR=None, ngrids=50, llim=-10, ulim=10, e
         try:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
-                new_opt_delta = optimize.newton(_redll, opt_delta, args=(eig_vals, sq_etas),
-                                                tol=esp, maxiter=100)              # :847
+                if method == 'REML':
+                    new_opt_delta = optimize.newton(_redll, opt_delta, args=(eig_vals, sq_etas),
+                                                    tol=esp, maxiter=100)          # :847
+                else:
+                    new_opt_delta = optimize.newton(_dll, opt_delta, args=(eig_vals, eigL['values'], sq_etas),
+                                                    tol=esp, maxiter=100)          # :849
         except Exception:
             new_opt_delta = opt_delta
         if opt_i > 1 and deltas[opt_i - 1] - esp < new_opt_delta < deltas[opt_i] + esp:
@@ -160,7 +185,8 @@ def get_estimates(y, X, K, eigL=None, eigR=None, ngrids=50, llim=-10, ulim=10, e
         elif opt_i == len(deltas) - 1 and new_opt_delta > deltas[opt_i - 1] - esp \
                 and not np.isinf(new_opt_delta):
             opt_delta = new_opt_delta
-        opt_ll = _rell(opt_delta, eig_vals, sq_etas)         # :882
+        opt_ll = _rell(opt_delta, eig_vals, sq_etas) if method == 'REML' \
+            else _ll(opt_delta, eig_vals, eigL['values'], sq_etas)                 # :880-884
         if opt_ll < max_ll:                                  # :886
             opt_delta = deltas[max_ll_i]
     else:
@@ -252,22 +278,38 @@ def scan_loop(snps, prep, dtype=np.float64):
             'h0_rss': h0, 'h0_betas': prep['h0_betas']}
 
 
-def emmax(snps, y, K, cofactors=None):
-    """linear_models.py:1790-1816 + :1233-1267 (emma_num=0, Z=None, with_betas=False):
-    scale_k again (:580), eig_L, eig_R, REML, scan."""
+def emmax(snps, y, K, cofactors=None, Z=None):
+    """linear_models.py:1790-1816 + :1233-1267 (emma_num=0, with_betas=False):
+    scale_k again (:580), eig_L, eig_R, REML, scan.  Z: incidence matrix of replicated measurements
+    [n_values x n_individuals] -- the random effect becomes Z K Z' (:1796), cofactors Z c (:1799), and the
+    SNPs are expanded through H Z (:1296-1297)."""
     y = np.asarray(y, dtype=np.float64)
     n = len(y)
     X = np.ones((n, 1))
+    if Z is not None:
+        Z = np.asarray(Z, dtype=np.float64)
+        K = Z @ np.asarray(K, dtype=np.float64) @ Z.T
     if cofactors is not None:
         for c in cofactors:
-            X = np.hstack([X, np.asarray(c, dtype=np.float64).reshape(n, 1)])
+            c = np.asarray(c, dtype=np.float64).reshape(-1)
+            X = np.hstack([X, (Z @ c if Z is not None else c).reshape(n, 1)])
     Ks = scale_k(K)
     est = get_estimates(y, X, Ks)
-    prep = scan_prepare(y, X, est['H_sqrt_inv'])
+    prep = scan_prepare(y, X, est['H_sqrt_inv'], Z=Z)
     res = scan_closed(snps, prep)
     for k in ('pseudo_heritability', 've', 'vg', 'max_ll', 'delta'):
         res[k] = est[k]
     return res
+
+
+def emmax_multi(snps, ys, K, cofactors=None):
+    """Several phenotypes over the same genotypes and kinship = the reference's loop of emmax() calls
+    (one LinearMixedModel, REML and scan per phenotype: phenotypeData.py:70-78, hdf5_data.py:262-330)."""
+    res = [emmax(snps, y, K, cofactors=cofactors) for y in np.asarray(ys, dtype=np.float64)]
+    out = {k: np.asarray([r[k] for r in res]) for k in ('ps', 'f_stats', 'rss', 'var_perc')}
+    for k in ('h0_rss', 'pseudo_heritability', 'max_ll', 'delta'):
+        out[k] = np.asarray([float(np.asarray(r[k]).reshape(-1)[0]) for r in res])
+    return out
 
 
 def linear_model(snps, y, cofactors=None):
@@ -303,7 +345,7 @@ def exact_emma(snps, y, X, K, eigL=None, ngrids=50, llim=-4, ulim=10, esp=1e-6):
     n = len(y)
     if eigL is None:
         eigL = eig_L(K)
-    out = {k: [] for k in ('ps', 'f_stats', 'rss', 'var_perc')}
+    out = {k: [] for k in ('ps', 'f_stats', 'rss', 'var_perc', 'vgs', 'ves', 'max_lls', 'betas')}
     for s in np.asarray(snps, dtype=np.float64):
         Xf = np.hstack([X, s.reshape(n, 1)])
         est = get_estimates(y, Xf, K, eigL=eigL, eigR=None, ngrids=ngrids, llim=llim, ulim=ulim, esp=esp)
@@ -318,6 +360,10 @@ def exact_emma(snps, y, X, K, eigL=None, ngrids=50, llim=-4, ulim=10, esp=1e-6):
         out['ps'].append(float(stats.f.sf(f, 1, p)))
         out['rss'].append(est['rss'])
         out['var_perc'].append(1.0 - est['mahalanobis_rss'] / h0_rss)
+        out['vgs'].append(est['vg'])                             # :955-963
+        out['ves'].append(est['ve'])
+        out['max_lls'].append(est['max_ll'])
+        out['betas'].append(np.asarray(est['beta']).reshape(-1))
     return {k: np.asarray(v) for k, v in out.items()}
 
 

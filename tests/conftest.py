@@ -28,3 +28,11 @@ CASE_NAMES = ["struct_n150_s0", "struct_n150_s1", "struct_n300_s2", "struct_n300
 @pytest.fixture(params=CASE_NAMES)
 def case(request):
     return load_case(request.param)
+
+
+def load_extras():
+    """tests/golden/extras_n150.npz: replicates (Z), emma(), get_ML and the multi-phenotype loop of the reference."""
+    d = dict(np.load(os.path.join(GOLDEN, "extras_n150.npz")))
+    n = int(d["n"])
+    d["snps"] = np.unpackbits(d["snps_packed"], axis=1)[:, :n].astype(np.int8)
+    return d

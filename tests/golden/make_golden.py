@@ -147,6 +147,67 @@ def run_case(mods, snps, y, cof, nperm, perm_seed):
     return out
 
 
+def run_extras(mods_by_mode):
+    """Extra known answers (kept in their own file so the five case files stay bit-identical): replicated
+    measurements through Z (linear_models.py:1796,1296-1297), exact EMMA per SNP (emma(), :1725-1745), get_ML
+    (:672-683) and a multi-phenotype run = the reference's loop of emmax() calls over phenotypes that share the
+    genotypes and the kinship (hdf5_data.py:262-330 / phenotypeData.py:70-78 shape), without and with a cofactor."""
+    rng = np.random.RandomState(11)
+    n, m = 150, 700
+    snps = structured_genotypes(rng, n, m)
+    data = {'snps_packed': np.packbits(snps.astype(np.uint8), axis=1), 'n': np.int64(n)}
+    # --- multi-phenotype: different heritabilities -> different delta per phenotype
+    h2s = [0.2, 0.5, 0.8, 0.35, 0.65, 0.9]
+    ys = np.asarray([phenotype(rng, snps, h2=h, ncausal=5 + 2 * i) for i, h in enumerate(h2s)])
+    cof = rng.randn(n) + 0.4 * snps[11]
+    data['multi_ys'] = ys
+    data['multi_cof'] = cof
+    # --- replicates: 190 measurements of 150 accessions, ecotypes consecutive (get_incidence_matrix assumes sorted)
+    reps = np.sort(np.concatenate([np.arange(n), rng.choice(n, 40, replace=False)]))
+    Z = (reps[:, None] == np.arange(n)[None, :]).astype(np.int8)
+    yz = Z @ ys[1] + 0.3 * rng.randn(len(reps))
+    data['z_Z'] = Z
+    data['z_y'] = yz
+    for mode, mods in mods_by_mode.items():
+        lm, kin = mods['linear_models'], mods['kinship']
+        snp_list = list(snps)
+        k_ibs = np.asarray(quiet(kin.calc_ibs_kinship, snp_list))
+        if mode == 'dbl':
+            data['ibs_scaled'] = k_ibs
+        for tag, cf in (('multi', None), ('multic', [cof])):
+            rows = {k: [] for k in ('ps', 'f_stats', 'rss', 'var_perc', 'h0_rss', 'pseudo_heritability', 'max_ll')}
+            for y in ys:
+                r = quiet(lm.emmax, snp_list, list(y), k_ibs, cofactors=cf)
+                for k in ('ps', 'f_stats', 'rss', 'var_perc'):
+                    rows[k].append(np.asarray(r[k], dtype=np.float64).reshape(-1))
+                rows['h0_rss'].append(float(np.asarray(r['h0_rss']).reshape(-1)[0]))
+                rows['pseudo_heritability'].append(float(r['pseudo_heritability']))
+                rows['max_ll'].append(float(r['max_ll']))
+            for k, v in rows.items():
+                data['%s_%s_%s' % (mode, tag, k)] = np.asarray(v)
+        rz = quiet(lm.emmax, snp_list, list(yz), k_ibs, Z=np.asmatrix(Z))
+        for k in ('ps', 'f_stats', 'rss', 'var_perc'):
+            data['%s_z_%s' % (mode, k)] = np.asarray(rz[k], dtype=np.float64).reshape(-1)
+        data['%s_z_h0_rss' % mode] = np.asarray(rz['h0_rss'], dtype=np.float64).reshape(-1)
+        data['%s_z_pseudo_heritability' % mode] = np.float64(rz['pseudo_heritability'])
+        re_ = quiet(lm.emma, [sn for sn in snps[:12]], list(ys[2]), k_ibs)
+        for k in ('ps', 'f_stats', 'vgs', 'ves', 'var_perc', 'max_lls', 'rss'):
+            data['%s_emma_%s' % (mode, k)] = np.asarray(re_[k], dtype=np.float64).reshape(-1)
+        data['%s_emma_betas' % mode] = np.asarray(re_['betas'], dtype=np.float64)
+        lmm = lm.LinearMixedModel(list(ys[2]))
+        lmm.add_random_effect(k_ibs)
+        ml = quiet(lmm.get_ML)
+        for k in ('max_ll', 'delta', 've', 'vg', 'pseudo_heritability'):
+            data['%s_ml_%s' % (mode, k)] = np.float64(ml[k])
+        data['%s_ml_beta' % mode] = np.asarray(ml['beta'], dtype=np.float64).reshape(-1)
+        rl = quiet(lmm.get_REML)
+        data['%s_reml100_delta' % mode] = np.float64(rl['delta'])
+        data['%s_reml100_max_ll' % mode] = np.float64(rl['max_ll'])
+    path = os.path.join(HERE, 'extras_n150.npz')
+    np.savez_compressed(path, **data)
+    print('extras_n150', snps.shape, '%.0f KB' % (os.path.getsize(path) / 1024.0))
+
+
 CASES = [
     # name, kind, N, M, seed, n_cofactors, nperm
     ('struct_n150_s0', 'struct', 150, 600, 0, 0, 20),
@@ -162,6 +223,10 @@ def main():
         print('reference not mounted; nothing to do')
         return
     mods = {'lit': refshim.load('literal'), 'dbl': refshim.load('double')}
+    if os.environ.get('MMG_GOLDEN_ONLY', '') in ('', 'extras'):
+        run_extras(mods)
+    if os.environ.get('MMG_GOLDEN_ONLY', '') == 'extras':
+        return
     for name, kind, n, m, seed, ncof, nperm in CASES:
         rng = np.random.RandomState(seed)
         snps = structured_genotypes(rng, n, m) if kind == 'struct' else bernoulli_genotypes(rng, n, m)

@@ -116,7 +116,9 @@ from mixmogam_amd import dist as mdist
 from oracle import emmax_oracle as orc
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-coll = mdist.TorchCollectives()
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from torch_coll import TorchCollectives
+coll = TorchCollectives()
 rng = np.random.RandomState(0)
 n, m = 60, 501
 snps = (rng.random_sample((m, n)) < rng.uniform(0.1, 0.9, size=(m, 1))).astype(np.int8)
