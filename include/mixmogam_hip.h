@@ -35,6 +35,7 @@ typedef struct mmg_ctx mmg_ctx;
 typedef struct mmg_geno mmg_geno;    /* device-resident padded genotype store */
 typedef struct mmg_comm mmg_comm;    /* RCCL communicator, one rank per process */
 typedef struct mmg_kin_acc mmg_kin_acc;  /* device-resident N x N kinship accumulator */
+typedef struct mmg_rot mmg_rot;      /* eigen-rotated genotype store (multi-phenotype scans) */
 
 /* ---- library / context -------------------------------------------------------------- */
 int mmg_version(void);
@@ -48,7 +49,8 @@ const char* mmg_last_error(mmg_ctx* ctx);    /* ctx may be NULL: last global err
 int mmg_device_info(mmg_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
 /* milliseconds the dominant kernel of the last call took, from hipEvents recorded on the
  * ctx stream around it.  which: 0 = kinship GEMM, 1 = scan quadratic-form GEMM,
- * 2 = scan finalize (per-SNP dot + F + p), 3 = permutation GEMM, 4 = eigh, 5 = transpose/pack */
+ * 2 = scan finalize (per-SNP dot + F + p), 3 = permutation GEMM, 4 = eigh, 5 = transpose/pack,
+ * 7 = eigen-rotation GEMM (mmg_rot_load), 8 = multi-phenotype passes (mmg_emmax_scan_multi, summed over batches) */
 int mmg_last_kernel_ms(mmg_ctx* ctx, int which, double* ms);
 
 /* Page-lock (unlock) a caller-owned host buffer so that result fetches into it run at full PCIe
@@ -73,6 +75,9 @@ int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, i
 int mmg_geno_upload_f32(mmg_ctx* ctx, mmg_geno* g, const float* snps, int64_t m0, int64_t rows);
 int mmg_geno_upload_f64(mmg_ctx* ctx, mmg_geno* g, const double* snps, int64_t m0, int64_t rows);
 int mmg_geno_download(mmg_ctx* ctx, mmg_geno* g, int8_t* snps, int64_t m0, int64_t rows);
+/* Gather cnt rows idx[0..cnt) (host int64, any order) into a host [cnt x N] buffer: the top-hit rows of the
+ * exact-EMMA refinement (linear_models.py:1365-1370) without moving the whole store over PCIe. */
+int mmg_geno_download_rows(mmg_ctx* ctx, mmg_geno* g, const int64_t* idx, int64_t cnt, int8_t* snps);
 /* Synthetic Bernoulli genotypes generated on the device (restates simulations.py:21-23 with a
  * counter-based hash so that any SNP range can be regenerated on any rank or on the CPU):
  * s[m][i] = hash64(seed, m_global0 + m, i) >> 48 < thr16 (thr16 = 32768 -> p = 0.5). */
@@ -168,6 +173,28 @@ int mmg_emmax_scan_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N,
 int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const double* Ys,
                    int32_t P, double h0_rss, int ndigits, double* min_rss);
 
+/* ---- multi-phenotype scans (replaces a LOOP of emmax() runs over phenotypes that share genotypes and kinship:
+ * phenotypeData.py:70-78, hdf5_data.py:262-330 once per phenotype file) ------------------------ */
+/* Every phenotype p has its own variance ratio delta_p, hence its own H_p = diag((lambda+delta_p)^-1/2) U' and its
+ * own N x N scan matrix; with the eigenvectors U of K shared, everything SNP-dependent is a function of the rotated
+ * SNP tau_m = U s_m (linear_models.py:898,1290-1303,1328 in the eigenbasis):
+ *     den = sum_i d_p[i] tau_mi^2 - sum_c (sum_i G_p[c][i] tau_mi)^2,   dot = sum_i omega_p[i] tau_mi,
+ *     rss = h0_rss_p - dot^2/den,  F = (h0_rss_p/rss - 1) df2,  p = f.sf(F, 1, df2)
+ * with d_p = w^2, G_p[c] = Q_p[:,c] * w, omega_p = r_p * w, w = (lambda+delta_p)^-1/2, Q_p an orthonormal basis of
+ * the transformed covariates and r_p the residual of the transformed phenotype (host glue: O(N q^2) per phenotype).
+ * mmg_rot_create: evecs_rows host [N x N], ROWS are eigenvectors (mmg_eigh_f64's layout); digits them once and
+ * allocates T for up to M_cap SNPs (8 N bytes per SNP, eigen-major fp64).
+ * mmg_rot_load: T = S U' for the SNPs of g (exact int8-MFMA digit GEMM); g may be destroyed afterwards.
+ * mmg_emmax_scan_multi: d, omega host [P x N]; G host [P x q x N]; h0_rss host [P]; 1 <= q <= 4; outputs host
+ * [P x M] (any may be NULL).  One HBM-bound pass over T per 8 phenotypes.
+ * mmg_rot_fetch: out host [N x rows] = T[:, m0:m0+rows] (tests / diagnostics). */
+int mmg_rot_create(mmg_ctx* ctx, int32_t N, const double* evecs_rows, int64_t M_cap, mmg_rot** r);
+int mmg_rot_destroy(mmg_ctx* ctx, mmg_rot* r);
+int mmg_rot_load(mmg_ctx* ctx, mmg_rot* r, mmg_geno* g);
+int mmg_rot_fetch(mmg_ctx* ctx, mmg_rot* r, int64_t m0, int64_t rows, double* out);
+int mmg_emmax_scan_multi(mmg_ctx* ctx, mmg_rot* r, int32_t P, int32_t q, const double* d, const double* omega,
+                         const double* G, const double* h0_rss, int32_t df2, double* rss, double* F, double* p);
+
 /* ---- p-values (replaces scipy.stats.f.sf at linear_models.py:1349,1172) ------------------- */
 /* Upper tail of F(1, df2) evaluated on the device for n values (host in/out). */
 int mmg_f_sf(mmg_ctx* ctx, const double* F, int64_t n, int32_t df2, double* p);
@@ -190,6 +217,20 @@ int mmg_comm_allgather_scan(mmg_ctx* ctx, mmg_comm* c, int64_t count,
  * mmg_scan_deliver_wait returns.  One delivery in flight per context: begin waits for the previous. */
 int mmg_scan_deliver_begin(mmg_ctx* ctx, mmg_comm* c, int64_t count, double* rss, double* F, double* p);
 int mmg_scan_deliver_wait(mmg_ctx* ctx);
+/* Sharded twins of the entry points above: this rank holds a block of the SNP axis; the partial
+ * results never leave HBM before the RCCL reduction over xGMI.  comm == NULL (or a 1-rank communicator) makes each
+ * identical to its single-GPU form.
+ *   mmg_kinship_ibs_i8_sharded  C_out = SUM over ranks of the exact int64 count matrices (all ranks get it)
+ *   mmg_kin_acc_allreduce       in-place SUM of the device-resident fp64 accumulator and of its SNP count
+ *   mmg_emmax_perm_sharded      min_rss over the SNPs of ALL ranks (RCCL MAX of the per-permutation statistic) */
+int mmg_kinship_ibs_i8_sharded(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int64_t* C_out);
+int mmg_kin_acc_allreduce(mmg_ctx* ctx, mmg_comm* comm, mmg_kin_acc* acc);
+int mmg_emmax_perm_sharded(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int32_t N, const double* Ht, const double* Ys,
+                           int32_t P, double h0_rss, int ndigits, double* min_rss);
+/* rank / world of the communicator and the rank count RCCL itself reports (ncclCommCount); any may be NULL */
+int mmg_comm_info(mmg_comm* c, int* rank, int* world, int* nccl_count);
+/* all-gather of equal-sized host blocks (count doubles per rank; recv: world*count, rank-major) */
+int mmg_comm_allgather_f64(mmg_ctx* ctx, mmg_comm* c, const double* send, int64_t count, double* recv);
 /* in-place all-reduce of host double buffers through device staging (SUM: partial kinship;
  * MIN: permutation minima).  op: 0 = sum, 1 = min, 2 = max. */
 int mmg_comm_allreduce_f64(mmg_ctx* ctx, mmg_comm* c, double* buf, int64_t count, int op);

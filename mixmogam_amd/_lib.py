@@ -44,6 +44,7 @@ PROTOTYPES = {
     "mmg_geno_upload_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64]),
     "mmg_geno_upload_f64": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64]),
     "mmg_geno_download": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64]),
+    "mmg_geno_download_rows": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp]),
     "mmg_geno_fill_hash": (C.c_int, [c_vp, c_vp, C.c_uint64, C.c_int64, C.c_uint32]),
     "mmg_geno_snp_stats": (C.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "mmg_geno_matvec": (C.c_int, [c_vp, c_vp, c_vp, C.c_int32, c_vp]),
@@ -68,6 +69,18 @@ PROTOTYPES = {
     "mmg_emmax_scan_i8": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp, c_vp, C.c_double, C.c_int32,
                                     c_vp, c_vp, c_vp]),
     "mmg_emmax_perm": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, C.c_int, c_vp]),
+    "mmg_rot_create": (C.c_int, [c_vp, C.c_int32, c_vp, C.c_int64, C.POINTER(c_vp)]),
+    "mmg_rot_destroy": (C.c_int, [c_vp, c_vp]),
+    "mmg_rot_load": (C.c_int, [c_vp, c_vp, c_vp]),
+    "mmg_rot_fetch": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int64, c_vp]),
+    "mmg_emmax_scan_multi": (C.c_int, [c_vp, c_vp, C.c_int32, C.c_int32, c_vp, c_vp, c_vp, c_vp, C.c_int32,
+                                       c_vp, c_vp, c_vp]),
+    "mmg_kinship_ibs_i8_sharded": (C.c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "mmg_kin_acc_allreduce": (C.c_int, [c_vp, c_vp, c_vp]),
+    "mmg_emmax_perm_sharded": (C.c_int, [c_vp, c_vp, c_vp, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, C.c_int,
+                                         c_vp]),
+    "mmg_comm_info": (C.c_int, [c_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "mmg_comm_allgather_f64": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp]),
     "mmg_f_sf": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp]),
     "mmg_comm_unique_id": (C.c_int, [c_vp]),
     "mmg_comm_create": (C.c_int, [c_vp, c_vp, C.c_int, C.c_int, C.POINTER(c_vp)]),
@@ -159,6 +172,13 @@ class Geno(object):
         self.ctx._check(self.ctx.lib.mmg_geno_download(self.ctx.h, self.h, _ptr(out), int(m0), int(rows)))
         return out
 
+    def download_rows(self, idx):
+        """Rows idx (any order, repeats allowed) gathered on the device: only len(idx) x N bytes cross PCIe."""
+        idx = _arr(np.asarray(idx).reshape(-1), np.int64)
+        out = np.empty((len(idx), self.N), dtype=np.int8)
+        self.ctx._check(self.ctx.lib.mmg_geno_download_rows(self.ctx.h, self.h, _ptr(idx), len(idx), _ptr(out)))
+        return out
+
     def fill_hash(self, seed, m_global0=0, thr16=32768):
         self.ctx._check(self.ctx.lib.mmg_geno_fill_hash(self.ctx.h, self.h, int(seed), int(m_global0), int(thr16)))
         return self
@@ -202,6 +222,10 @@ class KinshipAccumulator(object):
         sh = None if shift is None else _arr(shift, np.float32)
         self.ctx._check(self.ctx.lib.mmg_kin_acc_add(self.ctx.h, self.h, g.h, _ptr(sc), _ptr(sh)))
 
+    def allreduce(self, comm):
+        """Sum the device-resident accumulator (and its SNP count) over the ranks of `comm` in HBM."""
+        self.ctx._check(self.ctx.lib.mmg_kin_acc_allreduce(self.ctx.h, comm, self.h))
+
     def fetch(self):
         out = np.empty((self.N, self.N))
         n = C.c_int64(0)
@@ -220,10 +244,46 @@ class KinshipAccumulator(object):
             pass
 
 
+class Rot(object):
+    """Eigen-rotated genotype store T[i][m] = u_i . s_m in HBM (mmg_rot_*): the SNP-dependent input of every
+    EMMAX scan that shares the kinship's eigenvectors, whatever its delta / phenotype / covariates."""
+
+    def __init__(self, ctx, evecs_rows, M_cap):
+        V = _arr(evecs_rows, np.float64)
+        assert V.ndim == 2 and V.shape[0] == V.shape[1]
+        self.ctx, self.N, self.M_cap, self.M = ctx, V.shape[0], int(M_cap), 0
+        h = c_vp()
+        ctx._check(ctx.lib.mmg_rot_create(ctx.h, self.N, _ptr(V), self.M_cap, C.byref(h)))
+        self.h = h
+
+    def load(self, g):
+        self.ctx._check(self.ctx.lib.mmg_rot_load(self.ctx.h, self.h, g.h))
+        self.M = g.M
+        return self
+
+    def fetch(self, m0=0, rows=None):
+        rows = self.M - m0 if rows is None else rows
+        out = np.empty((self.N, rows))
+        self.ctx._check(self.ctx.lib.mmg_rot_fetch(self.ctx.h, self.h, int(m0), int(rows), _ptr(out)))
+        return out
+
+    def close(self):
+        if self.h is not None:
+            self.ctx.lib.mmg_rot_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context(object):
     """One HIP device context (stream, scan model, result buffers)."""
 
-    KERNEL_SLOTS = {"kinship": 0, "scan_quad": 1, "scan_finalize": 2, "perm": 3, "eigh": 4, "pack": 5}
+    KERNEL_SLOTS = {"kinship": 0, "scan_quad": 1, "scan_finalize": 2, "perm": 3, "eigh": 4, "pack": 5,
+                    "rotate": 7, "scan_multi": 8}
 
     def __init__(self, device=0):
         self.lib = load()
@@ -282,9 +342,10 @@ class Context(object):
         return Geno(self, M, N)
 
     # --- kinship
-    def kinship_ibs_counts(self, g):
+    def kinship_ibs_counts(self, g, comm=None):
+        """comm: RCCL communicator handle -- the counts then cover the SNP blocks of all ranks (summed in HBM)."""
         out = np.empty((g.N, g.N), dtype=np.int64)
-        self._check(self.lib.mmg_kinship_ibs_i8(self.h, g.h, _ptr(out)))
+        self._check(self.lib.mmg_kinship_ibs_i8_sharded(self.h, comm, g.h, _ptr(out)))
         return out
 
     def kinship_indicator_counts(self, g, thr):
@@ -342,6 +403,24 @@ class Context(object):
             out.update(dot=dot, den=den, sum=sm)
         return out
 
+    def rot(self, evecs_rows, M_cap):
+        return Rot(self, evecs_rows, M_cap)
+
+    def scan_multi(self, rot, d, omega, G, h0_rss, df2, want=("rss", "f_stats", "ps")):
+        """P phenotypes over the rotated store: d, omega [P x N], G [P x q x N], h0_rss [P] -> {'rss','f_stats','ps'}
+        each [P x M] (mmg_emmax_scan_multi)."""
+        d = _arr(d, np.float64)
+        omega = _arr(omega, np.float64)
+        G = _arr(G, np.float64)
+        h0 = _arr(np.asarray(h0_rss).reshape(-1), np.float64)
+        P, N = d.shape
+        assert omega.shape == (P, N) and G.ndim == 3 and G.shape[0] == P and G.shape[2] == N and len(h0) == P
+        q = G.shape[1]
+        outs = {k: (np.empty((P, rot.M)) if k in want else None) for k in ("rss", "f_stats", "ps")}
+        self._check(self.lib.mmg_emmax_scan_multi(self.h, rot.h, P, q, _ptr(d), _ptr(omega), _ptr(G), _ptr(h0), int(df2),
+                                                  _ptr(outs["rss"]), _ptr(outs["f_stats"]), _ptr(outs["ps"])))
+        return {k: v for k, v in outs.items() if v is not None}
+
     def scan_last_stats(self):
         """{'adaptive', 'n_refined', 'eps_max', 'fell_back'} of the last scan (adaptive digit schedule)."""
         a, n, e, r, f = C.c_int32(0), C.c_int64(0), C.c_double(0.0), C.c_double(0.0), C.c_int32(0)
@@ -364,13 +443,14 @@ class Context(object):
         self._check(self.lib.mmg_f_sf(self.h, _ptr(F), len(F), int(df2), _ptr(p)))
         return p
 
-    def perm(self, g, H, Ys, h0_rss, ndigits=0):
+    def perm(self, g, H, Ys, h0_rss, ndigits=0, comm=None):
+        """comm: RCCL communicator handle -- the minima then cover the SNP blocks of all ranks (reduced in HBM)."""
         H = _arr(H, np.float64)
         Ys = _arr(Ys, np.float64)
         P = Ys.shape[1]
         out = np.empty(P)
-        self._check(self.lib.mmg_emmax_perm(self.h, g.h, g.N, _ptr(H), _ptr(Ys), P, float(h0_rss), int(ndigits),
-                                            _ptr(out)))
+        self._check(self.lib.mmg_emmax_perm_sharded(self.h, comm, g.h, g.N, _ptr(H), _ptr(Ys), P, float(h0_rss),
+                                                    int(ndigits), _ptr(out)))
         return out
 
     def close(self):

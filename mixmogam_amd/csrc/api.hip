@@ -142,6 +142,7 @@ int mmg_last_kernel_ms(mmg_ctx* ctx, int which, double* ms) {
   MMG_HIP(ctx, hipEventSynchronize(ctx->ev[which][1]));
   MMG_HIP(ctx, hipEventElapsedTime(&f, ctx->ev[which][0], ctx->ev[which][1]));
   *ms = (double)f;
+  if (which == EV_MULTI && ctx->multi_ms_total > 0.0) *ms = ctx->multi_ms_total;   // all batches of the last call
   if (which == EV_QUAD && ctx->ev_set[EV_QUAD2]) {       // adaptive scan: the refinement pass counts too
     MMG_HIP(ctx, hipEventSynchronize(ctx->ev[EV_QUAD2][1]));
     MMG_HIP(ctx, hipEventElapsedTime(&f, ctx->ev[EV_QUAD2][0], ctx->ev[EV_QUAD2][1]));
@@ -282,6 +283,24 @@ int mmg_geno_download(mmg_ctx* ctx, mmg_geno* g, int8_t* snps, int64_t m0, int64
   return MMG_OK;
 }
 
+int mmg_geno_download_rows(mmg_ctx* ctx, mmg_geno* g, const int64_t* idx, int64_t cnt, int8_t* snps) {
+  Scratch sc;
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, g && idx && snps && cnt >= 0);
+  if (cnt == 0) return MMG_OK;
+  for (int64_t i = 0; i < cnt; ++i) MMG_CHECK_ARG(ctx, idx[i] >= 0 && idx[i] < g->M);
+  int64_t* didx = nullptr;
+  int8_t* dS = nullptr;
+  MMG_HIP(ctx, sc.alloc(&didx, cnt * sizeof(int64_t)));
+  MMG_HIP(ctx, sc.alloc(&dS, (size_t)cnt * g->Npad));
+  MMG_HIP(ctx, hipMemcpyAsync(didx, idx, cnt * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+  launch_gather_rows(ctx, g, didx, cnt, dS);
+  MMG_HIP(ctx, hipGetLastError());
+  MMG_HIP(ctx, hipMemcpy2DAsync(snps, g->N, dS, g->Npad, g->N, cnt, hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MMG_OK;
+}
+
 int mmg_geno_fill_hash(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_global0, uint32_t thr16) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g != nullptr && thr16 <= 65536);
@@ -322,10 +341,15 @@ static int64_t kin_chunk() {
   return std::min<int64_t>(ch, MAX_LD / 128 * 128);
 }
 
-static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int thr, int64_t* C_out);
+static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int thr, int64_t* C_out,
+                             mmg_comm* comm = nullptr);
 
 int mmg_kinship_ibs_i8(mmg_ctx* ctx, mmg_geno* g, int64_t* C_out) {
   return kinship_counts_i8(ctx, g, 2, -1, 0, C_out);    // X = 2S - 1 (kinship.py:43)
+}
+
+int mmg_kinship_ibs_i8_sharded(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int64_t* C_out) {
+  return kinship_counts_i8(ctx, g, 2, -1, 0, C_out, comm);
 }
 
 int mmg_kinship_indicator_i8(mmg_ctx* ctx, mmg_geno* g, int32_t thr, int64_t* C_out) {
@@ -334,7 +358,7 @@ int mmg_kinship_indicator_i8(mmg_ctx* ctx, mmg_geno* g, int32_t thr, int64_t* C_
   return kinship_counts_i8(ctx, g, 0, 0, thr, C_out);   // X = [S >= thr]
 }
 
-static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int thr, int64_t* C_out) {
+static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int thr, int64_t* C_out, mmg_comm* comm) {
   Scratch sc;
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g && C_out && g->M > 0);
@@ -368,6 +392,11 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
   (void)kin_ms; (void)pack_ms;
   if (rc == MMG_OK) {
     launch_mirror_i32_to_i64(ctx, C32, g->Npad, g->N, C64);
+    if (comm && comm->world > 1) {
+      // the partial counts of this rank's SNP block never leave HBM: one in-place RCCL SUM over xGMI, one download
+      ncclResult_t r = ncclAllReduce(C64, C64, (size_t)g->N * g->N, ncclInt64, ncclSum, comm->comm, ctx->stream);
+      if (r != ncclSuccess) return set_err(ctx, MMG_E_LIB, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    }
     hipError_t e2 = hipMemcpyAsync(C_out, C64, (size_t)g->N * g->N * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
     if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
     if (e2 != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e2));
@@ -466,6 +495,25 @@ int mmg_kin_acc_fetch(mmg_ctx* ctx, mmg_kin_acc* a, double* C_out, int64_t* n_sn
   MMG_HIP(ctx, hipMemcpyAsync(C_out, a->dC, (size_t)a->N * a->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (n_snps) *n_snps = a->n_snps;
+  return MMG_OK;
+}
+
+int mmg_kin_acc_allreduce(mmg_ctx* ctx, mmg_comm* comm, mmg_kin_acc* a) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, a != nullptr);
+  if (!comm || comm->world <= 1) return MMG_OK;
+  Scratch sc;
+  long long* dn = nullptr;
+  MMG_HIP(ctx, sc.alloc(&dn, sizeof(long long)));
+  long long n = (long long)a->n_snps;
+  MMG_HIP(ctx, hipMemcpyAsync(dn, &n, sizeof(n), hipMemcpyHostToDevice, ctx->stream));
+  MMG_NCCL(ctx, ncclGroupStart());
+  MMG_NCCL(ctx, ncclAllReduce(a->dC, a->dC, (size_t)a->N * a->N, ncclDouble, ncclSum, comm->comm, ctx->stream));
+  MMG_NCCL(ctx, ncclAllReduce(dn, dn, 1, ncclInt64, ncclSum, comm->comm, ctx->stream));
+  MMG_NCCL(ctx, ncclGroupEnd());
+  MMG_HIP(ctx, hipMemcpyAsync(&n, dn, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  a->n_snps = (int64_t)n;
   return MMG_OK;
 }
 
@@ -968,6 +1016,11 @@ static int dgemm_dev(mmg_ctx* ctx, int ta, int tb, int M, int N, int K, const do
 
 int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const double* Ys, int32_t P, double h0_rss,
                    int ndigits, double* min_rss) {
+  return mmg_emmax_perm_sharded(ctx, nullptr, g, N, Ht, Ys, P, h0_rss, ndigits, min_rss);
+}
+
+int mmg_emmax_perm_sharded(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int32_t N, const double* Ht, const double* Ys,
+                           int32_t P, double h0_rss, int ndigits, double* min_rss) {
   Scratch sc;
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g && Ht && Ys && min_rss && P > 0 && N == g->N);
@@ -975,7 +1028,8 @@ int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const
   std::vector<double> yy((size_t)P, 0.0);
   for (int i = 0; i < N; ++i)
     for (int p = 0; p < P; ++p) yy[p] += Ys[(size_t)i * P + p] * Ys[(size_t)i * P + p];
-  if (g->M == 0) {
+  const bool reduce = comm && comm->world > 1;
+  if (g->M == 0 && !reduce) {
     for (int p = 0; p < P; ++p) min_rss[p] = h0_rss;
     return MMG_OK;
   }
@@ -1006,9 +1060,13 @@ int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const
   }
   mmg_scan_model pm;
   mmg_scan_result pr;
-  if (rc == MMG_OK) rc = model_from_device(ctx, pm, N, dA, dv, 4);
-  if (rc == MMG_OK) rc = ensure_result(ctx, pr, g->Mpad);
-  if (rc == MMG_OK) {
+  if (g->M == 0) {                                        // a rank without SNPs still joins the reduction
+    hipError_t e0 = hipMemsetAsync(dmax, 0, Ppad * sizeof(double), ctx->stream);
+    if (e0 != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e0));
+  }
+  if (rc == MMG_OK && g->M > 0) rc = model_from_device(ctx, pm, N, dA, dv, 4);
+  if (rc == MMG_OK && g->M > 0) rc = ensure_result(ctx, pr, g->Mpad);
+  if (rc == MMG_OK && g->M > 0) {
     double c0 = 0.0;
     for (int i = 0; i < N; ++i) c0 += v[i];
     hipMemsetAsync(pr.q, 0, g->Mpad * sizeof(unsigned long long), ctx->stream);
@@ -1016,6 +1074,11 @@ int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const
     launch_scan_finalize(ctx, g, pm, pr, 1.0, 1, 0.0);              // den = s'A's, dot = s.v, sum = s.1
     launch_perm_center(ctx, g, pr, c0, dmu, dinv);                  // mu, 1/(s~'A's~)   (:1159)
     rc = run_perm(ctx, g, N, dWt, P, dinv, dmu, 4, dmax);
+  }
+  if (rc == MMG_OK && reduce) {
+    // per-permutation maxima of this rank's SNP block stay in HBM: RCCL MAX over xGMI (exact, order independent)
+    ncclResult_t r = ncclAllReduce(dmax, dmax, (size_t)Ppad, ncclDouble, ncclMax, comm->comm, ctx->stream);
+    if (r != ncclSuccess) rc = set_err(ctx, MMG_E_LIB, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
   }
   std::vector<double> mx((size_t)Ppad, 0.0);
   if (rc == MMG_OK) {
@@ -1028,6 +1091,131 @@ int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const
   hipStreamSynchronize(ctx->stream);
   free_model(pm); free_result(pr);
   return rc;
+}
+
+
+// ------------------------------------------------------------------------- eigen-rotated store, multi-phenotype scan
+struct mmg_rot {
+  int32_t N = 0, Npad = 0, nVT = 0;
+  int64_t Mcap = 0;              // SNP capacity (multiple of 256) = leading dimension of T
+  int64_t M = 0;                 // SNPs currently loaded
+  int8_t* Vq = nullptr;          // [nVT][256][Npad] digits of the eigenvectors (operand layout of k_perm.hip)
+  double* dstep = nullptr;       // [nVT*64] per-eigenvector step
+  double* T = nullptr;           // [nVT*64][Mcap] fp64, eigen-major: T[i][m] = u_i . s_m
+};
+
+int mmg_rot_create(mmg_ctx* ctx, int32_t N, const double* evecs_rows, int64_t M_cap, mmg_rot** out) {
+  Scratch sc;
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, out && evecs_rows && N > 0 && M_cap > 0);
+  *out = nullptr;
+  mmg_rot* r = new mmg_rot();
+  r->N = N; r->Npad = (int32_t)round_up(N, 256); r->nVT = (N + 63) / 64;
+  r->Mcap = round_up(M_cap, 256);
+  double *dV = nullptr, *dcsum = nullptr;
+  hipError_t e = hipMalloc(&r->T, (size_t)r->nVT * 64 * r->Mcap * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&r->Vq, (size_t)r->nVT * TM * r->Npad);
+  if (e == hipSuccess) e = hipMalloc(&r->dstep, (size_t)r->nVT * 64 * sizeof(double));
+  if (e == hipSuccess) e = sc.alloc(&dV, (size_t)N * N * sizeof(double));
+  if (e == hipSuccess) e = sc.alloc(&dcsum, (size_t)r->nVT * 64 * sizeof(double));
+  if (e != hipSuccess) {
+    hipFree(r->T); hipFree(r->Vq); hipFree(r->dstep); delete r;
+    return set_err(ctx, MMG_E_NOMEM, std::string("hipMalloc rotated store: ") + hipGetErrorString(e));
+  }
+  int rc = MMG_OK;
+  e = hipMemcpyAsync(dV, evecs_rows, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e));
+  if (rc == MMG_OK) rc = quantize_rows_4digits(ctx, dV, N, r->Npad, N, r->Vq, r->dstep, dcsum);
+  if (rc == MMG_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_err(ctx, MMG_E_HIP, "rotated store setup");
+  if (rc) { hipFree(r->T); hipFree(r->Vq); hipFree(r->dstep); delete r; return rc; }
+  *out = r;
+  return MMG_OK;
+}
+
+int mmg_rot_destroy(mmg_ctx* ctx, mmg_rot* r) {
+  if (!r) return MMG_OK;
+  if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
+  hipFree(r->T); hipFree(r->Vq); hipFree(r->dstep);
+  delete r;
+  return MMG_OK;
+}
+
+int mmg_rot_load(mmg_ctx* ctx, mmg_rot* r, mmg_geno* g) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, r && g && g->N == r->N && g->Mpad <= r->Mcap);
+  // |sum_k digit * s| <= 128 * smax * Npad must fit the int32 accumulators of the digit GEMM
+  MMG_CHECK_ARG(ctx, (int64_t)128 * std::max(g->smax, 1) * r->Npad < ((int64_t)1 << 31));
+  r->M = g->M;
+  if (g->M == 0) return MMG_OK;
+  int rc = run_rotate(ctx, g, r->Vq, r->dstep, r->nVT, r->T, r->Mcap);
+  if (rc) return rc;
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MMG_OK;
+}
+
+int mmg_rot_fetch(mmg_ctx* ctx, mmg_rot* r, int64_t m0, int64_t rows, double* out) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, r && out && m0 >= 0 && rows >= 0 && m0 + rows <= r->M);
+  if (rows == 0) return MMG_OK;
+  // out[i][k] = T[i][m0 + k], i < N: a strided 2-D copy of the eigen-major store
+  MMG_HIP(ctx, hipMemcpy2DAsync(out, rows * sizeof(double), r->T + m0, r->Mcap * sizeof(double), rows * sizeof(double),
+                                r->N, hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MMG_OK;
+}
+
+int mmg_emmax_scan_multi(mmg_ctx* ctx, mmg_rot* r, int32_t P, int32_t q, const double* d, const double* omega,
+                         const double* G, const double* h0_rss, int32_t df2, double* rss, double* F, double* p) {
+  Scratch sc;
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, r && d && omega && G && h0_rss && P > 0 && q >= 1 && q <= 4 && df2 > 0);
+  const int64_t M = r->M;
+  if (M == 0) return MMG_OK;
+  const int N = r->N;
+  ctx->multi_ms_total = 0.0;
+  const int64_t ldOut = round_up(M, 256);
+  const int PBmax = 8, NCmax = PBmax * (2 + q);
+  double *dcoef = nullptr, *dh0 = nullptr, *dout[3] = {nullptr, nullptr, nullptr};
+  double* host[3] = {rss, F, p};
+  MMG_HIP(ctx, sc.alloc(&dcoef, (size_t)N * NCmax * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dh0, PBmax * sizeof(double)));
+  for (int k = 0; k < 3; ++k)
+    if (host[k]) MMG_HIP(ctx, sc.alloc(&dout[k], (size_t)PBmax * ldOut * sizeof(double)));
+  std::vector<double> coef((size_t)N * NCmax), h0b(PBmax);
+  const double lnb = ln_beta_half(0.5 * df2);
+  double ms_total = 0.0;
+  for (int p0 = 0; p0 < P; p0 += PBmax) {
+    const int nb = std::min(PBmax, P - p0);
+    int PB = 1;
+    while (PB < nb) PB *= 2;                         // 1, 2, 4, 8: unused columns carry zero coefficients
+    const int NC = PB * (2 + q);
+    std::fill(coef.begin(), coef.begin() + (size_t)N * NC, 0.0);
+    for (int k = 0; k < PB; ++k) h0b[k] = k < nb ? h0_rss[p0 + k] : 1.0;
+    for (int k = 0; k < nb; ++k) {
+      const double* dk = d + (size_t)(p0 + k) * N;
+      const double* wk = omega + (size_t)(p0 + k) * N;
+      const double* gk = G + (size_t)(p0 + k) * q * N;
+      for (int i = 0; i < N; ++i) {
+        double* row = coef.data() + (size_t)i * NC;
+        row[k] = dk[i];
+        row[PB + k * (1 + q)] = wk[i];
+        for (int c = 0; c < q; ++c) row[PB + k * (1 + q) + 1 + c] = gk[(size_t)c * N + i];
+      }
+    }
+    MMG_HIP(ctx, hipMemcpyAsync(dcoef, coef.data(), (size_t)N * NC * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MMG_HIP(ctx, hipMemcpyAsync(dh0, h0b.data(), PB * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    int rc = run_scan_multi(ctx, r->T, r->Mcap, N, M, PB, q, dcoef, dh0, df2, lnb, dout[0], dout[1], dout[2], ldOut);
+    if (rc) return rc;
+    for (int k = 0; k < 3; ++k)
+      if (host[k])
+        MMG_HIP(ctx, hipMemcpy2DAsync(host[k] + (size_t)p0 * M, M * sizeof(double), dout[k], ldOut * sizeof(double),
+                                      M * sizeof(double), nb, hipMemcpyDeviceToHost, ctx->stream));
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));  // coef / h0b are reused by the next batch
+    double ms = 0.0;
+    if (mmg_last_kernel_ms(ctx, EV_MULTI, &ms) == MMG_OK) ms_total += ms;
+  }
+  ctx->multi_ms_total = ms_total;
+  return MMG_OK;
 }
 
 // ------------------------------------------------------------------------- RCCL
@@ -1138,6 +1326,34 @@ static int allreduce_host(mmg_ctx* ctx, mmg_comm* c, T* buf, int64_t count, int 
 }
 
 }  // extern C++
+int mmg_comm_info(mmg_comm* c, int* rank, int* world, int* nccl_count) {
+  if (!c) return MMG_E_ARG;
+  if (rank) *rank = c->rank;
+  if (world) *world = c->world;
+  if (nccl_count) {
+    int n = 0;
+    ncclResult_t r = ncclCommCount(c->comm, &n);
+    if (r != ncclSuccess) return set_err(nullptr, MMG_E_LIB, std::string("ncclCommCount: ") + ncclGetErrorString(r));
+    *nccl_count = n;
+  }
+  return MMG_OK;
+}
+
+int mmg_comm_allgather_f64(mmg_ctx* ctx, mmg_comm* c, const double* send, int64_t count, double* recv) {
+  Scratch sc;
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, c && send && recv && count >= 0);
+  if (count == 0) return MMG_OK;
+  double *ds = nullptr, *dr = nullptr;
+  MMG_HIP(ctx, sc.alloc(&ds, count * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dr, (size_t)c->world * count * sizeof(double)));
+  MMG_HIP(ctx, hipMemcpyAsync(ds, send, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  MMG_NCCL(ctx, ncclAllGather(ds, dr, (size_t)count, ncclDouble, c->comm, ctx->stream));
+  MMG_HIP(ctx, hipMemcpyAsync(recv, dr, (size_t)c->world * count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MMG_OK;
+}
+
 int mmg_comm_allreduce_f64(mmg_ctx* ctx, mmg_comm* c, double* buf, int64_t count, int op) {
   return allreduce_host<double>(ctx, c, buf, count, op, ncclDouble);
 }

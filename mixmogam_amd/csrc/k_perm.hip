@@ -154,6 +154,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void perm_gemm_kernel(
   }
 }
 
+// Rows of Wt [P x N] (device fp64) -> four balanced base-256 digits per row with a per-row step, in the operand
+// layout of the 256-row P tile (64 rows x 4 digits per tile; see perm_quantize_kernel).  Wq: [ceil(P/64)][256][Npad],
+// dstep / dcsum: [ceil(P/64)*64] (zero beyond P).  Shared with the eigen-rotation GEMM (k_rot.hip).
+int quantize_rows_4digits(mmg_ctx* ctx, const double* dWt, int32_t N, int32_t Npad, int32_t P, int8_t* Wq, double* dstep,
+                          double* dcsum) {
+  const int nPT = (P + PERM_TILE - 1) / PERM_TILE;
+  const int Ppad = nPT * PERM_TILE;
+  MMG_HIP(ctx, hipMemsetAsync(dstep, 0, Ppad * sizeof(double), ctx->stream));
+  MMG_HIP(ctx, hipMemsetAsync(dcsum, 0, Ppad * sizeof(double), ctx->stream));
+  hipLaunchKernelGGL(perm_rowstat_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, ctx->stream, dWt, N, P, dstep,
+                     dcsum);
+  const int64_t total = (int64_t)Ppad * (Npad >> 4);
+  hipLaunchKernelGGL(perm_quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dWt, N,
+                     Npad, P, dstep, Wq);
+  MMG_HIP(ctx, hipGetLastError());
+  return MMG_OK;
+}
+
 int run_perm(mmg_ctx* ctx, const mmg_geno* g, int32_t N, const double* dWt, int32_t P, const double* d_inv,
              const double* d_mu, int ndigits, double* d_maxstat) {
   (void)ndigits;
@@ -161,22 +179,15 @@ int run_perm(mmg_ctx* ctx, const mmg_geno* g, int32_t N, const double* dWt, int3
   const int nPT = (P + PERM_TILE - 1) / PERM_TILE;
   const int Ppad = nPT * PERM_TILE;
   const int nSb = (int)(g->Mpad / TN);
+  Scratch sc;
   double *dstep = nullptr, *dcsum = nullptr;
   int8_t* Wq = nullptr;
-  MMG_HIP(ctx, hipMalloc(&dstep, Ppad * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&dcsum, Ppad * sizeof(double)));
-  MMG_HIP(ctx, hipMalloc(&Wq, (size_t)nPT * TM * Npad));
-  MMG_HIP(ctx, hipMemsetAsync(dstep, 0, Ppad * sizeof(double), ctx->stream));
-  MMG_HIP(ctx, hipMemsetAsync(dcsum, 0, Ppad * sizeof(double), ctx->stream));
+  MMG_HIP(ctx, sc.alloc(&dstep, Ppad * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dcsum, Ppad * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&Wq, (size_t)nPT * TM * Npad));
   MMG_HIP(ctx, hipMemsetAsync(d_maxstat, 0, Ppad * sizeof(double), ctx->stream));
-  hipLaunchKernelGGL(perm_rowstat_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, ctx->stream, dWt, N, P, dstep,
-                     dcsum);
-  {
-    const int64_t total = (int64_t)Ppad * (Npad >> 4);
-    hipLaunchKernelGGL(perm_quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dWt, N,
-                       Npad, P, dstep, Wq);
-  }
-  MMG_HIP(ctx, hipGetLastError());
+  int rcq = quantize_rows_4digits(ctx, dWt, N, Npad, P, Wq, dstep, dcsum);
+  if (rcq) return rcq;
   // grid: permutation tiles x SNP-block chunks, ~4 workgroups per CU in flight over the launch
   const int rounds = (nPT + 7) / 8;
   int nch = std::max(1, (4 * 256) / (8 * rounds));
@@ -193,7 +204,6 @@ int run_perm(mmg_ctx* ctx, const mmg_geno* g, int32_t N, const double* dWt, int3
   }
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  hipFree(dstep); hipFree(dcsum); hipFree(Wq);
   return MMG_OK;
 }
 

@@ -19,7 +19,7 @@ struct mmg_geno {
   int* d_smax = nullptr;
 };
 
-enum { EV_KIN = 0, EV_QUAD = 1, EV_FIN = 2, EV_PERM = 3, EV_EIGH = 4, EV_PACK = 5, EV_QUAD2 = 6, EV_COUNT = 7 };
+enum { EV_KIN = 0, EV_QUAD = 1, EV_FIN = 2, EV_PERM = 3, EV_EIGH = 4, EV_PACK = 5, EV_QUAD2 = 6, EV_ROT = 7, EV_MULTI = 8, EV_COUNT = 9 };
 
 struct mmg_scan_model {
   int32_t N = 0, Npad = 0, D = 0;
@@ -75,6 +75,7 @@ struct mmg_ctx {
   double* dstage = nullptr;
   size_t dstage_elems = 0;
   bool deliver_pending = false;
+  double multi_ms_total = 0.0;  // summed pass time of the last mmg_emmax_scan_multi
 };
 
 namespace mmg {
@@ -164,5 +165,16 @@ void launch_perm_center(mmg_ctx*, const mmg_geno*, const mmg_scan_result&, doubl
 // d_maxstat[p] = max_m (s~_m . W_p)^2 * inv[m];  dWt: device [P x N] row-major fp64
 int run_perm(mmg_ctx*, const mmg_geno*, int32_t N, const double* dWt, int32_t P, const double* d_inv,
              const double* d_mu, int ndigits, double* d_maxstat);
+
+int quantize_rows_4digits(mmg_ctx*, const double* dWt, int32_t N, int32_t Npad, int32_t P, int8_t* Wq, double* dstep,
+                          double* dcsum);
+
+// ---- k_rot.hip: eigen-rotated genotype store + multi-phenotype scan
+// T [nVT*64 x ldT] (fp64, eigen-major): T[i][m] = u_i . s_m for the SNPs of g (exact int8 digit GEMM)
+int run_rotate(mmg_ctx*, const mmg_geno* g, const int8_t* Vq, const double* dstep, int nVT, double* T, int64_t ldT);
+// one pass over T for PB <= 8 phenotypes with q <= 4 fixed-effect columns each; coef: device [N][PB*(2+q)]
+int run_scan_multi(mmg_ctx*, const double* T, int64_t ldT, int32_t N, int64_t M, int PB, int q, const double* coef,
+                   const double* h0 /*device [PB]*/, int32_t df2, double lnbeta, double* rss, double* F, double* p,
+                   int64_t ldOut);
 
 }  // namespace mmg

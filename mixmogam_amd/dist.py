@@ -18,42 +18,65 @@ def shard_range(total, rank, world):
     return m0, m0 + base + (1 if rank < rem else 0)
 
 
-def file_bootstrap(rank, world, timeout_s=120.0):
-    """Single-node bootstrap of rank 0's 128-byte ncclUniqueId through a file in /tmp, keyed by
-    the launcher's MASTER_PORT / run id (torchrun exports them).  Returns a `bcast(raw)`
-    callable for RcclCollectives.  No torch in the GPU process: the HIP library links the
-    system ROCm runtime, and importing torch's bundled runtime beside it is not safe."""
+def file_bootstrap(rank, world, timeout_s=None):
+    """Single-node bootstrap of rank 0's 128-byte ncclUniqueId through a file, keyed by the launcher's
+    MASTER_PORT / run id (torchrun exports them).  Returns a `bcast(raw)` callable for RcclCollectives.
+    No torch in the GPU process: the HIP library links the system ROCm runtime, and importing torch's bundled
+    runtime beside it is not safe.
+
+    The file lives in a per-user directory (mode 0700), is created with O_EXCL and mode 0600 after rank 0 has
+    removed whatever a crashed earlier launch left under the same key, and is removed again by rank 0 once the
+    communicator exists (RcclCollectives calls bcast.done()), so a relaunch on the same port never reads a stale
+    id.  Ranks > 0 give up after MMG_RDZV_TIMEOUT seconds (default 120) -- e.g. when rank 0 died before writing --
+    instead of entering ncclCommInitRank with nothing to meet."""
     import os
     import time
-    key = "%s_%s_%s_%d" % (os.environ.get("MASTER_ADDR", "local"), os.environ.get("MASTER_PORT", "0"),
-                           os.environ.get("TORCHELASTIC_RUN_ID", "none"), world)
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("MMG_RDZV_TIMEOUT", "120"))
+    key = "%s_%s_%s_%s_%d" % (os.environ.get("MASTER_ADDR", "local"), os.environ.get("MASTER_PORT", "0"),
+                              os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("MMG_RUN_ID", "none"), world)
     if "TORCHELASTIC_RUN_ID" in os.environ:
         # the ranks of one torch.distributed.run launch are children of the same agent process: its pid
-        # separates back-to-back launches that reuse a port (a stale file of a crashed run is never read)
+        # separates back-to-back launches that reuse a port
         key += "_%d" % os.getppid()
-    path = os.path.join("/tmp", "mmg_rdzv_" + "".join(c if c.isalnum() else "_" for c in key) + ".bin")
+    rdir = os.path.join(os.environ.get("MMG_RDZV_DIR", "/tmp"), "mmg_rdzv_%d" % os.getuid())
+    os.makedirs(rdir, mode=0o700, exist_ok=True)
+    path = os.path.join(rdir, "".join(c if c.isalnum() else "_" for c in key) + ".bin")
     t_start = time.time()
 
     def bcast(raw):
         if rank == 0:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
             tmp = path + ".%d" % os.getpid()
-            with open(tmp, "wb") as f:
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+            with os.fdopen(fd, "wb") as f:
                 f.write(raw)
             os.replace(tmp, path)
             return raw
         while True:
             try:
                 st = os.stat(path)
-                if st.st_size == 128 and st.st_mtime > t_start - 30.0:
+                if st.st_size == 128 and st.st_uid == os.getuid() and st.st_mtime > t_start - 30.0:
                     with open(path, "rb") as f:
                         return f.read()
             except OSError:
                 pass
             if time.time() - t_start > timeout_s:
-                raise RuntimeError("timed out waiting for rank 0's RCCL id at %s" % path)
+                raise RuntimeError("timed out after %.0f s waiting for rank 0's RCCL id at %s" % (timeout_s, path))
             time.sleep(0.05)
 
+    def done():
+        if rank == 0:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+
     bcast.path = path
+    bcast.done = done
     return bcast
 
 
@@ -72,6 +95,24 @@ class RcclCollectives(object):
         h = C.c_void_p()
         ctx._check(ctx.lib.mmg_comm_create(ctx.h, uid, rank, world, C.byref(h)))
         self.h = h
+        if hasattr(bootstrap_bcast, "done"):
+            self.barrier()                      # every rank holds the id (it is inside its communicator) ...
+            bootstrap_bcast.done()              # ... so rank 0 may remove the rendezvous file
+
+    def info(self):
+        """(rank, world, ncclCommCount) as RCCL reports them."""
+        import ctypes as C
+        r, w, n = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        self.ctx._check(self.ctx.lib.mmg_comm_info(self.h, C.byref(r), C.byref(w), C.byref(n)))
+        return r.value, w.value, n.value
+
+    def allgather(self, arr):
+        """Equal-sized host blocks -> [world * len] (rank-major), staged through HBM and RCCL."""
+        from . import _lib
+        a = np.ascontiguousarray(arr, dtype=np.float64).reshape(-1)
+        out = np.empty(self.world * a.size)
+        self.ctx._check(self.ctx.lib.mmg_comm_allgather_f64(self.ctx.h, self.h, _lib._ptr(a), a.size, _lib._ptr(out)))
+        return out
 
     def allreduce(self, arr, op="sum"):
         from . import _lib

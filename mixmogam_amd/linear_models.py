@@ -270,8 +270,10 @@ class LinearMixedModel(object):
 
     def get_estimates(self, eig_L, K=None, xs=None, ngrids=50, llim=-10, ulim=10, esp=1e-6,
                       return_pvalue=False, return_f_stat=False, method='REML', verbose=False,
-                      dtype='double', eig_R=None, rss_0=None, return_H=True, _rot=None):
-        """:771-927 -- EMMA variance-component estimates (Kang et al. 2008)."""
+                      dtype='double', eig_R=None, rss_0=None, return_H=True, _rot=None, use_eig_R=False):
+        """:771-927 -- EMMA variance-component estimates (Kang et al. 2008).
+        use_eig_R: take the likelihood sums from the caller's eig_R even when xs is None (the reference's `:787`
+        test would recompute it there); used by callers that already hold eig_R and by the route-comparison tests."""
         if xs is not None:
             xs = np.asarray(xs, dtype=np.float64).reshape(self.n, -1)
             X = np.hstack([self.X, xs])
@@ -292,7 +294,7 @@ class LinearMixedModel(object):
         # with H = K + delta I and P = H^-1 - H^-1 X (X'H^-1 X)^-1 X'H^-1, i.e. O(N q^2) per delta from eig_L alone
         # (_SpectralSums).  Where the reference would compute eig_R itself (:787) the second eigh is skipped;
         # a caller-supplied eig_R that the reference would use (xs given) is used as is.
-        if eig_R and xs is not None:
+        if eig_R and (xs is not None or use_eig_R):
             sums = _SpectralSumsR(eig_R, y, p)
         elif K is not None or not REML_SUMS_FROM_EIG_L:
             sums = _SpectralSumsR(self._get_eigen_R_(X=X, K=K), y, p)   # :787 (quirk kept)
@@ -455,17 +457,8 @@ class LinearMixedModel(object):
         return r
 
     def _get_estimates_with(self, eig_L, eig_R, method, ngrids=50):
-        """get_estimates on a PRECOMPUTED eig_R (the reference's own route, :787-799): its
-        `not (eig_R and xs != None)` would recompute eig_R when xs is None, so the given one is passed through a
-        tiny shim; used where a caller already holds eig_R and by the tests that compare the two routes."""
-        global REML_SUMS_FROM_EIG_L
-        saved, saved_flag = self._get_eigen_R_, REML_SUMS_FROM_EIG_L
-        try:
-            REML_SUMS_FROM_EIG_L = False
-            self._get_eigen_R_ = lambda X=None, K=None, **kw: eig_R
-            return self.get_estimates(eig_L, method=method, eig_R=eig_R, ngrids=ngrids)
-        finally:
-            self._get_eigen_R_, REML_SUMS_FROM_EIG_L = saved, saved_flag
+        """get_estimates on a PRECOMPUTED eig_R (the reference's own route, :787-799)."""
+        return self.get_estimates(eig_L, method=method, eig_R=eig_R, ngrids=ngrids, use_eig_R=True)
 
     def scan_prepare(self, H_sqrt_inv, Z=None, with_betas=False):
         """SNP-independent part of _emmax_f_test_ (:1290-1306) in closed form:
@@ -531,7 +524,7 @@ class LinearMixedModel(object):
                 res_d.update(bfs=bfs, pos=pos, ppas=pos / (1 + pos))
             if emma_num > 0 and num_snps > 0:                            # :1365-1377
                 order = np.argsort(p_vals, kind='stable')[:emma_num]
-                top = g.download(0, num_snps)[order] if not own else kinship._as_snp_matrix(snps)[order]
+                top = g.download_rows(order) if not own else kinship._as_snp_matrix(snps)[order]
                 top_res = self.expedited_REML_t_test(list(top), eig_L=eig_L)
                 for k, pi in enumerate(order):
                     res_d['ps'][pi] = top_res['ps'][k]
@@ -622,6 +615,112 @@ def emmax(snps, phenotypes, K, cofactors=None, Z=None, with_betas=False, emma_nu
     res = lmm.emmax_f_test(snps, Z=Z, with_betas=with_betas, emma_num=emma_num, verbose=verbose)
     if verbose:
         print('Took %f seconds.' % (time.time() - s1))
+    return res
+
+
+# ---------------------------------------------------------------------- multi-phenotype scans
+def _multi_models(ys, X, eig_L, method='REML'):
+    """Per-phenotype, SNP-independent part of a multi-phenotype scan: REML (:771-927) and the null fit of
+    _emmax_f_test_ (:1290-1303) written in the eigenbasis of K.  O(N^2 P) once for the rotation of Y, then
+    O(N q^2) per phenotype and grid point.  Returns (models, d, omega, G) with d, omega [P x N], G [P x q x N]
+    as mmg_emmax_scan_multi takes them."""
+    V = np.asarray(eig_L['vectors'], dtype=np.float64)
+    lam = np.asarray(eig_L['values'], dtype=np.float64)
+    ys = np.asarray(ys, dtype=np.float64)
+    P, n = ys.shape
+    q = X.shape[1]
+    Yt = V @ ys.T                                                        # N x P: every phenotype rotated at once
+    Xt = V @ X
+    models, d, omega, G = [], np.empty((P, n)), np.empty((P, n)), np.empty((P, q, n))
+    for p in range(P):
+        lmm = LinearMixedModel(ys[p], ctx=False)
+        lmm.X, lmm.p = X, q
+        est = lmm.get_estimates(eig_L, method=method, return_H=False, _rot=(Yt[:, p], Xt))
+        w = 1.0 / np.sqrt(lam + est['delta'])                            # :898 diag of H_sqrt_inv in the eigenbasis
+        h0_X = w[:, None] * Xt                                           # :1290
+        Y_t = w * Yt[:, p]                                               # :1291
+        (h0_betas, _r, _rank, _s) = linalg.lstsq(h0_X, Y_t)              # :1292
+        r = Y_t - h0_X @ h0_betas                                        # :1293
+        (Q, _R) = linalg.qr(h0_X, mode='economic')                       # :1300
+        d[p] = w * w
+        omega[p] = r * w
+        G[p] = (Q * w[:, None]).T
+        est.update(h0_rss=float(r @ r), h0_betas=[float(b) for b in h0_betas])
+        models.append(est)
+    return models, d, omega, G
+
+
+def emmax_multi(snps, phenotypes, K, cofactors=None, ctx=None, coll=None, max_store_bytes=64 << 30, method='REML'):
+    """EMMAX for P phenotypes measured on the same individuals: the result of a loop of `emmax(snps, y_p, K,
+    cofactors)` calls (one LinearMixedModel, REML and scan per phenotype -- what the reference does,
+    phenotypeData.py:70-78 / hdf5_data.py:262-330 once per phenotype), computed with ONE eigendecomposition and
+    ONE O(N^2) pass over the genotypes: the SNPs are rotated into the eigenbasis of K on the int8 matrix cores
+    (T = S U', kept in HBM) and each phenotype's scan -- its own delta_p, H_p, null model -- is then an HBM-bound
+    pass over T (mmg_emmax_scan_multi, 8 phenotypes per pass).
+
+    phenotypes: [P x N] (list of P lists).  snps: list / [M x N] array, or a device-resident _lib.Geno.
+    coll (mixmogam_amd.dist): SNP blocks are sharded over the ranks and the [P x M] results all-gathered.
+    Returns {'ps','f_stats','rss','var_perc'} as [P x M] arrays and per-phenotype lists 'h0_rss', 'h0_betas',
+    'pseudo_heritability', 've', 'vg', 'max_ll', 'delta' (the keys of emmax(), :1351-1354,:1262-1265)."""
+    ys = np.asarray(phenotypes, dtype=np.float64)
+    if ys.ndim != 2:
+        raise ValueError("phenotypes must be [num_phenotypes x num_individuals]")
+    P, n = ys.shape
+    lmm0 = LinearMixedModel(ys[0], ctx=ctx)
+    lmm0.add_random_effect(K)                                            # scale_k once (:580): same K for every phenotype
+    if cofactors:
+        for cofactor in cofactors:
+            lmm0.add_factor(cofactor)                                    # dependence on X only: same for every phenotype
+    ctx = lmm0.ctx
+    X = lmm0.X
+    q = X.shape[1]
+    if q > 4:
+        raise NotImplementedError("emmax_multi: at most 3 cofactors besides the intercept on the rotated path")
+    eig_L = lmm0._get_eigen_L_()
+    models, d, omega, G = _multi_models(ys, X, eig_L, method=method)
+    h0 = np.array([m['h0_rss'] for m in models])
+    n_p = n - (q + 1)
+    own = not isinstance(snps, _lib.Geno)
+    if own:
+        snps = kinship._as_snp_matrix(snps)
+    M = snps.M if not own else len(snps)
+    rank, world = (coll.rank, coll.world) if coll is not None else (0, 1)
+    from . import dist as mdist
+    m0, m1 = mdist.shard_range(M, rank, world)
+    rows_cap = max(256, int(max_store_bytes // (8 * (-(-n // 64) * 64))) // 256 * 256)
+    rot = ctx.rot(eig_L['vectors'], min(rows_cap, max(m1 - m0, 1)))
+    outs = {k: np.empty((P, m1 - m0)) for k in ('rss', 'f_stats', 'ps')}
+    try:
+        for c0 in range(m0, m1, rows_cap):
+            c1 = min(c0 + rows_cap, m1)
+            if own:
+                g = ctx.geno(snps[c0:c1])
+            elif (c0, c1) == (0, M):
+                g = snps
+            else:
+                g = ctx.geno(snps.download(c0, c1 - c0))
+            try:
+                rot.load(g)
+            finally:
+                if g is not snps:
+                    g.close()
+            part = ctx.scan_multi(rot, d, omega, G, h0, n_p)
+            for k in outs:
+                outs[k][:, c0 - m0:c1 - m0] = part[k]
+    finally:
+        rot.close()
+    if coll is not None and world > 1:
+        count = max(b - a for a, b in (mdist.shard_range(M, r, world) for r in range(world)))
+        for k in outs:
+            blk = np.full((P, count), np.nan)
+            blk[:, :m1 - m0] = outs[k]
+            gathered = coll.allgather(blk.reshape(-1)).reshape(world, P, count)
+            outs[k] = np.concatenate([gathered[r][:, :mdist.shard_range(M, r, world)[1] - mdist.shard_range(M, r, world)[0]]
+                                      for r in range(world)], axis=1)
+    res = {'ps': outs['ps'], 'f_stats': outs['f_stats'], 'rss': outs['rss'],
+           'var_perc': 1 - outs['rss'] / h0[:, None], 'h0_rss': h0, 'h0_betas': [m['h0_betas'] for m in models]}
+    for k in ('pseudo_heritability', 've', 'vg', 'max_ll', 'delta'):
+        res[k] = np.array([m[k] for m in models])
     return res
 
 

@@ -18,6 +18,9 @@ class FakeGeno(_lib.Geno):
         rows = self.M - m0 if rows is None else rows
         return self.data[m0:m0 + rows].copy()
 
+    def download_rows(self, idx):
+        return self.data[np.asarray(idx)].copy()
+
     def snp_stats(self):
         return self.data.mean(1), self.data.std(1)
 
@@ -32,6 +35,11 @@ class FakeAcc(object):
     def __init__(self, n):
         self.c, self.n = np.zeros((n, n)), 0
 
+    def allreduce(self, comm):
+        if comm is not None:
+            self.c = comm.allreduce(self.c, "sum").reshape(self.c.shape)
+            self.n = int(comm.allreduce(np.array([self.n], dtype=np.int64), "sum")[0])
+
     def add(self, g, scale=None, shift=None):
         s = g.data.astype(np.float64)
         x = 2 * s - 1 if scale is None else s * np.asarray(scale)[:, None] + np.asarray(shift)[:, None]
@@ -45,15 +53,32 @@ class FakeAcc(object):
         pass
 
 
+class FakeRot(object):
+    def __init__(self, V):
+        self.V, self.T, self.M = V, None, 0
+
+    def load(self, g):
+        self.T = self.V @ g.data.T.astype(np.float64)
+        self.M = g.M
+        return self
+
+    def fetch(self, m0=0, rows=None):
+        return self.T[:, m0:(self.M if rows is None else m0 + rows)].copy()
+
+    def close(self):
+        pass
+
+
 class FakeContext(object):
     device = 0
 
     def geno(self, snps=None, M=None, N=None):
         return FakeGeno(self, snps if snps is not None else np.zeros((M, N), dtype=np.int8))
 
-    def kinship_ibs_counts(self, g):
+    def kinship_ibs_counts(self, g, comm=None):
         x = 2 * g.data.astype(np.int64) - 1
-        return x.T @ x
+        c = x.T @ x
+        return comm.allreduce(c, "sum") if comm is not None else c     # comm: a torch_coll.TorchCollectives here
 
     def kinship_indicator_counts(self, g, thr):
         u = (g.data >= thr).astype(np.int64)
@@ -93,7 +118,21 @@ class FakeContext(object):
     def f_sf(self, F, df2):
         return stats.f.sf(np.asarray(F, dtype=np.float64), 1, df2)
 
-    def perm(self, g, H, Ys, h0_rss, ndigits=0):
+    def rot(self, evecs_rows, M_cap):
+        return FakeRot(np.asarray(evecs_rows, dtype=np.float64))
+
+    def scan_multi(self, rot, d, omega, G, h0_rss, df2, want=("rss", "f_stats", "ps")):
+        T = rot.T                                                    # N x M
+        h0 = np.asarray(h0_rss, dtype=np.float64)[:, None]
+        aq = np.asarray(d) @ (T * T)
+        den = aq - sum((np.asarray(G)[:, c, :] @ T) ** 2 for c in range(np.asarray(G).shape[1]))
+        dot = np.asarray(omega) @ T
+        ok = (den > 1e-7 * aq) & (den > 0)
+        rss = np.where(ok, h0 - dot * dot / np.where(ok, den, 1.0), h0)
+        F = (h0 / rss - 1.0) * df2
+        return {"rss": rss, "f_stats": F, "ps": self.f_sf(F, df2)}
+
+    def perm(self, g, H, Ys, h0_rss, ndigits=0, comm=None):
         S = g.data.astype(np.float64)
         S = S - S.mean(1, keepdims=True)
         T = S @ np.asarray(H).T
@@ -101,4 +140,7 @@ class FakeContext(object):
         G = T @ np.asarray(Ys)
         ok = tt > 1e-12 * max(tt.max(), 1e-300)
         stat = np.where(ok[:, None], G * G / np.where(ok, tt, 1.0)[:, None], 0.0)
-        return np.minimum(h0_rss, np.einsum('ij,ij->j', Ys, Ys) - stat.max(0))
+        mx = stat.max(0) if len(S) else np.zeros(np.asarray(Ys).shape[1])
+        if comm is not None:
+            mx = comm.allreduce(mx, "max")
+        return np.minimum(h0_rss, np.einsum('ij,ij->j', Ys, Ys) - mx)

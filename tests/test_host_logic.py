@@ -114,3 +114,22 @@ def test_reml_sums_from_eig_L_equal_the_eig_R_route(name):
     ref = m.get_estimates(eig_L, xs=xs, return_f_stat=True, return_pvalue=True, eig_R=m._get_eigen_R_(X=X))
     for k in ("delta", "max_ll", "f_stat", "p_val"):
         assert abs(fast[k] / ref[k] - 1) < 1e-9, k
+
+
+def test_emmax_multi_host_logic_vs_reference_loop(ctx):
+    """emmax_multi (one eigh, rotated SNPs, per-phenotype REML in the eigenbasis) == the reference's loop of emmax()
+    runs over six phenotypes with six different variance ratios, without and with a shared cofactor."""
+    from conftest import load_extras
+    ex = load_extras()
+    for tag, cof in (("multi", None), ("multic", [ex["multi_cof"]])):
+        res = lm.emmax_multi(list(ex["snps"]), ex["multi_ys"], ex["ibs_scaled"], cofactors=cof, ctx=ctx)
+        assert res["ps"].shape == ex["dbl_%s_ps" % tag].shape
+        assert rel(res["ps"], ex["dbl_%s_ps" % tag]) < 1e-7
+        assert rel(res["rss"], ex["dbl_%s_rss" % tag]) < 1e-8
+        assert np.max(np.abs(res["var_perc"] - ex["dbl_%s_var_perc" % tag])) < 1e-9
+        for k in ("h0_rss", "pseudo_heritability", "max_ll"):
+            assert rel(res[k], ex["dbl_%s_%s" % (tag, k)]) < 1e-8, k
+        # a small store budget forces several rotate + scan rounds over SNP chunks: same numbers
+        res2 = lm.emmax_multi(list(ex["snps"]), ex["multi_ys"], ex["ibs_scaled"], cofactors=cof, ctx=ctx,
+                              max_store_bytes=256 * 8 * 192)
+        assert np.array_equal(res2["ps"], res["ps"])

@@ -18,12 +18,14 @@ class TorchCollectives(object):
                                     "max": self.dist.ReduceOp.MAX}[op])
         return t.numpy()
 
-    def allgather_host(self, arr):
+    def allgather(self, arr):
         import torch
         t = torch.from_numpy(np.ascontiguousarray(arr))
         outs = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(outs, t)
         return np.concatenate([o.numpy() for o in outs])
+
+    allgather_host = allgather
 
     def barrier(self):
         self.dist.barrier()
