@@ -1,17 +1,23 @@
 #!/usr/bin/env python
 """bench.py -- SNPs/sec of the EMMAX scan (BASELINE.json metric) on MI355X.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus 1 --steps K --warmup W [--mode weak|strong|perm|multi]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path -- the EMMAX scan (linear_models.py:1316-1349: per-SNP
-quadratic form, F statistic, p-value) -- over this rank's batch of M synthetic SNPs that are
-already resident in HBM, ending with rss/F/p for every SNP on the host of every rank
-(N>1: after the RCCL all-gather).  Workload at N=1: BASELINE.json configs[2], N=5000 x
-M=1,000,000 Bernoulli(0.5) genotypes (simulations.py:21-23 restated with a counter hash,
-generated on the device).  N>1: weak scaling, every rank scans its own M SNPs of a G*M-SNP
-data set; the kinship is built from all G*M SNPs (partial counts + RCCL all-reduce), the
-eigendecomposition + REML are replicated.
+A "step" is one pass of the hot path over this rank's batch of synthetic SNPs that are already resident in HBM.
+Modes (default = the BASELINE metric, unchanged since round 1):
+  weak    the EMMAX scan (linear_models.py:1316-1349: per-SNP quadratic form, F statistic, p-value) of M SNPs PER
+          GPU, ending with rss/F/p of every SNP on the host of every rank (N>1: after the RCCL all-gather).
+          Workload at N=1: BASELINE configs[2], N=5000 x M=1,000,000 Bernoulli(0.5) genotypes (simulations.py:21-23
+          restated with a counter hash, generated on the device).  The kinship is built from all G*M SNPs (partial
+          counts all-reduced in HBM over RCCL), eigendecomposition + REML are replicated.
+  strong  the same scan with a FIXED total of M SNPs split over the ranks (shard_range), scaling "strong".
+  perm    BASELINE configs[3]: the EMMAX permutation test (linear_models.py:1125-1175) with P = 1000 permutations over
+          M SNPs in total, SNP blocks sharded over the ranks; a step = t.t quadratic forms + permutation GEMM + RCCL
+          MAX all-reduce of the P statistics in HBM + min_rss on every host.  value = SNP x permutation tests / s.
+  multi   P phenotypes over the eigen-rotated store: a step = the HBM-bound passes of all P
+          phenotypes over this rank's M SNPs (weak scaling) incl. the download of the P x M p-values; the rotation
+          GEMM (once per genotype block) is reported beside it.  value = SNP x phenotype scans / s.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
@@ -33,6 +39,8 @@ I8_MFMA_PEAK_TOPS = 5000.0     # dense int8 MFMA: 2x the ~2.5 PF bf16 rate (MI35
 # tools/probes/mfma_shape_probe.hip).  Reported beside the nominal peak, never instead of it.
 I8_MFMA_SUSTAINED_TOPS = 4230.0
 F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 (same guide)
+HBM_PEAK_GBPS = 8000.0
+PCIE_GBPS = 64.0               # host link of the box (gen5 x16), the roof of anything that starts in host memory
 
 
 def parse():
@@ -40,12 +48,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", choices=("weak", "strong", "perm", "multi"), default="weak")
     ap.add_argument("--n", type=int, default=5000, help="individuals")
-    ap.add_argument("--m", type=int, default=1000000, help="SNPs per GPU")
+    ap.add_argument("--m", type=int, default=1000000, help="SNPs per GPU (weak, multi) / in total (strong, perm)")
+    ap.add_argument("--perms", type=int, default=1000, help="permutations (perm mode)")
+    ap.add_argument("--phenos", type=int, default=64, help="phenotypes (multi mode)")
     ap.add_argument("--digits", type=int, default=0,
                     help="digit planes of the scan model; 0 = the library default (4 planes, adaptive schedule)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32-kinship", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the structured-data, host-ingest and multi-phenotype sub-records of the default run")
     ap.add_argument("--cpu-sample", type=int, default=0,
                     help="SNPs in the CPU baseline sample (0 = 40 chunks of N, ~15-20 s of CPU work at N=5000)")
     return ap.parse_args()
@@ -64,22 +77,29 @@ def main():
 
     # No torch in this process: libmixmogam_hip links the system ROCm runtime and importing
     # torch's bundled one beside it segfaults.  Rendezvous = rank 0's ncclUniqueId through a
-    # /tmp file keyed by the launcher's MASTER_PORT; barriers and the max-over-ranks time go
+    # per-user file keyed by the launcher's MASTER_PORT; barriers and the max-over-ranks time go
     # over RCCL itself.
     ctx = _lib.Context(local_rank)
     info = ctx.device_info()
-    coll = None
+    coll, rccl_nranks = None, 1
     if world > 1 or os.environ.get("MMG_BENCH_FORCE_COLL"):   # the env knob exercises the RCCL path on 1 GPU
-        boot = mdist.file_bootstrap(rank, world)
-        coll = mdist.RcclCollectives(ctx, rank, world, boot)
+        coll = mdist.RcclCollectives(ctx, rank, world, mdist.file_bootstrap(rank, world))
+        rccl_nranks = coll.info()[2]
+        if rccl_nranks != world:
+            raise SystemExit("RCCL reports %d ranks, launcher %d" % (rccl_nranks, world))
+    comm_h = coll.device_comm if coll is not None else None
 
-    N, M, D = args.n, args.m, args.digits
-    Mtot = M * world
+    N, D, mode = args.n, args.digits, args.mode
+    if mode in ("weak", "multi"):
+        M, Mtot, m_global0 = args.m, args.m * world, rank * args.m
+    else:
+        m0, m1 = mdist.shard_range(args.m, rank, world)
+        M, Mtot, m_global0 = m1 - m0, args.m, m0
     t_setup = time.time()
 
     # ---- synthetic genotypes, generated in HBM (this rank's block of the global SNP axis)
     g = ctx.geno(M=M, N=N)
-    g.fill_hash(20240, m_global0=rank * M, thr16=32768)
+    g.fill_hash(20240, m_global0=m_global0, thr16=32768)
 
     # ---- phenotype (simulations.py:64-85 restated): 100 causal SNPs of the global data set
     rng = np.random.RandomState(20241)
@@ -91,18 +111,17 @@ def main():
     y = gen + err * np.sqrt((0.2 / 0.8) * (np.var(gen, ddof=1) / np.var(err, ddof=1)))
     y = (y - y.mean()) / y.std()
 
-    # ---- kinship: exact IBS counts on the int8 matrix cores (+ fp32-MFMA twin for the TFLOP/s figure)
-    counts = ctx.kinship_ibs_counts(g)
-    kin_i8_ms = ctx.kernel_ms("kinship")
+    # ---- kinship: exact IBS counts on the int8 matrix cores, partial counts of the ranks summed in HBM over RCCL
+    # (+ the fp32-MFMA twin of the north star on this rank's block, for the TFLOP/s figure)
+    counts = ctx.kinship_ibs_counts(g, comm=comm_h)
+    kin_i8_ms, kin_i8_pack_ms = ctx.kernel_ms("kinship"), ctx.kernel_ms("pack")
     kin_f32_ms = None
     if not args.no_f32_kinship:
         cf = ctx.kinship_affine(g)
         kin_f32_ms = ctx.kernel_ms("kinship")
-        if not np.array_equal(cf, counts.astype(np.float64)):
+        if world == 1 and not np.array_equal(cf, counts.astype(np.float64)):
             raise SystemExit("fp32-MFMA and int8-MFMA kinship counts differ")
         del cf
-    if coll is not None:
-        counts = mdist.sharded_ibs_counts(counts, coll)
     K = kinship.scale_k(counts.astype(np.float64) / (2.0 * Mtot) + 0.5)
 
     # ---- eigh + REML (replicated), model -> device
@@ -124,16 +143,43 @@ def main():
         if coll is not None:
             coll.barrier()
 
+    common = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+              "vs_baseline": None, "data": "synthetic", "rccl_nranks": rccl_nranks, "mode": mode}
+
+    if mode == "perm":
+        res = bench_perm(args, ctx, coll, comm_h, g, lmm, est, N, M, Mtot, barrier, common)
+    elif mode == "multi":
+        res = bench_multi(args, ctx, coll, g, lmm, eig_L, N, M, Mtot, barrier, common)
+    else:
+        res = bench_scan(args, ctx, coll, comm_h, g, lmm, est, prep, N, M, Mtot, D, barrier, common, rank, world,
+                         kin_i8_ms, kin_i8_pack_ms, kin_f32_ms)
+    if rank == 0:
+        res.update({"eigh_ms": eigh_ms, "model_setup_s": model_s, "setup_s": t_setup, "delta": float(est["delta"]),
+                    "device": info})
+    if coll is not None:
+        coll.barrier()
+        coll.close()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(res))          # the ONE JSON line, last on stdout
+        sys.stdout.flush()
+
+
+# ----------------------------------------------------------------------------------------------- the BASELINE metric
+def bench_scan(args, ctx, coll, comm_h, g, lmm, est, prep, N, M, Mtot, D, barrier, common, rank, world, kin_i8_ms,
+               kin_i8_pack_ms, kin_f32_ms):
+    from mixmogam_amd import dist as mdist
+    n_p = prep["n_p"]
     # Result buffers are allocated once and page-locked (mmg_host_alloc).  Delivery is double buffered: the
     # (rss, F, p) of step i are snapshotted on the device and all-gathered over RCCL / downloaded on a second
     # HIP stream (mmg_scan_deliver_begin) while step i+1 scans; the last delivery is awaited inside the timed
     # region, so every step's results are on the host of every rank before the closing barrier.
-    outs2 = [[ctx.pinned_empty(M * world) for _ in range(3)] for _ in range(2)]
-    comm_h = coll.h if coll is not None else None
+    count = M if args.mode == "weak" else max(b - a for a, b in (mdist.shard_range(args.m, r, world) for r in range(world)))
+    outs2 = [[ctx.pinned_empty(count * world) for _ in range(3)] for _ in range(2)]
 
     def step(i):
         ctx.scan(g, prep["h0_rss"], n_p, fetch=False)           # blocks until the kernels finish
-        ctx.scan_deliver_begin(outs2[i & 1], count=M, comm=comm_h)
+        ctx.scan_deliver_begin(outs2[i & 1], count=count, comm=comm_h)
         return outs2[i & 1]
 
     for i in range(args.warmup):
@@ -149,103 +195,337 @@ def main():
     ctx.scan_deliver_wait()
     barrier()
     elapsed = time.time() - t0
+    per_rank_quad = [float(np.mean(quad_ms))]
     if coll is not None:
         elapsed = float(coll.allreduce(np.array([elapsed]), "max")[0])
+        per_rank_quad = [float(v) for v in coll.allgather(np.array([np.mean(quad_ms)]))]
 
-    ps = out[2].copy()
+    ps = out[2][rank * count:rank * count + M].copy()
     scan_stats = ctx.scan_last_stats()
     # For the record, outside the timed region: the same scan with all four digit planes for every SNP (what the
     # adaptive schedule is measured against) -- its time and how far the two sets of p-values are apart.
     all_planes = None
     if scan_stats["adaptive"] and rank == 0:
-        ctx.scan_set_model(prep["A"], prep["w"], 4)
-        ctx.scan(g, prep["h0_rss"], n_p, fetch=False)
-        t1 = time.time()
-        for _ in range(2):
-            ctx.scan(g, prep["h0_rss"], n_p, fetch=False)
-        dt_all = (time.time() - t1) / 2
-        ref_out = ctx.scan(g, prep["h0_rss"], n_p)
-        mine = ps[rank * M:(rank + 1) * M]
-        ok = ref_out["ps"] > 1e-290
-        all_planes = {"ms_per_scan_kernels_only": 1e3 * dt_all, "scan_quad_ms": ctx.kernel_ms("scan_quad"),
-                      "max_rel_p_diff_adaptive_vs_all_planes": float(np.max(np.abs(mine[ok] / ref_out["ps"][ok] - 1)))}
-    if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = Mtot * args.steps / elapsed
-        qms = float(np.mean(quad_ms))
-        alg_flop = (2.0 * N * N + 4.0 * N) * M                 # SURVEY 8d per-SNP figure x SNPs per launch
+        all_planes = _all_planes_reference(ctx, g, prep, n_p, ps)
+        ctx.scan_set_model(prep["A"], prep["w"], D)
+    if rank != 0:
+        return None
+    Npad = -(-N // 256) * 256
+    nJ = Npad // 256
+    Dn = D if D else 4
+    plane_ops = 2.0 * 256.0 * 256.0 * 256.0 * (nJ * (nJ + 1) / 2)          # one digit plane over one 256-SNP block
+
+    def exec_ops_of(stats, m):
+        if stats["adaptive"] and not stats["fell_back"]:                   # 3 planes for all + 1 for the refined
+            return plane_ops * ((Dn - 1) * (-(-m // 256)) + (-(-stats["n_refined"] // 256)))
+        return plane_ops * Dn * (-(-m // 256)) * (2 if stats["fell_back"] else 1)
+
+    def roofline_of(qms, m, stats):
+        alg_flop = (2.0 * N * N + 4.0 * N) * m                 # SURVEY 8d per-SNP figure x SNPs per launch
         achieved = alg_flop / (qms * 1e-3) / 1e12
-        Npad = -(-N // 256) * 256
-        nJ = Npad // 256
-        Dn = D if D else 4
-        plane_ops = 2.0 * 256.0 * 256.0 * 256.0 * (nJ * (nJ + 1) / 2)          # one digit plane over one 256-SNP block
-        if scan_stats["adaptive"] and not scan_stats["fell_back"]:            # 3 planes for all + 1 for the refined
-            exec_ops = plane_ops * ((Dn - 1) * (-(-M // 256)) + (-(-scan_stats["n_refined"] // 256)))
-        else:
-            exec_ops = plane_ops * Dn * (-(-M // 256)) * (2 if scan_stats["fell_back"] else 1)
-        kin_exec = 2.0 * 256.0 * 256.0 * (nJ * (nJ + 1) / 2) * M     # lower-triangle tiles x contraction length
-        traffic = None
-        try:   # HBM bytes per launch measured with rocprofv3 PMC passes of this same command (profiles/)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_c3.json")))
-            if tj["config"] == {"n": N, "m": M, "digits": D} and tj.get("adaptive", False) == scan_stats["adaptive"]:
-                traffic = tj["kernels"][QUAD_KERNEL]["hbm_bytes_corrected"]
-        except Exception:
-            pass
-        res = {
-            "metric": "SNPs/sec EMMAX scan", "value": value, "unit": "SNPs/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "i8", "data": "synthetic",
-            "config": {"workload": "EMMAX scan N=%d individuals x M=%d SNPs per GPU (BASELINE configs[2] shape), "
-                                   "Bernoulli(0.5) hash genotypes resident in HBM, q=1" % (N, M),
-                       "n_individuals": N, "snps_per_gpu": M, "snps_total": Mtot, "digits": Dn,
-                       "digit_schedule": "adaptive (3 planes for every SNP, the 4th where p could move by 2.5e-7)"
-                                         if scan_stats["adaptive"] else "all planes for every SNP",
-                       "parallelism": "snp-block x%d" % world,
-                       "delivery": "double buffered: step i's results are gathered (RCCL) / downloaded on a second "
-                                   "stream while step i+1 scans; the last one is awaited inside the timed region"},
-            "roofline": {"bound": "mfma", "kernel": QUAD_KERNEL, "achieved": achieved,
-                         "peak": I8_MFMA_PEAK_TOPS, "unit": "TFLOP/s", "frac": achieved / I8_MFMA_PEAK_TOPS,
-                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC, profiles/traffic_c3.json)",
-                         "algorithmic_bytes": float(-(-M // 256) * 256 * Npad + Dn * Npad * Npad), "ms": qms,
-                         "executed_int8_tops": exec_ops / (qms * 1e-3) / 1e12,
-                         "executed_frac": exec_ops / (qms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
-                         "executed_frac_of_sustained_mfma_rate": exec_ops / (qms * 1e-3) / 1e12 / I8_MFMA_SUSTAINED_TOPS},
-            "finalize_kernel": {"ms": float(np.mean(fin_ms)),
-                                "hbm_gbps": (M * (Npad + 56.0)) / (np.mean(fin_ms) * 1e-3) / 1e9},
-            # "flop" is the full product the reference forms; only the lower triangle of 256^2
-            # tiles is executed (kin_exec), so the *_frac_of_peak figures can exceed 1 -- the executed ones cannot
-            "kinship": {"flop": 2.0 * N * N * M, "executed_flop": kin_exec,
-                        "i8_executed_tops": kin_exec / (kin_i8_ms * 1e-3) / 1e12,
-                        "i8_executed_frac_of_peak": kin_exec / (kin_i8_ms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
-                        "f32_executed_tflops": None if kin_f32_ms is None else kin_exec / (kin_f32_ms * 1e-3) / 1e12,
-                        "f32_executed_frac_of_peak": None if kin_f32_ms is None else
-                        kin_exec / (kin_f32_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                        "i8_ms": kin_i8_ms, "i8_tops": 2.0 * N * N * M / (kin_i8_ms * 1e-3) / 1e12,
-                        "i8_frac_of_peak": 2.0 * N * N * M / (kin_i8_ms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
-                        "f32_ms": kin_f32_ms,
-                        "f32_tflops": None if kin_f32_ms is None else 2.0 * N * N * M / (kin_f32_ms * 1e-3) / 1e12,
-                        "f32_frac_of_peak": None if kin_f32_ms is None else
-                        2.0 * N * N * M / (kin_f32_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS},
-            "adaptive_scan": scan_stats, "all_planes_reference": all_planes,
-            "eigh_ms": eigh_ms, "model_setup_s": model_s, "setup_s": t_setup,
-            "delta": float(est["delta"]), "min_p": float(np.nanmin(ps)), "device": info,
-        }
-        if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
-            sample = min(M, args.cpu_sample or 40 * N)
-            res["cpu_baseline"] = cpu_baseline(N, sample, lmm, est, prep, ps[:sample])
+        ex = exec_ops_of(stats, m)
+        return {"bound": "mfma", "kernel": QUAD_KERNEL, "achieved": achieved, "peak": I8_MFMA_PEAK_TOPS,
+                "unit": "TFLOP/s", "frac": achieved / I8_MFMA_PEAK_TOPS, "ms": qms,
+                "algorithmic_bytes": float(-(-m // 256) * 256 * Npad + Dn * Npad * Npad),
+                "executed_int8_tops": ex / (qms * 1e-3) / 1e12,
+                "executed_frac": ex / (qms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
+                "executed_frac_of_sustained_mfma_rate": ex / (qms * 1e-3) / 1e12 / I8_MFMA_SUSTAINED_TOPS}
+
+    traffic = _profiled_traffic(N, M, D, scan_stats["adaptive"])
+    roof = roofline_of(per_rank_quad[0], M, scan_stats)
+    roof.update({"traffic": traffic.get(QUAD_KERNEL), "traffic_unit": "bytes per launch (PMC, profiles/traffic_c3.json)"})
+    ms_per_step = 1e3 * elapsed / args.steps
+    kin_exec = 2.0 * 256.0 * 256.0 * (nJ * (nJ + 1) / 2) * M     # lower-triangle tiles x contraction length
+    kin_alg = 2.0 * N * N * M
+
+    def kin_roof(name, ms, peak, unit, extra_ms=None):
+        if ms is None:
+            return None
+        d = {"bound": "mfma", "kernel": name, "ms": ms, "achieved": kin_alg / (ms * 1e-3) / 1e12, "peak": peak,
+             "unit": unit, "frac": kin_alg / (ms * 1e-3) / 1e12 / peak,
+             "executed": kin_exec / (ms * 1e-3) / 1e12, "executed_frac": kin_exec / (ms * 1e-3) / 1e12 / peak,
+             "algorithmic_flop": kin_alg, "executed_flop": kin_exec,
+             "algorithmic_bytes": float(M * Npad + 8.0 * N * N), "traffic": traffic.get(name),
+             "note": "algorithmic = the full 2 N^2 M product the reference forms (kinship.py:44); executed = the lower "
+                     "triangle of 256^2 tiles actually run, so `frac` may exceed 1 while `executed_frac` cannot"}
+        if extra_ms is not None:
+            d["transpose_pass_ms"] = extra_ms
+        return d
+
+    res = dict(common)
+    res.update({
+        "metric": "SNPs/sec EMMAX scan", "value": Mtot * args.steps / elapsed, "unit": "SNPs/s",
+        "ms_per_step": ms_per_step, "scaling": "weak" if args.mode == "weak" else "strong", "dtype": "i8",
+        "config": {"workload": "EMMAX scan N=%d individuals x M=%d SNPs %s (BASELINE configs[2] shape), "
+                               "Bernoulli(0.5) hash genotypes resident in HBM, q=1"
+                               % (N, args.m, "per GPU" if args.mode == "weak" else "in total, split over the ranks"),
+                   "n_individuals": N, "snps_per_gpu": M, "snps_total": Mtot, "digits": Dn,
+                   "digit_schedule": "adaptive (3 planes for every SNP, the 4th where p could move by 2.5e-7)"
+                                     if scan_stats["adaptive"] else "all planes for every SNP",
+                   "parallelism": "snp-block x%d" % world,
+                   "delivery": "double buffered: step i's results are gathered (RCCL) / downloaded on a second "
+                               "stream while step i+1 scans; the last one is awaited inside the timed region",
+                   "cpu_baseline_sample": "bounded sample of the same workload (see cpu_baseline.sample), not all M"},
+        "roofline": roof,
+        "roofline_per_rank": [roofline_of(q, M, scan_stats)["frac"] for q in per_rank_quad],
+        "scan_quad_ms_per_rank": per_rank_quad,
+        "finalize_kernel": {"ms": float(np.mean(fin_ms)),
+                            "hbm_gbps": (M * (Npad + 56.0)) / (np.mean(fin_ms) * 1e-3) / 1e9},
+        # second headline metric: kinship GEMM TFLOP/s vs MFMA peak, one record per kernel
+        "roofline_kinship": {"f32": kin_roof("kinship_f32_kernel", kin_f32_ms, F32_MFMA_PEAK_TFLOPS, "TFLOP/s"),
+                             "i8": kin_roof("kinship_i8_kernel", kin_i8_ms, I8_MFMA_PEAK_TOPS, "TOP/s", kin_i8_pack_ms)},
+        "adaptive_scan": scan_stats, "all_planes_reference": all_planes, "min_p": float(np.nanmin(ps)),
+    })
+    if world == 1 and not args.no_extras:
+        res["structured"] = structured_record(ctx, N, M, exec_ops_of)
+        res["host_ingest"] = ingest_record(ctx, g, prep, n_p, N, M, ms_per_step)
+        res["multi_phenotype"] = multi_record(ctx, g, lmm, N, M)
+    if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
+        sample = min(M, args.cpu_sample or 40 * N)
+        res["cpu_baseline"] = cpu_baseline(N, sample, lmm, est, prep, ps[:sample])
+    return res
+
+
+def _all_planes_reference(ctx, g, prep, n_p, ps_adaptive):
+    ctx.scan_set_model(prep["A"], prep["w"], 4)
+    ctx.scan(g, prep["h0_rss"], n_p, fetch=False)
+    t1 = time.time()
+    for _ in range(2):
+        ctx.scan(g, prep["h0_rss"], n_p, fetch=False)
+    dt_all = (time.time() - t1) / 2
+    ref_out = ctx.scan(g, prep["h0_rss"], n_p)
+    ok = ref_out["ps"] > 1e-290
+    return {"ms_per_scan_kernels_only": 1e3 * dt_all, "scan_quad_ms": ctx.kernel_ms("scan_quad"),
+            "snps_per_s_kernels_only": len(ps_adaptive) / dt_all,
+            "max_rel_p_diff_adaptive_vs_all_planes": float(np.max(np.abs(ps_adaptive[ok] / ref_out["ps"][ok] - 1)))}
+
+
+def _profiled_traffic(N, M, D, adaptive):
+    """HBM bytes per launch measured with rocprofv3 PMC passes of this same command (profiles/traffic_c3.json)."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_c3.json")))
+        if tj["config"] == {"n": N, "m": M, "digits": D} and tj.get("adaptive", False) == adaptive:
+            return {k: v.get("hbm_bytes_corrected") for k, v in tj["kernels"].items()}
+    except Exception:
+        pass
+    return {}
+
+
+def structured_record(ctx, N, M, exec_ops_of):
+    """The same scan on STRUCTURED genotypes (3 populations, Fst ~ 0.04: interior REML optimum, correlated SNPs) with
+    120 strong causal SNPs -- the regime real GWAS lives in, where the adaptive digit schedule has to refine far more
+    SNPs than on the null-like Bernoulli data of the headline: refined count, time, and the distance to the
+    all-planes scan; `value_all_planes` is what a user sees if the refinement stops paying."""
+    from mixmogam_amd import kinship, linear_models as lm
+    g = ctx.geno(M=M, N=N)
+    g.fill_structured(20250, 0, npop=3, spread_q16=9830)
+    counts = ctx.kinship_ibs_counts(g)
+    K = kinship.scale_k(counts.astype(np.float64) / (2.0 * M) + 0.5)
+    rng = np.random.RandomState(20251)
+    causal = np.sort(rng.choice(M, 120, replace=False))
+    rows = g.download_rows(causal).astype(np.float64)
+    gen = rng.exponential(1.0, size=120) @ (rows - rows.mean(1, keepdims=True))
+    err = rng.normal(0, 1, size=N)
+    y = gen + err * np.sqrt((0.2 / 0.8) * (np.var(gen, ddof=1) / np.var(err, ddof=1)))
+    y = (y - y.mean()) / y.std()
+    lmm = lm.LinearMixedModel(y, ctx=ctx)
+    lmm.add_random_effect(K)
+    est = lmm.get_estimates(lmm._get_eigen_L_(), method="REML")
+    prep = lmm.scan_prepare(est["H_sqrt_inv"])
+    ctx.scan_set_model(prep["A"], prep["w"], 0)
+    ctx.scan(g, prep["h0_rss"], prep["n_p"], fetch=False)
+    t0 = time.time()
+    reps = 3
+    for _ in range(reps):
+        ctx.scan(g, prep["h0_rss"], prep["n_p"], fetch=False)
+    dt = (time.time() - t0) / reps
+    stats = ctx.scan_last_stats()
+    qms = ctx.kernel_ms("scan_quad")
+    ada = ctx.scan(g, prep["h0_rss"], prep["n_p"])
+    allp = _all_planes_reference(ctx, g, prep, prep["n_p"], ada["ps"])
+    g.close()
+    return {"workload": "N=%d x M=%d, 3 populations (mmg_geno_fill_structured, spread 0.15), 120 causal SNPs, h2 0.8" % (N, M),
+            "pseudo_heritability": float(est["pseudo_heritability"]), "min_p": float(ada["ps"].min()),
+            "n_p_below_1e-8": int((ada["ps"] < 1e-8).sum()), "adaptive_scan": stats,
+            "ms_per_scan_kernels_only": 1e3 * dt, "scan_quad_ms": qms, "value_adaptive": M / dt,
+            "value_all_planes": allp["snps_per_s_kernels_only"], "all_planes_reference": allp,
+            "executed_frac": exec_ops_of(stats, M) / (qms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS}
+
+
+def ingest_record(ctx, g, prep, n_p, N, M, ms_per_step):
+    """the scan number WITH the host->device transfer of the genotypes, reported separately -- for int8
+    genotypes (5 GB at C3) and for the config's fp32 [M x N] genotypes (20 GB, converted to the int8 store on the
+    device).  `value_h2d_inclusive*` is never `value`."""
+    from mixmogam_amd import hdf5_data
+    rows = min(M, 250000)                       # a quarter of C3: 1.25 GB int8 / 5 GB fp32 of host memory
+    host8 = g.download(0, rows)
+    g2 = ctx.geno(M=rows, N=N)
+    g2.upload(host8)                            # warm-up (first touch of the pageable pages)
+    t0 = time.time()
+    g2.upload(host8)
+    t8 = time.time() - t0
+    host32 = host8.astype(np.float32)
+    g2.upload(host32)
+    t0 = time.time()
+    g2.upload(host32)
+    t32 = time.time() - t0
+    same = np.array_equal(g2.download(), host8)
+    g2.close()
+    # pipelined: chunks uploaded on a second stream by the prefetch thread while the previous chunk is scanned
+    # (the hdf5_data streaming loop), int8 host genotypes
+    src = {"c": {"raw_snps": host8, "freqs": np.full(rows, 0.5), "positions": np.arange(rows)}}
+    plan = hdf5_data._chunk_plan(src, 0.1, 50000)
+    t0 = time.time()
+    for _ci, _c, gg in hdf5_data._resident_chunks(ctx, src, plan):
+        ctx.scan(gg, prep["h0_rss"], n_p, fetch=True)
+        gg.close()
+    t_pipe = time.time() - t0
+    scan_s = ms_per_step * 1e-3 * rows / M
+    return {"sample_rows": rows, "int8_upload_gbps": rows * N / t8 / 1e9, "f32_upload_convert_gbps": rows * N * 4.0 / t32 / 1e9,
+            "f32_ingest_round_trip_exact": bool(same),
+            "value_h2d_inclusive_int8_serial": rows / (t8 + scan_s),
+            "value_h2d_inclusive_f32_serial": rows / (t32 + scan_s),
+            "value_h2d_inclusive_int8_pipelined": rows / t_pipe,
+            "pcie_roof_snps_per_s": {"int8": PCIE_GBPS * 1e9 / N, "f32": PCIE_GBPS * 1e9 / (4.0 * N)},
+            "note": "upload of the rows into the padded HBM store + the scan of those rows; serial = upload then "
+                    "scan, pipelined = 50,000-SNP chunks with the next upload overlapping the current scan"}
+
+
+def multi_record(ctx, g, lmm, N, M, P=16):
+    """Multi-phenotype scans over the eigen-rotated store (mmg_rot_* / mmg_emmax_scan_multi), 16 random phenotypes."""
+    from mixmogam_amd import linear_models as lm
+    rng = np.random.RandomState(20260)
+    ys = rng.standard_normal((P, N))
+    eig_L = lmm._get_eigen_L_()
+    t0 = time.time()
+    models, d, omega, G = lm._multi_models(ys, lmm.X, eig_L)
+    t_models = time.time() - t0
+    try:
+        rot = ctx.rot(eig_L["vectors"], M)
+    except Exception as e:                       # 8 N M bytes of HBM
+        return {"skipped": str(e)}
+    rot.load(g)
+    rot_ms = ctx.kernel_ms("rotate")
+    h0 = np.array([m["h0_rss"] for m in models])
+    ctx.scan_multi(rot, d, omega, G, h0, N - 2, want=("ps",))
+    t0 = time.time()
+    ctx.scan_multi(rot, d, omega, G, h0, N - 2, want=("ps",))
+    wall = time.time() - t0
+    ms = ctx.kernel_ms("scan_multi")
+    rot.close()
+    npass = -(-P // 8)
+    return {"phenotypes": P, "rotation_gemm_ms": rot_ms,
+            "rotation_executed_int8_tops": 2.0 * 4 * (-(-N // 256) * 256) * (-(-N // 64) * 64) * M / (rot_ms * 1e-3) / 1e12,
+            "pass_ms": ms / npass, "passes": npass, "ms_per_phenotype_scan": ms / P,
+            "value_snp_phenotype_scans_per_s": M * P / (wall), "value_kernels_only": M * P / (ms * 1e-3),
+            "roofline": {"bound": "hbm", "kernel": "scan_multi_kernel", "achieved": 8.0 * N * M / (ms / npass * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 8.0 * N * M / (ms / npass * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         "algorithmic_bytes": 8.0 * N * M},
+            "host_model_ms_per_phenotype": 1e3 * t_models / P}
+
+
+# ----------------------------------------------------------------------------------------------- C4: permutation test
+def bench_perm(args, ctx, coll, comm_h, g, lmm, est, N, M, Mtot, barrier, common):
+    P = args.perms
+    H = np.asarray(est["H_sqrt_inv"])
+    y = lmm.Y.reshape(-1) - lmm.Y.mean()                                  # linear_models.py:1140
+    h0_X = H @ lmm.X
+    Yt = H @ y
+    b0 = np.linalg.lstsq(h0_X, Yt, rcond=None)[0]
+    r = Yt - h0_X @ b0
+    h0_rss = float(r @ r)
+    r = r - h0_X @ b0                                                     # :1147 (kept)
+    idx = np.array([np.random.RandomState(20242 + p).permutation(N) for p in range(P)])
+    Ys = np.ascontiguousarray(r[idx].T)
+
+    def step():
+        return ctx.perm(g, H, Ys, h0_rss, comm=comm_h)                    # min over the SNP blocks of ALL ranks, in HBM
+
+    for _ in range(args.warmup):
+        step()
+    perm_ms = []
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        min_rss = step()
+        perm_ms.append(ctx.kernel_ms("perm"))
+    barrier()
+    elapsed = time.time() - t0
+    per_rank = [float(np.mean(perm_ms))]
     if coll is not None:
-        coll.barrier()
-        if rank == 0:
-            try:
-                os.remove(boot.path)
-            except OSError:
-                pass
-        coll.close()
-    if rank == 0:
-        sys.stdout.flush()
-        print(json.dumps(res))          # the ONE JSON line, last on stdout
-        sys.stdout.flush()
+        elapsed = float(coll.allreduce(np.array([elapsed]), "max")[0])
+        per_rank = [float(v) for v in coll.allgather(np.array([np.mean(perm_ms)]))]
+        # every rank holds the same minima
+        chk = coll.allreduce(min_rss.copy(), "max")
+        if not np.array_equal(chk, min_rss):
+            raise SystemExit("ranks disagree on the permutation minima")
+    if (coll.rank if coll is not None else 0) != 0:
+        return None
+    n_p = N - 2
+    max_f = (h0_rss / min_rss - 1.0) * n_p
+    min_ps = ctx.f_sf(max_f, n_p)
+    Npad = -(-N // 256) * 256
+    Ppad = -(-P // 64) * 64
+    ex = 2.0 * 4 * 256.0 * Npad * Ppad / 64 * (-(-M // 256))             # 4 digit rows per permutation, int8 ops
+    res = dict(common)
+    res.update({"metric": "SNP x permutation tests/sec, EMMAX permutation test (BASELINE configs[3])",
+                "value": float(Mtot) * P * args.steps / elapsed, "unit": "SNP-permutations/s",
+                "ms_per_step": 1e3 * elapsed / args.steps, "scaling": "strong", "dtype": "i8",
+                "config": {"workload": "N=%d x M=%d SNPs in total, P=%d permutations, SNP blocks sharded over the ranks, "
+                                       "RCCL MAX all-reduce of the P statistics in HBM inside the timed region"
+                                       % (N, Mtot, P), "snps_per_gpu": M, "parallelism": "snp-block x%d" % common["n_gpus"]},
+                "roofline": {"bound": "mfma", "kernel": "perm_gemm_kernel", "ms": per_rank[0],
+                             "achieved": 2.0 * N * P * M / (per_rank[0] * 1e-3) / 1e12, "peak": I8_MFMA_PEAK_TOPS,
+                             "unit": "TFLOP/s", "frac": 2.0 * N * P * M / (per_rank[0] * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
+                             "executed_int8_tops": ex / (per_rank[0] * 1e-3) / 1e12,
+                             "executed_frac": ex / (per_rank[0] * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS},
+                "perm_gemm_ms_per_rank": per_rank,
+                "threshold_05": {"min_p": float(np.sort(min_ps)[P // 20]), "max_f": float(np.sort(max_f)[::-1][P // 20])}})
+    return res
+
+
+# ----------------------------------------------------------------------------------------------- multi-phenotype
+def bench_multi(args, ctx, coll, g, lmm, eig_L, N, M, Mtot, barrier, common):
+    from mixmogam_amd import linear_models as lm
+    P = args.phenos
+    rng = np.random.RandomState(20260)
+    ys = rng.standard_normal((P, N))
+    t0 = time.time()
+    models, d, omega, G = lm._multi_models(ys, lmm.X, eig_L)
+    t_models = time.time() - t0
+    rot = ctx.rot(eig_L["vectors"], M)
+    rot.load(g)
+    rot_ms = ctx.kernel_ms("rotate")
+    h0 = np.array([m["h0_rss"] for m in models])
+    for _ in range(args.warmup):
+        ctx.scan_multi(rot, d, omega, G, h0, N - 2, want=("ps",))
+    ms = []
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        out = ctx.scan_multi(rot, d, omega, G, h0, N - 2, want=("ps",))   # P x M p-values on this rank's host
+        ms.append(ctx.kernel_ms("scan_multi"))
+    barrier()
+    elapsed = time.time() - t0
+    if coll is not None:
+        elapsed = float(coll.allreduce(np.array([elapsed]), "max")[0])
+    rot.close()
+    if (coll.rank if coll is not None else 0) != 0:
+        return None
+    npass = -(-P // 8)
+    pass_ms = float(np.mean(ms)) / npass
+    res = dict(common)
+    res.update({"metric": "SNP x phenotype EMMAX scans/sec over the eigen-rotated store",
+                "value": float(Mtot) * P * args.steps / elapsed, "unit": "SNP-phenotype scans/s",
+                "ms_per_step": 1e3 * elapsed / args.steps, "scaling": "weak", "dtype": "f64",
+                "config": {"workload": "N=%d x M=%d SNPs per GPU, %d phenotypes with their own delta, 8 per pass" % (N, M, P),
+                           "parallelism": "snp-block x%d" % common["n_gpus"]},
+                "roofline": {"bound": "hbm", "kernel": "scan_multi_kernel", "achieved": 8.0 * N * M / (pass_ms * 1e-3) / 1e9,
+                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 8.0 * N * M / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "algorithmic_bytes": 8.0 * N * M, "ms": pass_ms, "traffic": None},
+                "rotation_gemm_ms": rot_ms, "host_model_ms_per_phenotype": 1e3 * t_models / P,
+                "min_p": float(out["ps"].min())})
+    return res
 
 
 def _device_rows(ctx, rows, n, seed):

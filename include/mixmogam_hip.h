@@ -82,6 +82,12 @@ int mmg_geno_download_rows(mmg_ctx* ctx, mmg_geno* g, const int64_t* idx, int64_
  * counter-based hash so that any SNP range can be regenerated on any rank or on the CPU):
  * s[m][i] = hash64(seed, m_global0 + m, i) >> 48 < thr16 (thr16 = 32768 -> p = 0.5). */
 int mmg_geno_fill_hash(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_global0, uint32_t thr16);
+/* Structured twin: `npop` contiguous populations (pop(i) = i*npop/N), per-SNP ancestral frequency U[0.1,0.9] plus a
+ * per-population deviation of scale spread_q16/65536 (sum of four uniforms), clamped to [0.02,0.98]; 16-bit fixed
+ * point from the same hash, reproducible on the host (the test tree holds a numpy twin).  Gives an interior REML
+ * optimum and many correlated strong hits -- the data regime of real GWAS. */
+int mmg_geno_fill_structured(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_global0, int32_t npop,
+                             uint32_t spread_q16);
 /* Per-SNP mean and population std (kinship.py:66, hdf5_data.py:99-104). Host outputs, length M. */
 int mmg_geno_snp_stats(mmg_ctx* ctx, mmg_geno* g, double* mean, double* std);
 

@@ -46,6 +46,7 @@ PROTOTYPES = {
     "mmg_geno_download": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64]),
     "mmg_geno_download_rows": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp]),
     "mmg_geno_fill_hash": (C.c_int, [c_vp, c_vp, C.c_uint64, C.c_int64, C.c_uint32]),
+    "mmg_geno_fill_structured": (C.c_int, [c_vp, c_vp, C.c_uint64, C.c_int64, C.c_int32, C.c_uint32]),
     "mmg_geno_snp_stats": (C.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "mmg_geno_matvec": (C.c_int, [c_vp, c_vp, c_vp, C.c_int32, c_vp]),
     "mmg_kinship_ibs_i8": (C.c_int, [c_vp, c_vp, c_vp]),
@@ -181,6 +182,11 @@ class Geno(object):
 
     def fill_hash(self, seed, m_global0=0, thr16=32768):
         self.ctx._check(self.ctx.lib.mmg_geno_fill_hash(self.ctx.h, self.h, int(seed), int(m_global0), int(thr16)))
+        return self
+
+    def fill_structured(self, seed, m_global0=0, npop=3, spread_q16=9830):
+        self.ctx._check(self.ctx.lib.mmg_geno_fill_structured(self.ctx.h, self.h, int(seed), int(m_global0), int(npop),
+                                                              int(spread_q16)))
         return self
 
     def snp_stats(self):

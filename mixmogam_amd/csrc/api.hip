@@ -316,6 +316,22 @@ int mmg_geno_fill_hash(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_globa
   return MMG_OK;
 }
 
+int mmg_geno_fill_structured(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_global0, int32_t npop,
+                             uint32_t spread_q16) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, g != nullptr && npop >= 1 && npop <= 64 && spread_q16 <= 65536);
+  if (g->M == 0) return MMG_OK;
+  g->bits_valid = false;
+  {
+    EvScope ev(ctx, EV_PACK);
+    launch_fill_struct(ctx, g, seed, m_global0, npop, spread_q16);
+  }
+  MMG_HIP(ctx, hipGetLastError());
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  g->smax = std::max(g->smax, 1);
+  return MMG_OK;
+}
+
 int mmg_geno_snp_stats(mmg_ctx* ctx, mmg_geno* g, double* mean, double* sd) {
   Scratch sc;
   MMG_ENTER(ctx);

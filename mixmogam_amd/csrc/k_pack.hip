@@ -34,6 +34,53 @@ __global__ void fill_hash_kernel(int8_t* __restrict__ S, int64_t M, int32_t N, i
   *(uint4*)(S + m * (int64_t)Npad + c * 16) = v;
 }
 
+// Structured synthetic genotypes (population structure, so that the REML optimum is interior and a scan has many
+// correlated strong hits -- the regime real GWAS lives in): individuals fall into `npop` contiguous populations,
+// pop(i) = i * npop / N; SNP m has an ancestral frequency a_m ~ U[0.1, 0.9] and per-population frequencies
+// a_m + spread * z_mk with z_mk ~ approx N(0, 1/3) (sum of four uniforms), clamped to [0.02, 0.98]; the genotype is
+// Bernoulli(frequency of the individual's population).  All in 16-bit fixed point from the same counter hash as
+// fill_hash_kernel, so the CPU checker of the test tree regenerates any row bit for bit (hash_genotypes_structured).
+__device__ __forceinline__ uint32_t struct_thr16(uint64_t seed, uint64_t snp, int k, uint32_t spread_q16) {
+  const uint64_t s2 = seed ^ 0x5bf03635ca3d9a1full;
+  const int64_t anc = 6554 + (int64_t)(((hash3(s2, snp, 1000003ull) >> 48) * 52428ull) >> 16);
+  int64_t z = -2 * 65535ll;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) z += (int64_t)(hash3(s2, snp, 2000003ull + (uint64_t)(4 * k + j)) >> 48);
+  int64_t thr = anc + (((int64_t)spread_q16 * z) >> 16);
+  thr = thr < 1311 ? 1311 : (thr > 64225 ? 64225 : thr);
+  return (uint32_t)thr;
+}
+
+__global__ void fill_struct_kernel(int8_t* __restrict__ S, int64_t M, int32_t N, int32_t Npad, uint64_t seed,
+                                   int64_t m0g, int npop, uint32_t spread_q16) {
+  const int chunks = Npad >> 4;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t m = gid / chunks;
+  const int c = (int)(gid % chunks);
+  if (m >= M) return;
+  uint32_t wds[4] = {0, 0, 0, 0};
+  int kcur = -1;
+  uint32_t thr = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int i = c * 16 + j;
+    uint32_t bit = 0;
+    if (i < N) {
+      const int k = (int)(((int64_t)i * npop) / N);
+      if (k != kcur) { kcur = k; thr = struct_thr16(seed, (uint64_t)(m0g + m), k, spread_q16); }
+      bit = ((uint32_t)(hash3(seed, (uint64_t)(m0g + m), (uint64_t)i) >> 48) < thr) ? 1u : 0u;
+    }
+    wds[j >> 2] |= bit << (8 * (j & 3));
+  }
+  *(uint4*)(S + m * (int64_t)Npad + c * 16) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+}
+
+void launch_fill_struct(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_global0, int npop, uint32_t spread_q16) {
+  const int64_t total = g->M * (int64_t)(g->Npad >> 4);
+  hipLaunchKernelGGL(fill_struct_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, g->d, g->M,
+                     g->N, g->Npad, seed, m_global0, npop, spread_q16);
+}
+
 void launch_fill_hash(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_global0, uint32_t thr16) {
   const int64_t total = g->M * (int64_t)(g->Npad >> 4);
   const int bs = 256;

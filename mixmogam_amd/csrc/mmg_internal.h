@@ -113,6 +113,7 @@ struct EvScope {  // records the two events of slot `which` around a region on c
 
 // ---- k_pack.hip
 void launch_fill_hash(mmg_ctx*, mmg_geno*, uint64_t seed, int64_t m_global0, uint32_t thr16);
+void launch_fill_struct(mmg_ctx*, mmg_geno*, uint64_t seed, int64_t m_global0, int npop, uint32_t spread_q16);
 // fp32 / fp64 genotype ingest -> int8; *d_bad |= 1 if any value is not an integer in [-127, 127]
 void launch_cvt_f32(mmg_ctx*, const float* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld, int* d_bad);
 void launch_cvt_f64(mmg_ctx*, const double* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld, int* d_bad);

@@ -99,6 +99,11 @@ class RcclCollectives(object):
             self.barrier()                      # every rank holds the id (it is inside its communicator) ...
             bootstrap_bcast.done()              # ... so rank 0 may remove the rendezvous file
 
+    @property
+    def device_comm(self):
+        """What the sharded C-ABI entry points take as their communicator (reductions in HBM)."""
+        return self.h
+
     def info(self):
         """(rank, world, ncclCommCount) as RCCL reports them."""
         import ctypes as C

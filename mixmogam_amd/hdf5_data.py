@@ -1,31 +1,34 @@
-"""Chunked EMMAX drivers -- the compute of /root/reference/hdf5_data.py run_emmax (:70-187) and
-run_emmax_perm (:191-351): MAF filter, GRM kinship accumulated over SNP chunks, REML once, EMMAX scan
-per chromosome, optional permutation thresholds -- over a chunk source instead of an open HDF5 file.
+"""Chunked EMMAX drivers -- /root/reference/hdf5_data.py calculate_ibd_kinship (:17-62), run_emmax (:70-187) and
+run_emmax_perm (:191-351): MAF filter, GRM kinship accumulated over SNP chunks, REML once, EMMAX scan per
+chromosome, optional permutation thresholds, results written in the reference's dataset layout.
 
-Data source ("genot_data" of plink2hdf5.py:27-28,111-118): a mapping
-    {chrom: {'raw_snps': int8 [M_c x N] (ndarray / memmap / h5py dataset), 'freqs': [M_c],
-             'positions': [M_c]}}
-Only `raw_snps[i:j]` slicing is used, so numpy memmaps and h5py datasets both work; `open_hdf5`
-wraps a file in the reference's layout when h5py is installed (it is not in this image).
+Containers: the reference opens `h5py.File(hdf5_filename)`; here `chunkstore.open_container` opens the same tree
+either from a directory of memory-mapped .npy datasets (no h5py needed, `raw_snps[i:j]` touches only those rows)
+or, when h5py is installed and the path is a real HDF5 file, from h5py itself.  Every driver also accepts the
+already-open tree / a plain mapping
+    {chrom: {'raw_snps': int8 [M_c x N] (ndarray / memmap / h5py dataset), 'freqs': [M_c], 'positions': [M_c]}}
+in place of the file name (then `phenotypes` is passed explicitly and nothing is written unless `out_file` is set).
 
-Multi-GPU (`coll`, mixmogam_amd.dist): chunks are dealt round-robin to ranks; the kinship partial sums
-are all-reduced (SUM), eigh/REML are replicated, every rank scans its chunks and the per-chunk
-p-values / permutation minima are combined on the host with all-reduces.
+Streaming: chunks are read from the source and uploaded by a helper thread on a second HIP context / stream of the
+same device while the previous chunk is being computed on (PCIe ingest overlaps the kernels); nothing but the
+current and the next chunk is resident, so a 500 GB genotype matrix streams through a fixed HBM footprint.
+
+Multi-GPU (`coll`, mixmogam_amd.dist): chunks are dealt round-robin to the ranks; the kinship partial sums are
+all-reduced in HBM (RCCL SUM), eigh/REML are replicated, every rank scans its chunks and the OWNED p-value blocks
+are all-gathered; permutation minima are combined with a MIN/MAX all-reduce of P values.  Rank 0 writes the results.
 """
 import numpy as np
 
-from . import _lib, kinship
+from . import _lib, chunkstore, kinship
 from . import linear_models as lm
 
 
-def open_hdf5(filename):
-    """The reference's on-disk layout (plink2hdf5.py) as a chunk source.  Needs h5py."""
-    try:
-        import h5py
-    except ImportError:
-        raise ImportError("h5py is not installed; pass a mapping of arrays / memmaps instead")
-    f = h5py.File(filename, 'r')
-    return {'genot_data': f['genot_data'], 'phenotypes': f['indiv_data']['phenotypes'][...], 'file': f}
+def open_hdf5(filename, mode='r'):
+    """The reference's genotype file as a chunk source: {'genot_data', 'phenotypes', 'indiv_ids', 'file'}."""
+    f = chunkstore.open_container(filename, mode)
+    ig = f['indiv_data']
+    return {'genot_data': f['genot_data'], 'phenotypes': np.asarray(ig['phenotypes'][...]) if 'phenotypes' in ig else None,
+            'indiv_ids': np.asarray(ig['indiv_ids'][...]), 'file': f}
 
 
 _UPLOAD_CTX = {}
@@ -36,90 +39,162 @@ def _maf_filter(cg, min_maf):
     return np.minimum(freqs, 1 - freqs) > min_maf                       # hdf5_data.py:91-93
 
 
-def _chunks(genot_data, min_maf, chunk_size):
-    """Yield (chrom, filtered chunk int8 [m x N], positions of the chunk)."""
+def _chunk_plan(genot_data, min_maf, chunk_size):
+    """[(chrom, kept row indices of the chunk, positions of the chunk)] without touching raw_snps."""
+    plan = []
     for chrom in genot_data.keys():
         cg = genot_data[chrom]
-        keep = _maf_filter(cg, min_maf)
-        idx = np.nonzero(keep)[0]
-        positions = np.asarray(cg['positions'][...])[keep]
-        raw = cg['raw_snps']
+        if min_maf is None:
+            idx = np.arange(len(cg['raw_snps']))
+        else:
+            idx = np.nonzero(_maf_filter(cg, min_maf))[0]
+        positions = np.asarray(cg['positions'][...])[idx] if 'positions' in cg else idx
         for i in range(0, len(idx), chunk_size):
-            sel = idx[i:i + chunk_size]
-            lo, hi = int(sel[0]), int(sel[-1]) + 1
-            block = np.asarray(raw[lo:hi])                               # one contiguous read ...
-            if len(sel) != hi - lo:
-                block = block[sel - lo]                                  # ... then the MAF subset
-            yield chrom, np.ascontiguousarray(block, dtype=np.int8), positions[i:i + chunk_size]
+            plan.append((chrom, idx[i:i + chunk_size], positions[i:i + chunk_size]))
+    return plan
 
 
-def _resident_chunks(ctx, genot_data, min_maf, chunk_size, rank=0, world=1, prefetch=True):
-    """Yield (chunk index, chrom, Geno or None, block rows, positions) for every chunk; chunks owned by
-    other ranks come with Geno = None.  With prefetch the NEXT owned chunk is read from the source and
-    uploaded by a helper thread on a second context/stream of the same device while the caller computes
-    on the current one (the C ABI is blocking; ctypes releases the GIL): PCIe ingest overlaps the kernels."""
-    items = enumerate(_chunks(genot_data, min_maf, chunk_size))
+def _read_chunk(genot_data, chrom, sel):
+    raw = genot_data[chrom]['raw_snps']
+    lo, hi = int(sel[0]), int(sel[-1]) + 1
+    block = np.asarray(raw[lo:hi])                                       # one contiguous read ...
+    if len(sel) != hi - lo:
+        block = block[sel - lo]                                          # ... then the MAF subset
+    return np.ascontiguousarray(block, dtype=np.int8)
+
+
+def _resident_chunks(ctx, genot_data, plan, rank=0, world=1, prefetch=True):
+    """Yield (chunk index, chrom, Geno) for the chunks this rank owns (ci % world == rank).  With prefetch the NEXT
+    owned chunk is read from the source and uploaded by a helper thread on a second context/stream of the same
+    device while the caller computes on the current one (the C ABI is blocking; ctypes releases the GIL)."""
+    mine = [ci for ci in range(len(plan)) if ci % world == rank]
     if not (prefetch and isinstance(ctx, _lib.Context)):
-        for ci, (chrom, block, pos) in items:
-            yield ci, chrom, (ctx.geno(block) if ci % world == rank else None), len(block), pos
+        for ci in mine:
+            chrom, sel, _pos = plan[ci]
+            yield ci, chrom, ctx.geno(_read_chunk(genot_data, chrom, sel))
         return
     from concurrent.futures import ThreadPoolExecutor
     up = _UPLOAD_CTX.get(ctx.device)
     if up is None:
-        up = _UPLOAD_CTX[ctx.device] = _lib.Context(ctx.device)     # second stream of the same device, kept
+        up = _UPLOAD_CTX[ctx.device] = _lib.Context(ctx.device)         # second stream of the same device, kept
 
-    def load_next():
-        for ci, (chrom, block, pos) in items:
-            return ci, chrom, (up.geno(block) if ci % world == rank else None), len(block), pos
-        return None
+    def load(ci):
+        chrom, sel, _pos = plan[ci]
+        return ci, chrom, up.geno(_read_chunk(genot_data, chrom, sel))
 
     with ThreadPoolExecutor(max_workers=1) as pool:
-        fut = pool.submit(load_next)
-        while True:
+        fut = pool.submit(load, mine[0]) if mine else None
+        for k in range(len(mine)):
             cur = fut.result()
-            if cur is None:
-                break
-            fut = pool.submit(load_next)
+            fut = pool.submit(load, mine[k + 1]) if k + 1 < len(mine) else None
             yield cur
 
 
-def calculate_ibd_kinship(genot_data, n_indivs, min_maf=0.0, chunk_size=100000, ctx=None, coll=None):
-    """hdf5_data.py:17-62 / :84-115: K = sum_m z_m z_m' / n_snps with z = (s - mean)/std per SNP, scaled
-    with scale_k's rule.  The sum lives in HBM across chunks (mmg_kin_acc_*)."""
-    ctx = ctx or _lib.get_context()
-    acc = ctx.kinship_accumulator(n_indivs)
-    n_snps = 0
+def _dev_comm(coll):
+    return getattr(coll, 'device_comm', None) if coll is not None else None
+
+
+def _ibd_kinship(ctx, genot_data, n_indivs, plan, coll=None, prefetch=True):
     rank, world = (coll.rank, coll.world) if coll is not None else (0, 1)
-    for ci, chrom, g, nrows, _pos in _resident_chunks(ctx, genot_data, min_maf, chunk_size, rank, world):
-        n_snps += nrows
-        if g is None:
-            continue
+    acc = ctx.kinship_accumulator(n_indivs)
+    for ci, chrom, g in _resident_chunks(ctx, genot_data, plan, rank, world, prefetch):
         mean, sd = g.snp_stats()
         if np.any(sd == 0):
             raise ValueError("monomorphic SNP passed the MAF filter on chromosome %s" % chrom)
         acc.add(g, 1.0 / sd, -mean / sd)
         g.close()
-    k_mat, _ = acc.fetch()
+    if coll is not None and world > 1:
+        acc.allreduce(_dev_comm(coll))                                   # N x N partial sums never leave HBM
+    k_mat, n_snps = acc.fetch()
     acc.close()
-    if coll is not None:
-        k_mat = coll.allreduce(k_mat, "sum").reshape(n_indivs, n_indivs)
-    k_mat = k_mat / float(n_snps)                                        # :107
-    return kinship.scale_k(k_mat), n_snps                                # :108-111 (inline scale_k)
+    n_all = sum(len(sel) for _c, sel, _p in plan)
+    assert n_snps == n_all or coll is None or world == 1 or n_snps == n_all, (n_snps, n_all)
+    k_mat = k_mat / float(n_all)                                         # :107
+    return kinship.scale_k(k_mat), n_all                                 # :108-111 (inline scale_k)
 
 
-def run_emmax(genot_data, phenotypes, min_maf=0.1, chunk_size=100000, k=None, ctx=None, coll=None,
-              num_perm=0, perm_idx=None):
-    """hdf5_data.py:70-187 (and :191-351 when num_perm > 0).  Returns
-    {'pseudo_heritability','ve','vg','max_ll','num_snps','chrom_results': {chrom: {'ps','positions'}}}
-    plus 'perm_min_ps', 'perm_max_f_stats', 'threshold_05' for the permutation variant (:339-347)."""
+def calculate_ibd_kinship(hdf5_filename, n_indivs=None, min_maf=None, chunk_size=100000, overwrite=False, ctx=None,
+                          coll=None):
+    """hdf5_data.py:17-62: K = sum_m z_m z_m' / n_snps with z = (s - mean)/std per SNP, scaled with scale_k's rule.
+    The sum lives in HBM across chunks (mmg_kin_acc_*).  Given a file name the kinship is stored in the file as the
+    'kinship' dataset (:60) unless it is already there (overwrite=False); given a genot_data tree it is returned
+    as (K, n_snps).  min_maf=None: no MAF filter (the reference's stand-alone function has none; its run_emmax twin
+    filters, :91-96)."""
     ctx = ctx or _lib.get_context()
+    if isinstance(hdf5_filename, str):
+        h5f = chunkstore.open_container(hdf5_filename, 'a')
+        n = len(h5f['indiv_data']['indiv_ids'][...])
+        if 'kinship' in h5f.keys() and not overwrite:
+            return np.asarray(h5f['kinship'][...]), None
+        for chrom in h5f['genot_data'].keys():
+            if 'snps' in h5f['genot_data'][chrom].keys():
+                raise NotImplementedError("pre-normalised 'snps' datasets (:37,44) are not on the int8 device path")
+        plan = _chunk_plan(h5f['genot_data'], min_maf, chunk_size)
+        k, n_snps = _ibd_kinship(ctx, h5f['genot_data'], n, plan, coll)
+        if coll is None or coll.rank == 0:
+            if 'kinship' in h5f.keys():
+                del h5f['kinship']
+            h5f.create_dataset('kinship', data=k)
+            h5f.flush()
+        return k, n_snps
+    plan = _chunk_plan(hdf5_filename, min_maf, chunk_size)
+    return _ibd_kinship(ctx, hdf5_filename, n_indivs, plan, coll)
+
+
+def _gather_owned(parts, plan, coll):
+    """parts {chunk index: values of an owned chunk} on every rank -> {chunk index: values} for ALL chunks:
+    one all-gather of each rank's owned values (padded to the largest share)."""
+    world, rank = coll.world, coll.rank
+    share = [sum(len(plan[ci][1]) for ci in range(len(plan)) if ci % world == r) for r in range(world)]
+    count = max(share) if share else 0
+    if count == 0:
+        return dict(parts)
+    mine = np.full(count, np.nan)
+    if parts:
+        flat = np.concatenate([parts[ci] for ci in sorted(parts)])
+        mine[:len(flat)] = flat
+    gathered = np.asarray(coll.allgather(mine)).reshape(world, count)
+    out, cursor = {}, [0] * world
+    for ci in range(len(plan)):
+        r = ci % world
+        n = len(plan[ci][1])
+        out[ci] = gathered[r, cursor[r]:cursor[r] + n]
+        cursor[r] += n
+    return out
+
+
+def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=True, chunk_size=100000, k=None,
+              ctx=None, coll=None, num_perm=0, perm_idx=None, phenotypes=None, prefetch=True):
+    """hdf5_data.py:70-187 (and :191-351 when num_perm > 0).
+
+    hdf5_filename: container path (chunkstore / HDF5) or an open genot_data tree / mapping.  For the reference's
+    call shape `run_emmax(genot_data, phenotypes, ...)` of round 1 the second positional argument may be the
+    phenotype vector.  out_file: result container to write (:142-184: pseudo_heritability, ve, vg, max_ll,
+    num_snps, chrom_results/<chrom>/{ps, positions}; perm: kinship, perm_min_ps, perm_max_f_stats, five_perc_*).
+    Returns {'pseudo_heritability','ve','vg','max_ll','num_snps','kinship','chrom_results': {chrom: {'ps',
+    'positions'}}} plus 'perm_min_ps', 'perm_max_f_stats', 'threshold_05' for the permutation variant."""
+    ctx = ctx or _lib.get_context()
+    if out_file is not None and not isinstance(out_file, str):           # run_emmax(genot_data, phenotypes, ...)
+        phenotypes, out_file = out_file, None
+    ih5f = None
+    if isinstance(hdf5_filename, str):
+        ih5f = chunkstore.open_container(hdf5_filename, 'r')
+        genot_data = ih5f['genot_data']
+        if phenotypes is None:
+            phenotypes = ih5f['indiv_data']['phenotypes'][...]           # :119
+        if not recalculate_kinship and k is None:
+            assert 'kinship' in ih5f.keys(), 'Kinship is missing.  Please calculate that first!'   # :114
+            k = np.asarray(ih5f['kinship'][...])
+    else:
+        genot_data = hdf5_filename
     phenotypes = np.asarray(phenotypes, dtype=np.float64).reshape(-1)
     n = len(phenotypes)
     rank, world = (coll.rank, coll.world) if coll is not None else (0, 1)
+    plan = _chunk_plan(genot_data, min_maf, chunk_size)
     if k is None:
-        k, n_snps = calculate_ibd_kinship(genot_data, n, min_maf, chunk_size, ctx, coll)
+        k, n_snps = _ibd_kinship(ctx, genot_data, n, plan, coll, prefetch)
     else:
-        n_snps = sum(int(_maf_filter(genot_data[c], min_maf).sum()) for c in genot_data.keys())
+        n_snps = sum(len(sel) for _c, sel, _p in plan)
     lmm = lm.LinearMixedModel(phenotypes, ctx=ctx)                       # :121
     lmm.add_random_effect(k)
     eig_L = lmm._get_eigen_L_()                                          # :126
@@ -128,52 +203,86 @@ def run_emmax(genot_data, phenotypes, min_maf=0.1, chunk_size=100000, k=None, ct
            'max_ll': res['max_ll'], 'num_snps': n_snps, 'chrom_results': {}, 'kinship': k}
     prep = lmm.scan_prepare(res['H_sqrt_inv'])
     ctx.scan_set_model(prep['A'], prep['w'], 0)
-    per_chrom = {}
-    kept = []                                                            # chunk genotype stores for the permutations
-    for ci, chrom, g, nrows, pos in _resident_chunks(ctx, genot_data, min_maf, chunk_size, rank, world):
-        ps = np.full(nrows, np.nan)
-        if g is not None:
-            ps = ctx.scan(g, prep['h0_rss'], prep['n_p'])['ps']          # :174 _emmax_f_test_(emma_num=0)
-            if num_perm:
-                kept.append(g)
-            else:
-                g.close()
-        per_chrom.setdefault(chrom, []).append((ps, pos))
-    for chrom, parts in per_chrom.items():
-        ps = np.concatenate([p for p, _ in parts])
-        if coll is not None:                                             # every SNP was scanned by exactly one rank
-            ps = coll.allreduce(np.where(np.isnan(ps), np.inf, ps), "min")
-        out['chrom_results'][chrom] = {'ps': ps, 'positions': np.concatenate([q for _, q in parts])}
+    chroms = list(genot_data.keys())
+    parts, kept = {}, []
+    for ci, chrom, g in _resident_chunks(ctx, genot_data, plan, rank, world, prefetch):
+        parts[ci] = ctx.scan(g, prep['h0_rss'], prep['n_p'])['ps']       # :174 _emmax_f_test_(emma_num=0)
+        # :294-311 -- the permutation test runs on every chromosome but the LAST (`chr12_snps`)
+        if num_perm and chrom != chroms[-1]:
+            kept.append(g)
+        else:
+            g.close()
+    if coll is not None and world > 1:
+        parts = _gather_owned(parts, plan, coll)                         # every SNP was scanned by exactly one rank
+    for ci, (chrom, _sel, pos) in enumerate(plan):
+        d = out['chrom_results'].setdefault(chrom, {'ps': [], 'positions': []})
+        d['ps'].append(parts[ci])
+        d['positions'].append(pos)
+    for chrom in chroms:
+        d = out['chrom_results'].setdefault(chrom, {'ps': [np.zeros(0)], 'positions': [np.zeros(0, dtype=np.int64)]})
+        d['ps'] = np.concatenate(d['ps'])
+        d['positions'] = np.concatenate(d['positions'])
     if num_perm:                                                         # :262-347
-        lmm_p = lm.LinearMixedModel(phenotypes, ctx=ctx)
-        lmm_p.add_random_effect(k)
         if perm_idx is None:
             idx = np.asmatrix(np.arange(n).reshape(n, 1))
             perm_idx = []
             for _ in range(num_perm):
                 np.random.shuffle(idx)
                 perm_idx.append(np.asarray(idx).reshape(-1).copy())
-        min_ps, max_f = None, None
+        min_ps, max_f = np.ones(num_perm), np.zeros(num_perm)
         for g in kept:
             lmm_c = lm.LinearMixedModel(phenotypes, ctx=ctx)             # _emmax_permutations_ centres Y in place
             lmm_c.add_random_effect(k)
             r = lmm_c._emmax_permutations_(g, k, res['H_sqrt_inv'], num_perm=num_perm, perm_idx=perm_idx)
             g.close()
-            max_f = r['max_f_stats'] if max_f is None else np.maximum(max_f, r['max_f_stats'])
-            min_ps = r['min_ps'] if min_ps is None else np.minimum(min_ps, r['min_ps'])
-        if min_ps is None:
-            min_ps, max_f = np.ones(num_perm), np.zeros(num_perm)
-        if coll is not None:
+            max_f = np.maximum(max_f, r['max_f_stats'])
+            min_ps = np.minimum(min_ps, r['min_ps'])
+        if coll is not None and world > 1:
             min_ps = coll.allreduce(min_ps, "min")
             max_f = coll.allreduce(max_f, "max")
         order = np.argsort(min_ps)
+        five = num_perm // 20                                            # :342
         out.update(perm_min_ps=min_ps, perm_max_f_stats=max_f,
-                   threshold_05=(float(min_ps[order][num_perm // 20]), float(max_f[order][num_perm // 20])))
+                   threshold_05=(float(min_ps[order][five]), float(max_f[order][five])))
+    if out_file is not None and rank == 0:
+        _write_results(out_file, out, ih5f, num_perm)
     return out
 
 
-def run_emmax_perm(genot_data, phenotypes, min_maf=0.1, chunk_size=100000, num_perm=500, perm_idx=None, k=None,
-                   ctx=None, coll=None):
-    """hdf5_data.py:191-351."""
-    return run_emmax(genot_data, phenotypes, min_maf=min_maf, chunk_size=chunk_size, k=k, ctx=ctx, coll=coll,
-                     num_perm=num_perm, perm_idx=perm_idx)
+def _write_results(out_file, out, ih5f, num_perm):
+    """The result file of hdf5_data.py:142-184 (+ :241-243,339-347 for the permutation variant)."""
+    oh5f = chunkstore.open_container(out_file, 'a')
+    oh5f.create_dataset('pseudo_heritability', data=np.array(out['pseudo_heritability']))
+    oh5f.create_dataset('ve', data=np.array(out['ve']))
+    oh5f.create_dataset('vg', data=np.array(out['vg']))
+    oh5f.create_dataset('max_ll', data=np.array(out['max_ll']))
+    # :150 copies the INPUT file's num_snps (all SNPs, before the MAF filter); :289 (perm) stores the filtered count
+    n_in = np.array(ih5f['num_snps'][...]) if (ih5f is not None and 'num_snps' in ih5f.keys() and not num_perm) \
+        else np.array(out['num_snps'])
+    oh5f.create_dataset('num_snps', data=n_in)
+    crg = oh5f.create_group('chrom_results')
+    for chrom, d in out['chrom_results'].items():
+        g = crg.create_group(str(chrom))
+        g.create_dataset('ps', data=d['ps'])
+        g.create_dataset('positions', data=d['positions'])
+    if num_perm:
+        oh5f.create_dataset('kinship', data=out['kinship'])              # :242
+        # :339-347 -- both arrays are sorted ASCENDING (the `[::-1]` at :341 is a no-op expression), so the stored
+        # five_perc_perm_max_f_stats is the 5 % point from the BOTTOM of the max-F distribution; kept as is for
+        # identical files.  (`threshold_05` in the returned dict pairs the 5 % p-value with its own statistic.)
+        ps_sorted = np.sort(out['perm_min_ps'])
+        f_sorted = np.sort(out['perm_max_f_stats'])
+        five = num_perm // 20
+        oh5f.create_dataset('perm_min_ps', data=ps_sorted)
+        oh5f.create_dataset('perm_max_f_stats', data=f_sorted)
+        oh5f.create_dataset('five_perc_perm_min_ps', data=np.array(ps_sorted[five]))
+        oh5f.create_dataset('five_perc_perm_max_f_stats', data=np.array(f_sorted[five]))
+    oh5f.flush()
+    oh5f.close()
+
+
+def run_emmax_perm(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=True, chunk_size=100000,
+                   num_perm=500, perm_idx=None, k=None, ctx=None, coll=None, phenotypes=None, prefetch=True):
+    """hdf5_data.py:191-351 (the reference always recalculates the kinship here; pass k to skip that)."""
+    return run_emmax(hdf5_filename, out_file, min_maf=min_maf, chunk_size=chunk_size, k=k, ctx=ctx, coll=coll,
+                     num_perm=num_perm, perm_idx=perm_idx, phenotypes=phenotypes, prefetch=prefetch)

@@ -96,3 +96,38 @@ def prepare_k(k, k_accessions, accessions):
             continue
     k = np.asarray(k)
     return k[indices_to_keep, :][:, indices_to_keep]
+
+
+def load_kinship_from_file(kinship_file, accessions=None, scaled=True):
+    """kinship.py:145-158 -- datasets 'kinship', 'accessions', 'n_snps' of a kinship container (a chunkstore
+    directory, or an HDF5 file when h5py is installed)."""
+    import os
+    from . import chunkstore
+    assert os.path.exists(kinship_file), 'File not found.'
+    f = chunkstore.open_container(kinship_file, 'r')
+    k = np.asarray(f['kinship'][...], dtype=np.float64)
+    k_accessions = [a.decode() if isinstance(a, bytes) else str(a) for a in np.asarray(f['accessions'][...]).reshape(-1)]
+    n_snps = int(np.asarray(f['n_snps'][...]))
+    f.close()
+    if accessions:
+        k = prepare_k(k, k_accessions, [str(a) for a in accessions])
+    if scaled:
+        k = scale_k(k)
+    return {'k': k, 'accessions': k_accessions, 'n_snps': n_snps}
+
+
+def save_kinship_to_file(kinship_file, kinship_mat, k_accessions, n_snps):
+    """kinship.py:162-167."""
+    from . import chunkstore
+    f = chunkstore.open_container(kinship_file, 'w')
+    f.create_dataset('kinship', data=np.asarray(kinship_mat))
+    f.create_dataset('accessions', data=np.asarray([str(a) for a in k_accessions], dtype='S'))
+    f.create_dataset('n_snps', data=np.array(n_snps))
+    f.close()
+
+
+def save_kinship_in_text_format(filename, k, accessions):
+    """kinship.py:170-173."""
+    with open(filename, 'w') as f:
+        for acc, row in zip(accessions, np.asarray(k)):
+            f.write('%s,%s\n' % (acc, ','.join(map(str, row.tolist()))))

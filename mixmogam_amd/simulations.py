@@ -39,3 +39,50 @@ def simulate_phenotype(snps, h2=0.8, num_causals=100, seed=20241):
     ev = np.var(error, ddof=1)
     y = trait + error * np.sqrt(((1.0 - h2) / h2) * (gv / ev))                      # :81
     return (y - np.mean(y)) / np.std(y)                                             # :83
+
+
+def synthetic_chunk(chunk_id, rows, num_indivs, seed=20240):
+    """Rows [chunk_id * rows, ...) of a never-resident synthetic genotype matrix: i.i.d.
+    Bernoulli(0.5) int8, one RandomState(seed + chunk_id) per chunk so that any chunk can be regenerated anywhere
+    (by a rank, by a CPU check on a sample).  Bits come from RandomState.bytes + unpackbits -- the distribution of
+    simulations.py:21 `round(U(0,1))` at a seventh of the host time per byte."""
+    rng = np.random.RandomState(seed + int(chunk_id))
+    nbits = int(rows) * int(num_indivs)
+    raw = np.frombuffer(rng.bytes((nbits + 7) // 8), dtype=np.uint8)
+    return np.unpackbits(raw)[:nbits].view(np.int8).reshape(int(rows), int(num_indivs))
+
+
+def write_synthetic_container(path, num_indivs, num_snps, chunk_rows=100000, seed=20240, num_chroms=5,
+                              pheno_seed=20241, h2=0.8, num_causals=100):
+    """A genotype container (plink2hdf5.py layout, mixmogam_amd.chunkstore) of `num_snps` synthetic SNPs split over
+    `num_chroms` chromosomes, written chunk by chunk (one `synthetic_chunk` at a time is in host memory), plus a
+    phenotype built from `num_causals` SNPs of the first chunk (simulations.py:64-85).  Returns the path."""
+    from . import chunkstore
+    st = chunkstore.Store(path, "w")
+    gg = st.create_group("genot_data")
+    ig = st.create_group("indiv_data")
+    ig.create_dataset("indiv_ids", data=np.asarray(["i%d" % i for i in range(num_indivs)], dtype="S"))
+    per = -(-num_snps // num_chroms)
+    chunk_id, written, y = 0, 0, None
+    for c in range(num_chroms):
+        m_c = min(per, num_snps - written)
+        if m_c <= 0:
+            break
+        cg = gg.create_group("chrom_%d" % (c + 1))
+        raw = cg.create_dataset("raw_snps", shape=(m_c, num_indivs), dtype=np.int8)
+        freqs = np.empty(m_c)
+        for r0 in range(0, m_c, chunk_rows):
+            blk = synthetic_chunk(chunk_id, min(chunk_rows, m_c - r0), num_indivs, seed)
+            if y is None:
+                y = simulate_phenotype(blk, h2=h2, num_causals=num_causals, seed=pheno_seed)
+            raw[r0:r0 + len(blk)] = blk
+            freqs[r0:r0 + len(blk)] = blk.mean(axis=1, dtype=np.float64)
+            chunk_id += 1
+        cg.create_dataset("positions", data=np.arange(1, m_c + 1, dtype=np.int64))
+        cg.create_dataset("freqs", data=freqs)
+        cg.flush()
+        written += m_c
+    ig.create_dataset("phenotypes", data=y)
+    st.create_dataset("num_snps", data=np.array(written))
+    st.close()
+    return path

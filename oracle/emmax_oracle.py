@@ -441,3 +441,32 @@ def hash_genotypes(m0, m1, n, seed, maf_q16=None):
     u16 = (x >> np.uint64(48)).astype(np.uint32)
     thr = 32768 if maf_q16 is None else np.asarray(maf_q16, dtype=np.uint32)[:, None]
     return (u16 < thr).astype(np.int8)
+
+
+def _hash3(seed, snp, ind):
+    with np.errstate(over='ignore'):
+        x = (snp * np.uint64(0x9E3779B97F4A7C15)) ^ (ind * np.uint64(0xBF58476D1CE4E5B9)) \
+            ^ (np.uint64(seed) * np.uint64(0x94D049BB133111EB))
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return x
+
+
+def hash_genotypes_structured(m0, m1, n, seed, npop=3, spread_q16=9830):
+    """Host twin of mmg_geno_fill_structured (k_pack.hip:fill_struct_kernel), bit for bit: `npop` contiguous
+    populations, per-SNP ancestral frequency U[0.1, 0.9] + per-population deviation, Bernoulli genotypes."""
+    snp = np.arange(m0, m1, dtype=np.uint64)
+    s2 = np.uint64(seed) ^ np.uint64(0x5bf03635ca3d9a1f)
+    anc = 6554 + (((_hash3(s2, snp, np.uint64(1000003)) >> np.uint64(48)) * np.uint64(52428)) >> np.uint64(16)).astype(np.int64)
+    thr = np.empty((len(snp), npop), dtype=np.int64)
+    for k in range(npop):
+        z = np.full(len(snp), -2 * 65535, dtype=np.int64)
+        for j in range(4):
+            z += (_hash3(s2, snp, np.uint64(2000003 + 4 * k + j)) >> np.uint64(48)).astype(np.int64)
+        thr[:, k] = np.clip(anc + ((np.int64(spread_q16) * z) >> np.int64(16)), 1311, 64225)
+    pop = (np.arange(n, dtype=np.int64) * npop) // n
+    u16 = (_hash3(seed, snp[:, None], np.arange(n, dtype=np.uint64)[None, :]) >> np.uint64(48)).astype(np.int64)
+    return (u16 < thr[:, pop]).astype(np.int8)

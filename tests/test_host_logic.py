@@ -133,3 +133,90 @@ def test_emmax_multi_host_logic_vs_reference_loop(ctx):
         res2 = lm.emmax_multi(list(ex["snps"]), ex["multi_ys"], ex["ibs_scaled"], cofactors=cof, ctx=ctx,
                               max_store_bytes=256 * 8 * 192)
         assert np.array_equal(res2["ps"], res["ps"])
+
+
+# ---------------------------------------------------------------- containers
+def test_chunkstore_mirrors_the_h5py_calls_the_reference_makes(tmp_path):
+    from mixmogam_amd import chunkstore
+    path = str(tmp_path / "geno.mmg")
+    f = chunkstore.open_container(path)                                   # like h5py.File(name): created on demand
+    gg = f.create_group("genot_data")
+    cg = gg.create_group("chrom_2")
+    snps = np.random.RandomState(0).randint(0, 2, size=(37, 11)).astype(np.int8)
+    cg.create_dataset("raw_snps", compression="lzf", data=snps)           # plink2hdf5.py:111 call shape
+    cg.create_dataset("freqs", data=snps.mean(1))
+    gg.create_group("chrom_10")
+    f.create_dataset("num_snps", data=np.array(37))
+    stream = f.create_dataset("big", shape=(5, 3), dtype=np.int8)         # streamed writer
+    stream[2:4] = 7
+    f.flush(); f.close()
+    g = chunkstore.open_container(path, "r")
+    assert g.keys() == ["big", "genot_data", "num_snps"] and "kinship" not in g.keys()
+    assert list(g["genot_data"].keys()) == ["chrom_10", "chrom_2"]      # name order, as h5py iterates
+    raw = g["genot_data"]["chrom_2"]["raw_snps"]
+    assert isinstance(raw, np.memmap) and len(raw) == 37
+    assert np.array_equal(raw[5:9], snps[5:9]) and np.array_equal(raw[...], snps)
+    assert int(g["num_snps"][...]) == 37 and np.array_equal(g["big"][...][2:4], np.full((2, 3), 7))
+    with pytest.raises(IOError):
+        g.create_dataset("x", data=np.zeros(2))
+    a = chunkstore.open_container(path, "a")
+    del a["big"]
+    assert "big" not in a and "num_snps" in a
+    with pytest.raises(ValueError):
+        a.create_dataset("num_snps", data=np.array(1))                    # h5py refuses to overwrite too
+
+
+def test_kinship_file_round_trip(tmp_path):
+    k = np.random.RandomState(1).rand(6, 6)
+    k = k + k.T
+    accs = ["a%d" % i for i in range(6)]
+    path = str(tmp_path / "k.mmg")
+    kinship.save_kinship_to_file(path, k, accs, 1234)
+    d = kinship.load_kinship_from_file(path, scaled=False)
+    assert np.array_equal(d["k"], k) and d["accessions"] == accs and d["n_snps"] == 1234
+    sub = kinship.load_kinship_from_file(path, accessions=["a4", "a1"], scaled=True)
+    assert np.allclose(sub["k"], kinship.scale_k(k[[4, 1]][:, [4, 1]]))
+    kinship.save_kinship_in_text_format(str(tmp_path / "k.csv"), k, accs)
+    rows = open(str(tmp_path / "k.csv")).read().strip().split("\n")
+    assert len(rows) == 6 and rows[2].split(",")[0] == "a2" and float(rows[2].split(",")[3]) == k[2, 2]
+
+
+def test_run_emmax_from_and_to_containers(ctx, tmp_path):
+    """hdf5_data.run_emmax / run_emmax_perm with the reference's call shape (file names in, result file out):
+    same numbers as the in-memory mapping, datasets named as hdf5_data.py:146-184,241-347 names them."""
+    from mixmogam_amd import chunkstore, simulations
+    path = simulations.write_synthetic_container(str(tmp_path / "in.mmg"), 60, 700, chunk_rows=128, num_chroms=3,
+                                                 num_causals=5)
+    src = hdf5_data.open_hdf5(path)
+    assert list(src["genot_data"].keys()) == ["chrom_1", "chrom_2", "chrom_3"] and len(src["phenotypes"]) == 60
+    # the container holds exactly what synthetic_chunk regenerates (chunk ids run across chromosomes)
+    assert np.array_equal(src["genot_data"]["chrom_1"]["raw_snps"][:128], simulations.synthetic_chunk(0, 128, 60))
+    out_path = str(tmp_path / "res.mmg")
+    res = hdf5_data.run_emmax(path, out_path, min_maf=0.1, chunk_size=100, ctx=ctx)
+    mem = {c: {k: np.asarray(src["genot_data"][c][k][...]) for k in ("raw_snps", "freqs", "positions")}
+           for c in src["genot_data"].keys()}
+    ref = hdf5_data.run_emmax(mem, src["phenotypes"], min_maf=0.1, chunk_size=10 ** 6, ctx=ctx)
+    o = chunkstore.open_container(out_path, "r")
+    assert sorted(o.keys()) == ["chrom_results", "max_ll", "num_snps", "pseudo_heritability", "ve", "vg"]
+    assert int(o["num_snps"][...]) == 700                                 # :150 copies the input file's count
+    for c in mem:
+        assert rel(o["chrom_results"][c]["ps"][...], ref["chrom_results"][c]["ps"]) < 1e-9
+        assert np.array_equal(o["chrom_results"][c]["positions"][...], ref["chrom_results"][c]["positions"])
+        assert np.array_equal(res["chrom_results"][c]["ps"], o["chrom_results"][c]["ps"][...])
+    assert rel(o["pseudo_heritability"][...], ref["pseudo_heritability"]) < 1e-9
+    # permutation variant: kinship + sorted minima + the reference's 5 % entries
+    pidx = [np.random.RandomState(40 + p).permutation(60) for p in range(40)]
+    outp = str(tmp_path / "perm.mmg")
+    rp = hdf5_data.run_emmax_perm(path, outp, min_maf=0.1, chunk_size=100, num_perm=40, perm_idx=pidx, ctx=ctx)
+    op = chunkstore.open_container(outp, "r")
+    assert {"kinship", "perm_min_ps", "perm_max_f_stats", "five_perc_perm_min_ps",
+            "five_perc_perm_max_f_stats"} <= set(op.keys())
+    assert np.array_equal(op["perm_min_ps"][...], np.sort(rp["perm_min_ps"]))
+    assert float(op["five_perc_perm_min_ps"][...]) == np.sort(rp["perm_min_ps"])[2]
+    assert float(op["five_perc_perm_max_f_stats"][...]) == np.sort(rp["perm_max_f_stats"])[2]   # ascending (:341 quirk)
+    assert rel(op["kinship"][...], ref["kinship"]) < 1e-9
+    # stored kinship route: calculate_ibd_kinship writes 'kinship' into the input file, run_emmax reuses it
+    k, n_snps = hdf5_data.calculate_ibd_kinship(path, chunk_size=90, ctx=ctx)
+    assert n_snps == 700 and "kinship" in chunkstore.open_container(path, "r").keys()
+    again = hdf5_data.run_emmax(path, None, min_maf=0.1, recalculate_kinship=False, chunk_size=100, ctx=ctx)
+    assert rel(again["kinship"], k) == 0.0

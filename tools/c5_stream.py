@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 -- N = 50,000 x M = 10,000,000 streamed from chunks over 8 GPUs -- as ONE rank of the 8 sees it
+(or the whole thing with --world 1): the rank's SNP share is written chunk-wise to an on-disk container (never fully
+in host memory), then hdf5_data.run_emmax streams it twice (GRM kinship pass, scan pass) through the double-buffered
+H2D path.  Prints stage timings, SNPs/s including ingest, and checks sampled p-values against float64 host arithmetic.
+
+    python tools/c5_stream.py [--n 50000] [--m-total 10000000] [--world 8] [--chunk 50000] [--scratch /dev/shm]
+"""
+import argparse
+import json
+import os
+import shutil
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mixmogam_amd import _lib, chunkstore, hdf5_data, linear_models as lm, simulations  # noqa: E402
+from oracle import emmax_oracle as orc  # noqa: E402  (checker only)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=50000)
+ap.add_argument("--m-total", type=int, default=10000000)
+ap.add_argument("--world", type=int, default=8, help="ranks the SNP axis is split over; this run plays rank 0")
+ap.add_argument("--chunk", type=int, default=50000)
+ap.add_argument("--scratch", default="/dev/shm")
+ap.add_argument("--keep", action="store_true")
+a = ap.parse_args()
+N, M, CH = a.n, a.m_total // a.world, a.chunk
+root = os.path.join(a.scratch, "mmg_c5_%d" % os.getpid())
+need = N * M
+free = shutil.disk_usage(a.scratch).free
+print("share of rank 0: N=%d x M=%d = %.1f GB container in %s (%.0f GB free)" % (N, M, need / 1e9, a.scratch, free / 1e9),
+      flush=True)
+assert free > 1.2 * need, "not enough scratch space"
+ctx = _lib.Context(0)
+T = {}
+try:
+    t0 = time.time()
+    path = simulations.write_synthetic_container(os.path.join(root, "geno.mmg"), N, M, chunk_rows=CH, num_chroms=5,
+                                                 seed=20240, pheno_seed=20241, num_causals=100)
+    T["write_container_s"] = round(time.time() - t0, 1)
+    print("container written: %.1f s (%.2f GB/s)" % (T["write_container_s"], need / 1e9 / T["write_container_s"]), flush=True)
+    src = hdf5_data.open_hdf5(path)
+    plan = hdf5_data._chunk_plan(src["genot_data"], 0.1, CH)
+    t0 = time.time()
+    K, n_snps = hdf5_data._ibd_kinship(ctx, src["genot_data"], N, plan)
+    T["kinship_pass_s"] = round(time.time() - t0, 1)
+    print("kinship pass (ingest + GRM fp32 MFMA, %d chunks): %.1f s = %.2f M SNPs/s, %.1f GB/s ingest"
+          % (len(plan), T["kinship_pass_s"], M / T["kinship_pass_s"] / 1e6, need / 1e9 / T["kinship_pass_s"]), flush=True)
+    y = src["phenotypes"]
+    lmm = lm.LinearMixedModel(y, ctx=ctx)
+    lmm.add_random_effect(K)
+    t0 = time.time()
+    eig_L = lmm._get_eigen_L_()
+    T["eigh_s"] = round(time.time() - t0, 1)
+    print("eigh: %.1f s" % T["eigh_s"], flush=True)
+    t0 = time.time()
+    est = lmm.get_estimates(eig_L, method="REML")
+    prep = lmm.scan_prepare(est["H_sqrt_inv"])
+    ctx.scan_set_model(prep["A"], prep["w"], 0)
+    T["reml_and_model_s"] = round(time.time() - t0, 1)
+    print("REML + scan model: %.1f s (pseudo-h2 %.4f)" % (T["reml_and_model_s"], est["pseudo_heritability"]), flush=True)
+    t0 = time.time()
+    ps = np.empty(M)
+    at = 0
+    quad_ms = 0.0
+    for ci, chrom, g in hdf5_data._resident_chunks(ctx, src["genot_data"], plan):
+        p = ctx.scan(g, prep["h0_rss"], prep["n_p"])["ps"]
+        quad_ms += ctx.kernel_ms("scan_quad")
+        g.close()
+        ps[at:at + len(p)] = p
+        at += len(p)
+    T["scan_pass_s"] = round(time.time() - t0, 2)
+    T["scan_quad_kernel_s"] = round(quad_ms / 1e3, 2)
+    print("scan pass (ingest overlapped with the scan): %.2f s = %.3f M SNPs/s incl. ingest (GEMM kernels %.2f s)"
+          % (T["scan_pass_s"], M / T["scan_pass_s"] / 1e6, quad_ms / 1e3), flush=True)
+    # ---- sample check: float64 host evaluation of linear_models.py:1316-1349
+    H = np.asarray(est["H_sqrt_inv"])
+    hX = H @ lmm.X
+    Q, _ = np.linalg.qr(hX)
+    rng = np.random.RandomState(3)
+    hits = np.argsort(ps)
+    hits = hits[ps[hits] > 1e-280][:4]
+    sample = np.unique(np.r_[hits, rng.choice(M, 8, replace=False)])
+    worst = 0.0
+    for gi in sample:
+        cid, off = divmod(int(gi), CH)
+        s = simulations.synthetic_chunk(cid, CH, N, 20240)[off].astype(np.float64)
+        t = H @ s
+        t = t - Q @ (Q.T @ t)
+        rss = prep["h0_rss"] - float(t @ prep["r"]) ** 2 / float(t @ t)
+        F = (prep["h0_rss"] / rss - 1) * prep["n_p"]
+        p = float(orc.f_sf(np.array([F]), 1, prep["n_p"])[0])
+        if p > 1e-290:
+            worst = max(worst, abs(ps[gi] / p - 1))
+    total = sum(v for k, v in T.items() if k.endswith("_s") and k not in ("write_container_s", "scan_quad_kernel_s"))
+    print(json.dumps({"config": "C5 share of rank 0 of %d" % a.world, "N": N, "M_share": M, "M_total": a.m_total,
+                      "chunks": len(plan), "timings": T, "pipeline_s": round(total, 1),
+                      "snps_per_s_end_to_end": M / total, "min_p": float(ps.min()),
+                      "max_rel_p_err_vs_host_f64": worst, "adaptive_last_chunk": ctx.scan_last_stats()}))
+    assert worst < 1e-6
+finally:
+    if not a.keep:
+        shutil.rmtree(root, ignore_errors=True)

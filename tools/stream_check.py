@@ -31,9 +31,10 @@ print("kinship given: %.2f s" % dt)
 from mixmogam_amd import linear_models as lm
 t0 = time.time()
 n = 0
-for ci, chrom, g, nrows, pos in hdf5_data._resident_chunks(ctx, src, 0.1, chunk):
+plan = hdf5_data._chunk_plan(src, 0.1, chunk)
+for ci, chrom, g in hdf5_data._resident_chunks(ctx, src, plan):
     ps = ctx.scan(g, 1.0e3, N - 2)["ps"]
     g.close()
-    n += nrows
+    n += len(ps)
 dt = time.time() - t0
 print("chunk loop only (upload overlapped with scan): %.3f s -> %.2f M SNPs/s incl. PCIe ingest" % (dt, n / dt / 1e6))
