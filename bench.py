@@ -466,7 +466,7 @@ def bench_perm(args, ctx, coll, comm_h, g, lmm, est, N, M, Mtot, barrier, common
     min_ps = ctx.f_sf(max_f, n_p)
     Npad = -(-N // 256) * 256
     Ppad = -(-P // 64) * 64
-    ex = 2.0 * 4 * 256.0 * Npad * Ppad / 64 * (-(-M // 256))             # 4 digit rows per permutation, int8 ops
+    ex = 2.0 * 256.0 * 256.0 * Npad * (Ppad / 64) * (-(-M // 256))       # 256 x 256 tiles (64 permutations x 4 digit rows), int8 ops
     res = dict(common)
     res.update({"metric": "SNP x permutation tests/sec, EMMAX permutation test (BASELINE configs[3])",
                 "value": float(Mtot) * P * args.steps / elapsed, "unit": "SNP-permutations/s",

@@ -305,7 +305,7 @@ def test_structured_generator_matches_oracle_and_adaptive_scan_on_structured_dat
     ctx.scan_set_model(prep["A"], prep["w"], 4)
     allp = ctx.scan(g, prep["h0_rss"], prep["n_p"])
     ok = allp["ps"] > 1e-290
-    assert int((allp["ps"] < 1e-8).sum()) >= 20 and int((allp["ps"] < 1e-5).sum()) >= 40   # many strong hits
+    assert int((allp["ps"] < 1e-8).sum()) >= 20 and int((allp["ps"] < 1e-5).sum()) >= 30   # many strong hits
     assert rel(ada["ps"][ok], allp["ps"][ok]) < 1e-6
     H = np.asarray(est["H_sqrt_inv"])
     Q, _ = np.linalg.qr(H @ lmm.X)

@@ -167,6 +167,12 @@ solop = hdf5_data.run_emmax(src, y, min_maf=0.05, chunk_size=50, ctx=FakeContext
 assert np.allclose(bothp["perm_min_ps"], solop["perm_min_ps"], rtol=1e-9)
 assert np.allclose(bothp["perm_max_f_stats"], solop["perm_max_f_stats"], rtol=1e-9)
 assert bothp["threshold_05"] == solop["threshold_05"] or np.allclose(bothp["threshold_05"], solop["threshold_05"], rtol=1e-9)
+# multi-phenotype scan: SNP shards + all-gather of the [P x M] blocks == unsharded (numpy stand-in context)
+from mixmogam_amd import linear_models as lm
+ys = rng.randn(3, n) + snps[[3, 9, 27]]
+one = lm.emmax_multi(snps, ys, K, ctx=FakeContext())
+two = lm.emmax_multi(snps, ys, K, ctx=FakeContext(), coll=coll)
+assert np.allclose(one["ps"], two["ps"], rtol=1e-12) and two["ps"].shape == (3, m)
 coll.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
