@@ -66,6 +66,10 @@ int mmg_host_free(mmg_ctx* ctx, void* p);
  * rounded up to 256) in HBM. */
 int mmg_geno_create(mmg_ctx* ctx, int64_t M, int32_t N, mmg_geno** g);
 int mmg_geno_destroy(mmg_ctx* ctx, mmg_geno* g);
+/* Reuse a store for another block of M <= (M at creation) SNPs without freeing / allocating HBM (both synchronise
+ * the device): the chunk loop of hdf5_data.py:99-106,153-184 ping-pongs two stores.  Rows are rewritten by the
+ * following upload; the padding rows are zeroed here. */
+int mmg_geno_reset(mmg_ctx* ctx, mmg_geno* g, int64_t M);
 /* Copy SNP rows [m0, m0+rows) from a host [rows x N] int8 C-contiguous buffer. */
 int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, int64_t rows);
 /* Same from a host float32 / float64 [rows x N] buffer holding small integers (the C3 config's
@@ -189,7 +193,7 @@ int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const
  * with d_p = w^2, G_p[c] = Q_p[:,c] * w, omega_p = r_p * w, w = (lambda+delta_p)^-1/2, Q_p an orthonormal basis of
  * the transformed covariates and r_p the residual of the transformed phenotype (host glue: O(N q^2) per phenotype).
  * mmg_rot_create: evecs_rows host [N x N], ROWS are eigenvectors (mmg_eigh_f64's layout); digits them once and
- * allocates T for up to M_cap SNPs (8 N bytes per SNP, eigen-major fp64).
+ * allocates T for up to M_cap SNPs (8 N bytes per SNP; fp64, eigen-major inside blocks of 256 SNPs).
  * mmg_rot_load: T = S U' for the SNPs of g (exact int8-MFMA digit GEMM); g may be destroyed afterwards.
  * mmg_emmax_scan_multi: d, omega host [P x N]; G host [P x q x N]; h0_rss host [P]; 1 <= q <= 4; outputs host
  * [P x M] (any may be NULL).  One HBM-bound pass over T per 8 phenotypes.

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "mmg_host_free": (C.c_int, [c_vp, c_vp]),
     "mmg_geno_create": (C.c_int, [c_vp, C.c_int64, C.c_int32, C.POINTER(c_vp)]),
     "mmg_geno_destroy": (C.c_int, [c_vp, c_vp]),
+    "mmg_geno_reset": (C.c_int, [c_vp, c_vp, C.c_int64]),
     "mmg_geno_upload": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64]),
     "mmg_geno_upload_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64]),
     "mmg_geno_upload_f64": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64]),
@@ -153,6 +154,12 @@ class Geno(object):
         h = c_vp()
         ctx._check(ctx.lib.mmg_geno_create(ctx.h, self.M, self.N, C.byref(h)))
         self.h = h
+
+    def reset(self, M):
+        """Reuse the allocation for another block of M <= capacity SNPs (no hipFree / hipMalloc)."""
+        self.ctx._check(self.ctx.lib.mmg_geno_reset(self.ctx.h, self.h, int(M)))
+        self.M = int(M)
+        return self
 
     def upload(self, snps, m0=0):
         a = as_store_array(snps)

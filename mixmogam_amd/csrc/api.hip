@@ -189,6 +189,7 @@ int mmg_geno_create(mmg_ctx* ctx, int64_t M, int32_t N, mmg_geno** out) {
   mmg_geno* g = new mmg_geno();
   g->M = M; g->N = N;
   g->Mpad = std::max<int64_t>(round_up(M, 256), 256);
+  g->Mcap = g->Mpad;
   g->Npad = (int32_t)round_up(N, 256);
   hipError_t e = hipMalloc(&g->d, (size_t)g->Mpad * g->Npad);
   if (e != hipSuccess) { delete g; return set_err(ctx, MMG_E_NOMEM, std::string("hipMalloc genotype store: ") + hipGetErrorString(e)); }
@@ -198,6 +199,21 @@ int mmg_geno_create(mmg_ctx* ctx, int64_t M, int32_t N, mmg_geno** out) {
   MMG_HIP(ctx, hipMemsetAsync(g->d, 0, (size_t)g->Mpad * g->Npad, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *out = g;
+  return MMG_OK;
+}
+
+int mmg_geno_reset(mmg_ctx* ctx, mmg_geno* g, int64_t M) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, g && M >= 0);
+  const int64_t Mpad = std::max<int64_t>(round_up(M, 256), 256);
+  if (Mpad > g->Mcap) return set_err(ctx, MMG_E_ARG, "mmg_geno_reset: M exceeds the capacity the store was created with");
+  // rows [M, Mpad) must read as zeros (every kernel walks whole 256-row blocks); the columns beyond N of the rows an
+  // upload rewrites stay zero because uploads only touch the first N bytes of a row
+  if (Mpad > M)
+    MMG_HIP(ctx, hipMemsetAsync(g->d + M * (int64_t)g->Npad, 0, (size_t)(Mpad - M) * g->Npad, ctx->stream));
+  MMG_HIP(ctx, hipMemsetAsync(g->d_smax, 0, sizeof(int), ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  g->M = M; g->Mpad = Mpad; g->smax = 0; g->bits_valid = false;
   return MMG_OK;
 }
 
@@ -1113,11 +1129,11 @@ int mmg_emmax_perm_sharded(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int32_t N,
 // ------------------------------------------------------------------------- eigen-rotated store, multi-phenotype scan
 struct mmg_rot {
   int32_t N = 0, Npad = 0, nVT = 0;
-  int64_t Mcap = 0;              // SNP capacity (multiple of 256) = leading dimension of T
+  int64_t Mcap = 0;              // SNP capacity (multiple of 256)
   int64_t M = 0;                 // SNPs currently loaded
   int8_t* Vq = nullptr;          // [nVT][256][Npad] digits of the eigenvectors (operand layout of k_perm.hip)
   double* dstep = nullptr;       // [nVT*64] per-eigenvector step
-  double* T = nullptr;           // [nVT*64][Mcap] fp64, eigen-major: T[i][m] = u_i . s_m
+  double* T = nullptr;           // [Mcap/256][nVT*64][256] fp64: T[m/256][i][m%256] = u_i . s_m
 };
 
 int mmg_rot_create(mmg_ctx* ctx, int32_t N, const double* evecs_rows, int64_t M_cap, mmg_rot** out) {
@@ -1163,7 +1179,7 @@ int mmg_rot_load(mmg_ctx* ctx, mmg_rot* r, mmg_geno* g) {
   MMG_CHECK_ARG(ctx, (int64_t)128 * std::max(g->smax, 1) * r->Npad < ((int64_t)1 << 31));
   r->M = g->M;
   if (g->M == 0) return MMG_OK;
-  int rc = run_rotate(ctx, g, r->Vq, r->dstep, r->nVT, r->T, r->Mcap);
+  int rc = run_rotate(ctx, g, r->Vq, r->dstep, r->nVT, r->T);
   if (rc) return rc;
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MMG_OK;
@@ -1173,9 +1189,14 @@ int mmg_rot_fetch(mmg_ctx* ctx, mmg_rot* r, int64_t m0, int64_t rows, double* ou
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, r && out && m0 >= 0 && rows >= 0 && m0 + rows <= r->M);
   if (rows == 0) return MMG_OK;
-  // out[i][k] = T[i][m0 + k], i < N: a strided 2-D copy of the eigen-major store
-  MMG_HIP(ctx, hipMemcpy2DAsync(out, rows * sizeof(double), r->T + m0, r->Mcap * sizeof(double), rows * sizeof(double),
-                                r->N, hipMemcpyDeviceToHost, ctx->stream));
+  // out[i][k] = T[(m0+k)/256][i][(m0+k)%256], i < N: one strided 2-D copy per 256-SNP block touched
+  const int64_t nrows = (int64_t)r->nVT * 64;
+  for (int64_t m = m0; m < m0 + rows;) {
+    const int64_t sb = m / 256, o = m % 256, w = std::min<int64_t>(256 - o, m0 + rows - m);
+    MMG_HIP(ctx, hipMemcpy2DAsync(out + (m - m0), rows * sizeof(double), r->T + sb * nrows * 256 + o, 256 * sizeof(double),
+                                  w * sizeof(double), r->N, hipMemcpyDeviceToHost, ctx->stream));
+    m += w;
+  }
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MMG_OK;
 }
@@ -1220,7 +1241,7 @@ int mmg_emmax_scan_multi(mmg_ctx* ctx, mmg_rot* r, int32_t P, int32_t q, const d
     }
     MMG_HIP(ctx, hipMemcpyAsync(dcoef, coef.data(), (size_t)N * NC * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     MMG_HIP(ctx, hipMemcpyAsync(dh0, h0b.data(), PB * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    int rc = run_scan_multi(ctx, r->T, r->Mcap, N, M, PB, q, dcoef, dh0, df2, lnb, dout[0], dout[1], dout[2], ldOut);
+    int rc = run_scan_multi(ctx, r->T, (int64_t)r->nVT * 64, N, M, PB, q, dcoef, dh0, df2, lnb, dout[0], dout[1], dout[2], ldOut);
     if (rc) return rc;
     for (int k = 0; k < 3; ++k)
       if (host[k])

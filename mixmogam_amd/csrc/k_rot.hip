@@ -11,7 +11,8 @@
 //     rss   = h0_rss_p - dot^2 / den,   F = (h0_rss_p / rss - 1) df2,   p = f.sf(F, 1, df2)
 // so the O(N^2) work per SNP is done ONCE (T = S U', an exact int8-MFMA digit GEMM, 4 balanced base-256 digits per
 // eigenvector with a per-eigenvector step -- the operand layout and mainloop of the permutation GEMM, k_perm.hip),
-// kept in HBM eigen-major as fp64 (T[i][m]; 8 N bytes per SNP: 41 GB at N = 5000, M = 1e6 -- what 288 GB are for),
+// kept in HBM as fp64, eigen-major inside blocks of 256 SNPs (T[m / 256][i][m % 256]: a scan workgroup streams one
+// contiguous 2 KB x N region, page after page; 8 N bytes per SNP: 41 GB at N = 5000, M = 1e6 -- what 288 GB are for),
 // and every phenotype afterwards costs one HBM-bound pass of 2 + q fused multiply-adds per element:
 //   * rot_gemm_kernel:  one register of a 32x32 accumulator = 32 consecutive SNPs of one eigen-coordinate, so the
 //     eigen-major store is written as the accumulators stand (256-B segments, no shuffle);
@@ -22,6 +23,7 @@
 // 2 * 4 * N^2 ops per SNP (no symmetry to exploit -- twice the work of one single-phenotype scan, amortised over
 // every phenotype that follows).
 #include <algorithm>
+#include <cstdlib>
 #include "f_sf.h"
 #include "gemm_i8_core.h"
 #include "mmg_internal.h"
@@ -32,7 +34,7 @@ constexpr int ROT_TILE = 64;                       // eigenvectors per workgroup
 
 __global__ __launch_bounds__(NTHREADS, 2) void rot_gemm_kernel(
     const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Vq, int64_t ldV, int nVT, int nch,
-    int sb_per_chunk, int nks, const double* __restrict__ step, double* __restrict__ T, int64_t ldT) {
+    int sb_per_chunk, int nks, const double* __restrict__ step, double* __restrict__ T, int64_t nrows) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int b = blockIdx.x;
   const int x = b & 7, i = b >> 3;
@@ -49,24 +51,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void rot_gemm_kernel(
   const int8_t* P = Vq + (int64_t)vt * TM * ldV;
   for (int sb = sb0; sb < sb1; ++sb) {
     const int8_t* Q = S + (int64_t)sb * TN * ldS;
+    double* Tb = T + (int64_t)sb * nrows * TN;             // block sb: [nrows][256 SNPs]
     v16i acc[4][2];                                        // acc[d]: digit d of the wave's 32 eigenvectors
     gemm_tile_i8(P, ldV, Q, ldS, 0, nks, lds, acc);
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
-      const int64_t snp = (int64_t)sb * TN + wn * 64 + nn * 32 + r;
+      const int snp = wn * 64 + nn * 32 + r;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int pl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         const long long gi = (long long)acc[0][nn][e] + ((long long)acc[1][nn][e] << 8) +
                              ((long long)acc[2][nn][e] << 16) + ((long long)acc[3][nn][e] << 24);
-        T[(int64_t)(vt * ROT_TILE + pl) * ldT + snp] = (double)gi * ex[pl];
+        Tb[(int64_t)(vt * ROT_TILE + pl) * TN + snp] = (double)gi * ex[pl];
       }
     }
   }
 }
 
-int run_rotate(mmg_ctx* ctx, const mmg_geno* g, const int8_t* Vq, const double* dstep, int nVT, double* T,
-               int64_t ldT) {
+int run_rotate(mmg_ctx* ctx, const mmg_geno* g, const int8_t* Vq, const double* dstep, int nVT, double* T) {
   const int nSb = (int)(g->Mpad / TN);
   if (nSb == 0 || nVT == 0) return MMG_OK;
   const int rounds = (nVT + 7) / 8;
@@ -80,68 +82,132 @@ int run_rotate(mmg_ctx* ctx, const mmg_geno* g, const int8_t* Vq, const double* 
     EvScope ev(ctx, EV_ROT);
     hipLaunchKernelGGL(rot_gemm_kernel, dim3((unsigned)(8 * rounds * nch)), dim3(NTHREADS), LDS_BYTES + ROT_TILE * 8,
                        ctx->stream, g->d, (int64_t)g->Npad, nSb, Vq, (int64_t)g->Npad, nVT, nch, per, g->Npad / BK,
-                       dstep, T, ldT);
+                       dstep, T, (int64_t)nVT * ROT_TILE);
   }
   MMG_HIP(ctx, hipGetLastError());
   return MMG_OK;
 }
 
 // coef row i: [ d_0 .. d_{PB-1} | omega_0, g_00 .. g_0(Q-1) | omega_1, g_10 .. | ... ]   (PB + PB * (1 + Q) doubles)
-template <int PB, int Q>
-__global__ __launch_bounds__(256) void scan_multi_kernel(const double* __restrict__ T, int64_t ldT, int32_t N, int64_t M,
+// R = SNPs per lane (R workgroup-blocks of 256 SNPs side by side): the wave-uniform coefficients are fetched once per
+// R elements -- at R = 1 the scalar cache, not the fp64 VALU or HBM, sets the pace (measured: 3.9 TB/s of T).
+template <int PB, int Q, int R, int ABL = 0>   // ABL (timing ablations, wrong results): 1 = no loads of T, 2 = loads + one FMA
+__global__ __launch_bounds__(256) void scan_multi_kernel(const double* __restrict__ T, int64_t nrows, int32_t N, int64_t M,
                                                          const double* __restrict__ coef, const double* __restrict__ h0,
                                                          double nu, double lnbeta, double* __restrict__ rss,
                                                          double* __restrict__ Fst, double* __restrict__ pv, int64_t ldOut) {
   constexpr int NL = PB * (1 + Q), NC = PB + NL;
-  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;   // T rows are padded to a multiple of 256 SNPs
-  double aq[PB], al[NL];
+  const int64_t nblk = (M + 255) / 256;
+  double aq[R][PB], al[R][NL];
+  const double* tp[R];
 #pragma unroll
-  for (int k = 0; k < PB; ++k) aq[k] = 0.0;
+  for (int rr = 0; rr < R; ++rr) {
 #pragma unroll
-  for (int k = 0; k < NL; ++k) al[k] = 0.0;
-  const double* tp = T + m;
-#pragma unroll 4
-  for (int i = 0; i < N; ++i) {
-    const double tau = tp[(int64_t)i * ldT];
-    const double t2 = tau * tau;
-    const double* c = coef + (int64_t)i * NC;                  // wave-uniform: scalar loads
+    for (int k = 0; k < PB; ++k) aq[rr][k] = 0.0;
 #pragma unroll
-    for (int k = 0; k < PB; ++k) aq[k] = fma(t2, c[k], aq[k]);
-#pragma unroll
-    for (int k = 0; k < NL; ++k) al[k] = fma(tau, c[PB + k], al[k]);
+    for (int k = 0; k < NL; ++k) al[rr][k] = 0.0;
+    // a block index beyond the last one re-reads the last block (its results are not written)
+    const int64_t blk = min((int64_t)blockIdx.x * R + rr, nblk - 1);
+    tp[rr] = T + blk * nrows * 256 + threadIdx.x;
   }
-  if (m >= M) return;
+  // The elements of the next DEPTH eigen-coordinates are in flight while the current one is multiplied out (a ring of
+  // registers): with loads issued only at the top of an iteration the memory stream and the fp64 FMAs took turns
+  // (10.1 ms per pass = the SUM of 6.5 ms loads-only and 5.4 ms FMAs-only) instead of overlapping.
+  constexpr int DEPTH = 4;
+  auto accumulate = [&](const double (&tau)[R], int i) {
+    const double* c = coef + (int64_t)i * NC;                  // wave-uniform: scalar loads
+    if (ABL == 2) {
 #pragma unroll
-  for (int k = 0; k < PB; ++k) {
-    double den = aq[k];
+      for (int rr = 0; rr < R; ++rr) aq[rr][0] = fma(tau[rr], c[0], aq[rr][0]);
+      return;
+    }
 #pragma unroll
-    for (int c = 0; c < Q; ++c) den = fma(-al[k * (1 + Q) + 1 + c], al[k * (1 + Q) + 1 + c], den);
-    const double dot = al[k * (1 + Q)];
-    const double h = h0[k];
-    double r = h;
-    // den ~ 0: the SNP is constant after projecting the covariates out; the reference's lstsq returns no residual
-    // and rss stays h0_rss (linear_models.py:1308,1329) -- same rule as scan_finalize_kernel
-    if (den > 1e-7 * aq[k] && den > 0.0) r = h - dot * dot / den;
-    const double F = (h / r - 1.0) * nu;
-    if (rss) rss[(int64_t)k * ldOut + m] = r;
-    if (Fst) Fst[(int64_t)k * ldOut + m] = F;
-    if (pv) pv[(int64_t)k * ldOut + m] = f_sf_1(F, nu, lnbeta);
+    for (int rr = 0; rr < R; ++rr) {
+      const double t2 = tau[rr] * tau[rr];
+#pragma unroll
+      for (int k = 0; k < PB; ++k) aq[rr][k] = fma(t2, c[k], aq[rr][k]);
+#pragma unroll
+      for (int k = 0; k < NL; ++k) al[rr][k] = fma(tau[rr], c[PB + k], al[rr][k]);
+    }
+  };
+  double ring[DEPTH][R];
+  const int last = (int)nrows - 1;                              // rows N .. nrows-1 exist (zeros); never read past them
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u)
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) ring[u][rr] = ABL == 1 ? 1e-3 * (u + rr) : tp[rr][(int64_t)min(u, last) * 256];
+  const int N4 = N / DEPTH * DEPTH;
+  for (int i = 0; i < N4; i += DEPTH) {
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      double tau[R];
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) {
+        tau[rr] = ring[u][rr];
+        ring[u][rr] = ABL == 1 ? tau[rr] + 1e-9 : tp[rr][(int64_t)min(i + u + DEPTH, last) * 256];
+      }
+      accumulate(tau, i + u);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u)
+    if (N4 + u < N) {
+      double tau[R];
+#pragma unroll
+      for (int rr = 0; rr < R; ++rr) tau[rr] = ring[u][rr];
+      accumulate(tau, N4 + u);
+    }
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr) {
+    const int64_t m = ((int64_t)blockIdx.x * R + rr) * 256 + threadIdx.x;
+    if (m >= M) continue;
+#pragma unroll
+    for (int k = 0; k < PB; ++k) {
+      double den = aq[rr][k];
+#pragma unroll
+      for (int c = 0; c < Q; ++c) den = fma(-al[rr][k * (1 + Q) + 1 + c], al[rr][k * (1 + Q) + 1 + c], den);
+      const double dot = al[rr][k * (1 + Q)];
+      const double h = h0[k];
+      double r = h;
+      // den ~ 0: the SNP is constant after projecting the covariates out; the reference's lstsq returns no residual
+      // and rss stays h0_rss (linear_models.py:1308,1329) -- same rule as scan_finalize_kernel
+      if (den > 1e-7 * aq[rr][k] && den > 0.0) r = h - dot * dot / den;
+      const double F = (h / r - 1.0) * nu;
+      if (rss) rss[(int64_t)k * ldOut + m] = r;
+      if (Fst) Fst[(int64_t)k * ldOut + m] = F;
+      if (pv) pv[(int64_t)k * ldOut + m] = f_sf_1(F, nu, lnbeta);
+    }
   }
 }
 
 template <int PB, int Q>
-static void launch_multi(mmg_ctx* ctx, const double* T, int64_t ldT, int32_t N, int64_t M, const double* coef,
+static void launch_multi(mmg_ctx* ctx, const double* T, int64_t nrows, int32_t N, int64_t M, const double* coef,
                          const double* h0, int32_t df2, double lnbeta, double* rss, double* F, double* p, int64_t ldOut) {
-  const int64_t nb = (M + 255) / 256;
-  hipLaunchKernelGGL((scan_multi_kernel<PB, Q>), dim3((unsigned)nb), dim3(256), 0, ctx->stream, T, ldT, N, M, coef, h0,
-                     (double)df2, lnbeta, rss, F, p, ldOut);
+  constexpr int R = (PB * (2 + Q) <= 24) ? 2 : 1;            // accumulators: 2 R PB (2 + Q) VGPRs
+  int rsel = R;
+  if (const char* e = std::getenv("MMG_MULTI_R")) rsel = std::atoi(e) == 1 ? 1 : R;
+  const int64_t nblk = (M + 255) / 256;
+  int abl = 0;
+  if (const char* e = std::getenv("MMG_MULTI_ABL")) abl = std::atoi(e);
+  if (abl == 1 && PB == 8 && Q == 1)
+    hipLaunchKernelGGL((scan_multi_kernel<8, 1, 2, 1>), dim3((unsigned)((nblk + 1) / 2)), dim3(256), 0, ctx->stream, T,
+                       nrows, N, M, coef, h0, (double)df2, lnbeta, rss, F, p, ldOut);
+  else if (abl == 2 && PB == 8 && Q == 1)
+    hipLaunchKernelGGL((scan_multi_kernel<8, 1, 2, 2>), dim3((unsigned)((nblk + 1) / 2)), dim3(256), 0, ctx->stream, T,
+                       nrows, N, M, coef, h0, (double)df2, lnbeta, rss, F, p, ldOut);
+  else if (rsel == 2)
+    hipLaunchKernelGGL((scan_multi_kernel<PB, Q, R>), dim3((unsigned)((nblk + R - 1) / R)), dim3(256), 0, ctx->stream, T,
+                       nrows, N, M, coef, h0, (double)df2, lnbeta, rss, F, p, ldOut);
+  else
+    hipLaunchKernelGGL((scan_multi_kernel<PB, Q, 1>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, T, nrows, N, M,
+                       coef, h0, (double)df2, lnbeta, rss, F, p, ldOut);
 }
 
-int run_scan_multi(mmg_ctx* ctx, const double* T, int64_t ldT, int32_t N, int64_t M, int PB, int q, const double* coef,
+int run_scan_multi(mmg_ctx* ctx, const double* T, int64_t nrows, int32_t N, int64_t M, int PB, int q, const double* coef,
                    const double* h0, int32_t df2, double lnbeta, double* rss, double* F, double* p, int64_t ldOut) {
   if (M == 0) return MMG_OK;
   EvScope ev(ctx, EV_MULTI);
-#define MMG_MULTI(PB_, Q_) launch_multi<PB_, Q_>(ctx, T, ldT, N, M, coef, h0, df2, lnbeta, rss, F, p, ldOut)
+#define MMG_MULTI(PB_, Q_) launch_multi<PB_, Q_>(ctx, T, nrows, N, M, coef, h0, df2, lnbeta, rss, F, p, ldOut)
 #define MMG_MULTI_Q(PB_)                                  \
   do {                                                    \
     if (q == 1) MMG_MULTI(PB_, 1);                        \

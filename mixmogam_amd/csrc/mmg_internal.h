@@ -8,6 +8,7 @@
 
 struct mmg_geno {
   int64_t M = 0, Mpad = 0;      // SNPs, padded to 256
+  int64_t Mcap = 0;             // rows allocated (mmg_geno_reset may shrink M / Mpad below it and grow them back)
   int32_t N = 0, Npad = 0;      // individuals, padded to 256
   int8_t* d = nullptr;          // [Mpad x Npad] SNP-major, zero padded
   // lazily built bit-packed twin [Mpad x Npad/8] (k_scan_bits.hip); invalidated by every write
@@ -171,10 +172,11 @@ int quantize_rows_4digits(mmg_ctx*, const double* dWt, int32_t N, int32_t Npad, 
                           double* dcsum);
 
 // ---- k_rot.hip: eigen-rotated genotype store + multi-phenotype scan
-// T [nVT*64 x ldT] (fp64, eigen-major): T[i][m] = u_i . s_m for the SNPs of g (exact int8 digit GEMM)
-int run_rotate(mmg_ctx*, const mmg_geno* g, const int8_t* Vq, const double* dstep, int nVT, double* T, int64_t ldT);
+// T [Mpad/256][nVT*64][256] (fp64; eigen-major inside 256-SNP blocks): T[m/256][i][m%256] = u_i . s_m for the SNPs
+// of g (exact int8 digit GEMM)
+int run_rotate(mmg_ctx*, const mmg_geno* g, const int8_t* Vq, const double* dstep, int nVT, double* T);
 // one pass over T for PB <= 8 phenotypes with q <= 4 fixed-effect columns each; coef: device [N][PB*(2+q)]
-int run_scan_multi(mmg_ctx*, const double* T, int64_t ldT, int32_t N, int64_t M, int PB, int q, const double* coef,
+int run_scan_multi(mmg_ctx*, const double* T, int64_t nrows, int32_t N, int64_t M, int PB, int q, const double* coef,
                    const double* h0 /*device [PB]*/, int32_t df2, double lnbeta, double* rss, double* F, double* p,
                    int64_t ldOut);
 

@@ -63,10 +63,25 @@ def _read_chunk(genot_data, chrom, sel):
     return np.ascontiguousarray(block, dtype=np.int8)
 
 
-def _resident_chunks(ctx, genot_data, plan, rank=0, world=1, prefetch=True):
+class _Borrowed(object):
+    """A pooled store handed to the chunk loop: close() gives it back instead of freeing HBM."""
+
+    def __init__(self, g):
+        self._g = g
+
+    def __getattr__(self, name):
+        return getattr(self._g, name)
+
+    def close(self):
+        pass
+
+
+def _resident_chunks(ctx, genot_data, plan, rank=0, world=1, prefetch=True, reuse=False):
     """Yield (chunk index, chrom, Geno) for the chunks this rank owns (ci % world == rank).  With prefetch the NEXT
     owned chunk is read from the source and uploaded by a helper thread on a second context/stream of the same
-    device while the caller computes on the current one (the C ABI is blocking; ctypes releases the GIL)."""
+    device while the caller computes on the current one (the C ABI is blocking; ctypes releases the GIL).
+    reuse: the chunks ping-pong between TWO stores allocated once (mmg_geno_reset; hipMalloc / hipFree synchronise
+    the device and would serialise the two streams) -- a yielded store is valid until the next-but-one chunk."""
     mine = [ci for ci in range(len(plan)) if ci % world == rank]
     if not (prefetch and isinstance(ctx, _lib.Context)):
         for ci in mine:
@@ -77,17 +92,29 @@ def _resident_chunks(ctx, genot_data, plan, rank=0, world=1, prefetch=True):
     up = _UPLOAD_CTX.get(ctx.device)
     if up is None:
         up = _UPLOAD_CTX[ctx.device] = _lib.Context(ctx.device)         # second stream of the same device, kept
+    pool = []
+    if reuse and mine:
+        cap = max(len(plan[ci][1]) for ci in mine)
+        n_ind = int(np.asarray(genot_data[plan[mine[0]][0]]['raw_snps'][0:1]).shape[1])
+        pool = [up.geno(M=cap, N=n_ind) for _ in range(2)]
 
-    def load(ci):
+    def load(ci, slot):
         chrom, sel, _pos = plan[ci]
-        return ci, chrom, up.geno(_read_chunk(genot_data, chrom, sel))
+        block = _read_chunk(genot_data, chrom, sel)
+        if pool:
+            return ci, chrom, _Borrowed(pool[slot].reset(len(block)).upload(block))
+        return ci, chrom, up.geno(block)
 
-    with ThreadPoolExecutor(max_workers=1) as pool:
-        fut = pool.submit(load, mine[0]) if mine else None
-        for k in range(len(mine)):
-            cur = fut.result()
-            fut = pool.submit(load, mine[k + 1]) if k + 1 < len(mine) else None
-            yield cur
+    try:
+        with ThreadPoolExecutor(max_workers=1) as ex:
+            fut = ex.submit(load, mine[0], 0) if mine else None
+            for k in range(len(mine)):
+                cur = fut.result()
+                fut = ex.submit(load, mine[k + 1], (k + 1) & 1) if k + 1 < len(mine) else None
+                yield cur
+    finally:
+        for g in pool:
+            g.close()
 
 
 def _dev_comm(coll):
@@ -97,7 +124,7 @@ def _dev_comm(coll):
 def _ibd_kinship(ctx, genot_data, n_indivs, plan, coll=None, prefetch=True):
     rank, world = (coll.rank, coll.world) if coll is not None else (0, 1)
     acc = ctx.kinship_accumulator(n_indivs)
-    for ci, chrom, g in _resident_chunks(ctx, genot_data, plan, rank, world, prefetch):
+    for ci, chrom, g in _resident_chunks(ctx, genot_data, plan, rank, world, prefetch, reuse=True):
         mean, sd = g.snp_stats()
         if np.any(sd == 0):
             raise ValueError("monomorphic SNP passed the MAF filter on chromosome %s" % chrom)
@@ -205,7 +232,7 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
     ctx.scan_set_model(prep['A'], prep['w'], 0)
     chroms = list(genot_data.keys())
     parts, kept = {}, []
-    for ci, chrom, g in _resident_chunks(ctx, genot_data, plan, rank, world, prefetch):
+    for ci, chrom, g in _resident_chunks(ctx, genot_data, plan, rank, world, prefetch, reuse=not num_perm):
         parts[ci] = ctx.scan(g, prep['h0_rss'], prep['n_p'])['ps']       # :174 _emmax_f_test_(emma_num=0)
         # :294-311 -- the permutation test runs on every chromosome but the LAST (`chr12_snps`)
         if num_perm and chrom != chroms[-1]:

@@ -37,6 +37,19 @@ print("share of rank 0: N=%d x M=%d = %.1f GB container in %s (%.0f GB free)" % 
 assert free > 1.2 * need, "not enough scratch space"
 ctx = _lib.Context(0)
 T = {}
+# heartbeat: the eigendecomposition at N = 50,000 is silent for several minutes, and a GPU box takes a job that
+# writes nothing for 7 minutes to be hung
+import threading
+_t00 = time.time()
+_stop = threading.Event()
+
+
+def _beat():
+    while not _stop.wait(60.0):
+        print("[%4.0f s] working ..." % (time.time() - _t00), flush=True)
+
+
+threading.Thread(target=_beat, daemon=True).start()
 try:
     t0 = time.time()
     path = simulations.write_synthetic_container(os.path.join(root, "geno.mmg"), N, M, chunk_rows=CH, num_chroms=5,
@@ -67,7 +80,7 @@ try:
     ps = np.empty(M)
     at = 0
     quad_ms = 0.0
-    for ci, chrom, g in hdf5_data._resident_chunks(ctx, src["genot_data"], plan):
+    for ci, chrom, g in hdf5_data._resident_chunks(ctx, src["genot_data"], plan, reuse=True):
         p = ctx.scan(g, prep["h0_rss"], prep["n_p"])["ps"]
         quad_ms += ctx.kernel_ms("scan_quad")
         g.close()
