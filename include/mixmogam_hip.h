@@ -127,6 +127,10 @@ int mmg_kin_acc_destroy(mmg_ctx* ctx, mmg_kin_acc* acc);
 int mmg_kinship_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N,
                    const float* scale, const float* shift, double* C_out);
 
+/* float32-genotype twin (values must be small integers, see mmg_geno_upload_f32) */
+int mmg_kinship_f32(mmg_ctx* ctx, const float* snps, int64_t M, int32_t N,
+                    const float* scale, const float* shift, double* C_out);
+
 /* ---- eigendecomposition (replaces scipy.linalg.eigh at linear_models.py:594,613) ---------- */
 /* Symmetric eigendecomposition on the device (rocSOLVER dsyevd). A: host [N x N] (symmetric,
  * both triangles present).  evals ascending; evecs (may be NULL) host [N x N] row-major whose
@@ -175,6 +179,11 @@ int mmg_emmax_scan_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N,
                       const double* A, const double* w, double h0_rss, int32_t df2,
                       double* rss, double* F, double* p);
 
+/* float32-genotype twin of the one-shot scan */
+int mmg_emmax_scan_f32(mmg_ctx* ctx, const float* snps, int64_t M, int32_t N,
+                       const double* A, const double* w, double h0_rss, int32_t df2,
+                       double* rss, double* F, double* p);
+
 /* ---- EMMAX permutation test (replaces linear_models.py:1157-1164) ------------------------- */
 /* Ht: host [N x N] = H_sqrt_inv (row-major, as the reference holds it), Ys: host [N x P]
  * permuted residual columns (:1150-1154).  For every permutation p returns
@@ -182,6 +191,10 @@ int mmg_emmax_scan_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N,
  * (:1159-1164).  min_rss: host [P]. */
 int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const double* Ys,
                    int32_t P, double h0_rss, int ndigits, double* min_rss);
+
+/* One-shot twin taking host genotypes (mmg_emmax_perm_i8(ctx, snps, M, N, Ht, Ys, P, min_rss)). */
+int mmg_emmax_perm_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N, const double* Ht, const double* Ys,
+                      int32_t P, double h0_rss, double* min_rss);
 
 /* ---- multi-phenotype scans (replaces a LOOP of emmax() runs over phenotypes that share genotypes and kinship:
  * phenotypeData.py:70-78, hdf5_data.py:262-330 once per phenotype file) ------------------------ */
@@ -237,6 +250,14 @@ int mmg_kinship_ibs_i8_sharded(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int64_
 int mmg_kin_acc_allreduce(mmg_ctx* ctx, mmg_comm* comm, mmg_kin_acc* acc);
 int mmg_emmax_perm_sharded(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int32_t N, const double* Ht, const double* Ys,
                            int32_t P, double h0_rss, int ndigits, double* min_rss);
+/* The same test right after an EMMAX scan of the same store with the same H (the flow of hdf5_data.py:315-330): the
+ * quadratic form t.t = s~'H'H s~ is rebuilt from the scan's den = s'(H'H - sum_c u_c u_c')s (still in HBM) plus
+ * 1 + q dot products per SNP instead of a second O(N^2) pass: HtQ host [q x N], rows u_c = H'Q_c with Q the
+ * orthonormal basis of the scan's transformed covariates (linear_models.py:1300).  Fails with MMG_E_STATE unless the
+ * last mmg_emmax_scan_device of ctx ran over g in its current state.  den carries the scan's precision (adaptive
+ * digit schedule: ~1e-8 relative where it did not refine), i.e. min_rss to ~1e-9 relative instead of 1e-12. */
+int mmg_emmax_perm_after_scan(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int32_t N, const double* Ht, const double* Ys,
+                              int32_t P, double h0_rss, const double* HtQ, int32_t q, double* min_rss);
 /* rank / world of the communicator and the rank count RCCL itself reports (ncclCommCount); any may be NULL */
 int mmg_comm_info(mmg_comm* c, int* rank, int* world, int* nccl_count);
 /* all-gather of equal-sized host blocks (count doubles per rank; recv: world*count, rank-major) */

@@ -70,6 +70,10 @@ PROTOTYPES = {
     "mmg_scan_fetch_stats": (C.c_int, [c_vp, C.c_int64, c_vp, c_vp, c_vp]),
     "mmg_emmax_scan_i8": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp, c_vp, C.c_double, C.c_int32,
                                     c_vp, c_vp, c_vp]),
+    "mmg_kinship_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp, c_vp, c_vp]),
+    "mmg_emmax_scan_f32": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp, c_vp, C.c_double, C.c_int32,
+                                     c_vp, c_vp, c_vp]),
+    "mmg_emmax_perm_i8": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, c_vp]),
     "mmg_emmax_perm": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, C.c_int, c_vp]),
     "mmg_rot_create": (C.c_int, [c_vp, C.c_int32, c_vp, C.c_int64, C.POINTER(c_vp)]),
     "mmg_rot_destroy": (C.c_int, [c_vp, c_vp]),
@@ -81,6 +85,8 @@ PROTOTYPES = {
     "mmg_kin_acc_allreduce": (C.c_int, [c_vp, c_vp, c_vp]),
     "mmg_emmax_perm_sharded": (C.c_int, [c_vp, c_vp, c_vp, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, C.c_int,
                                          c_vp]),
+    "mmg_emmax_perm_after_scan": (C.c_int, [c_vp, c_vp, c_vp, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, c_vp,
+                                            C.c_int32, c_vp]),
     "mmg_comm_info": (C.c_int, [c_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mmg_comm_allgather_f64": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp]),
     "mmg_f_sf": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp]),
@@ -456,12 +462,20 @@ class Context(object):
         self._check(self.lib.mmg_f_sf(self.h, _ptr(F), len(F), int(df2), _ptr(p)))
         return p
 
-    def perm(self, g, H, Ys, h0_rss, ndigits=0, comm=None):
-        """comm: RCCL communicator handle -- the minima then cover the SNP blocks of all ranks (reduced in HBM)."""
+    def perm(self, g, H, Ys, h0_rss, ndigits=0, comm=None, after_scan_HtQ=None):
+        """comm: RCCL communicator handle -- the minima then cover the SNP blocks of all ranks (reduced in HBM).
+        after_scan_HtQ: [q x N] rows H'Q_c of the scan that just ran over g with the same H -- t.t is then rebuilt
+        from that scan's quadratic forms (mmg_emmax_perm_after_scan) instead of a second O(N^2) pass."""
         H = _arr(H, np.float64)
         Ys = _arr(Ys, np.float64)
         P = Ys.shape[1]
         out = np.empty(P)
+        if after_scan_HtQ is not None:
+            U = _arr(np.atleast_2d(after_scan_HtQ), np.float64)
+            assert U.shape[1] == g.N
+            self._check(self.lib.mmg_emmax_perm_after_scan(self.h, comm, g.h, g.N, _ptr(H), _ptr(Ys), P, float(h0_rss),
+                                                           _ptr(U), U.shape[0], _ptr(out)))
+            return out
         self._check(self.lib.mmg_emmax_perm_sharded(self.h, comm, g.h, g.N, _ptr(H), _ptr(Ys), P, float(h0_rss),
                                                     int(ndigits), _ptr(out)))
         return out

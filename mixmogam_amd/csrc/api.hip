@@ -213,7 +213,7 @@ int mmg_geno_reset(mmg_ctx* ctx, mmg_geno* g, int64_t M) {
     MMG_HIP(ctx, hipMemsetAsync(g->d + M * (int64_t)g->Npad, 0, (size_t)(Mpad - M) * g->Npad, ctx->stream));
   MMG_HIP(ctx, hipMemsetAsync(g->d_smax, 0, sizeof(int), ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  g->M = M; g->Mpad = Mpad; g->smax = 0; g->bits_valid = false;
+  g->M = M; g->Mpad = Mpad; g->smax = 0; g->bits_valid = false; ++g->version;
   return MMG_OK;
 }
 
@@ -242,7 +242,7 @@ int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, i
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g && snps && m0 >= 0 && rows >= 0 && m0 + rows <= g->M);
   if (rows == 0) return MMG_OK;
-  g->bits_valid = false;
+  g->bits_valid = false; ++g->version;
   MMG_HIP(ctx, hipMemcpy2DAsync(g->d + m0 * (int64_t)g->Npad, g->Npad, snps, g->N, g->N, rows,
                                 hipMemcpyHostToDevice, ctx->stream));
   int rc = refresh_smax(ctx, g, m0, rows);
@@ -257,7 +257,7 @@ static int upload_cvt(mmg_ctx* ctx, mmg_geno* g, const T* snps, int64_t m0, int6
   Scratch sc;
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g && snps && m0 >= 0 && rows >= 0 && m0 + rows <= g->M);
-  g->bits_valid = false;
+  g->bits_valid = false; ++g->version;
   const int64_t chunk = std::max<int64_t>(1, (int64_t)(256 << 20) / ((int64_t)g->N * sizeof(T)));
   T* tmp = nullptr;
   int* dbad = nullptr;
@@ -321,7 +321,7 @@ int mmg_geno_fill_hash(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_globa
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g != nullptr && thr16 <= 65536);
   if (g->M == 0) return MMG_OK;
-  g->bits_valid = false;
+  g->bits_valid = false; ++g->version;
   {
     EvScope ev(ctx, EV_PACK);
     launch_fill_hash(ctx, g, seed, m_global0, thr16);
@@ -337,7 +337,7 @@ int mmg_geno_fill_structured(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g != nullptr && npop >= 1 && npop <= 64 && spread_q16 <= 65536);
   if (g->M == 0) return MMG_OK;
-  g->bits_valid = false;
+  g->bits_valid = false; ++g->version;
   {
     EvScope ev(ctx, EV_PACK);
     launch_fill_struct(ctx, g, seed, m_global0, npop, spread_q16);
@@ -843,6 +843,7 @@ int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2)
   int rc = ensure_result(ctx, ctx->res, g->Mpad);
   if (rc) return rc;
   ctx->res.M = g->M;
+  ctx->res.geno = g; ctx->res.geno_version = g->version;
   if (g->M == 0) return MMG_OK;
   mmg_scan_result& res = ctx->res;
   const mmg_scan_model& md = ctx->model;
@@ -998,6 +999,57 @@ int mmg_emmax_scan_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N, co
   return rc;
 }
 
+// One-shot twins over caller-owned host genotypes: float32 genotypes (the C3 config's "fp32 [M x N]") and
+// the permutation test.  Each uploads into a temporary store and calls the resident form.
+extern "C++" {
+template <typename F>
+static int with_temp_geno_f32(mmg_ctx* ctx, const float* snps, int64_t M, int32_t N, F&& body) {
+  mmg_geno* g = nullptr;
+  int rc = mmg_geno_create(ctx, M, N, &g);
+  if (rc) return rc;
+  rc = mmg_geno_upload_f32(ctx, g, snps, 0, M);
+  if (rc == MMG_OK) rc = body(g);
+  mmg_geno_destroy(ctx, g);
+  return rc;
+}
+}  // extern C++
+
+int mmg_kinship_f32(mmg_ctx* ctx, const float* snps, int64_t M, int32_t N, const float* scale, const float* shift,
+                    double* C_out) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, snps && C_out && M > 0 && N > 0 && (scale == nullptr) == (shift == nullptr));
+  return with_temp_geno_f32(ctx, snps, M, N, [&](mmg_geno* g) {
+    if (scale) return mmg_kinship_affine_f32(ctx, g, scale, shift, C_out);
+    std::vector<int64_t> c64((size_t)N * N);
+    int rc = mmg_kinship_ibs_i8(ctx, g, c64.data());
+    if (rc == MMG_OK) for (size_t i = 0; i < c64.size(); ++i) C_out[i] = (double)c64[i];
+    return rc;
+  });
+}
+
+int mmg_emmax_scan_f32(mmg_ctx* ctx, const float* snps, int64_t M, int32_t N, const double* A, const double* w,
+                       double h0_rss, int32_t df2, double* rss, double* F, double* p) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, snps && M >= 0 && N > 0);
+  int rc = mmg_scan_set_model(ctx, N, A, w, 0);
+  if (rc) return rc;
+  if (M == 0) return MMG_OK;
+  return with_temp_geno_f32(ctx, snps, M, N, [&](mmg_geno* g) { return mmg_emmax_scan(ctx, g, h0_rss, df2, rss, F, p); });
+}
+
+int mmg_emmax_perm_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N, const double* Ht, const double* Ys,
+                      int32_t P, double h0_rss, double* min_rss) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, snps && M >= 0 && N > 0);
+  mmg_geno* g = nullptr;
+  int rc = mmg_geno_create(ctx, M, N, &g);
+  if (rc) return rc;
+  if (M > 0) rc = mmg_geno_upload(ctx, g, snps, 0, M);
+  if (rc == MMG_OK) rc = mmg_emmax_perm(ctx, g, N, Ht, Ys, P, h0_rss, 0, min_rss);
+  mmg_geno_destroy(ctx, g);
+  return rc;
+}
+
 int mmg_geno_matvec(mmg_ctx* ctx, mmg_geno* g, const double* V, int32_t nv, double* out) {
   Scratch sc;
   MMG_ENTER(ctx);
@@ -1125,6 +1177,65 @@ int mmg_emmax_perm_sharded(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int32_t N,
   return rc;
 }
 
+
+int mmg_emmax_perm_after_scan(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int32_t N, const double* Ht, const double* Ys,
+                              int32_t P, double h0_rss, const double* HtQ, int32_t q, double* min_rss) {
+  Scratch sc;
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, g && Ht && Ys && HtQ && min_rss && P > 0 && q >= 1 && N == g->N);
+  if (ctx->res.geno != g || ctx->res.geno_version != g->version || ctx->res.M != g->M || ctx->model.N != N)
+    return set_err(ctx, MMG_E_STATE, "mmg_emmax_perm_after_scan: the last mmg_emmax_scan_device of this context was not "
+                                     "over this genotype store in its current state");
+  std::vector<double> yy((size_t)P, 0.0);
+  for (int i = 0; i < N; ++i)
+    for (int p = 0; p < P; ++p) yy[p] += Ys[(size_t)i * P + p] * Ys[(size_t)i * P + p];
+  const bool reduce = comm && comm->world > 1;
+  const int Ppad = (int)round_up(P, 64);
+  const int Npad = g->Npad;
+  double *dH = nullptr, *dYs = nullptr, *dWt = nullptr, *dones = nullptr, *dh1 = nullptr, *dvecs = nullptr;
+  double *ddots = nullptr, *dmu = nullptr, *dinv = nullptr, *dmax = nullptr;
+  MMG_HIP(ctx, sc.alloc(&dmax, Ppad * sizeof(double)));
+  MMG_HIP(ctx, hipMemsetAsync(dmax, 0, Ppad * sizeof(double), ctx->stream));
+  int rc = MMG_OK;
+  if (g->M > 0) {
+    MMG_HIP(ctx, sc.alloc(&dH, (size_t)N * N * sizeof(double)));
+    MMG_HIP(ctx, sc.alloc(&dYs, (size_t)N * P * sizeof(double)));
+    MMG_HIP(ctx, sc.alloc(&dWt, (size_t)P * N * sizeof(double)));
+    MMG_HIP(ctx, sc.alloc(&dones, N * sizeof(double)));
+    MMG_HIP(ctx, sc.alloc(&dh1, N * sizeof(double)));
+    MMG_HIP(ctx, sc.alloc(&dvecs, (size_t)(1 + q) * Npad * sizeof(double)));
+    MMG_HIP(ctx, sc.alloc(&ddots, (size_t)(1 + q) * g->Mpad * sizeof(double)));
+    MMG_HIP(ctx, sc.alloc(&dmu, g->Mpad * sizeof(double)));
+    MMG_HIP(ctx, sc.alloc(&dinv, g->Mpad * sizeof(double)));
+    MMG_HIP(ctx, hipMemcpyAsync(dH, Ht, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MMG_HIP(ctx, hipMemcpyAsync(dYs, Ys, (size_t)N * P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    std::vector<double> ones((size_t)N, 1.0), h1((size_t)N);
+    MMG_HIP(ctx, hipMemcpyAsync(dones, ones.data(), N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MMG_HIP(ctx, hipMemsetAsync(dvecs, 0, (size_t)(1 + q) * Npad * sizeof(double), ctx->stream));
+    for (int c = 0; c < q; ++c)
+      MMG_HIP(ctx, hipMemcpyAsync(dvecs + (size_t)(1 + c) * Npad, HtQ + (size_t)c * N, N * sizeof(double),
+                                  hipMemcpyHostToDevice, ctx->stream));
+    rc = dgemm_dev(ctx, 1, 0, P, N, N, dYs, dH, dWt);                       // W' = Ys'H  [P x N]
+    if (rc == MMG_OK) rc = dgemm_dev(ctx, 0, 0, N, 1, N, dH, dones, dh1);   // H 1
+    if (rc == MMG_OK) rc = dgemm_dev(ctx, 1, 0, N, 1, N, dH, dh1, dvecs);   // v = H'(H 1) -> vector 0
+    if (rc) return rc;
+    MMG_HIP(ctx, hipMemcpyAsync(h1.data(), dh1, N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double c0 = 0.0;
+    for (int i = 0; i < N; ++i) c0 += h1[i] * h1[i];                        // 1'H'H1
+    for (int k = 0; k < 1 + q; ++k) launch_snp_dot(ctx, g, dvecs + (size_t)k * Npad, ddots + (size_t)k * g->Mpad);
+    launch_perm_center_reuse(ctx, g, ctx->res.den, ddots, q, ctx->res.sum, c0, dmu, dinv);
+    MMG_HIP(ctx, hipGetLastError());
+    rc = run_perm(ctx, g, N, dWt, P, dinv, dmu, 4, dmax);
+    if (rc) return rc;
+  }
+  if (reduce) MMG_NCCL(ctx, ncclAllReduce(dmax, dmax, (size_t)Ppad, ncclDouble, ncclMax, comm->comm, ctx->stream));
+  std::vector<double> mx((size_t)Ppad, 0.0);
+  MMG_HIP(ctx, hipMemcpyAsync(mx.data(), dmax, Ppad * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int p = 0; p < P; ++p) min_rss[p] = std::min(h0_rss, yy[p] - mx[p]);
+  return MMG_OK;
+}
 
 // ------------------------------------------------------------------------- eigen-rotated store, multi-phenotype scan
 struct mmg_rot {

@@ -39,6 +39,32 @@ void launch_perm_center(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_result& 
                      r.dot, r.sum, g->M, g->Mpad, 1.0 / (double)g->N, c0, d_mu, d_inv);
 }
 
+// tt from the quadratic form a preceding EMMAX scan of the same SNPs left behind: den = s'(H'H - sum_c u_c u_c')s with
+// u_c = H'Q_c (linear_models.py:1300-1303), so s'H'Hs = den + sum_c (s.u_c)^2 and, centred (:1159),
+// tt = s'H'Hs - 2 mu s.v + mu^2 c0 with v = H'H 1.  dots: [1 + q][Mpad] = s.v, s.u_0 .. s.u_{q-1}.
+__global__ void perm_center_reuse_kernel(const double* __restrict__ den, const double* __restrict__ dots, int q,
+                                         const double* __restrict__ sum, int64_t M, int64_t Mpad, double invN, double c0,
+                                         double* __restrict__ mu, double* __restrict__ inv) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= Mpad) return;
+  double u = 0.0, iv = 0.0;
+  if (m < M) {
+    u = sum[m] * invN;
+    double full = den[m];
+    for (int c = 0; c < q; ++c) { const double d = dots[(int64_t)(1 + c) * Mpad + m]; full = fma(d, d, full); }
+    const double tt = full - 2.0 * u * dots[m] + u * u * c0;
+    if (tt > 1e-7 * fabs(full) && tt > 0.0) iv = 1.0 / tt;
+  }
+  mu[m] = u;
+  inv[m] = iv;
+}
+
+void launch_perm_center_reuse(mmg_ctx* ctx, const mmg_geno* g, const double* den, const double* dots, int q,
+                              const double* sum, double c0, double* d_mu, double* d_inv) {
+  hipLaunchKernelGGL(perm_center_reuse_kernel, dim3((unsigned)((g->Mpad + 255) / 256)), dim3(256), 0, ctx->stream, den,
+                     dots, q, sum, g->M, g->Mpad, 1.0 / (double)g->N, c0, d_mu, d_inv);
+}
+
 // one wave per permutation row: max |W_p|, sum W_p
 __global__ __launch_bounds__(256) void perm_rowstat_kernel(const double* __restrict__ Wt, int32_t N, int32_t P,
                                                            double* __restrict__ step, double* __restrict__ csum) {

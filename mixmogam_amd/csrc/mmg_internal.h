@@ -8,6 +8,7 @@
 
 struct mmg_geno {
   int64_t M = 0, Mpad = 0;      // SNPs, padded to 256
+  uint64_t version = 0;         // bumped by every write path
   int64_t Mcap = 0;             // rows allocated (mmg_geno_reset may shrink M / Mpad below it and grow them back)
   int32_t N = 0, Npad = 0;      // individuals, padded to 256
   int8_t* d = nullptr;          // [Mpad x Npad] SNP-major, zero padded
@@ -53,6 +54,8 @@ struct mmg_scan_result {
   unsigned long long* scal = nullptr;      // [0] = count, [1] = max eps bits, [2] = max (observed / 6 sigma) bits
   unsigned long long* q2 = nullptr;
   int64_t q2_cap = 0;
+  const void* geno = nullptr;    // the store the last scan ran on and its write version (mmg_emmax_perm_after_scan)
+  uint64_t geno_version = 0;
   // what the last scan did (mmg_scan_last_stats)
   int64_t n_refined = 0;
   double eps_max = 0.0, sigma_ratio_max = 0.0;
@@ -164,6 +167,8 @@ void launch_f_sf(mmg_ctx*, const double* F, int64_t n, int32_t df2, double lnbet
 // ---- k_perm.hip
 // mu[m] = sum/N, inv[m] = 1/(den - 2 mu dot + mu^2 c0) (0 for SNPs that are constant after centring)
 void launch_perm_center(mmg_ctx*, const mmg_geno*, const mmg_scan_result&, double c0, double* d_mu, double* d_inv);
+void launch_perm_center_reuse(mmg_ctx*, const mmg_geno*, const double* den, const double* dots, int q, const double* sum,
+                              double c0, double* d_mu, double* d_inv);
 // d_maxstat[p] = max_m (s~_m . W_p)^2 * inv[m];  dWt: device [P x N] row-major fp64
 int run_perm(mmg_ctx*, const mmg_geno*, int32_t N, const double* dWt, int32_t P, const double* d_inv,
              const double* d_mu, int ndigits, double* d_maxstat);

@@ -191,8 +191,9 @@ def _gather_owned(parts, plan, coll):
 
 
 def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=True, chunk_size=100000, k=None,
-              ctx=None, coll=None, num_perm=0, perm_idx=None, phenotypes=None, prefetch=True):
-    """hdf5_data.py:70-187 (and :191-351 when num_perm > 0).
+              ctx=None, coll=None, num_perm=0, perm_idx=None, phenotypes=None, prefetch=True, fast_perm=True):
+    """hdf5_data.py:70-187 (and :191-351 when num_perm > 0).  fast_perm: the permutation test of a chunk reuses the
+    quadratic forms of the scan that just ran over it (mmg_emmax_perm_after_scan) instead of recomputing them.
 
     hdf5_filename: container path (chunkstore / HDF5) or an open genot_data tree / mapping.  For the reference's
     call shape `run_emmax(genot_data, phenotypes, ...)` of round 1 the second positional argument may be the
@@ -231,14 +232,25 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
     prep = lmm.scan_prepare(res['H_sqrt_inv'])
     ctx.scan_set_model(prep['A'], prep['w'], 0)
     chroms = list(genot_data.keys())
-    parts, kept = {}, []
-    for ci, chrom, g in _resident_chunks(ctx, genot_data, plan, rank, world, prefetch, reuse=not num_perm):
+    parts = {}
+    pp = None
+    if num_perm:                                                         # :262-330: SNP-independent part, once
+        lmm_p = lm.LinearMixedModel(phenotypes, ctx=ctx)                 # perm_prepare centres Y in place
+        lmm_p.add_random_effect(k)
+        pp = lmm_p.perm_prepare(res['H_sqrt_inv'], num_perm=num_perm, perm_idx=perm_idx)
+        min_rss = np.full(num_perm, pp['h0_rss'])
+    for ci, chrom, g in _resident_chunks(ctx, genot_data, plan, rank, world, prefetch, reuse=True):
         parts[ci] = ctx.scan(g, prep['h0_rss'], prep['n_p'])['ps']       # :174 _emmax_f_test_(emma_num=0)
-        # :294-311 -- the permutation test runs on every chromosome but the LAST (`chr12_snps`)
+        # :294-311,330 -- the permutation test runs on every chromosome but the LAST (`chr12_snps`); here chunk by
+        # chunk right behind the scan of the same chunk, whose quadratic forms it reuses (same H; t.t needs only
+        # 1 + q dot products per SNP on top of them)
         if num_perm and chrom != chroms[-1]:
-            kept.append(g)
-        else:
-            g.close()
+            if fast_perm and isinstance(ctx, _lib.Context):
+                mr = ctx.perm(g, pp['H'], pp['Ys'], pp['h0_rss'], after_scan_HtQ=prep['HtQ'])
+            else:
+                mr = ctx.perm(g, pp['H'], pp['Ys'], pp['h0_rss'])
+            min_rss = np.minimum(min_rss, mr)
+        g.close()
     if coll is not None and world > 1:
         parts = _gather_owned(parts, plan, coll)                         # every SNP was scanned by exactly one rank
     for ci, (chrom, _sel, pos) in enumerate(plan):
@@ -249,24 +261,11 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
         d = out['chrom_results'].setdefault(chrom, {'ps': [np.zeros(0)], 'positions': [np.zeros(0, dtype=np.int64)]})
         d['ps'] = np.concatenate(d['ps'])
         d['positions'] = np.concatenate(d['positions'])
-    if num_perm:                                                         # :262-347
-        if perm_idx is None:
-            idx = np.asmatrix(np.arange(n).reshape(n, 1))
-            perm_idx = []
-            for _ in range(num_perm):
-                np.random.shuffle(idx)
-                perm_idx.append(np.asarray(idx).reshape(-1).copy())
-        min_ps, max_f = np.ones(num_perm), np.zeros(num_perm)
-        for g in kept:
-            lmm_c = lm.LinearMixedModel(phenotypes, ctx=ctx)             # _emmax_permutations_ centres Y in place
-            lmm_c.add_random_effect(k)
-            r = lmm_c._emmax_permutations_(g, k, res['H_sqrt_inv'], num_perm=num_perm, perm_idx=perm_idx)
-            g.close()
-            max_f = np.maximum(max_f, r['max_f_stats'])
-            min_ps = np.minimum(min_ps, r['min_ps'])
+    if num_perm:                                                         # :339-347
         if coll is not None and world > 1:
-            min_ps = coll.allreduce(min_ps, "min")
-            max_f = coll.allreduce(max_f, "max")
+            min_rss = coll.allreduce(min_rss, "min")
+        max_f = (pp['h0_rss'] / min_rss - 1.0) * pp['n_p']               # linear_models.py:1171
+        min_ps = ctx.f_sf(max_f, pp['n_p'])                              # :1172
         order = np.argsort(min_ps)
         five = num_perm // 20                                            # :342
         out.update(perm_min_ps=min_ps, perm_max_f_stats=max_f,
@@ -309,7 +308,9 @@ def _write_results(out_file, out, ih5f, num_perm):
 
 
 def run_emmax_perm(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=True, chunk_size=100000,
-                   num_perm=500, perm_idx=None, k=None, ctx=None, coll=None, phenotypes=None, prefetch=True):
+                   num_perm=500, perm_idx=None, k=None, ctx=None, coll=None, phenotypes=None, prefetch=True,
+                   fast_perm=True):
     """hdf5_data.py:191-351 (the reference always recalculates the kinship here; pass k to skip that)."""
     return run_emmax(hdf5_filename, out_file, min_maf=min_maf, chunk_size=chunk_size, k=k, ctx=ctx, coll=coll,
-                     num_perm=num_perm, perm_idx=perm_idx, phenotypes=phenotypes, prefetch=prefetch)
+                     num_perm=num_perm, perm_idx=perm_idx, phenotypes=phenotypes, prefetch=prefetch,
+                     fast_perm=fast_perm)

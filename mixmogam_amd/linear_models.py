@@ -478,7 +478,9 @@ class LinearMixedModel(object):
         A = 0.5 * (A + A.T)
         w = T.T @ r
         prep = {'h0_rss': h0_rss, 'h0_betas': [float(b) for b in h0_betas], 'r': r, 'A': A, 'w': w,
-                'n_p': self.n - (self.X.shape[1] + 1)}
+                'n_p': self.n - (self.X.shape[1] + 1),
+                'HtQ': np.ascontiguousarray((H.T @ Q).T)}              # [q x n_geno]: A = H'H - sum_c u_c u_c'
+
         if with_betas:
             prep['C'] = linalg.solve_triangular(R, Q.T @ H)              # q x n_geno: (X0'X0)^-1 X0' H
         return prep
@@ -537,14 +539,13 @@ class LinearMixedModel(object):
         return res_d
 
     # ------------------------------------------------------------------ permutations
-    def _emmax_permutations_(self, snps, K, H_sqrt_inv, num_perm=100, perm_idx=None, ndigits=0):
-        """:1125-1175.  perm_idx: optional [num_perm x n] index matrix (column p of Ys is r[perm_idx[p]]);
-        when None the permutations are drawn exactly as the reference draws them -- successive
-        in-place numpy.random.shuffle calls on the global RNG (:1151-1154)."""
-        ctx = self.ctx
+    def perm_prepare(self, H_sqrt_inv, num_perm=100, perm_idx=None):
+        """SNP-independent part of _emmax_permutations_ (:1135-1156): centred Y (mutated, as the reference does),
+        null fit, the N x P matrix of permuted residuals.  perm_idx: optional [num_perm x n] index matrix (column p
+        of Ys is r[perm_idx[p]]); when None the permutations are drawn exactly as the reference draws them --
+        successive in-place numpy.random.shuffle calls on the global RNG (:1151-1154)."""
         H = np.asarray(H_sqrt_inv, dtype=np.float64)
         n = self.n
-        n_p = n - (self.X.shape[1] + 1)
         self.Y = self.Y - np.mean(self.Y)                                # :1140 (mutates, as the reference)
         y = self.Y.reshape(-1)
         h0_X = H @ self.X
@@ -560,16 +561,22 @@ class LinearMixedModel(object):
                 np.random.shuffle(idx)
                 perm_idx.append(np.asarray(idx).reshape(-1).copy())
         perm_idx = np.asarray(perm_idx)
-        Ys = np.ascontiguousarray(r[perm_idx].T)                          # n x P: column p = r[perm_idx[p]]
+        return {'H': H, 'Ys': np.ascontiguousarray(r[perm_idx].T), 'h0_rss': h0_rss,   # n x P: column p = r[perm_idx[p]]
+                'n_p': n - (self.X.shape[1] + 1)}
+
+    def _emmax_permutations_(self, snps, K, H_sqrt_inv, num_perm=100, perm_idx=None, ndigits=0):
+        """:1125-1175 (perm_idx: see perm_prepare)."""
+        ctx = self.ctx
+        pp = self.perm_prepare(H_sqrt_inv, num_perm=num_perm, perm_idx=perm_idx)
         own = not isinstance(snps, _lib.Geno)
         g = ctx.geno(kinship._as_snp_matrix(snps)) if own else snps
         try:
-            min_rss = ctx.perm(g, H, Ys, h0_rss, ndigits)
+            min_rss = ctx.perm(g, pp['H'], pp['Ys'], pp['h0_rss'], ndigits)
         finally:
             if own:
                 g.close()
-        max_f_stats = ((h0_rss / min_rss) - 1.0) * n_p                    # :1171
-        min_pvals = ctx.f_sf(max_f_stats, n_p)                           # :1172
+        max_f_stats = ((pp['h0_rss'] / min_rss) - 1.0) * pp['n_p']        # :1171
+        min_pvals = ctx.f_sf(max_f_stats, pp['n_p'])                     # :1172
         return {'min_ps': min_pvals, 'max_f_stats': max_f_stats}
 
     def emmax_permutations(self, snps, num_perm, method='REML', perm_idx=None):

@@ -132,7 +132,7 @@ class FakeContext(object):
         F = (h0 / rss - 1.0) * df2
         return {"rss": rss, "f_stats": F, "ps": self.f_sf(F, df2)}
 
-    def perm(self, g, H, Ys, h0_rss, ndigits=0, comm=None):
+    def perm(self, g, H, Ys, h0_rss, ndigits=0, comm=None, after_scan_HtQ=None):
         S = g.data.astype(np.float64)
         S = S - S.mean(1, keepdims=True)
         T = S @ np.asarray(H).T

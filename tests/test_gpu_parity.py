@@ -303,6 +303,26 @@ def test_one_shot_c_abi(ctx):
     rc = ctx.lib.mmg_kinship_i8(ctx.h, _lib._ptr(snps), m, n, None, None, _lib._ptr(Cout))
     assert rc == 0
     assert np.array_equal(Cout, orc.ibs_counts(snps).astype(float))
+    # float32-genotype twins (the C3 config hands over fp32 [M x N] genotypes): same results
+    s32 = snps.astype(np.float32)
+    p32, C32 = np.empty(m), np.empty((n, n))
+    assert ctx.lib.mmg_emmax_scan_f32(ctx.h, _lib._ptr(s32), m, n, _lib._ptr(A), _lib._ptr(w), C.c_double(prep["h0_rss"]),
+                                      n - 2, None, None, _lib._ptr(p32)) == 0
+    assert np.array_equal(p32, p)
+    assert ctx.lib.mmg_kinship_f32(ctx.h, _lib._ptr(s32), m, n, None, None, _lib._ptr(C32)) == 0
+    assert np.array_equal(C32, Cout)
+    s32[3, 7] = 0.5                                                       # a dosage: refused, not rounded
+    assert ctx.lib.mmg_kinship_f32(ctx.h, _lib._ptr(s32), m, n, None, None, _lib._ptr(C32)) != 0
+    assert b"integers" in ctx.lib.mmg_last_error(ctx.h)
+    # one-shot permutation test over host genotypes == the resident form
+    H = np.ascontiguousarray(case["dbl_perm_H"])
+    Ys = np.ascontiguousarray(prep["r"][case["dbl_perm_idx"]].T)
+    mn = np.empty(Ys.shape[1])
+    assert ctx.lib.mmg_emmax_perm_i8(ctx.h, _lib._ptr(snps), m, n, _lib._ptr(H), _lib._ptr(Ys), Ys.shape[1],
+                                     C.c_double(prep["h0_rss"]), _lib._ptr(mn)) == 0
+    gres = ctx.geno(snps)
+    assert np.array_equal(mn, ctx.perm(gres, H, Ys, prep["h0_rss"]))
+    gres.close()
     # error behaviour: scan before a model of matching N -> error code + message, no crash
     g = ctx.geno(M=4, N=n + 1)
     rc = ctx.lib.mmg_emmax_scan_device(ctx.h, g.h, C.c_double(1.0), 10)

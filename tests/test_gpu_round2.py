@@ -323,3 +323,42 @@ def test_structured_generator_matches_oracle_and_adaptive_scan_on_structured_dat
         worst = max(worst, abs(ada["ps"][gi] / p - 1))
     assert worst < 1e-6, worst
     g.close()
+
+
+def test_perm_after_scan_equals_the_standalone_test(ctx, case):
+    """mmg_emmax_perm_after_scan (t.t rebuilt from the quadratic forms of the scan that just ran over the same store
+    with the same H, plus 1 + q dot products per SNP) against the standalone permutation test and, where the golden
+    case has one, against the reference's run: min_rss within 1e-7 relative of the exact path (den carries the
+    adaptive scan's precision), max F / min p within 1e-6 of the reference."""
+    from mixmogam_amd import _lib, linear_models as lm
+    lmm = lm.LinearMixedModel(list(case["y"]), ctx=ctx)
+    lmm.add_random_effect(case["dbl_ibs_scaled"])
+    if case["cof"] is not None:
+        for c in case["cof"]:
+            lmm.add_factor(c)
+    eig_L = lmm._get_eigen_L_()
+    est = lmm.get_estimates(eig_L, method="REML")
+    H = np.asarray(case["dbl_perm_H"]) if "dbl_perm_H" in case else est["H_sqrt_inv"]
+    prep = lmm.scan_prepare(H)
+    n = lmm.n
+    idx = case["dbl_perm_idx"] if "dbl_perm_idx" in case else \
+        np.array([np.random.RandomState(p).permutation(n) for p in range(17)])
+    lmm_p = lm.LinearMixedModel(list(case["y"]), ctx=ctx)
+    lmm_p.X, lmm_p.p = lmm.X, lmm.p
+    pp = lmm_p.perm_prepare(H, perm_idx=idx)
+    g = ctx.geno(case["snps"])
+    with pytest.raises(_lib.MixmogamHipError):                       # no scan over this store yet
+        ctx.perm(ctx.geno(case["snps"][:10]), pp["H"], pp["Ys"], pp["h0_rss"], after_scan_HtQ=prep["HtQ"])
+    exact = ctx.perm(g, pp["H"], pp["Ys"], pp["h0_rss"])
+    ctx.scan_set_model(prep["A"], prep["w"], 0)
+    ctx.scan(g, prep["h0_rss"], prep["n_p"], fetch=False)
+    fast = ctx.perm(g, pp["H"], pp["Ys"], pp["h0_rss"], after_scan_HtQ=prep["HtQ"])
+    assert rel(fast, exact) < 1e-7
+    if "dbl_perm_max_f_stats" in case and case["cof"] is None:
+        max_f = (pp["h0_rss"] / fast - 1.0) * pp["n_p"]
+        assert rel(max_f, case["dbl_perm_max_f_stats"]) < 1e-6
+        assert rel(ctx.f_sf(max_f, pp["n_p"]), case["dbl_perm_min_ps"]) < 1e-6
+    g.upload(case["snps"][:1], 0)                                     # any write invalidates the scan's state
+    with pytest.raises(_lib.MixmogamHipError):
+        ctx.perm(g, pp["H"], pp["Ys"], pp["h0_rss"], after_scan_HtQ=prep["HtQ"])
+    g.close()
