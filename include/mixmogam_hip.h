@@ -36,6 +36,7 @@ typedef struct mmg_geno mmg_geno;    /* device-resident padded genotype store */
 typedef struct mmg_comm mmg_comm;    /* RCCL communicator, one rank per process */
 typedef struct mmg_kin_acc mmg_kin_acc;  /* device-resident N x N kinship accumulator */
 typedef struct mmg_rot mmg_rot;      /* eigen-rotated genotype store (multi-phenotype scans) */
+typedef struct mmg_reml mmg_reml;    /* eigendecomposition-free REML workspace (K, X, y resident) */
 
 /* ---- library / context -------------------------------------------------------------- */
 int mmg_version(void);
@@ -141,6 +142,23 @@ int mmg_eigh_f64(mmg_ctx* ctx, const double* A, int32_t N, double* evals, double
  * the O(N^3) products of linear_models.py:610,898,1303.  ta/tb: 0 = as is, 1 = transposed. */
 int mmg_dgemm_f64(mmg_ctx* ctx, int ta, int tb, int32_t M, int32_t N, int32_t K,
                   const double* A, const double* B, double* C);
+
+/* ---- REML and the scan model without an eigendecomposition (large N: beyond rocSOLVER's syevd index range) ----
+ * The reference evaluates the EMMA likelihood from eigh(K) and eigh(S(K+I)S) (linear_models.py:589-615,794-810);
+ * what it consumes per variance ratio delta are four sums -- with H = K + delta I and
+ * P = H^-1 - H^-1 X (X'H^-1 X)^-1 X'H^-1:  s1 = y'Py, s2 = log|H| + log|X'H^-1 X| - log|X'X|, s3 = |Py|^2,
+ * s4 = tr P -- and sum_sq_etas = |Sy|^2.  mmg_reml_sums evaluates them for nd values of delta from one Cholesky
+ * factorisation each (potrf_64 + recursive triangular inverse, 2 N^3/3 flops per delta; the values are
+ * independent, so ranks can share a grid).  mmg_reml_scan_model builds the EMMAX scan model at delta straight on
+ * the device -- A = Mp Mp' = P, w = Mp r = Py (linear_models.py:1290-1303 in closed form) -- and returns
+ * h0_rss = y'Py (= the Mahalanobis RSS of the null model, :906) and the GLS estimate beta [q] (:902).
+ * K: host [N x N] symmetric (scaled as the model holds it); X: host [N x q] row-major (intercept first), q <= 16. */
+int mmg_reml_create(mmg_ctx* ctx, int32_t N, int32_t q, const double* K, const double* X, const double* y, mmg_reml** r);
+int mmg_reml_destroy(mmg_ctx* ctx, mmg_reml* r);
+int mmg_reml_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3,
+                  double* s4, double* sum_sq_etas);
+int mmg_reml_scan_model(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, double* h0_rss, double* beta,
+                        double* mahalanobis_rss);
 
 /* ---- EMMAX scan (replaces the loop of linear_models.py:1316-1349) ------------------------- */
 /* Loads the SNP-independent model onto the device:

@@ -75,6 +75,10 @@ PROTOTYPES = {
                                      c_vp, c_vp, c_vp]),
     "mmg_emmax_perm_i8": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, c_vp]),
     "mmg_emmax_perm": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, C.c_int, c_vp]),
+    "mmg_reml_create": (C.c_int, [c_vp, C.c_int32, C.c_int32, c_vp, c_vp, c_vp, C.POINTER(c_vp)]),
+    "mmg_reml_destroy": (C.c_int, [c_vp, c_vp]),
+    "mmg_reml_sums": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64p]),
+    "mmg_reml_scan_model": (C.c_int, [c_vp, c_vp, C.c_double, C.c_int, c_f64p, c_vp, c_f64p]),
     "mmg_rot_create": (C.c_int, [c_vp, C.c_int32, c_vp, C.c_int64, C.POINTER(c_vp)]),
     "mmg_rot_destroy": (C.c_int, [c_vp, c_vp]),
     "mmg_rot_load": (C.c_int, [c_vp, c_vp, c_vp]),
@@ -298,6 +302,48 @@ class Rot(object):
             pass
 
 
+class Reml(object):
+    """Eigendecomposition-free REML workspace (mmg_reml_*): K, X, y resident; the four likelihood sums per delta from
+    one Cholesky factorisation each; the scan model P(delta), P y built on the device."""
+
+    def __init__(self, ctx, K, X, y):
+        K = _arr(K, np.float64)
+        X = _arr(X, np.float64)
+        y = _arr(np.asarray(y).reshape(-1), np.float64)
+        self.ctx, self.N, self.q = ctx, K.shape[0], X.shape[1]
+        assert K.shape == (self.N, self.N) and X.shape[0] == self.N and len(y) == self.N
+        h = c_vp()
+        ctx._check(ctx.lib.mmg_reml_create(ctx.h, self.N, self.q, _ptr(K), _ptr(X), _ptr(y), C.byref(h)))
+        self.h = h
+
+    def sums(self, deltas):
+        d = _arr(np.asarray(deltas).reshape(-1), np.float64)
+        out = [np.empty(len(d)) for _ in range(4)]
+        sse = C.c_double(0.0)
+        self.ctx._check(self.ctx.lib.mmg_reml_sums(self.ctx.h, self.h, len(d), _ptr(d), *[_ptr(o) for o in out],
+                                                   C.byref(sse)))
+        return out[0], out[1], out[2], out[3], sse.value
+
+    def scan_model(self, delta, ndigits=0):
+        """Load the EMMAX scan model of `delta` into the context; returns (h0_rss, beta)."""
+        h0, mah = C.c_double(0.0), C.c_double(0.0)
+        beta = np.empty(self.q)
+        self.ctx._check(self.ctx.lib.mmg_reml_scan_model(self.ctx.h, self.h, float(delta), int(ndigits), C.byref(h0),
+                                                         _ptr(beta), C.byref(mah)))
+        return h0.value, beta
+
+    def close(self):
+        if self.h is not None:
+            self.ctx.lib.mmg_reml_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context(object):
     """One HIP device context (stream, scan model, result buffers)."""
 
@@ -424,6 +470,9 @@ class Context(object):
 
     def rot(self, evecs_rows, M_cap):
         return Rot(self, evecs_rows, M_cap)
+
+    def reml(self, K, X, y):
+        return Reml(self, K, X, y)
 
     def scan_multi(self, rot, d, omega, G, h0_rss, df2, want=("rss", "f_stats", "ps")):
         """P phenotypes over the rotated store: d, omega [P x N], G [P x q x N], h0_rss [P] -> {'rss','f_stats','ps'}

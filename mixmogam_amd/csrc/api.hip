@@ -794,6 +794,14 @@ static int model_from_device(mmg_ctx* ctx, mmg_scan_model& md, int32_t N, const 
   return build_schedule(ctx, md);
 }
 
+}  // extern "C"
+namespace mmg {
+int model_from_device_public(mmg_ctx* ctx, int32_t N, const double* dA, const double* dw, int ndigits, bool adaptive) {
+  return model_from_device(ctx, ctx->model, N, dA, dw, ndigits, adaptive);
+}
+}  // namespace mmg
+extern "C" {
+
 int mmg_scan_set_model(mmg_ctx* ctx, int32_t N, const double* A, const double* w, int ndigits) {
   Scratch sc;
   MMG_ENTER(ctx);

@@ -1,0 +1,389 @@
+// reml_chol.hip -- the EMMA restricted likelihood and the EMMAX scan model WITHOUT an eigendecomposition.
+//
+// The reference gets everything from eigh(K) and eigh(S(K+I)S) (linear_models.py:589-615, 771-927).  What it
+// actually consumes are four sums per variance ratio delta (H = K + delta I, P = H^-1 - H^-1 X (X'H^-1 X)^-1 X'H^-1):
+//     s1 = y'Py,   s2 = log|H| + log|X'H^-1 X| - log|X'X|,   s3 = |Py|^2,   s4 = tr P
+// (the 51-point grid :796-810, the secant iterations :847, the final log-likelihood :882, vg :894) and, for the
+// scan, A = Mp Mp' = P,  w = Mp r = Py,  h0_rss = y'Py  (:1290-1303 in closed form).  All of these follow from ONE
+// Cholesky factorisation per delta:  H = LL',  Z = L^-1 [X y],  G = L^-T Z = H^-1 [X y],  tr H^-1 = |L^-1|_F^2.
+// Cost per delta: N^3/3 (potrf) + N^3/3 (triangular inverse, recursive over trsm so that the zero half is never
+// touched) against ~10 N^3 for the eigendecomposition -- and, unlike rocsolver_dsyevd, every routine used here has
+// a 64-bit-index form (rocsolver_dpotrf_64, rocblas_dtrsm_64, rocblas_dsyrk_64, rocblas_dgemm_64), so it runs at
+// N = 50,000 where the eigensolver has to fall back to block Jacobi (397 s, eigh_block.hip).  The grid points are
+// independent: a multi-GPU run can deal them out (mixmogam_amd/linear_models.py:_SpectralSumsChol, `coll`).
+// Roofline: fp64 MFMA through rocSOLVER / rocBLAS (library GEMMs, off the SNPs/s metric).
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mmg_internal.h"
+
+namespace mmg {
+
+__global__ void add_diag_kernel(double* __restrict__ A, int64_t N, double delta) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) A[i * N + i] += delta;
+}
+
+// sum of log(diag) and, of the lower triangle incl. diagonal (column-major view: rows >= cols), the squared Frobenius norm
+// one block, fixed summation order (the likelihood must not depend on atomics' arrival order)
+__global__ __launch_bounds__(256) void logdiag_kernel(const double* __restrict__ A, int64_t N, double* __restrict__ out) {
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < N; i += 256) s += log(A[i * N + i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ double w[4];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (w[0] + w[1]) + (w[2] + w[3]);
+}
+
+__global__ __launch_bounds__(256) void lower_sqnorm_kernel(const double* __restrict__ A, int64_t N, double* __restrict__ part) {
+  // one block per column (column-major: column j holds rows j..N-1 of the lower triangle contiguously)
+  const int64_t j = blockIdx.x;
+  double s = 0.0;
+  for (int64_t i = j + threadIdx.x; i < N; i += 256) { const double v = A[j * N + i]; s = fma(v, v, s); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ double w[4];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[j] = w[0] + w[1] + w[2] + w[3];
+}
+
+// zero the strictly upper triangle (column-major: rows < cols) so that the triangular factor can be used as a dense matrix
+__global__ void zero_upper_kernel(double* __restrict__ A, int64_t N) {
+  const int64_t j = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < j) A[j * N + i] = 0.0;
+}
+
+// mirror the lower triangle into the upper one (column-major A[j*N + i], i > j  ->  A[i*N + j])
+__global__ void mirror_lower_kernel(double* __restrict__ A, int64_t N) {
+  const int64_t j = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N && i > j) A[i * N + j] = A[j * N + i];
+}
+
+}  // namespace mmg
+using namespace mmg;
+
+struct mmg_reml {
+  int32_t N = 0, q = 0;
+  double* dK = nullptr;     // [N x N] symmetric
+  double* dL = nullptr;     // [N x N] work: H -> L -> L^-1
+  double* dB = nullptr;     // [N x (q+1)] = [X y] (column-major: column c contiguous)
+  double* dZ = nullptr;     // [N x (q+1)]
+  double* dG = nullptr;     // [N x (q+1)]
+  double* dsc = nullptr;    // scalars / per-column partials [N + 8]
+  std::vector<double> X, y; // host copies (X row-major N x q)
+  double logdet_xtx = 0.0, sum_sq_etas = 0.0;
+  void* rocblas = nullptr;
+};
+
+#define RC_HIP(ctx, call)                                                                     \
+  do {                                                                                        \
+    hipError_t e__ = (call);                                                                  \
+    if (e__ != hipSuccess) return set_err(ctx, MMG_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+#define RC_RB(ctx, call)                                                                      \
+  do {                                                                                        \
+    rocblas_status s__ = (call);                                                              \
+    if (s__ != rocblas_status_success)                                                        \
+      return set_err(ctx, MMG_E_LIB, std::string(#call) + ": rocblas status " + std::to_string((int)s__)); \
+  } while (0)
+
+// small dense helpers on the host (q x q, q <= 16)
+static bool chol_solve_small(int q, std::vector<double> a, std::vector<double>& b, int nrhs, double* logdet) {
+  // a: q x q SPD row-major (destroyed); b: q x nrhs row-major, overwritten with a^-1 b
+  double ld = 0.0;
+  for (int j = 0; j < q; ++j) {
+    double d = a[j * q + j];
+    for (int k = 0; k < j; ++k) d -= a[j * q + k] * a[j * q + k];
+    if (!(d > 0.0)) return false;
+    d = std::sqrt(d);
+    a[j * q + j] = d;
+    ld += 2.0 * std::log(d);
+    for (int i = j + 1; i < q; ++i) {
+      double v = a[i * q + j];
+      for (int k = 0; k < j; ++k) v -= a[i * q + k] * a[j * q + k];
+      a[i * q + j] = v / d;
+    }
+  }
+  for (int r = 0; r < nrhs; ++r) {
+    for (int i = 0; i < q; ++i) {
+      double v = b[i * nrhs + r];
+      for (int k = 0; k < i; ++k) v -= a[i * q + k] * b[k * nrhs + r];
+      b[i * nrhs + r] = v / a[i * q + i];
+    }
+    for (int i = q - 1; i >= 0; --i) {
+      double v = b[i * nrhs + r];
+      for (int k = i + 1; k < q; ++k) v -= a[k * q + i] * b[k * nrhs + r];
+      b[i * nrhs + r] = v / a[i * q + i];
+    }
+  }
+  if (logdet) *logdet = ld;
+  return true;
+}
+
+static int reml_handle(mmg_ctx* ctx, rocblas_handle* h) {
+  if (!ctx->rocblas) {
+    rocblas_handle hh;
+    RC_RB(ctx, rocblas_create_handle(&hh));
+    RC_RB(ctx, rocblas_set_stream(hh, ctx->stream));
+    ctx->rocblas = hh;
+  }
+  *h = (rocblas_handle)ctx->rocblas;
+  return MMG_OK;
+}
+
+// in-place inverse of the lower-triangular n x n block at L (leading dimension ld, column-major), recursive:
+// [[L11, 0], [L21, L22]]^-1 = [[X11, 0], [-X22 L21 X11, X22]] -- two trsm per level touch only the non-zero half.
+static int tri_inv_lower(mmg_ctx* ctx, rocblas_handle h, double* L, int64_t n, int64_t ld, rocblas_int* dinfo) {
+  const int64_t NB = 4096;
+  if (n <= NB) {
+    RC_RB(ctx, rocsolver_dtrtri(h, rocblas_fill_lower, rocblas_diagonal_non_unit, (rocblas_int)n, L, (rocblas_int)ld, dinfo));
+    return MMG_OK;
+  }
+  const int64_t n1 = (n / 2 + 63) / 64 * 64, n2 = n - n1;
+  double* L11 = L;
+  double* L21 = L + n1;
+  double* L22 = L + n1 + n1 * ld;
+  const double one = 1.0, mone = -1.0;
+  // L21 <- L21 L11^-1   (X L11 = L21)
+  RC_RB(ctx, rocblas_dtrsm_64(h, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
+                              n2, n1, &one, L11, ld, L21, ld));
+  // L21 <- -L22^-1 L21
+  RC_RB(ctx, rocblas_dtrsm_64(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
+                              n2, n1, &mone, L22, ld, L21, ld));
+  int rc = tri_inv_lower(ctx, h, L11, n1, ld, dinfo);
+  if (rc) return rc;
+  return tri_inv_lower(ctx, h, L22, n2, ld, dinfo);
+}
+
+struct RemlPoint {           // everything one delta yields
+  double s1, s2, s3, s4;
+  std::vector<double> beta;  // GLS estimate (q)
+  std::vector<double> Py;    // N (only when asked for)
+  std::vector<double> GA;    // N x q row-major: H^-1 X (X'H^-1 X)^-1 (only when asked for)
+};
+
+// factor H = K + delta I in r->dL and fill `pt`; leaves L^-1 (lower) in r->dL when inverse is true
+static int reml_point(mmg_ctx* ctx, mmg_reml* r, double delta, bool inverse, bool want_vectors, RemlPoint& pt) {
+  rocblas_handle h;
+  int rc = reml_handle(ctx, &h);
+  if (rc) return rc;
+  const int64_t N = r->N;
+  const int q = r->q, q1 = q + 1;
+  hipStream_t st = ctx->stream;
+  rocblas_int* dinfo = (rocblas_int*)(r->dsc + N + 4);
+  RC_HIP(ctx, hipMemcpyAsync(r->dL, r->dK, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, st));
+  hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, r->dL, N, delta);
+  RC_RB(ctx, rocsolver_dpotrf_64(h, rocblas_fill_lower, N, r->dL, N, (int64_t*)dinfo));
+  RC_HIP(ctx, hipMemsetAsync(r->dsc, 0, 4 * sizeof(double), st));
+  hipLaunchKernelGGL(logdiag_kernel, dim3(1), dim3(256), 0, st, r->dL, N, r->dsc);
+  // Z = L^-1 [X y];  G = L^-T Z
+  const double one = 1.0;
+  RC_HIP(ctx, hipMemcpyAsync(r->dZ, r->dB, (size_t)N * q1 * sizeof(double), hipMemcpyDeviceToDevice, st));
+  RC_RB(ctx, rocblas_dtrsm_64(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N,
+                              q1, &one, r->dL, N, r->dZ, N));
+  RC_HIP(ctx, hipMemcpyAsync(r->dG, r->dZ, (size_t)N * q1 * sizeof(double), hipMemcpyDeviceToDevice, st));
+  RC_RB(ctx, rocblas_dtrsm_64(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
+                              N, q1, &one, r->dL, N, r->dG, N));
+  std::vector<double> Z((size_t)N * q1), G((size_t)N * q1);
+  double sc[4] = {0, 0, 0, 0};
+  int64_t info64 = 0;
+  RC_HIP(ctx, hipMemcpyAsync(Z.data(), r->dZ, Z.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  RC_HIP(ctx, hipMemcpyAsync(G.data(), r->dG, G.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  RC_HIP(ctx, hipMemcpyAsync(sc, r->dsc, sizeof(sc), hipMemcpyDeviceToHost, st));
+  RC_HIP(ctx, hipMemcpyAsync(&info64, dinfo, sizeof(info64), hipMemcpyDeviceToHost, st));
+  RC_HIP(ctx, hipStreamSynchronize(st));
+  if (info64 != 0) return set_err(ctx, MMG_E_LIB, "K + delta I is not positive definite (dpotrf info " + std::to_string((long long)info64) + ")");
+  const double logdetH = 2.0 * sc[0];
+  double trHinv = 0.0;
+  if (inverse) {
+    rc = tri_inv_lower(ctx, h, r->dL, N, N, dinfo);
+    if (rc) return rc;
+    hipLaunchKernelGGL(lower_sqnorm_kernel, dim3((unsigned)N), dim3(256), 0, st, r->dL, N, r->dsc + 4);
+    std::vector<double> part((size_t)N);
+    RC_HIP(ctx, hipMemcpyAsync(part.data(), r->dsc + 4, N * sizeof(double), hipMemcpyDeviceToHost, st));
+    RC_HIP(ctx, hipStreamSynchronize(st));
+    for (int64_t j = 0; j < N; ++j) trHinv += part[j];
+  }
+  // ---- q x q algebra on the host (columns of Z / G are contiguous: column-major N x q1)
+  auto colZ = [&](int c) { return Z.data() + (size_t)c * N; };
+  auto colG = [&](int c) { return G.data() + (size_t)c * N; };
+  auto dot = [&](const double* a, const double* b) { double s = 0; for (int64_t i = 0; i < N; ++i) s += a[i] * b[i]; return s; };
+  std::vector<double> a((size_t)q * q), b((size_t)q), B2((size_t)q * q);
+  for (int i = 0; i < q; ++i) {
+    for (int j = 0; j <= i; ++j) {
+      a[i * q + j] = a[j * q + i] = dot(colZ(i), colZ(j));                  // X'H^-1 X
+      B2[i * q + j] = B2[j * q + i] = dot(colG(i), colG(j));               // X'H^-2 X
+    }
+    b[i] = dot(colZ(i), colZ(q));                                          // X'H^-1 y
+  }
+  const double c = dot(colZ(q), colZ(q));                                  // y'H^-1 y
+  std::vector<double> beta = b;
+  double logdet_a = 0.0;
+  if (!chol_solve_small(q, a, beta, 1, &logdet_a)) return set_err(ctx, MMG_E_LIB, "X'H^-1 X is not positive definite");
+  std::vector<double> aB2 = B2;
+  chol_solve_small(q, a, aB2, q, nullptr);                                 // a^-1 B2
+  double tr_aB2 = 0.0, bb = 0.0;
+  for (int i = 0; i < q; ++i) { tr_aB2 += aB2[i * q + i]; bb += b[i] * beta[i]; }
+  std::vector<double> Py((size_t)N);
+  double s3 = 0.0;
+  for (int64_t i = 0; i < N; ++i) {
+    double v = colG(q)[i];
+    for (int k = 0; k < q; ++k) v -= colG(k)[i] * beta[k];
+    Py[i] = v;
+    s3 += v * v;
+  }
+  pt.s1 = c - bb;
+  pt.s2 = logdetH + logdet_a - r->logdet_xtx;
+  pt.s3 = s3;
+  pt.s4 = trHinv - tr_aB2;
+  pt.beta = beta;
+  if (want_vectors) {
+    pt.Py = Py;
+    // GA = Gx a^-1  (N x q row-major)
+    std::vector<double> ainv((size_t)q * q, 0.0);
+    for (int i = 0; i < q; ++i) ainv[i * q + i] = 1.0;
+    chol_solve_small(q, a, ainv, q, nullptr);
+    pt.GA.assign((size_t)N * q, 0.0);
+    for (int64_t i = 0; i < N; ++i)
+      for (int j = 0; j < q; ++j) {
+        double v = 0.0;
+        for (int k = 0; k < q; ++k) v += colG(k)[i] * ainv[k * q + j];
+        pt.GA[(size_t)i * q + j] = v;
+      }
+  }
+  return MMG_OK;
+}
+
+namespace mmg {
+int model_from_device_public(mmg_ctx* ctx, int32_t N, const double* dA, const double* dw, int ndigits, bool adaptive);
+}
+
+extern "C" {
+
+int mmg_reml_create(mmg_ctx* ctx, int32_t N, int32_t q, const double* K, const double* X, const double* y, mmg_reml** out) {
+  if (!ctx) return MMG_E_ARG;
+  RC_HIP(ctx, hipSetDevice(ctx->device));
+  if (!(out && K && X && y && N > 0 && q >= 1 && q <= 16 && q < N)) return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_create");
+  *out = nullptr;
+  mmg_reml* r = new mmg_reml();
+  r->N = N; r->q = q;
+  const size_t nn = (size_t)N * N * sizeof(double), nq = (size_t)N * (q + 1) * sizeof(double);
+  hipError_t e = hipMalloc(&r->dK, nn);
+  if (e == hipSuccess) e = hipMalloc(&r->dL, nn);
+  if (e == hipSuccess) e = hipMalloc(&r->dB, nq);
+  if (e == hipSuccess) e = hipMalloc(&r->dZ, nq);
+  if (e == hipSuccess) e = hipMalloc(&r->dG, nq);
+  if (e == hipSuccess) e = hipMalloc(&r->dsc, ((size_t)N + 16) * sizeof(double));
+  if (e != hipSuccess) {
+    hipFree(r->dK); hipFree(r->dL); hipFree(r->dB); hipFree(r->dZ); hipFree(r->dG); hipFree(r->dsc); delete r;
+    return set_err(ctx, MMG_E_NOMEM, std::string("hipMalloc REML workspace: ") + hipGetErrorString(e));
+  }
+  r->X.assign(X, X + (size_t)N * q);
+  r->y.assign(y, y + N);
+  std::vector<double> B((size_t)N * (q + 1));                              // column-major [X y]
+  for (int64_t i = 0; i < N; ++i) {
+    for (int c = 0; c < q; ++c) B[(size_t)c * N + i] = X[(size_t)i * q + c];
+    B[(size_t)q * N + i] = y[i];
+  }
+  RC_HIP(ctx, hipMemcpyAsync(r->dK, K, nn, hipMemcpyHostToDevice, ctx->stream));
+  RC_HIP(ctx, hipMemcpyAsync(r->dB, B.data(), nq, hipMemcpyHostToDevice, ctx->stream));
+  RC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // log|X'X| and |Sy|^2 = y'y - y'X (X'X)^-1 X'y
+  std::vector<double> xtx((size_t)q * q, 0.0), xty((size_t)q, 0.0);
+  double yy = 0.0;
+  for (int64_t i = 0; i < N; ++i) {
+    for (int a = 0; a < q; ++a) {
+      for (int b = 0; b < q; ++b) xtx[a * q + b] += X[(size_t)i * q + a] * X[(size_t)i * q + b];
+      xty[a] += X[(size_t)i * q + a] * y[i];
+    }
+    yy += y[i] * y[i];
+  }
+  std::vector<double> sol = xty;
+  if (!chol_solve_small(q, xtx, sol, 1, &r->logdet_xtx)) { mmg_reml_destroy(ctx, r); return set_err(ctx, MMG_E_ARG, "X'X is singular"); }
+  double t = 0.0;
+  for (int a = 0; a < q; ++a) t += xty[a] * sol[a];
+  r->sum_sq_etas = yy - t;
+  *out = r;
+  return MMG_OK;
+}
+
+int mmg_reml_destroy(mmg_ctx* ctx, mmg_reml* r) {
+  if (!r) return MMG_OK;
+  if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
+  hipFree(r->dK); hipFree(r->dL); hipFree(r->dB); hipFree(r->dZ); hipFree(r->dG); hipFree(r->dsc);
+  delete r;
+  return MMG_OK;
+}
+
+int mmg_reml_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3,
+                  double* s4, double* sum_sq_etas) {
+  if (!ctx) return MMG_E_ARG;
+  RC_HIP(ctx, hipSetDevice(ctx->device));
+  if (!(r && deltas && s1 && s2 && s3 && s4 && nd >= 0)) return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_sums");
+  if (sum_sq_etas) *sum_sq_etas = r->sum_sq_etas;
+  for (int k = 0; k < nd; ++k) {
+    RemlPoint pt;
+    int rc = reml_point(ctx, r, deltas[k], true, false, pt);
+    if (rc) return rc;
+    s1[k] = pt.s1; s2[k] = pt.s2; s3[k] = pt.s3; s4[k] = pt.s4;
+  }
+  return MMG_OK;
+}
+
+int mmg_reml_scan_model(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, double* h0_rss, double* beta,
+                        double* mahalanobis_rss) {
+  if (!ctx) return MMG_E_ARG;
+  RC_HIP(ctx, hipSetDevice(ctx->device));
+  if (!r) return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_scan_model");
+  rocblas_handle h;
+  int rc = reml_handle(ctx, &h);
+  if (rc) return rc;
+  RemlPoint pt;
+  rc = reml_point(ctx, r, delta, true, true, pt);          // leaves L^-1 (lower) in dL
+  if (rc) return rc;
+  const int64_t N = r->N;
+  const int q = r->q;
+  hipStream_t st = ctx->stream;
+  Scratch sc;
+  double *dP = nullptr, *dw = nullptr, *dGA = nullptr, *dGx = nullptr;
+  RC_HIP(ctx, sc.alloc(&dP, (size_t)N * N * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&dw, N * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&dGA, (size_t)N * q * sizeof(double)));
+  // H^-1 = L^-T L^-1: syrk on the triangular factor used as a dense matrix (upper triangle zeroed first)
+  hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)N), dim3(256), 0, st, r->dL, N);
+  const double one = 1.0, zero = 0.0, mone = -1.0;
+  RC_RB(ctx, rocblas_dsyrk_64(h, rocblas_fill_lower, rocblas_operation_transpose, N, N, &one, r->dL, N, &zero, dP, N));
+  hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)N), dim3(256), 0, st, dP, N);
+  // P = H^-1 - (Gx a^-1) Gx'   (GA row-major N x q == column-major q x N;  dG column-major N x (q+1): Gx = first q columns)
+  RC_HIP(ctx, hipMemcpyAsync(dGA, pt.GA.data(), (size_t)N * q * sizeof(double), hipMemcpyHostToDevice, st));
+  dGx = r->dG;
+  // column-major: P (N x N) -= Gx (N x q) * GA' (q x N) where GA' in column-major is the row-major GA buffer read as q x N
+  RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_none, N, N, q, &mone, dGx, N, dGA, q, &one, dP, N));
+  RC_HIP(ctx, hipMemcpyAsync(dw, pt.Py.data(), N * sizeof(double), hipMemcpyHostToDevice, st));
+  RC_HIP(ctx, hipGetLastError());
+  bool adaptive = false;
+  if (ndigits == 0) {
+    ndigits = 4;
+    const char* e = std::getenv("MMG_SCAN_ADAPTIVE");
+    adaptive = !(e && e[0] == '0');
+  }
+  rc = model_from_device_public(ctx, (int32_t)N, dP, dw, ndigits, adaptive);
+  if (rc) return rc;
+  RC_HIP(ctx, hipStreamSynchronize(st));
+  if (h0_rss) *h0_rss = pt.s1;
+  if (mahalanobis_rss) *mahalanobis_rss = pt.s1;
+  if (beta) std::memcpy(beta, pt.beta.data(), q * sizeof(double));
+  return MMG_OK;
+}
+
+}  // extern "C"

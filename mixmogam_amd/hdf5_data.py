@@ -191,9 +191,13 @@ def _gather_owned(parts, plan, coll):
 
 
 def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=True, chunk_size=100000, k=None,
-              ctx=None, coll=None, num_perm=0, perm_idx=None, phenotypes=None, prefetch=True, fast_perm=True):
+              ctx=None, coll=None, num_perm=0, perm_idx=None, phenotypes=None, prefetch=True, fast_perm=True,
+              eigen_free=None):
     """hdf5_data.py:70-187 (and :191-351 when num_perm > 0).  fast_perm: the permutation test of a chunk reuses the
     quadratic forms of the scan that just ran over it (mmg_emmax_perm_after_scan) instead of recomputing them.
+    eigen_free: REML and the scan model from Cholesky factorisations instead of eigh(K) (linear_models.
+    get_estimates_eigen_free); default: exactly when N is beyond rocSOLVER's syevd range (N > 46,340) and no
+    permutation test is asked for (that one needs H_sqrt_inv itself).
 
     hdf5_filename: container path (chunkstore / HDF5) or an open genot_data tree / mapping.  For the reference's
     call shape `run_emmax(genot_data, phenotypes, ...)` of round 1 the second positional argument may be the
@@ -225,12 +229,19 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
         n_snps = sum(len(sel) for _c, sel, _p in plan)
     lmm = lm.LinearMixedModel(phenotypes, ctx=ctx)                       # :121
     lmm.add_random_effect(k)
-    eig_L = lmm._get_eigen_L_()                                          # :126
-    res = lmm.get_estimates(eig_L, method='REML')                        # :131-137 (no eig_R: linear_models._SpectralSumsL)
+    if eigen_free is None:
+        eigen_free = n > 46340 and not num_perm and isinstance(ctx, _lib.Context)
+    if eigen_free:
+        res = lmm.get_estimates_eigen_free(coll=coll)                    # :126-137 without either eigendecomposition
+        prep = lmm.scan_model_eigen_free(res)
+        res.pop('reml').close()
+    else:
+        eig_L = lmm._get_eigen_L_()                                      # :126
+        res = lmm.get_estimates(eig_L, method='REML')                    # :131-137 (no eig_R: linear_models._SpectralSumsL)
+        prep = lmm.scan_prepare(res['H_sqrt_inv'])
+        ctx.scan_set_model(prep['A'], prep['w'], 0)
     out = {'pseudo_heritability': res['pseudo_heritability'], 've': res['ve'], 'vg': res['vg'],
            'max_ll': res['max_ll'], 'num_snps': n_snps, 'chrom_results': {}, 'kinship': k}
-    prep = lmm.scan_prepare(res['H_sqrt_inv'])
-    ctx.scan_set_model(prep['A'], prep['w'], 0)
     chroms = list(genot_data.keys())
     parts = {}
     pp = None

@@ -147,6 +147,43 @@ class _SpectralSumsL(object):
         return s1, s2, s3, s4
 
 
+class _SpectralSumsChol(object):
+    """The same four sums with NO eigendecomposition: one Cholesky factorisation of K + delta I per delta on the
+    device (_lib.Reml / mmg_reml_sums; csrc/reml_chol.hip).  For N beyond rocSOLVER's syevd index range
+    (N > 46,340), where eigh falls back to block Jacobi (6.6 min at N = 50,000), this is the cheaper route: the
+    likelihood needs ~60 factorisations of N^3/3 + N^3/3 flops each.  coll: the grid values are dealt out to the ranks
+    (every rank holds K) and the sums all-gathered."""
+
+    def __init__(self, reml, coll=None):
+        self.reml, self.coll = reml, coll
+        self.sum_sq_etas = None
+        self.n_factorisations = 0
+
+    def at(self, deltas):
+        deltas = np.asarray(deltas, dtype=np.float64).reshape(-1)
+        coll = self.coll
+        if coll is not None and coll.world > 1 and len(deltas) >= coll.world:
+            mine = np.arange(coll.rank, len(deltas), coll.world)
+            part = self.reml.sums(deltas[mine])
+            self.n_factorisations += len(mine)
+            count = -(-len(deltas) // coll.world)
+            blk = np.full((4, count), np.nan)
+            for k in range(4):
+                blk[k, :len(mine)] = part[k]
+            allb = np.asarray(coll.allgather(blk.reshape(-1))).reshape(coll.world, 4, count)
+            out = [np.empty(len(deltas)) for _ in range(4)]
+            for r in range(coll.world):
+                idx = np.arange(r, len(deltas), coll.world)
+                for k in range(4):
+                    out[k][idx] = allb[r, k, :len(idx)]
+            self.sum_sq_etas = part[4]
+            return tuple(out)
+        s1, s2, s3, s4, sse = self.reml.sums(deltas)
+        self.n_factorisations += len(deltas)
+        self.sum_sq_etas = sse
+        return s1, s2, s3, s4
+
+
 class LinearMixedModel(object):
     """linear_models.py:554 (and the parts of LinearModel :81 it inherits on this path)."""
 
@@ -270,7 +307,7 @@ class LinearMixedModel(object):
 
     def get_estimates(self, eig_L, K=None, xs=None, ngrids=50, llim=-10, ulim=10, esp=1e-6,
                       return_pvalue=False, return_f_stat=False, method='REML', verbose=False,
-                      dtype='double', eig_R=None, rss_0=None, return_H=True, _rot=None, use_eig_R=False):
+                      dtype='double', eig_R=None, rss_0=None, return_H=True, _rot=None, use_eig_R=False, _sums=None):
         """:771-927 -- EMMA variance-component estimates (Kang et al. 2008).
         use_eig_R: take the likelihood sums from the caller's eig_R even when xs is None (the reference's `:787`
         test would recompute it there); used by callers that already hold eig_R and by the route-comparison tests."""
@@ -286,7 +323,7 @@ class LinearMixedModel(object):
         y = self.Y.reshape(-1)
         log_deltas = (np.arange(m, dtype=np.float64) / ngrids) * (ulim - llim) + llim
         deltas = np.exp(log_deltas)
-        eig_vals_L = np.asarray(eig_L['values'], dtype=np.float64)
+        eig_vals_L = np.asarray(eig_L['values'], dtype=np.float64) if eig_L is not None else None
         # The likelihood only needs four sums over the spectrum of S(K+delta I)S -- s1 = sum eta^2/(xi+delta),
         # s3 = sum eta^2/(xi+delta)^2, s2 = sum log(xi+delta), s4 = sum 1/(xi+delta) -- and sum eta^2.  The
         # reference gets them from a second N^3 eigendecomposition (eig_R, :787-799); they are also
@@ -294,7 +331,11 @@ class LinearMixedModel(object):
         # with H = K + delta I and P = H^-1 - H^-1 X (X'H^-1 X)^-1 X'H^-1, i.e. O(N q^2) per delta from eig_L alone
         # (_SpectralSums).  Where the reference would compute eig_R itself (:787) the second eigh is skipped;
         # a caller-supplied eig_R that the reference would use (xs given) is used as is.
-        if eig_R and (xs is not None or use_eig_R):
+        if _sums is not None:
+            sums = _sums                                                 # e.g. _SpectralSumsChol: no eigen-pairs at all
+            if method != 'REML':
+                raise NotImplementedError("the eigendecomposition-free route evaluates the restricted likelihood only")
+        elif eig_R and (xs is not None or use_eig_R):
             sums = _SpectralSumsR(eig_R, y, p)
         elif K is not None or not REML_SUMS_FROM_EIG_L:
             sums = _SpectralSumsR(self._get_eigen_R_(X=X, K=K), y, p)   # :787 (quirk kept)
@@ -366,6 +407,11 @@ class LinearMixedModel(object):
         # is reported as is so that results are identical; nothing on the scan path uses it.
         opt_vg = sums.sum_sq_etas * sums.at(np.array([opt_delta], dtype=np.float64))[3][0] / p
         opt_ve = opt_vg * opt_delta
+        if isinstance(sums, _SpectralSumsChol):
+            # no H_sqrt_inv without eigenvectors: the GLS estimate and the Mahalanobis RSS (= y'Py = s1) come with
+            # the scan model (LinearMixedModel.scan_model_eigen_free)
+            return {'max_ll': opt_ll, 'delta': opt_delta, 've': opt_ve, 'vg': opt_vg, 'H_sqrt_inv': None,
+                    'pseudo_heritability': 1.0 / (1 + opt_delta), 'n_factorisations': sums.n_factorisations}
         # :898-907.  H_sqrt_inv = diag((lambda+delta)^-1/2) U'; its products with X and y are row scalings of the
         # rotated U'X, U'y that _SpectralSumsL already holds (O(N q) instead of O(N^2 q)); the N x N matrix itself
         # is only formed when the caller wants it (return_H; the exact-EMMA loop does not).
@@ -459,6 +505,27 @@ class LinearMixedModel(object):
     def _get_estimates_with(self, eig_L, eig_R, method, ngrids=50):
         """get_estimates on a PRECOMPUTED eig_R (the reference's own route, :787-799)."""
         return self.get_estimates(eig_L, method=method, eig_R=eig_R, ngrids=ngrids, use_eig_R=True)
+
+    def get_estimates_eigen_free(self, ngrids=50, llim=-10, ulim=10, esp=1e-6, coll=None):
+        """get_estimates(method='REML') (:771-927) without eig_L / eig_R: the likelihood sums come from Cholesky
+        factorisations on the device (_SpectralSumsChol).  Returns the same scalars (max_ll, delta, ve, vg,
+        pseudo_heritability) plus 'reml': the device workspace to hand to scan_model_eigen_free.  No H_sqrt_inv:
+        callers that need the matrix itself (permutation test, exact EMMA) take the eigen route."""
+        K = self.random_effects[1][1]
+        reml = self.ctx.reml(K, self.X, self.Y.reshape(-1))
+        res = self.get_estimates(None, ngrids=ngrids, llim=llim, ulim=ulim, esp=esp, method='REML',
+                                 _sums=_SpectralSumsChol(reml, coll))
+        res['reml'] = reml
+        return res
+
+    def scan_model_eigen_free(self, res, ndigits=0):
+        """Load the EMMAX scan model of res['delta'] (A = P, w = Py, built on the device; :1290-1303 in closed form)
+        into the context and return the SNP-independent outputs of scan_prepare: h0_rss, h0_betas, n_p."""
+        h0_rss, beta = res['reml'].scan_model(res['delta'], ndigits)
+        y = self.Y.reshape(-1)
+        resid = y - self.X @ beta
+        res.update(beta=beta.reshape(-1, 1), mahalanobis_rss=np.array([h0_rss]), rss=float(resid @ resid))
+        return {'h0_rss': h0_rss, 'h0_betas': [float(b) for b in beta], 'n_p': self.n - (self.X.shape[1] + 1)}
 
     def scan_prepare(self, H_sqrt_inv, Z=None, with_betas=False):
         """SNP-independent part of _emmax_f_test_ (:1290-1306) in closed form:

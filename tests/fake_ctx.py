@@ -69,8 +69,45 @@ class FakeRot(object):
         pass
 
 
+class FakeReml(object):
+    """numpy stand-in for _lib.Reml (mmg_reml_*): the four likelihood sums from H = K + delta I by dense solves."""
+
+    def __init__(self, ctx, K, X, y):
+        self.ctx, self.K, self.X, self.y = ctx, np.asarray(K, float), np.asarray(X, float), np.asarray(y, float).reshape(-1)
+        xtx = self.X.T @ self.X
+        xty = self.X.T @ self.y
+        self.sse = float(self.y @ self.y - xty @ np.linalg.solve(xtx, xty))
+        self.logdet_xtx = np.linalg.slogdet(xtx)[1]
+
+    def _point(self, delta):
+        H = self.K + delta * np.eye(len(self.K))
+        Hi = np.linalg.inv(H)
+        HiX, Hiy = Hi @ self.X, Hi @ self.y
+        a = self.X.T @ HiX
+        beta = np.linalg.solve(a, self.X.T @ Hiy)
+        Py = Hiy - HiX @ beta
+        P = Hi - HiX @ np.linalg.solve(a, HiX.T)
+        return (float(self.y @ Py), np.linalg.slogdet(H)[1] + np.linalg.slogdet(a)[1] - self.logdet_xtx,
+                float(Py @ Py), float(np.trace(P)), beta, Py, P)
+
+    def sums(self, deltas):
+        pts = [self._point(d) for d in np.asarray(deltas).reshape(-1)]
+        return tuple(np.array([p[k] for p in pts]) for k in range(4)) + (self.sse,)
+
+    def scan_model(self, delta, ndigits=0):
+        s1, _s2, _s3, _s4, beta, Py, P = self._point(delta)
+        self.ctx.scan_set_model(P, Py)
+        return s1, beta
+
+    def close(self):
+        pass
+
+
 class FakeContext(object):
     device = 0
+
+    def reml(self, K, X, y):
+        return FakeReml(self, K, X, y)
 
     def geno(self, snps=None, M=None, N=None):
         return FakeGeno(self, snps if snps is not None else np.zeros((M, N), dtype=np.int8))

@@ -362,3 +362,52 @@ def test_perm_after_scan_equals_the_standalone_test(ctx, case):
     with pytest.raises(_lib.MixmogamHipError):
         ctx.perm(g, pp["H"], pp["Ys"], pp["h0_rss"], after_scan_HtQ=prep["HtQ"])
     g.close()
+
+
+def test_eigen_free_reml_on_the_device_vs_golden(ctx, case):
+    """mmg_reml_sums / mmg_reml_scan_model (Cholesky per delta, recursive triangular inverse, P and Py built in HBM):
+    the likelihood sums equal the eig_L route's to 1e-9, the REML scalars and the p-values equal the reference's."""
+    from mixmogam_amd import linear_models as lm
+    lmm = lm.LinearMixedModel(list(case["y"]), ctx=ctx)
+    lmm.add_random_effect(case["dbl_ibs_scaled"])
+    if case["cof"] is not None:
+        for c in case["cof"]:
+            lmm.add_factor(c)
+    eig_L = lmm._get_eigen_L_()
+    reml = ctx.reml(lmm.random_effects[1][1], lmm.X, lmm.Y.reshape(-1))
+    deltas = np.exp(np.array([-10.0, -3.0, 0.0, 0.7, 4.0, 10.0]))
+    a = lm._SpectralSumsChol(reml).at(deltas)
+    b = lm._SpectralSumsL(eig_L, lmm.X, lmm.Y.reshape(-1)).at(deltas)
+    for k in range(4):
+        assert rel(a[k], b[k]) < 1e-8, k
+    reml.close()
+    res = lmm.get_estimates_eigen_free()
+    for k in ("pseudo_heritability", "ve", "vg", "max_ll"):
+        assert rel(res[k], case["dbl_emmax_" + k]) < 1e-7, k
+    prep = lmm.scan_model_eigen_free(res)
+    res.pop("reml").close()
+    assert rel(prep["h0_rss"], case["dbl_emmax_h0_rss"]) < 1e-7
+    assert rel(prep["h0_betas"], case["dbl_emmax_h0_betas"]) < 1e-6
+    g = ctx.geno(case["snps"])
+    out = ctx.scan(g, prep["h0_rss"], prep["n_p"])
+    g.close()
+    assert rel(out["ps"], case["dbl_emmax_ps"]) < 1e-6
+
+
+def test_eigen_free_recursive_inverse_beyond_one_block(ctx):
+    """N = 9,000 > the 4,096-row base block of the recursive triangular inverse: tr H^-1 against the eigenvalues."""
+    from mixmogam_amd import linear_models as lm
+    rng = np.random.RandomState(4)
+    n = 9000
+    B = rng.standard_normal((n, 40))
+    K = B @ B.T / 40 + 0.05 * np.eye(n)
+    y = rng.standard_normal(n)
+    X = np.ones((n, 1))
+    reml = ctx.reml(K, X, y)
+    deltas = np.array([0.3, 5.0])
+    s1, s2, s3, s4 = lm._SpectralSumsChol(reml).at(deltas)
+    reml.close()
+    vals, vecs = ctx.eigh(K)
+    ref = lm._SpectralSumsL({"values": vals, "vectors": vecs}, X, y).at(deltas)
+    for got, want in zip((s1, s2, s3, s4), ref):
+        assert rel(got, want) < 1e-8

@@ -220,3 +220,22 @@ def test_run_emmax_from_and_to_containers(ctx, tmp_path):
     assert n_snps == 700 and "kinship" in chunkstore.open_container(path, "r").keys()
     again = hdf5_data.run_emmax(path, None, min_maf=0.1, recalculate_kinship=False, chunk_size=100, ctx=ctx)
     assert rel(again["kinship"], k) == 0.0
+
+
+def test_eigen_free_reml_and_scan_model_equal_the_eigen_route(case, ctx):
+    """get_estimates_eigen_free / scan_model_eigen_free (likelihood sums and the scan model from H = K + delta I
+    directly, no eig_L / eig_R) against the reference's numbers: same delta, ve, vg, max_ll, p-values."""
+    lmm = lm.LinearMixedModel(list(case["y"]), ctx=ctx)
+    lmm.add_random_effect(case["dbl_ibs_scaled"])
+    if case["cof"] is not None:
+        for c in case["cof"]:
+            lmm.add_factor(c)
+    res = lmm.get_estimates_eigen_free()
+    assert res["H_sqrt_inv"] is None and res["n_factorisations"] >= 51
+    for k in ("pseudo_heritability", "ve", "vg", "max_ll"):
+        assert rel(res[k], case["dbl_emmax_" + k]) < 1e-7, k
+    prep = lmm.scan_model_eigen_free(res)
+    assert rel(prep["h0_rss"], case["dbl_emmax_h0_rss"]) < 1e-7
+    assert rel(prep["h0_betas"], case["dbl_emmax_h0_betas"]) < 1e-6
+    out = ctx.scan(ctx.geno(case["snps"]), prep["h0_rss"], prep["n_p"])
+    assert rel(out["ps"], case["dbl_emmax_ps"]) < 1e-6

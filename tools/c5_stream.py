@@ -27,6 +27,7 @@ ap.add_argument("--world", type=int, default=8, help="ranks the SNP axis is spli
 ap.add_argument("--chunk", type=int, default=50000)
 ap.add_argument("--scratch", default="/dev/shm")
 ap.add_argument("--keep", action="store_true")
+ap.add_argument("--eig", action="store_true", help="take the eigendecomposition route (eigh of K) even beyond N = 46,340")
 a = ap.parse_args()
 N, M, CH = a.n, a.m_total // a.world, a.chunk
 root = os.path.join(a.scratch, "mmg_c5_%d" % os.getpid())
@@ -66,16 +67,30 @@ try:
     y = src["phenotypes"]
     lmm = lm.LinearMixedModel(y, ctx=ctx)
     lmm.add_random_effect(K)
-    t0 = time.time()
-    eig_L = lmm._get_eigen_L_()
-    T["eigh_s"] = round(time.time() - t0, 1)
-    print("eigh: %.1f s" % T["eigh_s"], flush=True)
-    t0 = time.time()
-    est = lmm.get_estimates(eig_L, method="REML")
-    prep = lmm.scan_prepare(est["H_sqrt_inv"])
-    ctx.scan_set_model(prep["A"], prep["w"], 0)
-    T["reml_and_model_s"] = round(time.time() - t0, 1)
-    print("REML + scan model: %.1f s (pseudo-h2 %.4f)" % (T["reml_and_model_s"], est["pseudo_heritability"]), flush=True)
+    eigen_free = N > 46340 and not a.eig
+    if eigen_free:
+        # REML from Cholesky factorisations of K + delta I, scan model P(delta), P y built in HBM: no eigh at all
+        t0 = time.time()
+        est = lmm.get_estimates_eigen_free()
+        T["reml_cholesky_s"] = round(time.time() - t0, 1)
+        print("REML, eigendecomposition-free (%d Cholesky factorisations + triangular inverses): %.1f s (pseudo-h2 %.4f)"
+              % (est["n_factorisations"], T["reml_cholesky_s"], est["pseudo_heritability"]), flush=True)
+        t0 = time.time()
+        prep = lmm.scan_model_eigen_free(est)
+        est.pop("reml").close()
+        T["scan_model_s"] = round(time.time() - t0, 1)
+        print("scan model P(delta), P y on the device: %.1f s" % T["scan_model_s"], flush=True)
+    else:
+        t0 = time.time()
+        eig_L = lmm._get_eigen_L_()
+        T["eigh_s"] = round(time.time() - t0, 1)
+        print("eigh: %.1f s" % T["eigh_s"], flush=True)
+        t0 = time.time()
+        est = lmm.get_estimates(eig_L, method="REML")
+        prep = lmm.scan_prepare(est["H_sqrt_inv"])
+        ctx.scan_set_model(prep["A"], prep["w"], 0)
+        T["reml_and_model_s"] = round(time.time() - t0, 1)
+        print("REML + scan model: %.1f s (pseudo-h2 %.4f)" % (T["reml_and_model_s"], est["pseudo_heritability"]), flush=True)
     t0 = time.time()
     ps = np.empty(M)
     at = 0
@@ -90,10 +105,37 @@ try:
     T["scan_quad_kernel_s"] = round(quad_ms / 1e3, 2)
     print("scan pass (ingest overlapped with the scan): %.2f s = %.3f M SNPs/s incl. ingest (GEMM kernels %.2f s)"
           % (T["scan_pass_s"], M / T["scan_pass_s"] / 1e6, quad_ms / 1e3), flush=True)
-    # ---- sample check: float64 host evaluation of linear_models.py:1316-1349
-    H = np.asarray(est["H_sqrt_inv"])
-    hX = H @ lmm.X
-    Q, _ = np.linalg.qr(hX)
+    # ---- sample check in float64 on the host, independent of either route: with H = K + delta I the reference's
+    # per-SNP statistic (linear_models.py:1316-1349) is rss = y'Py - (s'Py)^2 / (s'Ps), P = H^-1 - H^-1X(X'H^-1X)^-1X'H^-1;
+    # the H^-1 b are solved by conjugate gradients on the dense kinship (no factorisation, no eigenvectors)
+    Ks = lmm.random_effects[1][1]
+    delta = float(est["delta"])
+
+    def solve(b):
+        x = np.zeros_like(b)
+        r = b.copy()
+        p = r.copy()
+        rs = float(r @ r)
+        b2 = float(b @ b)
+        for _ in range(500):
+            Ap = Ks @ p + delta * p
+            alpha = rs / float(p @ Ap)
+            x += alpha * p
+            r -= alpha * Ap
+            rs_new = float(r @ r)
+            if rs_new < 1e-26 * b2:
+                break
+            p = r + (rs_new / rs) * p
+            rs = rs_new
+        return x
+
+    X = lmm.X
+    HiX = np.column_stack([solve(np.ascontiguousarray(X[:, c])) for c in range(X.shape[1])])
+    Hiy = solve(np.asarray(y, dtype=np.float64))
+    a_ = X.T @ HiX
+    Py = Hiy - HiX @ np.linalg.solve(a_, X.T @ Hiy)
+    h0_rss = float(np.asarray(y) @ Py)
+    print("h0_rss device %.12g vs host CG %.12g" % (prep["h0_rss"], h0_rss), flush=True)
     rng = np.random.RandomState(3)
     hits = np.argsort(ps)
     hits = hits[ps[hits] > 1e-280][:4]
@@ -102,10 +144,10 @@ try:
     for gi in sample:
         cid, off = divmod(int(gi), CH)
         s = simulations.synthetic_chunk(cid, CH, N, 20240)[off].astype(np.float64)
-        t = H @ s
-        t = t - Q @ (Q.T @ t)
-        rss = prep["h0_rss"] - float(t @ prep["r"]) ** 2 / float(t @ t)
-        F = (prep["h0_rss"] / rss - 1) * prep["n_p"]
+        His = solve(s)
+        den = float(s @ His) - float((X.T @ His) @ np.linalg.solve(a_, X.T @ His))
+        rss = h0_rss - float(s @ Py) ** 2 / den
+        F = (h0_rss / rss - 1) * prep["n_p"]
         p = float(orc.f_sf(np.array([F]), 1, prep["n_p"])[0])
         if p > 1e-290:
             worst = max(worst, abs(ps[gi] / p - 1))
@@ -113,6 +155,7 @@ try:
     print(json.dumps({"config": "C5 share of rank 0 of %d" % a.world, "N": N, "M_share": M, "M_total": a.m_total,
                       "chunks": len(plan), "timings": T, "pipeline_s": round(total, 1),
                       "snps_per_s_end_to_end": M / total, "min_p": float(ps.min()),
+                      "route": "eigendecomposition-free (Cholesky REML)" if eigen_free else "eigh",
                       "max_rel_p_err_vs_host_f64": worst, "adaptive_last_chunk": ctx.scan_last_stats()}))
     assert worst < 1e-6
 finally:
