@@ -173,6 +173,12 @@ ys = rng.randn(3, n) + snps[[3, 9, 27]]
 one = lm.emmax_multi(snps, ys, K, ctx=FakeContext())
 two = lm.emmax_multi(snps, ys, K, ctx=FakeContext(), coll=coll)
 assert np.allclose(one["ps"], two["ps"], rtol=1e-12) and two["ps"].shape == (3, m)
+# eigendecomposition-free REML: the 51 grid values of delta dealt out to the two ranks, sums all-gathered
+lmm_a = lm.LinearMixedModel(y, ctx=FakeContext()); lmm_a.add_random_effect(K)
+lmm_b = lm.LinearMixedModel(y, ctx=FakeContext()); lmm_b.add_random_effect(K)
+ra, rb = lmm_a.get_estimates_eigen_free(coll=coll), lmm_b.get_estimates_eigen_free()
+assert abs(ra["delta"] / rb["delta"] - 1) < 1e-12 and abs(ra["max_ll"] - rb["max_ll"]) < 1e-9
+assert ra["n_factorisations"] < rb["n_factorisations"]            # each rank factorised about half the grid
 coll.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")

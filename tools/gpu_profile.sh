@@ -8,8 +8,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
-RE="scan_quad|scan_finalize|f_sf_kernel|kinship_i8|kinship_f32|transpose|perm_gemm"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extras $*"
+RE="scan_quad|scan_finalize|f_sf_kernel|kinship_i8|kinship_f32|transpose|perm_gemm|rot_gemm|scan_multi"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
