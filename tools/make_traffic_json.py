@@ -14,10 +14,23 @@ name = lambda r: r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "
 biggest = collections.defaultdict(int)
 for r in rows:
     biggest[name(r)] = max(biggest[name(r)], int(r["Grid_Size"]))
+adaptive = len(sys.argv) > 6 and sys.argv[6] == "adaptive"
+# adaptive bench runs launch the scan GEMM first with the 3-plane schedule (warm-up + timed steps) and afterwards, for
+# the all-planes reference record, with all four planes (same grid): split the full-grid dispatches in dispatch
+# order -- first half adaptive (the timed region), second half all planes
+per_counter_seq = collections.defaultdict(list)
 for r in rows:
     if int(r["Grid_Size"]) == biggest[name(r)]:
-        vals[name(r)][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"config": {"n": n, "m": m, "digits": d}, "adaptive": len(sys.argv) > 6 and sys.argv[6] == "adaptive",
+        per_counter_seq[(name(r), r["Counter_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+for (k, c), seq in per_counter_seq.items():
+    seq.sort()
+    v = [x for _, x in seq]
+    if adaptive and k.startswith("scan_quad") and len(v) >= 2 and len(v) % 2 == 0:
+        vals[k][c] = v[:len(v) // 2]
+        vals[k + "_all_planes"][c] = v[len(v) // 2:]
+    else:
+        vals[k][c] = v
+out = {"config": {"n": n, "m": m, "digits": d}, "adaptive": adaptive,
        "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes on bench.py (tools/gpu_profile.sh %s); "
                "FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md HBM section); "
                "WRITE_SIZE as is; counter unit KB" % tag,
