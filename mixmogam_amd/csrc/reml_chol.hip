@@ -15,7 +15,10 @@
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -181,9 +184,13 @@ static int reml_point(mmg_ctx* ctx, mmg_reml* r, double delta, bool inverse, boo
   const int q = r->q, q1 = q + 1;
   hipStream_t st = ctx->stream;
   rocblas_int* dinfo = (rocblas_int*)(r->dsc + N + 4);
+  const bool verbose = std::getenv("MMG_REML_VERBOSE") != nullptr;
+  auto now = [&]() { (void)hipStreamSynchronize(st); return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t0 = verbose ? now() : 0.0, t1 = 0.0, t2 = 0.0;
   RC_HIP(ctx, hipMemcpyAsync(r->dL, r->dK, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, r->dL, N, delta);
   RC_RB(ctx, rocsolver_dpotrf_64(h, rocblas_fill_lower, N, r->dL, N, (int64_t*)dinfo));
+  if (verbose) t1 = now();
   RC_HIP(ctx, hipMemsetAsync(r->dsc, 0, 4 * sizeof(double), st));
   hipLaunchKernelGGL(logdiag_kernel, dim3(1), dim3(256), 0, st, r->dL, N, r->dsc);
   // Z = L^-1 [X y];  G = L^-T Z
@@ -205,6 +212,7 @@ static int reml_point(mmg_ctx* ctx, mmg_reml* r, double delta, bool inverse, boo
   if (info64 != 0) return set_err(ctx, MMG_E_LIB, "K + delta I is not positive definite (dpotrf info " + std::to_string((long long)info64) + ")");
   const double logdetH = 2.0 * sc[0];
   double trHinv = 0.0;
+  if (verbose) t2 = now();
   if (inverse) {
     rc = tri_inv_lower(ctx, h, r->dL, N, N, dinfo);
     if (rc) return rc;
@@ -214,6 +222,9 @@ static int reml_point(mmg_ctx* ctx, mmg_reml* r, double delta, bool inverse, boo
     RC_HIP(ctx, hipStreamSynchronize(st));
     for (int64_t j = 0; j < N; ++j) trHinv += part[j];
   }
+  if (verbose)
+    fprintf(stderr, "[reml] N=%lld delta=%.4g: copy+potrf %.3f s, solves+download %.3f s, triangular inverse %.3f s\n",
+            (long long)N, delta, t1 - t0, t2 - t1, now() - t2);
   // ---- q x q algebra on the host (columns of Z / G are contiguous: column-major N x q1)
   auto colZ = [&](int c) { return Z.data() + (size_t)c * N; };
   auto colG = [&](int c) { return G.data() + (size_t)c * N; };

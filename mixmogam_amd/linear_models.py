@@ -96,6 +96,8 @@ class LinearModel(object):
 
 # Where get_estimates would compute eig_R itself, take the spectral sums from eig_L instead (no second eigh).
 REML_SUMS_FROM_EIG_L = True
+# emmax_f_test builds the scan model on the device from K and delta (mmg_reml_scan_model) when nothing needs H itself.
+DEVICE_SCAN_MODEL = True
 
 
 class _SpectralSumsR(object):
@@ -158,9 +160,18 @@ class _SpectralSumsChol(object):
         self.reml, self.coll = reml, coll
         self.sum_sq_etas = None
         self.n_factorisations = 0
+        self._memo = {}
 
     def at(self, deltas):
         deltas = np.asarray(deltas, dtype=np.float64).reshape(-1)
+        if len(deltas) == 1:                                             # rell(opt), vg, ... ask for the same delta again
+            key = float(deltas[0])
+            if key not in self._memo:
+                self._memo[key] = self._at(deltas)
+            return self._memo[key]
+        return self._at(deltas)
+
+    def _at(self, deltas):
         coll = self.coll
         if coll is not None and coll.world > 1 and len(deltas) >= coll.world:
             mine = np.arange(coll.rank, len(deltas), coll.world)
@@ -487,11 +498,20 @@ class LinearMixedModel(object):
         # The reference computes eig_R here (:1252) and again inside get_estimates (:787).  The likelihood sums
         # come from eig_L alone (_SpectralSumsL), so neither N^3 eigendecomposition is needed; a caller-supplied
         # eig_R is still honoured.
-        res = self._get_estimates_with(eig_L, eig_R, method) if eig_R else self.get_estimates(eig_L, method=method)
+        # The scan model A = Mp Mp' = P(delta), w = P y can be built from K and delta on the device (one Cholesky
+        # factorisation, mmg_reml_scan_model) instead of forming H_sqrt_inv and the N^3 product T'T on the host and
+        # moving three N x N matrices over PCIe: 0.6 s -> 0.05 s at N = 5000.  Taken when nothing needs H itself.
+        device_model = (DEVICE_SCAN_MODEL and Z is None and not with_betas and isinstance(self.ctx, _lib.Context)
+                        and len(self.random_effects) == 2)
+        if eig_R:
+            res = self._get_estimates_with(eig_L, eig_R, method)
+        else:
+            res = self.get_estimates(eig_L, method=method, return_H=not device_model)
         t['reml'] = time.time() - s0
         s0 = time.time()
         r = self._emmax_f_test_(snps, res['H_sqrt_inv'], snp_priors=snp_priors, Z=Z, with_betas=with_betas,
-                                emma_num=emma_num, eig_L=eig_L, verbose=verbose)
+                                emma_num=emma_num, eig_L=eig_L, verbose=verbose,
+                                _delta=res['delta'] if device_model else None)
         t['scan'] = time.time() - s0
         r['pseudo_heritability'] = res['pseudo_heritability']
         r['ve'] = res['ve']
@@ -553,18 +573,29 @@ class LinearMixedModel(object):
         return prep
 
     def _emmax_f_test_(self, snps, H_sqrt_inv, snp_priors=None, verbose=True, return_transformed_snps=False,
-                       Z=None, with_betas=False, emma_num=100, eig_L=None, ndigits=0, **kwargs):
-        """:1272-1380.  `snps`: list of M arrays / [M x N] array, or a device-resident _lib.Geno."""
+                       Z=None, with_betas=False, emma_num=100, eig_L=None, ndigits=0, _delta=None, **kwargs):
+        """:1272-1380.  `snps`: list of M arrays / [M x N] array, or a device-resident _lib.Geno.
+        _delta (internal): build the scan model from K and this variance ratio on the device instead of from
+        H_sqrt_inv on the host (same matrix: Mp Mp' = P(delta))."""
         if return_transformed_snps:
             raise NotImplementedError("return_transformed_snps (used by MLMM, SURVEY 8f N1) is not on the "
                                       "device path yet")
         ctx = self.ctx
-        prep = self.scan_prepare(H_sqrt_inv, Z=Z, with_betas=with_betas)
+        if _delta is not None and Z is None and not with_betas:
+            reml = ctx.reml(self.random_effects[1][1], self.X, self.Y.reshape(-1))
+            try:
+                h0_rss_d, beta_d = reml.scan_model(_delta, ndigits)
+            finally:
+                reml.close()
+            prep = {'h0_rss': h0_rss_d, 'h0_betas': [float(b) for b in beta_d], 'n_p': self.n - (self.X.shape[1] + 1)}
+        else:
+            prep = self.scan_prepare(H_sqrt_inv, Z=Z, with_betas=with_betas)
         own = not isinstance(snps, _lib.Geno)
         g = ctx.geno(kinship._as_snp_matrix(snps)) if own else snps
         try:
             num_snps = g.M
-            ctx.scan_set_model(prep['A'], prep['w'], ndigits)
+            if 'A' in prep:
+                ctx.scan_set_model(prep['A'], prep['w'], ndigits)
             n_p = prep['n_p']
             h0_rss = prep['h0_rss']
             out = ctx.scan(g, h0_rss, n_p, stats=with_betas)
@@ -902,7 +933,7 @@ def mlmm(phenotypes, K, sd=None, num_steps=10, forward_backwards=True, sign_thre
     geno = ctx.geno(all_snps)                                            # resident for every step
 
     def scan_active():
-        r = lmm._emmax_f_test_(geno, H_sqrt_inv, snp_priors=all_priors, emma_num=0, verbose=False)
+        r = lmm._emmax_f_test_(geno, H_sqrt_inv, snp_priors=all_priors, emma_num=0, verbose=False, _delta=dev_delta())
         idx = np.asarray(active)
         out = {k: np.asarray(r[k])[idx] for k in ('ps', 'rss', 'var_perc', 'ppas', 'f_stats')}
         if emma_num > 0:                                                 # :1365-1377 on the active list
@@ -912,6 +943,10 @@ def mlmm(phenotypes, K, sd=None, num_steps=10, forward_backwards=True, sign_thre
                 for key in ('ps', 'f_stats', 'rss', 'var_perc'):
                     out[key][pi] = top[key][k2]
         return out
+
+    def dev_delta():
+        # the scan model of the current variance ratio is built on the device from K and delta (no H_sqrt_inv product)
+        return reml_res['delta'] if (DEVICE_SCAN_MODEL and isinstance(ctx, _lib.Context)) else None
 
     def reestimate():
         # get_REML / get_ML use 100 grid points; no eig_R: every step would need a fresh N^3 eigh for its X
@@ -925,7 +960,7 @@ def mlmm(phenotypes, K, sd=None, num_steps=10, forward_backwards=True, sign_thre
             t = [all_snps[j] for k2, j in enumerate(cofactor_ids) if k2 != i]
             lmm.set_factors(t)
             r = lmm._emmax_f_test_(all_snps[gid:gid + 1], H_sqrt_inv, snp_priors=[cof_snp_priors[i]], emma_num=0,
-                                   verbose=False)
+                                   verbose=False, _delta=dev_delta())
             pvals.append(float(r['ps'][0])); ppas.append(float(r['ppas'][0])); fstats.append(float(r['f_stats'][0]))
         lmm.set_factors([all_snps[j] for j in cofactor_ids])
         return pvals, ppas, fstats
