@@ -15,6 +15,7 @@
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -70,6 +71,11 @@ __global__ void mirror_lower_kernel(double* __restrict__ A, int64_t N) {
   const int64_t j = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N && i > j) A[i * N + j] = A[j * N + i];
+}
+
+// first failing block of the blocked Cholesky: acc = (row offset of the block) + (info of its potrf), once
+__global__ void note_info_kernel(const rocblas_int* __restrict__ info, long long* __restrict__ acc, long long base) {
+  if (*info != 0 && *acc == 0) *acc = base + (long long)*info;
 }
 
 }  // namespace mmg
@@ -157,6 +163,19 @@ static int tri_inv_lower(mmg_ctx* ctx, rocblas_handle h, double* L, int64_t n, i
   double* L21 = L + n1;
   double* L22 = L + n1 + n1 * ld;
   const double one = 1.0, mone = -1.0;
+  static const bool use_trmm = [] { const char* e = std::getenv("MMG_REML_TRTRI"); return !(e && std::string(e) == "trsm"); }();
+  if (use_trmm) {
+    // invert the diagonal blocks first, then L21 <- -X22 L21 X11 by two triangular multiplies (in place)
+    int rc = tri_inv_lower(ctx, h, L11, n1, ld, dinfo);
+    if (rc) return rc;
+    rc = tri_inv_lower(ctx, h, L22, n2, ld, dinfo);
+    if (rc) return rc;
+    RC_RB(ctx, rocblas_dtrmm_64(h, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
+                                n2, n1, &one, L11, ld, L21, ld, L21, ld));
+    RC_RB(ctx, rocblas_dtrmm_64(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
+                                n2, n1, &mone, L22, ld, L21, ld, L21, ld));
+    return MMG_OK;
+  }
   // L21 <- L21 L11^-1   (X L11 = L21)
   RC_RB(ctx, rocblas_dtrsm_64(h, rocblas_side_right, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit,
                               n2, n1, &one, L11, ld, L21, ld));
@@ -166,6 +185,27 @@ static int tri_inv_lower(mmg_ctx* ctx, rocblas_handle h, double* L, int64_t n, i
   int rc = tri_inv_lower(ctx, h, L11, n1, ld, dinfo);
   if (rc) return rc;
   return tri_inv_lower(ctx, h, L22, n2, ld, dinfo);
+}
+
+// Right-looking blocked Cholesky (lower, column-major, in place) over the 64-bit rocBLAS level-3 routines:
+// diagonal block by rocsolver_dpotrf, panel by trsm, trailing update by syrk -- the trailing update carries
+// N^3/3 of the flops at GEMM speed.  Selected with MMG_REML_POTRF=blocked (A/B against rocsolver_dpotrf_64).
+static int potrf_blocked(mmg_ctx* ctx, rocblas_handle h, double* A, int64_t N, int64_t nb, rocblas_int* dinfo, long long* dacc) {
+  const double one = 1.0, mone = -1.0;
+  for (int64_t k0 = 0; k0 < N; k0 += nb) {
+    const int64_t kb = std::min(nb, N - k0), rest = N - k0 - kb;
+    double* Akk = A + k0 + k0 * N;
+    RC_RB(ctx, rocsolver_dpotrf(h, rocblas_fill_lower, (rocblas_int)kb, Akk, (rocblas_int)N, dinfo));
+    hipLaunchKernelGGL(note_info_kernel, dim3(1), dim3(1), 0, ctx->stream, dinfo, dacc, (long long)k0);
+    if (rest > 0) {
+      double* Apk = A + (k0 + kb) + k0 * N;                 // panel below the diagonal block
+      RC_RB(ctx, rocblas_dtrsm_64(h, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose,
+                                  rocblas_diagonal_non_unit, rest, kb, &one, Akk, N, Apk, N));
+      double* Att = A + (k0 + kb) + (k0 + kb) * N;
+      RC_RB(ctx, rocblas_dsyrk_64(h, rocblas_fill_lower, rocblas_operation_none, rest, kb, &mone, Apk, N, &one, Att, N));
+    }
+  }
+  return MMG_OK;
 }
 
 struct RemlPoint {           // everything one delta yields
@@ -183,13 +223,29 @@ static int reml_point(mmg_ctx* ctx, mmg_reml* r, double delta, bool inverse, boo
   const int64_t N = r->N;
   const int q = r->q, q1 = q + 1;
   hipStream_t st = ctx->stream;
-  rocblas_int* dinfo = (rocblas_int*)(r->dsc + N + 4);
+  rocblas_int* dinfo = (rocblas_int*)(r->dsc + N + 4);   // [N+4]: info word read back; [N+6]: first failing block; [N+8]: scratch
   const bool verbose = std::getenv("MMG_REML_VERBOSE") != nullptr;
   auto now = [&]() { (void)hipStreamSynchronize(st); return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t0 = verbose ? now() : 0.0, t1 = 0.0, t2 = 0.0;
   RC_HIP(ctx, hipMemcpyAsync(r->dL, r->dK, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, r->dL, N, delta);
-  RC_RB(ctx, rocsolver_dpotrf_64(h, rocblas_fill_lower, N, r->dL, N, (int64_t*)dinfo));
+  {
+    // measured at N = 50,000: rocsolver_dpotrf_64 1.31 s (32 TF); the blocked form over syrk_64 0.80 s (52 TF) at
+    // nb = 2048 (0.83 / 0.89 s at 4096 / 8192).  MMG_REML_POTRF=rocsolver | blocked:<nb> overrides.
+    const char* pe = std::getenv("MMG_REML_POTRF");
+    const std::string ps = pe ? pe : "";
+    long long* dacc = (long long*)(r->dsc + N + 6);
+    RC_HIP(ctx, hipMemsetAsync(dinfo, 0, 4 * sizeof(int64_t), st));
+    if (ps != "rocsolver" && (N >= 4096 || ps.rfind("blocked", 0) == 0)) {
+      int64_t nb = 2048;
+      if (ps.size() > 8) nb = std::max<int64_t>(256, std::atoll(ps.c_str() + 8));    // "blocked:<nb>"
+      int rcb = potrf_blocked(ctx, h, r->dL, N, nb, (rocblas_int*)(r->dsc + N + 8), dacc);
+      if (rcb) return rcb;
+      RC_HIP(ctx, hipMemcpyAsync(dinfo, dacc, sizeof(long long), hipMemcpyDeviceToDevice, st));
+    } else {
+      RC_RB(ctx, rocsolver_dpotrf_64(h, rocblas_fill_lower, N, r->dL, N, (int64_t*)dinfo));
+    }
+  }
   if (verbose) t1 = now();
   RC_HIP(ctx, hipMemsetAsync(r->dsc, 0, 4 * sizeof(double), st));
   hipLaunchKernelGGL(logdiag_kernel, dim3(1), dim3(256), 0, st, r->dL, N, r->dsc);

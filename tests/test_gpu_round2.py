@@ -411,3 +411,19 @@ def test_eigen_free_recursive_inverse_beyond_one_block(ctx):
     ref = lm._SpectralSumsL({"values": vals, "vectors": vecs}, X, y).at(deltas)
     for got, want in zip((s1, s2, s3, s4), ref):
         assert rel(got, want) < 1e-8
+
+
+@pytest.mark.parametrize("n", [300, 4500])
+def test_eigen_free_reports_an_indefinite_matrix(ctx, n):
+    """K + delta I not positive definite (a kinship with a negative eigenvalue and a tiny delta): both Cholesky paths
+    (rocSOLVER below 4,096 rows, the blocked one above) fail with an error instead of returning numbers."""
+    from mixmogam_amd import _lib
+    rng = np.random.RandomState(n)
+    B = rng.standard_normal((n, 8))
+    K = B @ B.T / 8 - 0.5 * np.eye(n)                       # eigenvalues down to -0.5
+    reml = ctx.reml(K, np.ones((n, 1)), rng.standard_normal(n))
+    with pytest.raises(_lib.MixmogamHipError, match="positive definite"):
+        reml.sums([1e-3])
+    s = reml.sums([1.0])                                     # K + I is fine again
+    assert np.all(np.isfinite([v[0] for v in s[:4]]))
+    reml.close()
