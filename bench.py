@@ -122,6 +122,17 @@ def main():
         if world == 1 and not np.array_equal(cf, counts.astype(np.float64)):
             raise SystemExit("fp32-MFMA and int8-MFMA kinship counts differ")
         del cf
+    grm = None
+    if not args.no_f32_kinship and world == 1 and mode == "weak":
+        # the GRM through the exact int8 route (the chunked drivers' kinship): per-SNP weights 1/std^2 as int8 digits
+        acc = ctx.kinship_accumulator(N)
+        t0 = time.time()
+        acc.add_grm(g)
+        grm = {"wall_ms": 1e3 * (time.time() - t0), "digit_plane_gemms_ms": ctx.kernel_ms("grm"),
+               "pack_ms": ctx.kernel_ms("pack"),
+               "note": "mmg_kin_acc_add_grm: z z' = a^2 s s' + ab(s 1' + 1 s') + b^2 1 1', the weighted Gram matrix as 4 "
+                       "exact int8-MFMA GEMMs (kinship_i8_kernel, digit image x plain image); compare kinship_f32_kernel"}
+        acc.close()
     K = kinship.scale_k(counts.astype(np.float64) / (2.0 * Mtot) + 0.5)
 
     # ---- eigh + REML (replicated), model -> device
@@ -153,6 +164,8 @@ def main():
     else:
         res = bench_scan(args, ctx, coll, comm_h, g, lmm, est, prep, N, M, Mtot, D, barrier, common, rank, world,
                          kin_i8_ms, kin_i8_pack_ms, kin_f32_ms)
+        if res is not None and grm is not None:
+            res["roofline_kinship"]["grm_exact_i8"] = grm
     if rank == 0:
         res.update({"eigh_ms": eigh_ms, "model_setup_s": model_s, "setup_s": t_setup, "delta": float(est["delta"]),
                     "device": info})

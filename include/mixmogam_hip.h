@@ -51,7 +51,8 @@ int mmg_device_info(mmg_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
 /* milliseconds the dominant kernel of the last call took, from hipEvents recorded on the
  * ctx stream around it.  which: 0 = kinship GEMM, 1 = scan quadratic-form GEMM,
  * 2 = scan finalize (per-SNP dot + F + p), 3 = permutation GEMM, 4 = eigh, 5 = transpose/pack,
- * 7 = eigen-rotation GEMM (mmg_rot_load), 8 = multi-phenotype passes (mmg_emmax_scan_multi, summed over batches) */
+ * 7 = eigen-rotation GEMM (mmg_rot_load), 8 = multi-phenotype passes (mmg_emmax_scan_multi, summed over batches),
+ * 9 = digit-plane GEMMs of the last mmg_kin_acc_add_grm (summed) */
 int mmg_last_kernel_ms(mmg_ctx* ctx, int which, double* ms);
 
 /* Page-lock (unlock) a caller-owned host buffer so that result fetches into it run at full PCIe
@@ -122,6 +123,12 @@ int mmg_kinship_affine_f32(mmg_ctx* ctx, mmg_geno* g, const float* scale, const 
  * mmg_kinship_affine_f32; NULL/NULL = 2s-1); fetch: host double [N x N] and the SNP count so far. */
 int mmg_kin_acc_create(mmg_ctx* ctx, int32_t N, mmg_kin_acc** acc);
 int mmg_kin_acc_add(mmg_ctx* ctx, mmg_kin_acc* acc, mmg_geno* g, const float* scale, const float* shift);
+/* GRM chunk (kinship.py:66-69, hdf5_data.py:99-106): acc += sum_m z_m z_m' with z = (s - mean)/std computed per SNP on
+ * the device in fp64 -- EXACT route: z z' = a^2 s s' + a b (s 1' + 1 s') + b^2 1 1'; the weighted Gram matrix
+ * sum_m s s'/std^2 is 4-5 int8-MFMA GEMMs of the IBS kind (the weight 1/std^2 split into balanced digits folded into
+ * one operand), the rank-one terms fp64 dot products.  ~5x faster than the fp32-MFMA kernel and good to ~1e-9; falls
+ * back to that kernel for genotype alphabets beyond 0..4.  A SNP with std == 0 is an error (kinship.py:67). */
+int mmg_kin_acc_add_grm(mmg_ctx* ctx, mmg_kin_acc* acc, mmg_geno* g);
 int mmg_kin_acc_fetch(mmg_ctx* ctx, mmg_kin_acc* acc, double* C_out, int64_t* n_snps);
 int mmg_kin_acc_destroy(mmg_ctx* ctx, mmg_kin_acc* acc);
 /* One-shot twin taking host genotypes: upload + mmg_kinship_affine_f32 / _ibs_i8. */

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "mmg_kinship_affine_f32": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mmg_kin_acc_create": (C.c_int, [c_vp, C.c_int32, C.POINTER(c_vp)]),
     "mmg_kin_acc_add": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mmg_kin_acc_add_grm": (C.c_int, [c_vp, c_vp, c_vp]),
     "mmg_kin_acc_fetch": (C.c_int, [c_vp, c_vp, c_vp, c_i64p]),
     "mmg_kin_acc_destroy": (C.c_int, [c_vp, c_vp]),
     "mmg_kinship_i8": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp, c_vp, c_vp]),
@@ -245,6 +246,10 @@ class KinshipAccumulator(object):
         sh = None if shift is None else _arr(shift, np.float32)
         self.ctx._check(self.ctx.lib.mmg_kin_acc_add(self.ctx.h, self.h, g.h, _ptr(sc), _ptr(sh)))
 
+    def add_grm(self, g):
+        """acc += sum_m z_m z_m', z = (s - mean)/std per SNP: the exact int8 route (mmg_kin_acc_add_grm)."""
+        self.ctx._check(self.ctx.lib.mmg_kin_acc_add_grm(self.ctx.h, self.h, g.h))
+
     def allreduce(self, comm):
         """Sum the device-resident accumulator (and its SNP count) over the ranks of `comm` in HBM."""
         self.ctx._check(self.ctx.lib.mmg_kin_acc_allreduce(self.ctx.h, comm, self.h))
@@ -348,7 +353,7 @@ class Context(object):
     """One HIP device context (stream, scan model, result buffers)."""
 
     KERNEL_SLOTS = {"kinship": 0, "scan_quad": 1, "scan_finalize": 2, "perm": 3, "eigh": 4, "pack": 5,
-                    "rotate": 7, "scan_multi": 8}
+                    "rotate": 7, "scan_multi": 8, "grm": 9}
 
     def __init__(self, device=0):
         self.lib = load()

@@ -137,12 +137,18 @@ int mmg_device_info(mmg_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
 int mmg_last_kernel_ms(mmg_ctx* ctx, int which, double* ms) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, which >= 0 && which < EV_COUNT && ms != nullptr);
+  if (which == EV_GRM) {                                   // summed digit-plane GEMMs of the last exact GRM pass
+    if (ctx->grm_ms_total <= 0.0) return set_err(ctx, MMG_E_STATE, "no exact GRM pass has run");
+    *ms = ctx->grm_ms_total;
+    return MMG_OK;
+  }
   if (!ctx->ev_set[which]) return set_err(ctx, MMG_E_STATE, "no kernel of that kind has run");
   float f = 0.f;
   MMG_HIP(ctx, hipEventSynchronize(ctx->ev[which][1]));
   MMG_HIP(ctx, hipEventElapsedTime(&f, ctx->ev[which][0], ctx->ev[which][1]));
   *ms = (double)f;
   if (which == EV_MULTI && ctx->multi_ms_total > 0.0) *ms = ctx->multi_ms_total;   // all batches of the last call
+
   if (which == EV_QUAD && ctx->ev_set[EV_QUAD2]) {       // adaptive scan: the refinement pass counts too
     MMG_HIP(ctx, hipEventSynchronize(ctx->ev[EV_QUAD2][1]));
     MMG_HIP(ctx, hipEventElapsedTime(&f, ctx->ev[EV_QUAD2][0], ctx->ev[EV_QUAD2][1]));
@@ -517,6 +523,128 @@ int mmg_kin_acc_add(mmg_ctx* ctx, mmg_kin_acc* a, mmg_geno* g, const float* scal
   MMG_CHECK_ARG(ctx, a && g && g->N == a->N && (scale == nullptr) == (shift == nullptr));
   if (g->M == 0) return MMG_OK;
   int rc = kinship_affine_into(ctx, g, scale, shift, a->dC, true);
+  if (rc == MMG_OK) a->n_snps += g->M;
+  return rc;
+}
+
+// Exact GRM (kinship.py:63-69, hdf5_data.py:99-106): K (+)= sum_m z_m z_m', z_m = (s_m - mean_m) / std_m.
+//     z z' = a^2 s s' + a b (s 1' + 1 s') + b^2 1 1',   a = 1/std, b = -mean/std
+// The first term is a Gram matrix weighted per SNP by omega_m = 1/std_m^2.  omega is written as D balanced digits
+// whose range makes digit * s fit int8 (8 bits for 0/1 genotypes, 7 for 0/1/2, 6 up to 4); each digit plane is then
+// ONE exact int8-MFMA GEMM of the IBS kind (digit image x plain image, upper tiles only) -- 4-5 planes at 32x the
+// fp32-MFMA rate instead of the fp32 GEMM, and entries good to ~1e-9 instead of fp32 products.  The rank-one terms
+// are two dot-product passes in fp64.  Returns MMG_E_STATE (caller falls back to the fp32 kernel) when the genotype
+// alphabet is too wide for int8 digit products.
+static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accumulate) {
+  Scratch sc;
+  int bd = 0;
+  if (g->smax <= 1) bd = 8; else if (g->smax <= 2) bd = 7; else if (g->smax <= 4) bd = 6;
+  if (bd == 0) return MMG_E_STATE;
+  const int D = (30 + bd - 1) / bd;                        // >= 30 bits of the weight: 4, 5, 5 planes
+  const double base = (double)(1 << bd);
+  const int64_t M = g->M, CH = kin_chunk();
+  const int64_t Mk_max = std::min(round_up(M, BK), CH);
+  // per-SNP mean / std in fp64 on the device, weights and digits on the host (M values)
+  double *dm = nullptr, *ds = nullptr, *dcoef = nullptr, *dc1 = nullptr, *dc1acc = nullptr;
+  int8_t *ddig = nullptr, *Xq = nullptr, *Xp = nullptr;
+  int* C32 = nullptr;
+  MMG_HIP(ctx, sc.alloc(&dm, M * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&ds, M * sizeof(double)));
+  launch_snp_stats(ctx, g, dm, ds);
+  std::vector<double> mean((size_t)M), sd((size_t)M);
+  MMG_HIP(ctx, hipMemcpyAsync(mean.data(), dm, M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipMemcpyAsync(sd.data(), ds, M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double wmax = 0.0, c0 = 0.0;
+  std::vector<double> omega((size_t)M), coef((size_t)M);
+  for (int64_t m = 0; m < M; ++m) {
+    if (!(sd[m] > 0.0)) return set_err(ctx, MMG_E_ARG, "monomorphic SNP (std == 0) in the GRM kinship");
+    omega[m] = 1.0 / (sd[m] * sd[m]);
+    coef[m] = -mean[m] * omega[m];                         // a b
+    c0 += mean[m] * mean[m] * omega[m];                    // b^2
+    wmax = std::max(wmax, omega[m]);
+  }
+  // D balanced digits reach (B/2 - 1)(B^D - 1)/(B - 1) (0.996 / 0.992 / 0.984 of 2^(bd*D - 1) for B = 256 / 128 / 64):
+  // the largest weight is scaled onto exactly that
+  const double step = wmax / std::floor((base / 2 - 1) * (std::pow(base, D) - 1) / (base - 1));
+  MMG_HIP(ctx, sc.alloc(&Xq, (size_t)g->Npad * Mk_max));
+  hipError_t e = sc.alloc(&Xp, (size_t)D * g->Npad * Mk_max);
+  if (e != hipSuccess) return set_err(ctx, MMG_E_NOMEM, "hipMalloc digit images of the GRM kinship");
+  MMG_HIP(ctx, sc.alloc(&C32, (size_t)D * g->Npad * g->Npad * sizeof(int)));
+  MMG_HIP(ctx, sc.alloc(&ddig, (size_t)D * Mk_max));
+  MMG_HIP(ctx, sc.alloc(&dcoef, Mk_max * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dc1, g->Npad * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&dc1acc, g->Npad * sizeof(double)));
+  MMG_HIP(ctx, hipMemsetAsync(C32, 0, (size_t)D * g->Npad * g->Npad * sizeof(int), ctx->stream));
+  std::vector<double> c1((size_t)g->Npad, 0.0), c1part((size_t)g->Npad);
+  std::vector<int8_t> dig((size_t)D * Mk_max);
+  std::vector<double> cf((size_t)Mk_max);
+  const long long half = 1ll << (bd - 1), mask = (1ll << bd) - 1;
+  int rc = MMG_OK;
+  double kin_ms = 0.0;
+  for (int64_t mb = 0; mb < M && rc == MMG_OK; mb += CH) {
+    const int64_t Mk = round_up(std::min(CH, M - mb), BK);
+    std::fill(dig.begin(), dig.end(), (int8_t)0);
+    std::fill(cf.begin(), cf.end(), 0.0);
+    for (int64_t k = 0; k < Mk && mb + k < M; ++k) {
+      long long Z = std::llrint(omega[mb + k] / step);
+      for (int d = 0; d < D; ++d) {
+        const long long z = ((Z + half) & mask) - half;
+        Z = (Z - z) >> bd;
+        dig[(size_t)d * Mk + k] = (int8_t)z;
+      }
+      cf[k] = coef[mb + k];
+    }
+    MMG_HIP(ctx, hipMemcpyAsync(ddig, dig.data(), (size_t)D * Mk, hipMemcpyHostToDevice, ctx->stream));
+    MMG_HIP(ctx, hipMemcpyAsync(dcoef, cf.data(), Mk * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    {
+      EvScope ev(ctx, EV_PACK);
+      launch_transpose_digits(ctx, g, Xq, Xp, Mk, mb, ddig, D);
+    }
+    MMG_HIP(ctx, hipGetLastError());
+    for (int d = 0; d < D && rc == MMG_OK; ++d) {
+      rc = run_kinship_i8_pq(ctx, Xp + (size_t)d * g->Npad * Mk, Xq, g->Npad, Mk, C32 + (size_t)d * g->Npad * g->Npad);
+      double a = 0.0;
+      if (rc == MMG_OK && mmg_last_kernel_ms(ctx, EV_KIN, &a) == MMG_OK) kin_ms += a;
+    }
+    if (rc) break;
+    // c1[i] += sum_m (a b)_m s_mi: one dot product per row of the plain image
+    launch_snp_dot_raw(ctx, Xq, Mk, g->Npad, (int32_t)Mk, dcoef, dc1);
+    MMG_HIP(ctx, hipMemcpyAsync(c1part.data(), dc1, g->Npad * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < g->Npad; ++i) c1[i] += c1part[i];
+  }
+  if (rc) return rc;
+  ctx->grm_ms_total = kin_ms;
+  MMG_HIP(ctx, hipMemcpyAsync(dc1acc, c1.data(), g->Npad * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  launch_grm_combine(ctx, C32, D, g->Npad, g->N, step, base, dc1acc, c0, dC, accumulate ? 1 : 0);
+  MMG_HIP(ctx, hipGetLastError());
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MMG_OK;
+}
+
+int mmg_kin_acc_add_grm(mmg_ctx* ctx, mmg_kin_acc* a, mmg_geno* g) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, a && g && g->N == a->N);
+  if (g->M == 0) return MMG_OK;
+  int rc = kinship_grm_i8_into(ctx, g, a->dC, true);
+  if (rc == MMG_E_STATE) {                                  // genotype alphabet too wide for int8 digit products
+    Scratch sc;
+    double *dm = nullptr, *ds = nullptr;
+    MMG_HIP(ctx, sc.alloc(&dm, g->M * sizeof(double)));
+    MMG_HIP(ctx, sc.alloc(&ds, g->M * sizeof(double)));
+    launch_snp_stats(ctx, g, dm, ds);
+    std::vector<double> mean((size_t)g->M), sd((size_t)g->M);
+    MMG_HIP(ctx, hipMemcpyAsync(mean.data(), dm, g->M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MMG_HIP(ctx, hipMemcpyAsync(sd.data(), ds, g->M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<float> sc_((size_t)g->M), sh_((size_t)g->M);
+    for (int64_t m = 0; m < g->M; ++m) {
+      if (!(sd[m] > 0.0)) return set_err(ctx, MMG_E_ARG, "monomorphic SNP (std == 0) in the GRM kinship");
+      sc_[m] = (float)(1.0 / sd[m]); sh_[m] = (float)(-mean[m] / sd[m]);
+    }
+    rc = kinship_affine_into(ctx, g, sc_.data(), sh_.data(), a->dC, true);
+  }
   if (rc == MMG_OK) a->n_snps += g->M;
   return rc;
 }

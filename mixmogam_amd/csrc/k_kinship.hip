@@ -23,14 +23,17 @@ __device__ __forceinline__ int xcd_job_index(int b) {
   return (b & ~255) + (b & 7) * 32 + ((b >> 3) & 31);
 }
 
-__global__ __launch_bounds__(NTHREADS, 2) void kinship_i8_kernel(const int8_t* __restrict__ Xt, int64_t Mk,
+// Xp == Xq: IBS / indicator counts X X'.  Xp != Xq: one digit plane of the weighted Gram matrix of the exact GRM
+// (rows of tile I from the digit image, rows of tile J from the plain image; the product is symmetric all the same).
+__global__ __launch_bounds__(NTHREADS, 2) void kinship_i8_kernel(const int8_t* __restrict__ Xp,
+                                                                 const int8_t* __restrict__ Xq, int64_t Mk,
                                                                  int32_t Npad, const KinJob* __restrict__ jobs,
                                                                  int* __restrict__ C32) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const KinJob job = jobs[xcd_job_index(blockIdx.x)];
   if (job.ks1 <= job.ks0) return;
   v16i acc[4][2];
-  gemm_tile_i8(Xt + (int64_t)job.I * TM * Mk, Mk, Xt + (int64_t)job.J * TN * Mk, Mk, job.ks0, job.ks1, lds,
+  gemm_tile_i8(Xp + (int64_t)job.I * TM * Mk, Mk, Xq + (int64_t)job.J * TN * Mk, Mk, job.ks0, job.ks1, lds,
                acc);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 2, wn = wave & 3, h = lane >> 5, r = lane & 31;
@@ -210,7 +213,35 @@ int kinship_pick_ksplit(int32_t Npad, int64_t Mk, bool f32) {
   return choose_ksplit(nT * (nT + 1) / 2, nk, f32 ? 2 : 8, f32 ? 16 : 64);
 }
 
+// dC (fp64 [N x N]) (+)= step * sum_d base^d C32[d] (upper tiles mirrored) + c1[i] + c1[j] + c0
+__global__ void grm_combine_kernel(const int* __restrict__ C32, int D, int32_t Npad, int32_t N, double step, double base,
+                                   const double* __restrict__ c1, double c0, double* __restrict__ C, int accumulate) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)N * N) return;
+  const int i = (int)(gid / N), j = (int)(gid % N);
+  int a = i, b = j;
+  if ((i / TM) > (j / TN)) { a = j; b = i; }
+  double s = 0.0, pw = 1.0;
+  for (int d = 0; d < D; ++d) {
+    s = fma((double)C32[(int64_t)d * Npad * Npad + (int64_t)a * Npad + b], pw, s);   // exact: integers below 2^53
+    pw *= base;
+  }
+  const double v = fma(step, s, c1[i] + c1[j] + c0);
+  C[gid] = accumulate ? C[gid] + v : v;
+}
+
+void launch_grm_combine(mmg_ctx* ctx, const int* C32, int D, int32_t Npad, int32_t N, double step, double base,
+                        const double* c1, double c0, double* C, int accumulate) {
+  const int64_t total = (int64_t)N * N;
+  hipLaunchKernelGGL(grm_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, C32, D, Npad,
+                     N, step, base, c1, c0, C, accumulate);
+}
+
 int run_kinship_i8(mmg_ctx* ctx, const int8_t* Xt, int32_t Npad, int64_t Mk, int* C32) {
+  return run_kinship_i8_pq(ctx, Xt, Xt, Npad, Mk, C32);
+}
+
+int run_kinship_i8_pq(mmg_ctx* ctx, const int8_t* Xp, const int8_t* Xq, int32_t Npad, int64_t Mk, int* C32) {
   const int nT = Npad / TM, nk = (int)(Mk / BK);
   const int ksplit = kinship_pick_ksplit(Npad, Mk, false);
   std::vector<KinJob> jobs = build_jobs(nT, nk, ksplit);
@@ -220,7 +251,7 @@ int run_kinship_i8(mmg_ctx* ctx, const int8_t* Xt, int32_t Npad, int64_t Mk, int
   MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   {
     EvScope ev(ctx, EV_KIN);
-    hipLaunchKernelGGL(kinship_i8_kernel, dim3((unsigned)jobs.size()), dim3(NTHREADS), LDS_BYTES, ctx->stream, Xt,
+    hipLaunchKernelGGL(kinship_i8_kernel, dim3((unsigned)jobs.size()), dim3(NTHREADS), LDS_BYTES, ctx->stream, Xp, Xq,
                        Mk, Npad, djobs, C32);
   }
   MMG_HIP(ctx, hipGetLastError());

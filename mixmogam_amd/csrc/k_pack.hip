@@ -146,6 +146,64 @@ __global__ __launch_bounds__(256) void transpose_kernel(const int8_t* __restrict
   *(uint4*)(Xt + (int64_t)(i0 + i) * Mk + m0 + mc * 16) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
 }
 
+// Weighted twin for the exact GRM (api.hip:kinship_grm_i8_into): one pass over S writes the plain image Xq[i][m] = s
+// and D digit images Xp[d][i][m] = dig[d][m] * s, where dig holds balanced digits of the per-SNP weight 1/std^2 whose
+// range was chosen so that every product fits int8.  Images are [Npad x Mk], digit image d at Xp + d * Npad * Mk.
+template <int D>
+__global__ __launch_bounds__(256) void transpose_digits_kernel(const int8_t* __restrict__ S, int64_t M, int32_t N,
+                                                               int32_t Npad, int8_t* __restrict__ Xq,
+                                                               int8_t* __restrict__ Xp, int64_t Mk, int64_t m_begin,
+                                                               const int8_t* __restrict__ dig /*[D][Mk]*/) {
+  __shared__ int8_t tile[64][64 + 4];
+  const int t = threadIdx.x;
+  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  const int i0 = blockIdx.y * 64;
+  {
+    const int r = t >> 2, c = t & 3;
+    const uint4 v = *(const uint4*)(S + (m_begin + m0 + r) * (int64_t)Npad + i0 + c * 16);
+    uint32_t* dstw = (uint32_t*)&tile[r][c * 16];
+    dstw[0] = v.x; dstw[1] = v.y; dstw[2] = v.z; dstw[3] = v.w;
+  }
+  __syncthreads();
+  const int i = t >> 2, mc = t & 3;
+  uint32_t wq[4] = {0, 0, 0, 0};
+  uint32_t wp[D][4];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wp[d][e] = 0;
+  const bool ivalid = (i0 + i) < N;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int64_t mk = m0 + mc * 16 + j;
+    int sv = 0;
+    if (ivalid && m_begin + mk < M) sv = (int)tile[mc * 16 + j][i];
+    wq[j >> 2] |= ((uint32_t)(sv & 0xff)) << (8 * (j & 3));
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int v = sv * (int)dig[(int64_t)d * Mk + mk];
+      wp[d][j >> 2] |= ((uint32_t)(v & 0xff)) << (8 * (j & 3));
+    }
+  }
+  const int64_t off = (int64_t)(i0 + i) * Mk + m0 + mc * 16;
+  *(uint4*)(Xq + off) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    *(uint4*)(Xp + (int64_t)d * Npad * Mk + off) = make_uint4(wp[d][0], wp[d][1], wp[d][2], wp[d][3]);
+}
+
+void launch_transpose_digits(mmg_ctx* ctx, const mmg_geno* g, int8_t* Xq, int8_t* Xp, int64_t Mk, int64_t m_begin,
+                             const int8_t* dig, int D) {
+  dim3 grid((unsigned)(Mk / 64), (unsigned)(g->Npad / 64));
+#define MMG_TD(D_)                                                                                                  \
+  hipLaunchKernelGGL(transpose_digits_kernel<D_>, grid, dim3(256), 0, ctx->stream, g->d, g->M, g->N, g->Npad, Xq, Xp, \
+                     Mk, m_begin, dig)
+  if (D == 4) MMG_TD(4);
+  else if (D == 5) MMG_TD(5);
+  else MMG_TD(6);
+#undef MMG_TD
+}
+
 void launch_transpose(mmg_ctx* ctx, const mmg_geno* g, int8_t* Xt, int64_t Mk, int mul, int add, int64_t m_begin,
                       int thr) {
   dim3 grid((unsigned)(Mk / 64), (unsigned)(g->Npad / 64));

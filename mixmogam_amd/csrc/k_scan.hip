@@ -345,6 +345,14 @@ void launch_snp_dot(mmg_ctx* ctx, const mmg_geno* g, const double* v, double* ou
                      (int64_t)g->Npad, g->M, g->Npad, v, out);
 }
 
+// the same kernel over any int8 matrix [rows x ld] with row length len16 (a multiple of 16): out[r] = row_r . v
+void launch_snp_dot_raw(mmg_ctx* ctx, const int8_t* S, int64_t ldS, int64_t rows, int32_t len16, const double* v,
+                        double* out) {
+  const int64_t nwaves = (rows + 3) / 4;
+  hipLaunchKernelGGL(snp_dot_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, ctx->stream, S, ldS, rows, len16, v,
+                     out);
+}
+
 void launch_scan_finalize(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, mmg_scan_result& res,
                           double h0_rss, int32_t df2, double lnbeta, bool with_p, double bias) {
   hipLaunchKernelGGL(scan_finalize_kernel, dim3((unsigned)(g->Mpad / FIN_ROWS)), dim3(256), 0, ctx->stream, g->d,

@@ -21,7 +21,7 @@ struct mmg_geno {
   int* d_smax = nullptr;
 };
 
-enum { EV_KIN = 0, EV_QUAD = 1, EV_FIN = 2, EV_PERM = 3, EV_EIGH = 4, EV_PACK = 5, EV_QUAD2 = 6, EV_ROT = 7, EV_MULTI = 8, EV_COUNT = 9 };
+enum { EV_KIN = 0, EV_QUAD = 1, EV_FIN = 2, EV_PERM = 3, EV_EIGH = 4, EV_PACK = 5, EV_QUAD2 = 6, EV_ROT = 7, EV_MULTI = 8, EV_GRM = 9, EV_COUNT = 10 };
 
 struct mmg_scan_model {
   int32_t N = 0, Npad = 0, D = 0;
@@ -80,6 +80,7 @@ struct mmg_ctx {
   size_t dstage_elems = 0;
   bool deliver_pending = false;
   double multi_ms_total = 0.0;  // summed pass time of the last mmg_emmax_scan_multi
+  double grm_ms_total = 0.0;    // summed digit-plane GEMM time of the last mmg_kin_acc_add_grm
 };
 
 namespace mmg {
@@ -133,6 +134,12 @@ void launch_absmax_i8(mmg_ctx*, const int8_t* p, int64_t bytes, int* d_out);   /
 int kinship_pick_ksplit(int32_t Npad, int64_t Mk, bool f32);
 // C32 [Npad x Npad] int32 += Xt Xt^T (upper-triangular tiles only, mirrored by the caller).
 int run_kinship_i8(mmg_ctx*, const int8_t* Xt, int32_t Npad, int64_t Mk, int* C32);
+int run_kinship_i8_pq(mmg_ctx*, const int8_t* Xp, const int8_t* Xq, int32_t Npad, int64_t Mk, int* C32);
+void launch_grm_combine(mmg_ctx*, const int* C32, int D, int32_t Npad, int32_t N, double step, double base,
+                        const double* c1, double c0, double* C, int accumulate);
+void launch_transpose_digits(mmg_ctx*, const mmg_geno*, int8_t* Xq, int8_t* Xp, int64_t Mk, int64_t m_begin,
+                             const int8_t* dig, int D);
+void launch_snp_dot_raw(mmg_ctx*, const int8_t* S, int64_t ldS, int64_t rows, int32_t len16, const double* v, double* out);
 // slabs [ksplit][Npad x Npad] fp32; returns ksplit through *ksplit_out.
 int run_kinship_f32(mmg_ctx*, const int8_t* Xt, int32_t Npad, int64_t Mk, const float* scale,
                     const float* shift, float* slabs, int ksplit);

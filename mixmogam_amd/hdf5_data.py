@@ -125,10 +125,7 @@ def _ibd_kinship(ctx, genot_data, n_indivs, plan, coll=None, prefetch=True):
     rank, world = (coll.rank, coll.world) if coll is not None else (0, 1)
     acc = ctx.kinship_accumulator(n_indivs)
     for ci, chrom, g in _resident_chunks(ctx, genot_data, plan, rank, world, prefetch, reuse=True):
-        mean, sd = g.snp_stats()
-        if np.any(sd == 0):
-            raise ValueError("monomorphic SNP passed the MAF filter on chromosome %s" % chrom)
-        acc.add(g, 1.0 / sd, -mean / sd)
+        acc.add_grm(g)                                                   # :99-106; a SNP with std == 0 is an error
         g.close()
     if coll is not None and world > 1:
         acc.allreduce(_dev_comm(coll))                                   # N x N partial sums never leave HBM

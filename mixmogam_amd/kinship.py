@@ -63,18 +63,20 @@ def calc_ibs_kinship(snps, snps_data_format='binary', snp_dtype='int8', dtype='s
 def calc_ibd_kinship(snps, dtype='single', scaled=True, ctx=None, geno=None):
     """kinship.py:59-75: z = (s - mean)/std per SNP (population std), K = sum z z^T / M, scale_k.
 
-    fp32 MFMA GEMM with the standardisation applied while expanding int8 -> fp32 from LDS
-    (scale = 1/std, shift = -mean/std).  A monomorphic SNP has std = 0: the reference divides by
-    zero there and asserts (:67); here it raises ValueError."""
+    Exact route (mmg_kin_acc_add_grm): z z' = a^2 s s' + a b (s 1' + 1 s') + b^2 1 1' with the per-SNP weight
+    a^2 = 1/std^2 split into int8 digits -- 4-5 exact int8-MFMA GEMMs instead of the fp32-MFMA GEMM
+    (`ctx.kinship_affine(g, 1/std, -mean/std)`, the north star's stated kernel, stays available and is what bench.py
+    times).  A monomorphic SNP has std = 0: the reference divides by zero there and asserts (:67); here it raises."""
     ctx = ctx or _lib.get_context()
     own = geno is None
     g = ctx.geno(_as_snp_matrix(snps)) if own else geno
     try:
-        mean, sd = g.snp_stats()
-        if np.any(sd == 0):
-            raise ValueError("monomorphic SNP (std == 0) in calc_ibd_kinship")
-        k_mat = ctx.kinship_affine(g, 1.0 / sd, -mean / sd)
-        num_snps = g.M
+        acc = ctx.kinship_accumulator(g.N)
+        try:
+            acc.add_grm(g)
+            k_mat, num_snps = acc.fetch()
+        finally:
+            acc.close()
     finally:
         if own:
             g.close()

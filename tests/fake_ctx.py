@@ -40,6 +40,15 @@ class FakeAcc(object):
             self.c = comm.allreduce(self.c, "sum").reshape(self.c.shape)
             self.n = int(comm.allreduce(np.array([self.n], dtype=np.int64), "sum")[0])
 
+    def add_grm(self, g):
+        s = g.data.astype(np.float64)
+        sd = s.std(1)
+        if np.any(sd == 0):
+            raise ValueError("monomorphic SNP (std == 0)")
+        z = (s - s.mean(1, keepdims=True)) / sd[:, None]
+        self.c += z.T @ z
+        self.n += g.M
+
     def add(self, g, scale=None, shift=None):
         s = g.data.astype(np.float64)
         x = 2 * s - 1 if scale is None else s * np.asarray(scale)[:, None] + np.asarray(shift)[:, None]

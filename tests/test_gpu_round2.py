@@ -427,3 +427,58 @@ def test_eigen_free_reports_an_indefinite_matrix(ctx, n):
     s = reml.sums([1.0])                                     # K + I is fine again
     assert np.all(np.isfinite([v[0] for v in s[:4]]))
     reml.close()
+
+
+# ------------------------------------------------------------------ exact GRM on the int8 matrix cores
+def _grm_f64(snps):
+    s = snps.astype(np.float64)
+    z = (s - s.mean(1, keepdims=True)) / s.std(1)[:, None]
+    return z.T @ z
+
+
+def test_grm_exact_route_vs_golden(ctx, case):
+    """calc_ibd_kinship through mmg_kin_acc_add_grm (weight digits folded into one int8 operand, 4 exact GEMMs):
+    the double-promoted reference's GRM to 3e-9 -- the weights carry 31 bits relative to the LARGEST 1/std^2 (the
+    rarest SNP of these structured cases, 40x the typical weight) -- where the fp32-MFMA kernel was good to 2e-5."""
+    from mixmogam_amd import kinship
+    k = kinship.calc_ibd_kinship(case["snps"], ctx=ctx)
+    assert np.max(np.abs(k - case["dbl_ibd_scaled"])) < 3e-9
+
+
+@pytest.mark.parametrize("hi,n,m", [(2, 300, 2000), (3, 257, 1500), (5, 130, 900), (10, 100, 500)])
+def test_grm_exact_route_alphabets_and_chunks(ctx, monkeypatch, hi, n, m):
+    """0/1 (8-bit digits), 0/1/2 (7-bit), 0..4 (6-bit) genotypes against float64; wider alphabets fall back to the
+    fp32-MFMA kernel (1e-5); several passes over the SNP axis (MMG_KIN_CHUNK) and accumulation over two stores give
+    the same matrix."""
+    rng = np.random.RandomState(hi * 1000 + n)
+    snps = rng.randint(0, hi, size=(m, n)).astype(np.int8)
+    snps = snps[snps.std(1) > 0]
+    ref = _grm_f64(snps)
+    tol = 1e-9 if hi <= 5 else 2e-5
+    g = ctx.geno(snps)
+    acc = ctx.kinship_accumulator(n)
+    acc.add_grm(g)
+    k1, cnt = acc.fetch()
+    assert cnt == len(snps)
+    assert np.max(np.abs(k1 - ref)) < tol * np.max(np.abs(ref))
+    acc.close()
+    monkeypatch.setenv("MMG_KIN_CHUNK", "256")
+    acc = ctx.kinship_accumulator(n)
+    half = len(snps) // 2
+    ga, gb = ctx.geno(snps[:half]), ctx.geno(snps[half:])
+    acc.add_grm(ga); acc.add_grm(gb)
+    k2, cnt = acc.fetch()
+    monkeypatch.delenv("MMG_KIN_CHUNK")
+    assert cnt == len(snps)
+    assert np.max(np.abs(k2 - ref)) < tol * np.max(np.abs(ref))
+    for x in (g, ga, gb):
+        x.close()
+    acc.close()
+
+
+def test_grm_monomorphic_snp_is_an_error(ctx):
+    from mixmogam_amd import _lib, kinship
+    snps = np.random.RandomState(1).randint(0, 2, size=(50, 40)).astype(np.int8)
+    snps[7] = 1
+    with pytest.raises(_lib.MixmogamHipError, match="std == 0"):
+        kinship.calc_ibd_kinship(snps, ctx=ctx)
