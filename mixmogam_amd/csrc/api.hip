@@ -4,6 +4,7 @@
 #include <rocsolver/rocsolver.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -503,7 +504,20 @@ int mmg_kinship_affine_f32(mmg_ctx* ctx, mmg_geno* g, const float* scale, const 
 
 // Device-resident kinship accumulator for chunked / streamed genotypes (the `k_mat += x'x` loop of
 // hdf5_data.py:99-106 and kinship.py:63-69): the N x N sum stays in HBM between chunks.
-struct mmg_kin_acc { int32_t N = 0; double* dC = nullptr; int64_t n_snps = 0; };
+// workspace of the exact GRM route, kept between chunks: hipMalloc / hipFree of tens of GB per chunk cost more than the
+// GEMMs they serve (measured at N = 50,000: 1.4-1.8 s of allocation around 0.2 s of matrix-core work)
+struct GrmWorkspace {
+  int8_t *Xq = nullptr, *Xp = nullptr, *ddig = nullptr;
+  int* C32 = nullptr;
+  double *dm = nullptr, *ds = nullptr, *dcoef = nullptr, *dc1 = nullptr, *dc1acc = nullptr;
+  size_t cap_img = 0, cap_c32 = 0, cap_m = 0, cap_mk = 0, cap_n = 0;
+  int capD = 0;
+  void release() {
+    hipFree(Xq); hipFree(Xp); hipFree(ddig); hipFree(C32); hipFree(dm); hipFree(ds); hipFree(dcoef); hipFree(dc1); hipFree(dc1acc);
+    *this = GrmWorkspace();
+  }
+};
+struct mmg_kin_acc { int32_t N = 0; double* dC = nullptr; int64_t n_snps = 0; GrmWorkspace ws; };
 
 int mmg_kin_acc_create(mmg_ctx* ctx, int32_t N, mmg_kin_acc** out) {
   MMG_ENTER(ctx);
@@ -535,8 +549,11 @@ int mmg_kin_acc_add(mmg_ctx* ctx, mmg_kin_acc* a, mmg_geno* g, const float* scal
 // fp32-MFMA rate instead of the fp32 GEMM, and entries good to ~1e-9 instead of fp32 products.  The rank-one terms
 // are two dot-product passes in fp64.  Returns MMG_E_STATE (caller falls back to the fp32 kernel) when the genotype
 // alphabet is too wide for int8 digit products.
-static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accumulate) {
-  Scratch sc;
+static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accumulate, GrmWorkspace& ws) {
+  const bool verbose = std::getenv("MMG_KIN_VERBOSE") != nullptr;
+  auto now = [&]() { (void)hipStreamSynchronize(ctx->stream); return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tv0 = verbose ? now() : 0.0;
+  double tv_alloc = 0.0, tv_pack = 0.0, tv_gemm = 0.0, tv_tail = 0.0;
   int bd = 0;
   if (g->smax <= 1) bd = 8; else if (g->smax <= 2) bd = 7; else if (g->smax <= 4) bd = 6;
   if (bd == 0) return MMG_E_STATE;
@@ -545,11 +562,28 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
   const int64_t M = g->M, CH = kin_chunk();
   const int64_t Mk_max = std::min(round_up(M, BK), CH);
   // per-SNP mean / std in fp64 on the device, weights and digits on the host (M values)
-  double *dm = nullptr, *ds = nullptr, *dcoef = nullptr, *dc1 = nullptr, *dc1acc = nullptr;
-  int8_t *ddig = nullptr, *Xq = nullptr, *Xp = nullptr;
-  int* C32 = nullptr;
-  MMG_HIP(ctx, sc.alloc(&dm, M * sizeof(double)));
-  MMG_HIP(ctx, sc.alloc(&ds, M * sizeof(double)));
+  {
+    const size_t need_img = (size_t)g->Npad * Mk_max, need_c32 = (size_t)g->Npad * g->Npad;
+    if (ws.cap_img < need_img || ws.cap_c32 < need_c32 || ws.capD < D || ws.cap_m < (size_t)M || ws.cap_mk < (size_t)Mk_max ||
+        ws.cap_n < (size_t)g->Npad) {
+      ws.release();
+      hipError_t e = hipMalloc(&ws.Xq, need_img);
+      if (e == hipSuccess) e = hipMalloc(&ws.Xp, (size_t)D * need_img);
+      if (e == hipSuccess) e = hipMalloc(&ws.C32, (size_t)D * need_c32 * sizeof(int));
+      if (e == hipSuccess) e = hipMalloc(&ws.ddig, (size_t)D * Mk_max);
+      if (e == hipSuccess) e = hipMalloc(&ws.dcoef, Mk_max * sizeof(double));
+      if (e == hipSuccess) e = hipMalloc(&ws.dc1, g->Npad * sizeof(double));
+      if (e == hipSuccess) e = hipMalloc(&ws.dc1acc, g->Npad * sizeof(double));
+      if (e == hipSuccess) e = hipMalloc(&ws.dm, M * sizeof(double));
+      if (e == hipSuccess) e = hipMalloc(&ws.ds, M * sizeof(double));
+      if (e != hipSuccess) { ws.release(); return set_err(ctx, MMG_E_NOMEM, std::string("hipMalloc GRM workspace: ") + hipGetErrorString(e)); }
+      ws.cap_img = need_img; ws.cap_c32 = need_c32; ws.capD = D; ws.cap_m = (size_t)M; ws.cap_mk = (size_t)Mk_max;
+      ws.cap_n = (size_t)g->Npad;
+    }
+  }
+  double *dm = ws.dm, *ds = ws.ds, *dcoef = ws.dcoef, *dc1 = ws.dc1, *dc1acc = ws.dc1acc;
+  int8_t *ddig = ws.ddig, *Xq = ws.Xq, *Xp = ws.Xp;
+  int* C32 = ws.C32;
   launch_snp_stats(ctx, g, dm, ds);
   std::vector<double> mean((size_t)M), sd((size_t)M);
   MMG_HIP(ctx, hipMemcpyAsync(mean.data(), dm, M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -567,15 +601,8 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
   // D balanced digits reach (B/2 - 1)(B^D - 1)/(B - 1) (0.996 / 0.992 / 0.984 of 2^(bd*D - 1) for B = 256 / 128 / 64):
   // the largest weight is scaled onto exactly that
   const double step = wmax / std::floor((base / 2 - 1) * (std::pow(base, D) - 1) / (base - 1));
-  MMG_HIP(ctx, sc.alloc(&Xq, (size_t)g->Npad * Mk_max));
-  hipError_t e = sc.alloc(&Xp, (size_t)D * g->Npad * Mk_max);
-  if (e != hipSuccess) return set_err(ctx, MMG_E_NOMEM, "hipMalloc digit images of the GRM kinship");
-  MMG_HIP(ctx, sc.alloc(&C32, (size_t)D * g->Npad * g->Npad * sizeof(int)));
-  MMG_HIP(ctx, sc.alloc(&ddig, (size_t)D * Mk_max));
-  MMG_HIP(ctx, sc.alloc(&dcoef, Mk_max * sizeof(double)));
-  MMG_HIP(ctx, sc.alloc(&dc1, g->Npad * sizeof(double)));
-  MMG_HIP(ctx, sc.alloc(&dc1acc, g->Npad * sizeof(double)));
   MMG_HIP(ctx, hipMemsetAsync(C32, 0, (size_t)D * g->Npad * g->Npad * sizeof(int), ctx->stream));
+  if (verbose) tv_alloc = now();
   std::vector<double> c1((size_t)g->Npad, 0.0), c1part((size_t)g->Npad);
   std::vector<int8_t> dig((size_t)D * Mk_max);
   std::vector<double> cf((size_t)Mk_max);
@@ -597,17 +624,21 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
     }
     MMG_HIP(ctx, hipMemcpyAsync(ddig, dig.data(), (size_t)D * Mk, hipMemcpyHostToDevice, ctx->stream));
     MMG_HIP(ctx, hipMemcpyAsync(dcoef, cf.data(), Mk * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    const double tp0 = verbose ? now() : 0.0;
     {
       EvScope ev(ctx, EV_PACK);
       launch_transpose_digits(ctx, g, Xq, Xp, Mk, mb, ddig, D);
     }
     MMG_HIP(ctx, hipGetLastError());
+    const double tp1 = verbose ? now() : 0.0;
+    tv_pack += tp1 - tp0;
     for (int d = 0; d < D && rc == MMG_OK; ++d) {
       rc = run_kinship_i8_pq(ctx, Xp + (size_t)d * g->Npad * Mk, Xq, g->Npad, Mk, C32 + (size_t)d * g->Npad * g->Npad);
       double a = 0.0;
       if (rc == MMG_OK && mmg_last_kernel_ms(ctx, EV_KIN, &a) == MMG_OK) kin_ms += a;
     }
     if (rc) break;
+    if (verbose) tv_gemm += now() - tp1;
     // c1[i] += sum_m (a b)_m s_mi: one dot product per row of the plain image
     launch_snp_dot_raw(ctx, Xq, Mk, g->Npad, (int32_t)Mk, dcoef, dc1);
     MMG_HIP(ctx, hipMemcpyAsync(c1part.data(), dc1, g->Npad * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -617,9 +648,16 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
   if (rc) return rc;
   ctx->grm_ms_total = kin_ms;
   MMG_HIP(ctx, hipMemcpyAsync(dc1acc, c1.data(), g->Npad * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const double tt0 = verbose ? now() : 0.0;
   launch_grm_combine(ctx, C32, D, g->Npad, g->N, step, base, dc1acc, c0, dC, accumulate ? 1 : 0);
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (verbose) {
+    tv_tail = now() - tt0;
+    fprintf(stderr, "[grm] N=%d M=%lld D=%d: stats+alloc+memset %.3f s, pack %.3f s, gemms(+launch) %.3f s (kernels %.3f s), "
+                    "combine %.3f s, total %.3f s\n", g->N, (long long)M, D, tv_alloc - tv0, tv_pack, tv_gemm, kin_ms * 1e-3,
+            tv_tail, now() - tv0);
+  }
   return MMG_OK;
 }
 
@@ -627,7 +665,7 @@ int mmg_kin_acc_add_grm(mmg_ctx* ctx, mmg_kin_acc* a, mmg_geno* g) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, a && g && g->N == a->N);
   if (g->M == 0) return MMG_OK;
-  int rc = kinship_grm_i8_into(ctx, g, a->dC, true);
+  int rc = kinship_grm_i8_into(ctx, g, a->dC, true, a->ws);
   if (rc == MMG_E_STATE) {                                  // genotype alphabet too wide for int8 digit products
     Scratch sc;
     double *dm = nullptr, *ds = nullptr;
@@ -681,6 +719,7 @@ int mmg_kin_acc_destroy(mmg_ctx* ctx, mmg_kin_acc* a) {
   if (!a) return MMG_OK;
   if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
   hipFree(a->dC);
+  a->ws.release();
   delete a;
   return MMG_OK;
 }

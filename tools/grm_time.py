@@ -1,0 +1,13 @@
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mixmogam_amd import _lib
+N, M = int(sys.argv[1]), int(sys.argv[2])
+ctx = _lib.get_context()
+g = ctx.geno(M=M, N=N).fill_hash(1)
+acc = ctx.kinship_accumulator(N)
+for rep in range(3):
+    t0 = time.time(); acc.add_grm(g); print("add_grm %.3f s" % (time.time() - t0), flush=True)
+mean, sd = g.snp_stats()
+for rep in range(2):
+    t0 = time.time(); acc.add(g, 1.0 / sd, -mean / sd); print("add (fp32 MFMA) %.3f s, kernel %.1f ms" % (time.time() - t0, ctx.kernel_ms("kinship")), flush=True)
