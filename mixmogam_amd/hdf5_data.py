@@ -32,6 +32,7 @@ def open_hdf5(filename, mode='r'):
 
 
 _UPLOAD_CTX = {}
+_READ_THREADS = 4          # parallel readinto() streams per chunk (a single page-cache copy runs at 5-8 GB/s)
 
 
 def _maf_filter(cg, min_maf):
@@ -54,9 +55,39 @@ def _chunk_plan(genot_data, min_maf, chunk_size):
     return plan
 
 
-def _read_chunk(genot_data, chrom, sel):
+def _read_chunk(genot_data, chrom, sel, out=None):
+    """Rows `sel` of a chromosome's raw_snps as a C-contiguous int8 block.  out: a reusable (page-locked) host buffer
+    of at least len(sel) * N bytes -- a memory-mapped dataset is then read with one readinto() into it instead of
+    being faulted in page by page through the mapping (2.8 GB/s at config 5's chunk size) and staged a second time."""
     raw = genot_data[chrom]['raw_snps']
     lo, hi = int(sel[0]), int(sel[-1]) + 1
+    n_ind = raw.shape[1]
+    if (out is not None and isinstance(raw, np.memmap) and raw.dtype == np.int8 and raw.flags['C_CONTIGUOUS']
+            and len(sel) == hi - lo and getattr(raw, 'filename', None) is not None):
+        block = out[:(hi - lo) * n_ind].reshape(hi - lo, n_ind)
+        mv = memoryview(block).cast('B')
+        base = raw.offset + lo * n_ind
+
+        def part(a, b):                                                  # bytes [a, b) of the block; GIL released in readinto
+            with open(raw.filename, 'rb', buffering=0) as f:
+                f.seek(base + a)
+                got = a
+                while got < b:
+                    k = f.readinto(mv[got:b])
+                    if not k:
+                        raise IOError("short read from %s" % raw.filename)
+                    got += k
+
+        nbytes = len(mv)
+        nthr = min(_READ_THREADS, max(1, nbytes >> 26))                  # one reader per 64 MB, a page-cache copy each
+        if nthr == 1:
+            part(0, nbytes)
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            cuts = [nbytes * t // nthr // 4096 * 4096 for t in range(nthr)] + [nbytes]
+            with ThreadPoolExecutor(max_workers=nthr) as ex:
+                list(ex.map(lambda ab: part(*ab), zip(cuts[:-1], cuts[1:])))
+        return block
     block = np.asarray(raw[lo:hi])                                       # one contiguous read ...
     if len(sel) != hi - lo:
         block = block[sel - lo]                                          # ... then the MAF subset
@@ -92,15 +123,16 @@ def _resident_chunks(ctx, genot_data, plan, rank=0, world=1, prefetch=True, reus
     up = _UPLOAD_CTX.get(ctx.device)
     if up is None:
         up = _UPLOAD_CTX[ctx.device] = _lib.Context(ctx.device)         # second stream of the same device, kept
-    pool = []
+    pool, host = [], [None, None]
     if reuse and mine:
         cap = max(len(plan[ci][1]) for ci in mine)
         n_ind = int(np.asarray(genot_data[plan[mine[0]][0]]['raw_snps'][0:1]).shape[1])
         pool = [up.geno(M=cap, N=n_ind) for _ in range(2)]
+        host = [up.pinned_empty(cap * n_ind, dtype=np.int8) for _ in range(2)]   # page-locked staging, reused
 
     def load(ci, slot):
         chrom, sel, _pos = plan[ci]
-        block = _read_chunk(genot_data, chrom, sel)
+        block = _read_chunk(genot_data, chrom, sel, out=host[slot])
         if pool:
             return ci, chrom, _Borrowed(pool[slot].reset(len(block)).upload(block))
         return ci, chrom, up.geno(block)

@@ -62,7 +62,7 @@ try:
     t0 = time.time()
     K, n_snps = hdf5_data._ibd_kinship(ctx, src["genot_data"], N, plan)
     T["kinship_pass_s"] = round(time.time() - t0, 1)
-    print("kinship pass (ingest + GRM fp32 MFMA, %d chunks): %.1f s = %.2f M SNPs/s, %.1f GB/s ingest"
+    print("kinship pass (ingest + exact int8 GRM, %d chunks): %.1f s = %.2f M SNPs/s, %.1f GB/s ingest"
           % (len(plan), T["kinship_pass_s"], M / T["kinship_pass_s"] / 1e6, need / 1e9 / T["kinship_pass_s"]), flush=True)
     y = src["phenotypes"]
     lmm = lm.LinearMixedModel(y, ctx=ctx)
