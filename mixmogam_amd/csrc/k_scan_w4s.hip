@@ -62,6 +62,17 @@ __device__ __forceinline__ void sched_slice() {
   }
 }
 
+// MMG_W4S_PIN=1 (A/B builds, `make DEFS=-DMMG_W4S_PIN=1`): every (MFMA, read, MFMA, read/DMA) group ends in a full
+// scheduling barrier and the slice in front of the step's barrier issues its eight fragment reads in the first four
+// MFMA pairs.  Tried in round 2 because the ISA of the default build shows one slice's reads issued in reverse order
+// (the first MFMA of the next slice waits for the two reads issued last) and the last read of a step issued one MFMA
+// before `s_waitcnt lgkmcnt(0)`; measured on the same box: 24.93 vs 24.88 ms, per-K-step stamps 2730 vs 2702 cycles --
+// no gain, the LDS latency was already covered by the MFMAs in flight.  Bit-identical results either way.
+#ifndef MMG_W4S_PIN
+#define MMG_W4S_PIN 0
+#endif
+constexpr bool PIN_SLICES = MMG_W4S_PIN != 0;
+
 // Fragments are fetched in the order a0 b0 a1 b1 a2 b2 a3 b3 (one per two MFMAs) and the MFMAs of the next
 // slice consume them in the order of their arrival (ORD), so every fragment has at least 12 MFMA slots
 // (~400 cycles) between its ds_read and its first use.
@@ -70,34 +81,49 @@ __device__ constexpr int ORD_N[16] = {0, 0, 1, 1, 0, 1, 2, 2, 2, 0, 1, 2, 3, 3, 
 
 // One slice: 16 MFMA on `cur`; fragment reads of (slot `src`, chunk) into `nxt`; DMA pieces [P0, P1) of the
 // cursor's stage (pieces 0-7: P rows, 8-15: Q rows of this wave) into slot `dst`.
-template <bool LOAD, int P0, int P1, bool ZERO = false, int HOT = 0>   // HOT: 1 = all pieces, 2 = Q pieces, 3 = P pieces
+// FRONT (the slice in front of the step's barrier): all eight fragment reads are issued in the first four MFMA
+// pairs (two per pair), so that they have returned when the wave reaches `s_waitcnt lgkmcnt(0)` before the barrier
+// -- spread one per pair, the last read is issued one MFMA before that wait and its whole LDS latency is exposed
+// once per K step.  Every (MFMA, read, MFMA, read/DMA) group ends in a full scheduling barrier: the class-level
+// sched_group_barrier hints of the first version left the compiler free to choose WHICH read fills a slot, and it
+// issued one slice's reads in reverse (bottom-up) order, so that the first MFMA of the following slice waited for
+// the two reads issued last.
+template <bool LOAD, int P0, int P1, bool ZERO = false, int HOT = 0, bool FRONT = false>   // HOT: 1 = all pieces, 2 = Q pieces, 3 = P pieces
 __device__ __forceinline__ void slice(v16i (&acc)[4][4], const Frag4& cur, Frag4& nxt, const char* src, int arow,
                                       int brow, int chunk, const StageOp4& sp, const StageOp4& sq, int k0, char* dst,
                                       int wave) {
   static_assert(P1 - P0 <= 8, "at most one DMA piece per MFMA pair");
+  static_assert(!FRONT || P1 == P0, "the front-loaded slice carries no DMA pieces");
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m0 = ORD_M[2 * i], n0 = ORD_N[2 * i], m1 = ORD_M[2 * i + 1], n1 = ORD_N[2 * i + 1];
     if (ZERO) acc[m0][n0] = mfma8(cur.a[m0], cur.b[n0], v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0});
     else acc[m0][n0] = mfma8(cur.a[m0], cur.b[n0], acc[m0][n0]);
     if (LOAD) {
-      if ((i & 1) == 0) nxt.a[i >> 1] = lds_frag(src, arow + (i >> 1) * 32, chunk);
-      else nxt.b[i >> 1] = lds_frag(src + TILE_BYTES, brow + (i >> 1) * 32, chunk);
+      if (FRONT) {
+        if (i < 4) nxt.a[i] = lds_frag(src, arow + i * 32, chunk);
+      } else {
+        if ((i & 1) == 0) nxt.a[i >> 1] = lds_frag(src, arow + (i >> 1) * 32, chunk);
+        else nxt.b[i >> 1] = lds_frag(src + TILE_BYTES, brow + (i >> 1) * 32, chunk);
+      }
     }
     if (ZERO) acc[m1][n1] = mfma8(cur.a[m1], cur.b[n1], v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0});
     else acc[m1][n1] = mfma8(cur.a[m1], cur.b[n1], acc[m1][n1]);
+    if (LOAD && FRONT && i < 4) nxt.b[i] = lds_frag(src + TILE_BYTES, brow + i * 32, chunk);
     if (P0 + i < P1) {
       const int pc = P0 + i;
       if (HOT == 1 || (HOT == 2 && pc >= 8) || (HOT == 3 && pc < 8)) {   // ablation: same LDS-DMA traffic, source always the same 2 KiB
         if (pc < 8) stage_piece4(sq, 0, dst, wave, pc & 1);
         else stage_piece4(sq, 0, dst + TILE_BYTES, wave, pc & 1);
-        continue;
+      } else if (pc < 8) {
+        stage_piece4(sp, k0, dst, wave, pc);
+      } else {
+        stage_piece4(sq, k0, dst + TILE_BYTES, wave, pc - 8);
       }
-      if (pc < 8) stage_piece4(sp, k0, dst, wave, pc);
-      else stage_piece4(sq, k0, dst + TILE_BYTES, wave, pc - 8);
     }
+    if (PIN_SLICES) __builtin_amdgcn_sched_barrier(0);
   }
-  sched_slice<(P1 > P0 ? P1 - P0 : 0)>();
+  if (!PIN_SLICES) sched_slice<(P1 > P0 ? P1 - P0 : 0)>();
 }
 
 // ABL: 0 = production; timing ablations with WRONG results: 1 = no DMA in the loop, 2 = no fragment reads in
@@ -202,7 +228,7 @@ __global__ __launch_bounds__(W4_THREADS) void scan_quad_w4s_kernel(
     if (ks == 0) slice<LD, E3, E0, true, HOT>(acc, f0, f1, cur, arow, brow, 2 + h, sp, sq, k1, oth, wave);
     else slice<LD, E3, E0, false, HOT>(acc, f0, f1, cur, arow, brow, 2 + h, sp, sq, k1, oth, wave);
     slice<LD, E0, E1, false, HOT>(acc, f1, f0, cur, arow, brow, 4 + h, sp, sq, k1, oth, wave);
-    slice<LD, E1, E2, false, HOT>(acc, f0, f1, cur, arow, brow, 6 + h, sp, sq, k1, oth, wave);
+    slice<LD, E1, E2, false, HOT, PIN_SLICES && (E2 == E1)>(acc, f0, f1, cur, arow, brow, 6 + h, sp, sq, k1, oth, wave);
     const unsigned long long tb0 = ABL == 4 ? stamp() : 0;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long tb1 = ABL == 4 ? stamp() : 0;
