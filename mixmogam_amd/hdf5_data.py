@@ -32,6 +32,16 @@ def open_hdf5(filename, mode='r'):
 
 
 _UPLOAD_CTX = {}
+_POOLS = {}                # (device, N) -> (capacity in SNPs, [two chunk stores], [two page-locked staging buffers])
+
+
+def release_pools():
+    """Free the chunk stores and staging buffers the streaming loops keep between calls."""
+    for _cap, stores, _host in _POOLS.values():
+        for g in stores:
+            g.close()
+    _POOLS.clear()
+
 _READ_THREADS = 4          # parallel readinto() streams per chunk (a single page-cache copy runs at 5-8 GB/s)
 
 
@@ -127,8 +137,17 @@ def _resident_chunks(ctx, genot_data, plan, rank=0, world=1, prefetch=True, reus
     if reuse and mine:
         cap = max(len(plan[ci][1]) for ci in mine)
         n_ind = int(np.asarray(genot_data[plan[mine[0]][0]]['raw_snps'][0:1]).shape[1])
-        pool = [up.geno(M=cap, N=n_ind) for _ in range(2)]
-        host = [up.pinned_empty(cap * n_ind, dtype=np.int8) for _ in range(2)]   # page-locked staging, reused
+        # two HBM stores + two page-locked staging buffers, kept between calls (kinship pass, scan pass, the next
+        # file ...): allocating them costs ~0.1 s, as much as streaming 5 GB
+        key = (ctx.device, n_ind)
+        cached = _POOLS.get(key)
+        if cached is None or cached[0] < cap:
+            if cached is not None:
+                for g in cached[1]:
+                    g.close()
+            cached = _POOLS[key] = (cap, [up.geno(M=cap, N=n_ind) for _ in range(2)],
+                                    [up.pinned_empty(cap * n_ind, dtype=np.int8) for _ in range(2)])
+        pool, host = cached[1], cached[2]
 
     def load(ci, slot):
         chrom, sel, _pos = plan[ci]
@@ -145,8 +164,7 @@ def _resident_chunks(ctx, genot_data, plan, rank=0, world=1, prefetch=True, reus
                 fut = ex.submit(load, mine[k + 1], (k + 1) & 1) if k + 1 < len(mine) else None
                 yield cur
     finally:
-        for g in pool:
-            g.close()
+        pass                                                             # pooled stores stay allocated: release_pools()
 
 
 def _dev_comm(coll):
