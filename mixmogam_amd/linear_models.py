@@ -96,6 +96,9 @@ class LinearModel(object):
 
 # Where get_estimates would compute eig_R itself, take the spectral sums from eig_L instead (no second eigh).
 REML_SUMS_FROM_EIG_L = True
+# above this many individuals emmax_f_test takes the eigendecomposition-free route (rocSOLVER's dsyevd indexes with 32
+# bits: N^2 < 2^31)
+EIGEN_FREE_MIN_N = 46340
 # emmax_f_test builds the scan model on the device from K and delta (mmg_reml_scan_model) when nothing needs H itself.
 DEVICE_SCAN_MODEL = True
 
@@ -490,6 +493,24 @@ class LinearMixedModel(object):
         """:1233-1267."""
         t = {}
         s0 = time.time()
+        if (self.n > EIGEN_FREE_MIN_N and not eig_L and not eig_R and Z is None and not with_betas and emma_num == 0
+                and method == 'REML' and isinstance(self.ctx, _lib.Context) and len(self.random_effects) == 2):
+            # beyond rocSOLVER's syevd index range: REML and the scan model from Cholesky factorisations of K + delta I
+            # (get_estimates_eigen_free) instead of the block-Jacobi eigendecomposition (6.6 min at N = 50,000)
+            res = self.get_estimates_eigen_free()
+            t['eig_L'] = t['eig_R'] = 0.0
+            t['reml'] = time.time() - s0
+            s0 = time.time()
+            reml = res.pop('reml')
+            try:
+                r = self._emmax_f_test_(snps, None, snp_priors=snp_priors, emma_num=0, verbose=verbose,
+                                        _delta=res['delta'], _reml=reml)
+            finally:
+                reml.close()
+            t['scan'] = time.time() - s0
+            r.update(pseudo_heritability=res['pseudo_heritability'], ve=res['ve'], vg=res['vg'], max_ll=res['max_ll'],
+                     timings=t)
+            return r
         if not eig_L:
             eig_L = self._get_eigen_L_()
         t['eig_L'] = time.time() - s0
@@ -573,7 +594,8 @@ class LinearMixedModel(object):
         return prep
 
     def _emmax_f_test_(self, snps, H_sqrt_inv, snp_priors=None, verbose=True, return_transformed_snps=False,
-                       Z=None, with_betas=False, emma_num=100, eig_L=None, ndigits=0, _delta=None, **kwargs):
+                       Z=None, with_betas=False, emma_num=100, eig_L=None, ndigits=0, _delta=None, _reml=None,
+                       **kwargs):
         """:1272-1380.  `snps`: list of M arrays / [M x N] array, or a device-resident _lib.Geno.
         _delta (internal): build the scan model from K and this variance ratio on the device instead of from
         H_sqrt_inv on the host (same matrix: Mp Mp' = P(delta))."""
@@ -582,11 +604,12 @@ class LinearMixedModel(object):
                                       "device path yet")
         ctx = self.ctx
         if _delta is not None and Z is None and not with_betas:
-            reml = ctx.reml(self.random_effects[1][1], self.X, self.Y.reshape(-1))
+            reml = _reml if _reml is not None else ctx.reml(self.random_effects[1][1], self.X, self.Y.reshape(-1))
             try:
                 h0_rss_d, beta_d = reml.scan_model(_delta, ndigits)
             finally:
-                reml.close()
+                if _reml is None:
+                    reml.close()
             prep = {'h0_rss': h0_rss_d, 'h0_betas': [float(b) for b in beta_d], 'n_p': self.n - (self.X.shape[1] + 1)}
         else:
             prep = self.scan_prepare(H_sqrt_inv, Z=Z, with_betas=with_betas)

@@ -86,6 +86,12 @@ for c in solo["chrom_results"]:
         src, y, min_maf=0.05, chunk_size=200, ctx=ctx, k=solo["kinship"])["chrom_results"][c]["ps"])
 bk = hdf5_data.run_emmax(src, y, min_maf=0.05, chunk_size=200, ctx=ctx, coll=coll)
 assert np.max(np.abs(bk["kinship"] - solo["kinship"])) < 1e-9
+# eigendecomposition-free REML: the grid values of delta dealt out to the ranks, sums all-gathered over RCCL
+lmm_a = lm.LinearMixedModel(y, ctx=ctx); lmm_a.add_random_effect(K)
+lmm_b = lm.LinearMixedModel(y, ctx=ctx); lmm_b.add_random_effect(K)
+ra, rb = lmm_a.get_estimates_eigen_free(coll=coll), lmm_b.get_estimates_eigen_free()
+assert ra["delta"] == rb["delta"] and ra["max_ll"] == rb["max_ll"], (ra["delta"], rb["delta"])
+ra.pop("reml").close(); rb.pop("reml").close()
 coll.barrier()
 coll.close()
 print("rank", rank, "of", world, "ok")

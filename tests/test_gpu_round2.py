@@ -482,3 +482,14 @@ def test_grm_monomorphic_snp_is_an_error(ctx):
     snps[7] = 1
     with pytest.raises(_lib.MixmogamHipError, match="std == 0"):
         kinship.calc_ibd_kinship(snps, ctx=ctx)
+
+
+def test_emmax_takes_the_eigen_free_route_above_the_threshold(ctx, case, monkeypatch):
+    """lm.emmax() switches to the Cholesky route by N alone (threshold lowered for the test): same p-values."""
+    from mixmogam_amd import linear_models as lm
+    monkeypatch.setattr(lm, "EIGEN_FREE_MIN_N", 100)
+    res = lm.emmax(list(case["snps"]), list(case["y"]), case["dbl_ibs_scaled"], cofactors=case["cof"], ctx=ctx)
+    assert res["timings"]["eig_L"] == 0.0
+    assert rel(res["ps"], case["dbl_emmax_ps"]) < 1e-6
+    for k in ("pseudo_heritability", "ve", "vg", "max_ll"):
+        assert rel(res[k], case["dbl_emmax_" + k]) < 1e-7, k
