@@ -52,37 +52,60 @@ def synthetic_chunk(chunk_id, rows, num_indivs, seed=20240):
     return np.unpackbits(raw)[:nbits].view(np.int8).reshape(int(rows), int(num_indivs))
 
 
+def _fill_rows(args):
+    """Worker of write_synthetic_container: rows [r0, r0 + rows) of one chromosome's raw_snps <- synthetic_chunk."""
+    npy_path, r0, rows, num_indivs, chunk_id, seed = args
+    mm = np.lib.format.open_memmap(npy_path, mode="r+")
+    blk = synthetic_chunk(chunk_id, rows, num_indivs, seed)
+    mm[r0:r0 + rows] = blk
+    mm.flush()
+    del mm
+    return r0, blk.mean(axis=1, dtype=np.float64)
+
+
 def write_synthetic_container(path, num_indivs, num_snps, chunk_rows=100000, seed=20240, num_chroms=5,
-                              pheno_seed=20241, h2=0.8, num_causals=100):
+                              pheno_seed=20241, h2=0.8, num_causals=100, workers=1):
     """A genotype container (plink2hdf5.py layout, mixmogam_amd.chunkstore) of `num_snps` synthetic SNPs split over
-    `num_chroms` chromosomes, written chunk by chunk (one `synthetic_chunk` at a time is in host memory), plus a
-    phenotype built from `num_causals` SNPs of the first chunk (simulations.py:64-85).  Returns the path."""
+    `num_chroms` chromosomes, written chunk by chunk (one `synthetic_chunk` per worker at a time is in host memory),
+    plus a phenotype built from `num_causals` SNPs of the first chunk (simulations.py:64-85).  workers > 1: the
+    chunks are generated and written by that many processes (the generator is one core's 1.4 GB/s).  Returns path."""
+    import os
     from . import chunkstore
     st = chunkstore.Store(path, "w")
     gg = st.create_group("genot_data")
     ig = st.create_group("indiv_data")
     ig.create_dataset("indiv_ids", data=np.asarray(["i%d" % i for i in range(num_indivs)], dtype="S"))
     per = -(-num_snps // num_chroms)
-    chunk_id, written, y = 0, 0, None
+    chunk_id, written = 0, 0
+    jobs, chrom_rows = [], []
     for c in range(num_chroms):
         m_c = min(per, num_snps - written)
         if m_c <= 0:
             break
         cg = gg.create_group("chrom_%d" % (c + 1))
         raw = cg.create_dataset("raw_snps", shape=(m_c, num_indivs), dtype=np.int8)
-        freqs = np.empty(m_c)
+        raw.flush()
+        npy = os.path.join(path, "genot_data", "chrom_%d" % (c + 1), "raw_snps.npy")
         for r0 in range(0, m_c, chunk_rows):
-            blk = synthetic_chunk(chunk_id, min(chunk_rows, m_c - r0), num_indivs, seed)
-            if y is None:
-                y = simulate_phenotype(blk, h2=h2, num_causals=num_causals, seed=pheno_seed)
-            raw[r0:r0 + len(blk)] = blk
-            freqs[r0:r0 + len(blk)] = blk.mean(axis=1, dtype=np.float64)
+            jobs.append((c, (npy, r0, min(chunk_rows, m_c - r0), num_indivs, chunk_id, seed)))
             chunk_id += 1
         cg.create_dataset("positions", data=np.arange(1, m_c + 1, dtype=np.int64))
-        cg.create_dataset("freqs", data=freqs)
-        cg.flush()
+        chrom_rows.append((cg, m_c))
         written += m_c
-    ig.create_dataset("phenotypes", data=y)
+    freqs = [np.empty(m_c) for _cg, m_c in chrom_rows]
+    if workers > 1:
+        from concurrent.futures import ProcessPoolExecutor
+        with ProcessPoolExecutor(max_workers=workers) as ex:
+            for (c, _a), (r0, f) in zip(jobs, ex.map(_fill_rows, [a for _c, a in jobs])):
+                freqs[c][r0:r0 + len(f)] = f
+    else:
+        for c, a in jobs:
+            r0, f = _fill_rows(a)
+            freqs[c][r0:r0 + len(f)] = f
+    for (cg, _m), f in zip(chrom_rows, freqs):
+        cg.create_dataset("freqs", data=f)
+    first = synthetic_chunk(0, min(chunk_rows, per, num_snps), num_indivs, seed)
+    ig.create_dataset("phenotypes", data=simulate_phenotype(first, h2=h2, num_causals=num_causals, seed=pheno_seed))
     st.create_dataset("num_snps", data=np.array(written))
     st.close()
     return path

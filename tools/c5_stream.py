@@ -27,6 +27,7 @@ ap.add_argument("--world", type=int, default=8, help="ranks the SNP axis is spli
 ap.add_argument("--chunk", type=int, default=50000)
 ap.add_argument("--scratch", default="/dev/shm")
 ap.add_argument("--keep", action="store_true")
+ap.add_argument("--writers", type=int, default=8, help="processes generating / writing the container")
 ap.add_argument("--eig", action="store_true", help="take the eigendecomposition route (eigh of K) even beyond N = 46,340")
 a = ap.parse_args()
 N, M, CH = a.n, a.m_total // a.world, a.chunk
@@ -54,7 +55,7 @@ threading.Thread(target=_beat, daemon=True).start()
 try:
     t0 = time.time()
     path = simulations.write_synthetic_container(os.path.join(root, "geno.mmg"), N, M, chunk_rows=CH, num_chroms=5,
-                                                 seed=20240, pheno_seed=20241, num_causals=100)
+                                                 seed=20240, pheno_seed=20241, num_causals=100, workers=a.writers)
     T["write_container_s"] = round(time.time() - t0, 1)
     print("container written: %.1f s (%.2f GB/s)" % (T["write_container_s"], need / 1e9 / T["write_container_s"]), flush=True)
     src = hdf5_data.open_hdf5(path)
