@@ -27,6 +27,7 @@ ap.add_argument("--world", type=int, default=8, help="ranks the SNP axis is spli
 ap.add_argument("--chunk", type=int, default=50000)
 ap.add_argument("--scratch", default="/dev/shm")
 ap.add_argument("--keep", action="store_true")
+ap.add_argument("--max-gb", type=float, default=80.0, help="largest container this run may put into the scratch directory")
 ap.add_argument("--writers", type=int, default=8, help="processes generating / writing the container")
 ap.add_argument("--eig", action="store_true", help="take the eigendecomposition route (eigh of K) even beyond N = 46,340")
 a = ap.parse_args()
@@ -37,6 +38,9 @@ free = shutil.disk_usage(a.scratch).free
 print("share of rank 0: N=%d x M=%d = %.1f GB container in %s (%.0f GB free)" % (N, M, need / 1e9, a.scratch, free / 1e9),
       flush=True)
 assert free > 1.2 * need, "not enough scratch space"
+# A container in /dev/shm is host MEMORY, and a GPU box's job is limited far below what `free` shows for the machine:
+# the full 10 M-SNP container (500 GB) took a box down in round 2.  Refuse anything beyond --max-gb.
+assert need <= a.max_gb * 1e9, "container of %.0f GB exceeds --max-gb %.0f (host memory of the job)" % (need / 1e9, a.max_gb)
 ctx = _lib.Context(0)
 T = {}
 # heartbeat: the eigendecomposition at N = 50,000 is silent for several minutes, and a GPU box takes a job that
