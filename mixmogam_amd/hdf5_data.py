@@ -278,8 +278,8 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
     lmm.add_random_effect(k)
     if eigen_free is None:
         eigen_free = n > 46340 and not num_perm and isinstance(ctx, _lib.Context)
-    if eigen_free:
-        res = lmm.get_estimates_eigen_free(coll=coll)                    # :126-137 without either eigendecomposition
+    res = lmm._try_eigen_free(coll=coll) if eigen_free else None         # :126-137 without either eigendecomposition
+    if res is not None:
         prep = lmm.scan_model_eigen_free(res)
         res.pop('reml').close()
     else:

@@ -497,7 +497,10 @@ class LinearMixedModel(object):
                 and method == 'REML' and isinstance(self.ctx, _lib.Context) and len(self.random_effects) == 2):
             # beyond rocSOLVER's syevd index range: REML and the scan model from Cholesky factorisations of K + delta I
             # (get_estimates_eigen_free) instead of the block-Jacobi eigendecomposition (6.6 min at N = 50,000)
-            res = self.get_estimates_eigen_free()
+            res = self._try_eigen_free()
+        else:
+            res = None
+        if res is not None:
             t['eig_L'] = t['eig_R'] = 0.0
             t['reml'] = time.time() - s0
             s0 = time.time()
@@ -511,6 +514,7 @@ class LinearMixedModel(object):
             r.update(pseudo_heritability=res['pseudo_heritability'], ve=res['ve'], vg=res['vg'], max_ll=res['max_ll'],
                      timings=t)
             return r
+        s0 = time.time()
         if not eig_L:
             eig_L = self._get_eigen_L_()
         t['eig_L'] = time.time() - s0
@@ -530,9 +534,17 @@ class LinearMixedModel(object):
             res = self.get_estimates(eig_L, method=method, return_H=not device_model)
         t['reml'] = time.time() - s0
         s0 = time.time()
-        r = self._emmax_f_test_(snps, res['H_sqrt_inv'], snp_priors=snp_priors, Z=Z, with_betas=with_betas,
-                                emma_num=emma_num, eig_L=eig_L, verbose=verbose,
-                                _delta=res['delta'] if device_model else None)
+        try:
+            r = self._emmax_f_test_(snps, res['H_sqrt_inv'], snp_priors=snp_priors, Z=Z, with_betas=with_betas,
+                                    emma_num=emma_num, eig_L=eig_L, verbose=verbose,
+                                    _delta=res['delta'] if device_model else None)
+        except _lib.MixmogamHipError as e:
+            if not (device_model and "positive definite" in str(e)):
+                raise
+            # an indefinite kinship: K + delta I has no Cholesky factor; build the model from H_sqrt_inv instead
+            res = self.get_estimates(eig_L, method=method)
+            r = self._emmax_f_test_(snps, res['H_sqrt_inv'], snp_priors=snp_priors, Z=Z, with_betas=with_betas,
+                                    emma_num=emma_num, eig_L=eig_L, verbose=verbose)
         t['scan'] = time.time() - s0
         r['pseudo_heritability'] = res['pseudo_heritability']
         r['ve'] = res['ve']
@@ -546,6 +558,17 @@ class LinearMixedModel(object):
     def _get_estimates_with(self, eig_L, eig_R, method, ngrids=50):
         """get_estimates on a PRECOMPUTED eig_R (the reference's own route, :787-799)."""
         return self.get_estimates(eig_L, method=method, eig_R=eig_R, ngrids=ngrids, use_eig_R=True)
+
+    def _try_eigen_free(self, coll=None):
+        """get_estimates_eigen_free, or None when K + delta I is not positive definite somewhere on the grid (an
+        indefinite user-supplied kinship: the eigen route copes with that, Cholesky cannot)."""
+        try:
+            return self.get_estimates_eigen_free(coll=coll)
+        except _lib.MixmogamHipError as e:
+            if "positive definite" not in str(e):
+                raise
+            warnings.warn("K + delta*I is not positive definite on the REML grid; taking the eigendecomposition route")
+            return None
 
     def get_estimates_eigen_free(self, ngrids=50, llim=-10, ulim=10, esp=1e-6, coll=None):
         """get_estimates(method='REML') (:771-927) without eig_L / eig_R: the likelihood sums come from Cholesky

@@ -493,3 +493,31 @@ def test_emmax_takes_the_eigen_free_route_above_the_threshold(ctx, case, monkeyp
     assert rel(res["ps"], case["dbl_emmax_ps"]) < 1e-6
     for k in ("pseudo_heritability", "ve", "vg", "max_ll"):
         assert rel(res[k], case["dbl_emmax_" + k]) < 1e-7, k
+
+
+def test_indefinite_kinship_falls_back_to_the_eigen_route(ctx):
+    """A user-supplied kinship with negative eigenvalues: the device-built scan model (Cholesky of K + delta I) is not
+    available, emmax() still answers through H_sqrt_inv -- same p-values as with the device model switched off."""
+    import warnings
+    from mixmogam_amd import linear_models as lm
+    rng = np.random.RandomState(8)
+    n, m = 200, 400
+    snps = rng.randint(0, 2, size=(m, n)).astype(np.int8)
+    snps = snps[snps.std(1) > 0]
+    B = rng.standard_normal((n, 30))
+    K = B @ B.T / 30
+    K -= 0.3 * np.outer(B[:, 0], B[:, 0]) / 30 * 4          # push one direction negative
+    K = 0.5 * (K + K.T)
+    assert np.linalg.eigvalsh(K).min() < -1e-3
+    y = rng.standard_normal(n)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = lm.emmax(snps, y, K, ctx=ctx)
+        lm.DEVICE_SCAN_MODEL = False
+        try:
+            b = lm.emmax(snps, y, K, ctx=ctx)
+        finally:
+            lm.DEVICE_SCAN_MODEL = True
+    ok = np.isfinite(b["ps"])
+    assert np.array_equal(np.isfinite(a["ps"]), ok)
+    assert rel(a["ps"][ok], b["ps"][ok]) < 1e-6
