@@ -18,7 +18,11 @@ def scale_k(k, verbose=False):
     """kinship.py:94-100 -- c = tr(K) - sum(K)/n, K * (n-1)/c.  Host fp64, O(N^2)."""
     k = np.asarray(k, dtype=np.float64)
     n = len(k)
-    c = np.sum((np.eye(n) - (1.0 / n) * np.ones(k.shape)) * k)
+    if n <= 16384:
+        c = np.sum((np.eye(n) - (1.0 / n) * np.ones(k.shape)) * k)      # as the reference writes it (:95)
+    else:
+        # the same number without three N x N temporaries (60 GB at N = 50,000): sum_ij (d_ij - 1/n) K_ij
+        c = float(np.trace(k)) - float(np.sum(k)) / n
     scalar = (n - 1) / c
     if verbose:
         print('Kinship scaled by: %0.4f' % scalar)

@@ -239,3 +239,16 @@ def test_eigen_free_reml_and_scan_model_equal_the_eigen_route(case, ctx):
     assert rel(prep["h0_betas"], case["dbl_emmax_h0_betas"]) < 1e-6
     out = ctx.scan(ctx.geno(case["snps"]), prep["h0_rss"], prep["n_p"])
     assert rel(out["ps"], case["dbl_emmax_ps"]) < 1e-6
+
+
+def test_run_emmax_over_a_never_resident_source(ctx):
+    """hdf5_data.run_emmax over simulations.lazy_synthetic_source (rows regenerated on every read, config 5's "never
+    fully resident") == the same run over the materialised arrays."""
+    from mixmogam_amd import simulations
+    tree, y = simulations.lazy_synthetic_source(50, 900, num_chroms=3, gen_rows=64, num_causals=5, threads=3)
+    mem = {c: {"raw_snps": v["raw_snps"][:], "freqs": v["freqs"], "positions": v["positions"]} for c, v in tree.items()}
+    a = hdf5_data.run_emmax(tree, y, min_maf=0.1, chunk_size=100, ctx=ctx)
+    b = hdf5_data.run_emmax(mem, y, min_maf=0.1, chunk_size=10 ** 6, ctx=ctx)
+    assert a["num_snps"] == b["num_snps"] == 900
+    for c in mem:
+        assert rel(a["chrom_results"][c]["ps"], b["chrom_results"][c]["ps"]) < 1e-9

@@ -27,16 +27,19 @@ ap.add_argument("--world", type=int, default=8, help="ranks the SNP axis is spli
 ap.add_argument("--chunk", type=int, default=50000)
 ap.add_argument("--scratch", default="/dev/shm")
 ap.add_argument("--keep", action="store_true")
+ap.add_argument("--lazy", action="store_true",
+                help="no container: every chunk is regenerated on each read (simulations.LazySyntheticGenotypes), "
+                     "nothing but the current chunks is ever in host memory -- the whole 10 M SNPs on one GPU")
 ap.add_argument("--max-gb", type=float, default=80.0, help="largest container this run may put into the scratch directory")
 ap.add_argument("--writers", type=int, default=8, help="processes generating / writing the container")
 ap.add_argument("--eig", action="store_true", help="take the eigendecomposition route (eigh of K) even beyond N = 46,340")
 a = ap.parse_args()
 N, M, CH = a.n, a.m_total // a.world, a.chunk
 root = os.path.join(a.scratch, "mmg_c5_%d" % os.getpid())
-need = N * M
+need = 0 if a.lazy else N * M
 free = shutil.disk_usage(a.scratch).free
-print("share of rank 0: N=%d x M=%d = %.1f GB container in %s (%.0f GB free)" % (N, M, need / 1e9, a.scratch, free / 1e9),
-      flush=True)
+print("share of rank 0: N=%d x M=%d = %.1f GB %s" % (N, M, N * M / 1e9, "regenerated on every read, never stored" if a.lazy
+      else "container in %s (%.0f GB free)" % (a.scratch, free / 1e9)), flush=True)
 assert free > 1.2 * need, "not enough scratch space"
 # A container in /dev/shm is host MEMORY, and a GPU box's job is limited far below what `free` shows for the machine:
 # the full 10 M-SNP container (500 GB) took a box down in round 2.  Refuse anything beyond --max-gb.
@@ -57,18 +60,34 @@ def _beat():
 
 threading.Thread(target=_beat, daemon=True).start()
 try:
+    GEN = 6250                                               # generation chunk of the lazy source (8 per 50,000-SNP read)
+    if a.lazy:
+        tree, y_lazy = simulations.lazy_synthetic_source(N, M, num_chroms=5, gen_rows=GEN, seed=20240, pheno_seed=20241,
+                                                         num_causals=100, threads=a.writers)
     t0 = time.time()
-    path = simulations.write_synthetic_container(os.path.join(root, "geno.mmg"), N, M, chunk_rows=CH, num_chroms=5,
+    path = None if a.lazy else simulations.write_synthetic_container(os.path.join(root, "geno.mmg"), N, M, chunk_rows=CH, num_chroms=5,
                                                  seed=20240, pheno_seed=20241, num_causals=100, workers=a.writers)
     T["write_container_s"] = round(time.time() - t0, 1)
-    print("container written: %.1f s (%.2f GB/s)" % (T["write_container_s"], need / 1e9 / T["write_container_s"]), flush=True)
-    src = hdf5_data.open_hdf5(path)
+    if not a.lazy:
+        print("container written: %.1f s (%.2f GB/s)" % (T["write_container_s"], need / 1e9 / max(T["write_container_s"], 1e-9)), flush=True)
+    src = {"genot_data": tree, "phenotypes": y_lazy} if a.lazy else hdf5_data.open_hdf5(path)
+
+    def regenerate(gi):                                       # genotype row of global SNP index gi, from the generator
+        if not a.lazy:
+            cid, off = divmod(int(gi), CH)
+            return simulations.synthetic_chunk(cid, CH, N, 20240)[off]
+        for chrom in tree:
+            ds = tree[chrom]["raw_snps"]
+            if gi < len(ds):
+                return ds[int(gi)]
+            gi -= len(ds)
+        raise IndexError(gi)
     plan = hdf5_data._chunk_plan(src["genot_data"], 0.1, CH)
     t0 = time.time()
     K, n_snps = hdf5_data._ibd_kinship(ctx, src["genot_data"], N, plan)
     T["kinship_pass_s"] = round(time.time() - t0, 1)
     print("kinship pass (ingest + exact int8 GRM, %d chunks): %.1f s = %.2f M SNPs/s, %.1f GB/s ingest"
-          % (len(plan), T["kinship_pass_s"], M / T["kinship_pass_s"] / 1e6, need / 1e9 / T["kinship_pass_s"]), flush=True)
+          % (len(plan), T["kinship_pass_s"], M / T["kinship_pass_s"] / 1e6, N * M / 1e9 / T["kinship_pass_s"]), flush=True)
     y = src["phenotypes"]
     lmm = lm.LinearMixedModel(y, ctx=ctx)
     lmm.add_random_effect(K)
@@ -147,8 +166,7 @@ try:
     sample = np.unique(np.r_[hits, rng.choice(M, 8, replace=False)])
     worst = 0.0
     for gi in sample:
-        cid, off = divmod(int(gi), CH)
-        s = simulations.synthetic_chunk(cid, CH, N, 20240)[off].astype(np.float64)
+        s = regenerate(gi).astype(np.float64)
         His = solve(s)
         den = float(s @ His) - float((X.T @ His) @ np.linalg.solve(a_, X.T @ His))
         rss = h0_rss - float(s @ Py) ** 2 / den
@@ -157,7 +175,7 @@ try:
         if p > 1e-290:
             worst = max(worst, abs(ps[gi] / p - 1))
     total = sum(v for k, v in T.items() if k.endswith("_s") and k not in ("write_container_s", "scan_quad_kernel_s"))
-    print(json.dumps({"config": "C5 share of rank 0 of %d" % a.world, "N": N, "M_share": M, "M_total": a.m_total,
+    print(json.dumps({"config": ("C5 share of rank 0 of %d" % a.world) + (", lazily generated" if a.lazy else ""), "N": N, "M_share": M, "M_total": a.m_total,
                       "chunks": len(plan), "timings": T, "pipeline_s": round(total, 1),
                       "snps_per_s_end_to_end": M / total, "min_p": float(ps.min()),
                       "route": "eigendecomposition-free (Cholesky REML)" if eigen_free else "eigh",
