@@ -36,6 +36,7 @@ typedef struct mmg_geno mmg_geno;    /* device-resident padded genotype store */
 typedef struct mmg_comm mmg_comm;    /* RCCL communicator, one rank per process */
 typedef struct mmg_kin_acc mmg_kin_acc;  /* device-resident N x N kinship accumulator */
 typedef struct mmg_rot mmg_rot;      /* eigen-rotated genotype store (multi-phenotype scans) */
+typedef struct mmg_perm_plan mmg_perm_plan;  /* SNP-independent half of the permutation test, built once per (H, Ys) */
 typedef struct mmg_reml mmg_reml;    /* eigendecomposition-free REML workspace (K, X, y resident) */
 
 /* ---- library / context -------------------------------------------------------------- */
@@ -283,6 +284,16 @@ int mmg_emmax_perm_sharded(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int32_t N,
  * digit schedule: ~1e-8 relative where it did not refine), i.e. min_rss to ~1e-9 relative instead of 1e-12. */
 int mmg_emmax_perm_after_scan(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int32_t N, const double* Ht, const double* Ys,
                               int32_t P, double h0_rss, const double* HtQ, int32_t q, double* min_rss);
+/* The SNP-independent half of the test (linear_models.py:1135-1156 plus the operand images: H'H as digit planes,
+ * W' = Ys'H as a 4-digit int8 image, v = H'H 1, Ys_p.Ys_p) prepared ONCE and run over any number of genotype stores
+ * -- the chunk loop of hdf5_data.py:294-330, the ranks' blocks, repeated tests.  mmg_perm_plan_run: HtQ == NULL is
+ * the stand-alone test (exact t.t, all four planes); HtQ [q x N] is the after-scan form above.  The one-shot entry
+ * points are create + run + destroy. */
+int mmg_perm_plan_create(mmg_ctx* ctx, int32_t N, const double* Ht, const double* Ys, int32_t P, double h0_rss,
+                         mmg_perm_plan** plan);
+int mmg_perm_plan_run(mmg_ctx* ctx, mmg_comm* comm, mmg_perm_plan* plan, mmg_geno* g, const double* HtQ, int32_t q,
+                      double* min_rss);
+int mmg_perm_plan_destroy(mmg_ctx* ctx, mmg_perm_plan* plan);
 /* rank / world of the communicator and the rank count RCCL itself reports (ncclCommCount); any may be NULL */
 int mmg_comm_info(mmg_comm* c, int* rank, int* world, int* nccl_count);
 /* all-gather of equal-sized host blocks (count doubles per rank; recv: world*count, rank-major) */

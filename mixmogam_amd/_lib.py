@@ -92,6 +92,9 @@ PROTOTYPES = {
                                          c_vp]),
     "mmg_emmax_perm_after_scan": (C.c_int, [c_vp, c_vp, c_vp, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, c_vp,
                                             C.c_int32, c_vp]),
+    "mmg_perm_plan_create": (C.c_int, [c_vp, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, C.POINTER(c_vp)]),
+    "mmg_perm_plan_run": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int32, c_vp]),
+    "mmg_perm_plan_destroy": (C.c_int, [c_vp, c_vp]),
     "mmg_comm_info": (C.c_int, [c_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mmg_comm_allgather_f64": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp]),
     "mmg_f_sf": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp]),
@@ -307,6 +310,41 @@ class Rot(object):
             pass
 
 
+class PermPlan(object):
+    """SNP-independent half of the EMMAX permutation test on the device (mmg_perm_plan_*): built once per (H, Ys),
+    run over any number of genotype stores."""
+
+    def __init__(self, ctx, H, Ys, h0_rss):
+        H = _arr(H, np.float64)
+        Ys = _arr(Ys, np.float64)
+        self.ctx, self.N, self.P = ctx, H.shape[0], Ys.shape[1]
+        assert H.shape == (self.N, self.N) and Ys.shape[0] == self.N
+        h = c_vp()
+        ctx._check(ctx.lib.mmg_perm_plan_create(ctx.h, self.N, _ptr(H), _ptr(Ys), self.P, float(h0_rss), C.byref(h)))
+        self.h = h
+
+    def run(self, g, comm=None, after_scan_HtQ=None):
+        out = np.empty(self.P)
+        U, q = None, 0
+        if after_scan_HtQ is not None:
+            U = _arr(np.atleast_2d(after_scan_HtQ), np.float64)
+            assert U.shape[1] == self.N
+            q = U.shape[0]
+        self.ctx._check(self.ctx.lib.mmg_perm_plan_run(self.ctx.h, comm, self.h, g.h, _ptr(U), q, _ptr(out)))
+        return out
+
+    def close(self):
+        if self.h is not None:
+            self.ctx.lib.mmg_perm_plan_destroy(self.ctx.h, self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Reml(object):
     """Eigendecomposition-free REML workspace (mmg_reml_*): K, X, y resident; the four likelihood sums per delta from
     one Cholesky factorisation each; the scan model P(delta), P y built on the device."""
@@ -478,6 +516,9 @@ class Context(object):
 
     def reml(self, K, X, y):
         return Reml(self, K, X, y)
+
+    def perm_plan(self, H, Ys, h0_rss):
+        return PermPlan(self, H, Ys, h0_rss)
 
     def scan_multi(self, rot, d, omega, G, h0_rss, df2, want=("rss", "f_stats", "ps")):
         """P phenotypes over the rotated store: d, omega [P x N], G [P x q x N], h0_rss [P] -> {'rss','f_stats','ps'}

@@ -1273,6 +1273,139 @@ static int dgemm_dev(mmg_ctx* ctx, int ta, int tb, int M, int N, int K, const do
   return MMG_OK;
 }
 
+// ------------------------------------------------------------------------- permutation plan
+// Everything of _emmax_permutations_ that does not depend on the SNPs (linear_models.py:1135-1156 + the operand images
+// of the two GEMMs): H, W' = Ys'H as 4-digit int8 image, the quadratic-form model of H'H, v = H'H 1, c0 = 1'H'H 1,
+// Ys_p.Ys_p.  Built once per (H, Ys) -- per phenotype -- and run over any number of genotype stores (chunks).
+struct mmg_perm_plan {
+  int32_t N = 0, Npad = 0, P = 0, Ppad = 0;
+  double h0_rss = 0.0, c0 = 0.0;
+  std::vector<double> yy;
+  int8_t* Wq = nullptr;
+  double *dstep = nullptr, *dcsum = nullptr, *dv = nullptr /*[Npad] v = H'H 1 (zero padded)*/;
+  mmg_scan_model pm;             // digit planes of H'H (t.t quadratic form), w slot = v
+  mmg_scan_result pr;            // per-SNP work arrays of the quadratic form
+  double *dmu = nullptr, *dinv = nullptr, *dmax = nullptr, *dvecs = nullptr, *ddots = nullptr;
+  int64_t cap = 0;               // SNP capacity of dmu / dinv / ddots
+  int qcap = 0;
+};
+
+static void perm_plan_free(mmg_perm_plan* p) {
+  hipFree(p->Wq); hipFree(p->dstep); hipFree(p->dcsum); hipFree(p->dv); hipFree(p->dmu); hipFree(p->dinv); hipFree(p->dmax);
+  hipFree(p->dvecs); hipFree(p->ddots);
+  free_model(p->pm); free_result(p->pr);
+  delete p;
+}
+
+int mmg_perm_plan_create(mmg_ctx* ctx, int32_t N, const double* Ht, const double* Ys, int32_t P, double h0_rss,
+                         mmg_perm_plan** out) {
+  Scratch sc;
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, out && Ht && Ys && N > 0 && P > 0);
+  *out = nullptr;
+  mmg_perm_plan* p = new mmg_perm_plan();
+  p->N = N; p->Npad = (int32_t)round_up(N, 256); p->P = P; p->Ppad = (int)round_up(P, 64); p->h0_rss = h0_rss;
+  p->yy.assign((size_t)P, 0.0);
+  for (int i = 0; i < N; ++i)
+    for (int k = 0; k < P; ++k) p->yy[k] += Ys[(size_t)i * P + k] * Ys[(size_t)i * P + k];
+  double *dH = nullptr, *dYs = nullptr, *dA = nullptr, *dWt = nullptr, *dones = nullptr, *dh1 = nullptr;
+  const int nPT = p->Ppad / 64;
+  hipError_t e = hipMalloc(&p->Wq, (size_t)nPT * TM * p->Npad);
+  if (e == hipSuccess) e = hipMalloc(&p->dstep, p->Ppad * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&p->dcsum, p->Ppad * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&p->dv, p->Npad * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&p->dmax, p->Ppad * sizeof(double));
+  if (e == hipSuccess) e = sc.alloc(&dH, (size_t)N * N * sizeof(double));
+  if (e == hipSuccess) e = sc.alloc(&dYs, (size_t)N * P * sizeof(double));
+  if (e == hipSuccess) e = sc.alloc(&dA, (size_t)N * N * sizeof(double));
+  if (e == hipSuccess) e = sc.alloc(&dWt, (size_t)P * N * sizeof(double));
+  if (e == hipSuccess) e = sc.alloc(&dones, N * sizeof(double));
+  if (e == hipSuccess) e = sc.alloc(&dh1, N * sizeof(double));
+  if (e != hipSuccess) { perm_plan_free(p); return set_err(ctx, MMG_E_NOMEM, std::string("hipMalloc permutation plan: ") + hipGetErrorString(e)); }
+  int rc = MMG_OK;
+  auto fail = [&](int code) { perm_plan_free(p); return code; };
+  std::vector<double> ones((size_t)N, 1.0), h1((size_t)N);
+  if (hipMemcpyAsync(dH, Ht, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+      hipMemcpyAsync(dYs, Ys, (size_t)N * P * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+      hipMemcpyAsync(dones, ones.data(), N * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+      hipMemsetAsync(p->dv, 0, p->Npad * sizeof(double), ctx->stream) != hipSuccess)
+    return fail(set_err(ctx, MMG_E_HIP, "permutation plan: upload"));
+  rc = dgemm_dev(ctx, 1, 0, N, N, N, dH, dH, dA);                          // A' = H'H      (t.t = s~' A' s~, :1160,1163)
+  if (rc == MMG_OK) rc = dgemm_dev(ctx, 1, 0, P, N, N, dYs, dH, dWt);      // W' = Ys'H [P x N]  (t.Ys_p = s~ . W_p)
+  if (rc == MMG_OK) rc = dgemm_dev(ctx, 0, 0, N, 1, N, dH, dones, dh1);    // H 1
+  if (rc == MMG_OK) rc = dgemm_dev(ctx, 1, 0, N, 1, N, dH, dh1, p->dv);    // v = H'(H 1) = A' 1
+  if (rc) return fail(rc);
+  if (hipMemcpyAsync(h1.data(), dh1, N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess)
+    return fail(set_err(ctx, MMG_E_HIP, "permutation plan: H 1"));
+  for (int i = 0; i < N; ++i) p->c0 += h1[i] * h1[i];                       // 1'H'H 1
+  rc = model_from_device(ctx, p->pm, N, dA, p->dv, 4);                      // exact: all four planes for every SNP
+  if (rc == MMG_OK) rc = quantize_rows_4digits(ctx, dWt, N, p->Npad, P, p->Wq, p->dstep, p->dcsum);
+  if (rc == MMG_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_err(ctx, MMG_E_HIP, "permutation plan: setup");
+  if (rc) return fail(rc);
+  *out = p;
+  return MMG_OK;
+}
+
+int mmg_perm_plan_destroy(mmg_ctx* ctx, mmg_perm_plan* p) {
+  if (!p) return MMG_OK;
+  if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
+  perm_plan_free(p);
+  return MMG_OK;
+}
+
+int mmg_perm_plan_run(mmg_ctx* ctx, mmg_comm* comm, mmg_perm_plan* p, mmg_geno* g, const double* HtQ, int32_t q,
+                      double* min_rss) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, p && g && min_rss && g->N == p->N && (HtQ == nullptr || q >= 1));
+  const bool reduce = comm && comm->world > 1;
+  const bool reuse = HtQ != nullptr;
+  if (reuse && (ctx->res.geno != g || ctx->res.geno_version != g->version || ctx->res.M != g->M || ctx->model.N != p->N))
+    return set_err(ctx, MMG_E_STATE, "mmg_perm_plan_run: the last mmg_emmax_scan_device of this context was not over this "
+                                     "genotype store in its current state");
+  MMG_HIP(ctx, hipMemsetAsync(p->dmax, 0, p->Ppad * sizeof(double), ctx->stream));
+  if (g->M > 0) {
+    if (p->cap < g->Mpad || p->qcap < (reuse ? q : 0)) {
+      hipFree(p->dmu); hipFree(p->dinv); hipFree(p->ddots); hipFree(p->dvecs);
+      p->dmu = p->dinv = p->ddots = p->dvecs = nullptr; p->cap = 0;
+      const int qq = std::max(reuse ? q : 0, p->qcap);
+      MMG_HIP(ctx, hipMalloc(&p->dmu, g->Mpad * sizeof(double)));
+      MMG_HIP(ctx, hipMalloc(&p->dinv, g->Mpad * sizeof(double)));
+      MMG_HIP(ctx, hipMalloc(&p->ddots, (size_t)(1 + qq) * g->Mpad * sizeof(double)));
+      MMG_HIP(ctx, hipMalloc(&p->dvecs, (size_t)(1 + qq) * p->Npad * sizeof(double)));
+      p->cap = g->Mpad; p->qcap = qq;
+    }
+    if (reuse) {
+      // t.t from the quadratic forms of the scan that just ran over g with the same H (see mmg_emmax_perm_after_scan)
+      MMG_HIP(ctx, hipMemsetAsync(p->dvecs, 0, (size_t)(1 + q) * p->Npad * sizeof(double), ctx->stream));
+      MMG_HIP(ctx, hipMemcpyAsync(p->dvecs, p->dv, p->Npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+      for (int c = 0; c < q; ++c)
+        MMG_HIP(ctx, hipMemcpyAsync(p->dvecs + (size_t)(1 + c) * p->Npad, HtQ + (size_t)c * p->N, p->N * sizeof(double),
+                                    hipMemcpyHostToDevice, ctx->stream));
+      for (int k = 0; k < 1 + q; ++k) launch_snp_dot(ctx, g, p->dvecs + (size_t)k * p->Npad, p->ddots + (size_t)k * g->Mpad);
+      launch_perm_center_reuse(ctx, g, ctx->res.den, p->ddots, q, ctx->res.sum, p->c0, p->dmu, p->dinv);
+    } else {
+      int rc = ensure_result(ctx, p->pr, g->Mpad);
+      if (rc) return rc;
+      MMG_HIP(ctx, hipMemsetAsync(p->pr.q, 0, g->Mpad * sizeof(unsigned long long), ctx->stream));
+      rc = run_scan_quad(ctx, g, p->pm, p->pr.q);
+      if (rc) return rc;
+      launch_scan_finalize(ctx, g, p->pm, p->pr, 1.0, 1, 0.0);            // den = s'A's, dot = s.v, sum = s.1
+      launch_perm_center(ctx, g, p->pr, p->c0, p->dmu, p->dinv);         // mu, 1/(s~'A's~)   (:1159)
+    }
+    MMG_HIP(ctx, hipGetLastError());
+    int rc = run_perm_q(ctx, g, p->Wq, p->dstep, p->dcsum, p->P, p->dinv, p->dmu, p->dmax);
+    if (rc) return rc;
+  }
+  if (reduce)   // per-permutation maxima of this rank's SNP block stay in HBM: RCCL MAX over xGMI (exact, order independent)
+    MMG_NCCL(ctx, ncclAllReduce(p->dmax, p->dmax, (size_t)p->Ppad, ncclDouble, ncclMax, comm->comm, ctx->stream));
+  std::vector<double> mx((size_t)p->Ppad, 0.0);
+  MMG_HIP(ctx, hipMemcpyAsync(mx.data(), p->dmax, p->Ppad * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < p->P; ++k) min_rss[k] = std::min(p->h0_rss, p->yy[k] - mx[k]);   // :1164 running min from h0_rss (:1156)
+  return MMG_OK;
+}
+
 int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const double* Ys, int32_t P, double h0_rss,
                    int ndigits, double* min_rss) {
   return mmg_emmax_perm_sharded(ctx, nullptr, g, N, Ht, Ys, P, h0_rss, ndigits, min_rss);
@@ -1280,136 +1413,27 @@ int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const
 
 int mmg_emmax_perm_sharded(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int32_t N, const double* Ht, const double* Ys,
                            int32_t P, double h0_rss, int ndigits, double* min_rss) {
-  Scratch sc;
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g && Ht && Ys && min_rss && P > 0 && N == g->N);
   MMG_CHECK_ARG(ctx, ndigits == 0 || ndigits == 4);
-  std::vector<double> yy((size_t)P, 0.0);
-  for (int i = 0; i < N; ++i)
-    for (int p = 0; p < P; ++p) yy[p] += Ys[(size_t)i * P + p] * Ys[(size_t)i * P + p];
-  const bool reduce = comm && comm->world > 1;
-  if (g->M == 0 && !reduce) {
-    for (int p = 0; p < P; ++p) min_rss[p] = h0_rss;
-    return MMG_OK;
-  }
-  double *dH = nullptr, *dYs = nullptr, *dA = nullptr, *dWt = nullptr, *dv = nullptr, *dones = nullptr;
-  double *dmu = nullptr, *dinv = nullptr, *dmax = nullptr;
-  const int Ppad = (int)round_up(P, 64);
-  MMG_HIP(ctx, sc.alloc(&dH, (size_t)N * N * sizeof(double)));
-  MMG_HIP(ctx, sc.alloc(&dYs, (size_t)N * P * sizeof(double)));
-  MMG_HIP(ctx, sc.alloc(&dA, (size_t)N * N * sizeof(double)));
-  MMG_HIP(ctx, sc.alloc(&dWt, (size_t)P * N * sizeof(double)));
-  MMG_HIP(ctx, sc.alloc(&dv, N * sizeof(double)));
-  MMG_HIP(ctx, sc.alloc(&dones, N * sizeof(double)));
-  MMG_HIP(ctx, sc.alloc(&dmu, g->Mpad * sizeof(double)));
-  MMG_HIP(ctx, sc.alloc(&dinv, g->Mpad * sizeof(double)));
-  MMG_HIP(ctx, sc.alloc(&dmax, Ppad * sizeof(double)));
-  MMG_HIP(ctx, hipMemcpyAsync(dH, Ht, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  MMG_HIP(ctx, hipMemcpyAsync(dYs, Ys, (size_t)N * P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  std::vector<double> ones((size_t)N, 1.0);
-  MMG_HIP(ctx, hipMemcpyAsync(dones, ones.data(), N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  int rc = dgemm_dev(ctx, 1, 0, N, N, N, dH, dH, dA);               // A' = H'H         (t.t = s~' A' s~, :1160,1163)
-  if (rc == MMG_OK) rc = dgemm_dev(ctx, 1, 0, P, N, N, dYs, dH, dWt);  // W' = Ys'H  [P x N] (t.Ys_p = s~ . W_p)
-  if (rc == MMG_OK) rc = dgemm_dev(ctx, 0, 0, N, 1, N, dA, dones, dv); // v = A' 1
-  std::vector<double> v((size_t)N);
-  if (rc == MMG_OK) {
-    hipError_t e = hipMemcpyAsync(v.data(), dv, N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e));
-  }
-  mmg_scan_model pm;
-  mmg_scan_result pr;
-  if (g->M == 0) {                                        // a rank without SNPs still joins the reduction
-    hipError_t e0 = hipMemsetAsync(dmax, 0, Ppad * sizeof(double), ctx->stream);
-    if (e0 != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e0));
-  }
-  if (rc == MMG_OK && g->M > 0) rc = model_from_device(ctx, pm, N, dA, dv, 4);
-  if (rc == MMG_OK && g->M > 0) rc = ensure_result(ctx, pr, g->Mpad);
-  if (rc == MMG_OK && g->M > 0) {
-    double c0 = 0.0;
-    for (int i = 0; i < N; ++i) c0 += v[i];
-    hipMemsetAsync(pr.q, 0, g->Mpad * sizeof(unsigned long long), ctx->stream);
-    rc = run_scan_quad(ctx, g, pm, pr.q);
-    launch_scan_finalize(ctx, g, pm, pr, 1.0, 1, 0.0);              // den = s'A's, dot = s.v, sum = s.1
-    launch_perm_center(ctx, g, pr, c0, dmu, dinv);                  // mu, 1/(s~'A's~)   (:1159)
-    rc = run_perm(ctx, g, N, dWt, P, dinv, dmu, 4, dmax);
-  }
-  if (rc == MMG_OK && reduce) {
-    // per-permutation maxima of this rank's SNP block stay in HBM: RCCL MAX over xGMI (exact, order independent)
-    ncclResult_t r = ncclAllReduce(dmax, dmax, (size_t)Ppad, ncclDouble, ncclMax, comm->comm, ctx->stream);
-    if (r != ncclSuccess) rc = set_err(ctx, MMG_E_LIB, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
-  }
-  std::vector<double> mx((size_t)Ppad, 0.0);
-  if (rc == MMG_OK) {
-    hipError_t e = hipMemcpyAsync(mx.data(), dmax, Ppad * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e));
-  }
-  if (rc == MMG_OK)
-    for (int p = 0; p < P; ++p) min_rss[p] = std::min(h0_rss, yy[p] - mx[p]);   // :1164 running min from h0_rss (:1156)
-  hipStreamSynchronize(ctx->stream);
-  free_model(pm); free_result(pr);
+  mmg_perm_plan* plan = nullptr;
+  int rc = mmg_perm_plan_create(ctx, N, Ht, Ys, P, h0_rss, &plan);
+  if (rc) return rc;
+  rc = mmg_perm_plan_run(ctx, comm, plan, g, nullptr, 0, min_rss);
+  mmg_perm_plan_destroy(ctx, plan);
   return rc;
 }
 
-
 int mmg_emmax_perm_after_scan(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int32_t N, const double* Ht, const double* Ys,
                               int32_t P, double h0_rss, const double* HtQ, int32_t q, double* min_rss) {
-  Scratch sc;
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g && Ht && Ys && HtQ && min_rss && P > 0 && q >= 1 && N == g->N);
-  if (ctx->res.geno != g || ctx->res.geno_version != g->version || ctx->res.M != g->M || ctx->model.N != N)
-    return set_err(ctx, MMG_E_STATE, "mmg_emmax_perm_after_scan: the last mmg_emmax_scan_device of this context was not "
-                                     "over this genotype store in its current state");
-  std::vector<double> yy((size_t)P, 0.0);
-  for (int i = 0; i < N; ++i)
-    for (int p = 0; p < P; ++p) yy[p] += Ys[(size_t)i * P + p] * Ys[(size_t)i * P + p];
-  const bool reduce = comm && comm->world > 1;
-  const int Ppad = (int)round_up(P, 64);
-  const int Npad = g->Npad;
-  double *dH = nullptr, *dYs = nullptr, *dWt = nullptr, *dones = nullptr, *dh1 = nullptr, *dvecs = nullptr;
-  double *ddots = nullptr, *dmu = nullptr, *dinv = nullptr, *dmax = nullptr;
-  MMG_HIP(ctx, sc.alloc(&dmax, Ppad * sizeof(double)));
-  MMG_HIP(ctx, hipMemsetAsync(dmax, 0, Ppad * sizeof(double), ctx->stream));
-  int rc = MMG_OK;
-  if (g->M > 0) {
-    MMG_HIP(ctx, sc.alloc(&dH, (size_t)N * N * sizeof(double)));
-    MMG_HIP(ctx, sc.alloc(&dYs, (size_t)N * P * sizeof(double)));
-    MMG_HIP(ctx, sc.alloc(&dWt, (size_t)P * N * sizeof(double)));
-    MMG_HIP(ctx, sc.alloc(&dones, N * sizeof(double)));
-    MMG_HIP(ctx, sc.alloc(&dh1, N * sizeof(double)));
-    MMG_HIP(ctx, sc.alloc(&dvecs, (size_t)(1 + q) * Npad * sizeof(double)));
-    MMG_HIP(ctx, sc.alloc(&ddots, (size_t)(1 + q) * g->Mpad * sizeof(double)));
-    MMG_HIP(ctx, sc.alloc(&dmu, g->Mpad * sizeof(double)));
-    MMG_HIP(ctx, sc.alloc(&dinv, g->Mpad * sizeof(double)));
-    MMG_HIP(ctx, hipMemcpyAsync(dH, Ht, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    MMG_HIP(ctx, hipMemcpyAsync(dYs, Ys, (size_t)N * P * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    std::vector<double> ones((size_t)N, 1.0), h1((size_t)N);
-    MMG_HIP(ctx, hipMemcpyAsync(dones, ones.data(), N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    MMG_HIP(ctx, hipMemsetAsync(dvecs, 0, (size_t)(1 + q) * Npad * sizeof(double), ctx->stream));
-    for (int c = 0; c < q; ++c)
-      MMG_HIP(ctx, hipMemcpyAsync(dvecs + (size_t)(1 + c) * Npad, HtQ + (size_t)c * N, N * sizeof(double),
-                                  hipMemcpyHostToDevice, ctx->stream));
-    rc = dgemm_dev(ctx, 1, 0, P, N, N, dYs, dH, dWt);                       // W' = Ys'H  [P x N]
-    if (rc == MMG_OK) rc = dgemm_dev(ctx, 0, 0, N, 1, N, dH, dones, dh1);   // H 1
-    if (rc == MMG_OK) rc = dgemm_dev(ctx, 1, 0, N, 1, N, dH, dh1, dvecs);   // v = H'(H 1) -> vector 0
-    if (rc) return rc;
-    MMG_HIP(ctx, hipMemcpyAsync(h1.data(), dh1, N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    double c0 = 0.0;
-    for (int i = 0; i < N; ++i) c0 += h1[i] * h1[i];                        // 1'H'H1
-    for (int k = 0; k < 1 + q; ++k) launch_snp_dot(ctx, g, dvecs + (size_t)k * Npad, ddots + (size_t)k * g->Mpad);
-    launch_perm_center_reuse(ctx, g, ctx->res.den, ddots, q, ctx->res.sum, c0, dmu, dinv);
-    MMG_HIP(ctx, hipGetLastError());
-    rc = run_perm(ctx, g, N, dWt, P, dinv, dmu, 4, dmax);
-    if (rc) return rc;
-  }
-  if (reduce) MMG_NCCL(ctx, ncclAllReduce(dmax, dmax, (size_t)Ppad, ncclDouble, ncclMax, comm->comm, ctx->stream));
-  std::vector<double> mx((size_t)Ppad, 0.0);
-  MMG_HIP(ctx, hipMemcpyAsync(mx.data(), dmax, Ppad * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (int p = 0; p < P; ++p) min_rss[p] = std::min(h0_rss, yy[p] - mx[p]);
-  return MMG_OK;
+  mmg_perm_plan* plan = nullptr;
+  int rc = mmg_perm_plan_create(ctx, N, Ht, Ys, P, h0_rss, &plan);
+  if (rc) return rc;
+  rc = mmg_perm_plan_run(ctx, comm, plan, g, HtQ, q, min_rss);
+  mmg_perm_plan_destroy(ctx, plan);
+  return rc;
 }
 
 // ------------------------------------------------------------------------- eigen-rotated store, multi-phenotype scan

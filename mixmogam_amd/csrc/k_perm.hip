@@ -204,16 +204,25 @@ int run_perm(mmg_ctx* ctx, const mmg_geno* g, int32_t N, const double* dWt, int3
   const int Npad = g->Npad;
   const int nPT = (P + PERM_TILE - 1) / PERM_TILE;
   const int Ppad = nPT * PERM_TILE;
-  const int nSb = (int)(g->Mpad / TN);
   Scratch sc;
   double *dstep = nullptr, *dcsum = nullptr;
   int8_t* Wq = nullptr;
   MMG_HIP(ctx, sc.alloc(&dstep, Ppad * sizeof(double)));
   MMG_HIP(ctx, sc.alloc(&dcsum, Ppad * sizeof(double)));
   MMG_HIP(ctx, sc.alloc(&Wq, (size_t)nPT * TM * Npad));
-  MMG_HIP(ctx, hipMemsetAsync(d_maxstat, 0, Ppad * sizeof(double), ctx->stream));
   int rcq = quantize_rows_4digits(ctx, dWt, N, Npad, P, Wq, dstep, dcsum);
   if (rcq) return rcq;
+  return run_perm_q(ctx, g, Wq, dstep, dcsum, P, d_inv, d_mu, d_maxstat);
+}
+
+// the GEMM + max-reduce over a digit image of W prepared once (mmg_perm_plan): Wq [ceil(P/64)][256][Npad]
+int run_perm_q(mmg_ctx* ctx, const mmg_geno* g, const int8_t* Wq, const double* dstep, const double* dcsum, int32_t P,
+               const double* d_inv, const double* d_mu, double* d_maxstat) {
+  const int Npad = g->Npad;
+  const int nPT = (P + PERM_TILE - 1) / PERM_TILE;
+  const int Ppad = nPT * PERM_TILE;
+  const int nSb = (int)(g->Mpad / TN);
+  MMG_HIP(ctx, hipMemsetAsync(d_maxstat, 0, Ppad * sizeof(double), ctx->stream));
   // grid: permutation tiles x SNP-block chunks, ~4 workgroups per CU in flight over the launch
   const int rounds = (nPT + 7) / 8;
   int nch = std::max(1, (4 * 256) / (8 * rounds));

@@ -180,6 +180,8 @@ void launch_perm_center_reuse(mmg_ctx*, const mmg_geno*, const double* den, cons
 int run_perm(mmg_ctx*, const mmg_geno*, int32_t N, const double* dWt, int32_t P, const double* d_inv,
              const double* d_mu, int ndigits, double* d_maxstat);
 
+int run_perm_q(mmg_ctx*, const mmg_geno*, const int8_t* Wq, const double* dstep, const double* dcsum, int32_t P,
+               const double* d_inv, const double* d_mu, double* d_maxstat);
 int quantize_rows_4digits(mmg_ctx*, const double* dWt, int32_t N, int32_t Npad, int32_t P, int8_t* Wq, double* dstep,
                           double* dcsum);
 

@@ -297,16 +297,14 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
         lmm_p.add_random_effect(k)
         pp = lmm_p.perm_prepare(res['H_sqrt_inv'], num_perm=num_perm, perm_idx=perm_idx)
         min_rss = np.full(num_perm, pp['h0_rss'])
+        plan_p = ctx.perm_plan(pp['H'], pp['Ys'], pp['h0_rss'])          # operand images of the test, once for all chunks
     for ci, chrom, g in _resident_chunks(ctx, genot_data, plan, rank, world, prefetch, reuse=True):
         parts[ci] = ctx.scan(g, prep['h0_rss'], prep['n_p'])['ps']       # :174 _emmax_f_test_(emma_num=0)
         # :294-311,330 -- the permutation test runs on every chromosome but the LAST (`chr12_snps`); here chunk by
         # chunk right behind the scan of the same chunk, whose quadratic forms it reuses (same H; t.t needs only
         # 1 + q dot products per SNP on top of them)
         if num_perm and chrom != chroms[-1]:
-            if fast_perm and isinstance(ctx, _lib.Context):
-                mr = ctx.perm(g, pp['H'], pp['Ys'], pp['h0_rss'], after_scan_HtQ=prep['HtQ'])
-            else:
-                mr = ctx.perm(g, pp['H'], pp['Ys'], pp['h0_rss'])
+            mr = plan_p.run(g, after_scan_HtQ=prep['HtQ'] if (fast_perm and isinstance(ctx, _lib.Context)) else None)
             min_rss = np.minimum(min_rss, mr)
         g.close()
     if coll is not None and world > 1:
@@ -320,6 +318,7 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
         d['ps'] = np.concatenate(d['ps'])
         d['positions'] = np.concatenate(d['positions'])
     if num_perm:                                                         # :339-347
+        plan_p.close()
         if coll is not None and world > 1:
             min_rss = coll.allreduce(min_rss, "min")
         max_f = (pp['h0_rss'] / min_rss - 1.0) * pp['n_p']               # linear_models.py:1171

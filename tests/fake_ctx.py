@@ -164,6 +164,17 @@ class FakeContext(object):
     def f_sf(self, F, df2):
         return stats.f.sf(np.asarray(F, dtype=np.float64), 1, df2)
 
+    def perm_plan(self, H, Ys, h0_rss):
+        ctx = self
+
+        class _Plan(object):
+            def run(self, g, comm=None, after_scan_HtQ=None):
+                return ctx.perm(g, H, Ys, h0_rss, comm=comm)
+
+            def close(self):
+                pass
+        return _Plan()
+
     def rot(self, evecs_rows, M_cap):
         return FakeRot(np.asarray(evecs_rows, dtype=np.float64))
 

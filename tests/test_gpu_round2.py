@@ -521,3 +521,34 @@ def test_indefinite_kinship_falls_back_to_the_eigen_route(ctx):
     ok = np.isfinite(b["ps"])
     assert np.array_equal(np.isfinite(a["ps"]), ok)
     assert rel(a["ps"][ok], b["ps"][ok]) < 1e-6
+
+
+def test_perm_plan_equals_the_one_shot_test(ctx):
+    """mmg_perm_plan_*: the SNP-independent half prepared once, run over several stores -- the same bits as the one-shot
+    entry points, stand-alone and after a scan."""
+    from mixmogam_amd import linear_models as lm
+    case = load_case("struct_n300_s2")
+    lmm = lm.LinearMixedModel(list(case["y"]), ctx=ctx)
+    lmm.add_random_effect(case["dbl_ibs_scaled"])
+    H = np.asarray(case["dbl_perm_H"])
+    prep = lmm.scan_prepare(H)
+    lmm_p = lm.LinearMixedModel(list(case["y"]), ctx=ctx)
+    pp = lmm_p.perm_prepare(H, perm_idx=case["dbl_perm_idx"])
+    plan = ctx.perm_plan(pp["H"], pp["Ys"], pp["h0_rss"])
+    ga, gb = ctx.geno(case["snps"][:1700]), ctx.geno(case["snps"][1700:])
+    for g in (ga, gb):
+        assert np.array_equal(plan.run(g), ctx.perm(g, pp["H"], pp["Ys"], pp["h0_rss"]))
+    ctx.scan_set_model(prep["A"], prep["w"], 0)
+    for g in (ga, gb):
+        ctx.scan(g, prep["h0_rss"], prep["n_p"], fetch=False)
+        a = plan.run(g, after_scan_HtQ=prep["HtQ"])
+        ctx.scan(g, prep["h0_rss"], prep["n_p"], fetch=False)
+        assert np.array_equal(a, ctx.perm(g, pp["H"], pp["Ys"], pp["h0_rss"], after_scan_HtQ=prep["HtQ"]))
+    both = np.minimum(plan.run(ga), plan.run(gb))
+    gall = ctx.geno(case["snps"])
+    assert np.array_equal(both, plan.run(gall))
+    max_f = (pp["h0_rss"] / both - 1.0) * pp["n_p"]
+    assert rel(max_f, case["dbl_perm_max_f_stats"]) < 1e-6
+    plan.close()
+    for g in (ga, gb, gall):
+        g.close()
