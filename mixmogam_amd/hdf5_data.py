@@ -371,3 +371,74 @@ def run_emmax_perm(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinshi
     return run_emmax(hdf5_filename, out_file, min_maf=min_maf, chunk_size=chunk_size, k=k, ctx=ctx, coll=coll,
                      num_perm=num_perm, perm_idx=perm_idx, phenotypes=phenotypes, prefetch=prefetch,
                      fast_perm=fast_perm)
+
+
+def run_emmax_multi(hdf5_filename, out_file=None, phenotypes=None, min_maf=0.1, chunk_size=50000, k=None, ctx=None,
+                    coll=None, prefetch=True):
+    """Several phenotypes over one streamed genotype file: what a user of the reference gets by calling run_emmax
+    (:70-187) once per phenotype, computed in ONE pass over the SNPs after the kinship -- per chunk the SNPs are
+    rotated into the eigenbasis of K (mmg_rot_load) and every phenotype, with its own delta and null model, is an
+    HBM-bound pass over the rotated chunk (mmg_emmax_scan_multi; linear_models.emmax_multi is the in-memory form).
+    phenotypes: [P x N] (default: the file's indiv_data/phenotypes, 1-D or 2-D).  Multi-GPU: chunks round-robin,
+    owned blocks all-gathered per phenotype.  Result file: the scalars of run_emmax as length-P arrays and
+    chrom_results/<chrom>/{ps [P x M_c], positions}.  N must be within the eigensolver's range (N <= 46,340)."""
+    ctx = ctx or _lib.get_context()
+    ih5f = None
+    if isinstance(hdf5_filename, str):
+        ih5f = chunkstore.open_container(hdf5_filename, 'r')
+        genot_data = ih5f['genot_data']
+        if phenotypes is None:
+            phenotypes = ih5f['indiv_data']['phenotypes'][...]
+    else:
+        genot_data = hdf5_filename
+    ys = np.atleast_2d(np.asarray(phenotypes, dtype=np.float64))
+    P, n = ys.shape
+    rank, world = (coll.rank, coll.world) if coll is not None else (0, 1)
+    plan = _chunk_plan(genot_data, min_maf, chunk_size)
+    if k is None:
+        k, n_snps = _ibd_kinship(ctx, genot_data, n, plan, coll, prefetch)
+    else:
+        n_snps = sum(len(sel) for _c, sel, _p in plan)
+    lmm0 = lm.LinearMixedModel(ys[0], ctx=ctx)
+    lmm0.add_random_effect(k)
+    eig_L = lmm0._get_eigen_L_()
+    models, d, omega, G = lm._multi_models(ys, lmm0.X, eig_L)
+    h0 = np.array([m['h0_rss'] for m in models])
+    n_p = n - (lmm0.X.shape[1] + 1)
+    cap = max([len(sel) for _c, sel, _p in plan] or [1])
+    rot = ctx.rot(eig_L['vectors'], cap)
+    parts = {}
+    try:
+        for ci, chrom, g in _resident_chunks(ctx, genot_data, plan, rank, world, prefetch, reuse=True):
+            rot.load(g)
+            parts[ci] = ctx.scan_multi(rot, d, omega, G, h0, n_p, want=("ps",))["ps"]      # [P x rows]
+            g.close()
+    finally:
+        rot.close()
+    if coll is not None and world > 1:
+        gathered = [_gather_owned({ci: v[p] for ci, v in parts.items()}, plan, coll) for p in range(P)]
+        parts = {ci: np.vstack([gathered[p][ci] for p in range(P)]) for ci in range(len(plan))}
+    out = {'num_snps': n_snps, 'kinship': k, 'chrom_results': {}}
+    for key in ('pseudo_heritability', 've', 'vg', 'max_ll', 'delta'):
+        out[key] = np.array([m[key] for m in models])
+    for ci, (chrom, _sel, pos) in enumerate(plan):
+        dct = out['chrom_results'].setdefault(chrom, {'ps': [], 'positions': []})
+        dct['ps'].append(parts[ci])
+        dct['positions'].append(pos)
+    for chrom in genot_data.keys():
+        dct = out['chrom_results'].setdefault(chrom, {'ps': [np.zeros((P, 0))], 'positions': [np.zeros(0, dtype=np.int64)]})
+        dct['ps'] = np.concatenate(dct['ps'], axis=1)
+        dct['positions'] = np.concatenate(dct['positions'])
+    if out_file is not None and rank == 0:
+        oh5f = chunkstore.open_container(out_file, 'a')
+        for key in ('pseudo_heritability', 've', 'vg', 'max_ll'):
+            oh5f.create_dataset(key, data=out[key])
+        oh5f.create_dataset('num_snps', data=np.array(n_snps))
+        crg = oh5f.create_group('chrom_results')
+        for chrom, dct in out['chrom_results'].items():
+            gq = crg.create_group(str(chrom))
+            gq.create_dataset('ps', data=dct['ps'])
+            gq.create_dataset('positions', data=dct['positions'])
+        oh5f.flush()
+        oh5f.close()
+    return out

@@ -86,6 +86,12 @@ for c in solo["chrom_results"]:
         src, y, min_maf=0.05, chunk_size=200, ctx=ctx, k=solo["kinship"])["chrom_results"][c]["ps"])
 bk = hdf5_data.run_emmax(src, y, min_maf=0.05, chunk_size=200, ctx=ctx, coll=coll)
 assert np.max(np.abs(bk["kinship"] - solo["kinship"])) < 1e-9
+# streamed multi-phenotype driver: chunks round-robin, owned [P x rows] blocks gathered per phenotype
+m_solo = hdf5_data.run_emmax_multi(src, None, phenotypes=ys[:3], min_maf=0.05, chunk_size=200, ctx=ctx, k=solo["kinship"])
+m_both = hdf5_data.run_emmax_multi(src, None, phenotypes=ys[:3], min_maf=0.05, chunk_size=200, ctx=ctx, k=solo["kinship"],
+                                   coll=coll)
+for c in m_solo["chrom_results"]:
+    assert np.array_equal(m_both["chrom_results"][c]["ps"], m_solo["chrom_results"][c]["ps"])
 # eigendecomposition-free REML: the grid values of delta dealt out to the ranks, sums all-gathered over RCCL
 lmm_a = lm.LinearMixedModel(y, ctx=ctx); lmm_a.add_random_effect(K)
 lmm_b = lm.LinearMixedModel(y, ctx=ctx); lmm_b.add_random_effect(K)

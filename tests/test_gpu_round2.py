@@ -552,3 +552,22 @@ def test_perm_plan_equals_the_one_shot_test(ctx):
     plan.close()
     for g in (ga, gb, gall):
         g.close()
+
+
+def test_run_emmax_multi_streamed_vs_per_phenotype(ctx, tmp_path):
+    """hdf5_data.run_emmax_multi over an on-disk container (chunks rotated into the eigenbasis and scanned for all
+    phenotypes in one pass, double-buffered ingest) == hdf5_data.run_emmax once per phenotype (the reference's shape)."""
+    from mixmogam_amd import hdf5_data, simulations
+    path = simulations.write_synthetic_container(str(tmp_path / "in.mmg"), 300, 3000, chunk_rows=500, num_chroms=3,
+                                                 num_causals=10)
+    src = hdf5_data.open_hdf5(path)
+    rng = np.random.RandomState(5)
+    raw1 = np.asarray(src["genot_data"]["chrom_2"]["raw_snps"][...])
+    ys = np.vstack([src["phenotypes"], rng.randn(300) + 1.5 * raw1[11], rng.randn(300) + raw1[5] - raw1[70]])
+    out = hdf5_data.run_emmax_multi(path, str(tmp_path / "multi.mmg"), phenotypes=ys, min_maf=0.1, chunk_size=700, ctx=ctx)
+    assert len(set(np.round(out["delta"], 9))) == 3
+    for p in range(3):
+        one = hdf5_data.run_emmax(path, None, phenotypes=ys[p], min_maf=0.1, chunk_size=700, k=out["kinship"], ctx=ctx)
+        assert rel(out["pseudo_heritability"][p], one["pseudo_heritability"]) < 1e-8
+        for c in one["chrom_results"]:
+            assert rel(out["chrom_results"][c]["ps"][p], one["chrom_results"][c]["ps"]) < 1e-6

@@ -252,3 +252,23 @@ def test_run_emmax_over_a_never_resident_source(ctx):
     assert a["num_snps"] == b["num_snps"] == 900
     for c in mem:
         assert rel(a["chrom_results"][c]["ps"], b["chrom_results"][c]["ps"]) < 1e-9
+
+
+def test_run_emmax_multi_equals_run_emmax_per_phenotype(ctx, tmp_path):
+    """hdf5_data.run_emmax_multi (one pass over the chunks for all phenotypes) == run_emmax once per phenotype."""
+    from mixmogam_amd import chunkstore, simulations
+    path = simulations.write_synthetic_container(str(tmp_path / "in.mmg"), 60, 500, chunk_rows=128, num_chroms=2,
+                                                 num_causals=5)
+    src = hdf5_data.open_hdf5(path)
+    rng = np.random.RandomState(3)
+    raw1 = np.asarray(src["genot_data"]["chrom_1"]["raw_snps"][...])
+    ys = np.vstack([src["phenotypes"], rng.randn(60) + 2 * raw1[7], rng.randn(60)])
+    out = hdf5_data.run_emmax_multi(path, str(tmp_path / "multi.mmg"), phenotypes=ys, min_maf=0.1, chunk_size=100, ctx=ctx)
+    o = chunkstore.open_container(str(tmp_path / "multi.mmg"), "r")
+    for p in range(3):
+        one = hdf5_data.run_emmax(path, None, phenotypes=ys[p], min_maf=0.1, chunk_size=100, k=out["kinship"], ctx=ctx)
+        assert rel(out["pseudo_heritability"][p], one["pseudo_heritability"]) < 1e-9
+        for c in one["chrom_results"]:
+            assert rel(out["chrom_results"][c]["ps"][p], one["chrom_results"][c]["ps"]) < 1e-7
+            assert np.array_equal(o["chrom_results"][c]["ps"][...][p], out["chrom_results"][c]["ps"][p])
+    assert o["pseudo_heritability"][...].shape == (3,)
