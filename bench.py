@@ -131,7 +131,7 @@ def main():
         grm = {"wall_ms": 1e3 * (time.time() - t0), "digit_plane_gemms_ms": ctx.kernel_ms("grm"),
                "pack_ms": ctx.kernel_ms("pack"),
                "note": "mmg_kin_acc_add_grm: z z' = a^2 s s' + ab(s 1' + 1 s') + b^2 1 1', the weighted Gram matrix as 4 "
-                       "exact int8-MFMA GEMMs (kinship_i8_kernel, digit image x plain image); compare kinship_f32_kernel"}
+                       "exact int8-MFMA GEMMs (kinship_i8_w4_kernel, digit image x plain image); compare kinship_f32_kernel"}
         acc.close()
     K = kinship.scale_k(counts.astype(np.float64) / (2.0 * Mtot) + 0.5)
 
@@ -286,7 +286,7 @@ def bench_scan(args, ctx, coll, comm_h, g, lmm, est, prep, N, M, Mtot, D, barrie
                             "hbm_gbps": (M * (Npad + 56.0)) / (np.mean(fin_ms) * 1e-3) / 1e9},
         # second headline metric: kinship GEMM TFLOP/s vs MFMA peak, one record per kernel
         "roofline_kinship": {"f32": kin_roof("kinship_f32_kernel", kin_f32_ms, F32_MFMA_PEAK_TFLOPS, "TFLOP/s"),
-                             "i8": kin_roof("kinship_i8_kernel", kin_i8_ms, I8_MFMA_PEAK_TOPS, "TOP/s", kin_i8_pack_ms)},
+                             "i8": kin_roof("kinship_i8_w4_kernel", kin_i8_ms, I8_MFMA_PEAK_TOPS, "TOP/s", kin_i8_pack_ms)},
         "adaptive_scan": scan_stats, "all_planes_reference": all_planes, "min_p": float(np.nanmin(ps)),
     })
     if world == 1 and not args.no_extras:
@@ -513,7 +513,7 @@ def bench_perm(args, ctx, coll, comm_h, g, lmm, est, N, M, Mtot, barrier, common
                                        "RCCL MAX all-reduce of the P statistics in HBM inside the timed region; the "
                                        "SNP-independent operand images (mmg_perm_plan_create) are setup"
                                        % (N, Mtot, P), "snps_per_gpu": M, "parallelism": "snp-block x%d" % common["n_gpus"]},
-                "roofline": {"bound": "mfma", "kernel": "perm_gemm_kernel", "ms": per_rank[0],
+                "roofline": {"bound": "mfma", "kernel": "perm_gemm_w4_kernel", "ms": per_rank[0],
                              "achieved": 2.0 * N * P * M / (per_rank[0] * 1e-3) / 1e12, "peak": I8_MFMA_PEAK_TOPS,
                              "unit": "TFLOP/s", "frac": 2.0 * N * P * M / (per_rank[0] * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
                              "executed_int8_tops": ex / (per_rank[0] * 1e-3) / 1e12,

@@ -10,7 +10,10 @@
 //                        fixed order (deterministic).
 // Only upper-triangular tiles (I <= J) are computed.
 #include <algorithm>
+#include <cstdlib>
+#include <string>
 #include "gemm_i8_core.h"
+#include "gemm_i8_w4s.h"
 #include "mmg_internal.h"
 
 namespace mmg {
@@ -48,6 +51,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void kinship_i8_kernel(const int8_t* _
         atomicAdd(C32 + (int64_t)row * Npad + col, acc[m][n][i]);
       }
     }
+}
+
+// The same job on the 4-wave pipeline of gemm_i8_w4s.h (one job per workgroup: a K-split slice of one tile).
+__global__ __launch_bounds__(W4_THREADS) void kinship_i8_w4_kernel(const int8_t* __restrict__ Xp,
+                                                                   const int8_t* __restrict__ Xq, int64_t Mk,
+                                                                   int32_t Npad, const KinJob* __restrict__ jobs,
+                                                                   int* __restrict__ C32) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const KinJob job = jobs[xcd_job_index(blockIdx.x)];
+  if (job.ks1 <= job.ks0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;
+  // (a K-step-major image [Mk / 128][Npad][128] -- 32 KB contiguous per stage instead of 256 rows 1 MB apart -- was
+  // timed with this kernel in round 2: no difference, the row-major image stays)
+  const int8_t* P = Xp + (int64_t)job.I * TM * Mk + (int64_t)job.ks0 * BK;
+  const int8_t* Q = Xq + (int64_t)job.J * TN * Mk + (int64_t)job.ks0 * BK;
+  const int nks = job.ks1 - job.ks0;
+  w4s_stream(
+      0, 1, Mk, Mk, lds, [&](int) { return W4Job{P, Q, nks}; }, [](int) {},
+      [&](int, v16i (&acc)[4][4]) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            const int col = job.J * TN + wn * 128 + n * 32 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int row = job.I * TM + wm * 128 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+              atomicAdd(C32 + (int64_t)row * Npad + col, acc[m][n][i]);
+            }
+          }
+      });
 }
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -164,6 +199,25 @@ __global__ void mirror_i32_kernel(const int* __restrict__ C32, int32_t Npad, int
   C[gid] = (int64_t)C32[(int64_t)a * Npad + b];
 }
 
+// IBS counts from the Gram matrix of the RAW genotypes: sum_m (2 s_i - 1)(2 s_j - 1) = 4 (S'S)_ij - 2 (r_i + r_j) + M,
+// r = column sums of S, M = SNPs (exact integers).
+__global__ void mirror_ibs_kernel(const int* __restrict__ C32, int32_t Npad, int32_t N, const long long* __restrict__ r,
+                                  long long Mtot, int64_t* __restrict__ C) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)N * N) return;
+  const int i = (int)(gid / N), j = (int)(gid % N);
+  int a = i, b = j;
+  if ((i / TM) > (j / TN)) { a = j; b = i; }
+  C[gid] = 4 * (int64_t)C32[(int64_t)a * Npad + b] - 2 * (r[i] + r[j]) + Mtot;
+}
+
+void launch_mirror_ibs(mmg_ctx* ctx, const int* C32, int32_t Npad, int32_t N, const long long* r, long long Mtot,
+                       int64_t* C) {
+  const int64_t total = (int64_t)N * N;
+  hipLaunchKernelGGL(mirror_ibs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, C32, Npad, N, r,
+                     Mtot, C);
+}
+
 void launch_reduce_slabs(mmg_ctx* ctx, const float* slabs, int ksplit, int32_t Npad, int32_t N, double* C,
                          int accumulate) {
   const int64_t total = (int64_t)N * N;
@@ -248,11 +302,18 @@ int run_kinship_i8_pq(mmg_ctx* ctx, const int8_t* Xp, const int8_t* Xq, int32_t 
   KinJob* djobs = nullptr;
   MMG_HIP(ctx, hipMalloc(&djobs, jobs.size() * sizeof(KinJob)));
   MMG_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(KinJob), hipMemcpyHostToDevice, ctx->stream));
-  MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_i8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  // MMG_KIN_KERNEL=w8: the first-generation 8-wave kernel (A/B runs; same bits)
+  static const bool w8 = [] { const char* e = std::getenv("MMG_KIN_KERNEL"); return e && std::string(e) == "w8"; }();
+  const void* fn = w8 ? (const void*)kinship_i8_kernel : (const void*)kinship_i8_w4_kernel;
+  MMG_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   {
     EvScope ev(ctx, EV_KIN);
-    hipLaunchKernelGGL(kinship_i8_kernel, dim3((unsigned)jobs.size()), dim3(NTHREADS), LDS_BYTES, ctx->stream, Xp, Xq,
-                       Mk, Npad, djobs, C32);
+    if (w8)
+      hipLaunchKernelGGL(kinship_i8_kernel, dim3((unsigned)jobs.size()), dim3(NTHREADS), LDS_BYTES, ctx->stream, Xp, Xq,
+                         Mk, Npad, djobs, C32);
+    else
+      hipLaunchKernelGGL(kinship_i8_w4_kernel, dim3((unsigned)jobs.size()), dim3(W4_THREADS), LDS_BYTES, ctx->stream, Xp,
+                         Xq, Mk, Npad, djobs, C32);
   }
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));

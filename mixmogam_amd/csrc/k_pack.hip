@@ -211,6 +211,38 @@ void launch_transpose(mmg_ctx* ctx, const mmg_geno* g, int8_t* Xt, int64_t Mk, i
                      mul, add, m_begin, thr);
 }
 
+// Column sums of the store, r[i] += sum over rows [0, M) of S[m][i] (exact, 64-bit atomics): the rank-1 terms of the
+// IBS kinship written on the raw 0/1 genotypes (api.hip:kinship_counts_i8).  One thread per 16-byte column chunk and
+// slab of rows.
+__global__ __launch_bounds__(256) void colsum_kernel(const int8_t* __restrict__ S, int64_t M, int32_t Npad,
+                                                     int64_t rows_per_slab, unsigned long long* __restrict__ r) {
+  const int nchunk = Npad >> 4;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (int)(gid % nchunk);
+  const int64_t m0 = (gid / nchunk) * rows_per_slab, m1 = min(M, m0 + rows_per_slab);
+  if (m0 >= m1) return;
+  int acc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0;
+  for (int64_t m = m0; m < m1; ++m) {
+    const uint4 v = *(const uint4*)(S + m * (int64_t)Npad + c * 16);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] += (int)(int8_t)((w[e >> 2] >> (8 * (e & 3))) & 0xff);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+    if (acc[e]) atomicAdd(r + c * 16 + e, (unsigned long long)(long long)acc[e]);
+}
+
+void launch_colsum(mmg_ctx* ctx, const mmg_geno* g, unsigned long long* r) {
+  const int64_t rows_per_slab = 1024;                    // |sum| <= 1024 * 127 per thread: int32 partials
+  const int64_t slabs = (g->M + rows_per_slab - 1) / rows_per_slab;
+  const int64_t total = slabs * (g->Npad >> 4);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, g->d, g->M, g->Npad,
+                     rows_per_slab, r);
+}
+
 // one wave per SNP: exact integer sum and sum of squares -> mean, population std
 __global__ __launch_bounds__(256) void snp_stats_kernel(const int8_t* __restrict__ S, int64_t M, int32_t N,
                                                         int32_t Npad, double* __restrict__ mean,

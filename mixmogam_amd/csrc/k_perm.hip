@@ -10,7 +10,11 @@
 // 1/tt_m and max-reduced over SNPs without ever leaving the chip; one 64-bit atomicMax per
 // (permutation, workgroup) at the end (order independent -> reproducible).
 #include <algorithm>
+#include <cstdlib>
+#include <string>
+#include <vector>
 #include "gemm_i8_core.h"
+#include "gemm_i8_w4s.h"
 #include "mmg_internal.h"
 
 namespace mmg {
@@ -180,6 +184,85 @@ __global__ __launch_bounds__(NTHREADS, 2) void perm_gemm_kernel(
   }
 }
 
+// The same GEMM + max-reduce on the 4-wave job stream of gemm_i8_w4s.h (wave tile 128 x 128: the four digit rows
+// of 32 permutations x 128 SNPs; the SNP blocks of the workgroup's chunk are the jobs of ONE pipeline, so the
+// prefetch never drains between blocks).  Bit-identical to perm_gemm_kernel: the integers are exact and the
+// maximum is order independent.
+template <bool FAST>
+__global__ __launch_bounds__(W4_THREADS) void perm_gemm_w4_kernel(
+    const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Wq, int64_t ldW, int nPT,
+    const int2* __restrict__ groups, int nch, int sb_per_chunk, int nks, const double* __restrict__ step,
+    const double* __restrict__ csum, const double* __restrict__ mu, const double* __restrict__ inv,
+    unsigned long long* __restrict__ maxstat) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  int pt, chunk;
+  if (!w4_group_place(groups, blockIdx.x, nPT, nch, pt, chunk)) return;
+  const int sb0 = chunk * sb_per_chunk;
+  const int sb1 = min(sb0 + sb_per_chunk, nSb);
+  if (sb0 >= sb1) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;
+  double* ex = (double*)(lds + LDS_BYTES);
+  if (threadIdx.x < PERM_TILE) {
+    ex[threadIdx.x] = step[pt * PERM_TILE + threadIdx.x];
+    ex[PERM_TILE + threadIdx.x] = csum[pt * PERM_TILE + threadIdx.x];
+  }
+  __syncthreads();
+  const int8_t* P = Wq + (int64_t)pt * TM * ldW;
+  double maxv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) maxv[e] = 0.0;
+  double u[4], iv[4];
+  w4s_stream(
+      sb0, sb1, ldW, ldS, lds,
+      [&](int sb) { return W4Job{P, S + (int64_t)sb * TN * ldS, nks}; },
+      [&](int sb) {
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) {
+          const int64_t snp = (int64_t)sb * TN + wn * 128 + nn * 32 + r;
+          u[nn] = mu[snp];
+          iv[nn] = inv[snp];
+        }
+      },
+      [&](int, v16i (&acc)[4][4]) {
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int pl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const double gd = digits4_to_f64<FAST>(acc[0][nn][e], acc[1][nn][e], acc[2][nn][e], acc[3][nn][e]);
+            const double G = fma(gd, ex[pl], -u[nn] * ex[PERM_TILE + pl]);
+            maxv[e] = fmax(maxv[e], G * G * iv[nn]);
+          }
+        }
+      });
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    double v = maxv[e];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    if (r == 0) {
+      const int p = pt * PERM_TILE + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      atomicMax(maxstat + p, (unsigned long long)__double_as_longlong(v));
+    }
+  }
+}
+
+int upload_group_table(mmg_ctx* ctx, const std::vector<int2>& tab) {
+  if (tab.size() > ctx->grp_cap) {
+    if (ctx->grp_tab) MMG_HIP(ctx, hipFree(ctx->grp_tab));
+    ctx->grp_tab = nullptr;
+    ctx->grp_cap = 0;
+    MMG_HIP(ctx, hipMalloc(&ctx->grp_tab, 2 * tab.size() * sizeof(int2)));
+    ctx->grp_cap = 2 * tab.size();
+  }
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));       // an earlier upload may still read grp_host
+  ctx->grp_host = tab;
+  MMG_HIP(ctx, hipMemcpyAsync(ctx->grp_tab, ctx->grp_host.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice,
+                              ctx->stream));
+  return MMG_OK;
+}
+
 // Rows of Wt [P x N] (device fp64) -> four balanced base-256 digits per row with a per-row step, in the operand
 // layout of the 256-row P tile (64 rows x 4 digits per tile; see perm_quantize_kernel).  Wq: [ceil(P/64)][256][Npad],
 // dstep / dcsum: [ceil(P/64)*64] (zero beyond P).  Shared with the eigen-rotation GEMM (k_rot.hip).
@@ -229,13 +312,35 @@ int run_perm_q(mmg_ctx* ctx, const mmg_geno* g, const int8_t* Wq, const double* 
   nch = std::min(nch, nSb);
   const int per = (nSb + nch - 1) / nch;
   nch = (nSb + per - 1) / per;
-  MMG_HIP(ctx, hipFuncSetAttribute((const void*)perm_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   LDS_BYTES + PERM_LDS_EXTRA));
-  {
+  // MMG_PERM_KERNEL=w8: the first-generation 8-wave kernel (A/B runs; same bits)
+  static const bool w8 = [] { const char* e = std::getenv("MMG_PERM_KERNEL"); return e && std::string(e) == "w8"; }();
+  if (w8) {
+    MMG_HIP(ctx, hipFuncSetAttribute((const void*)perm_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     LDS_BYTES + PERM_LDS_EXTRA));
     EvScope ev(ctx, EV_PERM);
     hipLaunchKernelGGL(perm_gemm_kernel, dim3((unsigned)(8 * rounds * nch)), dim3(NTHREADS), LDS_BYTES + PERM_LDS_EXTRA,
                        ctx->stream, g->d, (int64_t)Npad, nSb, Wq, (int64_t)Npad, nPT, nch, per, Npad / BK, dstep, dcsum,
                        d_mu, d_inv, (unsigned long long*)d_maxstat);
+  } else {
+    // groups of 2 permutation tiles x 16 SNP chunks per XCD (gemm_i8_w4s.h: w4_group_table)
+    int GV = 2;
+    if (const char* e = std::getenv("MMG_PERM_GV")) GV = std::max(1, std::min(32, std::atoi(e)));
+    int nch4 = std::min(nSb, std::max(32, (4 * 256) / (8 * rounds) / 32 * 32));
+    const int per4 = (nSb + nch4 - 1) / nch4;
+    nch4 = (nSb + per4 - 1) / per4;
+    const std::vector<int2> tab = w4_group_table(rounds, nch4, GV);
+    int rct = upload_group_table(ctx, tab);
+    if (rct) return rct;
+    const bool fast = w4_digits_fast(g->smax, Npad) && !std::getenv("MMG_W4_SLOW_EPI");
+    const void* fn = fast ? (const void*)perm_gemm_w4_kernel<true> : (const void*)perm_gemm_w4_kernel<false>;
+    MMG_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + PERM_LDS_EXTRA));
+    EvScope ev(ctx, EV_PERM);
+#define MMG_LAUNCH_PERM_W4(F)                                                                                          \
+  hipLaunchKernelGGL(perm_gemm_w4_kernel<F>, dim3((unsigned)(256 * tab.size())), dim3(W4_THREADS),                     \
+                     LDS_BYTES + PERM_LDS_EXTRA, ctx->stream, g->d, (int64_t)Npad, nSb, Wq, (int64_t)Npad, nPT,        \
+                     ctx->grp_tab, nch4, per4, Npad / BK, dstep, dcsum, d_mu, d_inv, (unsigned long long*)d_maxstat)
+    if (fast) MMG_LAUNCH_PERM_W4(true); else MMG_LAUNCH_PERM_W4(false);
+#undef MMG_LAUNCH_PERM_W4
   }
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -25,7 +25,10 @@
 #include <algorithm>
 #include <cstdlib>
 #include "f_sf.h"
+#include <string>
+#include <vector>
 #include "gemm_i8_core.h"
+#include "gemm_i8_w4s.h"
 #include "mmg_internal.h"
 
 namespace mmg {
@@ -68,6 +71,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void rot_gemm_kernel(
   }
 }
 
+// The rotation on the 4-wave job stream of gemm_i8_w4s.h (wave tile: 4 digits x 32 eigenvectors x 128 SNPs; the SNP
+// blocks of the workgroup's chunk are the jobs of one pipeline).  Same integers, same stores as rot_gemm_kernel.
+template <bool FAST>
+__global__ __launch_bounds__(W4_THREADS) void rot_gemm_w4_kernel(
+    const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Vq, int64_t ldV, int nVT,
+    const int2* __restrict__ groups, int nch, int sb_per_chunk, int nks, const double* __restrict__ step,
+    double* __restrict__ T, int64_t nrows) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  int vt, chunk;
+  if (!w4_group_place(groups, blockIdx.x, nVT, nch, vt, chunk)) return;
+  const int sb0 = chunk * sb_per_chunk;
+  const int sb1 = min(sb0 + sb_per_chunk, nSb);
+  if (sb0 >= sb1) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;
+  double* ex = (double*)(lds + LDS_BYTES);
+  if (threadIdx.x < ROT_TILE) ex[threadIdx.x] = step[vt * ROT_TILE + threadIdx.x];
+  __syncthreads();
+  const int8_t* P = Vq + (int64_t)vt * TM * ldV;
+  w4s_stream(
+      sb0, sb1, ldV, ldS, lds, [&](int sb) { return W4Job{P, S + (int64_t)sb * TN * ldS, nks}; }, [](int) {},
+      [&](int sb, v16i (&acc)[4][4]) {
+        double* Tb = T + (int64_t)sb * nrows * TN;
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) {
+          const int snp = wn * 128 + nn * 32 + r;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int pl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            Tb[(int64_t)(vt * ROT_TILE + pl) * TN + snp] =
+                digits4_to_f64<FAST>(acc[0][nn][e], acc[1][nn][e], acc[2][nn][e], acc[3][nn][e]) * ex[pl];
+          }
+        }
+      });
+}
+
 int run_rotate(mmg_ctx* ctx, const mmg_geno* g, const int8_t* Vq, const double* dstep, int nVT, double* T) {
   const int nSb = (int)(g->Mpad / TN);
   if (nSb == 0 || nVT == 0) return MMG_OK;
@@ -76,13 +115,35 @@ int run_rotate(mmg_ctx* ctx, const mmg_geno* g, const int8_t* Vq, const double* 
   nch = std::min(nch, nSb);
   const int per = (nSb + nch - 1) / nch;
   nch = (nSb + per - 1) / per;
-  MMG_HIP(ctx, hipFuncSetAttribute((const void*)rot_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   LDS_BYTES + ROT_TILE * 8));
-  {
+  // MMG_ROT_KERNEL=w8: the first-generation 8-wave kernel (A/B runs; same bits)
+  static const bool w8 = [] { const char* e = std::getenv("MMG_ROT_KERNEL"); return e && std::string(e) == "w8"; }();
+  if (w8) {
+    MMG_HIP(ctx, hipFuncSetAttribute((const void*)rot_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     LDS_BYTES + ROT_TILE * 8));
     EvScope ev(ctx, EV_ROT);
     hipLaunchKernelGGL(rot_gemm_kernel, dim3((unsigned)(8 * rounds * nch)), dim3(NTHREADS), LDS_BYTES + ROT_TILE * 8,
                        ctx->stream, g->d, (int64_t)g->Npad, nSb, Vq, (int64_t)g->Npad, nVT, nch, per, g->Npad / BK,
                        dstep, T, (int64_t)nVT * ROT_TILE);
+  } else {
+    // groups of 4 eigen tiles x 8 SNP chunks per XCD (gemm_i8_w4s.h: w4_group_table)
+    int GV = 4;
+    if (const char* e = std::getenv("MMG_ROT_GV")) GV = std::max(1, std::min(32, std::atoi(e)));
+    int nch4 = std::min(nSb, std::max(32, (16 * 256) / (8 * rounds) / 32 * 32));
+    const int per4 = (nSb + nch4 - 1) / nch4;
+    nch4 = (nSb + per4 - 1) / per4;
+    const std::vector<int2> tab = w4_group_table(rounds, nch4, GV);
+    int rct = upload_group_table(ctx, tab);
+    if (rct) return rct;
+    const bool fast = w4_digits_fast(g->smax, g->Npad) && !std::getenv("MMG_W4_SLOW_EPI");
+    const void* fn = fast ? (const void*)rot_gemm_w4_kernel<true> : (const void*)rot_gemm_w4_kernel<false>;
+    MMG_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + ROT_TILE * 8));
+    EvScope ev(ctx, EV_ROT);
+#define MMG_LAUNCH_ROT_W4(F)                                                                                           \
+  hipLaunchKernelGGL(rot_gemm_w4_kernel<F>, dim3((unsigned)(256 * tab.size())), dim3(W4_THREADS),                      \
+                     LDS_BYTES + ROT_TILE * 8, ctx->stream, g->d, (int64_t)g->Npad, nSb, Vq, (int64_t)g->Npad, nVT,    \
+                     ctx->grp_tab, nch4, per4, g->Npad / BK, dstep, T, (int64_t)nVT * ROT_TILE)
+    if (fast) MMG_LAUNCH_ROT_W4(true); else MMG_LAUNCH_ROT_W4(false);
+#undef MMG_LAUNCH_ROT_W4
   }
   MMG_HIP(ctx, hipGetLastError());
   return MMG_OK;

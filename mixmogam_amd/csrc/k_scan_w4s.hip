@@ -39,28 +39,10 @@
 #include <string>
 #include <vector>
 #include "gemm_i8_core.h"
-#include "gemm_i8_w4.h"
+#include "gemm_i8_w4s.h"
 #include "mmg_internal.h"
 
 namespace mmg {
-
-struct Frag4 {
-  v4i a[4], b[4];
-};
-
-__device__ __forceinline__ v16i mfma8(v4i a, v4i b, v16i c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
-
-// interleave hint for one slice: (MFMA, ds_read, MFMA, [DMA]) x 8
-template <int NDMA>
-__device__ __forceinline__ void sched_slice() {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    if (i < NDMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-  }
-}
 
 // MMG_W4S_PIN=1 (A/B builds, `make DEFS=-DMMG_W4S_PIN=1`): every (MFMA, read, MFMA, read/DMA) group ends in a full
 // scheduling barrier and the slice in front of the step's barrier issues its eight fragment reads in the first four
@@ -72,12 +54,6 @@ __device__ __forceinline__ void sched_slice() {
 #define MMG_W4S_PIN 0
 #endif
 constexpr bool PIN_SLICES = MMG_W4S_PIN != 0;
-
-// Fragments are fetched in the order a0 b0 a1 b1 a2 b2 a3 b3 (one per two MFMAs) and the MFMAs of the next
-// slice consume them in the order of their arrival (ORD), so every fragment has at least 12 MFMA slots
-// (~400 cycles) between its ds_read and its first use.
-__device__ constexpr int ORD_M[16] = {0, 1, 0, 1, 2, 2, 0, 1, 2, 3, 3, 3, 0, 1, 2, 3};
-__device__ constexpr int ORD_N[16] = {0, 0, 1, 1, 0, 1, 2, 2, 2, 0, 1, 2, 3, 3, 3, 3};
 
 // One slice: 16 MFMA on `cur`; fragment reads of (slot `src`, chunk) into `nxt`; DMA pieces [P0, P1) of the
 // cursor's stage (pieces 0-7: P rows, 8-15: Q rows of this wave) into slot `dst`.

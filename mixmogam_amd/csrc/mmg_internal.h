@@ -81,6 +81,9 @@ struct mmg_ctx {
   bool deliver_pending = false;
   double multi_ms_total = 0.0;  // summed pass time of the last mmg_emmax_scan_multi
   double grm_ms_total = 0.0;    // summed digit-plane GEMM time of the last mmg_kin_acc_add_grm
+  int2* grp_tab = nullptr;      // workgroup-group table of the perm / rotation GEMM launches (gemm_i8_w4s.h)
+  size_t grp_cap = 0;
+  std::vector<int2> grp_host;   // host image of grp_tab (source of the asynchronous upload: must outlive it)
 };
 
 namespace mmg {
@@ -182,6 +185,9 @@ int run_perm(mmg_ctx*, const mmg_geno*, int32_t N, const double* dWt, int32_t P,
 
 int run_perm_q(mmg_ctx*, const mmg_geno*, const int8_t* Wq, const double* dstep, const double* dcsum, int32_t P,
                const double* d_inv, const double* d_mu, double* d_maxstat);
+void launch_colsum(mmg_ctx*, const mmg_geno*, unsigned long long* r);          // r[Npad] += column sums of the store
+void launch_mirror_ibs(mmg_ctx*, const int* C32, int32_t Npad, int32_t N, const long long* r, long long Mtot, int64_t* C);
+int upload_group_table(mmg_ctx*, const std::vector<int2>& tab);   // k_perm.hip; into ctx->grp_tab
 int quantize_rows_4digits(mmg_ctx*, const double* dWt, int32_t N, int32_t Npad, int32_t P, int8_t* Wq, double* dstep,
                           double* dcsum);
 
