@@ -126,9 +126,12 @@ def main():
     if not args.no_f32_kinship and world == 1 and mode == "weak":
         # the GRM through the exact int8 route (the chunked drivers' kinship): per-SNP weights 1/std^2 as int8 digits
         acc = ctx.kinship_accumulator(N)
-        t0 = time.time()
-        acc.add_grm(g)
-        grm = {"wall_ms": 1e3 * (time.time() - t0), "digit_plane_gemms_ms": ctx.kernel_ms("grm"),
+        wall = []
+        for _ in range(3):                                   # the first call allocates the accumulator's workspace
+            t0 = time.time()
+            acc.add_grm(g)
+            wall.append(1e3 * (time.time() - t0))
+        grm = {"wall_ms": min(wall[1:]), "first_call_wall_ms": wall[0], "digit_plane_gemms_ms": ctx.kernel_ms("grm"),
                "pack_ms": ctx.kernel_ms("pack"),
                "note": "mmg_kin_acc_add_grm: z z' = a^2 s s' + ab(s 1' + 1 s') + b^2 1 1', the weighted Gram matrix as 4 "
                        "exact int8-MFMA GEMMs (kinship_i8_w4_kernel, digit image x plain image); compare kinship_f32_kernel"}
