@@ -413,6 +413,30 @@ def ingest_record(ctx, g, prep, n_p, N, M, ms_per_step):
                     "the current scan and the p-values of every chunk fetched"}
 
 
+FP64_PEAK_TFLOPS = 78.6      # MI355X_MICROARCH.md: fp64 vector = fp64 matrix (the two share the DP units)
+
+
+def multi_roofline(N, M, q, batch, pass_ms):
+    """Roofline of one pass of scan_multi over the rotated store: HBM (T is read once per pass, 8 N M bytes) against
+    fp64 (2 + q fused multiply-adds per element and phenotype of the batch); the binding one is reported as `bound`."""
+    hbm = 8.0 * N * M / (pass_ms * 1e-3) / 1e9
+    tf = 2.0 * (2 + q) * batch * N * M / (pass_ms * 1e-3) / 1e12
+    f_hbm, f_fp = hbm / HBM_PEAK_GBPS, tf / FP64_PEAK_TFLOPS
+    common = {"kernel": "scan_multi_mfma_kernel" if batch >= 8 else "scan_multi_kernel", "ms": pass_ms,
+              "phenotypes_per_pass": batch, "algorithmic_bytes": 8.0 * N * M,
+              "algorithmic_flop": 2.0 * (2 + q) * batch * N * M,
+              "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": f_hbm},
+              "fp64": {"achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f_fp,
+                       "note": "sustained fp64 on this part, measured with tools/probe/fp64_rate.hip: 61-69 TFLOP/s on "
+                               "the VALU, 36-48 on v_mfma_f64_16x16x4_f64, no more with both (shared units)"},
+              "traffic": None}
+    if f_fp >= f_hbm:
+        common.update({"bound": "fp64", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f_fp})
+    else:
+        common.update({"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": f_hbm})
+    return common
+
+
 def multi_record(ctx, g, lmm, N, M, P=16):
     """Multi-phenotype scans over the eigen-rotated store (mmg_rot_* / mmg_emmax_scan_multi), 16 random phenotypes."""
     from mixmogam_amd import linear_models as lm
@@ -435,14 +459,13 @@ def multi_record(ctx, g, lmm, N, M, P=16):
     wall = time.time() - t0
     ms = ctx.kernel_ms("scan_multi")
     rot.close()
-    npass = -(-P // 8)
-    return {"phenotypes": P, "rotation_gemm_ms": rot_ms,
+    from mixmogam_amd._lib import scan_multi_batch
+    npass = -(-P // scan_multi_batch())
+    return {"phenotypes": P, "phenotypes_per_pass": scan_multi_batch(), "rotation_gemm_ms": rot_ms,
             "rotation_executed_int8_tops": 2.0 * 4 * (-(-N // 256) * 256) * (-(-N // 64) * 64) * M / (rot_ms * 1e-3) / 1e12,
             "pass_ms": ms / npass, "passes": npass, "ms_per_phenotype_scan": ms / P,
             "value_snp_phenotype_scans_per_s": M * P / (wall), "value_kernels_only": M * P / (ms * 1e-3),
-            "roofline": {"bound": "hbm", "kernel": "scan_multi_kernel", "achieved": 8.0 * N * M / (ms / npass * 1e-3) / 1e9,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 8.0 * N * M / (ms / npass * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                         "algorithmic_bytes": 8.0 * N * M},
+            "roofline": multi_roofline(N, M, 1, min(P, scan_multi_batch()), ms / npass),
             "host_model_ms_per_phenotype": 1e3 * t_models / P}
 
 
@@ -544,13 +567,14 @@ def bench_multi(args, ctx, coll, g, lmm, eig_L, N, M, Mtot, barrier, common):
     rot.load(g)
     rot_ms = ctx.kernel_ms("rotate")
     h0 = np.array([m["h0_rss"] for m in models])
+    pinned = {"ps": ctx.pinned_empty(P * M)}                 # results land in page-locked memory, reused by every step
     for _ in range(args.warmup):
-        ctx.scan_multi(rot, d, omega, G, h0, N - 2, want=("ps",))
+        ctx.scan_multi(rot, d, omega, G, h0, N - 2, want=("ps",), out=pinned)
     ms = []
     barrier()
     t0 = time.time()
     for _ in range(args.steps):
-        out = ctx.scan_multi(rot, d, omega, G, h0, N - 2, want=("ps",))   # P x M p-values on this rank's host
+        out = ctx.scan_multi(rot, d, omega, G, h0, N - 2, want=("ps",), out=pinned)   # P x M p-values on this rank's host
         ms.append(ctx.kernel_ms("scan_multi"))
     barrier()
     elapsed = time.time() - t0
@@ -559,17 +583,16 @@ def bench_multi(args, ctx, coll, g, lmm, eig_L, N, M, Mtot, barrier, common):
     rot.close()
     if (coll.rank if coll is not None else 0) != 0:
         return None
-    npass = -(-P // 8)
+    from mixmogam_amd._lib import scan_multi_batch
+    npass = -(-P // scan_multi_batch())
     pass_ms = float(np.mean(ms)) / npass
     res = dict(common)
     res.update({"metric": "SNP x phenotype EMMAX scans/sec over the eigen-rotated store",
                 "value": float(Mtot) * P * args.steps / elapsed, "unit": "SNP-phenotype scans/s",
                 "ms_per_step": 1e3 * elapsed / args.steps, "scaling": "weak", "dtype": "f64",
-                "config": {"workload": "N=%d x M=%d SNPs per GPU, %d phenotypes with their own delta, 8 per pass" % (N, M, P),
+                "config": {"workload": "N=%d x M=%d SNPs per GPU, %d phenotypes with their own delta, %d per pass" % (N, M, P, scan_multi_batch()),
                            "parallelism": "snp-block x%d" % common["n_gpus"]},
-                "roofline": {"bound": "hbm", "kernel": "scan_multi_kernel", "achieved": 8.0 * N * M / (pass_ms * 1e-3) / 1e9,
-                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": 8.0 * N * M / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                             "algorithmic_bytes": 8.0 * N * M, "ms": pass_ms, "traffic": None},
+                "roofline": multi_roofline(N, M, 1, min(P, scan_multi_batch()), pass_ms),
                 "rotation_gemm_ms": rot_ms, "host_model_ms_per_phenotype": 1e3 * t_models / P,
                 "min_p": float(out["ps"].min())})
     return res

@@ -387,6 +387,14 @@ class Reml(object):
             pass
 
 
+def scan_multi_batch(q=1):
+    """Phenotypes per HBM pass of mmg_emmax_scan_multi (api.hip): 16 on the fp64 matrix pipe for q <= 2 fixed-effect
+    columns, else 8 (also with MMG_MULTI_KERNEL=valu / MMG_MULTI_PB=8, A/B runs)."""
+    if os.environ.get("MMG_MULTI_KERNEL") == "valu" or os.environ.get("MMG_MULTI_PB") == "8" or q > 2:
+        return 8
+    return 16
+
+
 class Context(object):
     """One HIP device context (stream, scan model, result buffers)."""
 
@@ -520,9 +528,11 @@ class Context(object):
     def perm_plan(self, H, Ys, h0_rss):
         return PermPlan(self, H, Ys, h0_rss)
 
-    def scan_multi(self, rot, d, omega, G, h0_rss, df2, want=("rss", "f_stats", "ps")):
+    def scan_multi(self, rot, d, omega, G, h0_rss, df2, want=("rss", "f_stats", "ps"), out=None):
         """P phenotypes over the rotated store: d, omega [P x N], G [P x q x N], h0_rss [P] -> {'rss','f_stats','ps'}
-        each [P x M] (mmg_emmax_scan_multi)."""
+        each [P x M] (mmg_emmax_scan_multi).  out: {'ps': array, ...} -- C-contiguous float64 buffers with at least
+        P * M elements to receive the results (page-locked ones from pinned_empty() arrive at PCIe rate, and the
+        download of one batch then hides behind the next batch's pass; reuse them across calls)."""
         d = _arr(d, np.float64)
         omega = _arr(omega, np.float64)
         G = _arr(G, np.float64)
@@ -530,7 +540,16 @@ class Context(object):
         P, N = d.shape
         assert omega.shape == (P, N) and G.ndim == 3 and G.shape[0] == P and G.shape[2] == N and len(h0) == P
         q = G.shape[1]
-        outs = {k: (np.empty((P, rot.M)) if k in want else None) for k in ("rss", "f_stats", "ps")}
+        outs = {}
+        for k in ("rss", "f_stats", "ps"):
+            if k not in want:
+                outs[k] = None
+            elif out is not None and out.get(k) is not None:
+                buf = out[k]
+                assert buf.dtype == np.float64 and buf.flags.c_contiguous and buf.size >= P * rot.M
+                outs[k] = buf.reshape(-1)[:P * rot.M].reshape(P, rot.M)
+            else:
+                outs[k] = np.empty((P, rot.M))
         self._check(self.lib.mmg_emmax_scan_multi(self.h, rot.h, P, q, _ptr(d), _ptr(omega), _ptr(G), _ptr(h0), int(df2),
                                                   _ptr(outs["rss"]), _ptr(outs["f_stats"]), _ptr(outs["ps"])))
         return {k: v for k, v in outs.items() if v is not None}

@@ -1536,45 +1536,82 @@ int mmg_emmax_scan_multi(mmg_ctx* ctx, mmg_rot* r, int32_t P, int32_t q, const d
   const int N = r->N;
   ctx->multi_ms_total = 0.0;
   const int64_t ldOut = round_up(M, 256);
-  const int PBmax = 8, NCmax = PBmax * (2 + q);
-  double *dcoef = nullptr, *dh0 = nullptr, *dout[3] = {nullptr, nullptr, nullptr};
+  // 16 phenotypes per pass with the linear columns on the fp64 matrix pipe (k_rot.hip:scan_multi_mfma_kernel), 8 with
+  // the all-VALU kernel (MMG_MULTI_KERNEL=valu, MMG_MULTI_PB=8)
+  int PBmax = q <= 2 ? 16 : 8;
+  if (const char* e = std::getenv("MMG_MULTI_KERNEL")) if (std::string(e) == "valu") PBmax = 8;
+  if (const char* e = std::getenv("MMG_MULTI_PB")) if (std::atoi(e) == 8) PBmax = 8;
+  const int NCmax = PBmax * (2 + q);
+  // Two sets of coefficient / output buffers: the download of a batch's results (second stream; a blocking copy when
+  // the caller's arrays are pageable) runs while the next batch's pass is on the device.
+  double *dcoef[2] = {nullptr, nullptr}, *dh0[2] = {nullptr, nullptr}, *dout[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   double* host[3] = {rss, F, p};
-  MMG_HIP(ctx, sc.alloc(&dcoef, (size_t)N * NCmax * sizeof(double)));
-  MMG_HIP(ctx, sc.alloc(&dh0, PBmax * sizeof(double)));
-  for (int k = 0; k < 3; ++k)
-    if (host[k]) MMG_HIP(ctx, sc.alloc(&dout[k], (size_t)PBmax * ldOut * sizeof(double)));
-  std::vector<double> coef((size_t)N * NCmax), h0b(PBmax);
+  const int nbatch = (P + PBmax - 1) / PBmax;
+  const int nset = nbatch > 1 ? 2 : 1;
+  for (int sI = 0; sI < nset; ++sI) {
+    MMG_HIP(ctx, sc.alloc(&dcoef[sI], (size_t)N * NCmax * sizeof(double)));
+    MMG_HIP(ctx, sc.alloc(&dh0[sI], PBmax * sizeof(double)));
+    for (int k = 0; k < 3; ++k)
+      if (host[k]) MMG_HIP(ctx, sc.alloc(&dout[sI][k], (size_t)PBmax * ldOut * sizeof(double)));
+  }
+  std::vector<double> coef[2], h0b[2];
+  for (int sI = 0; sI < nset; ++sI) { coef[sI].resize((size_t)N * NCmax); h0b[sI].resize(PBmax); }
   const double lnb = ln_beta_half(0.5 * df2);
-  double ms_total = 0.0;
-  for (int p0 = 0; p0 < P; p0 += PBmax) {
+  struct Events {                                      // per batch: kernel start / end; per set: results downloaded
+    std::vector<hipEvent_t> k0, k1;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    ~Events() { for (auto e : k0) hipEventDestroy(e); for (auto e : k1) hipEventDestroy(e); for (auto e : done) if (e) hipEventDestroy(e); }
+  } evs;
+  evs.k0.resize(nbatch); evs.k1.resize(nbatch);
+  for (int b = 0; b < nbatch; ++b) { MMG_HIP(ctx, hipEventCreate(&evs.k0[b])); MMG_HIP(ctx, hipEventCreate(&evs.k1[b])); }
+  for (int sI = 0; sI < nset; ++sI) MMG_HIP(ctx, hipEventCreateWithFlags(&evs.done[sI], hipEventDisableTiming));
+  auto download = [&](int b) -> int {
+    const int sI = b & (nset - 1), p0 = b * PBmax, nb = std::min(PBmax, P - p0);
+    MMG_HIP(ctx, hipStreamWaitEvent(ctx->stream2, evs.k1[b], 0));
+    for (int k = 0; k < 3; ++k)
+      if (host[k])
+        MMG_HIP(ctx, hipMemcpy2DAsync(host[k] + (size_t)p0 * M, M * sizeof(double), dout[sI][k], ldOut * sizeof(double),
+                                      M * sizeof(double), nb, hipMemcpyDeviceToHost, ctx->stream2));
+    MMG_HIP(ctx, hipEventRecord(evs.done[sI], ctx->stream2));
+    return MMG_OK;
+  };
+  for (int b = 0; b < nbatch; ++b) {
+    const int sI = b & (nset - 1), p0 = b * PBmax;
     const int nb = std::min(PBmax, P - p0);
     int PB = 1;
-    while (PB < nb) PB *= 2;                         // 1, 2, 4, 8: unused columns carry zero coefficients
+    while (PB < nb) PB *= 2;                         // 1, 2, 4, 8, 16: unused columns carry zero coefficients
     const int NC = PB * (2 + q);
-    std::fill(coef.begin(), coef.begin() + (size_t)N * NC, 0.0);
-    for (int k = 0; k < PB; ++k) h0b[k] = k < nb ? h0_rss[p0 + k] : 1.0;
+    std::vector<double>& cf = coef[sI];
+    if (b >= 2) MMG_HIP(ctx, hipEventSynchronize(evs.done[sI]));   // batch b-2 has left this set's buffers (host image too)
+    std::fill(cf.begin(), cf.begin() + (size_t)N * NC, 0.0);
+    for (int k = 0; k < PB; ++k) h0b[sI][k] = k < nb ? h0_rss[p0 + k] : 1.0;
     for (int k = 0; k < nb; ++k) {
       const double* dk = d + (size_t)(p0 + k) * N;
       const double* wk = omega + (size_t)(p0 + k) * N;
       const double* gk = G + (size_t)(p0 + k) * q * N;
       for (int i = 0; i < N; ++i) {
-        double* row = coef.data() + (size_t)i * NC;
+        double* row = cf.data() + (size_t)i * NC;
         row[k] = dk[i];
         row[PB + k * (1 + q)] = wk[i];
         for (int c = 0; c < q; ++c) row[PB + k * (1 + q) + 1 + c] = gk[(size_t)c * N + i];
       }
     }
-    MMG_HIP(ctx, hipMemcpyAsync(dcoef, coef.data(), (size_t)N * NC * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    MMG_HIP(ctx, hipMemcpyAsync(dh0, h0b.data(), PB * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    int rc = run_scan_multi(ctx, r->T, (int64_t)r->nVT * 64, N, M, PB, q, dcoef, dh0, df2, lnb, dout[0], dout[1], dout[2], ldOut);
+    MMG_HIP(ctx, hipMemcpyAsync(dcoef[sI], cf.data(), (size_t)N * NC * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MMG_HIP(ctx, hipMemcpyAsync(dh0[sI], h0b[sI].data(), PB * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MMG_HIP(ctx, hipEventRecord(evs.k0[b], ctx->stream));
+    int rc = run_scan_multi(ctx, r->T, (int64_t)r->nVT * 64, N, M, PB, q, dcoef[sI], dh0[sI], df2, lnb, dout[sI][0],
+                            dout[sI][1], dout[sI][2], ldOut);
     if (rc) return rc;
-    for (int k = 0; k < 3; ++k)
-      if (host[k])
-        MMG_HIP(ctx, hipMemcpy2DAsync(host[k] + (size_t)p0 * M, M * sizeof(double), dout[k], ldOut * sizeof(double),
-                                      M * sizeof(double), nb, hipMemcpyDeviceToHost, ctx->stream));
-    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));  // coef / h0b are reused by the next batch
-    double ms = 0.0;
-    if (mmg_last_kernel_ms(ctx, EV_MULTI, &ms) == MMG_OK) ms_total += ms;
+    MMG_HIP(ctx, hipEventRecord(evs.k1[b], ctx->stream));
+    if (b >= 1) { rc = download(b - 1); if (rc) return rc; }      // overlaps the pass just queued
+  }
+  { int rc = download(nbatch - 1); if (rc) return rc; }
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double ms_total = 0.0;
+  for (int b = 0; b < nbatch; ++b) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, evs.k0[b], evs.k1[b]) == hipSuccess) ms_total += ms;
   }
   ctx->multi_ms_total = ms_total;
   return MMG_OK;

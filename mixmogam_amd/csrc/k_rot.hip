@@ -241,9 +241,196 @@ __global__ __launch_bounds__(256) void scan_multi_kernel(const double* __restric
   }
 }
 
+// ---- second generation of the pass: every column on the fp64 MATRIX pipe, operands streamed by LDS-DMA.
+// Per rotated coordinate a phenotype needs d * tau^2 (one column) and omega * tau, G_c * tau (1 + Q columns).  With
+// SGPR coefficients on the VALU (scan_multi_kernel) a batch of 8 phenotypes is VALU-bound, and the scalar loads
+// (2 + Q doubles per phenotype and coordinate) cannot be hidden at all once fewer FMAs stand behind each of them
+// (measured: the 17 VALU operations per element of a 16-phenotype quadratic part alone took 14.5 ms per pass).
+// On v_mfma_f64_16x16x4_f64 the coefficients are an operand instead: A = 16 coefficient columns x 4 coordinates
+// (lane 16 k + c: column c of coordinate i0 + k), B = tau (lane 16 k + r: coordinate i0 + k of one SNP of the wave's
+// 64; the squares for the quadratic tile are the only VALU work left, one multiply per element).  Tile 0 = the PB
+// quadratic columns against tau^2, tiles 1.. = the PB (1 + Q) linear columns against tau.
+// Both operands come through LDS: a GROUP is 4 coordinates = 2 KB of T (4 rows x 64 SNPs of this wave) + the 4
+// coefficient rows (contiguous in the table), fetched by 2 + NCI buffer_load ... lds instructions into a per-wave ring
+// of DEPTH groups.  No register is the destination of a global load, so the only vmcnt waits are the ones written
+// here (a first version with register loads and a register ring spent as long waiting as computing: the compiler
+// placed one vmcnt for all groups in flight at the top of the unrolled body, 14.7 ms = 9.4 ms MFMA + 5.3 ms exposed
+// latency).  Nothing is shared between waves: no barrier in the loop.
+// LDS image of a group: tau row k at k * 512 (SNP pair p at + 16 p), coefficient row k at 2048 + k * NC * 8.
+// Fragment reads are conflict-free: a 16-lane ds_read_b128 group reads 256 contiguous bytes of one tau row; the two
+// coefficient rows of a 32-lane ds_read_b64 group lie 384 (mod 256: 128) bytes apart for NC = 48.
+// SNP of MFMA column r in SNP group g = (h, e): 32 h + 2 r + e (the two doubles of one 16-byte read feed two groups).
+// D layout of v_mfma_f64_16x16x4_f64 (probed, tools/probe/mfma_f64_layout.hip): lane l, register r holds row
+// 4 r + l / 16, column l % 16.
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+template <int PB, int Q>
+struct MultiMfmaCfg {
+  static constexpr int NL = PB * (1 + Q), NC = PB + NL, NTL = (NL + 15) / 16, NT = 1 + NTL;
+  static constexpr int NCI = (32 * NC + 1023) / 1024;            // DMA instructions per coefficient group
+  static constexpr int GROUP_BYTES = 2048 + 1024 * NCI;
+#ifndef MMG_MULTI_DEPTH
+#define MMG_MULTI_DEPTH 4
+#endif
+  static constexpr int DEPTH = GROUP_BYTES <= 4096 ? MMG_MULTI_DEPTH : 4;      // groups in flight per wave
+  static constexpr int WAVE_BYTES = DEPTH * GROUP_BYTES;
+  static constexpr int LDS_BYTES = 4 * WAVE_BYTES > 32768 ? 4 * WAVE_BYTES : 32768;
+};
+
+template <int PB, int Q, int ABL = 0>   // ABL (timing ablations, wrong results): 1 = no MFMA, 2 = no DMA in the loop
+__global__ __launch_bounds__(256) void scan_multi_mfma_kernel(const double* __restrict__ T, int64_t nrows, int32_t N,
+                                                              int64_t M, const double* __restrict__ coef,
+                                                              const double* __restrict__ h0, double nu, double lnbeta,
+                                                              double* __restrict__ rss, double* __restrict__ Fst,
+                                                              double* __restrict__ pv, int64_t ldOut) {
+  using Cfg = MultiMfmaCfg<PB, Q>;
+  constexpr int NL = Cfg::NL, NC = Cfg::NC, NTL = Cfg::NTL, NT = Cfg::NT, NCI = Cfg::NCI, GB = Cfg::GROUP_BYTES,
+                DEPTH = Cfg::DEPTH;
+  static_assert(PB <= 16, "one quadratic tile");
+  static_assert((2 + NCI) * DEPTH < 64, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) char mlds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kq = lane >> 4, r16 = lane & 15;
+  char* ring = mlds + wave * Cfg::WAVE_BYTES;
+  // out-of-range rows (coordinates beyond nrows, coefficient rows beyond N) read as zeros: raw buffers with exact sizes
+  const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(T + (int64_t)blockIdx.x * nrows * 256), 0, (int)(nrows * 2048), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)coef, 0, N * NC * 8, 0x00020000);
+  const int vT = (lane >> 5) * 2048 + wave * 512 + (lane & 31) * 16;
+  const int vC = lane * 16;
+  auto issue = [&](int grp, int slot) {
+    char* dst = ring + slot * GB;
+#pragma unroll
+    for (int qd = 0; qd < 2; ++qd)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsT, (MMG_AS3 void*)(dst + qd * 1024), 16, vT, (4 * grp + 2 * qd) * 2048, 0, 0);
+#pragma unroll
+    for (int qd = 0; qd < NCI; ++qd)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsC, (MMG_AS3 void*)(dst + 2048 + qd * 1024), 16, vC,
+                                               4 * grp * NC * 8 + qd * 1024, 0, 0);
+  };
+  v4d acc[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[t][g] = v4d{0.0, 0.0, 0.0, 0.0};
+  double sink = 0.0;                                             // ABL 1 only
+  static_assert(DEPTH % 2 == 0, "two fragment register sets alternate over an unrolled ring turn");
+  const int NG = ((N + 3) / 4 + DEPTH - 1) / DEPTH * DEPTH;      // whole ring turns; groups beyond N are zeros
+  struct Frag { v2d tau[2]; double a[NT]; };
+  auto read_frag = [&](Frag& f, int slot) {
+    const char* src = ring + slot * GB;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) f.tau[h] = *(const v2d*)(src + kq * 512 + (r16 + 16 * h) * 16);
+    f.a[0] = *(const double*)(src + 2048 + (kq * NC + r16) * 8);
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) f.a[1 + t] = *(const double*)(src + 2048 + (kq * NC + PB + 16 * t + r16) * 8);
+  };
+  // Schedule of step s (group s; fragments one group ahead, DMA DEPTH groups ahead):
+  //   lgkmcnt(0)                        fragments of group s are in registers -> its slot is free
+  //   DMA of group s + DEPTH            into that slot
+  //   vmcnt((2 + NCI)(DEPTH - 1))       group s + 1 (issued DEPTH - 1 steps ago) has landed
+  //   fragment reads of group s + 1     (overlap the MFMAs below)
+  //   4 multiplies + 4 NT MFMAs of group s
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u) issue(u, u);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((2 + NCI) * (DEPTH - 1)) : "memory");
+  Frag fr[2];
+  read_frag(fr[0], 0);
+  for (int gi = 0; gi < NG; gi += DEPTH) {
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      Frag& cur = fr[u & 1];
+      Frag& nxt = fr[(u + 1) & 1];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (ABL != 2) {
+        issue(gi + u + DEPTH, u);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((2 + NCI) * (DEPTH - 1)) : "memory");
+      }
+      read_frag(nxt, (u + 1) % DEPTH);
+      if (ABL != 1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const double x = cur.tau[g >> 1][g & 1];
+          acc[0][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a[0], x * x, acc[0][g], 0, 0, 0);
+#pragma unroll
+          for (int t = 1; t < NT; ++t) acc[t][g] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.a[t], x, acc[t][g], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sink = fma(cur.tau[g >> 1][g & 1], cur.a[0] + cur.a[NT - 1], sink);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (ABL == 1) acc[0][0][0] = sink;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the groups issued past the end must land before the ring is reused
+  // ---- matrix-pipe layout -> lane = SNP, one 16-column tile at a time through LDS (the ring's memory)
+  double (*xl)[16][64] = (double (*)[16][64])mlds;               // [wave][column][SNP]
+  double aq[PB], al[NL];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xl[wave][4 * r + kq][32 * (g >> 1) + 2 * r16 + (g & 1)] = acc[t][g][r];
+    __syncthreads();
+    if (t == 0) {
+#pragma unroll
+      for (int c = 0; c < PB; ++c) aq[c] = xl[wave][c][lane];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (16 * (t - 1) + c < NL) al[16 * (t - 1) + c] = xl[wave][c][lane];
+    }
+  }
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+#pragma unroll
+  for (int k = 0; k < PB; ++k) {
+    double den = aq[k];
+#pragma unroll
+    for (int c = 0; c < Q; ++c) den = fma(-al[k * (1 + Q) + 1 + c], al[k * (1 + Q) + 1 + c], den);
+    const double dot = al[k * (1 + Q)];
+    const double h = h0[k];
+    double r = h;
+    if (den > 1e-7 * aq[k] && den > 0.0) r = h - dot * dot / den;      // same rule as scan_multi_kernel
+    const double F = (h / r - 1.0) * nu;
+    if (rss) rss[(int64_t)k * ldOut + m] = r;
+    if (Fst) Fst[(int64_t)k * ldOut + m] = F;
+    if (pv) pv[(int64_t)k * ldOut + m] = f_sf_1(F, nu, lnbeta);
+  }
+}
+
 template <int PB, int Q>
 static void launch_multi(mmg_ctx* ctx, const double* T, int64_t nrows, int32_t N, int64_t M, const double* coef,
                          const double* h0, int32_t df2, double lnbeta, double* rss, double* F, double* p, int64_t ldOut) {
+  // MMG_MULTI_KERNEL=valu: the first-generation kernel (all columns on the VALU); default for batches of 8 and 16:
+  // linear columns on the fp64 matrix pipe
+  static const bool valu_only = [] { const char* e = std::getenv("MMG_MULTI_KERNEL"); return e && std::string(e) == "valu"; }();
+  if constexpr (PB >= 8) if (PB == 16 || !valu_only) {
+    const int64_t nb = (M + 255) / 256;
+    int ab = 0;
+    if (const char* e = std::getenv("MMG_MULTI_ABL")) ab = std::atoi(e);
+    constexpr int LB = MultiMfmaCfg<PB, Q>::LDS_BYTES;
+#define MMG_LAUNCH_MFMA(ABL_)                                                                                         \
+  do {                                                                                                                \
+    hipFuncSetAttribute((const void*)scan_multi_mfma_kernel<PB, Q, ABL_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                        LB);                                                                                          \
+    hipLaunchKernelGGL((scan_multi_mfma_kernel<PB, Q, ABL_>), dim3((unsigned)nb), dim3(256), LB, ctx->stream, T,      \
+                       nrows, N, M, coef, h0, (double)df2, lnbeta, rss, F, p, ldOut);                                 \
+  } while (0)
+    if constexpr (Q == 1) {
+      if (ab == 1) { MMG_LAUNCH_MFMA(1); return; }
+      if (ab == 2) { MMG_LAUNCH_MFMA(2); return; }
+    }
+    MMG_LAUNCH_MFMA(0);
+#undef MMG_LAUNCH_MFMA
+    return;
+  }
+  if constexpr (PB <= 8) {
   constexpr int R = (PB * (2 + Q) <= 24) ? 2 : 1;            // accumulators: 2 R PB (2 + Q) VGPRs
   int rsel = R;
   if (const char* e = std::getenv("MMG_MULTI_R")) rsel = std::atoi(e) == 1 ? 1 : R;
@@ -262,6 +449,7 @@ static void launch_multi(mmg_ctx* ctx, const double* T, int64_t nrows, int32_t N
   else
     hipLaunchKernelGGL((scan_multi_kernel<PB, Q, 1>), dim3((unsigned)nblk), dim3(256), 0, ctx->stream, T, nrows, N, M,
                        coef, h0, (double)df2, lnbeta, rss, F, p, ldOut);
+  }
 }
 
 int run_scan_multi(mmg_ctx* ctx, const double* T, int64_t nrows, int32_t N, int64_t M, int PB, int q, const double* coef,
@@ -281,7 +469,10 @@ int run_scan_multi(mmg_ctx* ctx, const double* T, int64_t nrows, int32_t N, int6
   else if (PB == 2) MMG_MULTI_Q(2);
   else if (PB == 4) MMG_MULTI_Q(4);
   else if (PB == 8) MMG_MULTI_Q(8);
-  else return set_err(ctx, MMG_E_ARG, "multi-phenotype scan: batch must be 1, 2, 4 or 8");
+  else if (PB == 16 && q <= 2) {                              // 1 + 2 / 1 + 3 tiles; wider models go 8 at a time
+    if (q == 1) MMG_MULTI(16, 1); else MMG_MULTI(16, 2);
+  }
+  else return set_err(ctx, MMG_E_ARG, "multi-phenotype scan: batch must be 1, 2, 4, 8 or (q <= 2) 16");
 #undef MMG_MULTI_Q
 #undef MMG_MULTI
   MMG_HIP(ctx, hipGetLastError());
