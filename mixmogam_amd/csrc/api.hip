@@ -102,7 +102,7 @@ static void free_model(mmg_scan_model& m) {
 }
 static void free_result(mmg_scan_result& r) {
   hipFree(r.q); hipFree(r.rss); hipFree(r.F); hipFree(r.p); hipFree(r.dot); hipFree(r.den); hipFree(r.sum);
-  hipFree(r.dd); hipFree(r.ssq); hipFree(r.idx); hipFree(r.scal); hipFree(r.q2);
+  hipFree(r.dd); hipFree(r.ssq); hipFree(r.idx); hipFree(r.scal); hipFree(r.q2); hipFree(r.linraw);
   r = mmg_scan_result();
 }
 
@@ -201,9 +201,9 @@ int mmg_geno_create(mmg_ctx* ctx, int64_t M, int32_t N, mmg_geno** out) {
   g->Npad = (int32_t)round_up(N, 256);
   hipError_t e = hipMalloc(&g->d, (size_t)g->Mpad * g->Npad);
   if (e != hipSuccess) { delete g; return set_err(ctx, MMG_E_NOMEM, std::string("hipMalloc genotype store: ") + hipGetErrorString(e)); }
-  e = hipMalloc(&g->d_smax, sizeof(int));
+  e = hipMalloc(&g->d_smax, 2 * sizeof(int));
   if (e != hipSuccess) { hipFree(g->d); delete g; return set_err(ctx, MMG_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
-  MMG_HIP(ctx, hipMemsetAsync(g->d_smax, 0, sizeof(int), ctx->stream));
+  MMG_HIP(ctx, hipMemsetAsync(g->d_smax, 0, 2 * sizeof(int), ctx->stream));
   MMG_HIP(ctx, hipMemsetAsync(g->d, 0, (size_t)g->Mpad * g->Npad, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *out = g;
@@ -219,9 +219,9 @@ int mmg_geno_reset(mmg_ctx* ctx, mmg_geno* g, int64_t M) {
   // upload rewrites stay zero because uploads only touch the first N bytes of a row
   if (Mpad > M)
     MMG_HIP(ctx, hipMemsetAsync(g->d + M * (int64_t)g->Npad, 0, (size_t)(Mpad - M) * g->Npad, ctx->stream));
-  MMG_HIP(ctx, hipMemsetAsync(g->d_smax, 0, sizeof(int), ctx->stream));
+  MMG_HIP(ctx, hipMemsetAsync(g->d_smax, 0, 2 * sizeof(int), ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  g->M = M; g->Mpad = Mpad; g->smax = 0; g->bits_valid = false; ++g->version;
+  g->M = M; g->Mpad = Mpad; g->smax = 0; g->sneg = 0; g->bits_valid = false; ++g->version;
   return MMG_OK;
 }
 
@@ -239,10 +239,11 @@ int mmg_geno_destroy(mmg_ctx* ctx, mmg_geno* g) {
 static int refresh_smax(mmg_ctx* ctx, mmg_geno* g, int64_t m0, int64_t rows) {
   launch_absmax_i8(ctx, g->d + m0 * (int64_t)g->Npad, rows * (int64_t)g->Npad, g->d_smax);
   MMG_HIP(ctx, hipGetLastError());
-  int v = 0;
-  MMG_HIP(ctx, hipMemcpyAsync(&v, g->d_smax, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  int v[2] = {0, 0};
+  MMG_HIP(ctx, hipMemcpyAsync(v, g->d_smax, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  g->smax = std::max(g->smax, v);
+  g->smax = std::max(g->smax, v[0]);
+  g->sneg = std::max(g->sneg, v[1]);
   return MMG_OK;
 }
 
@@ -920,6 +921,42 @@ static int build_schedule(mmg_ctx* ctx, mmg_scan_model& md) {
 }
 
 // Build a scan model from a DEVICE-resident fp64 matrix dA [N x N] and device vector dw [N].
+// Rows Npad-16 .. Npad-1 of the top digit plane (padding individuals: all-zero rows of the matrix, and the genotype
+// columns they meet in the GEMM's epilogue are zero too) <- seven balanced base-256 digits of w and of diag(A) and a
+// row of ones, laid out for k_scan_w4s.hip (LIN).  52 bits relative to the largest entry, i.e. the vectors as they
+// are in double precision.  Needs 16 free rows; otherwise the scan keeps the separate finalize pass over the store.
+static int add_linear_rows(mmg_ctx* ctx, mmg_scan_model& md) {
+  md.lin_rows = false;
+  if (md.Npad - md.N < 16 || md.D < 2) return MMG_OK;
+  const int N = md.N, Npad = md.Npad;
+  std::vector<double> w((size_t)N), dg((size_t)N);
+  MMG_HIP(ctx, hipMemcpyAsync(w.data(), md.w, N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipMemcpyAsync(dg.data(), md.diag, N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double mw = 0.0, mdg = 0.0;
+  for (int i = 0; i < N; ++i) { mw = std::max(mw, std::fabs(w[i])); mdg = std::max(mdg, std::fabs(dg[i])); }
+  if (!std::isfinite(mw) || !std::isfinite(mdg)) return MMG_OK;
+  md.lin_step_w = mw > 0.0 ? mw / std::ldexp(1.0, 52) : 1.0;
+  md.lin_step_d = mdg > 0.0 ? mdg / std::ldexp(1.0, 52) : 1.0;
+  std::vector<int8_t> rows((size_t)16 * Npad, 0);
+  static const int row_w[7] = {0, 1, 2, 3, 8, 9, 10}, row_d[7] = {4, 5, 6, 7, 12, 13, 14};   // row - 240
+  for (int k = 0; k < N; ++k) {
+    long long Zw = std::llrint(w[k] / md.lin_step_w), Zd = std::llrint(dg[k] / md.lin_step_d);
+    for (int d = 0; d < 7; ++d) {
+      const long long zw = ((Zw + 128) & 255) - 128, zd = ((Zd + 128) & 255) - 128;
+      Zw = (Zw - zw) >> 8; Zd = (Zd - zd) >> 8;
+      rows[(size_t)row_w[d] * Npad + k] = (int8_t)zw;
+      rows[(size_t)row_d[d] * Npad + k] = (int8_t)zd;
+    }
+    rows[(size_t)11 * Npad + k] = 1;
+  }
+  int8_t* dst = md.Bq + (size_t)(md.D - 1) * Npad * Npad + (size_t)(Npad - 16) * Npad;
+  MMG_HIP(ctx, hipMemcpyAsync(dst, rows.data(), rows.size(), hipMemcpyHostToDevice, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  md.lin_rows = true;
+  return MMG_OK;
+}
+
 static int model_from_device(mmg_ctx* ctx, mmg_scan_model& md, int32_t N, const double* dA, const double* dw,
                              int ndigits, bool adaptive = false) {
   Scratch sc;
@@ -973,6 +1010,8 @@ static int model_from_device(mmg_ctx* ctx, mmg_scan_model& md, int32_t N, const 
         if (dev > 8.0) { md.adaptive = false; break; }
       }
   }
+  int rcl = add_linear_rows(ctx, md);
+  if (rcl) return rcl;
   return build_schedule(ctx, md);
 }
 
@@ -1019,6 +1058,7 @@ static int ensure_result(mmg_ctx* ctx, mmg_scan_result& r, int64_t Mpad) {
   MMG_HIP(ctx, hipMalloc(&r.sum, Mpad * sizeof(double)));
   MMG_HIP(ctx, hipMalloc(&r.dd, Mpad * sizeof(double)));
   MMG_HIP(ctx, hipMalloc(&r.ssq, Mpad * sizeof(double)));
+  MMG_HIP(ctx, hipMalloc(&r.linraw, Mpad * 16 * sizeof(int)));
   MMG_HIP(ctx, hipMalloc(&r.idx, Mpad * sizeof(int64_t)));
   MMG_HIP(ctx, hipMalloc(&r.scal, 4 * sizeof(unsigned long long)));
   r.cap = Mpad;
@@ -1041,13 +1081,22 @@ int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2)
   res.n_refined = 0; res.eps_max = 0.0; res.sigma_ratio_max = 0.0; res.fell_back = 0; res.adaptive = md.adaptive ? 1 : 0;
   ctx->ev_set[EV_QUAD2] = false;
   MMG_HIP(ctx, hipMemsetAsync(res.q, 0, g->Mpad * sizeof(unsigned long long), ctx->stream));
+  // by-products of the GEMM (s.w, sum A_ii s_i, sum s_i; binary stores, k_scan_w4s.hip LIN) replace the finalize
+  // pass's second sweep over the genotype store
+  const LinOut lin_out{res.linraw};
+  const bool lin = scan_lin_usable(g, md);
+  const LinOut* linp = lin ? &lin_out : nullptr;
+  auto finalize = [&](bool with_p, double bias) {
+    if (lin) launch_scan_finalize_lin(ctx, g, md, res, h0_rss, df2, lnb, with_p, bias);
+    else launch_scan_finalize(ctx, g, md, res, h0_rss, df2, lnb, with_p, bias);
+  };
   if (!md.adaptive) {
-    rc = run_scan_quad(ctx, g, md, res.q);
+    rc = run_scan_quad(ctx, g, md, res.q, EV_QUAD, linp);
     if (rc) return rc;
     MMG_HIP(ctx, hipGetLastError());
     {
       EvScope ev(ctx, EV_FIN);
-      launch_scan_finalize(ctx, g, md, res, h0_rss, df2, lnb);
+      finalize(true, 0.0);
     }
     MMG_HIP(ctx, hipGetLastError());
     MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1066,12 +1115,12 @@ int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2)
   mmg_scan_model hi = md, lo = md;                        // shallow copies with the schedule swapped
   hi.job_off = md.job_off_hi; hi.jobs = md.jobs_hi; hi.njobs = md.njobs_hi;
   lo.job_off = md.job_off_lo; lo.jobs = md.jobs_lo; lo.njobs = md.njobs_lo;
-  rc = run_scan_quad(ctx, g, hi, res.q);
+  rc = run_scan_quad(ctx, g, hi, res.q, EV_QUAD, linp);
   if (rc) return rc;
   MMG_HIP(ctx, hipGetLastError());
   {
     EvScope ev(ctx, EV_FIN);
-    launch_scan_finalize(ctx, g, md, res, h0_rss, df2, lnb, false, md.step * md.mu0);
+    finalize(false, md.step * md.mu0);
   }
   MMG_HIP(ctx, hipMemsetAsync(res.scal, 0, 4 * sizeof(unsigned long long), ctx->stream));
   launch_scan_select(ctx, res, g->M, sig_unit, target, res.scal);
@@ -1093,7 +1142,7 @@ int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2)
       res.q2_cap = ctx->sel_geno->Mpad;
     }
     mmg_geno view = *ctx->sel_geno;                        // a cpad-row window of the compact store
-    view.M = cnt; view.Mpad = cpad; view.smax = g->smax; view.bits = nullptr; view.bits_valid = false;
+    view.M = cnt; view.Mpad = cpad; view.smax = g->smax; view.sneg = g->sneg; view.bits = nullptr; view.bits_valid = false;
     launch_gather_rows(ctx, g, res.idx, cnt, view.d);
     MMG_HIP(ctx, hipMemsetAsync(res.q2, 0, cpad * sizeof(unsigned long long), ctx->stream));
     rc = run_scan_quad(ctx, &view, lo, res.q2, EV_QUAD2);
@@ -1112,7 +1161,7 @@ int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2)
       // a store view whose refined rows are skipped -- simplest exact way: subtract is impossible on atomics, so
       // zero q and redo both passes over everything
       MMG_HIP(ctx, hipMemsetAsync(res.q, 0, g->Mpad * sizeof(unsigned long long), ctx->stream));
-      rc = run_scan_quad(ctx, g, md, res.q);
+      rc = run_scan_quad(ctx, g, md, res.q, EV_QUAD, linp);
       if (rc) return rc;
     }
   } else if (all) {
@@ -1121,7 +1170,7 @@ int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2)
   }
   if (all) {
     res.fell_back = 1;
-    launch_scan_finalize(ctx, g, md, res, h0_rss, df2, lnb, false);
+    finalize(false, 0.0);
   }
   if (res.p && g->M > 0) launch_f_sf(ctx, res.F, g->M, df2, lnb, res.p);
   MMG_HIP(ctx, hipGetLastError());

@@ -279,8 +279,9 @@ void launch_snp_stats(mmg_ctx* ctx, const mmg_geno* g, double* mean, double* sd)
 }
 
 // max |s| over a 16-byte aligned range (write paths of the genotype store keep an upper bound of it)
+// out[0] = max |s|, out[1] = max(-s) (0 for a store without negative values)
 __global__ __launch_bounds__(256) void absmax_i8_kernel(const int8_t* __restrict__ p, int64_t n16, int* __restrict__ out) {
-  int mx = 0;
+  int mx = 0, ng = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
     const uint4 v = *(const uint4*)(p + i * 16);
     const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
@@ -288,11 +289,13 @@ __global__ __launch_bounds__(256) void absmax_i8_kernel(const int8_t* __restrict
     for (int j = 0; j < 16; ++j) {
       const int x = (int)(int8_t)((wds[j >> 2] >> (8 * (j & 3))) & 0xff);
       mx = max(mx, x < 0 ? -x : x);
+      ng = max(ng, -x);
     }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+  for (int o = 32; o > 0; o >>= 1) { mx = max(mx, __shfl_xor(mx, o)); ng = max(ng, __shfl_xor(ng, o)); }
   if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(out, mx);
+  if ((threadIdx.x & 63) == 0 && ng > 0) atomicMax(out + 1, ng);
 }
 
 void launch_absmax_i8(mmg_ctx* ctx, const int8_t* p, int64_t bytes, int* d_out) {

@@ -353,6 +353,51 @@ void launch_snp_dot_raw(mmg_ctx* ctx, const int8_t* S, int64_t ldS, int64_t rows
                      out);
 }
 
+// The same arithmetic from the by-products of the quadratic-form GEMM (k_scan_w4s.hip, LIN): the raw accumulators of the
+// model's linear rows, raw[m][h][i] -- h = 0: digits 0..6 of s.w (i = 0..6) and sum s (i = 7); h = 1: digits 0..6 of
+// sum_i A_ii s_i.  Binary store (sum s^2 = sum s).  72 bytes per SNP instead of Npad.  Digits 0-3 and 4-6 are combined
+// as two exact integers (below 2^52 and 2^44) and added in double precision.
+__device__ __forceinline__ double digits7_to_f64(int4 lo4, int d4, int d5, int d6) {
+  const long long lo = (long long)lo4.x + ((long long)lo4.y << 8) + ((long long)lo4.z << 16) + ((long long)lo4.w << 24);
+  const long long hi = (long long)d4 + ((long long)d5 << 8) + ((long long)d6 << 16);
+  return fma((double)hi, 4294967296.0, (double)lo);
+}
+
+__global__ void scan_finalize_lin_kernel(int64_t M, const unsigned long long* __restrict__ q, const int* __restrict__ raw,
+                                         double step, double step_w, double step_d, double bias, double h0_rss, double nu,
+                                         double* __restrict__ rss, double* __restrict__ Fst, double* __restrict__ dotv,
+                                         double* __restrict__ denv, double* __restrict__ sumv, double* __restrict__ ddv,
+                                         double* __restrict__ ssqv) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const int4* rw = (const int4*)(raw + m * 16);
+  const int4 a0 = rw[0], a1 = rw[1], b0 = rw[2], b1 = rw[3];
+  const double my_dw = digits7_to_f64(a0, a1.x, a1.y, a1.z) * step_w;
+  const double my_dd = digits7_to_f64(b0, b1.x, b1.y, b1.z) * step_d;
+  const double sm = (double)a1.w;
+  const double qd = (double)(long long)q[m];
+  const double den = fma(step, qd, my_dd) + bias * (0.5 * (sm * sm - sm));
+  const double num = my_dw * my_dw;
+  double r = h0_rss;
+  if (den > 1e-7 * my_dd && den > 0.0) r = h0_rss - num / den;
+  const double F = (h0_rss / r - 1.0) * nu;
+  if (rss) rss[m] = r;
+  if (Fst) Fst[m] = F;
+  if (dotv) dotv[m] = my_dw;
+  if (denv) denv[m] = den;
+  if (sumv) sumv[m] = sm;
+  if (ddv) ddv[m] = my_dd;
+  if (ssqv) ssqv[m] = sm;
+}
+
+void launch_scan_finalize_lin(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, mmg_scan_result& res,
+                              double h0_rss, int32_t df2, double lnbeta, bool with_p, double bias) {
+  hipLaunchKernelGGL(scan_finalize_lin_kernel, dim3((unsigned)((g->M + 255) / 256)), dim3(256), 0, ctx->stream, g->M, res.q,
+                     res.linraw, md.step, md.lin_step_w, md.lin_step_d, bias, h0_rss, (double)df2, res.rss, res.F, res.dot,
+                     res.den, res.sum, res.dd, res.ssq);
+  if (with_p && res.p && g->M > 0) launch_f_sf(ctx, res.F, g->M, df2, lnbeta, res.p);
+}
+
 void launch_scan_finalize(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, mmg_scan_result& res,
                           double h0_rss, int32_t df2, double lnbeta, bool with_p, double bias) {
   hipLaunchKernelGGL(scan_finalize_kernel, dim3((unsigned)(g->Mpad / FIN_ROWS)), dim3(256), 0, ctx->stream, g->d,

@@ -108,11 +108,26 @@ __device__ __forceinline__ void slice(v16i (&acc)[4][4], const Frag4& cur, Frag4
 // 0 / 1 of the following step; the remaining 16 - N3 - N0 - N1 go into slice 2.
 // FAST: |s| * Npad < 2^16 and s^2 * Npad < 2^18 (checked on the host from the store's tracked max |s|): every
 // accumulator fits 24 bits and a lane's 64 products per SNP fit 32 bits, so the epilogue runs on v_mad_i32_i24.
-template <int ABL, int N3, int N0, int N1, bool FAST>
+// LIN: rows 240 .. 255 of the LAST tile row of the TOP digit plane are not matrix rows but digit images of the
+// vectors of the linear terms (api.hip:add_linear_rows; the genotype columns they would multiply in this kernel's
+// own epilogue are padding individuals, i.e. zeros): seven balanced base-256 digits of w in rows 240-243, 248-250,
+// ones in row 251, seven digits of diag(A) in rows 244-247, 252-254.  Their accumulators are s.w, sum_i s_i and
+// sum_i A_ii s_i of the tile's SNPs as exact integers -- in the C layout registers 8-15 of tile m = 3 of the waves with
+// wm = 1, lanes with h = 0 (w, ones) and h = 1 (diag) -- and are written out when the job (top plane, last tile row)
+// ends: for a binary store (s^2 = s) that is everything scan_finalize_kernel reads the 5 GB genotype store a second
+// time for.
+// The kernel only drops the raw accumulators (16 ints per SNP: [h][8]) -- anything more in this epilogue and the
+// register allocator, already at 488 of 512, starts spilling; scan_finalize_lin_kernel recombines the digits.
+struct LinArgs {
+  int* raw;                     // [Mpad][16]
+  int dtop, jlast;              // the job that carries the rows
+};
+
+template <int ABL, int N3, int N0, int N1, bool FAST, bool LIN = false>
 __global__ __launch_bounds__(W4_THREADS) void scan_quad_w4s_kernel(
     const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Bq, int64_t ldB,
     int64_t digit_stride, const int* __restrict__ job_off, const int2* __restrict__ jobs, int AS,
-    unsigned long long* __restrict__ q, unsigned long long* __restrict__ dbg) {
+    unsigned long long* __restrict__ q, unsigned long long* __restrict__ dbg, LinArgs lin) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr bool LD = ABL != 2;
   unsigned long long seg[4] = {0, 0, 0, 0};              // ABL 4: cycles in {vmcnt+lgkm wait, barrier, epilogue, total}
@@ -263,6 +278,23 @@ __global__ __launch_bounds__(W4_THREADS) void scan_quad_w4s_kernel(
       }
       qacc[n] += ((unsigned long long)part) << (8 * d);
     }
+    if (LIN) {
+      // No branch here: with one, the register allocator (488 of 512 in use) spilled 230 registers.  Every wave issues
+      // the eight stores at the end of every job, through a buffer descriptor that is EMPTY unless this is the job that
+      // carries the linear rows and the wave owns rows 128-255: out-of-range buffer stores are dropped by the address
+      // unit, no memory traffic.
+      const bool hit = d == lin.dtop && jb.y == lin.jlast && wm == 1;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(lin.raw + ((int64_t)sb * TN + wn * 128) * 16), 0, hit ? 128 * 16 * 4 : 0, 0x00020000);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int off = ((n * 32 + r) * 16 + h * 8) * 4;
+        __builtin_amdgcn_raw_buffer_store_b128(
+            v4i{acc[3][n][8], acc[3][n][9], acc[3][n][10], acc[3][n][11]}, rs, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(
+            v4i{acc[3][n][12], acc[3][n][13], acc[3][n][14], acc[3][n][15]}, rs, off + 16, 0, 0);
+      }
+    }
     if (ABL == 4) {
 #pragma unroll
       for (int n = 0; n < 4; ++n) asm volatile("" : "+v"(qacc[n]));
@@ -283,7 +315,17 @@ __global__ __launch_bounds__(W4_THREADS) void scan_quad_w4s_kernel(
   }
 }
 
-void launch_scan_quad_w4s(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, unsigned long long* q) {
+bool scan_lin_usable(const mmg_geno* g, const mmg_scan_model& md) {
+  const char* e = std::getenv("MMG_SCAN_FUSED_LINEAR");     // =0: keep the separate finalize pass over the store (A/B, tests)
+  const bool off = e && e[0] == '0';
+  // (diagnostic builds: only the production kernel writes the by-products)
+  return !off && md.lin_rows && g->smax <= 1 && g->sneg == 0 && std::getenv("MMG_W4S_ABL") == nullptr &&
+         std::getenv("MMG_SCAN_KERNEL") == nullptr && std::getenv("MMG_ABLATE") == nullptr &&
+         std::getenv("MMG_W4S_DIST") == nullptr;
+}
+
+void launch_scan_quad_w4s(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, unsigned long long* q,
+                          const LinOut* lin) {
   const int nSb = (int)(g->Mpad / TN);
   const int per = 8 * md.AS;
   const int ncoh = (nSb + per - 1) / per;
@@ -299,8 +341,11 @@ void launch_scan_quad_w4s(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model&
                         LDS_BYTES);                                                                                     \
     hipLaunchKernelGGL((scan_quad_w4s_kernel<__VA_ARGS__>), dim3((unsigned)(ncoh * 256)), dim3(W4_THREADS), LDS_BYTES, \
                        ctx->stream, g->d, (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad,                               \
-                       (int64_t)md.Npad * md.Npad, md.job_off, md.jobs, md.AS, q, dbg);                                 \
+                       (int64_t)md.Npad * md.Npad, md.job_off, md.jobs, md.AS, q, dbg, la);                             \
   } while (0)
+  LinArgs la{nullptr, -1, -1};
+  const bool use_lin = lin != nullptr && lin->raw != nullptr && scan_lin_usable(g, md);
+  if (use_lin) la = LinArgs{lin->raw, md.D - 1, md.Npad / TM - 1};
   static unsigned long long* dbg = nullptr;
   if (abl == 4) {
     const size_t n = (size_t)16384 * 4 * 8;
@@ -329,12 +374,15 @@ void launch_scan_quad_w4s(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model&
   else if (abl == 6) MMG_LAUNCH_W4S(6, 8, 8, 0, true);
   else if (abl == 7) MMG_LAUNCH_W4S(7, 8, 8, 0, true);
   else if (dist == 1 && fast) MMG_LAUNCH_W4S(0, 6, 5, 5, true);
+  else if (fast && use_lin) MMG_LAUNCH_W4S(0, 8, 8, 0, true, true);
   else if (fast) MMG_LAUNCH_W4S(0, 8, 8, 0, true);
+  else if (use_lin) MMG_LAUNCH_W4S(0, 8, 8, 0, false, true);
   else MMG_LAUNCH_W4S(0, 8, 8, 0, false);
 #undef MMG_LAUNCH_W4S
 }
 
-int run_scan_quad(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, unsigned long long* q, int ev_slot) {
+int run_scan_quad(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, unsigned long long* q, int ev_slot,
+                  const LinOut* lin) {
   // Production: the 4-wave x 128x128 hand-laid pipeline above.  A library built with `make EXPERIMENTS=1`
   // (csrc/experiments/: the superseded generations q8 / w4m / w4b / bits / timed / m16 / flat / ring / pp, all
   // bit-identical) honours MMG_SCAN_KERNEL / MMG_ABLATE for A/B runs; the shipped library ignores them.
@@ -352,11 +400,11 @@ int run_scan_quad(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, unsigned 
   if (want_w4b && g->binary) launch_scan_quad_w4b(ctx, g, md, q);
   else if (want_bits && g->binary) launch_scan_quad_bits(ctx, g, md, q);
   else if (!ablate && k == "w4m") launch_scan_quad_w4m(ctx, g, md, q);
-  else if (!ablate && (k.empty() || k == "w4s" || k == "w4b" || k == "bits")) launch_scan_quad_w4s(ctx, g, md, q);
+  else if (!ablate && (k.empty() || k == "w4s" || k == "w4b" || k == "bits")) launch_scan_quad_w4s(ctx, g, md, q, lin);
   else launch_scan_quad(ctx, g, md, q);
 #else
   EvScope ev(ctx, ev_slot);
-  launch_scan_quad_w4s(ctx, g, md, q);
+  launch_scan_quad_w4s(ctx, g, md, q, lin);
 #endif
   return MMG_OK;
 }

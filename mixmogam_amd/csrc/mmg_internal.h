@@ -17,8 +17,9 @@ struct mmg_geno {
   bool bits_valid = false, binary = false;
   // upper bound of |s| over everything ever written to the store (updated by every write path); the scan uses
   // it to prove that its 32-bit epilogue cannot overflow
-  int smax = 0;
-  int* d_smax = nullptr;
+  int smax = 0;                 // running bound of max |s| over everything written to the store
+  int sneg = 0;                 // ... and of max(-s): 0 = no negative value was ever written
+  int* d_smax = nullptr;        // device pair {max |s|, max(-s)}
 };
 
 enum { EV_KIN = 0, EV_QUAD = 1, EV_FIN = 2, EV_PERM = 3, EV_EIGH = 4, EV_PACK = 5, EV_QUAD2 = 6, EV_ROT = 7, EV_MULTI = 8, EV_GRM = 9, EV_COUNT = 10 };
@@ -40,6 +41,15 @@ struct mmg_scan_model {
   int *job_off_hi = nullptr, *job_off_lo = nullptr;
   int2 *jobs_hi = nullptr, *jobs_lo = nullptr;
   int njobs_hi = 0, njobs_lo = 0;
+  // linear rows (api.hip:add_linear_rows): rows Npad-16 .. Npad-1 of the top digit plane hold digit images of w and
+  // diag(A) and a row of ones, so that the quadratic-form GEMM yields s.w, sum diag_i s_i and sum s_i of every SNP as
+  // a by-product (binary stores) and the finalize pass need not read the genotype store a second time
+  bool lin_rows = false;
+  double lin_step_w = 0.0, lin_step_d = 0.0;
+};
+
+struct LinOut {                  // where the GEMM leaves the raw accumulators of the linear rows: [Mpad][16] ints
+  int* raw;
 };
 
 struct mmg_scan_result {
@@ -54,6 +64,7 @@ struct mmg_scan_result {
   unsigned long long* scal = nullptr;      // [0] = count, [1] = max eps bits, [2] = max (observed / 6 sigma) bits
   unsigned long long* q2 = nullptr;
   int64_t q2_cap = 0;
+  int* linraw = nullptr;         // [cap][16] raw accumulators of the model's linear rows (k_scan_w4s.hip LIN)
   const void* geno = nullptr;    // the store the last scan ran on and its write version (mmg_emmax_perm_after_scan)
   uint64_t geno_version = 0;
   // what the last scan did (mmg_scan_last_stats)
@@ -131,7 +142,7 @@ void launch_cvt_f64(mmg_ctx*, const double* src, int8_t* dst, int64_t rows, int3
 void launch_transpose(mmg_ctx*, const mmg_geno*, int8_t* Xt, int64_t Mk, int mul, int add, int64_t m_begin,
                       int thr = 0);
 void launch_snp_stats(mmg_ctx*, const mmg_geno*, double* mean, double* sd);
-void launch_absmax_i8(mmg_ctx*, const int8_t* p, int64_t bytes, int* d_out);   // *d_out = max(*d_out, max |p[i]|); bytes % 16 == 0
+void launch_absmax_i8(mmg_ctx*, const int8_t* p, int64_t bytes, int* d_out);   // d_out[0] = max(d_out[0], max |p[i]|), d_out[1] likewise for max(-p[i]); bytes % 16 == 0
 
 // ---- k_kinship.hip
 int kinship_pick_ksplit(int32_t Npad, int64_t Mk, bool f32);
@@ -155,7 +166,7 @@ void launch_quantize(mmg_ctx*, const double* A, int32_t N, int32_t Npad, int D, 
                      int8_t* Bq, double* diag, long long* z0_sum /*dev, accumulated; may be null*/,
                      long long* z0_tile /*dev [Npad/256]^2, accumulated; may be null*/);
 // ---- k_scan_w4s.hip: the production quadratic-form GEMM
-void launch_scan_quad_w4s(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
+void launch_scan_quad_w4s(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q, const LinOut* lin = nullptr);
 // ---- experiments/ (only in a `make EXPERIMENTS=1` library): superseded generations, bit-identical
 void launch_scan_quad(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);   // 8-wave family
 int ensure_bits(mmg_ctx*, mmg_geno*);
@@ -163,9 +174,13 @@ void launch_scan_quad_bits(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, uns
 void launch_scan_quad_w4m(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
 void launch_scan_quad_w4b(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, unsigned long long* q);
 // ev_slot: which event pair brackets the kernel (EV_QUAD, or EV_QUAD2 for the refinement pass)
-int run_scan_quad(mmg_ctx*, mmg_geno*, const mmg_scan_model&, unsigned long long* q, int ev_slot = EV_QUAD);
+int run_scan_quad(mmg_ctx*, mmg_geno*, const mmg_scan_model&, unsigned long long* q, int ev_slot = EV_QUAD,
+                  const LinOut* lin = nullptr);
+bool scan_lin_usable(const mmg_geno* g, const mmg_scan_model& md);   // by-products available for this store / model
 void launch_scan_finalize(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, mmg_scan_result&,
                           double h0_rss, int32_t df2, double lnbeta, bool with_p = true, double bias = 0.0);
+void launch_scan_finalize_lin(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, mmg_scan_result&, double h0_rss,
+                              int32_t df2, double lnbeta, bool with_p = true, double bias = 0.0);
 void launch_scan_select(mmg_ctx*, const mmg_scan_result&, int64_t M, double sig_unit, double target, unsigned long long* cnt);
 void launch_gather_rows(mmg_ctx*, const mmg_geno*, const int64_t* idx, int64_t cnt, int8_t* Sc);
 void launch_scan_refine(mmg_ctx*, const int64_t* idx, int64_t cnt, const mmg_scan_model&, mmg_scan_result&,

@@ -574,3 +574,45 @@ def test_run_emmax_multi_streamed_vs_per_phenotype(ctx, tmp_path):
         assert rel(out["pseudo_heritability"][p], one["pseudo_heritability"]) < 1e-8
         for c in one["chrom_results"]:
             assert rel(out["chrom_results"][c]["ps"][p], one["chrom_results"][c]["ps"]) < 1e-6
+
+
+def test_scan_linear_terms_from_the_gemm_equal_the_finalize_pass(ctx, monkeypatch):
+    """Binary stores with 16 free padding rows take s.w, sum A_ii s_i and sum s_i from digit rows riding in the
+    quadratic-form GEMM (k_scan_w4s.hip LIN) instead of a second sweep over the store: the quadratic form is the same
+    integer, the linear terms are exact sums of 52-bit digit images -- p-values equal to 1e-11, s.w to 1e-13 of
+    sum |s_k w_k|.  Stores with negative values, 0/1/2 genotypes or N a multiple of 256 keep the finalize pass."""
+    rng = np.random.RandomState(77)
+    for n, m, adaptive in [(300, 3000, 0), (1100, 2600, 4), (150, 700, 0)]:
+        snps = (rng.random_sample((m, n)) < rng.uniform(0.05, 0.95, size=(m, 1))).astype(np.int8)
+        snps[3] = 0
+        snps[4] = 1
+        B = rng.standard_normal((n, 20)) / 4
+        A = np.eye(n) * rng.uniform(0.5, 3.0, size=n) + B @ B.T / n
+        A = 0.5 * (A + A.T)
+        w = rng.standard_normal(n) * np.exp(rng.uniform(-6, 2, size=n))      # wide dynamic range
+        g = ctx.geno(snps)
+        ctx.scan_set_model(A, w, adaptive)
+        fused = ctx.scan(g, 5e6, n - 2, stats=True)
+        monkeypatch.setenv("MMG_SCAN_FUSED_LINEAR", "0")
+        plain = ctx.scan(g, 5e6, n - 2, stats=True)
+        monkeypatch.delenv("MMG_SCAN_FUSED_LINEAR")
+        S = snps.astype(np.float64)
+        scale = np.abs(S) @ np.abs(w)
+        assert np.max(np.abs(fused["dot"] - plain["dot"]) / np.maximum(scale, 1e-300)) < 1e-13
+        assert np.max(np.abs(fused["dot"] - S @ w) / np.maximum(scale, 1e-300)) < 1e-13
+        assert rel(fused["den"], plain["den"]) < 1e-13
+        ok = plain["ps"] > 1e-280
+        assert rel(fused["ps"][ok], plain["ps"][ok]) < 1e-11
+        assert np.array_equal(fused["rss"][3:5], plain["rss"][3:5])          # monomorphic rows: rss = h0_rss either way
+        g.close()
+    # a store with a negative value must not take the shortcut (s^2 != s): results identical with and without the switch
+    snps = rng.randint(-1, 2, size=(500, 300)).astype(np.int8)
+    g = ctx.geno(snps)
+    ctx.scan_set_model(A[:300, :300] if A.shape[0] >= 300 else np.eye(300), rng.standard_normal(300), 4)
+    a = ctx.scan(g, 5e6, 298, stats=True)
+    monkeypatch.setenv("MMG_SCAN_FUSED_LINEAR", "0")
+    b = ctx.scan(g, 5e6, 298, stats=True)
+    monkeypatch.delenv("MMG_SCAN_FUSED_LINEAR")
+    for k in ("den", "dot", "ps"):
+        assert np.array_equal(a[k], b[k]), k
+    g.close()
