@@ -978,15 +978,18 @@ static int model_from_device(mmg_ctx* ctx, mmg_scan_model& md, int32_t N, const 
   double maxoff;
   std::memcpy(&maxoff, &bits, sizeof(double));
   if (!(maxoff > 0.0) || !std::isfinite(maxoff)) maxoff = 1.0;   // diagonal matrix: all digits are zero
-  // |rint(2 A_jk / step)| <= 2^(8D-2): the top balanced digit stays within int8
-  md.step = 2.0 * maxoff / std::ldexp(1.0, 8 * md.D - 2);
+  // |rint(2 A_jk / step)| <= 2^(7D-1) - 2: shifted by offset = 2^(7D-1) every stored entry is a non-negative number
+  // below 2^(7D), i.e. D unsigned 7-bit digits (gemm_i8_core.h: SCAN_DIGIT_BITS)
+  md.offset = std::ldexp(1.0, SCAN_DIGIT_BITS * md.D - 1);
+  md.step = 2.0 * maxoff / (md.offset - 2.0);
   const int nT = md.Npad / 256;
   long long *dz0 = nullptr, *dzt = nullptr;
   MMG_HIP(ctx, sc.alloc(&dz0, sizeof(long long)));
   MMG_HIP(ctx, sc.alloc(&dzt, (size_t)nT * nT * sizeof(long long)));
   MMG_HIP(ctx, hipMemsetAsync(dz0, 0, sizeof(long long), ctx->stream));
   MMG_HIP(ctx, hipMemsetAsync(dzt, 0, (size_t)nT * nT * sizeof(long long), ctx->stream));
-  launch_quantize(ctx, dA, N, md.Npad, md.D, 1.0 / md.step, md.Bq, md.diag, dz0, md.adaptive ? dzt : nullptr);
+  launch_quantize(ctx, dA, N, md.Npad, md.D, 1.0 / md.step, (long long)md.offset, md.Bq, md.diag, dz0,
+                  md.adaptive ? dzt : nullptr);
   MMG_HIP(ctx, hipGetLastError());
   long long z0 = 0;
   std::vector<long long> zt((size_t)nT * nT, 0);
@@ -998,7 +1001,7 @@ static int model_from_device(mmg_ctx* ctx, mmg_scan_model& md, int32_t N, const 
   if (md.adaptive) {
     // The adaptive schedule treats the lowest digit plane as noise with mean mu0 around which nothing is
     // structured.  Guard: the mean of every 256 x 256 tile of that plane must be within 8 sigma of mu0 (a uniform
-    // digit has sigma 73.9); a matrix with blocks that are constant to 22 bits would fail -- then every plane is
+    // 7-bit digit has sigma 36.95); a matrix with blocks that are constant to 21 bits would fail -- then every plane is
     // run for every SNP.
     for (int tj = 0; tj < nT && md.adaptive; ++tj)
       for (int tk = 0; tk <= tj; ++tk) {
@@ -1006,7 +1009,7 @@ static int model_from_device(mmg_ctx* ctx, mmg_scan_model& md, int32_t N, const 
         if (rows <= 0 || cols <= 0) continue;
         const double cnt = tj == tk ? 0.5 * rows * (rows - 1) : (double)rows * cols;
         if (cnt < 1024) continue;
-        const double dev = std::fabs((double)zt[(size_t)tj * nT + tk] - md.mu0 * cnt) / (73.9 * std::sqrt(cnt));
+        const double dev = std::fabs((double)zt[(size_t)tj * nT + tk] - md.mu0 * cnt) / (36.95 * std::sqrt(cnt));
         if (dev > 8.0) { md.adaptive = false; break; }
       }
   }
@@ -1102,16 +1105,17 @@ int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2)
     MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MMG_OK;
   }
-  // ---- adaptive precision.  Pass 1: the three upper digit planes for every SNP, i.e. the matrix rounded to 22
-  // bits (balanced digits: dropping the lowest one IS round-to-nearest).  That leaves den off by a sum of
-  // independent roundings whose sigma is known per SNP (k_scan.hip:scan_select_kernel); a SNP whose p could move
+  // ---- adaptive precision.  Pass 1: the three upper digit planes for every SNP, i.e. the matrix truncated to 21
+  // bits (unsigned digits: dropping the lowest one cuts off a value uniform in [0, 128); its mean, mu0 per stored
+  // entry, goes back in as a bias term of the finalize kernels).  That leaves den off by a sum of
+  // independent errors whose sigma is known per SNP (k_scan.hip:scan_select_kernel); a SNP whose p could move
   // by more than `target` at six sigma -- large F, or a den that is small against the rounding noise -- gets the
   // lowest plane added to the same exact integer in pass 2, which makes it bit-identical to a full 4-plane scan.
   // The refined SNPs double as a check of the error model: if any of them moved by more than its six-sigma
   // prediction, everything is redone with all planes.
   double target = 2.5e-7;                                  // a quarter of the 1e-6 bar on p
   if (const char* e = std::getenv("MMG_SCAN_ADAPT_TARGET")) target = std::atof(e);
-  const double sig_unit = md.step * 256.0 / std::sqrt(12.0) / std::sqrt(2.0);   // sigma = sig_unit * sum s^2
+  const double sig_unit = md.step * (double)(1 << SCAN_DIGIT_BITS) / std::sqrt(12.0) / std::sqrt(2.0);   // sigma = sig_unit * sum s^2
   mmg_scan_model hi = md, lo = md;                        // shallow copies with the schedule swapped
   hi.job_off = md.job_off_hi; hi.jobs = md.jobs_hi; hi.njobs = md.njobs_hi;
   lo.job_off = md.job_off_lo; lo.jobs = md.jobs_lo; lo.njobs = md.njobs_lo;

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void scan_quad_bits_kernel(
             for (int e = 0; e < 4; ++e)
               part += ((nib >> e) & 1u) ? (long long)acc[m][nn][g4 * 4 + e] : 0ll;
           }
-        qacc[nn] += ((unsigned long long)part) << (8 * d);
+        qacc[nn] += ((unsigned long long)part) << (SCAN_DIGIT_BITS * d);
       }
     }
     __builtin_amdgcn_s_barrier();                     // the next job's prologue refills slots 0..2

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void scan_quad_kernel(
               part += (long long)acc[m][nn][g4 * 4 + e] * (long long)(int)(int8_t)((wd >> (8 * e)) & 0xff);
           }
         }
-      qacc[nn] += ((unsigned long long)part) << (8 * d);
+      qacc[nn] += ((unsigned long long)part) << (SCAN_DIGIT_BITS * d);
     }
     __syncthreads();   // the next job's prologue refills buffer 0
   }
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void scan_quad_flat_kernel(
           for (int e = 0; e < 4; ++e)
             part += (long long)acc[m][nn][g4 * 4 + e] * (long long)(int)(int8_t)((wd >> (8 * e)) & 0xff);
         }
-      qacc[nn] += ((unsigned long long)part) << (8 * d);
+      qacc[nn] += ((unsigned long long)part) << (SCAN_DIGIT_BITS * d);
     }
   };
   run_tiles_flat2(j1 - j0, ldB, ldS, lds, tile, hook, epi);
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void scan_quad16_kernel(
         for (int e = 0; e < 4; ++e)
           part += (long long)acc[m][nn][e] * (long long)(int)(int8_t)((wd >> (8 * e)) & 0xff);
       }
-      qacc[nn] += ((unsigned long long)part) << (8 * d);
+      qacc[nn] += ((unsigned long long)part) << (SCAN_DIGIT_BITS * d);
     }
   }
 #pragma unroll
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void scan_quad_ring_kernel(
           for (int e = 0; e < 4; ++e)
             part += (long long)acc[m][nn][g4 * 4 + e] * (long long)(int)(int8_t)((wd >> (8 * e)) & 0xff);
         }
-      qacc[nn] += ((unsigned long long)part) << (8 * d);
+      qacc[nn] += ((unsigned long long)part) << (SCAN_DIGIT_BITS * d);
     }
   };
   if (PINGPONG == 1) run_tiles_pingpong(j1 - j0, ldB, ldS, lds, tile, epi);

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(W4_THREADS) void scan_quad_w4b_kernel(
             for (int e = 0; e < 4; ++e) part += ((nib >> e) & 1u) ? (long long)acc[m][n][g4 * 4 + e] : 0ll;
           }
       }
-      qacc[n] += ((unsigned long long)part) << (8 * d);
+      qacc[n] += ((unsigned long long)part) << (SCAN_DIGIT_BITS * d);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the re-issued tail stages must land before LDS is released

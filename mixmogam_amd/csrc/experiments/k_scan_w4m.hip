@@ -201,7 +201,7 @@ __global__ __launch_bounds__(W4_THREADS) void scan_quad_w4m_kernel(
           for (int e = 0; e < 4; ++e) part += (long long)acc[m][n][e] * (long long)(int)(int8_t)((wd >> (8 * e)) & 0xff);
         }
       }
-      qacc[n] += ((unsigned long long)part) << (8 * d);
+      qacc[n] += ((unsigned long long)part) << (SCAN_DIGIT_BITS * d);
 #pragma unroll
       for (int m = 0; m < 8; ++m) acc[m][n] = v4i{0, 0, 0, 0};
     }

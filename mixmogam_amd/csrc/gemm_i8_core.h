@@ -29,6 +29,12 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int TM = 256, TN = 256, BK = 128;
+// Digit planes of the EMMAX scan matrix (k_scan.hip:quantize_kernel): UNSIGNED 7-bit digits of the entries shifted
+// into the non-negative range.  On this power-capped part the int8 matrix pipe sustains 4.56 POP/s on non-negative
+// digit bytes against 4.32 on balanced (signed) ones of any width (tools/probe/mfma_digit_range.hip; two's-complement
+// negatives toggle the sign-extension bits all the way up the adder tree), and the scan GEMM is at the cap: the same
+// kernel ran 7 % faster per plane (33.9 -> 31.6 ms, all planes) on non-negative planes.
+constexpr int SCAN_DIGIT_BITS = 7;
 constexpr int TILE_BYTES = TM * BK;            // 32 KiB per operand tile
 constexpr int BUF_BYTES = 2 * TILE_BYTES;      // P + Q
 constexpr int LDS_BYTES = 2 * BUF_BYTES;       // double buffered: 128 KiB

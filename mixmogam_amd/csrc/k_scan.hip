@@ -5,7 +5,11 @@
 //
 // den is the hot part (2 N^2 flop per SNP).  Genotypes are small integers, so the product
 // S . A is computed EXACTLY on the int8 matrix cores after writing the (fp64) matrix as D
-// balanced base-256 digits ("Ozaki" splitting):  2*A_jk = step * sum_d 256^d z_d[j][k], k < j.
+// unsigned 7-bit digits ("Ozaki" splitting) of the entries shifted into the non-negative range:
+//     2*A_jk = step * (sum_d 128^d u_d[j][k] - offset),  offset = 2^(7D-1),  k < j
+// (round 1 used balanced base-256 digits; non-negative digit bytes cost the power-capped matrix pipe 7 % less per
+// plane, gemm_i8_core.h SCAN_DIGIT_BITS -- the offset's contribution offset * sum_{j>k} s_j s_k is taken out again by
+// the finalize kernels, which know (sum s)^2 - sum s^2).
 // Only the strictly lower triangle is stored (A symmetric: s'As = sum_i A_ii s_i^2 +
 // sum_{k<j} 2 A_jk s_j s_k), which halves the MFMA work; the diagonal term and s.w are
 // evaluated in fp64 by the HBM-bound finalize kernel (one wave per 8 SNP rows, coalesced
@@ -48,9 +52,13 @@ void launch_absmax_offdiag(mmg_ctx* ctx, const double* A, int32_t N, unsigned lo
                      N, out_bits);
 }
 
-// one thread = 16 consecutive k of row j; Bq[d][j][k] = digit d of rint(2 A[j][k] / step), k < j
+// one thread = 16 consecutive k of row j; Bq[d][j][k] = digit d (SCAN_DIGIT_BITS wide, unsigned) of
+// rint(2 A[j][k] / step) + offset for the stored entries k < j < N, 0 elsewhere.  offset = 2^(7 D - 1) makes every stored
+// value non-negative; the integer the GEMM accumulates is then q' = q + offset * sum_{j>k} s_j s_k, and the finalize
+// kernels take the second term out again (it is a multiple of (sum s)^2 - sum s^2, which they have anyway).
 __global__ void quantize_kernel(const double* __restrict__ A, int32_t N, int32_t Npad, int D, double inv_step,
-                                int8_t* __restrict__ Bq, double* __restrict__ diag, long long* __restrict__ z0_sum,
+                                long long offset, int8_t* __restrict__ Bq, double* __restrict__ diag,
+                                long long* __restrict__ z0_sum,
                                 long long* __restrict__ z0_tile /*[nJ][nJ] sums of the lowest digit per 256 x 256 tile*/) {
   const int chunks = Npad >> 4;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -67,14 +75,14 @@ __global__ void quantize_kernel(const double* __restrict__ A, int32_t N, int32_t
   for (int e = 0; e < 16; ++e) {
     const int k = c * 16 + e;
     long long Z = 0;
-    if (j < N && k < j) Z = __double2ll_rn(2.0 * A[(int64_t)j * N + k] * inv_step);
+    if (j < N && k < j) Z = __double2ll_rn(2.0 * A[(int64_t)j * N + k] * inv_step) + offset;
 #pragma unroll
     for (int d = 0; d < 6; ++d) {
       if (d < D) {
-        const long long z = ((Z + 128) & 255) - 128;
-        Z = (Z - z) >> 8;
+        const long long z = Z & ((1 << SCAN_DIGIT_BITS) - 1);
+        Z >>= SCAN_DIGIT_BITS;
         if (d == 0) z0acc += z;
-        out[d][e >> 2] |= ((uint32_t)(z & 0xff)) << (8 * (e & 3));
+        out[d][e >> 2] |= ((uint32_t)z) << (8 * (e & 3));
       }
     }
   }
@@ -91,11 +99,11 @@ __global__ void quantize_kernel(const double* __restrict__ A, int32_t N, int32_t
   }
 }
 
-void launch_quantize(mmg_ctx* ctx, const double* A, int32_t N, int32_t Npad, int D, double inv_step, int8_t* Bq,
-                     double* diag, long long* z0_sum, long long* z0_tile) {
+void launch_quantize(mmg_ctx* ctx, const double* A, int32_t N, int32_t Npad, int D, double inv_step, long long offset,
+                     int8_t* Bq, double* diag, long long* z0_sum, long long* z0_tile) {
   const int64_t total = (int64_t)Npad * (Npad >> 4);
   hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, A, N, Npad,
-                     D, inv_step, Bq, diag, z0_sum, z0_tile);
+                     D, inv_step, offset, Bq, diag, z0_sum, z0_tile);
 }
 
 // ------------------------------------------------------------------ p-value (f_sf.h)
@@ -211,8 +219,9 @@ __global__ __launch_bounds__(256, 2) void scan_finalize_kernel(
 }
 
 // ---- adaptive precision (api.hip:mmg_emmax_scan_device): the first pass runs the three upper digit planes, i.e. the
-// matrix rounded to 22 bits.  Its error in den = s'As is a sum of ~(sum s^2)^2/2 independent roundings of +-step22/2:
-//     sigma_m = step22 / sqrt(12) * (sum_i s_i^2) / sqrt(2)          (absolute, 1 sigma)
+// matrix truncated to 21 bits.  Its error in den = s'As, after the mean of the dropped digit has been put back, is a sum
+// of ~(sum s^2)^2/2 independent errors uniform over a width step21 = 128 step:
+//     sigma_m = step21 / sqrt(12) * (sum_i s_i^2) / sqrt(2)          (absolute, 1 sigma)
 // and p moves by (F/2 + 1) * |d den| / den at most.  A SNP is refined (lowest plane added) when six sigma of that
 // could move p by more than `target`: large F, or a den that is small against its own rounding noise (a SNP nearly
 // collinear with the covariates).  idx[atomicAdd(cnt)] = m; order arbitrary, everything downstream is indexed.
@@ -244,11 +253,12 @@ __global__ void gather_rows_kernel(const int8_t* __restrict__ S, int32_t Npad, c
 }
 
 // q[idx[i]] += q2[i]; den / rss / F recomputed exactly as scan_finalize_kernel does from the full integer;
-// eps = max |den_before / den_after - 1| (what the 22-bit pass was off by on this sample)
+// eps = max |den_before / den_after - 1| (what the 21-bit pass was off by on this sample)
 __global__ void scan_refine_kernel(const int64_t* __restrict__ idx, int64_t cnt, unsigned long long* __restrict__ q,
                                    const unsigned long long* __restrict__ q2, const double* __restrict__ dd,
-                                   const double* __restrict__ dot, const double* __restrict__ ssq, double sig_unit,
-                                   double step, double h0_rss, double nu,
+                                   const double* __restrict__ dot, const double* __restrict__ ssq,
+                                   const double* __restrict__ sumv, double sig_unit, double step, double off_bias,
+                                   double h0_rss, double nu,
                                    double* __restrict__ den, double* __restrict__ rss, double* __restrict__ Fst,
                                    unsigned long long* __restrict__ eps_bits) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -259,7 +269,9 @@ __global__ void scan_refine_kernel(const int64_t* __restrict__ idx, int64_t cnt,
     q[m] = qn;
     const double my_dd = dd[m], my_dw = dot[m];
     const double d_old = den[m];
-    const double d_new = fma(step, (double)(long long)qn, my_dd);
+    // the same expression, term by term, as the finalize kernels evaluate for a scan over all planes
+    const double sm = sumv[m];
+    const double d_new = fma(step, (double)(long long)qn, my_dd) + off_bias * (0.5 * (sm * sm - ssq[m]));
     const double num = my_dw * my_dw;
     double r = h0_rss;
     if (d_new > 1e-7 * my_dd && d_new > 0.0) r = h0_rss - num / d_new;
@@ -297,7 +309,8 @@ void launch_scan_refine(mmg_ctx* ctx, const int64_t* idx, int64_t cnt, const mmg
                         unsigned long long* eps_bits) {
   if (cnt <= 0) return;
   hipLaunchKernelGGL(scan_refine_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, idx, cnt, res.q,
-                     q2, res.dd, res.dot, res.ssq, sig_unit, md.step, h0_rss, (double)df2, res.den, res.rss, res.F,
+                     q2, res.dd, res.dot, res.ssq, res.sum, sig_unit, md.step, -md.step * md.offset, h0_rss, (double)df2,
+                     res.den, res.rss, res.F,
                      eps_bits);
 }
 
@@ -393,7 +406,8 @@ __global__ void scan_finalize_lin_kernel(int64_t M, const unsigned long long* __
 void launch_scan_finalize_lin(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, mmg_scan_result& res,
                               double h0_rss, int32_t df2, double lnbeta, bool with_p, double bias) {
   hipLaunchKernelGGL(scan_finalize_lin_kernel, dim3((unsigned)((g->M + 255) / 256)), dim3(256), 0, ctx->stream, g->M, res.q,
-                     res.linraw, md.step, md.lin_step_w, md.lin_step_d, bias, h0_rss, (double)df2, res.rss, res.F, res.dot,
+                     res.linraw, md.step, md.lin_step_w, md.lin_step_d, bias - md.step * md.offset, h0_rss, (double)df2,
+                     res.rss, res.F, res.dot,
                      res.den, res.sum, res.dd, res.ssq);
   if (with_p && res.p && g->M > 0) launch_f_sf(ctx, res.F, g->M, df2, lnbeta, res.p);
 }
@@ -401,7 +415,8 @@ void launch_scan_finalize_lin(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_mo
 void launch_scan_finalize(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, mmg_scan_result& res,
                           double h0_rss, int32_t df2, double lnbeta, bool with_p, double bias) {
   hipLaunchKernelGGL(scan_finalize_kernel, dim3((unsigned)(g->Mpad / FIN_ROWS)), dim3(256), 0, ctx->stream, g->d,
-                     (int64_t)g->Npad, g->M, g->Npad, md.w, md.diag, res.q, md.step, bias, h0_rss, (double)df2, lnbeta,
+                     (int64_t)g->Npad, g->M, g->Npad, md.w, md.diag, res.q, md.step, bias - md.step * md.offset, h0_rss,
+                     (double)df2, lnbeta,
                      res.rss, res.F, res.p, res.dot, res.den, res.sum, res.dd, res.ssq);
   // p-values in their own launch: one lane per SNP (in the finalize kernel only 8 of 64 lanes hold a
   // finished SNP, and the continued fraction is ~100 dependent fp64 divisions long)

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(W4_THREADS) void scan_quad_w4s_kernel(
                 part += (long long)acc[m][n][g4 * 4 + e] * (long long)(int)(int8_t)((wd >> (8 * e)) & 0xff);
             }
       }
-      qacc[n] += ((unsigned long long)part) << (8 * d);
+      qacc[n] += ((unsigned long long)part) << (SCAN_DIGIT_BITS * d);
     }
     if (LIN) {
       // No branch here: with one, the register allocator (488 of 512 in use) spilled 230 registers.  Every wave issues

@@ -29,7 +29,8 @@ struct mmg_scan_model {
   int8_t* Bq = nullptr;         // [D][Npad][Npad] digits of the strictly-lower triangle of 2A
   double* diag = nullptr;       // [Npad] diagonal of A (0 padded)
   double* w = nullptr;          // [Npad] (0 padded)
-  double step = 0.0;            // den = step * q + sum_i diag_i s_i^2
+  double step = 0.0;            // den = step * (q' - offset * sum_{j>k} s_j s_k) + sum_i diag_i s_i^2
+  double offset = 0.0;          // 2^(7 D - 1): what quantize_kernel adds to every stored entry (non-negative digits)
   // tile schedule
   int AS = 2, G = 16;           // sub-blocks per cohort, job groups per cohort (AS * G = 32)
   int* job_off = nullptr;       // [G + 1]
@@ -162,7 +163,7 @@ void launch_mirror_i32_to_i64(mmg_ctx*, const int* C32, int32_t Npad, int32_t N,
 
 // ---- k_scan.hip
 void launch_absmax_offdiag(mmg_ctx*, const double* A, int32_t N, unsigned long long* out_bits);
-void launch_quantize(mmg_ctx*, const double* A, int32_t N, int32_t Npad, int D, double inv_step,
+void launch_quantize(mmg_ctx*, const double* A, int32_t N, int32_t Npad, int D, double inv_step, long long offset,
                      int8_t* Bq, double* diag, long long* z0_sum /*dev, accumulated; may be null*/,
                      long long* z0_tile /*dev [Npad/256]^2, accumulated; may be null*/);
 // ---- k_scan_w4s.hip: the production quadratic-form GEMM
