@@ -172,8 +172,8 @@ int mmg_reml_scan_model(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, do
 /* Loads the SNP-independent model onto the device:
  *   A [N x N] symmetric (= Mp Mp^T with Mp = H^T (I - QQ^T), linear_models.py:1300-1303),
  *   w [N]              (= Mp r, r the residualised transformed phenotype, :1293).
- * The off-diagonal of A is quantised to `ndigits` balanced base-256 digits (exact integer
- * GEMM on the int8 matrix cores; 4 digits = 2^-30 of max|A_ij| per entry); the diagonal and w
+ * The off-diagonal of A, shifted into the non-negative range, is quantised to `ndigits` unsigned 7-bit digit planes
+ * (exact integer GEMM on the int8 matrix cores; 4 planes = 2^-27 of max|A_ij| per entry); the diagonal and w
  * stay fp64.  ndigits in [2, 6] runs all its planes for every SNP; 0 = default: 4 digits with the adaptive
  * schedule described at mmg_scan_last_stats (p-values within 2.5e-7 relative of the 4-digit scan by construction,
  * bit-identical to it for every SNP that is refined). */
@@ -184,7 +184,7 @@ int mmg_scan_set_model(mmg_ctx* ctx, int32_t N, const double* A, const double* w
 int mmg_emmax_scan(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2,
                    double* rss, double* F, double* p);
 /* What the last mmg_emmax_scan_device did.  The default model (ndigits = 0 in mmg_scan_set_model) runs an ADAPTIVE
- * schedule: the three upper digit planes of the matrix for every SNP (the matrix rounded to 22 bits: den to ~1e-8
+ * schedule: the three upper digit planes of the matrix for every SNP (the matrix truncated to 21 bits: den to ~1e-8
  * relative), then the lowest plane only for the SNPs whose p-value could move by more than 2.5e-7 relative at six
  * sigma of that rounding noise (large F, or den small against the noise), which makes those bit-identical to a full
  * 4-plane scan.  sigma_ratio_max = max over the refined SNPs of (observed change of den) / (its six-sigma
