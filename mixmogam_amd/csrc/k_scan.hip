@@ -117,6 +117,14 @@ void launch_f_sf(mmg_ctx* ctx, const double* F, int64_t n, int32_t df2, double l
                      lnbeta, p);
 }
 
+// The integer the GEMM accumulated carries offset * sum_{j>k} s_j s_k on top of the quadratic form (quantize_kernel):
+// taken out in 64-bit modular arithmetic -- exact whatever the number of planes, the true value is far below 2^63.
+__device__ __forceinline__ double quad_without_offset(unsigned long long q, unsigned long long offset, long long sm,
+                                                      long long sq) {
+  const unsigned long long pairs = (unsigned long long)((sm * sm - sq) / 2);     // sum_{j>k} s_j s_k: (sum s)^2 - sum s^2 is even
+  return (double)(long long)(q - offset * pairs);
+}
+
 // ------------------------------------------------------------------ finalize
 // HBM-bound.  A block of 4 waves handles 32 SNP rows (8 per wave).  Per 1024-column chunk the block
 // stages w and diag(A) once into LDS (lane-interleaved 16-byte units: conflict-free ds_read_b128)
@@ -125,7 +133,8 @@ constexpr int FR = 8;                      // SNP rows per wave
 constexpr int FIN_ROWS = 4 * FR;           // per block
 __global__ __launch_bounds__(256, 2) void scan_finalize_kernel(
     const int8_t* __restrict__ S, int64_t ldS, int64_t M, int32_t Npad, const double* __restrict__ w,
-    const double* __restrict__ diag, const unsigned long long* __restrict__ q, double step, double bias, double h0_rss, double nu,
+    const double* __restrict__ diag, const unsigned long long* __restrict__ q, double step, unsigned long long offset,
+    double bias, double h0_rss, double nu,
     double lnbeta, double* __restrict__ rss, double* __restrict__ Fst, double* __restrict__ pv,
     double* __restrict__ dotv, double* __restrict__ denv, double* __restrict__ sumv, double* __restrict__ ddv,
     double* __restrict__ ssqv) {
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void scan_finalize_kernel(
   }
   const int64_t m = m0 + lane;
   if (lane < FR && m < M) {
-    const double qd = (double)(long long)q[m];
+    const double qd = quad_without_offset(q[m], offset, my_sm, my_sq);
     // bias: adaptive first pass only -- step * (mean of the digit plane that was left out), times the number of
     // (j > k) products sum_{j>k} s_j s_k = ((sum s)^2 - sum s^2) / 2: removes the coherent part of the rounding error
     const double den = fma(step, qd, my_dd) + bias * (0.5 * ((double)my_sm * (double)my_sm - (double)my_sq));
@@ -257,7 +266,8 @@ __global__ void gather_rows_kernel(const int8_t* __restrict__ S, int32_t Npad, c
 __global__ void scan_refine_kernel(const int64_t* __restrict__ idx, int64_t cnt, unsigned long long* __restrict__ q,
                                    const unsigned long long* __restrict__ q2, const double* __restrict__ dd,
                                    const double* __restrict__ dot, const double* __restrict__ ssq,
-                                   const double* __restrict__ sumv, double sig_unit, double step, double off_bias,
+                                   const double* __restrict__ sumv, double sig_unit, double step,
+                                   unsigned long long offset,
                                    double h0_rss, double nu,
                                    double* __restrict__ den, double* __restrict__ rss, double* __restrict__ Fst,
                                    unsigned long long* __restrict__ eps_bits) {
@@ -269,9 +279,9 @@ __global__ void scan_refine_kernel(const int64_t* __restrict__ idx, int64_t cnt,
     q[m] = qn;
     const double my_dd = dd[m], my_dw = dot[m];
     const double d_old = den[m];
-    // the same expression, term by term, as the finalize kernels evaluate for a scan over all planes
+    // the same expression as the finalize kernels evaluate for a scan over all planes (no first-pass bias)
     const double sm = sumv[m];
-    const double d_new = fma(step, (double)(long long)qn, my_dd) + off_bias * (0.5 * (sm * sm - ssq[m]));
+    const double d_new = fma(step, quad_without_offset(qn, offset, (long long)sm, (long long)ssq[m]), my_dd);
     const double num = my_dw * my_dw;
     double r = h0_rss;
     if (d_new > 1e-7 * my_dd && d_new > 0.0) r = h0_rss - num / d_new;
@@ -309,7 +319,7 @@ void launch_scan_refine(mmg_ctx* ctx, const int64_t* idx, int64_t cnt, const mmg
                         unsigned long long* eps_bits) {
   if (cnt <= 0) return;
   hipLaunchKernelGGL(scan_refine_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, idx, cnt, res.q,
-                     q2, res.dd, res.dot, res.ssq, res.sum, sig_unit, md.step, -md.step * md.offset, h0_rss, (double)df2,
+                     q2, res.dd, res.dot, res.ssq, res.sum, sig_unit, md.step, (unsigned long long)md.offset, h0_rss, (double)df2,
                      res.den, res.rss, res.F,
                      eps_bits);
 }
@@ -377,7 +387,8 @@ __device__ __forceinline__ double digits7_to_f64(int4 lo4, int d4, int d5, int d
 }
 
 __global__ void scan_finalize_lin_kernel(int64_t M, const unsigned long long* __restrict__ q, const int* __restrict__ raw,
-                                         double step, double step_w, double step_d, double bias, double h0_rss, double nu,
+                                         double step, unsigned long long offset, double step_w, double step_d, double bias,
+                                         double h0_rss, double nu,
                                          double* __restrict__ rss, double* __restrict__ Fst, double* __restrict__ dotv,
                                          double* __restrict__ denv, double* __restrict__ sumv, double* __restrict__ ddv,
                                          double* __restrict__ ssqv) {
@@ -388,7 +399,7 @@ __global__ void scan_finalize_lin_kernel(int64_t M, const unsigned long long* __
   const double my_dw = digits7_to_f64(a0, a1.x, a1.y, a1.z) * step_w;
   const double my_dd = digits7_to_f64(b0, b1.x, b1.y, b1.z) * step_d;
   const double sm = (double)a1.w;
-  const double qd = (double)(long long)q[m];
+  const double qd = quad_without_offset(q[m], offset, (long long)a1.w, (long long)a1.w);
   const double den = fma(step, qd, my_dd) + bias * (0.5 * (sm * sm - sm));
   const double num = my_dw * my_dw;
   double r = h0_rss;
@@ -406,7 +417,7 @@ __global__ void scan_finalize_lin_kernel(int64_t M, const unsigned long long* __
 void launch_scan_finalize_lin(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, mmg_scan_result& res,
                               double h0_rss, int32_t df2, double lnbeta, bool with_p, double bias) {
   hipLaunchKernelGGL(scan_finalize_lin_kernel, dim3((unsigned)((g->M + 255) / 256)), dim3(256), 0, ctx->stream, g->M, res.q,
-                     res.linraw, md.step, md.lin_step_w, md.lin_step_d, bias - md.step * md.offset, h0_rss, (double)df2,
+                     res.linraw, md.step, (unsigned long long)md.offset, md.lin_step_w, md.lin_step_d, bias, h0_rss, (double)df2,
                      res.rss, res.F, res.dot,
                      res.den, res.sum, res.dd, res.ssq);
   if (with_p && res.p && g->M > 0) launch_f_sf(ctx, res.F, g->M, df2, lnbeta, res.p);
@@ -415,7 +426,7 @@ void launch_scan_finalize_lin(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_mo
 void launch_scan_finalize(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, mmg_scan_result& res,
                           double h0_rss, int32_t df2, double lnbeta, bool with_p, double bias) {
   hipLaunchKernelGGL(scan_finalize_kernel, dim3((unsigned)(g->Mpad / FIN_ROWS)), dim3(256), 0, ctx->stream, g->d,
-                     (int64_t)g->Npad, g->M, g->Npad, md.w, md.diag, res.q, md.step, bias - md.step * md.offset, h0_rss,
+                     (int64_t)g->Npad, g->M, g->Npad, md.w, md.diag, res.q, md.step, (unsigned long long)md.offset, bias, h0_rss,
                      (double)df2, lnbeta,
                      res.rss, res.F, res.p, res.dot, res.den, res.sum, res.dd, res.ssq);
   // p-values in their own launch: one lane per SNP (in the finalize kernel only 8 of 64 lanes hold a

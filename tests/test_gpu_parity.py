@@ -174,7 +174,7 @@ def _prep(case):
     return orc.scan_prepare(y, X, est["H_sqrt_inv"])
 
 
-@pytest.mark.parametrize("ndigits", [3, 4, 5])
+@pytest.mark.parametrize("ndigits", [3, 4, 5, 6])
 def test_scan_c_abi_vs_oracle(ctx, case, ndigits):
     prep = _prep(case)
     ref = orc.scan_closed(case["snps"], prep)
@@ -183,7 +183,8 @@ def test_scan_c_abi_vs_oracle(ctx, case, ndigits):
     out = ctx.scan(g, prep["h0_rss"], prep["n"] - prep["q"] - 1, stats=True)
     # ndigits = number of 7-bit unsigned digit planes (gemm_i8_core.h SCAN_DIGIT_BITS): 3 planes = 20 bits of magnitude
     # relative to the largest off-diagonal entry (an explicitly reduced-precision mode), 4 = 27, 5 = 34
-    tol = {3: 3e-4, 4: 1e-6, 5: 1e-6}[ndigits]
+    # (6 planes: the offset term alone exceeds 2^63 at these sizes -- it is taken out in modular 64-bit arithmetic)
+    tol = {3: 3e-4, 4: 1e-6, 5: 1e-6, 6: 1e-6}[ndigits]
     assert rel(out["dot"], case["snps"].astype(float) @ prep["w"]) < 1e-10
     assert rel(out["den"], ref["den"]) < tol * 1e-1
     assert rel(out["rss"], ref["rss"]) < tol * 1e-1
