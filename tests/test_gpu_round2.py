@@ -616,3 +616,29 @@ def test_scan_linear_terms_from_the_gemm_equal_the_finalize_pass(ctx, monkeypatc
     for k in ("den", "dot", "ps"):
         assert np.array_equal(a[k], b[k]), k
     g.close()
+
+
+@pytest.mark.parametrize("n", [240, 241, 255, 256, 257, 512, 1008, 1009])
+def test_scan_at_the_edges_of_the_linear_row_condition(ctx, n):
+    """16 free padding rows (N mod 256 <= 240, N not a multiple of 256) decide whether the linear terms ride in the GEMM;
+    both sides of every edge against float64 numpy: den, s.w, sum s, p."""
+    rng = np.random.RandomState(n)
+    m = 700
+    snps = (rng.random_sample((m, n)) < 0.4).astype(np.int8)
+    B = rng.standard_normal((n, 12)) / 3
+    A = np.eye(n) * 1.3 + B @ B.T / n
+    A = 0.5 * (A + A.T)
+    w = rng.standard_normal(n)
+    g = ctx.geno(snps)
+    ctx.scan_set_model(A, w, 4)
+    out = ctx.scan(g, 3e5, n - 2, stats=True)
+    S = snps.astype(np.float64)
+    den = np.einsum("ij,ij->i", S @ A, S)
+    dot = S @ w
+    assert rel(out["den"], den) < 1e-7
+    assert np.max(np.abs(out["dot"] - dot) / (np.abs(S) @ np.abs(w))) < 1e-13
+    assert np.array_equal(out["sum"], S.sum(1))
+    rss = 3e5 - dot * dot / den
+    F = (3e5 / rss - 1) * (n - 2)
+    assert rel(out["ps"], orc.f_sf(np.maximum(F, 0), 1, n - 2)) < 1e-6
+    g.close()
