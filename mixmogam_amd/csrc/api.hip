@@ -1068,18 +1068,12 @@ static int ensure_result(mmg_ctx* ctx, mmg_scan_result& r, int64_t Mpad) {
   return MMG_OK;
 }
 
-int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2) {
-  MMG_ENTER(ctx);
-  MMG_CHECK_ARG(ctx, g != nullptr && df2 > 0);
-  if (!ctx->model.Bq) return set_err(ctx, MMG_E_STATE, "mmg_scan_set_model has not been called");
-  if (ctx->model.N != g->N) return set_err(ctx, MMG_E_ARG, "model N does not match the genotype store");
-  int rc = ensure_result(ctx, ctx->res, g->Mpad);
-  if (rc) return rc;
-  ctx->res.M = g->M;
-  ctx->res.geno = g; ctx->res.geno_version = g->version;
-  if (g->M == 0) return MMG_OK;
-  mmg_scan_result& res = ctx->res;
-  const mmg_scan_model& md = ctx->model;
+// The scan of g against model md into res: all planes for an explicit digit count, else the adaptive schedule.
+// f_free: the refinement criterion ignores F (a quadratic form wanted for its own sake -- the permutation test's t.t --
+// is refined wherever six sigma of the first pass exceed `target` of the form itself); with_p: p-values at the end.
+static int scan_into(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, mmg_scan_result& res, double h0_rss,
+                     int32_t df2, bool f_free, bool with_p) {
+  int rc = MMG_OK;
   const double lnb = ln_beta_half(0.5 * df2);
   res.n_refined = 0; res.eps_max = 0.0; res.sigma_ratio_max = 0.0; res.fell_back = 0; res.adaptive = md.adaptive ? 1 : 0;
   ctx->ev_set[EV_QUAD2] = false;
@@ -1099,7 +1093,7 @@ int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2)
     MMG_HIP(ctx, hipGetLastError());
     {
       EvScope ev(ctx, EV_FIN);
-      finalize(true, 0.0);
+      finalize(with_p, 0.0);
     }
     MMG_HIP(ctx, hipGetLastError());
     MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1127,7 +1121,7 @@ int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2)
     finalize(false, md.step * md.mu0);
   }
   MMG_HIP(ctx, hipMemsetAsync(res.scal, 0, 4 * sizeof(unsigned long long), ctx->stream));
-  launch_scan_select(ctx, res, g->M, sig_unit, target, res.scal);
+  launch_scan_select(ctx, res, g->M, sig_unit, target, res.scal, !f_free);
   unsigned long long hs[3] = {0, 0, 0};
   MMG_HIP(ctx, hipMemcpyAsync(hs, res.scal, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1176,10 +1170,24 @@ int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2)
     res.fell_back = 1;
     finalize(false, 0.0);
   }
-  if (res.p && g->M > 0) launch_f_sf(ctx, res.F, g->M, df2, lnb, res.p);
+  if (with_p && res.p && g->M > 0) launch_f_sf(ctx, res.F, g->M, df2, lnb, res.p);
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MMG_OK;
+}
+
+
+int mmg_emmax_scan_device(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, g != nullptr && df2 > 0);
+  if (!ctx->model.Bq) return set_err(ctx, MMG_E_STATE, "mmg_scan_set_model has not been called");
+  if (ctx->model.N != g->N) return set_err(ctx, MMG_E_ARG, "model N does not match the genotype store");
+  int rc = ensure_result(ctx, ctx->res, g->Mpad);
+  if (rc) return rc;
+  ctx->res.M = g->M;
+  ctx->res.geno = g; ctx->res.geno_version = g->version;
+  if (g->M == 0) return MMG_OK;
+  return scan_into(ctx, g, ctx->model, ctx->res, h0_rss, df2, false, true);
 }
 
 int mmg_scan_last_stats(mmg_ctx* ctx, int32_t* adaptive, int64_t* n_refined, double* eps_max, double* sigma_ratio_max,
@@ -1407,7 +1415,14 @@ int mmg_perm_plan_create(mmg_ctx* ctx, int32_t N, const double* Ht, const double
       hipStreamSynchronize(ctx->stream) != hipSuccess)
     return fail(set_err(ctx, MMG_E_HIP, "permutation plan: H 1"));
   for (int i = 0; i < N; ++i) p->c0 += h1[i] * h1[i];                       // 1'H'H 1
-  rc = model_from_device(ctx, p->pm, N, dA, p->dv, 4);                      // exact: all four planes for every SNP
+  // centred operands (k_perm.hip): A'' = C A' C is the model of the stand-alone test's t.t (adaptive digit schedule
+  // as in the scan unless MMG_SCAN_ADAPTIVE=0), W'' = C W the GEMM operand of both paths (s~.W_p = s.(C W_p))
+  launch_center_sym(ctx, dA, N, p->dv, p->c0);
+  launch_center_rows(ctx, dWt, N, P);
+  {
+    const char* e = std::getenv("MMG_SCAN_ADAPTIVE");
+    rc = model_from_device(ctx, p->pm, N, dA, p->dv, 4, !(e && e[0] == '0'));
+  }
   if (rc == MMG_OK) rc = quantize_rows_4digits(ctx, dWt, N, p->Npad, P, p->Wq, p->dstep, p->dcsum);
   if (rc == MMG_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_err(ctx, MMG_E_HIP, "permutation plan: setup");
   if (rc) return fail(rc);
@@ -1455,11 +1470,10 @@ int mmg_perm_plan_run(mmg_ctx* ctx, mmg_comm* comm, mmg_perm_plan* p, mmg_geno* 
     } else {
       int rc = ensure_result(ctx, p->pr, g->Mpad);
       if (rc) return rc;
-      MMG_HIP(ctx, hipMemsetAsync(p->pr.q, 0, g->Mpad * sizeof(unsigned long long), ctx->stream));
-      rc = run_scan_quad(ctx, g, p->pm, p->pr.q);
+      p->pr.M = g->M;
+      rc = scan_into(ctx, g, p->pm, p->pr, 1.0, 1, true, false);         // den = s'(C A' C)s = t.t   (:1159-1163)
       if (rc) return rc;
-      launch_scan_finalize(ctx, g, p->pm, p->pr, 1.0, 1, 0.0);            // den = s'A's, dot = s.v, sum = s.1
-      launch_perm_center(ctx, g, p->pr, p->c0, p->dmu, p->dinv);         // mu, 1/(s~'A's~)   (:1159)
+      launch_perm_inv(ctx, g, p->pr, p->dmu, p->dinv);                    // 1 / t.t, mu = 0
     }
     MMG_HIP(ctx, hipGetLastError());
     int rc = run_perm_q(ctx, g, p->Wq, p->dstep, p->dcsum, p->P, p->dinv, p->dmu, p->dmax);

@@ -43,6 +43,58 @@ void launch_perm_center(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_result& 
                      r.dot, r.sum, g->M, g->Mpad, 1.0 / (double)g->N, c0, d_mu, d_inv);
 }
 
+// ---- the stand-alone test works on CENTRED operands: with C = I - 11'/N (:1159 centres every SNP),
+//     t.t = s~'A's~ = s'(C A' C)s,   t.Ys_p = s~.W_p = s.(C W_p),
+// so the quadratic form of the model C A' C IS t.t -- no den - 2 mu s.v + mu^2 c0 with its cancellation, hence the
+// adaptive digit schedule of the scan applies to it (three planes + the fourth where six sigma exceed 2.5e-7 of t.t
+// itself) -- and the GEMM needs no mu * sum(W_p) term.
+__global__ void center_sym_kernel(double* __restrict__ A, int32_t N, const double* __restrict__ v, double c0) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)N * N) return;
+  const int j = (int)(gid / N), k = (int)(gid % N);
+  const double invN = 1.0 / (double)N;
+  A[gid] = A[gid] - (v[j] + v[k]) * invN + c0 * invN * invN;
+}
+void launch_center_sym(mmg_ctx* ctx, double* A, int32_t N, const double* v, double c0) {
+  const int64_t total = (int64_t)N * N;
+  hipLaunchKernelGGL(center_sym_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, A, N, v, c0);
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void center_rows_kernel(double* __restrict__ Wt, int32_t N, int32_t P) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= P) return;
+  double s = 0.0;
+  for (int k = lane; k < N; k += 64) s += Wt[(int64_t)p * N + k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const double mean = s / (double)N;
+  for (int k = lane; k < N; k += 64) Wt[(int64_t)p * N + k] -= mean;
+}
+void launch_center_rows(mmg_ctx* ctx, double* Wt, int32_t N, int32_t P) {
+  hipLaunchKernelGGL(center_rows_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, ctx->stream, Wt, N, P);
+}
+
+// mu = 0 (the operands are centred), inv = 1 / t.t with the scan's rule for a form that vanishes (a SNP that is
+// constant over the individuals: den ~ 0 against its own diagonal part)
+__global__ void perm_inv_kernel(const double* __restrict__ den, const double* __restrict__ dd, int64_t M, int64_t Mpad,
+                                double* __restrict__ mu, double* __restrict__ inv) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= Mpad) return;
+  double iv = 0.0;
+  if (m < M) {
+    const double tt = den[m];
+    if (tt > 1e-7 * fabs(dd[m]) && tt > 0.0) iv = 1.0 / tt;
+  }
+  mu[m] = 0.0;
+  inv[m] = iv;
+}
+void launch_perm_inv(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_result& r, double* d_mu, double* d_inv) {
+  hipLaunchKernelGGL(perm_inv_kernel, dim3((unsigned)((g->Mpad + 255) / 256)), dim3(256), 0, ctx->stream, r.den, r.dd,
+                     g->M, g->Mpad, d_mu, d_inv);
+}
+
 // tt from the quadratic form a preceding EMMAX scan of the same SNPs left behind: den = s'(H'H - sum_c u_c u_c')s with
 // u_c = H'Q_c (linear_models.py:1300-1303), so s'H'Hs = den + sum_c (s.u_c)^2 and, centred (:1159),
 // tt = s'H'Hs - 2 mu s.v + mu^2 c0 with v = H'H 1.  dots: [1 + q][Mpad] = s.v, s.u_0 .. s.u_{q-1}.

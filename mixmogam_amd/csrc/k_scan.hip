@@ -236,12 +236,14 @@ __global__ __launch_bounds__(256, 2) void scan_finalize_kernel(
 // collinear with the covariates).  idx[atomicAdd(cnt)] = m; order arbitrary, everything downstream is indexed.
 __global__ void scan_select_kernel(const double* __restrict__ F, const double* __restrict__ den,
                                    const double* __restrict__ ssq, const unsigned long long* __restrict__ q, int64_t M,
-                                   double sig_unit, double target, int64_t* __restrict__ idx,
+                                   double sig_unit, double target, int use_F, int64_t* __restrict__ idx,
                                    unsigned long long* __restrict__ cnt) {
   const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
   const double d = den[m], six_sigma = 6.0 * sig_unit * ssq[m];
-  bool refine = !(d > 0.0) ? six_sigma > 0.0 : (0.5 * F[m] + 1.0) * six_sigma > target * d;
+  // use_F = 0: the form is wanted for its own sake (permutation test): refine where six sigma exceed target * den
+  const double Fm = use_F ? F[m] : 0.0;
+  bool refine = !(d > 0.0) ? six_sigma > 0.0 : (0.5 * Fm + 1.0) * six_sigma > target * d;
   // plus about one SNP in 256 regardless -- picked by bits of its own first-pass integer, so that the choice does not
   // depend on where the SNP sits in the launch: a sample of thousands on which the refinement pass measures the
   // rounding error against its six-sigma prediction (the check that guards the error model), at the cost of one
@@ -304,9 +306,9 @@ __global__ void scan_refine_kernel(const int64_t* __restrict__ idx, int64_t cnt,
 }
 
 void launch_scan_select(mmg_ctx* ctx, const mmg_scan_result& res, int64_t M, double sig_unit, double target,
-                        unsigned long long* cnt) {
+                        unsigned long long* cnt, bool use_F) {
   hipLaunchKernelGGL(scan_select_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, res.F, res.den,
-                     res.ssq, res.q, M, sig_unit, target, res.idx, cnt);
+                     res.ssq, res.q, M, sig_unit, target, use_F ? 1 : 0, res.idx, cnt);
 }
 void launch_gather_rows(mmg_ctx* ctx, const mmg_geno* g, const int64_t* idx, int64_t cnt, int8_t* Sc) {
   const int64_t total = cnt * (g->Npad >> 4);

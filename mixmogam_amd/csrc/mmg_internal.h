@@ -182,7 +182,8 @@ void launch_scan_finalize(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, mmg_
                           double h0_rss, int32_t df2, double lnbeta, bool with_p = true, double bias = 0.0);
 void launch_scan_finalize_lin(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, mmg_scan_result&, double h0_rss,
                               int32_t df2, double lnbeta, bool with_p = true, double bias = 0.0);
-void launch_scan_select(mmg_ctx*, const mmg_scan_result&, int64_t M, double sig_unit, double target, unsigned long long* cnt);
+void launch_scan_select(mmg_ctx*, const mmg_scan_result&, int64_t M, double sig_unit, double target, unsigned long long* cnt,
+                        bool use_F = true);
 void launch_gather_rows(mmg_ctx*, const mmg_geno*, const int64_t* idx, int64_t cnt, int8_t* Sc);
 void launch_scan_refine(mmg_ctx*, const int64_t* idx, int64_t cnt, const mmg_scan_model&, mmg_scan_result&,
                         const unsigned long long* q2, double sig_unit, double h0_rss, int32_t df2,
@@ -203,6 +204,10 @@ int run_perm_q(mmg_ctx*, const mmg_geno*, const int8_t* Wq, const double* dstep,
                const double* d_inv, const double* d_mu, double* d_maxstat);
 void launch_colsum(mmg_ctx*, const mmg_geno*, unsigned long long* r);          // r[Npad] += column sums of the store
 void launch_mirror_ibs(mmg_ctx*, const int* C32, int32_t Npad, int32_t N, const long long* r, long long Mtot, int64_t* C);
+// ---- k_perm.hip: centring of the permutation test's operands, 1 / t.t from a centred quadratic form
+void launch_center_sym(mmg_ctx*, double* A, int32_t N, const double* v, double c0);   // A <- C A C given v = A 1, c0 = 1'A 1
+void launch_center_rows(mmg_ctx*, double* Wt, int32_t N, int32_t P);                  // rows of Wt [P x N] <- row - mean(row)
+void launch_perm_inv(mmg_ctx*, const mmg_geno*, const mmg_scan_result&, double* d_mu, double* d_inv);
 int upload_group_table(mmg_ctx*, const std::vector<int2>& tab);   // k_perm.hip; into ctx->grp_tab
 int quantize_rows_4digits(mmg_ctx*, const double* dWt, int32_t N, int32_t Npad, int32_t P, int8_t* Wq, double* dstep,
                           double* dcsum);
