@@ -214,7 +214,8 @@ int mmg_emmax_scan_f32(mmg_ctx* ctx, const float* snps, int64_t M, int32_t N,
 /* Ht: host [N x N] = H_sqrt_inv (row-major, as the reference holds it), Ys: host [N x P]
  * permuted residual columns (:1150-1154).  For every permutation p returns
  * min_rss[p] = min(h0_rss, min_m ( Ys_p.Ys_p - (t_m.Ys_p)^2 / (t_m.t_m) )), t_m = H (s_m - mean(s_m))
- * (:1159-1164).  min_rss: host [P]. */
+ * (:1159-1164).  min_rss: host [P].  t_m.t_m is the quadratic form of the centred model C H'H C on the int8 matrix
+ * cores with the adaptive digit schedule of the scan (within 2.5e-7 of itself; MMG_SCAN_ADAPTIVE=0: every plane). */
 int mmg_emmax_perm(mmg_ctx* ctx, mmg_geno* g, int32_t N, const double* Ht, const double* Ys,
                    int32_t P, double h0_rss, int ndigits, double* min_rss);
 
