@@ -35,9 +35,11 @@ if ROOT not in sys.path:
 
 QUAD_KERNEL = "scan_quad_w4s_kernel"   # the dominant kernel (k_scan_w4s.hip); its name in rocprofv3 / profiles/
 I8_MFMA_PEAK_TOPS = 5000.0     # dense int8 MFMA: 2x the ~2.5 PF bf16 rate (MI355X_MICROARCH.md, Matrix cores)
-# What a bare v_mfma_i32_32x32x32_i8 loop on random operands sustains on this chip (power-limited clock 2.07 GHz;
-# tools/probes/mfma_shape_probe.hip).  Reported beside the nominal peak, never instead of it.
-I8_MFMA_SUSTAINED_TOPS = 4230.0
+# What a bare v_mfma_i32_32x32x32_i8 loop sustains under this chip's power cap on the operands the scan GEMM feeds it
+# (non-negative 7-bit digits 0..127 as A, 0/1 genotypes as B): tools/probe/mfma_digit_range.hip, DESIGN.md 4.1
+# (signed base-256 digits: 4.30).  Reported beside the nominal peak, never instead of it.
+I8_MFMA_SUSTAINED_TOPS = 4560.0
+I8_MFMA_SUSTAINED_SOURCE = "tools/probe/mfma_digit_range.hip (digits 0..127 x 0/1 bytes, registers only, power-capped clock)"
 F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 (same guide)
 HBM_PEAK_GBPS = 8000.0
 PCIE_GBPS = 64.0               # host link of the box (gen5 x16), the roof of anything that starts in host memory
@@ -60,8 +62,71 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the structured-data, host-ingest and multi-phenotype sub-records of the default run")
     ap.add_argument("--cpu-sample", type=int, default=0,
-                    help="SNPs in the CPU baseline sample (0 = 40 chunks of N, ~15-20 s of CPU work at N=5000)")
+                    help="SNPs in the CPU baseline sample (0 = all M SNPs of the workload at the default size, "
+                         "~80 s of CPU work at N=5000, M=1M)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher check: every rank prints its rendezvous environment as JSON and exits without "
+                         "loading the HIP library or touching a GPU")
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------- self-launch
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start one child process per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / MMG_RUN_ID, the variables torch.distributed.run
+    exports and mixmogam_amd.dist.file_bootstrap keys the RCCL rendezvous on), forward rank 0's stdout -- whose last
+    line is the ONE JSON line -- and return non-zero if any rank does.  This parent never loads libmixmogam_hip and
+    never touches a GPU; nothing is exec'ed; children are stopped by their exact PIDs."""
+    import socket
+    import subprocess
+    import threading
+    world = args.gpus
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    run_id = "self%d_%d" % (os.getpid(), int(time.time()))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "MMG_RUN_ID": run_id})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE, stderr=None))
+    lines = [[] for _ in range(world)]
+
+    def pump(r):
+        for raw in procs[r].stdout:
+            line = raw.decode(errors="replace")
+            lines[r].append(line)
+            if r != 0 and not args.dry_launch:        # other ranks' chatter must not follow rank 0's JSON line on stdout
+                sys.stderr.write("[rank %d] %s" % (r, line))
+    threads = [threading.Thread(target=pump, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    rc = 0
+    alive = set(range(world))
+    while alive:                                      # a rank that dies leaves the others inside an RCCL call for good
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, code))
+                for o in sorted(alive):
+                    procs[o].terminate()
+        time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=5)
+    if args.dry_launch:
+        recs = [json.loads(l) for r in range(world) for l in lines[r] if l.startswith("{")]
+        print(json.dumps({"dry_launch": True, "world": world, "ranks": recs}))
+        return rc
+    sys.stdout.write("".join(lines[0]))
+    sys.stdout.flush()
+    return rc
 
 
 def main():
@@ -69,11 +134,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))               # the parent of the ranks: no GPU, no HIP library
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_launch:
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR",
+                                                         "MASTER_PORT", "MMG_RUN_ID")}))
+        return
     os.environ.setdefault("MMG_DEVICE", str(local_rank))
 
     from mixmogam_amd import _lib, dist as mdist, kinship, linear_models as lm
+
+    n_dev = _lib.device_count()
+    if n_dev < world:
+        raise SystemExit("bench.py: --gpus %d needs %d devices, this box has %d (rank %d)" % (world, world, n_dev, rank))
 
     # No torch in this process: libmixmogam_hip links the system ROCm runtime and importing
     # torch's bundled one beside it segfaults.  Rendezvous = rank 0's ncclUniqueId through a
@@ -115,10 +190,10 @@ def main():
     # (+ the fp32-MFMA twin of the north star on this rank's block, for the TFLOP/s figure)
     counts = ctx.kinship_ibs_counts(g, comm=comm_h)
     kin_i8_ms, kin_i8_pack_ms = ctx.kernel_ms("kinship"), ctx.kernel_ms("pack")
-    kin_f32_ms = None
+    kin_f32_ms = kin_f32_pack_ms = None
     if not args.no_f32_kinship:
         cf = ctx.kinship_affine(g)
-        kin_f32_ms = ctx.kernel_ms("kinship")
+        kin_f32_ms, kin_f32_pack_ms = ctx.kernel_ms("kinship"), ctx.kernel_ms("pack")
         if world == 1 and not np.array_equal(cf, counts.astype(np.float64)):
             raise SystemExit("fp32-MFMA and int8-MFMA kinship counts differ")
         del cf
@@ -166,12 +241,36 @@ def main():
         res = bench_multi(args, ctx, coll, g, lmm, eig_L, N, M, Mtot, barrier, common)
     else:
         res = bench_scan(args, ctx, coll, comm_h, g, lmm, est, prep, N, M, Mtot, D, barrier, common, rank, world,
-                         kin_i8_ms, kin_i8_pack_ms, kin_f32_ms)
+                         kin_i8_ms, kin_i8_pack_ms, kin_f32_ms, kin_f32_pack_ms)
         if res is not None and grm is not None:
             res["roofline_kinship"]["grm_exact_i8"] = grm
+    # What the timed region does not show: kinship is sharded, but eigh + REML + the scan model are
+    # REPLICATED on every rank, and a caller of linear_models.emmax() pays for them.  end_to_end_emmax_s = one
+    # lm.emmax()-equivalent call (LinearMixedModel -> emmax_f_test: eigh, REML, device scan model, scan of this rank's
+    # resident SNPs, results on the host) per rank; both are gathered so a scaling curve can be read against them.
+    e2e = None
+    if mode in ("weak", "strong"):
+        t0 = time.time()
+        lmm2 = lm.LinearMixedModel(y, ctx=ctx)
+        lmm2.add_random_effect(K)
+        r2 = lmm2.emmax_f_test(g, emma_num=0)
+        e2e = time.time() - t0
+        e2e_timings = r2.get("timings")
+        del r2, lmm2
+    setup_per_rank = [t_setup]
+    e2e_per_rank = [e2e]
+    if coll is not None:
+        setup_per_rank = [float(v) for v in coll.allgather(np.array([t_setup]))]
+        if e2e is not None:
+            e2e_per_rank = [float(v) for v in coll.allgather(np.array([e2e]))]
     if rank == 0:
         res.update({"eigh_ms": eigh_ms, "model_setup_s": model_s, "setup_s": t_setup, "delta": float(est["delta"]),
-                    "device": info})
+                    "device": info, "setup_s_per_rank": setup_per_rank,
+                    "setup_note": "genotype fill + kinship (SNP-sharded, all-reduced) + eigh + REML + scan model "
+                                  "(replicated on every rank), outside the timed region"})
+        if e2e is not None:
+            res.update({"end_to_end_emmax_s": max(e2e_per_rank), "end_to_end_emmax_s_per_rank": e2e_per_rank,
+                        "end_to_end_emmax_phases_s": e2e_timings})
     if coll is not None:
         coll.barrier()
         coll.close()
@@ -183,7 +282,7 @@ def main():
 
 # ----------------------------------------------------------------------------------------------- the BASELINE metric
 def bench_scan(args, ctx, coll, comm_h, g, lmm, est, prep, N, M, Mtot, D, barrier, common, rank, world, kin_i8_ms,
-               kin_i8_pack_ms, kin_f32_ms):
+               kin_i8_pack_ms, kin_f32_ms, kin_f32_pack_ms):
     from mixmogam_amd import dist as mdist
     n_p = prep["n_p"]
     # Result buffers are allocated once and page-locked (mmg_host_alloc).  Delivery is double buffered: the
@@ -245,27 +344,38 @@ def bench_scan(args, ctx, coll, comm_h, g, lmm, est, prep, N, M, Mtot, D, barrie
                 "algorithmic_bytes": float(-(-m // 256) * 256 * Npad + Dn * Npad * Npad),
                 "executed_int8_tops": ex / (qms * 1e-3) / 1e12,
                 "executed_frac": ex / (qms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
-                "executed_frac_of_sustained_mfma_rate": ex / (qms * 1e-3) / 1e12 / I8_MFMA_SUSTAINED_TOPS}
+                "executed_frac_of_sustained_mfma_rate": ex / (qms * 1e-3) / 1e12 / I8_MFMA_SUSTAINED_TOPS,
+                "sustained_mfma_rate_tops": I8_MFMA_SUSTAINED_TOPS, "sustained_mfma_rate_source": I8_MFMA_SUSTAINED_SOURCE}
 
     traffic = _profiled_traffic(N, M, D, scan_stats["adaptive"])
     roof = roofline_of(per_rank_quad[0], M, scan_stats)
-    roof.update({"traffic": traffic.get(QUAD_KERNEL), "traffic_unit": "bytes per launch (PMC, profiles/traffic_c3.json)"})
+    roof.update({"traffic": traffic.get(QUAD_KERNEL), "traffic_from_profiles": True,
+                 "traffic_unit": "HBM-side bytes per launch from committed rocprofv3 --pmc passes of this command "
+                                 "(profiles/traffic_c3.json: FETCH_SIZE, WRITE_SIZE in separate passes, gfx950 "
+                                 "corrections) -- NOT measured in this run; null when the config differs"})
     ms_per_step = 1e3 * elapsed / args.steps
     kin_exec = 2.0 * 256.0 * 256.0 * (nJ * (nJ + 1) / 2) * M     # lower-triangle tiles x contraction length
-    kin_alg = 2.0 * N * N * M
+    kin_sym = float(N) * (N + 1) * M                             # the symmetric product: N(N+1)/2 entries x 2M flop
+    kin_full = 2.0 * N * N * M                                   # what the reference forms (kinship.py:44)
 
-    def kin_roof(name, ms, peak, unit, extra_ms=None):
-        if ms is None:
+    def kin_roof(name, gemm_ms, peak, unit, pass_ms=0.0, pass_name=None):
+        if gemm_ms is None:
             return None
-        d = {"bound": "mfma", "kernel": name, "ms": ms, "achieved": kin_alg / (ms * 1e-3) / 1e12, "peak": peak,
-             "unit": unit, "frac": kin_alg / (ms * 1e-3) / 1e12 / peak,
+        ms = gemm_ms + (pass_ms or 0.0)                          # everything a caller pays for on the device
+        d = {"bound": "mfma", "kernel": name, "ms": ms, "ms_gemm": gemm_ms, "achieved": kin_sym / (ms * 1e-3) / 1e12,
+             "peak": peak, "unit": unit, "frac": kin_sym / (ms * 1e-3) / 1e12 / peak,
              "executed": kin_exec / (ms * 1e-3) / 1e12, "executed_frac": kin_exec / (ms * 1e-3) / 1e12 / peak,
-             "algorithmic_flop": kin_alg, "executed_flop": kin_exec,
+             "executed_frac_gemm_only": kin_exec / (gemm_ms * 1e-3) / 1e12 / peak,
+             "vs_reference_full_product": kin_full / (ms * 1e-3) / 1e12,
+             "algorithmic_flop": kin_sym, "executed_flop": kin_exec, "reference_full_product_flop": kin_full,
              "algorithmic_bytes": float(M * Npad + 8.0 * N * N), "traffic": traffic.get(name),
-             "note": "algorithmic = the full 2 N^2 M product the reference forms (kinship.py:44); executed = the lower "
-                     "triangle of 256^2 tiles actually run, so `frac` may exceed 1 while `executed_frac` cannot"}
-        if extra_ms is not None:
-            d["transpose_pass_ms"] = extra_ms
+             "traffic_from_profiles": True,
+             "note": "algorithmic = the symmetric product N(N+1)M (K = K'); the reference forms all 2 N^2 M "
+                     "(kinship.py:44): `vs_reference_full_product` is that figure over the same time, a speed-up "
+                     "statement, not a roofline fraction; executed = the lower triangle of 256^2 tiles actually run; "
+                     "`ms` includes every device pass the call needs (ms_gemm + the individual-major image pass)"}
+        if pass_name is not None:
+            d[pass_name] = pass_ms
         return d
 
     res = dict(common)
@@ -281,15 +391,16 @@ def bench_scan(args, ctx, coll, comm_h, g, lmm, est, prep, N, M, Mtot, D, barrie
                    "parallelism": "snp-block x%d" % world,
                    "delivery": "double buffered: step i's results are gathered (RCCL) / downloaded on a second "
                                "stream while step i+1 scans; the last one is awaited inside the timed region",
-                   "cpu_baseline_sample": "bounded sample of the same workload (see cpu_baseline.sample), not all M"},
+                   },
         "roofline": roof,
         "roofline_per_rank": [roofline_of(q, M, scan_stats)["frac"] for q in per_rank_quad],
         "scan_quad_ms_per_rank": per_rank_quad,
-        "finalize_kernel": {"ms": float(np.mean(fin_ms)),
-                            "hbm_gbps": (M * (Npad + 56.0)) / (np.mean(fin_ms) * 1e-3) / 1e9},
+        "finalize_kernel": _finalize_record(N, Npad, M, float(np.mean(fin_ms))),
         # second headline metric: kinship GEMM TFLOP/s vs MFMA peak, one record per kernel
-        "roofline_kinship": {"f32": kin_roof("kinship_f32_kernel", kin_f32_ms, F32_MFMA_PEAK_TFLOPS, "TFLOP/s"),
-                             "i8": kin_roof("kinship_i8_w4_kernel", kin_i8_ms, I8_MFMA_PEAK_TOPS, "TOP/s", kin_i8_pack_ms)},
+        "roofline_kinship": {"f32": kin_roof("kinship_f32_kernel", kin_f32_ms, F32_MFMA_PEAK_TFLOPS, "TFLOP/s",
+                                             kin_f32_pack_ms, "transpose_pass_ms"),
+                             "i8": kin_roof("kinship_i8_w4_kernel", kin_i8_ms, I8_MFMA_PEAK_TOPS, "TOP/s",
+                                            kin_i8_pack_ms, "transpose_pass_ms")},
         "adaptive_scan": scan_stats, "all_planes_reference": all_planes, "min_p": float(np.nanmin(ps)),
     })
     if world == 1 and not args.no_extras:
@@ -297,9 +408,21 @@ def bench_scan(args, ctx, coll, comm_h, g, lmm, est, prep, N, M, Mtot, D, barrie
         res["host_ingest"] = ingest_record(ctx, g, prep, n_p, N, M, ms_per_step)
         res["multi_phenotype"] = multi_record(ctx, g, lmm, N, M)
     if not args.no_cpu_baseline and world == 1:      # reported on rank 0 at N=1 only
-        sample = min(M, args.cpu_sample or 40 * N)
-        res["cpu_baseline"] = cpu_baseline(N, sample, lmm, est, prep, ps[:sample])
+        sample = min(M, args.cpu_sample or M)            # default: every SNP of the workload (the full C3)
+        res["cpu_baseline"] = cpu_baseline(N, sample, lmm, est, prep, ps[:sample], g)
     return res
+
+
+def _finalize_record(N, Npad, M, ms):
+    """The per-SNP pass after the quadratic-form GEMM.  On binary stores with >= 16 padding rows (1 <= N mod 256 <=
+    240; api.hip:scan_lin_usable -- true for the hash / structured genotypes of this bench) the linear terms come out
+    of the GEMM and scan_finalize_lin_kernel moves 16 int32 + 8 B q in and ~5 doubles out per SNP; otherwise
+    scan_finalize_kernel re-reads the store (Npad + 56 B per SNP)."""
+    lin = 1 <= N % 256 <= 240
+    b = (16 * 4 + 8 + 6 * 8.0) if lin else (Npad + 56.0)
+    return {"ms": ms, "kernel": "scan_finalize_lin_kernel" if lin else "scan_finalize_kernel", "bytes_per_snp": b,
+            "hbm_gbps": M * b / (ms * 1e-3) / 1e9, "peak_gbps": HBM_PEAK_GBPS,
+            "note": "launch-latency sized on the lin path (0.05 ms): not a bandwidth statement"}
 
 
 def _all_planes_reference(ctx, g, prep, n_p, ps_adaptive):
@@ -311,7 +434,7 @@ def _all_planes_reference(ctx, g, prep, n_p, ps_adaptive):
     dt_all = (time.time() - t1) / 2
     ref_out = ctx.scan(g, prep["h0_rss"], n_p)
     ok = ref_out["ps"] > 1e-290
-    return {"ms_per_scan_kernels_only": 1e3 * dt_all, "scan_quad_ms": ctx.kernel_ms("scan_quad"),
+    return {"repeats": 2, "ms_per_scan_kernels_only": 1e3 * dt_all, "scan_quad_ms": ctx.kernel_ms("scan_quad"),
             "snps_per_s_kernels_only": len(ps_adaptive) / dt_all,
             "max_rel_p_diff_adaptive_vs_all_planes": float(np.max(np.abs(ps_adaptive[ok] / ref_out["ps"][ok] - 1)))}
 
@@ -363,7 +486,7 @@ def structured_record(ctx, N, M, exec_ops_of):
     return {"workload": "N=%d x M=%d, 3 populations (mmg_geno_fill_structured, spread 0.15), 120 causal SNPs, h2 0.8" % (N, M),
             "pseudo_heritability": float(est["pseudo_heritability"]), "min_p": float(ada["ps"].min()),
             "n_p_below_1e-8": int((ada["ps"] < 1e-8).sum()), "adaptive_scan": stats,
-            "ms_per_scan_kernels_only": 1e3 * dt, "scan_quad_ms": qms, "value_adaptive": M / dt,
+            "repeats": reps, "ms_per_scan_kernels_only": 1e3 * dt, "scan_quad_ms": qms, "value_adaptive": M / dt,
             "value_all_planes": allp["snps_per_s_kernels_only"], "all_planes_reference": allp,
             "executed_frac": exec_ops_of(stats, M) / (qms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS}
 
@@ -376,15 +499,19 @@ def ingest_record(ctx, g, prep, n_p, N, M, ms_per_step):
     rows = min(M, 250000)                       # a quarter of C3: 1.25 GB int8 / 5 GB fp32 of host memory
     host8 = g.download(0, rows)
     g2 = ctx.geno(M=rows, N=N)
-    g2.upload(host8)                            # warm-up (first touch of the pageable pages)
-    t0 = time.time()
-    g2.upload(host8)
-    t8 = time.time() - t0
+    reps = 3
+
+    def timed_upload(buf):
+        g2.upload(buf)                          # warm-up (first touch of the pageable pages)
+        ts = []
+        for _ in range(reps):
+            t0 = time.time()
+            g2.upload(buf)
+            ts.append(time.time() - t0)
+        return float(np.median(ts))
+    t8 = timed_upload(host8)
     host32 = host8.astype(np.float32)
-    g2.upload(host32)
-    t0 = time.time()
-    g2.upload(host32)
-    t32 = time.time() - t0
+    t32 = timed_upload(host32)
     same = np.array_equal(g2.download(), host8)
     g2.close()
     # pipelined: chunks uploaded on a second stream by the prefetch thread while the previous chunk is scanned
@@ -394,15 +521,18 @@ def ingest_record(ctx, g, prep, n_p, N, M, ms_per_step):
     plan = hdf5_data._chunk_plan(src, 0.1, 50000)
     for _ci, _c, gg in hdf5_data._resident_chunks(ctx, src, plan[:2], reuse=True):     # allocate the two chunk stores
         ctx.scan(gg, prep["h0_rss"], n_p, fetch=True)
-    t0 = time.time()
-    for _ci, _c, gg in hdf5_data._resident_chunks(ctx, src, plan, reuse=True):
-        ctx.scan(gg, prep["h0_rss"], n_p, fetch=True)
-        gg.close()
-    t_pipe = time.time() - t0
+    t_pipes = []
+    for _ in range(reps):
+        t0 = time.time()
+        for _ci, _c, gg in hdf5_data._resident_chunks(ctx, src, plan, reuse=True):
+            ctx.scan(gg, prep["h0_rss"], n_p, fetch=True)
+            gg.close()
+        t_pipes.append(time.time() - t0)
+    t_pipe = float(np.median(t_pipes))
     del host_all
     hdf5_data.release_pools()
     scan_s = ms_per_step * 1e-3 * rows / M
-    return {"sample_rows": rows, "int8_upload_gbps": rows * N / t8 / 1e9, "f32_upload_convert_gbps": rows * N * 4.0 / t32 / 1e9,
+    return {"repeats": reps, "sample_rows": rows, "int8_upload_gbps": rows * N / t8 / 1e9, "f32_upload_convert_gbps": rows * N * 4.0 / t32 / 1e9,
             "f32_ingest_round_trip_exact": bool(same),
             "value_h2d_inclusive_int8_serial": rows / (t8 + scan_s),
             "value_h2d_inclusive_f32_serial": rows / (t32 + scan_s),
@@ -454,14 +584,17 @@ def multi_record(ctx, g, lmm, N, M, P=16):
     rot_ms = ctx.kernel_ms("rotate")
     h0 = np.array([m["h0_rss"] for m in models])
     ctx.scan_multi(rot, d, omega, G, h0, N - 2, want=("ps",))
-    t0 = time.time()
-    ctx.scan_multi(rot, d, omega, G, h0, N - 2, want=("ps",))
-    wall = time.time() - t0
-    ms = ctx.kernel_ms("scan_multi")
+    reps, walls, mss = 3, [], []
+    for _ in range(reps):
+        t0 = time.time()
+        ctx.scan_multi(rot, d, omega, G, h0, N - 2, want=("ps",))
+        walls.append(time.time() - t0)
+        mss.append(ctx.kernel_ms("scan_multi"))
+    wall, ms = float(np.median(walls)), float(np.median(mss))
     rot.close()
     from mixmogam_amd._lib import scan_multi_batch
     npass = -(-P // scan_multi_batch())
-    return {"phenotypes": P, "phenotypes_per_pass": scan_multi_batch(), "rotation_gemm_ms": rot_ms,
+    return {"repeats": reps, "phenotypes": P, "phenotypes_per_pass": scan_multi_batch(), "rotation_gemm_ms": rot_ms,
             "rotation_executed_int8_tops": 2.0 * 4 * (-(-N // 256) * 256) * (-(-N // 64) * 64) * M / (rot_ms * 1e-3) / 1e12,
             "pass_ms": ms / npass, "passes": npass, "ms_per_phenotype_scan": ms / P,
             "value_snp_phenotype_scans_per_s": M * P / (wall), "value_kernels_only": M * P / (ms * 1e-3),
@@ -609,37 +742,50 @@ def _device_rows(ctx, rows, n, seed):
     return np.vstack(out)
 
 
-def cpu_baseline(N, sample, lmm, est, prep, gpu_ps):
+def cpu_baseline(N, sample, lmm, est, prep, gpu_ps, g):
     """The reference's loop structure (chunks of N SNPs, float32 `chunk @ M` GEMM, one
     scipy.linalg.lstsq per SNP, scipy.stats.f.sf -- linear_models.py:1315-1349) as restated in
-    oracle/emmax_oracle.py:scan_loop, timed on this box's host cores on the first `sample` SNPs
-    of the same workload.  Reported, not a target."""
+    oracle/emmax_oracle.py:scan_loop, timed on this box's host cores over the first `sample` SNPs of the same
+    workload (default: all of them).  The genotype rows come from the device store block by block (untimed; the
+    first block is checked against the oracle's own host generator, the two share the counter hash).  Reported,
+    not a target."""
     from scipy import linalg
     from oracle import emmax_oracle as orc
-    snps = orc.hash_genotypes(0, sample, N, 20240)
     H = np.asarray(est["H_sqrt_inv"])
     h0_X = H @ lmm.X
     Q, _ = linalg.qr(h0_X, mode="economic")
     Mp = (H - Q @ (Q.T @ H)).T                                   # H'(I - QQ'), O(N^2 q)
     p = {"n": N, "q": lmm.X.shape[1], "Mp": Mp, "r": prep["r"], "h0_rss": prep["h0_rss"], "h0_betas": prep["h0_betas"]}
-    t0 = time.time()
-    out = orc.scan_loop(snps, p, dtype=np.float32)
-    dt = time.time() - t0
-    agree = float(np.nanmax(np.abs(out["ps"][:len(gpu_ps)] / gpu_ps[:len(out["ps"])] - 1)))
+    block = 20 * N                                               # 20 of the reference's chunks per download
+    dt, agree, first = 0.0, 0.0, None
+    for c0 in range(0, sample, block):
+        rows = min(block, sample - c0)
+        snps = g.download(c0, rows)
+        if first is None:
+            first = snps[:N].copy()
+            if not np.array_equal(first, orc.hash_genotypes(0, len(first), N, 20240)):
+                raise SystemExit("device genotypes differ from the oracle's host generator")
+        t0 = time.time()
+        out = orc.scan_loop(snps, p, dtype=np.float32)
+        dt += time.time() - t0
+        agree = max(agree, float(np.nanmax(np.abs(out["ps"] / gpu_ps[c0:c0 + rows] - 1))))
     blas, blas4 = "unknown", None
     try:
         import threadpoolctl
         blas = ";".join("%s:%s" % (d.get("internal_api"), d.get("num_threads")) for d in threadpoolctl.threadpool_info())
-        # the reference pins its BLAS to 4 threads (linear_models.py:37): the same loop on a quarter of the sample
+        # the reference pins its BLAS to 4 threads (linear_models.py:37): the same loop on a bounded sample
+        n4 = min(sample, 20 * N)
+        snps = g.download(0, n4)
         with threadpoolctl.threadpool_limits(limits=4):
             t0 = time.time()
-            orc.scan_loop(snps[:max(N, sample // 4)], p, dtype=np.float32)
-            blas4 = max(N, sample // 4) / (time.time() - t0)
+            orc.scan_loop(snps, p, dtype=np.float32)
+            blas4 = n4 / (time.time() - t0)
     except Exception:
         pass
     return {"value": sample / dt, "value_blas_4_threads": blas4, "unit": "SNPs/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "first %d SNPs of the same workload (chunks of N), fp32 reference loop, %.1f s; BLAS %s"
-                      % (sample, dt, blas),
+            "sample": "%s %d SNPs of the same workload (chunks of N), fp32 reference loop, %.1f s; BLAS %s; "
+                      "4-thread figure on the first %d SNPs"
+                      % ("all" if sample == g.M else "first", sample, dt, blas, min(sample, 20 * N)),
             "max_rel_p_diff_vs_gpu": agree}
 
 

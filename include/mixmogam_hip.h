@@ -126,9 +126,9 @@ int mmg_kin_acc_create(mmg_ctx* ctx, int32_t N, mmg_kin_acc** acc);
 int mmg_kin_acc_add(mmg_ctx* ctx, mmg_kin_acc* acc, mmg_geno* g, const float* scale, const float* shift);
 /* GRM chunk (kinship.py:66-69, hdf5_data.py:99-106): acc += sum_m z_m z_m' with z = (s - mean)/std computed per SNP on
  * the device in fp64 -- EXACT route: z z' = a^2 s s' + a b (s 1' + 1 s') + b^2 1 1'; the weighted Gram matrix
- * sum_m s s'/std^2 is 4-5 int8-MFMA GEMMs of the IBS kind (the weight 1/std^2 split into balanced digits folded into
+ * sum_m s s'/std^2 is 4-5 int8-MFMA GEMMs of the IBS kind (the weight 1/std^2 split into non-negative digits folded into
  * one operand), the rank-one terms fp64 dot products.  ~5x faster than the fp32-MFMA kernel and good to ~1e-9; falls
- * back to that kernel for genotype alphabets beyond 0..4.  A SNP with std == 0 is an error (kinship.py:67). */
+ * back to that kernel for genotype alphabets beyond -4..4.  A SNP with std == 0 is an error (kinship.py:67). */
 int mmg_kin_acc_add_grm(mmg_ctx* ctx, mmg_kin_acc* acc, mmg_geno* g);
 int mmg_kin_acc_fetch(mmg_ctx* ctx, mmg_kin_acc* acc, double* C_out, int64_t* n_snps);
 int mmg_kin_acc_destroy(mmg_ctx* ctx, mmg_kin_acc* acc);
@@ -292,6 +292,11 @@ int mmg_emmax_perm_after_scan(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int32_t
  * points are create + run + destroy. */
 int mmg_perm_plan_create(mmg_ctx* ctx, int32_t N, const double* Ht, const double* Ys, int32_t P, double h0_rss,
                          mmg_perm_plan** plan);
+/* flags bit 0: do NOT mean-centre the SNPs before the transform, t_m = Ht s_m as given.  The public
+ * LinearMixedModel.emmax_permutations (linear_models.py:1180-1230) centres the TRANSFORMED SNP instead
+ * (Xs - mean(Xs), :1211): t_m = C H s_m with C = I - 11'/n, i.e. this plan built on Ht = C H.  Stand-alone runs only. */
+int mmg_perm_plan_create_ex(mmg_ctx* ctx, int32_t N, const double* Ht, const double* Ys, int32_t P, double h0_rss,
+                            int flags, mmg_perm_plan** plan);
 int mmg_perm_plan_run(mmg_ctx* ctx, mmg_comm* comm, mmg_perm_plan* plan, mmg_geno* g, const double* HtQ, int32_t q,
                       double* min_rss);
 int mmg_perm_plan_destroy(mmg_ctx* ctx, mmg_perm_plan* plan);

@@ -93,6 +93,7 @@ PROTOTYPES = {
     "mmg_emmax_perm_after_scan": (C.c_int, [c_vp, c_vp, c_vp, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, c_vp,
                                             C.c_int32, c_vp]),
     "mmg_perm_plan_create": (C.c_int, [c_vp, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, C.POINTER(c_vp)]),
+    "mmg_perm_plan_create_ex": (C.c_int, [c_vp, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, C.c_int, C.POINTER(c_vp)]),
     "mmg_perm_plan_run": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int32, c_vp]),
     "mmg_perm_plan_destroy": (C.c_int, [c_vp, c_vp]),
     "mmg_comm_info": (C.c_int, [c_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -131,6 +132,13 @@ def load():
         return lib
 
 
+def device_count():
+    """Number of HIP devices the library sees (mmg_device_count); 0 when there is none or the runtime fails."""
+    n = C.c_int(0)
+    rc = load().mmg_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(c_vp)
 
@@ -148,7 +156,11 @@ def as_store_array(snps):
     a = np.asarray(snps)
     if a.ndim != 2:
         raise ValueError("snps must be [num_snps x num_individuals]")
-    if a.dtype == np.int8 or a.dtype in (np.float32, np.float64):
+    if a.dtype == np.int8:
+        if a.size and int(a.min()) == -128:
+            raise ValueError("genotype value -128 is outside the store's range [-127, 127]")
+        return np.ascontiguousarray(a)
+    if a.dtype in (np.float32, np.float64):
         return np.ascontiguousarray(a)
     if a.dtype == np.bool_:
         return np.ascontiguousarray(a, dtype=np.int8)
@@ -314,13 +326,14 @@ class PermPlan(object):
     """SNP-independent half of the EMMAX permutation test on the device (mmg_perm_plan_*): built once per (H, Ys),
     run over any number of genotype stores."""
 
-    def __init__(self, ctx, H, Ys, h0_rss):
+    def __init__(self, ctx, H, Ys, h0_rss, centre_snps=True):
         H = _arr(H, np.float64)
         Ys = _arr(Ys, np.float64)
         self.ctx, self.N, self.P = ctx, H.shape[0], Ys.shape[1]
         assert H.shape == (self.N, self.N) and Ys.shape[0] == self.N
         h = c_vp()
-        ctx._check(ctx.lib.mmg_perm_plan_create(ctx.h, self.N, _ptr(H), _ptr(Ys), self.P, float(h0_rss), C.byref(h)))
+        ctx._check(ctx.lib.mmg_perm_plan_create_ex(ctx.h, self.N, _ptr(H), _ptr(Ys), self.P, float(h0_rss),
+                                                   0 if centre_snps else 1, C.byref(h)))
         self.h = h
 
     def run(self, g, comm=None, after_scan_HtQ=None):
@@ -525,8 +538,8 @@ class Context(object):
     def reml(self, K, X, y):
         return Reml(self, K, X, y)
 
-    def perm_plan(self, H, Ys, h0_rss):
-        return PermPlan(self, H, Ys, h0_rss)
+    def perm_plan(self, H, Ys, h0_rss, centre_snps=True):
+        return PermPlan(self, H, Ys, h0_rss, centre_snps)
 
     def scan_multi(self, rot, d, omega, G, h0_rss, df2, want=("rss", "f_stats", "ps"), out=None):
         """P phenotypes over the rotated store: d, omega [P x N], G [P x q x N], h0_rss [P] -> {'rss','f_stats','ps'}

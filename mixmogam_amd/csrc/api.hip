@@ -254,9 +254,20 @@ int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, i
   g->bits_valid = false; ++g->version;
   MMG_HIP(ctx, hipMemcpy2DAsync(g->d + m0 * (int64_t)g->Npad, g->Npad, snps, g->N, g->N, rows,
                                 hipMemcpyHostToDevice, ctx->stream));
+  const int prev[2] = {g->smax, g->sneg};
   int rc = refresh_smax(ctx, g, m0, rows);
   if (rc) return rc;
-  if (g->smax > 127) return set_err(ctx, MMG_E_ARG, "genotype value -128 is outside the store's range [-127, 127]");
+  if (g->smax > 127) {
+    // -128 has no negation in int8.  The running bounds are maxima, so a bad block must not stay behind: zero the rows
+    // just written and put the bounds (host and device copies) back, or every later upload into this store would fail
+    // the same check on valid data (advisor r2).
+    MMG_HIP(ctx, hipMemsetAsync(g->d + m0 * (int64_t)g->Npad, 0, (size_t)rows * g->Npad, ctx->stream));
+    MMG_HIP(ctx, hipMemcpyAsync(g->d_smax, prev, 2 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    g->smax = prev[0]; g->sneg = prev[1];
+    return set_err(ctx, MMG_E_ARG, "genotype value -128 is outside the store's range [-127, 127]; the rows of this "
+                                   "upload were zeroed");
+  }
   return MMG_OK;
 }
 
@@ -559,8 +570,8 @@ int mmg_kin_acc_add(mmg_ctx* ctx, mmg_kin_acc* a, mmg_geno* g, const float* scal
 
 // Exact GRM (kinship.py:63-69, hdf5_data.py:99-106): K (+)= sum_m z_m z_m', z_m = (s_m - mean_m) / std_m.
 //     z z' = a^2 s s' + a b (s 1' + 1 s') + b^2 1 1',   a = 1/std, b = -mean/std
-// The first term is a Gram matrix weighted per SNP by omega_m = 1/std_m^2.  omega is written as D balanced digits
-// whose range makes digit * s fit int8 (8 bits for 0/1 genotypes, 7 for 0/1/2, 6 up to 4); each digit plane is then
+// The first term is a Gram matrix weighted per SNP by omega_m = 1/std_m^2.  omega is written as D non-negative digits
+// whose range makes digit * s fit int8 (7 bits for alphabets within +-1, 6 within +-2, 5 within +-4); each digit plane is then
 // ONE exact int8-MFMA GEMM of the IBS kind (digit image x plain image, upper tiles only) -- 4-5 planes at 32x the
 // fp32-MFMA rate instead of the fp32 GEMM, and entries good to ~1e-9 instead of fp32 products.  The rank-one terms
 // are two dot-product passes in fp64.  Returns MMG_E_STATE (caller falls back to the fp32 kernel) when the genotype
@@ -570,10 +581,18 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
   auto now = [&]() { (void)hipStreamSynchronize(ctx->stream); return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double tv0 = verbose ? now() : 0.0;
   double tv_alloc = 0.0, tv_pack = 0.0, tv_gemm = 0.0, tv_tail = 0.0;
+  // NON-NEGATIVE digits of the (positive) weight: digit * s must fit int8 for every genotype value, negative codes
+  // included (|s| <= smax covers both signs: the store tracks max|s|), so digits are 7 / 6 / 5 bits wide for
+  // alphabets within +-1 / +-2 / +-4.  Round 2 used balanced digits one bit wider -- their most negative value times a
+  // negative genotype wrapped (advisor r2), and two's-complement negatives cost ~6 % of the power-limited MFMA rate
+  // (tools/probe/mfma_digit_range.hip).  >= 30 bits of the largest weight; binary stores of >= 2^16 SNPs take 4
+  // planes (28 bits: the roundings are independent per SNP and average down as 1/sqrt(M)).
   int bd = 0;
-  if (g->smax <= 1) bd = 8; else if (g->smax <= 2) bd = 7; else if (g->smax <= 4) bd = 6;
+  if (g->smax <= 1) bd = 7; else if (g->smax <= 2) bd = 6; else if (g->smax <= 4) bd = 5;
   if (bd == 0) return MMG_E_STATE;
-  const int D = (30 + bd - 1) / bd;                        // >= 30 bits of the weight: 4, 5, 5 planes
+  int D = (30 + bd - 1) / bd;                              // 5, 5, 6 planes
+  if (bd == 7 && g->M >= 65536) D = 4;
+  if (const char* e = std::getenv("MMG_GRM_PLANES")) { const int v = std::atoi(e); if (v >= 4 && v <= 6) D = v; }
   const double base = (double)(1 << bd);
   const int64_t M = g->M, CH = kin_chunk();
   const int64_t Mk_max = std::min(round_up(M, BK), CH);
@@ -614,15 +633,14 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
     c0 += mean[m] * mean[m] * omega[m];                    // b^2
     wmax = std::max(wmax, omega[m]);
   }
-  // D balanced digits reach (B/2 - 1)(B^D - 1)/(B - 1) (0.996 / 0.992 / 0.984 of 2^(bd*D - 1) for B = 256 / 128 / 64):
-  // the largest weight is scaled onto exactly that
-  const double step = wmax / std::floor((base / 2 - 1) * (std::pow(base, D) - 1) / (base - 1));
+  // D unsigned digits reach B^D - 1: the largest weight is scaled onto exactly that
+  const double step = wmax / (std::pow(base, D) - 1.0);
   MMG_HIP(ctx, hipMemsetAsync(C32, 0, (size_t)D * g->Npad * g->Npad * sizeof(int), ctx->stream));
   if (verbose) tv_alloc = now();
   std::vector<double> c1((size_t)g->Npad, 0.0), c1part((size_t)g->Npad);
   std::vector<int8_t> dig((size_t)D * Mk_max);
   std::vector<double> cf((size_t)Mk_max);
-  const long long half = 1ll << (bd - 1), mask = (1ll << bd) - 1;
+  const long long mask = (1ll << bd) - 1;
   int rc = MMG_OK;
   double kin_ms = 0.0;
   for (int64_t mb = 0; mb < M && rc == MMG_OK; mb += CH) {
@@ -630,11 +648,10 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
     std::fill(dig.begin(), dig.end(), (int8_t)0);
     std::fill(cf.begin(), cf.end(), 0.0);
     for (int64_t k = 0; k < Mk && mb + k < M; ++k) {
-      long long Z = std::llrint(omega[mb + k] / step);
+      long long Z = std::llrint(omega[mb + k] / step);       // in [0, B^D - 1]
       for (int d = 0; d < D; ++d) {
-        const long long z = ((Z + half) & mask) - half;
-        Z = (Z - z) >> bd;
-        dig[(size_t)d * Mk + k] = (int8_t)z;
+        dig[(size_t)d * Mk + k] = (int8_t)(Z & mask);
+        Z >>= bd;
       }
       cf[k] = coef[mb + k];
     }
@@ -1364,6 +1381,7 @@ struct mmg_perm_plan {
   double *dmu = nullptr, *dinv = nullptr, *dmax = nullptr, *dvecs = nullptr, *ddots = nullptr;
   int64_t cap = 0;               // SNP capacity of dmu / dinv / ddots
   int qcap = 0;
+  bool centred = true;           // SNPs are mean-centred before the transform (:1159); false: t = Ht s as given
 };
 
 static void perm_plan_free(mmg_perm_plan* p) {
@@ -1375,11 +1393,17 @@ static void perm_plan_free(mmg_perm_plan* p) {
 
 int mmg_perm_plan_create(mmg_ctx* ctx, int32_t N, const double* Ht, const double* Ys, int32_t P, double h0_rss,
                          mmg_perm_plan** out) {
+  return mmg_perm_plan_create_ex(ctx, N, Ht, Ys, P, h0_rss, 0, out);
+}
+
+int mmg_perm_plan_create_ex(mmg_ctx* ctx, int32_t N, const double* Ht, const double* Ys, int32_t P, double h0_rss,
+                            int flags, mmg_perm_plan** out) {
   Scratch sc;
   MMG_ENTER(ctx);
-  MMG_CHECK_ARG(ctx, out && Ht && Ys && N > 0 && P > 0);
+  MMG_CHECK_ARG(ctx, out && Ht && Ys && N > 0 && P > 0 && (flags & ~1) == 0);
   *out = nullptr;
   mmg_perm_plan* p = new mmg_perm_plan();
+  p->centred = !(flags & 1);
   p->N = N; p->Npad = (int32_t)round_up(N, 256); p->P = P; p->Ppad = (int)round_up(P, 64); p->h0_rss = h0_rss;
   p->yy.assign((size_t)P, 0.0);
   for (int i = 0; i < N; ++i)
@@ -1417,8 +1441,10 @@ int mmg_perm_plan_create(mmg_ctx* ctx, int32_t N, const double* Ht, const double
   for (int i = 0; i < N; ++i) p->c0 += h1[i] * h1[i];                       // 1'H'H 1
   // centred operands (k_perm.hip): A'' = C A' C is the model of the stand-alone test's t.t (adaptive digit schedule
   // as in the scan unless MMG_SCAN_ADAPTIVE=0), W'' = C W the GEMM operand of both paths (s~.W_p = s.(C W_p))
-  launch_center_sym(ctx, dA, N, p->dv, p->c0);
-  launch_center_rows(ctx, dWt, N, P);
+  if (p->centred) {
+    launch_center_sym(ctx, dA, N, p->dv, p->c0);
+    launch_center_rows(ctx, dWt, N, P);
+  }
   {
     const char* e = std::getenv("MMG_SCAN_ADAPTIVE");
     rc = model_from_device(ctx, p->pm, N, dA, p->dv, 4, !(e && e[0] == '0'));
@@ -1443,6 +1469,8 @@ int mmg_perm_plan_run(mmg_ctx* ctx, mmg_comm* comm, mmg_perm_plan* p, mmg_geno* 
   MMG_CHECK_ARG(ctx, p && g && min_rss && g->N == p->N && (HtQ == nullptr || q >= 1));
   const bool reduce = comm && comm->world > 1;
   const bool reuse = HtQ != nullptr;
+  if (reuse && !p->centred)
+    return set_err(ctx, MMG_E_ARG, "mmg_perm_plan_run: the after-scan form needs a plan with centred SNPs");
   if (reuse && (ctx->res.geno != g || ctx->res.geno_version != g->version || ctx->res.M != g->M || ctx->model.N != p->N))
     return set_err(ctx, MMG_E_STATE, "mmg_perm_plan_run: the last mmg_emmax_scan_device of this context was not over this "
                                      "genotype store in its current state");

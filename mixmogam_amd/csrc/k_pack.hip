@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const int8_t* __restrict
 }
 
 // Weighted twin for the exact GRM (api.hip:kinship_grm_i8_into): one pass over S writes the plain image Xq[i][m] = s
-// and D digit images Xp[d][i][m] = dig[d][m] * s, where dig holds balanced digits of the per-SNP weight 1/std^2 whose
+// and D digit images Xp[d][i][m] = dig[d][m] * s, where dig holds non-negative digits of the per-SNP weight 1/std^2 whose
 // range was chosen so that every product fits int8.  Images are [Npad x Mk], digit image d at Xp + d * Npad * Mk.
 template <int D>
 __global__ __launch_bounds__(256) void transpose_digits_kernel(const int8_t* __restrict__ S, int64_t M, int32_t N,

@@ -182,7 +182,7 @@ def _ibd_kinship(ctx, genot_data, n_indivs, plan, coll=None, prefetch=True):
     k_mat, n_snps = acc.fetch()
     acc.close()
     n_all = sum(len(sel) for _c, sel, _p in plan)
-    assert n_snps == n_all or coll is None or world == 1 or n_snps == n_all, (n_snps, n_all)
+    assert n_snps == n_all, (n_snps, n_all)                              # after the all-reduce: every rank's chunks counted
     k_mat = k_mat / float(n_all)                                         # :107
     return kinship.scale_k(k_mat), n_all                                 # :108-111 (inline scale_k)
 
@@ -276,6 +276,9 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
         n_snps = sum(len(sel) for _c, sel, _p in plan)
     lmm = lm.LinearMixedModel(phenotypes, ctx=ctx)                       # :121
     lmm.add_random_effect(k)
+    if eigen_free and num_perm:
+        raise ValueError("run_emmax: the permutation test needs H_sqrt_inv, which the eigendecomposition-free route "
+                         "does not produce -- call with eigen_free=False (or None) when num_perm > 0")
     if eigen_free is None:
         eigen_free = n > 46340 and not num_perm and isinstance(ctx, _lib.Context)
     res = lmm._try_eigen_free(coll=coll) if eigen_free else None         # :126-137 without either eigendecomposition

@@ -178,13 +178,28 @@ class _SpectralSumsChol(object):
         coll = self.coll
         if coll is not None and coll.world > 1 and len(deltas) >= coll.world:
             mine = np.arange(coll.rank, len(deltas), coll.world)
-            part = self.reml.sums(deltas[mine])
+            # A factorisation may fail on SOME ranks only (an indefinite K: the smallest deltas sit on the low ranks).
+            # Every rank must still enter the all-gather, so the failure travels as a flag row of the gathered block
+            # and all ranks raise together afterwards (advisor r2: a rank that left early hung the others).
+            failure = None
+            try:
+                part = self.reml.sums(deltas[mine])
+            except _lib.MixmogamHipError as e:
+                failure, part = e, None
             self.n_factorisations += len(mine)
             count = -(-len(deltas) // coll.world)
-            blk = np.full((4, count), np.nan)
-            for k in range(4):
-                blk[k, :len(mine)] = part[k]
-            allb = np.asarray(coll.allgather(blk.reshape(-1))).reshape(coll.world, 4, count)
+            blk = np.full((5, count), np.nan)
+            blk[4, :] = 0.0 if failure is None else 1.0
+            if part is not None:
+                for k in range(4):
+                    blk[k, :len(mine)] = part[k]
+            allb = np.asarray(coll.allgather(blk.reshape(-1))).reshape(coll.world, 5, count)
+            failed = [r for r in range(coll.world) if allb[r, 4, 0] != 0.0]
+            if failed:
+                if failure is not None:
+                    raise failure
+                raise _lib.MixmogamHipError("K + delta*I is not positive definite on rank(s) %s of the shared REML grid"
+                                            % failed)
             out = [np.empty(len(deltas)) for _ in range(4)]
             for r in range(coll.world):
                 idx = np.arange(r, len(deltas), coll.world)
@@ -622,19 +637,26 @@ class LinearMixedModel(object):
         """:1272-1380.  `snps`: list of M arrays / [M x N] array, or a device-resident _lib.Geno.
         _delta (internal): build the scan model from K and this variance ratio on the device instead of from
         H_sqrt_inv on the host (same matrix: Mp Mp' = P(delta))."""
-        if return_transformed_snps:
-            raise NotImplementedError("return_transformed_snps (used by MLMM, SURVEY 8f N1) is not on the "
-                                      "device path yet")
         ctx = self.ctx
+        if return_transformed_snps and (H_sqrt_inv is None or with_betas):
+            # the reference's M is H' itself under with_betas (:1305); only the projected form is on the device path
+            raise NotImplementedError("return_transformed_snps needs H_sqrt_inv and with_betas=False")
+        prep = None
         if _delta is not None and Z is None and not with_betas:
             reml = _reml if _reml is not None else ctx.reml(self.random_effects[1][1], self.X, self.Y.reshape(-1))
             try:
                 h0_rss_d, beta_d = reml.scan_model(_delta, ndigits)
+                prep = {'h0_rss': h0_rss_d, 'h0_betas': [float(b) for b in beta_d],
+                        'n_p': self.n - (self.X.shape[1] + 1)}
+            except _lib.MixmogamHipError as e:
+                # an indefinite kinship has no Cholesky factor of K + delta I: callers that hold H_sqrt_inv (mlmm,
+                # the chunked drivers) get the model built from it instead; without it the error stands
+                if H_sqrt_inv is None or "positive definite" not in str(e):
+                    raise
             finally:
                 if _reml is None:
                     reml.close()
-            prep = {'h0_rss': h0_rss_d, 'h0_betas': [float(b) for b in beta_d], 'n_p': self.n - (self.X.shape[1] + 1)}
-        else:
+        if prep is None:
             prep = self.scan_prepare(H_sqrt_inv, Z=Z, with_betas=with_betas)
         own = not isinstance(snps, _lib.Geno)
         g = ctx.geno(kinship._as_snp_matrix(snps)) if own else snps
@@ -661,6 +683,8 @@ class LinearMixedModel(object):
                     else:
                         betas.append(list(prep['h0_betas']))
                 res_d['betas'] = betas
+            if return_transformed_snps:                                  # :1309-1321,:1355-1356
+                res_d['t_snps'] = self._transformed_snps(g, H_sqrt_inv, Z)
             if snp_priors is not None:                                   # :1311-1314,:1357-1363
                 snp_priors = np.asarray(snp_priors, dtype=np.float64)
                 n = self.n
@@ -681,6 +705,29 @@ class LinearMixedModel(object):
             if own:
                 g.close()
         return res_d
+
+    def _transformed_snps(self, g, H_sqrt_inv, Z=None):
+        """t_m = s_m Mp, Mp = H'(I - QQ') (:1300-1303,1318-1321): what the reference's loop regresses the residual
+        on, returned as a list of M arrays like the reference's `t_snps`.  T = S Mp is the rotation GEMM of the
+        multi-phenotype path with the rows of Mp' = (I - QQ')H in place of the eigenvectors (mmg_rot_load: exact int8
+        digit GEMM, 2^-31 of each row's largest entry).  With replicates (Z: n values x n_geno individuals) Mp' is
+        not square and the product is a device dgemm instead."""
+        H = np.asarray(H_sqrt_inv, dtype=np.float64)
+        h0_X = H @ self.X
+        if Z is not None:
+            H = H @ np.asarray(Z, dtype=np.float64)
+        (Q, _R) = linalg.qr(h0_X, mode='economic')
+        MpT = H - Q @ (Q.T @ H)                                          # (I - QQ') H = Mp'   [n x n_geno]
+        if MpT.shape[0] != MpT.shape[1] or g.M == 0:
+            S = g.download().astype(np.float64)
+            T = self.ctx.dgemm(MpT, S, tb=True) if g.M else np.zeros((MpT.shape[0], 0))
+        else:
+            rot = self.ctx.rot(np.ascontiguousarray(MpT), g.M)
+            try:
+                T = rot.load(g).fetch()                                  # [n x M]: T[i][m] = Mp'[i] . s_m
+            finally:
+                rot.close()
+        return list(np.ascontiguousarray(T.T))
 
     # ------------------------------------------------------------------ permutations
     def perm_prepare(self, H_sqrt_inv, num_perm=100, perm_idx=None):
@@ -723,13 +770,75 @@ class LinearMixedModel(object):
         min_pvals = ctx.f_sf(max_f_stats, pp['n_p'])                     # :1172
         return {'min_ps': min_pvals, 'max_f_stats': max_f_stats}
 
-    def emmax_permutations(self, snps, num_perm, method='REML', perm_idx=None):
-        """:1180-1230.  The reference indexes a per-permutation array by SNP (:1219) and fails for
-        num_snps > num_perm; this does what its docstring says via _emmax_permutations_."""
-        K = self.random_effects[1][1]
-        eig_L = self._get_eigen_L_(K)
-        res = self.get_estimates(eig_L=eig_L, method=method)
-        return self._emmax_permutations_(snps, K, res['H_sqrt_inv'], num_perm=num_perm, perm_idx=perm_idx)
+    def emmax_permutations(self, snps, num_perm, method='REML', perm_idx=None, H_sqrt_inv=None,
+                           reference_indexing=False):
+        """:1180-1230 -- the PUBLIC permutation test (emmax_perm_test's worker).  Its arithmetic is not that of
+        _emmax_permutations_ (:1125): Y is not centred, the null fit is subtracted once (:1200), and the SNP is
+        centred AFTER the transform, Xs - mean(Xs) (:1211), i.e. t_m = C H s_m with C = I - 11'/n -- the device
+        test run on Ht = C H without SNP centring (mmg_perm_plan_create_ex flag 1).
+
+        The reference then stores `rss_list.min()` -- the minimum over PERMUTATIONS of SNP i+j -- at index i+j of a
+        per-permutation array (:1213): an IndexError once num_snps > num_perm, and otherwise not what its docstring
+        ("the list of max_pvals and max_fstats" per permutation) describes.  Default here: what the docstring says,
+        min over SNPs per permutation.  reference_indexing=True reproduces the reference's literal output (first
+        num_snps slots = per-SNP minima over the permutations, the rest h0_rss; IndexError beyond num_perm SNPs) so
+        that the wrapper can be checked against the reference's own numbers.
+
+        perm_idx: optional [num_perm x n] index matrix (column p of Ys = r[perm_idx[p]]); None draws successive
+        in-place numpy.random.shuffle calls as the reference does (:1202-1205).  H_sqrt_inv: optional, the matrix the
+        estimates would give (its row signs are LAPACK's choice and the shuffled vector lives in that basis)."""
+        ctx = self.ctx
+        if H_sqrt_inv is None:
+            K = self.random_effects[1][1]
+            eig_L = self._get_eigen_L_(K)
+            H_sqrt_inv = self.get_estimates(eig_L=eig_L, method=method)['H_sqrt_inv']   # :1184-1186
+        H = np.asarray(H_sqrt_inv, dtype=np.float64)
+        n = self.n
+        n_p = n - (self.X.shape[1] + 1)                                  # :1190-1193
+        y = self.Y.reshape(-1)
+        Yt = H @ y                                                       # :1195
+        h0_X = H @ self.X                                                # :1196
+        (h0_betas, _r, _rank, _s) = linalg.lstsq(h0_X, Yt)               # :1197
+        r = Yt - h0_X @ h0_betas                                         # :1198
+        h0_rss = float(r @ r)
+        if perm_idx is None:                                             # :1202-1205
+            idx = np.asmatrix(np.arange(n).reshape(n, 1))
+            perm_idx = []
+            for _ in range(num_perm):
+                np.random.shuffle(idx)
+                perm_idx.append(np.asarray(idx).reshape(-1).copy())
+        perm_idx = np.asarray(perm_idx)
+        Ys = np.ascontiguousarray(r[perm_idx].T)                         # n x P
+        CH = H - H.mean(axis=0, keepdims=True)                           # C H: the transformed SNP minus its mean (:1211)
+        own = not isinstance(snps, _lib.Geno)
+        snp_mat = kinship._as_snp_matrix(snps) if own else None
+        num_snps = len(snp_mat) if own else snps.M
+        plan = ctx.perm_plan(CH, Ys, h0_rss, centre_snps=False)
+        try:
+            if not reference_indexing:
+                g = ctx.geno(snp_mat) if own else snps
+                try:
+                    min_rss = plan.run(g)
+                finally:
+                    if own:
+                        g.close()
+            else:
+                if num_snps > num_perm:
+                    raise IndexError("index %d is out of bounds for axis 0 with size %d (linear_models.py:1213 stores "
+                                     "a per-SNP minimum in a per-permutation array)" % (num_perm, num_perm))
+                min_rss = np.repeat(h0_rss, num_perm).astype(np.float64)  # :1207
+                rows = snp_mat if own else snps.download()
+                for j in range(num_snps):                                # one SNP per run: min over the permutations
+                    g1 = ctx.geno(rows[j:j + 1])
+                    try:
+                        min_rss[j] = plan.run(g1).min()
+                    finally:
+                        g1.close()
+        finally:
+            plan.close()
+        max_f_stats = ((h0_rss / min_rss) - 1.0) * n_p                   # :1221
+        min_pvals = ctx.f_sf(max_f_stats, n_p)                           # :1222
+        return {'min_ps': min_pvals, 'max_f_stats': max_f_stats}
 
 
 # ---------------------------------------------------------------------- module-level entry points
@@ -1120,11 +1229,13 @@ def mlmm(phenotypes, K, sd=None, num_steps=10, forward_backwards=True, sign_thre
             'criterias': criterias}
 
 
-def emmax_perm_test(snps, phenotypes, K, num_perm=100, perm_idx=None, ctx=None):
-    """:1819-1841."""
+def emmax_perm_test(snps, phenotypes, K, num_perm=100, perm_idx=None, ctx=None, H_sqrt_inv=None,
+                    reference_indexing=False):
+    """:1819-1841.  perm_idx / H_sqrt_inv / reference_indexing: see LinearMixedModel.emmax_permutations."""
     lmm = LinearMixedModel(phenotypes, ctx=ctx)
     lmm.add_random_effect(K)
-    res = lmm.emmax_permutations(snps, num_perm, perm_idx=perm_idx)
+    res = lmm.emmax_permutations(snps, num_perm, perm_idx=perm_idx, H_sqrt_inv=H_sqrt_inv,
+                                 reference_indexing=reference_indexing)
     p_f_list = sorted(zip(res['min_ps'], res['max_f_stats']))
     res['threshold_05'] = p_f_list[len(p_f_list) // 20]                  # :1831
     return res

@@ -422,6 +422,50 @@ def perm_closed(snps, pp):
     return {'min_rss': min_rss, 'max_f_stats': max_f, 'min_ps': f_sf(max_f, 1, n_p)}
 
 
+def transformed_snps(snps, X, H_sqrt_inv):
+    """t_snps of _emmax_f_test_(return_transformed_snps=True), linear_models.py:1300-1303,1316-1321:
+    M = H'(I - QQ') with Q from qr(H X); row m is s_m M."""
+    H = np.asarray(H_sqrt_inv, dtype=np.float64)
+    Q, _ = linalg.qr(H @ np.asarray(X, dtype=np.float64), mode='economic')
+    Mp = H.T @ (np.eye(len(H)) - Q @ Q.T)
+    return np.asarray(snps, dtype=np.float64) @ Mp
+
+
+def perm_public(snps, y, X, H_sqrt_inv, perm_idx, reference_indexing=True):
+    """LinearMixedModel.emmax_permutations, linear_models.py:1180-1230 (the worker of emmax_perm_test, :1819):
+    Y = H y not centred, ONE subtraction of the null fit (:1198), Xs = S H' then Xs - mean(Xs) per SNP (:1209-1211),
+    rss_{m,p} by lstsq(Xs[m], Ys) (:1212).  reference_indexing: the reference's literal result -- it writes
+    rss_list.min() (min over the permutations of SNP m) into slot m of a per-permutation array (:1213), which needs
+    num_snps <= num_perm; False: min over the SNPs per permutation, what the docstring describes."""
+    y = np.asarray(y, dtype=np.float64).reshape(-1)
+    X = np.asarray(X, dtype=np.float64)
+    H = np.asarray(H_sqrt_inv, dtype=np.float64)
+    n = len(y)
+    n_p = n - (X.shape[1] + 1)
+    Y = H @ y
+    h0_X = H @ X
+    h0_betas, _, _, _ = linalg.lstsq(h0_X, Y)
+    r = Y - h0_X @ h0_betas
+    h0_rss = float(r @ r)
+    Ys = np.stack([r[np.asarray(ix)] for ix in perm_idx], axis=1)            # n x P
+    P = Ys.shape[1]
+    T = np.asarray(snps, dtype=np.float64) @ H.T
+    T = T - T.mean(axis=1, keepdims=True)
+    tt = np.einsum('ij,ij->i', T, T)
+    G = T @ Ys
+    ok = tt > 0
+    rss = np.einsum('ij,ij->j', Ys, Ys)[None, :] - np.where(ok[:, None], G * G / np.where(ok, tt, 1.0)[:, None], 0.0)
+    if reference_indexing:
+        if len(T) > P:
+            raise IndexError("linear_models.py:1213 indexes a per-permutation array by SNP")
+        min_rss = np.repeat(h0_rss, P).astype(np.float64)
+        min_rss[:len(T)] = rss.min(axis=1)
+    else:
+        min_rss = np.minimum(h0_rss, rss.min(axis=0)) if len(T) else np.repeat(h0_rss, P)
+    max_f = (h0_rss / min_rss - 1.0) * n_p
+    return {'min_rss': min_rss, 'max_f_stats': max_f, 'min_ps': f_sf(max_f, 1, n_p), 'h0_rss': h0_rss}
+
+
 # ----------------------------------------------------------------------------- synthetic data
 def hash_genotypes(m0, m1, n, seed, maf_q16=None):
     """Counter-based Bernoulli genotypes shared by bench.py (device generator

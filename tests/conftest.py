@@ -36,3 +36,12 @@ def load_extras():
     n = int(d["n"])
     d["snps"] = np.unpackbits(d["snps_packed"], axis=1)[:, :n].astype(np.int8)
     return d
+
+
+def load_extras2():
+    """tests/golden/extras2_n150.npz (round 3): t_snps of _emmax_f_test_(return_transformed_snps=True) and the public
+    permutation test LinearMixedModel.emmax_permutations, both from the reference itself."""
+    d = dict(np.load(os.path.join(GOLDEN, "extras2_n150.npz")))
+    n = int(d["n"])
+    d["snps"] = np.unpackbits(d["snps_packed"], axis=1)[:, :n].astype(np.int8)
+    return d

@@ -164,12 +164,12 @@ class FakeContext(object):
     def f_sf(self, F, df2):
         return stats.f.sf(np.asarray(F, dtype=np.float64), 1, df2)
 
-    def perm_plan(self, H, Ys, h0_rss):
+    def perm_plan(self, H, Ys, h0_rss, centre_snps=True):
         ctx = self
 
         class _Plan(object):
             def run(self, g, comm=None, after_scan_HtQ=None):
-                return ctx.perm(g, H, Ys, h0_rss, comm=comm)
+                return ctx.perm(g, H, Ys, h0_rss, comm=comm, centre_snps=centre_snps)
 
             def close(self):
                 pass
@@ -189,9 +189,10 @@ class FakeContext(object):
         F = (h0 / rss - 1.0) * df2
         return {"rss": rss, "f_stats": F, "ps": self.f_sf(F, df2)}
 
-    def perm(self, g, H, Ys, h0_rss, ndigits=0, comm=None, after_scan_HtQ=None):
+    def perm(self, g, H, Ys, h0_rss, ndigits=0, comm=None, after_scan_HtQ=None, centre_snps=True):
         S = g.data.astype(np.float64)
-        S = S - S.mean(1, keepdims=True)
+        if centre_snps:
+            S = S - S.mean(1, keepdims=True)
         T = S @ np.asarray(H).T
         tt = np.einsum('ij,ij->i', T, T)
         G = T @ np.asarray(Ys)

@@ -208,6 +208,62 @@ def run_extras(mods_by_mode):
     print('extras_n150', snps.shape, '%.0f KB' % (os.path.getsize(path) / 1024.0))
 
 
+def run_extras2(mods_by_mode):
+    """Round-3 known answers, in their own file (the earlier fixture files stay bit-identical):
+    * t_snps of _emmax_f_test_(return_transformed_snps=True) (linear_models.py:1309-1321,1355-1356), with the
+      H_sqrt_inv the reference was handed (an argument, :1272; its row signs are LAPACK's choice);
+    * the PUBLIC permutation test LinearMixedModel.emmax_permutations (:1180-1230, the worker of emmax_perm_test
+      :1819-1841, whose own tail `p_f_list[len(p_f_list) / 20]` is a float index under Python 3) with the recorded
+      shuffles and the H_sqrt_inv it computed; num_snps <= num_perm, where its per-SNP indexing (:1213) runs."""
+    rng = np.random.RandomState(23)
+    n, m = 150, 500
+    snps = structured_genotypes(rng, n, m)
+    y = phenotype(rng, snps, h2=0.55, ncausal=8)
+    cof = rng.randn(n) + 0.5 * snps[5]
+    nperm, ksnps = 24, 16
+    data = {'snps_packed': np.packbits(snps.astype(np.uint8), axis=1), 'n': np.int64(n), 'y': y, 'cof': cof,
+            'perm_num_snps': np.int64(ksnps)}
+    for mode, mods in mods_by_mode.items():
+        lm, kin = mods['linear_models'], mods['kinship']
+        snp_list = list(snps)
+        k_ibs = np.asarray(quiet(kin.calc_ibs_kinship, snp_list))
+        if mode == 'dbl':
+            data['ibs_scaled'] = k_ibs
+        for tag, cf in (('t', None), ('tc', [cof])):
+            lmm = lm.LinearMixedModel(list(y))
+            lmm.add_random_effect(k_ibs)
+            if cf is not None:
+                for c in cf:
+                    lmm.add_factor(c)
+            eig_L = lmm._get_eigen_L_()
+            est = quiet(lmm.get_estimates, eig_L, method='REML')
+            H = np.asarray(est['H_sqrt_inv'], dtype=np.float64)
+            r = quiet(lmm._emmax_f_test_, snp_list[:64], est['H_sqrt_inv'], return_transformed_snps=True, emma_num=0)
+            data['%s_%s_H' % (mode, tag)] = H if mode == 'dbl' else H.astype(np.float32)
+            data['%s_%s_snps' % (mode, tag)] = np.asarray(r['t_snps'], dtype=np.float64)
+            data['%s_%s_ps' % (mode, tag)] = np.asarray(r['ps'], dtype=np.float64).reshape(-1)
+        # public permutation test: replay the shuffles, then run the reference with the same RNG state
+        lmm = lm.LinearMixedModel(list(y))
+        lmm.add_random_effect(k_ibs)
+        eig_L = lmm._get_eigen_L_(lmm.random_effects[1][1])
+        H = np.asarray(quiet(lmm.get_estimates, eig_L=eig_L, method='REML')['H_sqrt_inv'], dtype=np.float64)
+        np.random.seed(4242)
+        idx = np.asmatrix(np.arange(n).reshape(n, 1))
+        perm_idx = []
+        for _ in range(nperm):
+            np.random.shuffle(idx)
+            perm_idx.append(np.asarray(idx).reshape(-1).copy())
+        np.random.seed(4242)
+        pr = quiet(lmm.emmax_permutations, [s.astype(np.float64) for s in snps[:ksnps]], nperm)
+        data['%s_pub_perm_idx' % mode] = np.asarray(perm_idx, dtype=np.int32)
+        data['%s_pub_perm_H' % mode] = H if mode == 'dbl' else H.astype(np.float32)
+        data['%s_pub_min_ps' % mode] = np.asarray(pr['min_ps'], dtype=np.float64).reshape(-1)
+        data['%s_pub_max_f_stats' % mode] = np.asarray(pr['max_f_stats'], dtype=np.float64).reshape(-1)
+    path = os.path.join(HERE, 'extras2_n150.npz')
+    np.savez_compressed(path, **data)
+    print('extras2_n150', snps.shape, '%.0f KB' % (os.path.getsize(path) / 1024.0))
+
+
 CASES = [
     # name, kind, N, M, seed, n_cofactors, nperm
     ('struct_n150_s0', 'struct', 150, 600, 0, 0, 20),
@@ -225,7 +281,9 @@ def main():
     mods = {'lit': refshim.load('literal'), 'dbl': refshim.load('double')}
     if os.environ.get('MMG_GOLDEN_ONLY', '') in ('', 'extras'):
         run_extras(mods)
-    if os.environ.get('MMG_GOLDEN_ONLY', '') == 'extras':
+    if os.environ.get('MMG_GOLDEN_ONLY', '') in ('', 'extras2'):
+        run_extras2(mods)
+    if os.environ.get('MMG_GOLDEN_ONLY', '') in ('extras', 'extras2'):
         return
     for name, kind, n, m, seed, ncof, nperm in CASES:
         rng = np.random.RandomState(seed)

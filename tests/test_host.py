@@ -179,6 +179,24 @@ lmm_b = lm.LinearMixedModel(y, ctx=FakeContext()); lmm_b.add_random_effect(K)
 ra, rb = lmm_a.get_estimates_eigen_free(coll=coll), lmm_b.get_estimates_eigen_free()
 assert abs(ra["delta"] / rb["delta"] - 1) < 1e-12 and abs(ra["max_ll"] - rb["max_ll"]) < 1e-9
 assert ra["n_factorisations"] < rb["n_factorisations"]            # each rank factorised about half the grid
+# a factorisation that fails on ONE rank only (indefinite K: only the smallest delta, which rank 0 holds, breaks): every
+# rank still enters the all-gather, then all of them fall back together (advisor r2: the others used to hang)
+import warnings
+from mixmogam_amd import _lib
+from fake_ctx import FakeReml
+class BreakingReml(FakeReml):
+    def sums(self, deltas):
+        if np.min(deltas) < 5e-5:
+            raise _lib.MixmogamHipError("libmixmogam_hip error -4: K + delta I is not positive definite (dpotrf info 3)")
+        return FakeReml.sums(self, deltas)
+class BreakingCtx(FakeContext):
+    def reml(self, K, X, y):
+        return BreakingReml(self, K, X, y)
+lmm_c = lm.LinearMixedModel(y, ctx=BreakingCtx()); lmm_c.add_random_effect(K)
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    assert lmm_c._try_eigen_free(coll=coll) is None
+coll.barrier()                                                    # nobody is stuck in a collective
 coll.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
@@ -214,3 +232,39 @@ def test_config1_plumbing_phenotypes_and_coordination():
     assert all(before[e] == v for e, v in zip(phend.get_ecotypes(5), phend.get_values(5)))
     Z = phend.get_incidence_matrix(5)
     assert Z.shape == (198, 198) and Z.sum() == 198
+
+
+def test_bench_self_launch_dry(built):
+    """`python bench.py --gpus 2` without a launcher environment starts two ranks itself: the parent
+    never touches the GPU; --dry-launch makes the ranks report their rendezvous environment and exit."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MMG_RUN_ID")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                         capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["dry_launch"] and rec["world"] == 2 and len(rec["ranks"]) == 2
+    by_rank = {r["RANK"]: r for r in rec["ranks"]}
+    assert set(by_rank) == {"0", "1"}
+    for r, d in by_rank.items():
+        assert d["LOCAL_RANK"] == r and d["WORLD_SIZE"] == "2" and d["MASTER_ADDR"] == "127.0.0.1"
+    assert by_rank["0"]["MASTER_PORT"] == by_rank["1"]["MASTER_PORT"] and int(by_rank["0"]["MASTER_PORT"]) > 0
+    assert by_rank["0"]["MMG_RUN_ID"] == by_rank["1"]["MMG_RUN_ID"] != None   # noqa: E711
+    # under a launcher (WORLD_SIZE set) nothing is spawned: the process IS the rank
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"],
+                         capture_output=True, text=True, timeout=120,
+                         env=dict(env, RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", MASTER_PORT="1234"))
+    assert out.returncode == 0 and json.loads(out.stdout)["RANK"] == "1"
+
+
+def test_bench_self_launch_fails_cleanly_without_devices(built):
+    """On a box with fewer devices than ranks the children say so and the parent exits non-zero -- no hang in the
+    RCCL rendezvous, no partial JSON line."""
+    if built.device_count() >= 2:
+        pytest.skip("two devices present")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MMG_RUN_ID")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode != 0
+    assert "needs 2 devices" in out.stderr
+    assert not out.stdout.strip()

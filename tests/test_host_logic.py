@@ -272,3 +272,87 @@ def test_run_emmax_multi_equals_run_emmax_per_phenotype(ctx, tmp_path):
             assert rel(out["chrom_results"][c]["ps"][p], one["chrom_results"][c]["ps"]) < 1e-7
             assert np.array_equal(o["chrom_results"][c]["ps"][...][p], out["chrom_results"][c]["ps"][p])
     assert o["pseudo_heritability"][...].shape == (3,)
+
+
+# ------------------------------------------------------------------ round 3
+def test_return_transformed_snps_and_public_perm_test_host_logic(ctx):
+    """_emmax_f_test_(return_transformed_snps=True) (:1309-1321,1355-1356) and emmax_perm_test / emmax_permutations
+    (:1819-1841 / :1180-1230) through the numpy stand-in context against the reference's own outputs."""
+    from conftest import load_extras2
+    ex = load_extras2()
+    n = int(ex["n"])
+    for tag, cof in (("t", None), ("tc", [ex["cof"]])):
+        lmm = lm.LinearMixedModel(list(ex["y"]), ctx=ctx)
+        lmm.add_random_effect(ex["ibs_scaled"])
+        if cof:
+            lmm.add_factor(cof[0])
+        r = lmm._emmax_f_test_(list(ex["snps"][:64]), ex["dbl_%s_H" % tag], return_transformed_snps=True, emma_num=0)
+        assert isinstance(r["t_snps"], list) and len(r["t_snps"]) == 64 and r["t_snps"][0].shape == (n,)
+        ref = ex["dbl_%s_snps" % tag]
+        assert np.max(np.abs(np.asarray(r["t_snps"]) - ref)) < 1e-11 * np.max(np.abs(ref))
+        assert rel(r["ps"], ex["dbl_%s_ps" % tag]) < 1e-7
+    k = int(ex["perm_num_snps"])
+    res = lm.emmax_perm_test(list(ex["snps"][:k]), list(ex["y"]), ex["ibs_scaled"], num_perm=len(ex["dbl_pub_perm_idx"]),
+                             perm_idx=ex["dbl_pub_perm_idx"], H_sqrt_inv=ex["dbl_pub_perm_H"], reference_indexing=True,
+                             ctx=ctx)
+    assert rel(res["max_f_stats"], ex["dbl_pub_max_f_stats"]) < 1e-8
+    assert rel(res["min_ps"], ex["dbl_pub_min_ps"]) < 1e-7
+    p_f = sorted(zip(ex["dbl_pub_min_ps"], ex["dbl_pub_max_f_stats"]))
+    assert rel(res["threshold_05"], p_f[len(p_f) // 20]) < 1e-7           # :1831
+    with pytest.raises(IndexError):                                        # :1213 beyond num_perm SNPs
+        lm.emmax_perm_test(list(ex["snps"][:40]), list(ex["y"]), ex["ibs_scaled"], num_perm=24,
+                           perm_idx=ex["dbl_pub_perm_idx"], H_sqrt_inv=ex["dbl_pub_perm_H"], reference_indexing=True, ctx=ctx)
+    # default reduction (per permutation, over the SNPs): same global optimum; H computed by the wrapper itself
+    res2 = lm.emmax_perm_test(list(ex["snps"][:k]), list(ex["y"]), ex["ibs_scaled"], num_perm=24,
+                              perm_idx=ex["dbl_pub_perm_idx"], H_sqrt_inv=ex["dbl_pub_perm_H"], ctx=ctx)
+    assert abs(res2["max_f_stats"].max() / ex["dbl_pub_max_f_stats"].max() - 1) < 1e-8
+    res3 = lm.emmax_perm_test(list(ex["snps"][:k]), list(ex["y"]), ex["ibs_scaled"], num_perm=5, ctx=ctx)
+    assert len(res3["min_ps"]) == 5 and np.all(res3["min_ps"] <= 1)
+
+
+def test_real_hdf5_files_drive_the_same_driver(ctx, tmp_path):
+    """The real-HDF5 branch of chunkstore.open_container (the reference's own files: hdf5_data.py:77,146,199,241;
+    kinship.py:149): an h5py.File with the layout of plink2hdf5.py:27-28,111-118,226 (lzf-compressed int8 raw_snps)
+    goes through run_emmax / copy_tree / the kinship file helpers and gives the numbers of the directory container.
+    Skipped where h5py is not installed (this image)."""
+    h5py = pytest.importorskip("h5py")
+    from mixmogam_amd import chunkstore, simulations
+    dpath = simulations.write_synthetic_container(str(tmp_path / "in.mmg"), 60, 500, chunk_rows=128, num_chroms=2,
+                                                  num_causals=5)
+    hpath = str(tmp_path / "in.hdf5")
+    with h5py.File(hpath, "w") as h5f:
+        d = chunkstore.open_container(dpath, "r")
+        gg = h5f.create_group("genot_data")
+        for c in d["genot_data"].keys():
+            cg = gg.create_group(c)
+            cg.create_dataset("raw_snps", data=np.asarray(d["genot_data"][c]["raw_snps"][...]), compression="lzf",
+                              chunks=(64, 60))
+            for k in ("positions", "freqs"):
+                cg.create_dataset(k, data=np.asarray(d["genot_data"][c][k][...]))
+        ig = h5f.create_group("indiv_data")
+        for k in d["indiv_data"].keys():
+            ig.create_dataset(k, data=np.asarray(d["indiv_data"][k][...]))
+        h5f.create_dataset("num_snps", data=np.asarray(d["num_snps"][...]))
+    f = chunkstore.open_container(hpath, "r")
+    assert isinstance(f, h5py.File)
+    f.close()
+    ref = hdf5_data.run_emmax(dpath, str(tmp_path / "res.mmg"), min_maf=0.1, chunk_size=100, ctx=ctx)
+    res = hdf5_data.run_emmax(hpath, str(tmp_path / "res.hdf5"), min_maf=0.1, chunk_size=100, ctx=ctx)
+    with h5py.File(str(tmp_path / "res.hdf5"), "r") as o:
+        assert sorted(o.keys()) == ["chrom_results", "max_ll", "num_snps", "pseudo_heritability", "ve", "vg"]
+        for c in ref["chrom_results"]:
+            assert np.array_equal(o["chrom_results"][c]["ps"][...], ref["chrom_results"][c]["ps"])
+            assert np.array_equal(res["chrom_results"][c]["ps"], ref["chrom_results"][c]["ps"])
+    # HDF5 -> directory container and back
+    back = chunkstore.Store(str(tmp_path / "copy.mmg"), "w")
+    with h5py.File(hpath, "r") as h5f:
+        chunkstore.copy_tree(h5f, back)
+    for c in ref["chrom_results"]:
+        assert np.array_equal(back["genot_data"][c]["raw_snps"][...],
+                              chunkstore.open_container(dpath, "r")["genot_data"][c]["raw_snps"][...])
+    kpath = str(tmp_path / "k.hdf5")
+    kinship.save_kinship_to_file(kpath, ref["kinship"], [str(i) for i in range(60)], n_snps=500)
+    with h5py.File(kpath, "r") as kf:
+        assert sorted(kf.keys()) == ["accessions", "kinship", "n_snps"]        # kinship.py:163-166
+    kd = kinship.load_kinship_from_file(kpath, scaled=False)
+    assert np.array_equal(kd["k"], ref["kinship"]) and kd["n_snps"] == 500
