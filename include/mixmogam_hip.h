@@ -81,6 +81,15 @@ int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, i
  * takes arbitrary numeric SNPs (linear_models.py:1317), this int8 store does not, and says so. */
 int mmg_geno_upload_f32(mmg_ctx* ctx, mmg_geno* g, const float* snps, int64_t m0, int64_t rows);
 int mmg_geno_upload_f64(mmg_ctx* ctx, mmg_geno* g, const double* snps, int64_t m0, int64_t rows);
+/* Packed rows: bits = 1 (genotype i of a row = bit i & 7 of byte i >> 3) or 2 (bits 2(i & 3).. of byte i >> 2) --
+ * least significant first, the order of numpy.packbits(bitorder='little') and of a PLINK .bed row; row_bytes >=
+ * ceil(N * bits / 8) is the stride of the host rows.  lut: int8 value of each of the 2^bits codes, or NULL for
+ * code = value (0/1; 0/1/2/3 -- the 0/1/2 coding plink2hdf5.py:171-179 stores).  A .bed row (00 hom A1, 01 missing,
+ * 10 het, 11 hom A2) uploads as is with lut = {0, <imputed value>, 1, 2}.  Expanded to the int8 store on the device:
+ * the host link carries N/8 or N/4 bytes per SNP instead of N.  Not in the reference (it stores int8 with lzf,
+ * plink2hdf5.py:111-118); added because host-resident runs are bound by that link. */
+int mmg_geno_upload_packed(mmg_ctx* ctx, mmg_geno* g, const uint8_t* packed, int64_t m0, int64_t rows, int32_t bits,
+                           int64_t row_bytes, const int8_t* lut);
 int mmg_geno_download(mmg_ctx* ctx, mmg_geno* g, int8_t* snps, int64_t m0, int64_t rows);
 /* Gather cnt rows idx[0..cnt) (host int64, any order) into a host [cnt x N] buffer: the top-hit rows of the
  * exact-EMMA refinement (linear_models.py:1365-1370) without moving the whole store over PCIe. */

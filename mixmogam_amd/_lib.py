@@ -44,6 +44,7 @@ PROTOTYPES = {
     "mmg_geno_upload": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64]),
     "mmg_geno_upload_f32": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64]),
     "mmg_geno_upload_f64": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64]),
+    "mmg_geno_upload_packed": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64, C.c_int32, C.c_int64, c_vp]),
     "mmg_geno_download": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int64]),
     "mmg_geno_download_rows": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, c_vp]),
     "mmg_geno_fill_hash": (C.c_int, [c_vp, c_vp, C.c_uint64, C.c_int64, C.c_uint32]),
@@ -172,6 +173,36 @@ def as_store_array(snps):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+def pack_genotypes(snps, bits=1):
+    """[rows x N] genotypes with values in [0, 2^bits) -> uint8 [rows x ceil(N*bits/8)], genotype i in the low bits
+    first (numpy.packbits(bitorder='little') for bits=1; the bit order of a PLINK .bed row for bits=2)."""
+    a = np.asarray(snps)
+    if a.ndim != 2 or bits not in (1, 2):
+        raise ValueError("snps must be [rows x N], bits 1 or 2")
+    if a.size and (int(a.min()) < 0 or int(a.max()) >= (1 << bits)):
+        raise ValueError("genotype values must lie in [0, %d] for %d-bit packing" % ((1 << bits) - 1, bits))
+    a = a.astype(np.uint8)
+    if bits == 1:
+        return np.packbits(a, axis=1, bitorder='little')
+    n = a.shape[1]
+    pad = (-n) % 4
+    if pad:
+        a = np.hstack([a, np.zeros((a.shape[0], pad), dtype=np.uint8)])
+    q = a.reshape(a.shape[0], -1, 4)
+    return (q[:, :, 0] | (q[:, :, 1] << 2) | (q[:, :, 2] << 4) | (q[:, :, 3] << 6)).astype(np.uint8)
+
+
+def unpack_genotypes(packed, n, bits=1):
+    """Inverse of pack_genotypes on the host (tests, CPU-side consumers of packed containers)."""
+    p = np.asarray(packed, dtype=np.uint8)
+    if bits == 1:
+        return np.unpackbits(p, axis=1, bitorder='little')[:, :n].astype(np.int8)
+    out = np.empty((p.shape[0], p.shape[1] * 4), dtype=np.int8)
+    for k in range(4):
+        out[:, k::4] = (p >> (2 * k)) & 3
+    return out[:, :n]
+
+
 class Geno(object):
     """Device-resident genotype store ([M x N] int8, SNP-major, padded in HBM)."""
 
@@ -198,6 +229,19 @@ class Geno(object):
         else:
             fn = self.ctx.lib.mmg_geno_upload
         self.ctx._check(fn(self.ctx.h, self.h, _ptr(a), int(m0), a.shape[0]))
+        return self
+
+    def upload_packed(self, packed, bits=1, m0=0, lut=None):
+        """Rows packed 1 or 2 bits per genotype, least significant bit first (pack_genotypes; a PLINK .bed row for
+        bits=2), expanded on the device.  packed: uint8 [rows x >= ceil(N*bits/8)]; lut: the int8 value per code."""
+        a = np.ascontiguousarray(packed, dtype=np.uint8)
+        if a.ndim != 2 or a.shape[1] < (self.N * bits + 7) // 8:
+            raise ValueError("expected [rows x >= %d] packed bytes, got %r" % ((self.N * bits + 7) // 8, a.shape))
+        lt = None if lut is None else np.ascontiguousarray(lut, dtype=np.int8)
+        if lt is not None and lt.size != (1 << bits):
+            raise ValueError("lut needs %d entries" % (1 << bits))
+        self.ctx._check(self.ctx.lib.mmg_geno_upload_packed(self.ctx.h, self.h, _ptr(a), int(m0), a.shape[0], int(bits),
+                                                            a.shape[1], _ptr(lt)))
         return self
 
     def download(self, m0=0, rows=None):

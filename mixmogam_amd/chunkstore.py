@@ -181,10 +181,12 @@ def copy_tree(src, dst):
             dst.create_dataset(name, data=np.asarray(item[...]))
 
 
-def write_genotype_container(path, chrom_snps, indiv_ids, phenotypes=None, positions=None, mode="w"):
+def write_genotype_container(path, chrom_snps, indiv_ids, phenotypes=None, positions=None, mode="w", packed_bits=0):
     """Write a genotype file in the layout of plink2hdf5.py:27-28,111-118,226 from in-memory arrays:
     chrom_snps {chrom: int8 [M_c x N]}; freqs = per-SNP mean of the 0/1 genotypes (the allele frequency that
-    hdf5_data.py:91-93 filters on)."""
+    hdf5_data.py:91-93 filters on).  packed_bits = 1 / 2: the rows are stored as `raw_snps_packed` (uint8, 1 or 2
+    bits per genotype, low bits first) with `packed_bits` and `num_indivs` beside them instead of `raw_snps` -- an
+    eighth / a quarter of the bytes for the streamed drivers to read and upload (hdf5_data._raw_dataset)."""
     st = Store(path, mode)
     gg = st.create_group("genot_data")
     ig = st.create_group("indiv_data")
@@ -195,7 +197,13 @@ def write_genotype_container(path, chrom_snps, indiv_ids, phenotypes=None, posit
     for chrom, snps in chrom_snps.items():
         snps = np.ascontiguousarray(snps, dtype=np.int8)
         cg = gg.create_group(str(chrom))
-        cg.create_dataset("raw_snps", data=snps)
+        if packed_bits:
+            from ._lib import pack_genotypes
+            cg.create_dataset("raw_snps_packed", data=pack_genotypes(snps, packed_bits))
+            cg.create_dataset("packed_bits", data=np.array(packed_bits))
+            cg.create_dataset("num_indivs", data=np.array(snps.shape[1]))
+        else:
+            cg.create_dataset("raw_snps", data=snps)
         cg.create_dataset("positions", data=np.asarray(positions[chrom]) if positions is not None
                           else np.arange(len(snps), dtype=np.int64))
         cg.create_dataset("freqs", data=snps.mean(axis=1, dtype=np.float64))

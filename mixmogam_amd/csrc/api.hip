@@ -116,6 +116,7 @@ int mmg_ctx_destroy(mmg_ctx* ctx) {
   if (ctx->sel_geno) { hipFree(ctx->sel_geno->d); hipFree(ctx->sel_geno->bits); hipFree(ctx->sel_geno->d_smax); delete ctx->sel_geno; }
   hipFree(ctx->dstage);
   hipFree(ctx->grp_tab);
+  hipFree(ctx->ingest);
   if (ctx->rocblas) rocblas_destroy_handle((rocblas_handle)ctx->rocblas);
   for (int i = 0; i < EV_COUNT; ++i) { hipEventDestroy(ctx->ev[i][0]); hipEventDestroy(ctx->ev[i][1]); }
   hipEventDestroy(ctx->ev_snap);
@@ -235,6 +236,23 @@ int mmg_geno_destroy(mmg_ctx* ctx, mmg_geno* g) {
   return MMG_OK;
 }
 
+constexpr int64_t INGEST_STAGE_BYTES = (int64_t)256 << 20;
+
+static int ensure_ingest(mmg_ctx* ctx, size_t bytes) {
+  if (ctx->ingest_cap >= bytes) return MMG_OK;
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(ctx->ingest); ctx->ingest = nullptr; ctx->ingest_cap = 0;
+  MMG_HIP(ctx, hipMalloc(&ctx->ingest, bytes));
+  ctx->ingest_cap = bytes;
+  return MMG_OK;
+}
+
+static bool host_is_pinned(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain pageable memory
+  return a.type == hipMemoryTypeHost;
+}
+
 // every write path ends here: fold max |s| of the written rows into the store's running bound
 static int refresh_smax(mmg_ctx* ctx, mmg_geno* g, int64_t m0, int64_t rows) {
   launch_absmax_i8(ctx, g->d + m0 * (int64_t)g->Npad, rows * (int64_t)g->Npad, g->d_smax);
@@ -252,8 +270,27 @@ int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, i
   MMG_CHECK_ARG(ctx, g && snps && m0 >= 0 && rows >= 0 && m0 + rows <= g->M);
   if (rows == 0) return MMG_OK;
   g->bits_valid = false; ++g->version;
-  MMG_HIP(ctx, hipMemcpy2DAsync(g->d + m0 * (int64_t)g->Npad, g->Npad, snps, g->N, g->N, rows,
-                                hipMemcpyHostToDevice, ctx->stream));
+  // Page-locked host rows go straight into the padded store (strided DMA at link rate).  Pageable rows are staged:
+  // a strided copy out of pageable memory runs row by row through the runtime's bounce buffer (measured 20 GB/s on
+  // one box of the pool against 49-56 GB/s for contiguous copies), so the block crosses as ONE contiguous copy into
+  // device staging and pitch_rows_kernel spreads it over the padded rows.
+  if (g->N == g->Npad) {
+    MMG_HIP(ctx, hipMemcpyAsync(g->d + m0 * (int64_t)g->Npad, snps, (size_t)rows * g->N, hipMemcpyHostToDevice, ctx->stream));
+  } else if (host_is_pinned(snps)) {
+    MMG_HIP(ctx, hipMemcpy2DAsync(g->d + m0 * (int64_t)g->Npad, g->Npad, snps, g->N, g->N, rows,
+                                  hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    const int64_t chunk = std::max<int64_t>(1, INGEST_STAGE_BYTES / g->N);
+    int rc0 = ensure_ingest(ctx, (size_t)std::min(chunk, rows) * g->N);
+    if (rc0) return rc0;
+    for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
+      const int64_t nr = std::min(chunk, rows - r0);
+      MMG_HIP(ctx, hipMemcpyAsync(ctx->ingest, snps + r0 * g->N, (size_t)nr * g->N, hipMemcpyHostToDevice, ctx->stream));
+      launch_pitch_rows(ctx, (const int8_t*)ctx->ingest, g->d + (m0 + r0) * (int64_t)g->Npad, nr, g->N, g->Npad);
+      MMG_HIP(ctx, hipGetLastError());
+      if (r0 + chunk < rows) MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the staging is reused by the next piece
+    }
+  }
   const int prev[2] = {g->smax, g->sneg};
   int rc = refresh_smax(ctx, g, m0, rows);
   if (rc) return rc;
@@ -269,6 +306,39 @@ int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, i
                                    "upload were zeroed");
   }
   return MMG_OK;
+}
+
+// Packed ingest: 1 bit (0/1) or 2 bits (0..3, e.g. 0/1/2) per genotype cross PCIe / come off the disk instead of a
+// byte each -- the host link is the roof of every run whose genotypes are not resident (64 GB/s = 12.8 M SNPs/s at
+// N = 5000 for int8 rows; 8x / 4x that packed).  The rows are expanded into the int8 store on the device.
+int mmg_geno_upload_packed(mmg_ctx* ctx, mmg_geno* g, const uint8_t* packed, int64_t m0, int64_t rows, int32_t bits,
+                           int64_t row_bytes, const int8_t* lut) {
+  Scratch sc;
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, g && packed && m0 >= 0 && rows >= 0 && m0 + rows <= g->M && (bits == 1 || bits == 2));
+  MMG_CHECK_ARG(ctx, row_bytes >= ((int64_t)g->N * bits + 7) / 8);
+  if (rows == 0) return MMG_OK;
+  uint32_t lut32 = bits == 1 ? 0x00000100u : 0x03020100u;               // identity: code = value
+  if (lut) {
+    lut32 = 0;
+    for (int c = 0; c < (1 << bits); ++c) {
+      if (lut[c] == -128) return set_err(ctx, MMG_E_ARG, "mmg_geno_upload_packed: lut values must lie in [-127, 127]");
+      lut32 |= (uint32_t)(uint8_t)lut[c] << (8 * c);
+    }
+  }
+  g->bits_valid = false; ++g->version;
+  const int64_t chunk = std::max<int64_t>(1, INGEST_STAGE_BYTES / row_bytes);
+  int rc0 = ensure_ingest(ctx, (size_t)std::min(chunk, rows) * row_bytes);
+  if (rc0) return rc0;
+  uint8_t* tmp = (uint8_t*)ctx->ingest;
+  for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
+    const int64_t nr = std::min(chunk, rows - r0);
+    MMG_HIP(ctx, hipMemcpyAsync(tmp, packed + r0 * row_bytes, (size_t)nr * row_bytes, hipMemcpyHostToDevice, ctx->stream));
+    launch_unpack(ctx, tmp, row_bytes, g->d + (m0 + r0) * (int64_t)g->Npad, nr, g->N, g->Npad, bits, lut32);
+    MMG_HIP(ctx, hipGetLastError());
+    if (r0 + chunk < rows) MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));   // tmp is reused by the next piece
+  }
+  return refresh_smax(ctx, g, m0, rows);
 }
 
 extern "C++" {
@@ -1379,14 +1449,15 @@ struct mmg_perm_plan {
   mmg_scan_model pm;             // digit planes of H'H (t.t quadratic form), w slot = v
   mmg_scan_result pr;            // per-SNP work arrays of the quadratic form
   double *dmu = nullptr, *dinv = nullptr, *dmax = nullptr, *dvecs = nullptr, *ddots = nullptr;
-  int64_t cap = 0;               // SNP capacity of dmu / dinv / ddots
+  double* dssum = nullptr;       // [cap] exact genotype sum per SNP, 0 in the padding rows (digit offset of the GEMM operand)
+  int64_t cap = 0;               // SNP capacity of dmu / dinv / ddots / dssum
   int qcap = 0;
   bool centred = true;           // SNPs are mean-centred before the transform (:1159); false: t = Ht s as given
 };
 
 static void perm_plan_free(mmg_perm_plan* p) {
   hipFree(p->Wq); hipFree(p->dstep); hipFree(p->dcsum); hipFree(p->dv); hipFree(p->dmu); hipFree(p->dinv); hipFree(p->dmax);
-  hipFree(p->dvecs); hipFree(p->ddots);
+  hipFree(p->dvecs); hipFree(p->ddots); hipFree(p->dssum);
   free_model(p->pm); free_result(p->pr);
   delete p;
 }
@@ -1477,11 +1548,12 @@ int mmg_perm_plan_run(mmg_ctx* ctx, mmg_comm* comm, mmg_perm_plan* p, mmg_geno* 
   MMG_HIP(ctx, hipMemsetAsync(p->dmax, 0, p->Ppad * sizeof(double), ctx->stream));
   if (g->M > 0) {
     if (p->cap < g->Mpad || p->qcap < (reuse ? q : 0)) {
-      hipFree(p->dmu); hipFree(p->dinv); hipFree(p->ddots); hipFree(p->dvecs);
-      p->dmu = p->dinv = p->ddots = p->dvecs = nullptr; p->cap = 0;
+      hipFree(p->dmu); hipFree(p->dinv); hipFree(p->ddots); hipFree(p->dvecs); hipFree(p->dssum);
+      p->dmu = p->dinv = p->ddots = p->dvecs = p->dssum = nullptr; p->cap = 0;
       const int qq = std::max(reuse ? q : 0, p->qcap);
       MMG_HIP(ctx, hipMalloc(&p->dmu, g->Mpad * sizeof(double)));
       MMG_HIP(ctx, hipMalloc(&p->dinv, g->Mpad * sizeof(double)));
+      MMG_HIP(ctx, hipMalloc(&p->dssum, g->Mpad * sizeof(double)));
       MMG_HIP(ctx, hipMalloc(&p->ddots, (size_t)(1 + qq) * g->Mpad * sizeof(double)));
       MMG_HIP(ctx, hipMalloc(&p->dvecs, (size_t)(1 + qq) * p->Npad * sizeof(double)));
       p->cap = g->Mpad; p->qcap = qq;
@@ -1504,7 +1576,11 @@ int mmg_perm_plan_run(mmg_ctx* ctx, mmg_comm* comm, mmg_perm_plan* p, mmg_geno* 
       launch_perm_inv(ctx, g, p->pr, p->dmu, p->dinv);                    // 1 / t.t, mu = 0
     }
     MMG_HIP(ctx, hipGetLastError());
-    int rc = run_perm_q(ctx, g, p->Wq, p->dstep, p->dcsum, p->P, p->dinv, p->dmu, p->dmax);
+    // the finalize kernels of the scan wrote sum(s) of the M real SNPs (exact integers); the padding rows stay 0
+    MMG_HIP(ctx, hipMemsetAsync(p->dssum, 0, g->Mpad * sizeof(double), ctx->stream));
+    MMG_HIP(ctx, hipMemcpyAsync(p->dssum, reuse ? ctx->res.sum : p->pr.sum, g->M * sizeof(double), hipMemcpyDeviceToDevice,
+                                ctx->stream));
+    int rc = run_perm_q(ctx, g, p->Wq, p->dstep, p->dcsum, p->P, p->dinv, p->dmu, p->dssum, p->dmax);
     if (rc) return rc;
   }
   if (reduce)   // per-permutation maxima of this rank's SNP block stay in HBM: RCCL MAX over xGMI (exact, order independent)
@@ -1553,6 +1629,7 @@ struct mmg_rot {
   int64_t M = 0;                 // SNPs currently loaded
   int8_t* Vq = nullptr;          // [nVT][256][Npad] digits of the eigenvectors (operand layout of k_perm.hip)
   double* dstep = nullptr;       // [nVT*64] per-eigenvector step
+  double *dssum = nullptr, *dones = nullptr;   // [Mcap] genotype sum per loaded SNP (digit offset of the operand); [Npad] ones
   double* T = nullptr;           // [Mcap/256][nVT*64][256] fp64: T[m/256][i][m%256] = u_i . s_m
 };
 
@@ -1568,18 +1645,24 @@ int mmg_rot_create(mmg_ctx* ctx, int32_t N, const double* evecs_rows, int64_t M_
   hipError_t e = hipMalloc(&r->T, (size_t)r->nVT * 64 * r->Mcap * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&r->Vq, (size_t)r->nVT * TM * r->Npad);
   if (e == hipSuccess) e = hipMalloc(&r->dstep, (size_t)r->nVT * 64 * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&r->dssum, (size_t)r->Mcap * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&r->dones, (size_t)r->Npad * sizeof(double));
   if (e == hipSuccess) e = sc.alloc(&dV, (size_t)N * N * sizeof(double));
   if (e == hipSuccess) e = sc.alloc(&dcsum, (size_t)r->nVT * 64 * sizeof(double));
+  auto release = [&]() { hipFree(r->T); hipFree(r->Vq); hipFree(r->dstep); hipFree(r->dssum); hipFree(r->dones); delete r; };
   if (e != hipSuccess) {
-    hipFree(r->T); hipFree(r->Vq); hipFree(r->dstep); delete r;
+    release();
     return set_err(ctx, MMG_E_NOMEM, std::string("hipMalloc rotated store: ") + hipGetErrorString(e));
   }
   int rc = MMG_OK;
+  std::vector<double> ones((size_t)r->Npad, 0.0);
+  std::fill(ones.begin(), ones.begin() + N, 1.0);
   e = hipMemcpyAsync(dV, evecs_rows, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(r->dones, ones.data(), (size_t)r->Npad * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
   if (e != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e));
   if (rc == MMG_OK) rc = quantize_rows_4digits(ctx, dV, N, r->Npad, N, r->Vq, r->dstep, dcsum);
   if (rc == MMG_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = set_err(ctx, MMG_E_HIP, "rotated store setup");
-  if (rc) { hipFree(r->T); hipFree(r->Vq); hipFree(r->dstep); delete r; return rc; }
+  if (rc) { release(); return rc; }
   *out = r;
   return MMG_OK;
 }
@@ -1587,7 +1670,7 @@ int mmg_rot_create(mmg_ctx* ctx, int32_t N, const double* evecs_rows, int64_t M_
 int mmg_rot_destroy(mmg_ctx* ctx, mmg_rot* r) {
   if (!r) return MMG_OK;
   if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
-  hipFree(r->T); hipFree(r->Vq); hipFree(r->dstep);
+  hipFree(r->T); hipFree(r->Vq); hipFree(r->dstep); hipFree(r->dssum); hipFree(r->dones);
   delete r;
   return MMG_OK;
 }
@@ -1595,11 +1678,16 @@ int mmg_rot_destroy(mmg_ctx* ctx, mmg_rot* r) {
 int mmg_rot_load(mmg_ctx* ctx, mmg_rot* r, mmg_geno* g) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, r && g && g->N == r->N && g->Mpad <= r->Mcap);
-  // |sum_k digit * s| <= 128 * smax * Npad must fit the int32 accumulators of the digit GEMM
+  // |sum_k digit * s| <= 127 * smax * Npad must fit the int32 accumulators of the digit GEMM
   MMG_CHECK_ARG(ctx, (int64_t)128 * std::max(g->smax, 1) * r->Npad < ((int64_t)1 << 31));
   r->M = g->M;
   if (g->M == 0) return MMG_OK;
-  int rc = run_rotate(ctx, g, r->Vq, r->dstep, r->nVT, r->T);
+  // sum(s) per SNP (exact integers in fp64; 0 for the padding rows): the rotation GEMM's operand digits are shifted into
+  // the non-negative range and its epilogue takes 2^27 sum(s) back out
+  MMG_HIP(ctx, hipMemsetAsync(r->dssum, 0, (size_t)g->Mpad * sizeof(double), ctx->stream));
+  launch_snp_dot(ctx, g, r->dones, r->dssum);
+  MMG_HIP(ctx, hipGetLastError());
+  int rc = run_rotate(ctx, g, r->Vq, r->dstep, r->dssum, r->nVT, r->T);
   if (rc) return rc;
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MMG_OK;

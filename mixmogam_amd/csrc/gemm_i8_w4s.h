@@ -157,18 +157,29 @@ __device__ __forceinline__ void w4s_stream(int j0, int j1, int64_t ldP, int64_t 
 }
 
 
-// Four balanced base-256 digit accumulators -> the exact integer a0 + 2^8 a1 + 2^16 a2 + 2^24 a3 as a double.
-// FAST (host-checked: every |a_d| * 257 < 2^31, i.e. Npad * 128 * max|s| * 257 < 2^31): two 32-bit digit pairs and
-// one exact fp64 FMA -- 6 instructions instead of the ~19 of the 64-bit shift/add chain and its int64 -> double
-// conversion, which at 256 values per lane and tile was a quarter of the kernel.  Both forms are exact (|sum| < 2^53),
-// hence bit-identical.
+// Digit rows of the permutation / rotation GEMM operands (k_perm.hip:perm_quantize_kernel): a row's entries are
+// rounded to Z in [-(2^27 - 1), 2^27 - 1], shifted by ROWS_OFFSET = 2^27 into the non-negative range and written as four
+// UNSIGNED 7-bit digits (round 2: four balanced base-256 digits; non-negative bytes run 6-9 % faster on this
+// power-capped part, tools/probe/mfma_digit_range.hip, at 3 bits of the operand).  The GEMM then accumulates
+// sum_k s_k (Z_k + 2^27) = sum_k s_k Z_k + 2^27 sum(s): the epilogue takes the second term out with the SNP's exact
+// genotype sum.
+constexpr int ROWS_DIGIT_BITS = 7;
+constexpr long long ROWS_OFFSET = 1ll << 27;
+constexpr double ROWS_ZMAX = 134217727.0;                // 2^27 - 1
+
+// Four unsigned 7-bit digit accumulators and the SNP's genotype sum -> the exact integer
+// a0 + 2^7 a1 + 2^14 a2 + 2^21 a3 - 2^27 ssum = sum_k s_k Z_k as a double.
+// FAST (host-checked: every |a_d| * 257 < 2^31, i.e. Npad * 128 * max|s| * 257 < 2^31): two 32-bit digit pairs -- the
+// offset leaves with the upper pair as (ssum << 13) -- and one exact fp64 FMA instead of the 64-bit shift/add chain and
+// its int64 -> double conversion.  Both forms are exact (|sum| < 2^53), hence bit-identical.
 template <bool FAST>
-__device__ __forceinline__ double digits4_to_f64(int a0, int a1, int a2, int a3) {
+__device__ __forceinline__ double digits4_to_f64(int a0, int a1, int a2, int a3, int ssum) {
   if (FAST) {
-    const int lo = a0 + a1 * 256, hi = a2 + a3 * 256;
-    return fma((double)hi, 65536.0, (double)lo);
+    const int lo = a0 + a1 * 128, hi = a2 + a3 * 128 - (ssum << 13);
+    return fma((double)hi, 16384.0, (double)lo);
   }
-  const long long gi = (long long)a0 + ((long long)a1 << 8) + ((long long)a2 << 16) + ((long long)a3 << 24);
+  const long long gi = (long long)a0 + ((long long)a1 << 7) + ((long long)a2 << 14) + ((long long)a3 << 21) -
+                       ((long long)ssum << 27);
   return (double)gi;
 }
 

@@ -1,0 +1,192 @@
+// gemm_i8_w4tr.h -- the 4-wave int8 MFMA job stream of gemm_i8_w4s.h for operands that are CONTRACTION-MAJOR in
+// memory: both tiles are column windows of one row-major [k][col] image (the SNP-major genotype store itself:
+// k = SNP, col = individual), so the kinship GEMMs K = S'S read the store as it lies and the individual-major
+// transposed image (a 5 GB HBM round trip per call, 3.3 of 12.5 ms of the IBS kinship at N = 5000 x M = 1e6) is gone.
+//
+// What the MFMA wants -- 16 consecutive k per lane for the lane's row -- is produced by gfx950's transposed LDS read
+// ds_read_b64_tr_b8 (tools/probe/ds_read_tr_b8.hip, measured: within a group of 16 consecutive lanes, lane 2q + p
+// supplies the address of bytes 8p .. 8p+7 of row q of an 8 x 16 byte block, and lane i receives column i of the 8
+// rows, row 0 in its lowest byte).  Two such reads (k rows +0..7, +8..15) fill one v4i operand of
+// v_mfma_i32_32x32x32_i8: lanes 0-15 / 16-31 hold operand rows 0-15 / 16-31 with k 0..15, lanes 32-63 the same rows
+// with k 16..31.
+//
+// LDS image of an operand tile per K step: [128 k rows][256 cols] bytes (32 KiB, the size of the row-major tile of
+// gemm_i8_core.h), filled by the same lane-linear LDS-DMA (buffer_load ... lds, 16 B per lane, one instruction = 4 k
+// rows x 256 B); the 16-byte chunks of row k are XOR-swizzled in PAIRS, position = chunk ^ ((k & 7) << 1), applied
+// to the per-lane source offset of the DMA and again on the read side.  A transposed read of a 32-lane half covers 8
+// consecutive k rows x 32 bytes (2 chunks): with the pair swizzle the 8 rows fall into 8 different bank octets --
+// conflict free (bank = (addr / 4) % 64).
+//
+// Pipeline, barrier placement and the RAW / WAR argument: gemm_i8_w4s.h / k_scan_w4s.hip; per slice 16 MFMA and 16
+// ds_read_b64_tr_b8 (two per fragment) instead of 8 ds_read_b128 -- the same LDS bytes.
+#pragma once
+#include "gemm_i8_w4s.h"
+
+namespace mmg {
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+struct StageOpTr {
+  __amdgpu_buffer_rsrc_t rs;
+  int v_even, v_odd;   // per-lane source offsets (bytes) of even / odd pieces: the pair swizzle differs by (k & 4)
+  int ld4;             // 4 * ld
+};
+
+// base: byte 0 of the tile's column window at k row 0 of the stage; ld: row stride of the image
+__device__ __forceinline__ StageOpTr make_stage_op_tr(const int8_t* base, int64_t ld, int lane) {
+  StageOpTr s;
+  s.rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+  const int rp = lane >> 4, cp = lane & 15;            // row within the 4-row piece, chunk POSITION in LDS
+  s.v_even = rp * (int)ld + ((cp ^ (rp << 1)) << 4);
+  s.v_odd = rp * (int)ld + ((cp ^ ((4 + rp) << 1)) << 4);
+  s.ld4 = 4 * (int)ld;
+  return s;
+}
+
+// piece i in 0..7 of this wave: k rows wave*32 + i*4 .. +4 (1 KiB of LDS)
+__device__ __forceinline__ void stage_piece_tr(const StageOpTr& s, char* lds_tile, int wave, int i) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rs, (MMG_AS3 void*)(lds_tile + (wave * 8 + i) * 1024), 16,
+                                           (i & 1) ? s.v_odd : s.v_even, (wave * 8 + i) * s.ld4, 0, 0);
+}
+
+// fragment of operand-row block (32 rows, lane-constant byte offset `base`) for K slice `slice` (32 k rows)
+__device__ __forceinline__ v4i lds_frag_tr(const char* tile, int base, int slice) {
+  const char* p = tile + base + slice * (32 * 256);
+  const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((MMG_AS3 v2i*)p);
+  const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((MMG_AS3 v2i*)(p + 8 * 256));
+  return v4i{lo.x, lo.y, hi.x, hi.y};
+}
+
+// lane-constant part of a fragment address: operand rows tile_row0 + (lane & 31) .. , k half (lane >> 5)
+__device__ __forceinline__ int frag_base_tr(int tile_row0, int lane) {
+  const int i16 = lane & 15, g = lane >> 4, h = g >> 1;
+  const int chunk = (tile_row0 >> 4) + (g & 1);          // 16-column chunk of this lane group's rows
+  return (h * 16 + (i16 >> 1)) * 256 + ((chunk ^ (i16 & 14)) << 4) + (i16 & 1) * 8;
+}
+
+template <int NDMA>
+__device__ __forceinline__ void sched_slice_tr() {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if (i < NDMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+  }
+}
+
+struct W4JobTr {
+  const int8_t* P;     // column 0 of the job's 256-column P window at k row 0 of the job
+  const int8_t* Q;     // likewise for the Q window
+  int nks;             // K steps of 128 rows (>= 1)
+};
+
+template <int P0, int P1, bool ZERO>
+__device__ __forceinline__ void w4tr_slice(v16i (&acc)[4][4], const Frag4& cur, Frag4& nxt, const char* src,
+                                           const int (&ab)[4], const int (&bb)[4], int slice, const StageOpTr& sp,
+                                           const StageOpTr& sq, char* dst, int wave) {
+  static_assert(P1 - P0 <= 8, "at most one DMA piece per MFMA pair");
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m0 = ORD_M[2 * i], n0 = ORD_N[2 * i], m1 = ORD_M[2 * i + 1], n1 = ORD_N[2 * i + 1];
+    if (ZERO) acc[m0][n0] = mfma8(cur.a[m0], cur.b[n0], v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0});
+    else acc[m0][n0] = mfma8(cur.a[m0], cur.b[n0], acc[m0][n0]);
+    if ((i & 1) == 0) nxt.a[i >> 1] = lds_frag_tr(src, ab[i >> 1], slice);
+    else nxt.b[i >> 1] = lds_frag_tr(src + TILE_BYTES, bb[i >> 1], slice);
+    if (ZERO) acc[m1][n1] = mfma8(cur.a[m1], cur.b[n1], v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0});
+    else acc[m1][n1] = mfma8(cur.a[m1], cur.b[n1], acc[m1][n1]);
+    if (P0 + i < P1) {
+      const int pc = P0 + i;
+      if (pc < 8) stage_piece_tr(sp, dst, wave, pc);
+      else stage_piece_tr(sq, dst + TILE_BYTES, wave, pc - 8);
+    }
+  }
+  sched_slice_tr<(P1 > P0 ? P1 - P0 : 0)>();
+}
+
+// Runs jobs j0 .. j1-1 of this workgroup; job(j) -> W4JobTr (wave-uniform); ld: row stride of the image (bytes);
+// pre / epi as in w4s_stream: acc[m][n] = the wave's 4 x 4 accumulator tiles, rows = P columns wm*128 + m*32..,
+// columns = Q columns wn*128 + n*32.. (C layout of gemm_i8_core.h).
+template <class JobFn, class PreFn, class EpiFn>
+__device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* lds, JobFn&& job, PreFn&& pre, EpiFn&& epi) {
+  constexpr int N3 = 8;
+  if (j1 <= j0) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int ab[4], bb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ab[i] = frag_base_tr(wm * 128 + i * 32, lane);
+    bb[i] = frag_base_tr(wn * 128 + i * 32, lane);
+  }
+  const int64_t kstep_bytes = (int64_t)BK * ld;
+
+  // ---- issue cursor over the flattened stage stream (wave-uniform scalars); the descriptor base moves with the stage
+  // (a K step is 128 rows = 128 * ld bytes: beyond 32-bit offsets for long contraction ranges)
+  int cj = j0;
+  W4JobTr cjb = job(cj);
+  int cks = 0, cnks = cjb.nks;
+  StageOpTr sp = make_stage_op_tr(cjb.P, ld, lane);
+  StageOpTr sq = make_stage_op_tr(cjb.Q, ld, lane);
+  auto rebase = [&]() {
+    sp.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(cjb.P + cks * kstep_bytes), 0, 0x7fffffff, 0x00020000);
+    sq.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(cjb.Q + cks * kstep_bytes), 0, 0x7fffffff, 0x00020000);
+  };
+  auto advance = [&]() {
+    if (cks + 1 < cnks) { ++cks; rebase(); return; }
+    if (cj + 1 < j1) {
+      ++cj;
+      cjb = job(cj);
+      cks = 0;
+      cnks = cjb.nks;
+      rebase();
+    }                                                    // else: stay on the last stage (harmless re-issue)
+  };
+
+  // ---- prologue: stage 0 complete, the first N3 pieces of stage 1 in flight, fragments of step 0 slice 0
+#pragma unroll
+  for (int i = 0; i < 8; ++i) stage_piece_tr(sp, lds, wave, i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) stage_piece_tr(sq, lds + TILE_BYTES, wave, i);
+  advance();                                             // -> stage 1
+#pragma unroll
+  for (int i = 0; i < N3; ++i) stage_piece_tr(sp, lds + BUF_BYTES, wave, i);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N3) : "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  Frag4 f0, f1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f0.a[i] = lds_frag_tr(lds, ab[i], 0);
+    f0.b[i] = lds_frag_tr(lds + TILE_BYTES, bb[i], 0);
+  }
+
+  v16i acc[4][4];                                        // written (not accumulated) by the first slice of every job
+  int t = 0;
+  auto step = [&](bool first) {
+    char* cur = lds + (t & 1) * BUF_BYTES;
+    char* oth = lds + ((t + 1) & 1) * BUF_BYTES;
+    if (first) w4tr_slice<N3, 16, true>(acc, f0, f1, cur, ab, bb, 1, sp, sq, oth, wave);
+    else w4tr_slice<N3, 16, false>(acc, f0, f1, cur, ab, bb, 1, sp, sq, oth, wave);
+    w4tr_slice<16, 16, false>(acc, f1, f0, cur, ab, bb, 2, sp, sq, oth, wave);
+    w4tr_slice<16, 16, false>(acc, f0, f1, cur, ab, bb, 3, sp, sq, oth, wave);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    advance();                                           // -> stage t+2
+    w4tr_slice<0, N3, false>(acc, f1, f0, oth, ab, bb, 0, sp, sq, cur, wave);
+    ++t;
+  };
+  for (int jj = j0; jj < j1; ++jj) {
+    const int nks = job(jj).nks;
+    for (int ks = 0; ks < nks - 1; ++ks) step(ks == 0);
+    pre(jj);
+    step(nks == 1);
+    epi(jj, acc);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the re-issued tail stages must land before LDS is released
+}
+
+}  // namespace mmg

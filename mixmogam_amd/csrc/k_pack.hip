@@ -115,6 +115,74 @@ void launch_cvt_f64(mmg_ctx* ctx, const double* src, int8_t* dst, int64_t rows, 
                      src, dst, rows, N, ld, d_bad);
 }
 
+// Packed genotype rows -> the int8 store.  BITS = 1: genotype i of a row is bit (i & 7) of byte i >> 3; BITS = 2: bits
+// 2 (i & 3) .. +1 of byte i >> 2 (least significant first: the bit order of numpy.packbits(bitorder='little') and of a
+// PLINK .bed row).  lut: the int8 value of each code, one byte per code (4 codes in a uint32).  One thread writes one
+// 16-byte chunk of the store row (16 individuals = 2 or 4 packed bytes); columns >= N are written as zeros, so a
+// reused store needs no separate clearing of its padding columns.  HBM-bound on the store write: Npad B per SNP out,
+// Npad * BITS / 8 in.
+template <int BITS>
+__global__ __launch_bounds__(256) void unpack_kernel(const uint8_t* __restrict__ src, int64_t row_bytes,
+                                                     int8_t* __restrict__ dst, int64_t rows, int32_t N, int32_t Npad,
+                                                     uint32_t lut) {
+  const int nchunk = Npad >> 4;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= rows * nchunk) return;
+  const int64_t r = gid / nchunk;
+  const int c = (int)(gid % nchunk);
+  const uint8_t* row = src + r * row_bytes;
+  constexpr int NB = 2 * BITS;                           // packed bytes per 16 genotypes
+  uint32_t bits = 0;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int64_t o = (int64_t)c * NB + b;
+    if (o < row_bytes) bits |= (uint32_t)row[o] << (8 * b);
+  }
+  uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const uint32_t code = (bits >> (BITS * j)) & ((1u << BITS) - 1u);
+    const uint32_t v = (c * 16 + j < N) ? ((lut >> (8 * code)) & 0xffu) : 0u;
+    w[j >> 2] |= v << (8 * (j & 3));
+  }
+  *(uint4*)(dst + r * (int64_t)Npad + c * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// [rows x N] contiguous int8 -> rows of the padded store (columns >= N zero): the device half of a staged upload
+__global__ __launch_bounds__(256) void pitch_rows_kernel(const int8_t* __restrict__ src, int8_t* __restrict__ dst,
+                                                         int64_t rows, int32_t N, int32_t Npad) {
+  const int nchunk = Npad >> 4;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= rows * nchunk) return;
+  const int64_t r = gid / nchunk;
+  const int c = (int)(gid % nchunk);
+  const int8_t* row = src + r * (int64_t)N + c * 16;
+  uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (c * 16 + j < N) w[j >> 2] |= (uint32_t)(uint8_t)row[j] << (8 * (j & 3));
+  *(uint4*)(dst + r * (int64_t)Npad + c * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+void launch_pitch_rows(mmg_ctx* ctx, const int8_t* src, int8_t* dst, int64_t rows, int32_t N, int32_t Npad) {
+  const int64_t total = rows * (Npad >> 4);
+  if (total <= 0) return;
+  hipLaunchKernelGGL(pitch_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, src, dst, rows,
+                     N, Npad);
+}
+
+void launch_unpack(mmg_ctx* ctx, const uint8_t* src, int64_t row_bytes, int8_t* dst, int64_t rows, int32_t N,
+                   int32_t Npad, int bits, uint32_t lut) {
+  const int64_t total = rows * (Npad >> 4);
+  if (total <= 0) return;
+  if (bits == 1)
+    hipLaunchKernelGGL(unpack_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, src, row_bytes,
+                       dst, rows, N, Npad, lut);
+  else
+    hipLaunchKernelGGL(unpack_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, src, row_bytes,
+                       dst, rows, N, Npad, lut);
+}
+
 // 64 SNPs x 64 individuals per block; out[i][m] = valid ? mul * s + add : 0.
 __global__ __launch_bounds__(256) void transpose_kernel(const int8_t* __restrict__ S, int64_t M, int32_t N,
                                                         int32_t Npad, int8_t* __restrict__ Xt, int64_t Mk,

@@ -4,8 +4,8 @@
 // so  min_m rss_{m,p} = Ys_p.Ys_p - max_m G_{m,p}^2 / tt_m  with
 //     G_{m,p} = s_m.W_p - mu_m * sum(W_p),  W = H'Ys  [N x P],   tt_m = s~' (H'H) s~.
 // tt comes from the scan's quadratic-form GEMM (model H'H); G is the GEMM S . W computed exactly
-// on the int8 matrix cores with W written as 4 balanced base-256 digits per permutation column
-// (per-column scale).  The four digit rows of one permutation sit in the four 32-row MFMA tiles
+// on the int8 matrix cores with W written as 4 unsigned 7-bit digits per permutation column
+// (per-column scale, entries shifted into the non-negative range: gemm_i8_w4s.h ROWS_OFFSET).  The four digit rows of one permutation sit in the four 32-row MFMA tiles
 // of ONE wave, so the digits are recombined in registers (exact int64), squared, scaled by
 // 1/tt_m and max-reduced over SNPs without ever leaving the chip; one 64-bit atomicMax per
 // (permutation, workgroup) at the end (order independent -> reproducible).
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void perm_rowstat_kernel(const double* __restr
   }
   if (lane == 0) {
     if (!(mx > 0.0)) mx = 1.0;
-    step[p] = mx / 1073741824.0;       // |rint(W/step)| <= 2^30: four balanced digits fit int8
+    step[p] = mx / ROWS_ZMAX;          // |rint(W/step)| <= 2^27 - 1: shifted by 2^27 it is four unsigned 7-bit digits
     csum[p] = s;
   }
 }
@@ -163,13 +163,13 @@ __global__ void perm_quantize_kernel(const double* __restrict__ Wt, int32_t N, i
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int k = c * 16 + e;
-      long long Z = 0;
-      if (k < N) Z = __double2ll_rn(Wt[(int64_t)p * N + k] * inv);
+      // padding columns (k >= N) hold digit 0 in every plane: they meet zero genotypes, and an all-zero operand
+      // column keeps the GEMM's accumulators independent of what the offset would have put there
+      if (k < N) {
+        const long long Z = __double2ll_rn(Wt[(int64_t)p * N + k] * inv) + ROWS_OFFSET;   // in [1, 2^28 - 1]
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const long long z = ((Z + 128) & 255) - 128;
-        Z = (Z - z) >> 8;
-        out[d][e >> 2] |= ((uint32_t)(z & 0xff)) << (8 * (e & 3));
+        for (int d = 0; d < 4; ++d)
+          out[d][e >> 2] |= ((uint32_t)((Z >> (ROWS_DIGIT_BITS * d)) & 127)) << (8 * (e & 3));
       }
     }
   }
@@ -184,7 +184,8 @@ __global__ void perm_quantize_kernel(const double* __restrict__ Wt, int32_t N, i
 __global__ __launch_bounds__(NTHREADS, 2) void perm_gemm_kernel(
     const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Wq, int64_t ldW, int nPT,
     int nch, int sb_per_chunk, int nks, const double* __restrict__ step, const double* __restrict__ csum,
-    const double* __restrict__ mu, const double* __restrict__ inv, unsigned long long* __restrict__ maxstat) {
+    const double* __restrict__ mu, const double* __restrict__ inv, const double* __restrict__ ssum,
+    unsigned long long* __restrict__ maxstat) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int b = blockIdx.x;
   const int x = b & 7, i = b >> 3;
@@ -214,12 +215,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void perm_gemm_kernel(
     for (int nn = 0; nn < 2; ++nn) {
       const int64_t snp = (int64_t)sb * TN + wn * 64 + nn * 32 + r;
       const double u = mu[snp], iv = inv[snp];
+      const int ss = (int)ssum[snp];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int pl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const long long gi = (long long)acc[0][nn][e] + ((long long)acc[1][nn][e] << 8) +
-                             ((long long)acc[2][nn][e] << 16) + ((long long)acc[3][nn][e] << 24);
-        const double G = fma((double)gi, ex[pl], -u * ex[PERM_TILE + pl]);
+        const double gd = digits4_to_f64<false>(acc[0][nn][e], acc[1][nn][e], acc[2][nn][e], acc[3][nn][e], ss);
+        const double G = fma(gd, ex[pl], -u * ex[PERM_TILE + pl]);
         maxv[e] = fmax(maxv[e], G * G * iv);
       }
     }
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(W4_THREADS) void perm_gemm_w4_kernel(
     const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Wq, int64_t ldW, int nPT,
     const int2* __restrict__ groups, int nch, int sb_per_chunk, int nks, const double* __restrict__ step,
     const double* __restrict__ csum, const double* __restrict__ mu, const double* __restrict__ inv,
-    unsigned long long* __restrict__ maxstat) {
+    const double* __restrict__ ssum, unsigned long long* __restrict__ maxstat) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int pt, chunk;
   if (!w4_group_place(groups, blockIdx.x, nPT, nch, pt, chunk)) return;
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(W4_THREADS) void perm_gemm_w4_kernel(
 #pragma unroll
   for (int e = 0; e < 16; ++e) maxv[e] = 0.0;
   double u[4], iv[4];
+  int ss[4];
   w4s_stream(
       sb0, sb1, ldW, ldS, lds,
       [&](int sb) { return W4Job{P, S + (int64_t)sb * TN * ldS, nks}; },
@@ -274,6 +276,7 @@ __global__ __launch_bounds__(W4_THREADS) void perm_gemm_w4_kernel(
           const int64_t snp = (int64_t)sb * TN + wn * 128 + nn * 32 + r;
           u[nn] = mu[snp];
           iv[nn] = inv[snp];
+          ss[nn] = (int)ssum[snp];
         }
       },
       [&](int, v16i (&acc)[4][4]) {
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(W4_THREADS) void perm_gemm_w4_kernel(
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int pl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            const double gd = digits4_to_f64<FAST>(acc[0][nn][e], acc[1][nn][e], acc[2][nn][e], acc[3][nn][e]);
+            const double gd = digits4_to_f64<FAST>(acc[0][nn][e], acc[1][nn][e], acc[2][nn][e], acc[3][nn][e], ss[nn]);
             const double G = fma(gd, ex[pl], -u[nn] * ex[PERM_TILE + pl]);
             maxv[e] = fmax(maxv[e], G * G * iv[nn]);
           }
@@ -315,7 +318,7 @@ int upload_group_table(mmg_ctx* ctx, const std::vector<int2>& tab) {
   return MMG_OK;
 }
 
-// Rows of Wt [P x N] (device fp64) -> four balanced base-256 digits per row with a per-row step, in the operand
+// Rows of Wt [P x N] (device fp64) -> four unsigned 7-bit digits per row (entries shifted by ROWS_OFFSET) with a per-row step, in the operand
 // layout of the 256-row P tile (64 rows x 4 digits per tile; see perm_quantize_kernel).  Wq: [ceil(P/64)][256][Npad],
 // dstep / dcsum: [ceil(P/64)*64] (zero beyond P).  Shared with the eigen-rotation GEMM (k_rot.hip).
 int quantize_rows_4digits(mmg_ctx* ctx, const double* dWt, int32_t N, int32_t Npad, int32_t P, int8_t* Wq, double* dstep,
@@ -334,7 +337,7 @@ int quantize_rows_4digits(mmg_ctx* ctx, const double* dWt, int32_t N, int32_t Np
 }
 
 int run_perm(mmg_ctx* ctx, const mmg_geno* g, int32_t N, const double* dWt, int32_t P, const double* d_inv,
-             const double* d_mu, int ndigits, double* d_maxstat) {
+             const double* d_mu, const double* d_ssum, int ndigits, double* d_maxstat) {
   (void)ndigits;
   const int Npad = g->Npad;
   const int nPT = (P + PERM_TILE - 1) / PERM_TILE;
@@ -347,12 +350,13 @@ int run_perm(mmg_ctx* ctx, const mmg_geno* g, int32_t N, const double* dWt, int3
   MMG_HIP(ctx, sc.alloc(&Wq, (size_t)nPT * TM * Npad));
   int rcq = quantize_rows_4digits(ctx, dWt, N, Npad, P, Wq, dstep, dcsum);
   if (rcq) return rcq;
-  return run_perm_q(ctx, g, Wq, dstep, dcsum, P, d_inv, d_mu, d_maxstat);
+  return run_perm_q(ctx, g, Wq, dstep, dcsum, P, d_inv, d_mu, d_ssum, d_maxstat);
 }
 
-// the GEMM + max-reduce over a digit image of W prepared once (mmg_perm_plan): Wq [ceil(P/64)][256][Npad]
+// the GEMM + max-reduce over a digit image of W prepared once (mmg_perm_plan): Wq [ceil(P/64)][256][Npad];
+// d_ssum [Mpad]: the exact genotype sum of every SNP (takes the digit offset out of the accumulators)
 int run_perm_q(mmg_ctx* ctx, const mmg_geno* g, const int8_t* Wq, const double* dstep, const double* dcsum, int32_t P,
-               const double* d_inv, const double* d_mu, double* d_maxstat) {
+               const double* d_inv, const double* d_mu, const double* d_ssum, double* d_maxstat) {
   const int Npad = g->Npad;
   const int nPT = (P + PERM_TILE - 1) / PERM_TILE;
   const int Ppad = nPT * PERM_TILE;
@@ -372,7 +376,7 @@ int run_perm_q(mmg_ctx* ctx, const mmg_geno* g, const int8_t* Wq, const double* 
     EvScope ev(ctx, EV_PERM);
     hipLaunchKernelGGL(perm_gemm_kernel, dim3((unsigned)(8 * rounds * nch)), dim3(NTHREADS), LDS_BYTES + PERM_LDS_EXTRA,
                        ctx->stream, g->d, (int64_t)Npad, nSb, Wq, (int64_t)Npad, nPT, nch, per, Npad / BK, dstep, dcsum,
-                       d_mu, d_inv, (unsigned long long*)d_maxstat);
+                       d_mu, d_inv, d_ssum, (unsigned long long*)d_maxstat);
   } else {
     // groups of 2 permutation tiles x 16 SNP chunks per XCD (gemm_i8_w4s.h: w4_group_table)
     int GV = 2;
@@ -390,7 +394,8 @@ int run_perm_q(mmg_ctx* ctx, const mmg_geno* g, const int8_t* Wq, const double* 
 #define MMG_LAUNCH_PERM_W4(F)                                                                                          \
   hipLaunchKernelGGL(perm_gemm_w4_kernel<F>, dim3((unsigned)(256 * tab.size())), dim3(W4_THREADS),                     \
                      LDS_BYTES + PERM_LDS_EXTRA, ctx->stream, g->d, (int64_t)Npad, nSb, Wq, (int64_t)Npad, nPT,        \
-                     ctx->grp_tab, nch4, per4, Npad / BK, dstep, dcsum, d_mu, d_inv, (unsigned long long*)d_maxstat)
+                     ctx->grp_tab, nch4, per4, Npad / BK, dstep, dcsum, d_mu, d_inv, d_ssum,                            \
+                     (unsigned long long*)d_maxstat)
     if (fast) MMG_LAUNCH_PERM_W4(true); else MMG_LAUNCH_PERM_W4(false);
 #undef MMG_LAUNCH_PERM_W4
   }

@@ -9,8 +9,8 @@
 //     den   = t_m.t_m = sum_i w_pi^2 tau_mi^2 - sum_c (sum_i Q_p[i][c] w_pi tau_mi)^2
 //     dot   = t_m.r_p = sum_i w_pi r_pi tau_mi        (r_p: residual of the transformed phenotype, Q_p'r_p = 0)
 //     rss   = h0_rss_p - dot^2 / den,   F = (h0_rss_p / rss - 1) df2,   p = f.sf(F, 1, df2)
-// so the O(N^2) work per SNP is done ONCE (T = S U', an exact int8-MFMA digit GEMM, 4 balanced base-256 digits per
-// eigenvector with a per-eigenvector step -- the operand layout and mainloop of the permutation GEMM, k_perm.hip),
+// so the O(N^2) work per SNP is done ONCE (T = S U', an exact int8-MFMA digit GEMM, 4 unsigned 7-bit digits per
+// eigenvector (entries shifted into the non-negative range, gemm_i8_w4s.h ROWS_OFFSET) with a per-eigenvector step -- the operand layout and mainloop of the permutation GEMM, k_perm.hip),
 // kept in HBM as fp64, eigen-major inside blocks of 256 SNPs (T[m / 256][i][m % 256]: a scan workgroup streams one
 // contiguous 2 KB x N region, page after page; 8 N bytes per SNP: 41 GB at N = 5000, M = 1e6 -- what 288 GB are for),
 // and every phenotype afterwards costs one HBM-bound pass of 2 + q fused multiply-adds per element:
@@ -37,7 +37,8 @@ constexpr int ROT_TILE = 64;                       // eigenvectors per workgroup
 
 __global__ __launch_bounds__(NTHREADS, 2) void rot_gemm_kernel(
     const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Vq, int64_t ldV, int nVT, int nch,
-    int sb_per_chunk, int nks, const double* __restrict__ step, double* __restrict__ T, int64_t nrows) {
+    int sb_per_chunk, int nks, const double* __restrict__ step, const double* __restrict__ ssum, double* __restrict__ T,
+    int64_t nrows) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int b = blockIdx.x;
   const int x = b & 7, i = b >> 3;
@@ -60,12 +61,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void rot_gemm_kernel(
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn) {
       const int snp = wn * 64 + nn * 32 + r;
+      const int ss = (int)ssum[(int64_t)sb * TN + snp];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int pl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const long long gi = (long long)acc[0][nn][e] + ((long long)acc[1][nn][e] << 8) +
-                             ((long long)acc[2][nn][e] << 16) + ((long long)acc[3][nn][e] << 24);
-        Tb[(int64_t)(vt * ROT_TILE + pl) * TN + snp] = (double)gi * ex[pl];
+        Tb[(int64_t)(vt * ROT_TILE + pl) * TN + snp] =
+            digits4_to_f64<false>(acc[0][nn][e], acc[1][nn][e], acc[2][nn][e], acc[3][nn][e], ss) * ex[pl];
       }
     }
   }
@@ -77,7 +78,7 @@ template <bool FAST>
 __global__ __launch_bounds__(W4_THREADS) void rot_gemm_w4_kernel(
     const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Vq, int64_t ldV, int nVT,
     const int2* __restrict__ groups, int nch, int sb_per_chunk, int nks, const double* __restrict__ step,
-    double* __restrict__ T, int64_t nrows) {
+    const double* __restrict__ ssum, double* __restrict__ T, int64_t nrows) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int vt, chunk;
   if (!w4_group_place(groups, blockIdx.x, nVT, nch, vt, chunk)) return;
@@ -90,8 +91,13 @@ __global__ __launch_bounds__(W4_THREADS) void rot_gemm_w4_kernel(
   if (threadIdx.x < ROT_TILE) ex[threadIdx.x] = step[vt * ROT_TILE + threadIdx.x];
   __syncthreads();
   const int8_t* P = Vq + (int64_t)vt * TM * ldV;
+  int ss[4];
   w4s_stream(
-      sb0, sb1, ldV, ldS, lds, [&](int sb) { return W4Job{P, S + (int64_t)sb * TN * ldS, nks}; }, [](int) {},
+      sb0, sb1, ldV, ldS, lds, [&](int sb) { return W4Job{P, S + (int64_t)sb * TN * ldS, nks}; },
+      [&](int sb) {
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) ss[nn] = (int)ssum[(int64_t)sb * TN + wn * 128 + nn * 32 + r];
+      },
       [&](int sb, v16i (&acc)[4][4]) {
         double* Tb = T + (int64_t)sb * nrows * TN;
 #pragma unroll
@@ -101,13 +107,14 @@ __global__ __launch_bounds__(W4_THREADS) void rot_gemm_w4_kernel(
           for (int e = 0; e < 16; ++e) {
             const int pl = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             Tb[(int64_t)(vt * ROT_TILE + pl) * TN + snp] =
-                digits4_to_f64<FAST>(acc[0][nn][e], acc[1][nn][e], acc[2][nn][e], acc[3][nn][e]) * ex[pl];
+                digits4_to_f64<FAST>(acc[0][nn][e], acc[1][nn][e], acc[2][nn][e], acc[3][nn][e], ss[nn]) * ex[pl];
           }
         }
       });
 }
 
-int run_rotate(mmg_ctx* ctx, const mmg_geno* g, const int8_t* Vq, const double* dstep, int nVT, double* T) {
+int run_rotate(mmg_ctx* ctx, const mmg_geno* g, const int8_t* Vq, const double* dstep, const double* d_ssum, int nVT,
+               double* T) {
   const int nSb = (int)(g->Mpad / TN);
   if (nSb == 0 || nVT == 0) return MMG_OK;
   const int rounds = (nVT + 7) / 8;
@@ -123,7 +130,7 @@ int run_rotate(mmg_ctx* ctx, const mmg_geno* g, const int8_t* Vq, const double* 
     EvScope ev(ctx, EV_ROT);
     hipLaunchKernelGGL(rot_gemm_kernel, dim3((unsigned)(8 * rounds * nch)), dim3(NTHREADS), LDS_BYTES + ROT_TILE * 8,
                        ctx->stream, g->d, (int64_t)g->Npad, nSb, Vq, (int64_t)g->Npad, nVT, nch, per, g->Npad / BK,
-                       dstep, T, (int64_t)nVT * ROT_TILE);
+                       dstep, d_ssum, T, (int64_t)nVT * ROT_TILE);
   } else {
     // groups of 4 eigen tiles x 8 SNP chunks per XCD (gemm_i8_w4s.h: w4_group_table)
     int GV = 4;
@@ -141,7 +148,7 @@ int run_rotate(mmg_ctx* ctx, const mmg_geno* g, const int8_t* Vq, const double* 
 #define MMG_LAUNCH_ROT_W4(F)                                                                                           \
   hipLaunchKernelGGL(rot_gemm_w4_kernel<F>, dim3((unsigned)(256 * tab.size())), dim3(W4_THREADS),                      \
                      LDS_BYTES + ROT_TILE * 8, ctx->stream, g->d, (int64_t)g->Npad, nSb, Vq, (int64_t)g->Npad, nVT,    \
-                     ctx->grp_tab, nch4, per4, g->Npad / BK, dstep, T, (int64_t)nVT * ROT_TILE)
+                     ctx->grp_tab, nch4, per4, g->Npad / BK, dstep, d_ssum, T, (int64_t)nVT * ROT_TILE)
     if (fast) MMG_LAUNCH_ROT_W4(true); else MMG_LAUNCH_ROT_W4(false);
 #undef MMG_LAUNCH_ROT_W4
   }

@@ -96,6 +96,8 @@ struct mmg_ctx {
   int2* grp_tab = nullptr;      // workgroup-group table of the perm / rotation GEMM launches (gemm_i8_w4s.h)
   size_t grp_cap = 0;
   std::vector<int2> grp_host;   // host image of grp_tab (source of the asynchronous upload: must outlive it)
+  void* ingest = nullptr;       // device staging of the genotype ingest paths (packed rows, pageable int8 rows); kept:
+  size_t ingest_cap = 0;        // hipMalloc / hipFree per chunk would serialise the upload stream with the compute stream
 };
 
 namespace mmg {
@@ -135,6 +137,9 @@ struct EvScope {  // records the two events of slot `which` around a region on c
 void launch_fill_hash(mmg_ctx*, mmg_geno*, uint64_t seed, int64_t m_global0, uint32_t thr16);
 void launch_fill_struct(mmg_ctx*, mmg_geno*, uint64_t seed, int64_t m_global0, int npop, uint32_t spread_q16);
 // fp32 / fp64 genotype ingest -> int8; *d_bad |= 1 if any value is not an integer in [-127, 127]
+void launch_unpack(mmg_ctx*, const uint8_t* src, int64_t row_bytes, int8_t* dst, int64_t rows, int32_t N, int32_t Npad,
+                   int bits, uint32_t lut);              // 1- / 2-bit packed rows -> int8 store rows (k_pack.hip)
+void launch_pitch_rows(mmg_ctx*, const int8_t* src, int8_t* dst, int64_t rows, int32_t N, int32_t Npad);   // [rows x N] -> [rows x Npad], zero padded
 void launch_cvt_f32(mmg_ctx*, const float* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld, int* d_bad);
 void launch_cvt_f64(mmg_ctx*, const double* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld, int* d_bad);
 // Xt [Npad x Mk] = transpose of S with value map v -> mul*v + add for valid cells, 0 elsewhere.
@@ -197,11 +202,13 @@ void launch_perm_center(mmg_ctx*, const mmg_geno*, const mmg_scan_result&, doubl
 void launch_perm_center_reuse(mmg_ctx*, const mmg_geno*, const double* den, const double* dots, int q, const double* sum,
                               double c0, double* d_mu, double* d_inv);
 // d_maxstat[p] = max_m (s~_m . W_p)^2 * inv[m];  dWt: device [P x N] row-major fp64
+// d_ssum [Mpad]: exact genotype sum of every SNP (0 for the padding rows): takes the non-negative digit offset of the
+// operand rows out of the accumulators (gemm_i8_w4s.h ROWS_OFFSET)
 int run_perm(mmg_ctx*, const mmg_geno*, int32_t N, const double* dWt, int32_t P, const double* d_inv,
-             const double* d_mu, int ndigits, double* d_maxstat);
+             const double* d_mu, const double* d_ssum, int ndigits, double* d_maxstat);
 
 int run_perm_q(mmg_ctx*, const mmg_geno*, const int8_t* Wq, const double* dstep, const double* dcsum, int32_t P,
-               const double* d_inv, const double* d_mu, double* d_maxstat);
+               const double* d_inv, const double* d_mu, const double* d_ssum, double* d_maxstat);
 void launch_colsum(mmg_ctx*, const mmg_geno*, unsigned long long* r);          // r[Npad] += column sums of the store
 void launch_mirror_ibs(mmg_ctx*, const int* C32, int32_t Npad, int32_t N, const long long* r, long long Mtot, int64_t* C);
 // ---- k_perm.hip: centring of the permutation test's operands, 1 / t.t from a centred quadratic form
@@ -215,7 +222,8 @@ int quantize_rows_4digits(mmg_ctx*, const double* dWt, int32_t N, int32_t Npad, 
 // ---- k_rot.hip: eigen-rotated genotype store + multi-phenotype scan
 // T [Mpad/256][nVT*64][256] (fp64; eigen-major inside 256-SNP blocks): T[m/256][i][m%256] = u_i . s_m for the SNPs
 // of g (exact int8 digit GEMM)
-int run_rotate(mmg_ctx*, const mmg_geno* g, const int8_t* Vq, const double* dstep, int nVT, double* T);
+int run_rotate(mmg_ctx*, const mmg_geno* g, const int8_t* Vq, const double* dstep, const double* d_ssum /*[Mpad]*/, int nVT,
+               double* T);
 // one pass over T for PB <= 8 phenotypes with q <= 4 fixed-effect columns each; coef: device [N][PB*(2+q)]
 int run_scan_multi(mmg_ctx*, const double* T, int64_t nrows, int32_t N, int64_t M, int PB, int q, const double* coef,
                    const double* h0 /*device [PB]*/, int32_t df2, double lnbeta, double* rss, double* F, double* p,

@@ -50,13 +50,28 @@ def _maf_filter(cg, min_maf):
     return np.minimum(freqs, 1 - freqs) > min_maf                       # hdf5_data.py:91-93
 
 
+def _raw_dataset(cg):
+    """(dataset, bits): the chromosome's genotype rows -- `raw_snps` int8 [M_c x N] (plink2hdf5.py:111), or, where
+    that is absent, `raw_snps_packed` uint8 [M_c x ceil(N*bits/8)] with `packed_bits` (1 or 2) and `num_indivs`
+    (chunkstore.write_genotype_container(packed_bits=...)): 8x / 4x fewer bytes off the disk and over PCIe, expanded
+    on the device (mmg_geno_upload_packed)."""
+    if 'raw_snps' in cg:
+        return cg['raw_snps'], 0
+    return cg['raw_snps_packed'], int(np.asarray(cg['packed_bits'][...]))
+
+
+def _num_indivs(cg):
+    raw, bits = _raw_dataset(cg)
+    return int(np.asarray(cg['num_indivs'][...])) if bits else int(np.asarray(raw[0:1]).shape[1])
+
+
 def _chunk_plan(genot_data, min_maf, chunk_size):
     """[(chrom, kept row indices of the chunk, positions of the chunk)] without touching raw_snps."""
     plan = []
     for chrom in genot_data.keys():
         cg = genot_data[chrom]
         if min_maf is None:
-            idx = np.arange(len(cg['raw_snps']))
+            idx = np.arange(len(_raw_dataset(cg)[0]))
         else:
             idx = np.nonzero(_maf_filter(cg, min_maf))[0]
         positions = np.asarray(cg['positions'][...])[idx] if 'positions' in cg else idx
@@ -69,12 +84,13 @@ def _read_chunk(genot_data, chrom, sel, out=None):
     """Rows `sel` of a chromosome's raw_snps as a C-contiguous int8 block.  out: a reusable (page-locked) host buffer
     of at least len(sel) * N bytes -- a memory-mapped dataset is then read with one readinto() into it instead of
     being faulted in page by page through the mapping (2.8 GB/s at config 5's chunk size) and staged a second time."""
-    raw = genot_data[chrom]['raw_snps']
+    raw, bits = _raw_dataset(genot_data[chrom])
     lo, hi = int(sel[0]), int(sel[-1]) + 1
-    n_ind = raw.shape[1]
-    if (out is not None and isinstance(raw, np.memmap) and raw.dtype == np.int8 and raw.flags['C_CONTIGUOUS']
+    n_ind = raw.shape[1]                                                 # bytes per row (packed: ceil(N*bits/8))
+    want = np.uint8 if bits else np.int8
+    if (out is not None and isinstance(raw, np.memmap) and raw.dtype == want and raw.flags['C_CONTIGUOUS']
             and len(sel) == hi - lo and getattr(raw, 'filename', None) is not None):
-        block = out[:(hi - lo) * n_ind].reshape(hi - lo, n_ind)
+        block = out.view(want)[:(hi - lo) * n_ind].reshape(hi - lo, n_ind)
         mv = memoryview(block).cast('B')
         base = raw.offset + lo * n_ind
 
@@ -101,7 +117,18 @@ def _read_chunk(genot_data, chrom, sel, out=None):
     block = np.asarray(raw[lo:hi])                                       # one contiguous read ...
     if len(sel) != hi - lo:
         block = block[sel - lo]                                          # ... then the MAF subset
-    return np.ascontiguousarray(block, dtype=np.int8)
+    return np.ascontiguousarray(block, dtype=want)
+
+
+def _upload_chunk(ctx, genot_data, chrom, block, store=None):
+    """The chunk's rows into a (new or pooled) store: int8 rows as they are, packed rows through the device unpack."""
+    cg = genot_data[chrom]
+    _raw, bits = _raw_dataset(cg)
+    if not bits:
+        return ctx.geno(block) if store is None else store.reset(len(block)).upload(block)
+    n = _num_indivs(cg)
+    g = ctx.geno(M=len(block), N=n) if store is None else store.reset(len(block))
+    return g.upload_packed(block, bits=bits)
 
 
 class _Borrowed(object):
@@ -127,7 +154,7 @@ def _resident_chunks(ctx, genot_data, plan, rank=0, world=1, prefetch=True, reus
     if not (prefetch and isinstance(ctx, _lib.Context)):
         for ci in mine:
             chrom, sel, _pos = plan[ci]
-            yield ci, chrom, ctx.geno(_read_chunk(genot_data, chrom, sel))
+            yield ci, chrom, _upload_chunk(ctx, genot_data, chrom, _read_chunk(genot_data, chrom, sel))
         return
     from concurrent.futures import ThreadPoolExecutor
     up = _UPLOAD_CTX.get(ctx.device)
@@ -136,7 +163,7 @@ def _resident_chunks(ctx, genot_data, plan, rank=0, world=1, prefetch=True, reus
     pool, host = [], [None, None]
     if reuse and mine:
         cap = max(len(plan[ci][1]) for ci in mine)
-        n_ind = int(np.asarray(genot_data[plan[mine[0]][0]]['raw_snps'][0:1]).shape[1])
+        n_ind = _num_indivs(genot_data[plan[mine[0]][0]])
         # two HBM stores + two page-locked staging buffers, kept between calls (kinship pass, scan pass, the next
         # file ...): allocating them costs ~0.1 s, as much as streaming 5 GB
         key = (ctx.device, n_ind)
@@ -153,8 +180,8 @@ def _resident_chunks(ctx, genot_data, plan, rank=0, world=1, prefetch=True, reus
         chrom, sel, _pos = plan[ci]
         block = _read_chunk(genot_data, chrom, sel, out=host[slot])
         if pool:
-            return ci, chrom, _Borrowed(pool[slot].reset(len(block)).upload(block))
-        return ci, chrom, up.geno(block)
+            return ci, chrom, _Borrowed(_upload_chunk(up, genot_data, chrom, block, store=pool[slot]))
+        return ci, chrom, _upload_chunk(up, genot_data, chrom, block)
 
     try:
         with ThreadPoolExecutor(max_workers=1) as ex:

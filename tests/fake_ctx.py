@@ -14,6 +14,13 @@ class FakeGeno(_lib.Geno):
         self.M, self.N = self.data.shape
         self.h = None
 
+    def upload_packed(self, packed, bits=1, m0=0, lut=None):
+        vals = _lib.unpack_genotypes(packed, self.N, bits)
+        if lut is not None:
+            vals = np.asarray(lut, dtype=np.int8)[vals]
+        self.data[m0:m0 + len(vals)] = vals
+        return self
+
     def download(self, m0=0, rows=None):
         rows = self.M - m0 if rows is None else rows
         return self.data[m0:m0 + rows].copy()

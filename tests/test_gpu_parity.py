@@ -362,7 +362,9 @@ def test_permutations_vs_golden_and_oracle(ctx, name, monkeypatch):
     monkeypatch.setenv("MMG_SCAN_ADAPTIVE", "0")
     got = ctx.perm(ctx.geno(case["snps"]), est["H_sqrt_inv"], pp["Ys"], pp["h0_rss"])
     monkeypatch.delenv("MMG_SCAN_ADAPTIVE")
-    assert rel(got, ref["min_rss"]) < 1e-9
+    # round 3: the W digits of the permutation GEMM are 4 unsigned 7-bit planes (28 bits of each column's largest
+    # entry; round 2: 31 bits in balanced base-256 digits, 1e-9 here) -- G carries ~2e-9 relative, min_rss a tenth of it
+    assert rel(got, ref["min_rss"]) < 5e-9
 
 
 def test_permutations_ragged_and_many(ctx):
@@ -382,7 +384,7 @@ def test_permutations_ragged_and_many(ctx):
     keep[7] = False
     ref = orc.perm_closed(snps[keep], pp)
     got = ctx.perm(ctx.geno(snps), est["H_sqrt_inv"], pp["Ys"], pp["h0_rss"])
-    assert rel(got, ref["min_rss"]) < 1e-9
+    assert rel(got, ref["min_rss"]) < 5e-9                      # 28-bit W digits (round 3), see above
     # sharding property: min over two SNP halves == min over all (what the RCCL MIN all-reduce does)
     a = ctx.perm(ctx.geno(snps[:700]), est["H_sqrt_inv"], pp["Ys"], pp["h0_rss"])
     b = ctx.perm(ctx.geno(snps[700:]), est["H_sqrt_inv"], pp["Ys"], pp["h0_rss"])

@@ -35,9 +35,10 @@ def rel(a, b):
 # ------------------------------------------------------------------ eigen-rotated store
 @pytest.mark.parametrize("n,m,hi", [(150, 700, 2), (300, 1000, 3), (257, 513, 2), (1100, 2500, 2), (64, 5, 3)])
 def test_rot_store_equals_float64_rotation(ctx, n, m, hi):
-    """T[i][m] = u_i . s_m from the int8 digit GEMM (4 digits per eigenvector, exact integer accumulation) against
-    a float64 matrix product.  Every entry of u_i is rounded to 2^-31 max|u_i| (uniform), so the error of T is a
-    sum of sum(s^2) such roundings: sigma = 2^-31 max|u| sqrt(sum s^2 / 3); asserted at 8 sigma (~1e-9 of |T|)."""
+    """T[i][m] = u_i . s_m from the int8 digit GEMM (4 unsigned 7-bit digits per eigenvector, exact integer
+    accumulation) against a float64 matrix product.  Every entry of u_i is rounded to 2^-27 max|u_i| (uniform, +-half
+    a step), so the error of T is a sum of sum(s^2) such roundings: sigma = 2^-28 max|u| sqrt(sum s^2 / 3); asserted
+    at 8 sigma (~1e-8 of |T|; round 2's balanced base-256 digits carried three more bits at 6-9 % more time)."""
     rng = np.random.RandomState(n + m)
     Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
     V = np.ascontiguousarray(Q.T)                           # rows orthonormal, like eigh's eigenvectors
@@ -47,8 +48,8 @@ def test_rot_store_equals_float64_rotation(ctx, n, m, hi):
     T = rot.fetch()
     ref = V @ snps.T.astype(np.float64)
     assert T.shape == (n, m)
-    tol = 8 * 2.0 ** -31 * np.max(np.abs(V)) * np.sqrt(np.max((snps.astype(np.float64) ** 2).sum(1)) / 3)
-    assert tol < 5e-9 * np.max(np.abs(ref))
+    tol = 8 * 2.0 ** -28 * np.max(np.abs(V)) * np.sqrt(np.max((snps.astype(np.float64) ** 2).sum(1)) / 3)
+    assert tol < 4e-8 * np.max(np.abs(ref))
     assert np.max(np.abs(T - ref)) < tol
     assert np.max(np.abs(rot.fetch(3, 2) - ref[:, 3:5])) < tol
     # reloading another (smaller) block reuses the store
@@ -234,7 +235,7 @@ def test_non_integral_or_out_of_range_genotypes_are_rejected(ctx):
                 ctx.geno(s2.astype(dt))
     with pytest.raises(ValueError):
         ctx.geno(np.full((3, 70), 200, dtype=np.int16))               # would wrap to -56 in int8
-    with pytest.raises(_lib.MixmogamHipError):
+    with pytest.raises(ValueError):                                   # round 3: caught on the host before the copy
         ctx.geno(np.full((3, 70), -128, dtype=np.int8))
     assert np.array_equal(ctx.geno(np.full((3, 70), 2, dtype=np.int64)).download(), np.full((3, 70), 2, dtype=np.int8))
 

@@ -356,3 +356,33 @@ def test_real_hdf5_files_drive_the_same_driver(ctx, tmp_path):
         assert sorted(kf.keys()) == ["accessions", "kinship", "n_snps"]        # kinship.py:163-166
     kd = kinship.load_kinship_from_file(kpath, scaled=False)
     assert np.array_equal(kd["k"], ref["kinship"]) and kd["n_snps"] == 500
+
+
+@pytest.mark.parametrize("bits,hi", [(1, 2), (2, 3)])
+def test_packed_genotype_containers_drive_the_same_driver(ctx, tmp_path, bits, hi):
+    """`raw_snps_packed` (1 / 2 bits per genotype, low bits first) instead of `raw_snps`: pack / unpack round trip
+    and run_emmax over the packed container == run_emmax over the int8 one (host logic; the device unpack is
+    tests/test_gpu_round3.py)."""
+    from mixmogam_amd import _lib, chunkstore
+    rng = np.random.RandomState(bits)
+    n = 61                                                                # not a multiple of 8 or 4: ragged last byte
+    snps = {"chrom_%d" % c: rng.randint(0, hi, size=(150 + 10 * c, n)).astype(np.int8) for c in (1, 2)}
+    for c in snps:
+        p = _lib.pack_genotypes(snps[c], bits)
+        assert p.dtype == np.uint8 and p.shape == (len(snps[c]), (n * bits + 7) // 8)
+        assert np.array_equal(_lib.unpack_genotypes(p, n, bits), snps[c])
+    assert np.array_equal(_lib.pack_genotypes(np.array([[1, 0, 0, 0, 0, 0, 0, 0, 1]]), 1), [[1, 1]])        # LSB first
+    assert np.array_equal(_lib.pack_genotypes(np.array([[1, 2, 3, 0, 2]]), 2), [[1 | 2 << 2 | 3 << 4, 2]])  # .bed order
+    with pytest.raises(ValueError):
+        _lib.pack_genotypes(np.array([[0, 2]]), 1)
+    y = rng.randn(n) + snps["chrom_1"][7]
+    a = chunkstore.write_genotype_container(str(tmp_path / "plain.mmg"), snps, range(n), phenotypes=y)
+    b = chunkstore.write_genotype_container(str(tmp_path / "packed.mmg"), snps, range(n), phenotypes=y, packed_bits=bits)
+    g = chunkstore.open_container(b, "r")["genot_data"]["chrom_1"]
+    assert "raw_snps" not in g and int(g["packed_bits"][...]) == bits and int(g["num_indivs"][...]) == n
+    ra = hdf5_data.run_emmax(a, None, min_maf=0.05, chunk_size=64, ctx=ctx)
+    rb = hdf5_data.run_emmax(b, None, min_maf=0.05, chunk_size=64, ctx=ctx)
+    assert ra["num_snps"] == rb["num_snps"]
+    for c in ra["chrom_results"]:
+        assert np.array_equal(ra["chrom_results"][c]["ps"], rb["chrom_results"][c]["ps"])
+    assert np.array_equal(ra["kinship"], rb["kinship"])
