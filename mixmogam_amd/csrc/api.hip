@@ -247,10 +247,11 @@ static int ensure_ingest(mmg_ctx* ctx, size_t bytes) {
   return MMG_OK;
 }
 
-static bool host_is_pinned(const void* p) {
-  hipPointerAttribute_t a;
-  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain pageable memory
-  return a.type == hipMemoryTypeHost;
+
+// MMG_UPLOAD_PATH=2d: strided hipMemcpy2DAsync straight into the padded store instead of the staged copy (A/B timing)
+static bool upload_2d() {
+  static const bool forced = [] { const char* e = std::getenv("MMG_UPLOAD_PATH"); return e && std::string(e) == "2d"; }();
+  return forced;
 }
 
 // every write path ends here: fold max |s| of the written rows into the store's running bound
@@ -270,18 +271,17 @@ int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, i
   MMG_CHECK_ARG(ctx, g && snps && m0 >= 0 && rows >= 0 && m0 + rows <= g->M);
   if (rows == 0) return MMG_OK;
   g->bits_valid = false; ++g->version;
-  // Page-locked host rows go straight into the padded store (strided DMA at link rate).  Pageable rows are staged:
-  // a strided copy out of pageable memory runs row by row through the runtime's bounce buffer (measured 20 GB/s on
-  // one box of the pool against 49-56 GB/s for contiguous copies), so the block crosses as ONE contiguous copy into
-  // device staging and pitch_rows_kernel spreads it over the padded rows.
+  // The block crosses the link as contiguous copies into device staging and pitch_rows_kernel spreads it over the padded
+  // rows.  hipMemcpy2DAsync straight into the store runs row by row: 15-20 GB/s from page-locked AND pageable memory
+  // on this ROCm (tools/h2d_check.py) against 50+ GB/s for contiguous copies.  MMG_UPLOAD_PATH=2d keeps the old path.
   if (g->N == g->Npad) {
     MMG_HIP(ctx, hipMemcpyAsync(g->d + m0 * (int64_t)g->Npad, snps, (size_t)rows * g->N, hipMemcpyHostToDevice, ctx->stream));
-  } else if (host_is_pinned(snps)) {
+  } else if (upload_2d()) {
     MMG_HIP(ctx, hipMemcpy2DAsync(g->d + m0 * (int64_t)g->Npad, g->Npad, snps, g->N, g->N, rows,
                                   hipMemcpyHostToDevice, ctx->stream));
   } else {
     const int64_t chunk = std::max<int64_t>(1, INGEST_STAGE_BYTES / g->N);
-    int rc0 = ensure_ingest(ctx, (size_t)std::min(chunk, rows) * g->N);
+    int rc0 = ensure_ingest(ctx, (size_t)std::min(chunk, rows) * g->N + 32);
     if (rc0) return rc0;
     for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
       const int64_t nr = std::min(chunk, rows - r0);
@@ -493,17 +493,27 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
   MMG_CHECK_ARG(ctx, vmax * vmax * g->M < (int64_t(1) << 31));   // int32 accumulators: |C_ij| <= max|x|^2 M
   const int64_t CH = kin_chunk();
   const int64_t Mk_max = std::min(round_up(g->M, BK), CH);
+  // Round 3: the raw-genotype product reads the SNP-major store as it lies (gemm_i8_w4tr.h: transposed LDS reads) --
+  // no individual-major image, no transposition pass.  MMG_KIN_KERNEL=w4 / w8: the transposed-image generations.
+  static const bool tr_off = [] { const char* e = std::getenv("MMG_KIN_KERNEL"); return e && (std::string(e) == "w4" || std::string(e) == "w8"); }();
+  const bool direct = ibs && !tr_off;
   int8_t* Xt = nullptr;
   int* C32 = nullptr;
   int64_t* C64 = nullptr;
-  hipError_t e = sc.alloc(&Xt, (size_t)g->Npad * Mk_max);
-  if (e != hipSuccess) return set_err(ctx, MMG_E_NOMEM, "hipMalloc transposed genotype image");
+  if (!direct) {
+    hipError_t e = sc.alloc(&Xt, (size_t)g->Npad * Mk_max);
+    if (e != hipSuccess) return set_err(ctx, MMG_E_NOMEM, "hipMalloc transposed genotype image");
+  }
   MMG_HIP(ctx, sc.alloc(&C32, (size_t)g->Npad * g->Npad * sizeof(int)));
   MMG_HIP(ctx, sc.alloc(&C64, (size_t)g->N * g->N * sizeof(int64_t)));
   MMG_HIP(ctx, hipMemsetAsync(C32, 0, (size_t)g->Npad * g->Npad * sizeof(int), ctx->stream));
   int rc = MMG_OK;
   double kin_ms = 0.0, pack_ms = 0.0;
-  for (int64_t mb = 0; mb < g->M && rc == MMG_OK; mb += CH) {
+  if (direct) {
+    ctx->ev_set[EV_PACK] = false;                       // no pack pass in this call
+    rc = run_kinship_i8_tr(ctx, g->d, g->d, g->Npad, g->Npad, g->Mpad / BK, C32);   // rows M..Mpad are zero
+  }
+  for (int64_t mb = 0; !direct && mb < g->M && rc == MMG_OK; mb += CH) {
     const int64_t Mk = round_up(std::min(CH, g->M - mb), BK);
     {
       EvScope ev(ctx, EV_PACK);
@@ -606,11 +616,13 @@ int mmg_kinship_affine_f32(mmg_ctx* ctx, mmg_geno* g, const float* scale, const 
 struct GrmWorkspace {
   int8_t *Xq = nullptr, *Xp = nullptr, *ddig = nullptr;
   int* C32 = nullptr;
-  double *dm = nullptr, *ds = nullptr, *dcoef = nullptr, *dc1 = nullptr, *dc1acc = nullptr;
+  double *dm = nullptr, *ds = nullptr, *dcoef = nullptr, *dc1 = nullptr, *dc1acc = nullptr, *dpart = nullptr;
   size_t cap_img = 0, cap_c32 = 0, cap_m = 0, cap_mk = 0, cap_n = 0;
   int capD = 0;
+  bool direct = false;            // SNP-major images for the transposed-read GEMM (no plain image Xq)
   void release() {
     hipFree(Xq); hipFree(Xp); hipFree(ddig); hipFree(C32); hipFree(dm); hipFree(ds); hipFree(dcoef); hipFree(dc1); hipFree(dc1acc);
+    hipFree(dpart);
     *this = GrmWorkspace();
   }
 };
@@ -664,15 +676,22 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
   if (bd == 7 && g->M >= 65536) D = 4;
   if (const char* e = std::getenv("MMG_GRM_PLANES")) { const int v = std::atoi(e); if (v >= 4 && v <= 6) D = v; }
   const double base = (double)(1 << bd);
+  // Round 3: the digit images are SNP-major like the store (row m scaled by the digit of SNP m) and the GEMM reads both
+  // through transposed LDS reads (kinship_i8_tr_kernel) -- no transposition pass, no plain image.  MMG_KIN_KERNEL=w4 /
+  // w8: the individual-major generations.
+  static const bool tr_off = [] { const char* e = std::getenv("MMG_KIN_KERNEL"); return e && (std::string(e) == "w4" || std::string(e) == "w8"); }();
+  const bool direct = !tr_off;
   const int64_t M = g->M, CH = kin_chunk();
   const int64_t Mk_max = std::min(round_up(M, BK), CH);
   // per-SNP mean / std in fp64 on the device, weights and digits on the host (M values)
   {
     const size_t need_img = (size_t)g->Npad * Mk_max, need_c32 = (size_t)g->Npad * g->Npad;
     if (ws.cap_img < need_img || ws.cap_c32 < need_c32 || ws.capD < D || ws.cap_m < (size_t)M || ws.cap_mk < (size_t)Mk_max ||
-        ws.cap_n < (size_t)g->Npad) {
+        ws.cap_n < (size_t)g->Npad || ws.direct != direct) {
       ws.release();
-      hipError_t e = hipMalloc(&ws.Xq, need_img);
+      ws.direct = direct;
+      hipError_t e = direct ? hipMalloc(&ws.dpart, (size_t)grm_partial_doubles(Mk_max, g->Npad) * sizeof(double))
+                            : hipMalloc(&ws.Xq, need_img);
       if (e == hipSuccess) e = hipMalloc(&ws.Xp, (size_t)D * need_img);
       if (e == hipSuccess) e = hipMalloc(&ws.C32, (size_t)D * need_c32 * sizeof(int));
       if (e == hipSuccess) e = hipMalloc(&ws.ddig, (size_t)D * Mk_max);
@@ -728,22 +747,31 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
     MMG_HIP(ctx, hipMemcpyAsync(ddig, dig.data(), (size_t)D * Mk, hipMemcpyHostToDevice, ctx->stream));
     MMG_HIP(ctx, hipMemcpyAsync(dcoef, cf.data(), Mk * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     const double tp0 = verbose ? now() : 0.0;
+    const int8_t* Srow = g->d + mb * (int64_t)g->Npad;     // the chunk's rows in the store (rows M..Mpad are zero)
     {
       EvScope ev(ctx, EV_PACK);
-      launch_transpose_digits(ctx, g, Xq, Xp, Mk, mb, ddig, D);
+      if (direct)   // digit images + c1[i] = sum_m (a b)_m s_mi of the chunk in one pass over the store
+        launch_grm_scale_rows(ctx, Srow, std::min<int64_t>(Mk, g->Mpad - mb), Mk, g->Npad, g->sneg > 0, Xp, ddig, D, dcoef,
+                              ws.dpart, dc1);
+      else
+        launch_transpose_digits(ctx, g, Xq, Xp, Mk, mb, ddig, D);
     }
     MMG_HIP(ctx, hipGetLastError());
     const double tp1 = verbose ? now() : 0.0;
     tv_pack += tp1 - tp0;
     for (int d = 0; d < D && rc == MMG_OK; ++d) {
-      rc = run_kinship_i8_pq(ctx, Xp + (size_t)d * g->Npad * Mk, Xq, g->Npad, Mk, C32 + (size_t)d * g->Npad * g->Npad);
+      if (direct)
+        rc = run_kinship_i8_tr(ctx, Xp + (size_t)d * g->Npad * Mk, Srow, g->Npad, g->Npad, Mk / BK,
+                               C32 + (size_t)d * g->Npad * g->Npad);
+      else
+        rc = run_kinship_i8_pq(ctx, Xp + (size_t)d * g->Npad * Mk, Xq, g->Npad, Mk, C32 + (size_t)d * g->Npad * g->Npad);
       double a = 0.0;
       if (rc == MMG_OK && mmg_last_kernel_ms(ctx, EV_KIN, &a) == MMG_OK) kin_ms += a;
     }
     if (rc) break;
     if (verbose) tv_gemm += now() - tp1;
-    // c1[i] += sum_m (a b)_m s_mi: one dot product per row of the plain image
-    launch_snp_dot_raw(ctx, Xq, Mk, g->Npad, (int32_t)Mk, dcoef, dc1);
+    // c1[i] += sum_m (a b)_m s_mi: one dot product per row of the plain image (the direct path has it already)
+    if (!direct) launch_snp_dot_raw(ctx, Xq, Mk, g->Npad, (int32_t)Mk, dcoef, dc1);
     MMG_HIP(ctx, hipMemcpyAsync(c1part.data(), dc1, g->Npad * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < g->Npad; ++i) c1[i] += c1part[i];

@@ -49,12 +49,31 @@ __device__ __forceinline__ void stage_piece_tr(const StageOpTr& s, char* lds_til
                                            (i & 1) ? s.v_odd : s.v_even, (wave * 8 + i) * s.ld4, 0, 0);
 }
 
-// fragment of operand-row block (32 rows, lane-constant byte offset `base`) for K slice `slice` (32 k rows)
-__device__ __forceinline__ v4i lds_frag_tr(const char* tile, int base, int slice) {
-  const char* p = tile + base + slice * (32 * 256);
-  const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((MMG_AS3 v2i*)p);
-  const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((MMG_AS3 v2i*)(p + 8 * 256));
-  return v4i{lo.x, lo.y, hi.x, hi.y};
+// Fragment of a 32-row operand block for K slice `slice` (32 k rows): two transposed reads.  INLINE ASM on purpose:
+// the compiler models the ds_read_tr builtins as memory WRITES, and its waitcnt pass then puts an `s_waitcnt vmcnt(0)`
+// in front of every one of them that follows an LDS-DMA load (32 stalls on the stage in flight per K step; plain
+// ds_read_b128 get no such wait).  The price: the compiler does not know that the outputs arrive asynchronously, so
+// every consumer is preceded by an explicit counted `s_waitcnt lgkmcnt(n)` tied to the fragment registers
+// (frag_wait) -- the counts are derived in w4tr_slice.  addr: LDS byte address of the block for slice 0.
+__device__ __forceinline__ void lds_frag_tr(v4i& f, uint32_t addr, int slice) {
+  v2i lo, hi;
+  switch (slice) {                                       // the offset is an instruction immediate
+    case 0: asm volatile("ds_read_b64_tr_b8 %0, %2\n\tds_read_b64_tr_b8 %1, %2 offset:2048" : "=&v"(lo), "=&v"(hi) : "v"(addr)); break;
+    case 1: asm volatile("ds_read_b64_tr_b8 %0, %2 offset:8192\n\tds_read_b64_tr_b8 %1, %2 offset:10240" : "=&v"(lo), "=&v"(hi) : "v"(addr)); break;
+    case 2: asm volatile("ds_read_b64_tr_b8 %0, %2 offset:16384\n\tds_read_b64_tr_b8 %1, %2 offset:18432" : "=&v"(lo), "=&v"(hi) : "v"(addr)); break;
+    default: asm volatile("ds_read_b64_tr_b8 %0, %2 offset:24576\n\tds_read_b64_tr_b8 %1, %2 offset:26624" : "=&v"(lo), "=&v"(hi) : "v"(addr)); break;
+  }
+  f = v4i{lo.x, lo.y, hi.x, hi.y};
+}
+
+// at most N LDS reads may still be outstanding when the instructions that consume f issue
+template <int N>
+__device__ __forceinline__ void frag_wait(v4i& f) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void frag_wait2(v4i& f, v4i& g) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f), "+v"(g) : "n"(N));
 }
 
 // lane-constant part of a fragment address: operand rows tile_row0 + (lane & 31) .. , k half (lane >> 5)
@@ -64,44 +83,53 @@ __device__ __forceinline__ int frag_base_tr(int tile_row0, int lane) {
   return (h * 16 + (i16 >> 1)) * 256 + ((chunk ^ (i16 & 14)) << 4) + (i16 & 1) * 8;
 }
 
-template <int NDMA>
-__device__ __forceinline__ void sched_slice_tr() {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    if (i < NDMA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-  }
-}
-
 struct W4JobTr {
   const int8_t* P;     // column 0 of the job's 256-column P window at k row 0 of the job
   const int8_t* Q;     // likewise for the Q window
   int nks;             // K steps of 128 rows (>= 1)
 };
 
+// One slice: 16 MFMA on `cur`; the 8 fragments of (slot `src`, slice) into `nxt` (one per MFMA pair, order a0 b0 a1 b1
+// a2 b2 a3 b3, two reads each); DMA pieces [P0, P1) of the cursor's stage into slot `dst`.
+// Counted waits.  LDS reads return in order.  When a slice starts, the 16 reads of `cur` (issued during the previous
+// slice, or all complete after a barrier's lgkmcnt(0)) are the only LDS operations in flight; fragment position p
+// (a_m: 2m, b_n: 2n + 1) is complete once at most 16 - 2(p + 1) + r reads are outstanding, r = reads this slice has
+// issued so far (2 per finished MFMA pair, the pair's own two after its first MFMA).  The MFMAs run in ORD order, whose
+// first use of positions 0..7 is at MFMA index 0, 0, 1, 2, 4, 6, 9, 12 with r = 0, 0, 2, 2, 4, 6, 10, 12:
+// lgkmcnt(12), (12), (10), (10), (10), (12), (12).  No other lgkm operation may be issued inside the stream (scalar
+// loads return out of order): job descriptors are held in registers.
 template <int P0, int P1, bool ZERO>
-__device__ __forceinline__ void w4tr_slice(v16i (&acc)[4][4], const Frag4& cur, Frag4& nxt, const char* src,
+__device__ __forceinline__ void w4tr_slice(v16i (&acc)[4][4], Frag4& cur, Frag4& nxt, const char* src,
                                            const int (&ab)[4], const int (&bb)[4], int slice, const StageOpTr& sp,
                                            const StageOpTr& sq, char* dst, int wave) {
   static_assert(P1 - P0 <= 8, "at most one DMA piece per MFMA pair");
+  const uint32_t s32 = (uint32_t)(uintptr_t)src;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m0 = ORD_M[2 * i], n0 = ORD_N[2 * i], m1 = ORD_M[2 * i + 1], n1 = ORD_N[2 * i + 1];
+    if (i == 0) frag_wait2<12>(cur.a[0], cur.b[0]);      // MFMA 0: a0 b0
+    if (i == 1) frag_wait<10>(cur.b[1]);                 // MFMA 2: a0 b1
+    if (i == 2) frag_wait<10>(cur.a[2]);                 // MFMA 4: a2 b0
+    if (i == 3) frag_wait<10>(cur.b[2]);                 // MFMA 6: a0 b2
+    if (i == 6) frag_wait<12>(cur.b[3]);                 // MFMA 12: a0 b3
     if (ZERO) acc[m0][n0] = mfma8(cur.a[m0], cur.b[n0], v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0});
     else acc[m0][n0] = mfma8(cur.a[m0], cur.b[n0], acc[m0][n0]);
-    if ((i & 1) == 0) nxt.a[i >> 1] = lds_frag_tr(src, ab[i >> 1], slice);
-    else nxt.b[i >> 1] = lds_frag_tr(src + TILE_BYTES, bb[i >> 1], slice);
+    // the asm statements keep their order among themselves, but the MFMAs (no side effects) are free to sink below
+    // them -- the scheduler bunched all 16 at the end of the slice: pin the source order MFMA / reads / MFMA / DMA
+    __builtin_amdgcn_sched_barrier(0);
+    if ((i & 1) == 0) lds_frag_tr(nxt.a[i >> 1], s32 + (uint32_t)ab[i >> 1], slice);
+    else lds_frag_tr(nxt.b[i >> 1], s32 + (uint32_t)bb[i >> 1], slice);
+    if (i == 0) frag_wait<12>(cur.a[1]);                 // MFMA 1: a1 b0
+    if (i == 4) frag_wait<12>(cur.a[3]);                 // MFMA 9: a3 b0
     if (ZERO) acc[m1][n1] = mfma8(cur.a[m1], cur.b[n1], v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0});
     else acc[m1][n1] = mfma8(cur.a[m1], cur.b[n1], acc[m1][n1]);
+    __builtin_amdgcn_sched_barrier(0);
     if (P0 + i < P1) {
       const int pc = P0 + i;
       if (pc < 8) stage_piece_tr(sp, dst, wave, pc);
       else stage_piece_tr(sq, dst + TILE_BYTES, wave, pc - 8);
     }
   }
-  sched_slice_tr<(P1 > P0 ? P1 - P0 : 0)>();
 }
 
 // Runs jobs j0 .. j1-1 of this workgroup; job(j) -> W4JobTr (wave-uniform); ld: row stride of the image (bytes);
@@ -118,7 +146,7 @@ __device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* ld
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     ab[i] = frag_base_tr(wm * 128 + i * 32, lane);
-    bb[i] = frag_base_tr(wn * 128 + i * 32, lane);
+    bb[i] = frag_base_tr(wn * 128 + i * 32, lane) + TILE_BYTES;
   }
   const int64_t kstep_bytes = (int64_t)BK * ld;
 
@@ -157,10 +185,13 @@ __device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* ld
   asm volatile("" ::: "memory");
 
   Frag4 f0, f1;
+  {
+    const uint32_t l32 = (uint32_t)(uintptr_t)lds;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    f0.a[i] = lds_frag_tr(lds, ab[i], 0);
-    f0.b[i] = lds_frag_tr(lds + TILE_BYTES, bb[i], 0);
+    for (int i = 0; i < 4; ++i) {                        // the order the counted waits of the first slice assume
+      lds_frag_tr(f0.a[i], l32 + (uint32_t)ab[i], 0);
+      lds_frag_tr(f0.b[i], l32 + (uint32_t)bb[i], 0);
+    }
   }
 
   v16i acc[4][4];                                        // written (not accumulated) by the first slice of every job

@@ -14,6 +14,7 @@
 #include <string>
 #include "gemm_i8_core.h"
 #include "gemm_i8_w4s.h"
+#include "gemm_i8_w4tr.h"
 #include "mmg_internal.h"
 
 namespace mmg {
@@ -70,6 +71,38 @@ __global__ __launch_bounds__(W4_THREADS) void kinship_i8_w4_kernel(const int8_t*
   const int nks = job.ks1 - job.ks0;
   w4s_stream(
       0, 1, Mk, Mk, lds, [&](int) { return W4Job{P, Q, nks}; }, [](int) {},
+      [&](int, v16i (&acc)[4][4]) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            const int col = job.J * TN + wn * 128 + n * 32 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int row = job.I * TM + wm * 128 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+              atomicAdd(C32 + (int64_t)row * Npad + col, acc[m][n][i]);
+            }
+          }
+      });
+}
+
+// The same job straight off SNP-major images (the genotype store itself): both tiles are 256-column windows of rows
+// [ks0*128, ks1*128), read through the transposed LDS reads of gemm_i8_w4tr.h -- no individual-major copy.
+// Sp != Sq: digit-weighted rows x plain rows (exact GRM planes).
+__global__ __launch_bounds__(W4_THREADS) void kinship_i8_tr_kernel(const int8_t* __restrict__ Sp,
+                                                                   const int8_t* __restrict__ Sq, int64_t ld,
+                                                                   int32_t Npad, const KinJob* __restrict__ jobs,
+                                                                   int* __restrict__ C32) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const KinJob job = jobs[xcd_job_index(blockIdx.x)];
+  if (job.ks1 <= job.ks0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;
+  const int8_t* P = Sp + (int64_t)job.ks0 * BK * ld + (int64_t)job.I * TM;
+  const int8_t* Q = Sq + (int64_t)job.ks0 * BK * ld + (int64_t)job.J * TN;
+  const int nks = job.ks1 - job.ks0;
+  w4tr_stream(
+      0, 1, ld, lds, [&](int) { return W4JobTr{P, Q, nks}; }, [](int) {},
       [&](int, v16i (&acc)[4][4]) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -289,6 +322,26 @@ void launch_grm_combine(mmg_ctx* ctx, const int* C32, int D, int32_t Npad, int32
   const int64_t total = (int64_t)N * N;
   hipLaunchKernelGGL(grm_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, C32, D, Npad,
                      N, step, base, c1, c0, C, accumulate);
+}
+
+// C32 (upper tiles) += Sp' Sq over rows [0, nk * 128) of two SNP-major images with row stride ld (Sp == Sq: the store)
+int run_kinship_i8_tr(mmg_ctx* ctx, const int8_t* Sp, const int8_t* Sq, int64_t ld, int32_t Npad, int64_t nk, int* C32) {
+  const int nT = Npad / TM;
+  const int ksplit = kinship_pick_ksplit(Npad, nk * BK, false);
+  std::vector<KinJob> jobs = build_jobs(nT, (int)nk, ksplit);
+  KinJob* djobs = nullptr;
+  MMG_HIP(ctx, hipMalloc(&djobs, jobs.size() * sizeof(KinJob)));
+  MMG_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(KinJob), hipMemcpyHostToDevice, ctx->stream));
+  MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_i8_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  {
+    EvScope ev(ctx, EV_KIN);
+    hipLaunchKernelGGL(kinship_i8_tr_kernel, dim3((unsigned)jobs.size()), dim3(W4_THREADS), LDS_BYTES, ctx->stream, Sp, Sq,
+                       ld, Npad, djobs, C32);
+  }
+  MMG_HIP(ctx, hipGetLastError());
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MMG_HIP(ctx, hipFree(djobs));
+  return MMG_OK;
 }
 
 int run_kinship_i8(mmg_ctx* ctx, const int8_t* Xt, int32_t Npad, int64_t Mk, int* C32) {

@@ -148,7 +148,10 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint8_t* __restrict__
   *(uint4*)(dst + r * (int64_t)Npad + c * 16) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// [rows x N] contiguous int8 -> rows of the padded store (columns >= N zero): the device half of a staged upload
+// [rows x N] contiguous int8 -> rows of the padded store (columns >= N zero): the device half of a staged upload.
+// A row starts at byte r * N of the source -- any alignment -- so a thread fetches the 5 aligned dwords that cover its
+// 16 bytes and realigns them with v_alignbyte (16 single-byte loads per thread ran at a third of the copy rate of the
+// link: 19 GB/s end to end).  The staging buffer carries 32 bytes of slack behind the last row.
 __global__ __launch_bounds__(256) void pitch_rows_kernel(const int8_t* __restrict__ src, int8_t* __restrict__ dst,
                                                          int64_t rows, int32_t N, int32_t Npad) {
   const int nchunk = Npad >> 4;
@@ -156,12 +159,26 @@ __global__ __launch_bounds__(256) void pitch_rows_kernel(const int8_t* __restric
   if (gid >= rows * nchunk) return;
   const int64_t r = gid / nchunk;
   const int c = (int)(gid % nchunk);
-  const int8_t* row = src + r * (int64_t)N + c * 16;
-  uint32_t w[4] = {0, 0, 0, 0};
+  const int nvalid = min(16, max(0, N - c * 16));
+  uint32_t o[4] = {0, 0, 0, 0};
+  if (nvalid > 0) {
+    const int64_t a = r * (int64_t)N + c * 16;          // first source byte
+    const uint32_t* s32 = (const uint32_t*)(src + (a & ~(int64_t)3));
+    const uint32_t sh = (uint32_t)(a & 3);
+    uint32_t w[5];
 #pragma unroll
-  for (int j = 0; j < 16; ++j)
-    if (c * 16 + j < N) w[j >> 2] |= (uint32_t)(uint8_t)row[j] << (8 * (j & 3));
-  *(uint4*)(dst + r * (int64_t)Npad + c * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    for (int k = 0; k < 5; ++k) w[k] = s32[k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_alignbyte(w[j + 1], w[j], sh);
+    if (nvalid < 16) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int keep = min(4, max(0, nvalid - 4 * j));   // bytes of dword j inside the row
+        o[j] = keep == 4 ? o[j] : (keep == 0 ? 0u : (o[j] & ((1u << (8 * keep)) - 1u)));
+      }
+    }
+  }
+  *(uint4*)(dst + r * (int64_t)Npad + c * 16) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
 void launch_pitch_rows(mmg_ctx* ctx, const int8_t* src, int8_t* dst, int64_t rows, int32_t N, int32_t Npad) {
@@ -258,6 +275,90 @@ __global__ __launch_bounds__(256) void transpose_digits_kernel(const int8_t* __r
 #pragma unroll
   for (int d = 0; d < D; ++d)
     *(uint4*)(Xp + (int64_t)d * Npad * Mk + off) = make_uint4(wp[d][0], wp[d][1], wp[d][2], wp[d][3]);
+}
+
+// SNP-major twin for the transposed-read kinship GEMM (gemm_i8_w4tr.h): nothing is transposed -- image d holds row m
+// of the store times digit d of that SNP's weight, Xp[d][m - m_begin][i] = dig[d][m - m_begin] * s_mi, and the plain
+// operand is the store itself.  One thread owns one 16-byte column chunk over a slab of GRM_SLAB rows, which also gives
+// it the weighted column sums c1[i] = sum_m coef[m] s_mi (the a b (s 1' + 1 s') term of z z') of its slab in 16 fp64
+// registers: partial[slab][Npad], reduced over the slabs in fixed order by grm_colsum_reduce_kernel (deterministic).
+// HBM-bound: Npad in + D * Npad out per SNP, fully coalesced (round 2: 16.3 ms of a 64 ms GRM for the transposing
+// version with its byte-wise LDS reads).
+constexpr int GRM_SLAB = 512;
+
+template <int D, bool NEG>
+__global__ __launch_bounds__(256) void grm_scale_rows_kernel(const int8_t* __restrict__ S, int64_t rows_valid, int64_t Mk,
+                                                             int32_t Npad, int8_t* __restrict__ Xp,
+                                                             const int8_t* __restrict__ dig /*[D][Mk]*/,
+                                                             const double* __restrict__ coef /*[Mk]*/,
+                                                             double* __restrict__ partial /*[slabs][Npad]*/) {
+  const int nchunk = Npad >> 4;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t nslab = (Mk + GRM_SLAB - 1) / GRM_SLAB;
+  if (gid >= nslab * nchunk) return;
+  const int64_t slab = gid / nchunk;
+  const int c = (int)(gid % nchunk);
+  const int64_t r0 = slab * GRM_SLAB, r1 = min(Mk, r0 + GRM_SLAB);
+  double acc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.0;
+  for (int64_t r = r0; r < r1; ++r) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < rows_valid) v = *(const uint4*)(S + r * (int64_t)Npad + c * 16);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const double cf = coef[r];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = fma(cf, (double)(int)(int8_t)((w[e >> 2] >> (8 * (e & 3))) & 0xff), acc[e]);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int dg = (int)dig[(int64_t)d * Mk + r];       // 0 .. 127, digit * |s| <= 127
+      uint32_t o[4];
+      if (!NEG) {
+        // non-negative genotype bytes: every byte product stays below 128, so one dword multiply does four of them
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = w[q] * (uint32_t)dg;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint32_t x = 0;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) x |= ((uint32_t)(((int)(int8_t)((w[q] >> (8 * b)) & 0xff) * dg) & 0xff)) << (8 * b);
+          o[q] = x;
+        }
+      }
+      *(uint4*)(Xp + ((int64_t)d * Mk + r) * Npad + c * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  double* out = partial + slab * Npad + c * 16;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) out[e] = acc[e];
+}
+
+__global__ void grm_colsum_reduce_kernel(const double* __restrict__ partial, int64_t nslab, int32_t Npad,
+                                         double* __restrict__ c1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Npad) return;
+  double s = 0.0;
+  for (int64_t k = 0; k < nslab; ++k) s += partial[k * Npad + i];
+  c1[i] = s;
+}
+
+int64_t grm_partial_doubles(int64_t Mk, int32_t Npad) { return (Mk + GRM_SLAB - 1) / GRM_SLAB * (int64_t)Npad; }
+
+// S: first row of the chunk in the store (row stride Npad); rows_valid: rows of the chunk that exist in the store
+void launch_grm_scale_rows(mmg_ctx* ctx, const int8_t* S, int64_t rows_valid, int64_t Mk, int32_t Npad, bool neg,
+                           int8_t* Xp, const int8_t* dig, int D, const double* coef, double* partial, double* c1) {
+  const int64_t nslab = (Mk + GRM_SLAB - 1) / GRM_SLAB;
+  const int64_t total = nslab * (Npad >> 4);
+  const dim3 grid((unsigned)((total + 255) / 256));
+#define MMG_GS(D_, NEG_)                                                                                              \
+  hipLaunchKernelGGL((grm_scale_rows_kernel<D_, NEG_>), grid, dim3(256), 0, ctx->stream, S, rows_valid, Mk, Npad, Xp, dig, \
+                     coef, partial)
+  if (neg) { if (D == 4) MMG_GS(4, true); else if (D == 5) MMG_GS(5, true); else MMG_GS(6, true); }
+  else { if (D == 4) MMG_GS(4, false); else if (D == 5) MMG_GS(5, false); else MMG_GS(6, false); }
+#undef MMG_GS
+  hipLaunchKernelGGL(grm_colsum_reduce_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, ctx->stream, partial,
+                     nslab, Npad, c1);
 }
 
 void launch_transpose_digits(mmg_ctx* ctx, const mmg_geno* g, int8_t* Xq, int8_t* Xp, int64_t Mk, int64_t m_begin,

@@ -153,10 +153,15 @@ void launch_absmax_i8(mmg_ctx*, const int8_t* p, int64_t bytes, int* d_out);   /
 // ---- k_kinship.hip
 int kinship_pick_ksplit(int32_t Npad, int64_t Mk, bool f32);
 // C32 [Npad x Npad] int32 += Xt Xt^T (upper-triangular tiles only, mirrored by the caller).
+int run_kinship_i8_tr(mmg_ctx*, const int8_t* Sp, const int8_t* Sq, int64_t ld, int32_t Npad, int64_t nk, int* C32);
 int run_kinship_i8(mmg_ctx*, const int8_t* Xt, int32_t Npad, int64_t Mk, int* C32);
 int run_kinship_i8_pq(mmg_ctx*, const int8_t* Xp, const int8_t* Xq, int32_t Npad, int64_t Mk, int* C32);
 void launch_grm_combine(mmg_ctx*, const int* C32, int D, int32_t Npad, int32_t N, double step, double base,
                         const double* c1, double c0, double* C, int accumulate);
+// SNP-major digit images for the transposed-read kinship GEMM + the weighted column sums of the chunk (k_pack.hip)
+int64_t grm_partial_doubles(int64_t Mk, int32_t Npad);
+void launch_grm_scale_rows(mmg_ctx*, const int8_t* S, int64_t rows_valid, int64_t Mk, int32_t Npad, bool neg, int8_t* Xp,
+                           const int8_t* dig, int D, const double* coef, double* partial, double* c1);
 void launch_transpose_digits(mmg_ctx*, const mmg_geno*, int8_t* Xq, int8_t* Xp, int64_t Mk, int64_t m_begin,
                              const int8_t* dig, int D);
 void launch_snp_dot_raw(mmg_ctx*, const int8_t* S, int64_t ldS, int64_t rows, int32_t len16, const double* v, double* out);

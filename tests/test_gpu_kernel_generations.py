@@ -54,4 +54,7 @@ def test_four_wave_kernels_give_the_bits_of_the_eight_wave_generation(tmp_path):
     old = _digest(tmp_path, {"MMG_PERM_KERNEL": "w8", "MMG_ROT_KERNEL": "w8", "MMG_KIN_KERNEL": "w8"})
     slow = _digest(tmp_path, {"MMG_W4_SLOW_EPI": "1"})
     gv1 = _digest(tmp_path, {"MMG_PERM_GV": "1", "MMG_ROT_GV": "8"})
-    assert new == old == slow == gv1
+    # round 3: the default IBS kinship reads the SNP-major store through transposed LDS reads (gemm_i8_w4tr.h);
+    # w4 / w8 are the two generations on the individual-major image
+    kin_w4 = _digest(tmp_path, {"MMG_KIN_KERNEL": "w4"})
+    assert new == old == slow == gv1 == kin_w4

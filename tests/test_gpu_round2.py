@@ -235,7 +235,7 @@ def test_non_integral_or_out_of_range_genotypes_are_rejected(ctx):
                 ctx.geno(s2.astype(dt))
     with pytest.raises(ValueError):
         ctx.geno(np.full((3, 70), 200, dtype=np.int16))               # would wrap to -56 in int8
-    with pytest.raises(ValueError):                                   # round 3: caught on the host before the copy
+    with pytest.raises(_lib.MixmogamHipError):                        # found on the device; the rows are rolled back
         ctx.geno(np.full((3, 70), -128, dtype=np.int8))
     assert np.array_equal(ctx.geno(np.full((3, 70), 2, dtype=np.int64)).download(), np.full((3, 70), 2, dtype=np.int8))
 

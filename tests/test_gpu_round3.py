@@ -82,8 +82,9 @@ def test_upload_of_minus_128_rolls_back(ctx):
     g.upload(good[:20], 0)
     bad = good[20:].copy()
     bad[5, 7] = -128
-    with pytest.raises(ValueError):
-        g.upload(bad, 20)                                                 # the host-side check of as_store_array
+    with pytest.raises(_lib.MixmogamHipError, match="-128"):
+        g.upload(bad, 20)
+    assert np.array_equal(g.download()[:20], good[:20]) and not g.download()[20:].any()
     rc = ctx.lib.mmg_geno_upload(ctx.h, g.h, bad.ctypes.data_as(C.c_void_p), 20, len(bad))   # raw C ABI
     assert rc == -1 and b"-128" in ctx.lib.mmg_last_error(ctx.h)
     got = g.download()
