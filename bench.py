@@ -593,7 +593,7 @@ def ingest_record(ctx, g, prep, n_p, N, M, ms_per_step):
 FP64_PEAK_TFLOPS = 78.6      # MI355X_MICROARCH.md: fp64 vector = fp64 matrix (the two share the DP units)
 
 
-def multi_roofline(N, M, q, batch, pass_ms):
+def multi_roofline(N, M, q, batch, pass_ms, traffic=None):
     """Roofline of one pass of scan_multi over the rotated store: HBM (T is read once per pass, 8 N M bytes) against
     fp64 (2 + q fused multiply-adds per element and phenotype of the batch); the binding one is reported as `bound`."""
     hbm = 8.0 * N * M / (pass_ms * 1e-3) / 1e9
@@ -606,7 +606,7 @@ def multi_roofline(N, M, q, batch, pass_ms):
               "fp64": {"achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f_fp,
                        "note": "sustained fp64 on this part, measured with tools/probe/fp64_rate.hip: 61-69 TFLOP/s on "
                                "the VALU, 36-48 on v_mfma_f64_16x16x4_f64, no more with both (shared units)"},
-              "traffic": None}
+              "traffic": traffic, "traffic_from_profiles": True}
     if f_fp >= f_hbm:
         common.update({"bound": "fp64", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f_fp})
     else:
@@ -645,7 +645,9 @@ def multi_record(ctx, g, lmm, N, M, P=16):
             "rotation_executed_int8_tops": 2.0 * 4 * (-(-N // 256) * 256) * (-(-N // 64) * 64) * M / (rot_ms * 1e-3) / 1e12,
             "pass_ms": ms / npass, "passes": npass, "ms_per_phenotype_scan": ms / P,
             "value_snp_phenotype_scans_per_s": M * P / (wall), "value_kernels_only": M * P / (ms * 1e-3),
-            "roofline": multi_roofline(N, M, 1, min(P, scan_multi_batch()), ms / npass),
+            "roofline": multi_roofline(N, M, 1, min(P, scan_multi_batch()), ms / npass,
+                                       _profiled_traffic(N, M, 0, True).get("scan_multi_mfma_kernel")),
+            "rotation_traffic_from_profiles": _profiled_traffic(N, M, 0, True).get("rot_gemm_w4_kernel"),
             "host_model_ms_per_phenotype": 1e3 * t_models / P}
 
 
