@@ -102,7 +102,8 @@ template <int P0, int P1, bool ZERO>
 __device__ __forceinline__ void w4tr_slice(v16i (&acc)[4][4], Frag4& cur, Frag4& nxt, const char* src,
                                            const int (&ab)[4], const int (&bb)[4], int slice, const StageOpTr& sp,
                                            const StageOpTr& sq, char* dst, int wave) {
-  static_assert(P1 - P0 <= 8, "at most one DMA piece per MFMA pair");
+  static_assert(P1 - P0 <= 16, "at most two DMA pieces per MFMA pair");
+  constexpr int PER = (P1 - P0 > 8) ? 2 : 1;             // DMA pieces per MFMA pair
   const uint32_t s32 = (uint32_t)(uintptr_t)src;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -124,10 +125,13 @@ __device__ __forceinline__ void w4tr_slice(v16i (&acc)[4][4], Frag4& cur, Frag4&
     if (ZERO) acc[m1][n1] = mfma8(cur.a[m1], cur.b[n1], v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0});
     else acc[m1][n1] = mfma8(cur.a[m1], cur.b[n1], acc[m1][n1]);
     __builtin_amdgcn_sched_barrier(0);
-    if (P0 + i < P1) {
-      const int pc = P0 + i;
-      if (pc < 8) stage_piece_tr(sp, dst, wave, pc);
-      else stage_piece_tr(sq, dst + TILE_BYTES, wave, pc - 8);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int pc = P0 + PER * i + u;
+      if (pc < P1) {
+        if (pc < 8) stage_piece_tr(sp, dst, wave, pc);
+        else stage_piece_tr(sq, dst + TILE_BYTES, wave, pc - 8);
+      }
     }
   }
 }
@@ -135,9 +139,12 @@ __device__ __forceinline__ void w4tr_slice(v16i (&acc)[4][4], Frag4& cur, Frag4&
 // Runs jobs j0 .. j1-1 of this workgroup; job(j) -> W4JobTr (wave-uniform); ld: row stride of the image (bytes);
 // pre / epi as in w4s_stream: acc[m][n] = the wave's 4 x 4 accumulator tiles, rows = P columns wm*128 + m*32..,
 // columns = Q columns wn*128 + n*32.. (C layout of gemm_i8_core.h).
-template <class JobFn, class PreFn, class EpiFn>
+// N3: DMA pieces of stage t+2 issued right after the barrier of step t (slice 3), the other 16 - N3 in slice 0 of step
+// t+1.  The operands of these kernels stream from HBM / the Infinity Cache (a 5 GB store, not an L2-resident digit
+// image): the later a piece is issued the likelier the next barrier waits for it.
+template <int N3 = 8, class JobFn, class PreFn, class EpiFn>
 __device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* lds, JobFn&& job, PreFn&& pre, EpiFn&& epi) {
-  constexpr int N3 = 8;
+  static_assert(N3 >= 8 && N3 <= 16, "N3");
   if (j1 <= j0) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -179,7 +186,10 @@ __device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* ld
   for (int i = 0; i < 8; ++i) stage_piece_tr(sq, lds + TILE_BYTES, wave, i);
   advance();                                             // -> stage 1
 #pragma unroll
-  for (int i = 0; i < N3; ++i) stage_piece_tr(sp, lds + BUF_BYTES, wave, i);
+  for (int i = 0; i < N3; ++i) {
+    if (i < 8) stage_piece_tr(sp, lds + BUF_BYTES, wave, i);
+    else stage_piece_tr(sq, lds + BUF_BYTES + TILE_BYTES, wave, i - 8);
+  }
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N3) : "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
