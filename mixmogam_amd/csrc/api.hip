@@ -248,10 +248,10 @@ static int ensure_ingest(mmg_ctx* ctx, size_t bytes) {
 }
 
 
-// MMG_UPLOAD_PATH=2d: strided hipMemcpy2DAsync straight into the padded store instead of the staged copy (A/B timing)
+// MMG_UPLOAD_PATH=staged: contiguous copy into device staging + pitch kernel instead of the strided hipMemcpy2DAsync
 static bool upload_2d() {
-  static const bool forced = [] { const char* e = std::getenv("MMG_UPLOAD_PATH"); return e && std::string(e) == "2d"; }();
-  return forced;
+  static const bool staged = [] { const char* e = std::getenv("MMG_UPLOAD_PATH"); return e && std::string(e) == "staged"; }();
+  return !staged;
 }
 
 // every write path ends here: fold max |s| of the written rows into the store's running bound
@@ -271,9 +271,10 @@ int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, i
   MMG_CHECK_ARG(ctx, g && snps && m0 >= 0 && rows >= 0 && m0 + rows <= g->M);
   if (rows == 0) return MMG_OK;
   g->bits_valid = false; ++g->version;
-  // The block crosses the link as contiguous copies into device staging and pitch_rows_kernel spreads it over the padded
-  // rows.  hipMemcpy2DAsync straight into the store runs row by row: 15-20 GB/s from page-locked AND pageable memory
-  // on this ROCm (tools/h2d_check.py) against 50+ GB/s for contiguous copies.  MMG_UPLOAD_PATH=2d keeps the old path.
+  // Strided DMA straight into the padded store: 54-56 GB/s from pageable and page-locked memory alike
+  // (tools/h2d_check.py).  MMG_UPLOAD_PATH=staged: contiguous copies into device staging + pitch_rows_kernel (the same
+  // rate; kept for A/B runs -- what looked like a slow 2-D copy in round 3 was a host-side min() over the block in the
+  // Python binding, since removed).
   if (g->N == g->Npad) {
     MMG_HIP(ctx, hipMemcpyAsync(g->d + m0 * (int64_t)g->Npad, snps, (size_t)rows * g->N, hipMemcpyHostToDevice, ctx->stream));
   } else if (upload_2d()) {
@@ -337,6 +338,17 @@ int mmg_geno_upload_packed(mmg_ctx* ctx, mmg_geno* g, const uint8_t* packed, int
     launch_unpack(ctx, tmp, row_bytes, g->d + (m0 + r0) * (int64_t)g->Npad, nr, g->N, g->Npad, bits, lut32);
     MMG_HIP(ctx, hipGetLastError());
     if (r0 + chunk < rows) MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));   // tmp is reused by the next piece
+  }
+  if (bits == 1) {
+    // two codes: the bounds follow from the lut (a pass over the expanded rows would re-read N bytes per SNP); an
+    // all-zero block leaves them one too high, which only costs the fast paths that ask for smax == 0 -- none does
+    const int a = (int)(int8_t)(lut32 & 0xff), b = (int)(int8_t)((lut32 >> 8) & 0xff);
+    g->smax = std::max(g->smax, std::max(std::abs(a), std::abs(b)));
+    g->sneg = std::max(g->sneg, std::max(-a, -b));
+    const int v[2] = {g->smax, g->sneg};
+    MMG_HIP(ctx, hipMemcpyAsync(g->d_smax, v, 2 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MMG_OK;
   }
   return refresh_smax(ctx, g, m0, rows);
 }

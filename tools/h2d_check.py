@@ -7,7 +7,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 if len(sys.argv) == 1:
-    for path in ("auto", "2d", "staged"):
+    for path in ("auto", "staged"):
         env = dict(os.environ)
         if path != "auto":
             env["MMG_UPLOAD_PATH"] = path
