@@ -505,6 +505,9 @@ def ingest_record(ctx, g, prep, n_p, N, M, ms_per_step):
     genotypes (5 GB at C3) and for the config's fp32 [M x N] genotypes (20 GB, converted to the int8 store on the
     device).  `value_h2d_inclusive*` is never `value`."""
     from mixmogam_amd import hdf5_data
+    # the headline model with its adaptive schedule (structured_record leaves ITS model, all planes, in the context --
+    # rounds 2-3 measured the pipelined figures below with that leftover: 41 instead of 33 ms per 10^6 packed SNPs)
+    ctx.scan_set_model(prep["A"], prep["w"], 0)
     rows = min(M, 250000)                       # a quarter of C3: 1.25 GB int8 / 5 GB fp32 of host memory
     host8 = g.download(0, rows)
     g2 = ctx.geno(M=rows, N=N)
@@ -557,18 +560,20 @@ def ingest_record(ctx, g, prep, n_p, N, M, ms_per_step):
     srcp = {"c": {"raw_snps_packed": packed_all, "packed_bits": np.array(1), "num_indivs": np.array(N),
                   "freqs": np.full(M, 0.5), "positions": np.arange(M)}}
     t_pk = {}
-    for csz in (50000, 200000):
-        planp = hdf5_data._chunk_plan(srcp, 0.1, csz)
-        for _ci, _c, gg in hdf5_data._resident_chunks(ctx, srcp, planp[:2], reuse=True):
-            ctx.scan(gg, prep["h0_rss"], n_p, fetch=True)
+    for csz, ramp in ((50000, False), (200000, False), (400000, True)):
+        planp = hdf5_data._chunk_plan(srcp, 0.1, csz, ramp=ramp)
+        pin = [ctx.pinned_empty(csz) for _ in range(3)]          # page-locked result buffers, reused by every chunk
+        big2 = sorted(planp, key=lambda c: -len(c[1]))[:2]       # allocate the two chunk stores at full size
+        for _ci, _c, gg in hdf5_data._resident_chunks(ctx, srcp, big2, reuse=True):
+            ctx.scan(gg, prep["h0_rss"], n_p, fetch=True, out=[b[:gg.M] for b in pin])
         ts = []
         for _ in range(reps):
             t0 = time.time()
             for _ci, _c, gg in hdf5_data._resident_chunks(ctx, srcp, planp, reuse=True):
-                ctx.scan(gg, prep["h0_rss"], n_p, fetch=True)
+                ctx.scan(gg, prep["h0_rss"], n_p, fetch=True, out=[b[:gg.M] for b in pin])
                 gg.close()
             ts.append(time.time() - t0)
-        t_pk[csz] = float(np.median(ts))
+        t_pk["%d%s" % (csz, "_ramp" if ramp else "")] = float(np.median(ts))
         hdf5_data.release_pools()
     del packed_all
     scan_s = ms_per_step * 1e-3 * rows / M
@@ -582,10 +587,13 @@ def ingest_record(ctx, g, prep, n_p, N, M, ms_per_step):
             "value_h2d_inclusive_int8_pipelined": M / t_pipe,
             "value_h2d_inclusive_packed1_pipelined": M / t_pk[best],
             "packed1_pipelined_by_chunk_size": {str(k): M / v for k, v in t_pk.items()},
+            "packed1_pipelined_note": "<chunk>_ramp: first chunks of chunk/8, /4, /2 (hdf5_data._chunk_plan(ramp=True)) so "
+                                      "that the first, unhidden upload is short",
             "pcie_roof_snps_per_s": {"int8": PCIE_GBPS * 1e9 / N, "f32": PCIE_GBPS * 1e9 / (4.0 * N),
                                      "packed1": PCIE_GBPS * 1e9 / (N / 8.0)},
             "note": "upload of the rows into the padded HBM store + the scan of those rows; serial = upload then "
-                    "scan (sample_rows); pipelined = all M rows in 50,000-SNP chunks with the next upload overlapping "
+                    "scan (sample_rows); pipelined = all M rows in chunks (50,000 SNPs for int8; see "
+                    "packed1_pipelined_by_chunk_size) with the next upload overlapping "
                     "the current scan and the p-values of every chunk fetched; packed1 = 1 bit per 0/1 genotype on the "
                     "host, expanded on the device (mmg_geno_upload_packed)"}
 

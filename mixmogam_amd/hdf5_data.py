@@ -65,9 +65,13 @@ def _num_indivs(cg):
     return int(np.asarray(cg['num_indivs'][...])) if bits else int(np.asarray(raw[0:1]).shape[1])
 
 
-def _chunk_plan(genot_data, min_maf, chunk_size):
-    """[(chrom, kept row indices of the chunk, positions of the chunk)] without touching raw_snps."""
+def _chunk_plan(genot_data, min_maf, chunk_size, ramp=False):
+    """[(chrom, kept row indices of the chunk, positions of the chunk)] without touching raw_snps.
+    ramp: the first chunks of the stream are chunk_size / 8, / 4, / 2 -- the first upload is not hidden behind any
+    compute, so a short first chunk starts the pipeline sooner while the later, full-size chunks keep the per-chunk costs
+    of a scan (tail of the GEMM, the adaptive schedule's bookkeeping) amortised."""
     plan = []
+    first = True
     for chrom in genot_data.keys():
         cg = genot_data[chrom]
         if min_maf is None:
@@ -75,8 +79,17 @@ def _chunk_plan(genot_data, min_maf, chunk_size):
         else:
             idx = np.nonzero(_maf_filter(cg, min_maf))[0]
         positions = np.asarray(cg['positions'][...])[idx] if 'positions' in cg else idx
-        for i in range(0, len(idx), chunk_size):
-            plan.append((chrom, idx[i:i + chunk_size], positions[i:i + chunk_size]))
+        i = 0
+        if ramp and first:
+            for div in (8, 4, 2):
+                step = max(256, chunk_size // div // 256 * 256)
+                if i + step >= len(idx):
+                    break
+                plan.append((chrom, idx[i:i + step], positions[i:i + step]))
+                i += step
+            first = False
+        for j in range(i, len(idx), chunk_size):
+            plan.append((chrom, idx[j:j + chunk_size], positions[j:j + chunk_size]))
     return plan
 
 

@@ -386,3 +386,22 @@ def test_packed_genotype_containers_drive_the_same_driver(ctx, tmp_path, bits, h
     for c in ra["chrom_results"]:
         assert np.array_equal(ra["chrom_results"][c]["ps"], rb["chrom_results"][c]["ps"])
     assert np.array_equal(ra["kinship"], rb["kinship"])
+
+
+def test_chunk_plan_ramp_covers_every_row_once():
+    """hdf5_data._chunk_plan(ramp=True): short first chunks (chunk/8, /4, /2) then full ones -- every kept row exactly
+    once, in order, per chromosome."""
+    rng = np.random.RandomState(0)
+    src = {"c%d" % c: {"raw_snps": np.zeros((m, 7), dtype=np.int8), "freqs": rng.uniform(0.05, 0.5, size=m),
+                       "positions": np.arange(m) * 3} for c, m in ((1, 5000), (2, 300), (3, 2600))}
+    for ramp in (False, True):
+        plan = hdf5_data._chunk_plan(src, 0.1, 2048, ramp=ramp)
+        for chrom in src:
+            keep = np.nonzero(np.minimum(src[chrom]["freqs"], 1 - src[chrom]["freqs"]) > 0.1)[0]
+            got = np.concatenate([sel for c, sel, _p in plan if c == chrom])
+            pos = np.concatenate([p for c, _s, p in plan if c == chrom])
+            assert np.array_equal(got, keep) and np.array_equal(pos, keep * 3)
+        sizes = [len(sel) for _c, sel, _p in plan]
+        assert max(sizes) <= 2048
+        if ramp:
+            assert sizes[:3] == [256, 512, 1024]
