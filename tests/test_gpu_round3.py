@@ -242,3 +242,32 @@ def test_run_emmax_over_a_packed_container_equals_the_int8_one(ctx, tmp_path):
     for c in ra["chrom_results"]:
         assert np.array_equal(ra["chrom_results"][c]["ps"], rb["chrom_results"][c]["ps"])
     hdf5_data.release_pools()
+
+
+def test_scan_model_falls_back_to_H_when_the_cholesky_route_fails(ctx, monkeypatch):
+    """mlmm() and the chunked drivers build a step's scan model on the device from K and delta (Cholesky of K + delta
+    I) but hold H_sqrt_inv as well: when the factorisation reports 'not positive definite' (an indefinite or
+    numerically borderline kinship), _emmax_f_test_ builds the model from H_sqrt_inv instead of raising (advisor r2).
+    The failure is injected; other device errors still propagate."""
+    from mixmogam_amd import _lib, linear_models as lm
+    case = load_case("struct_n150_s0")
+    lmm = lm.LinearMixedModel(list(case["y"]), ctx=ctx)
+    lmm.add_random_effect(case["dbl_ibs_scaled"])
+    est = lmm.get_estimates(lmm._get_eigen_L_(), method="REML")
+    want = lmm._emmax_f_test_(case["snps"], est["H_sqrt_inv"], emma_num=0)
+    via_device = lmm._emmax_f_test_(case["snps"], est["H_sqrt_inv"], emma_num=0, _delta=est["delta"])
+    assert rel(via_device["ps"], want["ps"]) < 1e-6
+
+    def broken(self, delta, ndigits=0):
+        raise _lib.MixmogamHipError("libmixmogam_hip error -4: K + delta I is not positive definite (dpotrf info 7)")
+    monkeypatch.setattr(_lib.Reml, "scan_model", broken)
+    got = lmm._emmax_f_test_(case["snps"], est["H_sqrt_inv"], emma_num=0, _delta=est["delta"])
+    assert np.array_equal(got["ps"], want["ps"])
+    with pytest.raises(_lib.MixmogamHipError):                      # nothing to fall back to
+        lmm._emmax_f_test_(case["snps"], None, emma_num=0, _delta=est["delta"])
+
+    def other(self, delta, ndigits=0):
+        raise _lib.MixmogamHipError("libmixmogam_hip error -2: hipMalloc failed")
+    monkeypatch.setattr(_lib.Reml, "scan_model", other)
+    with pytest.raises(_lib.MixmogamHipError, match="hipMalloc"):
+        lmm._emmax_f_test_(case["snps"], est["H_sqrt_inv"], emma_num=0, _delta=est["delta"])
