@@ -741,7 +741,29 @@ def bench_perm(args, ctx, coll, comm_h, g, lmm, est, N, M, Mtot, barrier, common
                             "(mmg_emmax_perm_after_scan): the per-chunk work of hdf5_data.run_emmax_perm",
                     "max_rel_min_rss_diff_vs_standalone": float(np.max(np.abs(min_rss_fast / min_rss - 1)))},
                 "threshold_05": {"min_p": float(np.sort(min_ps)[P // 20]), "max_f": float(np.sort(max_f)[::-1][P // 20])}})
+    if not args.no_cpu_baseline and common["n_gpus"] == 1:
+        res["cpu_baseline"] = cpu_baseline_perm(N, M, P, H, Ys, h0_rss, g, min_rss)
     return res
+
+
+def cpu_baseline_perm(N, M, P, H, Ys, h0_rss, g, gpu_min_rss):
+    """the C4 CPU baseline on a 1/100 SNP subsample, extrapolated linearly in M.  What is timed is the
+    arithmetic of linear_models.py:1157-1164 as the oracle restates it in closed form (perm_closed: row-centred SNPs,
+    t = H s, per-SNP rss over all P permutations as two float64 GEMMs) -- the reference's own loop runs one multi-RHS
+    lstsq per SNP on top of that, so this is a LOWER bound of its time."""
+    from oracle import emmax_oracle as orc
+    sample = max(N, M // 100)
+    snps = g.download(0, sample)
+    pp = {"H": H, "Ys": Ys, "h0_rss": h0_rss, "yy": np.einsum("ij,ij->j", Ys, Ys), "n": N, "q": 1}
+    t0 = time.time()
+    out = orc.perm_closed(snps, pp)
+    dt = time.time() - t0
+    # the minimum over a subsample is >= the minimum over all SNPs
+    ok = bool(np.all(out["min_rss"] >= gpu_min_rss * (1 - 1e-9)))
+    return {"value": float(sample) * P / dt, "unit": "SNP-permutations/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "first %d SNPs (1/100 of the workload; linear in M), closed-form float64 restatement "
+                      "(oracle.perm_closed), %.1f s" % (sample, dt),
+            "subsample_minima_bound_the_gpu_minima": ok}
 
 
 # ----------------------------------------------------------------------------------------------- multi-phenotype
