@@ -142,7 +142,15 @@ __device__ __forceinline__ void w4tr_slice(v16i (&acc)[4][4], Frag4& cur, Frag4&
 // N3: DMA pieces of stage t+2 issued right after the barrier of step t (slice 3), the other 16 - N3 in slice 0 of step
 // t+1.  The operands of these kernels stream from HBM / the Infinity Cache (a 5 GB store, not an L2-resident digit
 // image): the later a piece is issued the likelier the next barrier waits for it.
-template <int N3 = 8, class JobFn, class PreFn, class EpiFn>
+// PFD > 0: L2 prefetch.  The stream keeps ONE stage of LDS-DMA in flight (two LDS slots), so by Little's law a CU moves
+// at most one stage (64 KiB) per memory round trip: an L2 hit returns well inside a K step (~1 us), a line that has to
+// come from the Infinity Cache or HBM may not, and the barrier waits.  With PFD = d every wave touches the 128 lines
+// of ITS rows of stage (cursor + d) -- two 4-byte-per-lane `buffer_load ... lds` into a 256-byte scratch behind the
+// stage buffers (lds + LDS_BYTES + wave * 256: the caller allocates LDS_BYTES + 1024) -- one K step before the real
+// DMA of that stage is issued, so the DMA finds its lines in L2.  Same-job stages only.
+constexpr int W4TR_PF_LDS = 1024;
+
+template <int N3 = 8, int PFD = 0, class JobFn, class PreFn, class EpiFn>
 __device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* lds, JobFn&& job, PreFn&& pre, EpiFn&& epi) {
   static_assert(N3 >= 8 && N3 <= 16, "N3");
   if (j1 <= j0) return;
@@ -167,6 +175,19 @@ __device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* ld
   auto rebase = [&]() {
     sp.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(cjb.P + cks * kstep_bytes), 0, 0x7fffffff, 0x00020000);
     sq.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(cjb.Q + cks * kstep_bytes), 0, 0x7fffffff, 0x00020000);
+  };
+  // one 128-byte line per lane: lane l -> k row wave*32 + (l >> 1) of the stage, line (l & 1) of the 256-byte window
+  const int pf_off = (wave * 32 + (lane >> 1)) * (int)ld + (lane & 1) * 128;
+  auto prefetch = [&]() {
+    if (PFD > 0 && cks + PFD < cnks) {
+      char* scratch = lds + LDS_BYTES + wave * 256;
+      const __amdgpu_buffer_rsrc_t rp =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(cjb.P + (cks + PFD) * kstep_bytes), 0, 0x7fffffff, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rq =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(cjb.Q + (cks + PFD) * kstep_bytes), 0, 0x7fffffff, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rp, (MMG_AS3 void*)scratch, 4, pf_off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (MMG_AS3 void*)scratch, 4, pf_off, 0, 0, 0);
+    }
   };
   auto advance = [&]() {
     if (cks + 1 < cnks) { ++cks; rebase(); return; }
@@ -193,6 +214,7 @@ __device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* ld
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N3) : "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  prefetch();                                            // lines of stage 1+PFD (stage 2 for PFD = 1)
 
   Frag4 f0, f1;
   {
@@ -217,6 +239,7 @@ __device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* ld
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     advance();                                           // -> stage t+2
+    prefetch();                                          // lines of stage t+2+PFD -> L2
     w4tr_slice<0, N3, false>(acc, f1, f0, oth, ab, bb, 0, sp, sq, cur, wave);
     ++t;
   };

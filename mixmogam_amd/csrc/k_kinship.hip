@@ -89,7 +89,7 @@ __global__ __launch_bounds__(W4_THREADS) void kinship_i8_w4_kernel(const int8_t*
 // The same job straight off SNP-major images (the genotype store itself): both tiles are 256-column windows of rows
 // [ks0*128, ks1*128), read through the transposed LDS reads of gemm_i8_w4tr.h -- no individual-major copy.
 // Sp != Sq: digit-weighted rows x plain rows (exact GRM planes).
-template <int N3>
+template <int N3, int PFD>
 __global__ __launch_bounds__(W4_THREADS) void kinship_i8_tr_kernel(const int8_t* __restrict__ Sp,
                                                                    const int8_t* __restrict__ Sq, int64_t ld,
                                                                    int32_t Npad, const KinJob* __restrict__ jobs,
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(W4_THREADS) void kinship_i8_tr_kernel(const int8_t*
   const int8_t* P = Sp + (int64_t)job.ks0 * BK * ld + (int64_t)job.I * TM;
   const int8_t* Q = Sq + (int64_t)job.ks0 * BK * ld + (int64_t)job.J * TN;
   const int nks = job.ks1 - job.ks0;
-  w4tr_stream<N3>(
+  w4tr_stream<N3, PFD>(
       0, 1, ld, lds, [&](int) { return W4JobTr{P, Q, nks}; }, [](int) {},
       [&](int, v16i (&acc)[4][4]) {
 #pragma unroll
@@ -325,6 +325,8 @@ void launch_grm_combine(mmg_ctx* ctx, const int* C32, int D, int32_t Npad, int32
                      N, step, base, c1, c0, C, accumulate);
 }
 
+constexpr int KIN_PF_DEFAULT = 0;     // L2 prefetch distance of the transposed-read kinship kernel (see run_kinship_i8_tr)
+
 // C32 (upper tiles) += Sp' Sq over rows [0, nk * 128) of two SNP-major images with row stride ld (Sp == Sq: the store)
 int run_kinship_i8_tr(mmg_ctx* ctx, const int8_t* Sp, const int8_t* Sq, int64_t ld, int32_t Npad, int64_t nk, int* C32) {
   const int nT = Npad / TM;
@@ -333,16 +335,22 @@ int run_kinship_i8_tr(mmg_ctx* ctx, const int8_t* Sp, const int8_t* Sq, int64_t 
   KinJob* djobs = nullptr;
   MMG_HIP(ctx, hipMalloc(&djobs, jobs.size() * sizeof(KinJob)));
   MMG_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(KinJob), hipMemcpyHostToDevice, ctx->stream));
-  // MMG_KIN_N3 = 8 | 12 | 16: DMA pieces issued right behind the barrier (A/B timing of the prefetch lead)
-  static const int n3 = [] { const char* e = std::getenv("MMG_KIN_N3"); const int v = e ? std::atoi(e) : 8; return v == 12 || v == 16 ? v : 8; }();
-  const void* fn = n3 == 16 ? (const void*)kinship_i8_tr_kernel<16> : n3 == 12 ? (const void*)kinship_i8_tr_kernel<12> : (const void*)kinship_i8_tr_kernel<8>;
-  MMG_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  // MMG_KIN_N3 = 8 | 16: DMA pieces issued right behind the barrier; MMG_KIN_PF = 0 | 1 | 2: L2 prefetch distance
+  // (gemm_i8_w4tr.h) -- A/B timing
+  static const int n3 = [] { const char* e = std::getenv("MMG_KIN_N3"); return e && std::atoi(e) == 16 ? 16 : 8; }();
+  static const int pf = [] { const char* e = std::getenv("MMG_KIN_PF"); const int v = e ? std::atoi(e) : KIN_PF_DEFAULT; return v < 0 || v > 2 ? KIN_PF_DEFAULT : v; }();
+  const size_t lds_bytes = LDS_BYTES + (pf ? W4TR_PF_LDS : 0);
   {
-    EvScope ev(ctx, EV_KIN);
-#define MMG_LAUNCH_KTR(N3_)                                                                                          \
-  hipLaunchKernelGGL(kinship_i8_tr_kernel<N3_>, dim3((unsigned)jobs.size()), dim3(W4_THREADS), LDS_BYTES, ctx->stream, Sp, \
-                     Sq, ld, Npad, djobs, C32)
-    if (n3 == 16) MMG_LAUNCH_KTR(16); else if (n3 == 12) MMG_LAUNCH_KTR(12); else MMG_LAUNCH_KTR(8);
+#define MMG_LAUNCH_KTR(N3_, PF_)                                                                                       \
+  do {                                                                                                                 \
+    MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_i8_tr_kernel<N3_, PF_>,                                      \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                     \
+    EvScope ev(ctx, EV_KIN);                                                                                           \
+    hipLaunchKernelGGL((kinship_i8_tr_kernel<N3_, PF_>), dim3((unsigned)jobs.size()), dim3(W4_THREADS), lds_bytes,    \
+                       ctx->stream, Sp, Sq, ld, Npad, djobs, C32);                                                     \
+  } while (0)
+    if (n3 == 16) { if (pf == 2) MMG_LAUNCH_KTR(16, 2); else if (pf == 1) MMG_LAUNCH_KTR(16, 1); else MMG_LAUNCH_KTR(16, 0); }
+    else { if (pf == 2) MMG_LAUNCH_KTR(8, 2); else if (pf == 1) MMG_LAUNCH_KTR(8, 1); else MMG_LAUNCH_KTR(8, 0); }
 #undef MMG_LAUNCH_KTR
   }
   MMG_HIP(ctx, hipGetLastError());
