@@ -24,10 +24,11 @@ __device__ __forceinline__ StageOp4 make_stage_op4(const int8_t* base, int64_t l
   return s;
 }
 
-// piece i in 0..7: rows (wave*8 + i)*8 .. +8
+// piece i in 0..7: rows (wave*8 + i)*8 .. +8.  AUX: cache policy of the load (0 default, 2 = nt; experiments only)
+template <int AUX = 0>
 __device__ __forceinline__ void stage_piece4(const StageOp4& s, int k0, char* lds_tile, int wave, int i) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rs, (MMG_AS3 void*)(lds_tile + (wave * 8 + i) * 1024), 16,
-                                           (i & 1) ? s.v_odd : s.v_even, k0 + i * s.ld8, 0, 0);
+                                           (i & 1) ? s.v_odd : s.v_even, k0 + i * s.ld8, 0, AUX);
 }
 
 }  // namespace mmg

@@ -42,6 +42,15 @@
 #include "gemm_i8_w4s.h"
 #include "mmg_internal.h"
 
+// cache policy of the digit-tile (P) / genotype-tile (Q) LDS-DMA loads: 0 = default, 2 = nt.  Build-time experiment
+// knobs (make DEFS="-DMMG_SCAN_AUX_P=2"); see DESIGN.md 4.1 for what they measured.
+#ifndef MMG_SCAN_AUX_P
+#define MMG_SCAN_AUX_P 0
+#endif
+#ifndef MMG_SCAN_AUX_Q
+#define MMG_SCAN_AUX_Q 0
+#endif
+
 namespace mmg {
 
 // MMG_W4S_PIN=1 (A/B builds, `make DEFS=-DMMG_W4S_PIN=1`): every (MFMA, read, MFMA, read/DMA) group ends in a full
@@ -89,12 +98,12 @@ __device__ __forceinline__ void slice(v16i (&acc)[4][4], const Frag4& cur, Frag4
     if (P0 + i < P1) {
       const int pc = P0 + i;
       if (HOT == 1 || (HOT == 2 && pc >= 8) || (HOT == 3 && pc < 8)) {   // ablation: same LDS-DMA traffic, source always the same 2 KiB
-        if (pc < 8) stage_piece4(sq, 0, dst, wave, pc & 1);
-        else stage_piece4(sq, 0, dst + TILE_BYTES, wave, pc & 1);
+        if (pc < 8) stage_piece4<MMG_SCAN_AUX_Q>(sq, 0, dst, wave, pc & 1);
+        else stage_piece4<MMG_SCAN_AUX_Q>(sq, 0, dst + TILE_BYTES, wave, pc & 1);
       } else if (pc < 8) {
-        stage_piece4(sp, k0, dst, wave, pc);
+        stage_piece4<MMG_SCAN_AUX_P>(sp, k0, dst, wave, pc);
       } else {
-        stage_piece4(sq, k0, dst + TILE_BYTES, wave, pc - 8);
+        stage_piece4<MMG_SCAN_AUX_Q>(sq, k0, dst + TILE_BYTES, wave, pc - 8);
       }
     }
     if (PIN_SLICES) __builtin_amdgcn_sched_barrier(0);
@@ -168,14 +177,14 @@ __global__ __launch_bounds__(W4_THREADS) void scan_quad_w4s_kernel(
 
   // ---- prologue: stage 0 complete, the first N3 pieces of stage 1 in flight, fragments of step 0 slice 0
 #pragma unroll
-  for (int i = 0; i < 8; ++i) stage_piece4(sp, 0, lds, wave, i);
+  for (int i = 0; i < 8; ++i) stage_piece4<MMG_SCAN_AUX_P>(sp, 0, lds, wave, i);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) stage_piece4(sq, 0, lds + TILE_BYTES, wave, i);
+  for (int i = 0; i < 8; ++i) stage_piece4<MMG_SCAN_AUX_Q>(sq, 0, lds + TILE_BYTES, wave, i);
   advance();                                             // -> stage 1
 #pragma unroll
   for (int i = 0; i < N3; ++i) {
-    if (i < 8) stage_piece4(sp, cks * BK, lds + BUF_BYTES, wave, i);
-    else stage_piece4(sq, cks * BK, lds + BUF_BYTES + TILE_BYTES, wave, i - 8);
+    if (i < 8) stage_piece4<MMG_SCAN_AUX_P>(sp, cks * BK, lds + BUF_BYTES, wave, i);
+    else stage_piece4<MMG_SCAN_AUX_Q>(sq, cks * BK, lds + BUF_BYTES + TILE_BYTES, wave, i - 8);
   }
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N3) : "memory");
   __builtin_amdgcn_s_barrier();
