@@ -10,6 +10,7 @@
 //                        fixed order (deterministic).
 // Only upper-triangular tiles (I <= J) are computed.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 #include "gemm_i8_core.h"
@@ -280,11 +281,18 @@ static int choose_ksplit(int ntiles, int nk, int min_steps, int max_split) {
 }
 
 static std::vector<KinJob> build_jobs(int nT, int nk, int ksplit) {
+  // patch shape of the tile order (MMG_KIN_PATCH=IxJ, A/B runs): consecutive jobs share operand panels in an XCD's L2
+  static const std::pair<int, int> patch = [] {
+    int pi = 4, pj = 8;
+    if (const char* e = std::getenv("MMG_KIN_PATCH")) { int a = 0, b = 0; if (std::sscanf(e, "%dx%d", &a, &b) == 2 && a > 0 && b > 0) { pi = a; pj = b; } }
+    return std::make_pair(pi, pj);
+  }();
+  const int PI = patch.first, PJ = patch.second;
   std::vector<std::pair<int, int>> tiles;
-  for (int Ib = 0; Ib < nT; Ib += 4)
-    for (int Jb = 0; Jb < nT; Jb += 8)
-      for (int I = Ib; I < std::min(Ib + 4, nT); ++I)
-        for (int J = Jb; J < std::min(Jb + 8, nT); ++J)
+  for (int Ib = 0; Ib < nT; Ib += PI)
+    for (int Jb = 0; Jb < nT; Jb += PJ)
+      for (int I = Ib; I < std::min(Ib + PI, nT); ++I)
+        for (int J = Jb; J < std::min(Jb + PJ, nT); ++J)
           if (I <= J) tiles.push_back({I, J});
   std::vector<KinJob> jobs;
   for (int s = 0; s < ksplit; ++s) {
