@@ -40,6 +40,7 @@ I8_MFMA_PEAK_TOPS = 5000.0     # dense int8 MFMA: 2x the ~2.5 PF bf16 rate (MI35
 # (signed base-256 digits: 4.30).  Reported beside the nominal peak, never instead of it.
 I8_MFMA_SUSTAINED_TOPS = 4560.0
 I8_MFMA_SUSTAINED_SOURCE = "tools/probe/mfma_digit_range.hip (digits 0..127 x 0/1 bytes, registers only, power-capped clock)"
+F4_MFMA_PEAK_TOPS = 10000.0    # dense FP4 / FP6 on v_mfma_scale_f32_32x32x64_f8f6f4 (same guide: ~10 PF)
 F32_MFMA_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2_f32 (same guide)
 HBM_PEAK_GBPS = 8000.0
 PCIE_GBPS = 64.0               # host link of the box (gen5 x16), the roof of anything that starts in host memory
@@ -382,7 +383,8 @@ def bench_scan(args, ctx, coll, comm_h, g, lmm, est, prep, N, M, Mtot, D, barrie
              "note": "algorithmic = the symmetric product N(N+1)M (K = K'); the reference forms all 2 N^2 M "
                      "(kinship.py:44): `vs_reference_full_product` is that figure over the same time, a speed-up "
                      "statement, not a roofline fraction; executed = the lower triangle of 256^2 tiles actually run; "
-                     "`ms` includes every device pass the call needs (ms_gemm + the individual-major image pass)"}
+                     "`ms` includes every device pass the call needs (ms_gemm + the image pass: the individual-major "
+                     "copy of the fp32 kernel, the FP4 nibble image of the exact-count kernel)"}
         if pass_name is not None:
             d[pass_name] = pass_ms
         return d
@@ -408,8 +410,13 @@ def bench_scan(args, ctx, coll, comm_h, g, lmm, est, prep, N, M, Mtot, D, barrie
         # second headline metric: kinship GEMM TFLOP/s vs MFMA peak, one record per kernel
         "roofline_kinship": {"f32": kin_roof("kinship_f32_kernel", kin_f32_ms, F32_MFMA_PEAK_TFLOPS, "TFLOP/s",
                                              kin_f32_pack_ms, "transpose_pass_ms"),
-                             "i8": kin_roof("kinship_i8_tr_kernel", kin_i8_ms, I8_MFMA_PEAK_TOPS, "TOP/s",
-                                            kin_i8_pack_ms, "transpose_pass_ms")},
+                             # binary stores run the exact counts on FP4 operands (0/1 are exact in E2M1, fp32
+                             # accumulators hold exact integers): priced against the FP4 peak, not the int8 one
+                             "i8": (kin_roof("kinship_f4_tr_kernel", kin_i8_ms, F4_MFMA_PEAK_TOPS, "TOP/s",
+                                             kin_i8_pack_ms, "fp4_image_pass_ms")
+                                    if os.environ.get("MMG_KIN_FP4", "1") != "0" and not os.environ.get("MMG_KIN_KERNEL") else
+                                    kin_roof("kinship_i8_tr_kernel", kin_i8_ms, I8_MFMA_PEAK_TOPS, "TOP/s",
+                                             kin_i8_pack_ms, "transpose_pass_ms"))},
         "adaptive_scan": scan_stats, "all_planes_reference": all_planes, "min_p": float(np.nanmin(ps)),
     })
     if world == 1 and not args.no_extras:

@@ -522,8 +522,27 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
   int rc = MMG_OK;
   double kin_ms = 0.0, pack_ms = 0.0;
   if (direct) {
-    ctx->ev_set[EV_PACK] = false;                       // no pack pass in this call
-    rc = run_kinship_i8_tr(ctx, g->d, g->d, g->Npad, g->Npad, g->Mpad / BK, C32);   // rows M..Mpad are zero
+    // binary stores: the product on FP4 operands (twice the MACs per MFMA, half the bytes per LDS fill); MMG_KIN_FP4=0
+    // keeps the int8 kernel
+    static const bool fp4_off = [] { const char* e = std::getenv("MMG_KIN_FP4"); return e && e[0] == '0'; }();
+    rc = MMG_E_STATE;
+    if (!fp4_off && g->smax <= 1 && g->sneg == 0) {
+      uint8_t* X4 = nullptr;
+      if (sc.alloc(&X4, (size_t)g->Mpad * (g->Npad / 2)) == hipSuccess) {
+        {
+          EvScope ev(ctx, EV_PACK);
+          launch_pack_fp4(ctx, g->d, g->Mpad, g->Npad, X4);
+        }
+        MMG_HIP(ctx, hipGetLastError());
+        rc = run_kinship_f4_tr(ctx, X4, g->Npad, g->Mpad / 256, C32);
+      } else {
+        (void)hipGetLastError();
+      }
+    }
+    if (rc == MMG_E_STATE) {
+      ctx->ev_set[EV_PACK] = false;                     // no image pass in this call
+      rc = run_kinship_i8_tr(ctx, g->d, g->d, g->Npad, g->Npad, g->Mpad / BK, C32);   // rows M..Mpad are zero
+    }
   }
   for (int64_t mb = 0; !direct && mb < g->M && rc == MMG_OK; mb += CH) {
     const int64_t Mk = round_up(std::min(CH, g->M - mb), BK);

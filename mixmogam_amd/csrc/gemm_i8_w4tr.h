@@ -83,6 +83,58 @@ __device__ __forceinline__ int frag_base_tr(int tile_row0, int lane) {
   return (h * 16 + (i16 >> 1)) * 256 + ((chunk ^ (i16 & 14)) << 4) + (i16 & 1) * 8;
 }
 
+// ---- operand formats of the stream --------------------------------------------------------------------------------
+// FmtI8: int8 operands, v_mfma_i32_32x32x32_i8, K step = 128 k rows, tile image [128 k][256 B] (above).
+struct FmtI8 {
+  typedef v16i Acc;
+  typedef StageOpTr Stage;
+  static constexpr int KROWS = 128;
+  static __device__ __forceinline__ Stage make(const int8_t* base, int64_t ld, int wave, int lane) { (void)wave; return make_stage_op_tr(base, ld, lane); }
+  static __device__ __forceinline__ void piece(const Stage& s, char* tile, int wave, int i) { stage_piece_tr(s, tile, wave, i); }
+  static __device__ __forceinline__ int frag_base(int tile_row0, int lane) { return frag_base_tr(tile_row0, lane); }
+  static __device__ __forceinline__ void frag(v4i& f, uint32_t addr, int slice) { lds_frag_tr(f, addr, slice); }
+  static __device__ __forceinline__ Acc mma(v4i a, v4i b, Acc c) { return mfma8(a, b, c); }
+  static __device__ __forceinline__ Acc zero() { return v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
+};
+
+// FmtF4: FP4 (E2M1) operands -- 0/1 genotypes as the nibbles 0x0 / 0x2 (= 0.0 / 1.0) -- on
+// v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales: twice the MACs per instruction and half the bytes per operand
+// element of the int8 form; the fp32 accumulators hold exact integers while a job's partial counts stay below 2^24.
+// Image: [k][column nibbles], low nibble = even column; K step = 256 k rows, so that the LDS tile is the [256 rows][128
+// B] image of gemm_i8_core.h (32 KiB, 16-byte chunk swizzle c ^ ((row >> 1) & 7), staged by 8-row x 128-B pieces) with
+// k as the ROW.  ds_read_b64_tr_b4 (tools/probe/ds_read_tr_b4.hip): within a group of 16 lanes, lane q supplies the
+// address of the 8 bytes (16 nibble columns) of row q of a 16 x 16 nibble block and lane i receives column i, row 0 in
+// its lowest nibble; two reads (k rows +0..15, +16..31) are one 16-byte operand (32 k).  Bank check: a 32-lane half
+// reads 16 rows x 16 B; rows k, k+1 differ by 32 banks, row pairs by their swizzle: conflict free.
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+struct FmtF4 {
+  typedef v16f Acc;
+  typedef StageOp4 Stage;
+  static constexpr int KROWS = 256;
+  static __device__ __forceinline__ Stage make(const int8_t* base, int64_t ld, int wave, int lane) { return make_stage_op4(base, ld, wave, lane); }
+  static __device__ __forceinline__ void piece(const Stage& s, char* tile, int wave, int i) { stage_piece4(s, 0, tile, wave, i); }
+  static __device__ __forceinline__ int frag_base(int tile_row0, int lane) {
+    const int q = lane & 15, g = lane >> 4, h = g >> 1;
+    return (h * 32 + q) * 128 + (((tile_row0 >> 5) ^ (q >> 1)) << 4) + (g & 1) * 8;
+  }
+  static __device__ __forceinline__ void frag(v4i& f, uint32_t addr, int slice) {
+    v2i lo, hi;
+    switch (slice) {
+      case 0: asm volatile("ds_read_b64_tr_b4 %0, %2\n\tds_read_b64_tr_b4 %1, %2 offset:2048" : "=&v"(lo), "=&v"(hi) : "v"(addr)); break;
+      case 1: asm volatile("ds_read_b64_tr_b4 %0, %2 offset:8192\n\tds_read_b64_tr_b4 %1, %2 offset:10240" : "=&v"(lo), "=&v"(hi) : "v"(addr)); break;
+      case 2: asm volatile("ds_read_b64_tr_b4 %0, %2 offset:16384\n\tds_read_b64_tr_b4 %1, %2 offset:18432" : "=&v"(lo), "=&v"(hi) : "v"(addr)); break;
+      default: asm volatile("ds_read_b64_tr_b4 %0, %2 offset:24576\n\tds_read_b64_tr_b4 %1, %2 offset:26624" : "=&v"(lo), "=&v"(hi) : "v"(addr)); break;
+    }
+    f = v4i{lo.x, lo.y, hi.x, hi.y};
+  }
+  static __device__ __forceinline__ Acc mma(v4i a, v4i b, Acc c) {
+    const v8i a8{a.x, a.y, a.z, a.w, 0, 0, 0, 0}, b8{b.x, b.y, b.z, b.w, 0, 0, 0, 0};   // FP4 uses the first four dwords
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+  }
+  static __device__ __forceinline__ Acc zero() { return v16f{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
+};
+
 struct W4JobTr {
   const int8_t* P;     // column 0 of the job's 256-column P window at k row 0 of the job
   const int8_t* Q;     // likewise for the Q window
@@ -98,10 +150,11 @@ struct W4JobTr {
 // first use of positions 0..7 is at MFMA index 0, 0, 1, 2, 4, 6, 9, 12 with r = 0, 0, 2, 2, 4, 6, 10, 12:
 // lgkmcnt(12), (12), (10), (10), (10), (12), (12).  No other lgkm operation may be issued inside the stream (scalar
 // loads return out of order): job descriptors are held in registers.
-template <int P0, int P1, bool ZERO>
-__device__ __forceinline__ void w4tr_slice(v16i (&acc)[4][4], Frag4& cur, Frag4& nxt, const char* src,
-                                           const int (&ab)[4], const int (&bb)[4], int slice, const StageOpTr& sp,
-                                           const StageOpTr& sq, char* dst, int wave) {
+template <class Fmt, int P0, int P1, bool ZERO>
+__device__ __forceinline__ void w4tr_slice(typename Fmt::Acc (&acc)[4][4], Frag4& cur, Frag4& nxt, const char* src,
+                                           const int (&ab)[4], const int (&bb)[4], int slice,
+                                           const typename Fmt::Stage& sp, const typename Fmt::Stage& sq, char* dst,
+                                           int wave) {
   static_assert(P1 - P0 <= 16, "at most two DMA pieces per MFMA pair");
   constexpr int PER = (P1 - P0 > 8) ? 2 : 1;             // DMA pieces per MFMA pair
   const uint32_t s32 = (uint32_t)(uintptr_t)src;
@@ -113,24 +166,24 @@ __device__ __forceinline__ void w4tr_slice(v16i (&acc)[4][4], Frag4& cur, Frag4&
     if (i == 2) frag_wait<10>(cur.a[2]);                 // MFMA 4: a2 b0
     if (i == 3) frag_wait<10>(cur.b[2]);                 // MFMA 6: a0 b2
     if (i == 6) frag_wait<12>(cur.b[3]);                 // MFMA 12: a0 b3
-    if (ZERO) acc[m0][n0] = mfma8(cur.a[m0], cur.b[n0], v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0});
-    else acc[m0][n0] = mfma8(cur.a[m0], cur.b[n0], acc[m0][n0]);
+    if (ZERO) acc[m0][n0] = Fmt::mma(cur.a[m0], cur.b[n0], Fmt::zero());
+    else acc[m0][n0] = Fmt::mma(cur.a[m0], cur.b[n0], acc[m0][n0]);
     // the asm statements keep their order among themselves, but the MFMAs (no side effects) are free to sink below
     // them -- the scheduler bunched all 16 at the end of the slice: pin the source order MFMA / reads / MFMA / DMA
     __builtin_amdgcn_sched_barrier(0);
-    if ((i & 1) == 0) lds_frag_tr(nxt.a[i >> 1], s32 + (uint32_t)ab[i >> 1], slice);
-    else lds_frag_tr(nxt.b[i >> 1], s32 + (uint32_t)bb[i >> 1], slice);
+    if ((i & 1) == 0) Fmt::frag(nxt.a[i >> 1], s32 + (uint32_t)ab[i >> 1], slice);
+    else Fmt::frag(nxt.b[i >> 1], s32 + (uint32_t)bb[i >> 1], slice);
     if (i == 0) frag_wait<12>(cur.a[1]);                 // MFMA 1: a1 b0
     if (i == 4) frag_wait<12>(cur.a[3]);                 // MFMA 9: a3 b0
-    if (ZERO) acc[m1][n1] = mfma8(cur.a[m1], cur.b[n1], v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0});
-    else acc[m1][n1] = mfma8(cur.a[m1], cur.b[n1], acc[m1][n1]);
+    if (ZERO) acc[m1][n1] = Fmt::mma(cur.a[m1], cur.b[n1], Fmt::zero());
+    else acc[m1][n1] = Fmt::mma(cur.a[m1], cur.b[n1], acc[m1][n1]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int pc = P0 + PER * i + u;
       if (pc < P1) {
-        if (pc < 8) stage_piece_tr(sp, dst, wave, pc);
-        else stage_piece_tr(sq, dst + TILE_BYTES, wave, pc - 8);
+        if (pc < 8) Fmt::piece(sp, dst, wave, pc);
+        else Fmt::piece(sq, dst + TILE_BYTES, wave, pc - 8);
       }
     }
   }
@@ -150,9 +203,10 @@ __device__ __forceinline__ void w4tr_slice(v16i (&acc)[4][4], Frag4& cur, Frag4&
 // DMA of that stage is issued, so the DMA finds its lines in L2.  Same-job stages only.
 constexpr int W4TR_PF_LDS = 1024;
 
-template <int N3 = 8, int PFD = 0, class JobFn, class PreFn, class EpiFn>
+template <int N3 = 8, int PFD = 0, class Fmt = FmtI8, class JobFn, class PreFn, class EpiFn>
 __device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* lds, JobFn&& job, PreFn&& pre, EpiFn&& epi) {
   static_assert(N3 >= 8 && N3 <= 16, "N3");
+  static_assert(PFD == 0 || Fmt::KROWS == 128, "the L2 prefetch is written for the int8 image");
   if (j1 <= j0) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -160,18 +214,18 @@ __device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* ld
   int ab[4], bb[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    ab[i] = frag_base_tr(wm * 128 + i * 32, lane);
-    bb[i] = frag_base_tr(wn * 128 + i * 32, lane) + TILE_BYTES;
+    ab[i] = Fmt::frag_base(wm * 128 + i * 32, lane);
+    bb[i] = Fmt::frag_base(wn * 128 + i * 32, lane) + TILE_BYTES;
   }
-  const int64_t kstep_bytes = (int64_t)BK * ld;
+  const int64_t kstep_bytes = (int64_t)Fmt::KROWS * ld;
 
   // ---- issue cursor over the flattened stage stream (wave-uniform scalars); the descriptor base moves with the stage
   // (a K step is 128 rows = 128 * ld bytes: beyond 32-bit offsets for long contraction ranges)
   int cj = j0;
   W4JobTr cjb = job(cj);
   int cks = 0, cnks = cjb.nks;
-  StageOpTr sp = make_stage_op_tr(cjb.P, ld, lane);
-  StageOpTr sq = make_stage_op_tr(cjb.Q, ld, lane);
+  typename Fmt::Stage sp = Fmt::make(cjb.P, ld, wave, lane);
+  typename Fmt::Stage sq = Fmt::make(cjb.Q, ld, wave, lane);
   auto rebase = [&]() {
     sp.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(cjb.P + cks * kstep_bytes), 0, 0x7fffffff, 0x00020000);
     sq.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(cjb.Q + cks * kstep_bytes), 0, 0x7fffffff, 0x00020000);
@@ -202,14 +256,14 @@ __device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* ld
 
   // ---- prologue: stage 0 complete, the first N3 pieces of stage 1 in flight, fragments of step 0 slice 0
 #pragma unroll
-  for (int i = 0; i < 8; ++i) stage_piece_tr(sp, lds, wave, i);
+  for (int i = 0; i < 8; ++i) Fmt::piece(sp, lds, wave, i);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) stage_piece_tr(sq, lds + TILE_BYTES, wave, i);
+  for (int i = 0; i < 8; ++i) Fmt::piece(sq, lds + TILE_BYTES, wave, i);
   advance();                                             // -> stage 1
 #pragma unroll
   for (int i = 0; i < N3; ++i) {
-    if (i < 8) stage_piece_tr(sp, lds + BUF_BYTES, wave, i);
-    else stage_piece_tr(sq, lds + BUF_BYTES + TILE_BYTES, wave, i - 8);
+    if (i < 8) Fmt::piece(sp, lds + BUF_BYTES, wave, i);
+    else Fmt::piece(sq, lds + BUF_BYTES + TILE_BYTES, wave, i - 8);
   }
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N3) : "memory");
   __builtin_amdgcn_s_barrier();
@@ -221,26 +275,26 @@ __device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* ld
     const uint32_t l32 = (uint32_t)(uintptr_t)lds;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                        // the order the counted waits of the first slice assume
-      lds_frag_tr(f0.a[i], l32 + (uint32_t)ab[i], 0);
-      lds_frag_tr(f0.b[i], l32 + (uint32_t)bb[i], 0);
+      Fmt::frag(f0.a[i], l32 + (uint32_t)ab[i], 0);
+      Fmt::frag(f0.b[i], l32 + (uint32_t)bb[i], 0);
     }
   }
 
-  v16i acc[4][4];                                        // written (not accumulated) by the first slice of every job
+  typename Fmt::Acc acc[4][4];                           // written (not accumulated) by the first slice of every job
   int t = 0;
   auto step = [&](bool first) {
     char* cur = lds + (t & 1) * BUF_BYTES;
     char* oth = lds + ((t + 1) & 1) * BUF_BYTES;
-    if (first) w4tr_slice<N3, 16, true>(acc, f0, f1, cur, ab, bb, 1, sp, sq, oth, wave);
-    else w4tr_slice<N3, 16, false>(acc, f0, f1, cur, ab, bb, 1, sp, sq, oth, wave);
-    w4tr_slice<16, 16, false>(acc, f1, f0, cur, ab, bb, 2, sp, sq, oth, wave);
-    w4tr_slice<16, 16, false>(acc, f0, f1, cur, ab, bb, 3, sp, sq, oth, wave);
+    if (first) w4tr_slice<Fmt, N3, 16, true>(acc, f0, f1, cur, ab, bb, 1, sp, sq, oth, wave);
+    else w4tr_slice<Fmt, N3, 16, false>(acc, f0, f1, cur, ab, bb, 1, sp, sq, oth, wave);
+    w4tr_slice<Fmt, 16, 16, false>(acc, f1, f0, cur, ab, bb, 2, sp, sq, oth, wave);
+    w4tr_slice<Fmt, 16, 16, false>(acc, f0, f1, cur, ab, bb, 3, sp, sq, oth, wave);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     advance();                                           // -> stage t+2
     prefetch();                                          // lines of stage t+2+PFD -> L2
-    w4tr_slice<0, N3, false>(acc, f1, f0, oth, ab, bb, 0, sp, sq, cur, wave);
+    w4tr_slice<Fmt, 0, N3, false>(acc, f1, f0, oth, ab, bb, 0, sp, sq, cur, wave);
     ++t;
   };
   for (int jj = j0; jj < j1; ++jj) {

@@ -120,7 +120,38 @@ __global__ __launch_bounds__(W4_THREADS) void kinship_i8_tr_kernel(const int8_t*
       });
 }
 
-typedef float v16f __attribute__((ext_vector_type(16)));
+// The raw-genotype product of a BINARY store on FP4 operands (gemm_i8_w4tr.h FmtF4): v_mfma_scale_f32_32x32x64_f8f6f4
+// runs 0/1 x 0/1 at 9.05 POP/s under the power cap against 4.85 for int8 bytes (tools/probe/mfma_f8f6f4_rate.hip) and
+// every LDS fill carries half the bytes -- both bounds of the int8 kernel move.  X4: the FP4 image
+// (pack_fp4_kernel), row stride ld4 = Npad / 2; a K step is 256 SNP rows.  The fp32 accumulators of a job hold exact
+// counts (< 2^24: the host bounds the K range per job).
+__global__ __launch_bounds__(W4_THREADS) void kinship_f4_tr_kernel(const int8_t* __restrict__ X4, int64_t ld4,
+                                                                   int32_t Npad, const KinJob* __restrict__ jobs,
+                                                                   int* __restrict__ C32) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const KinJob job = jobs[xcd_job_index(blockIdx.x)];
+  if (job.ks1 <= job.ks0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;
+  const int8_t* P = X4 + (int64_t)job.ks0 * FmtF4::KROWS * ld4 + (int64_t)job.I * (TM / 2);
+  const int8_t* Q = X4 + (int64_t)job.ks0 * FmtF4::KROWS * ld4 + (int64_t)job.J * (TN / 2);
+  const int nks = job.ks1 - job.ks0;
+  w4tr_stream<8, 0, FmtF4>(
+      0, 1, ld4, lds, [&](int) { return W4JobTr{P, Q, nks}; }, [](int) {},
+      [&](int, v16f (&acc)[4][4]) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            const int col = job.J * TN + wn * 128 + n * 32 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int row = job.I * TM + wm * 128 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+              atomicAdd(C32 + (int64_t)row * Npad + col, (int)acc[m][n][i]);
+            }
+          }
+      });
+}
 
 __device__ __forceinline__ float byte_to_f32(int word, int j) {
   return (float)(int)(int8_t)((word >> (8 * j)) & 0xff);
@@ -360,6 +391,28 @@ int run_kinship_i8_tr(mmg_ctx* ctx, const int8_t* Sp, const int8_t* Sq, int64_t 
     if (n3 == 16) { if (pf == 2) MMG_LAUNCH_KTR(16, 2); else if (pf == 1) MMG_LAUNCH_KTR(16, 1); else MMG_LAUNCH_KTR(16, 0); }
     else { if (pf == 2) MMG_LAUNCH_KTR(8, 2); else if (pf == 1) MMG_LAUNCH_KTR(8, 1); else MMG_LAUNCH_KTR(8, 0); }
 #undef MMG_LAUNCH_KTR
+  }
+  MMG_HIP(ctx, hipGetLastError());
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MMG_HIP(ctx, hipFree(djobs));
+  return MMG_OK;
+}
+
+// C32 (upper tiles) += X'X over rows [0, nk4 * 256) of the FP4 image X4 (row stride Npad / 2); returns MMG_E_STATE when
+// the contraction range of a job could exceed the exact range of the fp32 accumulators (caller takes the int8 kernel)
+int run_kinship_f4_tr(mmg_ctx* ctx, const uint8_t* X4, int32_t Npad, int64_t nk4, int* C32) {
+  const int nT = Npad / TM;
+  const int ksplit = choose_ksplit(nT * (nT + 1) / 2, (int)nk4, 4, 64);
+  if ((nk4 + ksplit - 1) / ksplit * FmtF4::KROWS >= (int64_t(1) << 24)) return MMG_E_STATE;
+  std::vector<KinJob> jobs = build_jobs(nT, (int)nk4, ksplit);
+  KinJob* djobs = nullptr;
+  MMG_HIP(ctx, hipMalloc(&djobs, jobs.size() * sizeof(KinJob)));
+  MMG_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(KinJob), hipMemcpyHostToDevice, ctx->stream));
+  MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_f4_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  {
+    EvScope ev(ctx, EV_KIN);
+    hipLaunchKernelGGL(kinship_f4_tr_kernel, dim3((unsigned)jobs.size()), dim3(W4_THREADS), LDS_BYTES, ctx->stream,
+                       (const int8_t*)X4, (int64_t)(Npad / 2), Npad, djobs, C32);
   }
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -277,6 +277,38 @@ __global__ __launch_bounds__(256) void transpose_digits_kernel(const int8_t* __r
     *(uint4*)(Xp + (int64_t)d * Npad * Mk + off) = make_uint4(wp[d][0], wp[d][1], wp[d][2], wp[d][3]);
 }
 
+// FP4 image of a BINARY store for the FP4 kinship GEMM (gemm_i8_w4tr.h FmtF4): X4[m][i / 2] holds the genotypes of
+// individuals i (low nibble: even i) as E2M1 nibbles, 1 -> 0x2 (= 1.0), 0 -> 0x0.  One thread per 16 output bytes
+// (32 genotypes).  HBM-bound: Npad in + Npad / 2 out per SNP.
+__global__ __launch_bounds__(256) void pack_fp4_kernel(const int8_t* __restrict__ S, int64_t rows, int32_t Npad,
+                                                       uint8_t* __restrict__ X4) {
+  const int nchunk = Npad >> 5;                          // 16-byte output chunks per row
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= rows * nchunk) return;
+  const int64_t r = gid / nchunk;
+  const int c = (int)(gid % nchunk);
+  const uint4* src = (const uint4*)(S + r * (int64_t)Npad + c * 32);
+  const uint4 a = src[0], b = src[1];
+  const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    // dwords 2q, 2q+1 = 8 genotype bytes (0/1) -> 8 nibbles (0/2): byte j of the pair lands in nibble j
+    const uint32_t lo = w[2 * q] & 0x01010101u, hi = w[2 * q + 1] & 0x01010101u;
+    const uint32_t l4 = (lo | (lo >> 4)) & 0x00110011u, h4 = (hi | (hi >> 4)) & 0x00110011u;     // bytes 0,1 | 2,3 -> nibble pairs
+    const uint32_t l2 = (l4 | (l4 >> 8)) & 0x0000ffffu, h2 = (h4 | (h4 >> 8)) & 0x0000ffffu;
+    // l2 now holds nibbles n0 n1 (byte 0) n2 n3 (byte 1) as bits 0,4,8,12 -> value 1 each; scale to 0x2
+    o[q] = ((l2 & 0x1111u) | ((h2 & 0x1111u) << 16)) << 1;
+  }
+  *(uint4*)(X4 + r * (int64_t)(Npad >> 1) + c * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+void launch_pack_fp4(mmg_ctx* ctx, const int8_t* S, int64_t rows, int32_t Npad, uint8_t* X4) {
+  const int64_t total = rows * (Npad >> 5);
+  if (total <= 0) return;
+  hipLaunchKernelGGL(pack_fp4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, S, rows, Npad, X4);
+}
+
 // SNP-major twin for the transposed-read kinship GEMM (gemm_i8_w4tr.h): nothing is transposed -- image d holds row m
 // of the store times digit d of that SNP's weight, Xp[d][m - m_begin][i] = dig[d][m - m_begin] * s_mi, and the plain
 // operand is the store itself.  One thread owns one 16-byte column chunk over a slab of GRM_SLAB rows, which also gives

@@ -57,4 +57,7 @@ def test_four_wave_kernels_give_the_bits_of_the_eight_wave_generation(tmp_path):
     # round 3: the default IBS kinship reads the SNP-major store through transposed LDS reads (gemm_i8_w4tr.h);
     # w4 / w8 are the two generations on the individual-major image
     kin_w4 = _digest(tmp_path, {"MMG_KIN_KERNEL": "w4"})
-    assert new == old == slow == gv1 == kin_w4
+    # binary stores take the FP4-operand kinship GEMM by default (exact integers in fp32 accumulators);
+    # MMG_KIN_FP4=0 is the int8 transposed-read kernel (the 0/1/2 case of the script runs it in every variant)
+    kin_i8 = _digest(tmp_path, {"MMG_KIN_FP4": "0"})
+    assert new == old == slow == gv1 == kin_w4 == kin_i8
