@@ -529,12 +529,44 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
     if (!fp4_off && g->smax <= 1 && g->sneg == 0) {
       uint8_t* X4 = nullptr;
       if (sc.alloc(&X4, (size_t)g->Mpad * (g->Npad / 2)) == hipSuccess) {
-        {
-          EvScope ev(ctx, EV_PACK);
-          launch_pack_fp4(ctx, g->d, g->Mpad, g->Npad, X4);
+        // The nibble image can be written in SNP chunks on the second stream while the GEMM of the previous chunk runs on
+        // the first (MMG_KIN_FP4_CHUNKS; the GEMM's waves leave registers and LDS for the image kernel's).  Measured at
+        // C3: 1 chunk 6.66 ms (1.3 + 5.4), 2: 6.67, 4: 7.3, 8: 8.7 -- the passes do not hide behind a GEMM that sits at
+        // the power cap, and shorter contraction ranges cost more than the overlap returns.  Default: one chunk.
+        const int64_t ld4 = g->Npad / 2;
+        int nch = 1;
+        if (const char* e = std::getenv("MMG_KIN_FP4_CHUNKS")) nch = std::max(1, std::min(16, std::atoi(e)));
+        const int64_t rows_ch = round_up((g->Mpad + nch - 1) / nch, 256);
+        std::vector<hipEvent_t> evs;
+        hipEvent_t ev0 = nullptr;
+        MMG_HIP(ctx, hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
+        MMG_HIP(ctx, hipEventRecord(ev0, ctx->stream));                  // the store's writers are on the first stream
+        MMG_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ev0, 0));
+        for (int64_t r0 = 0; r0 < g->Mpad; r0 += rows_ch) {
+          const int64_t nr = std::min(rows_ch, g->Mpad - r0);
+          launch_pack_fp4_on(ctx, ctx->stream2, g->d + r0 * (int64_t)g->Npad, nr, g->Npad, X4 + r0 * ld4);
+          hipEvent_t ev = nullptr;
+          MMG_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+          MMG_HIP(ctx, hipEventRecord(ev, ctx->stream2));
+          evs.push_back(ev);
         }
-        MMG_HIP(ctx, hipGetLastError());
-        rc = run_kinship_f4_tr(ctx, X4, g->Npad, g->Mpad / 256, C32);
+        rc = MMG_OK;
+        {
+          EvScope ev(ctx, EV_KIN);                                        // inclusive: image chunks + GEMMs
+          size_t c = 0;
+          for (int64_t r0 = 0; r0 < g->Mpad && rc == MMG_OK; r0 += rows_ch, ++c) {
+            const int64_t nr = std::min(rows_ch, g->Mpad - r0);
+            MMG_HIP(ctx, hipStreamWaitEvent(ctx->stream, evs[c], 0));
+            rc = run_kinship_f4_tr(ctx, sc, X4 + r0 * ld4, g->Npad, nr / 256, C32);
+          }
+        }
+        hipError_t es = hipStreamSynchronize(ctx->stream);
+        if (es == hipSuccess) es = hipStreamSynchronize(ctx->stream2);
+        for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
+        (void)hipEventDestroy(ev0);
+        if (es != hipSuccess) return set_err(ctx, MMG_E_HIP, hipGetErrorString(es));
+        ctx->ev_set[EV_PACK] = false;                                     // its time is inside EV_KIN
+        if (rc == MMG_E_STATE) MMG_HIP(ctx, hipMemsetAsync(C32, 0, (size_t)g->Npad * g->Npad * sizeof(int), ctx->stream));
       } else {
         (void)hipGetLastError();
       }

@@ -398,25 +398,22 @@ int run_kinship_i8_tr(mmg_ctx* ctx, const int8_t* Sp, const int8_t* Sq, int64_t 
   return MMG_OK;
 }
 
-// C32 (upper tiles) += X'X over rows [0, nk4 * 256) of the FP4 image X4 (row stride Npad / 2); returns MMG_E_STATE when
-// the contraction range of a job could exceed the exact range of the fp32 accumulators (caller takes the int8 kernel)
-int run_kinship_f4_tr(mmg_ctx* ctx, const uint8_t* X4, int32_t Npad, int64_t nk4, int* C32) {
+// C32 (upper tiles) += X'X over rows [0, nk4 * 256) of the FP4 image X4 (row stride Npad / 2), enqueued on ctx->stream
+// WITHOUT synchronising (the caller overlaps the image pass of the next SNP chunk on a second stream); the job list lives
+// in `sc` until the caller's scope ends.  MMG_E_STATE: the contraction range of a job could exceed the exact range of the
+// fp32 accumulators (caller takes the int8 kernel).
+int run_kinship_f4_tr(mmg_ctx* ctx, Scratch& sc, const uint8_t* X4, int32_t Npad, int64_t nk4, int* C32) {
   const int nT = Npad / TM;
   const int ksplit = choose_ksplit(nT * (nT + 1) / 2, (int)nk4, 4, 64);
   if ((nk4 + ksplit - 1) / ksplit * FmtF4::KROWS >= (int64_t(1) << 24)) return MMG_E_STATE;
   std::vector<KinJob> jobs = build_jobs(nT, (int)nk4, ksplit);
   KinJob* djobs = nullptr;
-  MMG_HIP(ctx, hipMalloc(&djobs, jobs.size() * sizeof(KinJob)));
-  MMG_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(KinJob), hipMemcpyHostToDevice, ctx->stream));
+  MMG_HIP(ctx, sc.alloc(&djobs, jobs.size() * sizeof(KinJob)));
+  MMG_HIP(ctx, hipMemcpy(djobs, jobs.data(), jobs.size() * sizeof(KinJob), hipMemcpyHostToDevice));   // `jobs` dies with this call
   MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_f4_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  {
-    EvScope ev(ctx, EV_KIN);
-    hipLaunchKernelGGL(kinship_f4_tr_kernel, dim3((unsigned)jobs.size()), dim3(W4_THREADS), LDS_BYTES, ctx->stream,
-                       (const int8_t*)X4, (int64_t)(Npad / 2), Npad, djobs, C32);
-  }
+  hipLaunchKernelGGL(kinship_f4_tr_kernel, dim3((unsigned)jobs.size()), dim3(W4_THREADS), LDS_BYTES, ctx->stream,
+                     (const int8_t*)X4, (int64_t)(Npad / 2), Npad, djobs, C32);
   MMG_HIP(ctx, hipGetLastError());
-  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  MMG_HIP(ctx, hipFree(djobs));
   return MMG_OK;
 }
 

@@ -303,10 +303,11 @@ __global__ __launch_bounds__(256) void pack_fp4_kernel(const int8_t* __restrict_
   *(uint4*)(X4 + r * (int64_t)(Npad >> 1) + c * 16) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-void launch_pack_fp4(mmg_ctx* ctx, const int8_t* S, int64_t rows, int32_t Npad, uint8_t* X4) {
+void launch_pack_fp4_on(mmg_ctx* ctx, hipStream_t stream, const int8_t* S, int64_t rows, int32_t Npad, uint8_t* X4) {
+  (void)ctx;
   const int64_t total = rows * (Npad >> 5);
   if (total <= 0) return;
-  hipLaunchKernelGGL(pack_fp4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, S, rows, Npad, X4);
+  hipLaunchKernelGGL(pack_fp4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, S, rows, Npad, X4);
 }
 
 // SNP-major twin for the transposed-read kinship GEMM (gemm_i8_w4tr.h): nothing is transposed -- image d holds row m
