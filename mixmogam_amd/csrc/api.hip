@@ -508,25 +508,23 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
   // Round 3: the raw-genotype product reads the SNP-major store as it lies (gemm_i8_w4tr.h: transposed LDS reads) --
   // no individual-major image, no transposition pass.  MMG_KIN_KERNEL=w4 / w8: the transposed-image generations.
   static const bool tr_off = [] { const char* e = std::getenv("MMG_KIN_KERNEL"); return e && (std::string(e) == "w4" || std::string(e) == "w8"); }();
-  const bool direct = ibs && !tr_off;
+  // 0/1 operands -- the raw genotypes of a binary store, or an indicator [s >= thr] of any store -- run on FP4 (twice
+  // the MACs per MFMA, half the bytes per LDS fill); MMG_KIN_FP4=0 keeps int8
+  static const bool fp4_off = [] { const char* e = std::getenv("MMG_KIN_FP4"); return e && e[0] == '0'; }();
+  const bool binary = g->smax <= 1 && g->sneg == 0;
+  const bool fp4 = !fp4_off && !tr_off && ((ibs && binary) || thr > 0);
+  bool direct = (ibs && !tr_off) || fp4;
   int8_t* Xt = nullptr;
   int* C32 = nullptr;
   int64_t* C64 = nullptr;
-  if (!direct) {
-    hipError_t e = sc.alloc(&Xt, (size_t)g->Npad * Mk_max);
-    if (e != hipSuccess) return set_err(ctx, MMG_E_NOMEM, "hipMalloc transposed genotype image");
-  }
   MMG_HIP(ctx, sc.alloc(&C32, (size_t)g->Npad * g->Npad * sizeof(int)));
   MMG_HIP(ctx, sc.alloc(&C64, (size_t)g->N * g->N * sizeof(int64_t)));
   MMG_HIP(ctx, hipMemsetAsync(C32, 0, (size_t)g->Npad * g->Npad * sizeof(int), ctx->stream));
   int rc = MMG_OK;
   double kin_ms = 0.0, pack_ms = 0.0;
   if (direct) {
-    // binary stores: the product on FP4 operands (twice the MACs per MFMA, half the bytes per LDS fill); MMG_KIN_FP4=0
-    // keeps the int8 kernel
-    static const bool fp4_off = [] { const char* e = std::getenv("MMG_KIN_FP4"); return e && e[0] == '0'; }();
     rc = MMG_E_STATE;
-    if (!fp4_off && g->smax <= 1 && g->sneg == 0) {
+    if (fp4) {
       uint8_t* X4 = nullptr;
       if (sc.alloc(&X4, (size_t)g->Mpad * (g->Npad / 2)) == hipSuccess) {
         // The nibble image can be written in SNP chunks on the second stream while the GEMM of the previous chunk runs on
@@ -544,7 +542,8 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
         MMG_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ev0, 0));
         for (int64_t r0 = 0; r0 < g->Mpad; r0 += rows_ch) {
           const int64_t nr = std::min(rows_ch, g->Mpad - r0);
-          launch_pack_fp4_on(ctx, ctx->stream2, g->d + r0 * (int64_t)g->Npad, nr, g->Npad, X4 + r0 * ld4);
+          launch_pack_fp4_on(ctx, ctx->stream2, g->d + r0 * (int64_t)g->Npad, nr, g->Npad, X4 + r0 * ld4,
+                             thr > 0 ? thr : 1, binary);
           hipEvent_t ev = nullptr;
           MMG_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
           MMG_HIP(ctx, hipEventRecord(ev, ctx->stream2));
@@ -571,10 +570,17 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
         (void)hipGetLastError();
       }
     }
-    if (rc == MMG_E_STATE) {
+    if (rc == MMG_E_STATE && ibs && !tr_off) {
       ctx->ev_set[EV_PACK] = false;                     // no image pass in this call
       rc = run_kinship_i8_tr(ctx, g->d, g->d, g->Npad, g->Npad, g->Mpad / BK, C32);   // rows M..Mpad are zero
+    } else if (rc == MMG_E_STATE) {
+      direct = false;                                   // an indicator product beyond the FP4 range: transposed image
+      rc = MMG_OK;
     }
+  }
+  if (!direct) {
+    hipError_t e = sc.alloc(&Xt, (size_t)g->Npad * Mk_max);
+    if (e != hipSuccess) return set_err(ctx, MMG_E_NOMEM, "hipMalloc transposed genotype image");
   }
   for (int64_t mb = 0; !direct && mb < g->M && rc == MMG_OK; mb += CH) {
     const int64_t Mk = round_up(std::min(CH, g->M - mb), BK);

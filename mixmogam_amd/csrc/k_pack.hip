@@ -280,8 +280,11 @@ __global__ __launch_bounds__(256) void transpose_digits_kernel(const int8_t* __r
 // FP4 image of a BINARY store for the FP4 kinship GEMM (gemm_i8_w4tr.h FmtF4): X4[m][i / 2] holds the genotypes of
 // individuals i (low nibble: even i) as E2M1 nibbles, 1 -> 0x2 (= 1.0), 0 -> 0x0.  One thread per 16 output bytes
 // (32 genotypes).  HBM-bound: Npad in + Npad / 2 out per SNP.
+// thr = 1 on a binary store: the genotypes themselves; thr >= 1 in general: the indicator [s >= thr] (the two products of
+// the 'diploid_int' IBS kinship, kinship.py:33-41).
+template <bool BINARY>
 __global__ __launch_bounds__(256) void pack_fp4_kernel(const int8_t* __restrict__ S, int64_t rows, int32_t Npad,
-                                                       uint8_t* __restrict__ X4) {
+                                                       uint8_t* __restrict__ X4, int thr) {
   const int nchunk = Npad >> 5;                          // 16-byte output chunks per row
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= rows * nchunk) return;
@@ -289,25 +292,37 @@ __global__ __launch_bounds__(256) void pack_fp4_kernel(const int8_t* __restrict_
   const int c = (int)(gid % nchunk);
   const uint4* src = (const uint4*)(S + r * (int64_t)Npad + c * 32);
   const uint4 a = src[0], b = src[1];
-  const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  if (!BINARY) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      uint32_t x = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x |= ((int)(int8_t)((w[q] >> (8 * j)) & 0xff) >= thr ? 1u : 0u) << (8 * j);
+      w[q] = x;
+    }
+  }
   uint32_t o[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     // dwords 2q, 2q+1 = 8 genotype bytes (0/1) -> 8 nibbles (0/2): byte j of the pair lands in nibble j
     const uint32_t lo = w[2 * q] & 0x01010101u, hi = w[2 * q + 1] & 0x01010101u;
-    const uint32_t l4 = (lo | (lo >> 4)) & 0x00110011u, h4 = (hi | (hi >> 4)) & 0x00110011u;     // bytes 0,1 | 2,3 -> nibble pairs
+    const uint32_t l4 = (lo | (lo >> 4)) & 0x00110011u, h4 = (hi | (hi >> 4)) & 0x00110011u;
     const uint32_t l2 = (l4 | (l4 >> 8)) & 0x0000ffffu, h2 = (h4 | (h4 >> 8)) & 0x0000ffffu;
-    // l2 now holds nibbles n0 n1 (byte 0) n2 n3 (byte 1) as bits 0,4,8,12 -> value 1 each; scale to 0x2
     o[q] = ((l2 & 0x1111u) | ((h2 & 0x1111u) << 16)) << 1;
   }
   *(uint4*)(X4 + r * (int64_t)(Npad >> 1) + c * 16) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-void launch_pack_fp4_on(mmg_ctx* ctx, hipStream_t stream, const int8_t* S, int64_t rows, int32_t Npad, uint8_t* X4) {
+// binary: every stored value is 0 or 1 and thr == 1 (the bytes are the indicator already)
+void launch_pack_fp4_on(mmg_ctx* ctx, hipStream_t stream, const int8_t* S, int64_t rows, int32_t Npad, uint8_t* X4,
+                        int thr, bool binary) {
   (void)ctx;
   const int64_t total = rows * (Npad >> 5);
   if (total <= 0) return;
-  hipLaunchKernelGGL(pack_fp4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, S, rows, Npad, X4);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (binary && thr == 1) hipLaunchKernelGGL(pack_fp4_kernel<true>, grid, dim3(256), 0, stream, S, rows, Npad, X4, thr);
+  else hipLaunchKernelGGL(pack_fp4_kernel<false>, grid, dim3(256), 0, stream, S, rows, Npad, X4, thr);
 }
 
 // SNP-major twin for the transposed-read kinship GEMM (gemm_i8_w4tr.h): nothing is transposed -- image d holds row m

@@ -153,7 +153,8 @@ void launch_absmax_i8(mmg_ctx*, const int8_t* p, int64_t bytes, int* d_out);   /
 // ---- k_kinship.hip
 int kinship_pick_ksplit(int32_t Npad, int64_t Mk, bool f32);
 // C32 [Npad x Npad] int32 += Xt Xt^T (upper-triangular tiles only, mirrored by the caller).
-void launch_pack_fp4_on(mmg_ctx*, hipStream_t stream, const int8_t* S, int64_t rows, int32_t Npad, uint8_t* X4);   // binary store -> E2M1 nibble image
+void launch_pack_fp4_on(mmg_ctx*, hipStream_t stream, const int8_t* S, int64_t rows, int32_t Npad, uint8_t* X4, int thr,
+                        bool binary);   // [s >= thr] (the genotypes themselves for binary stores, thr 1) as E2M1 nibbles
 int run_kinship_f4_tr(mmg_ctx*, mmg::Scratch& sc, const uint8_t* X4, int32_t Npad, int64_t nk4, int* C32);   // enqueues, no sync
 int run_kinship_i8_tr(mmg_ctx*, const int8_t* Sp, const int8_t* Sq, int64_t ld, int32_t Npad, int64_t nk, int* C32);
 int run_kinship_i8(mmg_ctx*, const int8_t* Xt, int32_t Npad, int64_t Mk, int* C32);

@@ -271,3 +271,20 @@ def test_scan_model_falls_back_to_H_when_the_cholesky_route_fails(ctx, monkeypat
     monkeypatch.setattr(_lib.Reml, "scan_model", other)
     with pytest.raises(_lib.MixmogamHipError, match="hipMalloc"):
         lmm._emmax_f_test_(case["snps"], est["H_sqrt_inv"], emma_num=0, _delta=est["delta"])
+
+
+# ------------------------------------------------------------------ indicator kinship on FP4 operands
+@pytest.mark.parametrize("lo,hi,n,m", [(0, 3, 1000, 70000), (-1, 3, 333, 5000), (0, 2, 1100, 30000)])
+def test_indicator_counts_on_fp4_operands_bit_exact(ctx, lo, hi, n, m):
+    """mmg_kinship_indicator_counts (the two products of the 'diploid_int' IBS kinship, kinship.py:33-41) forms the
+    indicator [s >= thr] as E2M1 nibbles and multiplies on the FP4 MFMA: counts are integers below 2^24 per K chunk,
+    so the result is bit-identical to the integer product -- for 0/1/2, for negative codes (never >= thr) and for a
+    binary store at a threshold that selects nothing."""
+    rng = np.random.RandomState(n + m)
+    snps = rng.randint(lo, hi, size=(m, n)).astype(np.int8)
+    g = ctx.geno(snps)
+    for thr in (1, 2):
+        u = (snps >= thr).astype(np.float32)
+        want = (u.T @ u).astype(np.int64)                  # m < 2^24: exact in float32
+        assert np.array_equal(ctx.kinship_indicator_counts(g, thr), want), thr
+    g.close()
