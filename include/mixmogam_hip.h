@@ -164,9 +164,14 @@ int mmg_dgemm_f64(mmg_ctx* ctx, int ta, int tb, int32_t M, int32_t N, int32_t K,
  * The reference evaluates the EMMA likelihood from eigh(K) and eigh(S(K+I)S) (linear_models.py:589-615,794-810);
  * what it consumes per variance ratio delta are four sums -- with H = K + delta I and
  * P = H^-1 - H^-1 X (X'H^-1 X)^-1 X'H^-1:  s1 = y'Py, s2 = log|H| + log|X'H^-1 X| - log|X'X|, s3 = |Py|^2,
- * s4 = tr P -- and sum_sq_etas = |Sy|^2.  mmg_reml_sums evaluates them for nd values of delta from one Cholesky
- * factorisation each (potrf_64 + recursive triangular inverse, 2 N^3/3 flops per delta; the values are
- * independent, so ranks can share a grid).  mmg_reml_scan_model builds the EMMAX scan model at delta straight on
+ * s4 = tr P -- and sum_sq_etas = |Sy|^2.  mmg_reml_sums evaluates them for nd values of delta, by one of two routes
+ * (mmg_reml_sums_ex names it; mmg_reml_sums = AUTO: the band route from N = 256 up, MMG_REML_ROUTE=chol|band overrides):
+ *   CHOL  one Cholesky factorisation per delta (potrf_64 + recursive triangular inverse, 2 N^3/3 flops per delta;
+ *         the values are independent, so ranks can share a grid);
+ *   BAND  K is reduced ONCE to an orthogonally similar band matrix (bandwidth 64; 4 N^3/3 flops of level-3 BLAS, kept
+ *         in the workspace), after which every delta costs O(64^2 N): banded Cholesky, banded solves, the band of the
+ *         inverse for the trace -- all deltas of a call side by side on the device (csrc/reml_band.hip).
+ * mmg_reml_scan_model builds the EMMAX scan model at delta straight on
  * the device -- A = Mp Mp' = P, w = Mp r = Py (linear_models.py:1290-1303 in closed form) -- and returns
  * h0_rss = y'Py (= the Mahalanobis RSS of the null model, :906) and the GLS estimate beta [q] (:902).
  * K: host [N x N] symmetric (scaled as the model holds it); X: host [N x q] row-major (intercept first), q <= 16. */
@@ -174,6 +179,11 @@ int mmg_reml_create(mmg_ctx* ctx, int32_t N, int32_t q, const double* K, const d
 int mmg_reml_destroy(mmg_ctx* ctx, mmg_reml* r);
 int mmg_reml_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3,
                   double* s4, double* sum_sq_etas);
+#define MMG_REML_ROUTE_AUTO 0
+#define MMG_REML_ROUTE_CHOL 1
+#define MMG_REML_ROUTE_BAND 2
+int mmg_reml_sums_ex(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3,
+                     double* s4, double* sum_sq_etas, int32_t route);
 int mmg_reml_scan_model(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, double* h0_rss, double* beta,
                         double* mahalanobis_rss);
 

@@ -80,6 +80,7 @@ PROTOTYPES = {
     "mmg_reml_create": (C.c_int, [c_vp, C.c_int32, C.c_int32, c_vp, c_vp, c_vp, C.POINTER(c_vp)]),
     "mmg_reml_destroy": (C.c_int, [c_vp, c_vp]),
     "mmg_reml_sums": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64p]),
+    "mmg_reml_sums_ex": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64p, C.c_int32]),
     "mmg_reml_scan_model": (C.c_int, [c_vp, c_vp, C.c_double, C.c_int, c_f64p, c_vp, c_f64p]),
     "mmg_rot_create": (C.c_int, [c_vp, C.c_int32, c_vp, C.c_int64, C.POINTER(c_vp)]),
     "mmg_rot_destroy": (C.c_int, [c_vp, c_vp]),
@@ -414,12 +415,16 @@ class Reml(object):
         ctx._check(ctx.lib.mmg_reml_create(ctx.h, self.N, self.q, _ptr(K), _ptr(X), _ptr(y), C.byref(h)))
         self.h = h
 
-    def sums(self, deltas):
+    ROUTES = {"auto": 0, "chol": 1, "band": 2}
+
+    def sums(self, deltas, route="auto"):
+        """s1..s4 for every delta, sum_sq_etas.  route: 'chol' = one Cholesky factorisation per delta, 'band' = K reduced
+        once to a band matrix and every delta from that (csrc/reml_band.hip), 'auto' = band from N = 256 up."""
         d = _arr(np.asarray(deltas).reshape(-1), np.float64)
         out = [np.empty(len(d)) for _ in range(4)]
         sse = C.c_double(0.0)
-        self.ctx._check(self.ctx.lib.mmg_reml_sums(self.ctx.h, self.h, len(d), _ptr(d), *[_ptr(o) for o in out],
-                                                   C.byref(sse)))
+        self.ctx._check(self.ctx.lib.mmg_reml_sums_ex(self.ctx.h, self.h, len(d), _ptr(d), *[_ptr(o) for o in out],
+                                                      C.byref(sse), self.ROUTES[route]))
         return out[0], out[1], out[2], out[3], sse.value
 
     def scan_model(self, delta, ndigits=0):

@@ -540,6 +540,7 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
         MMG_HIP(ctx, hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
         MMG_HIP(ctx, hipEventRecord(ev0, ctx->stream));                  // the store's writers are on the first stream
         MMG_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ev0, 0));
+        if (nch == 1) MMG_HIP(ctx, hipEventRecord(ctx->ev[EV_PACK][0], ctx->stream2));   // the image pass on its own
         for (int64_t r0 = 0; r0 < g->Mpad; r0 += rows_ch) {
           const int64_t nr = std::min(rows_ch, g->Mpad - r0);
           launch_pack_fp4_on(ctx, ctx->stream2, g->d + r0 * (int64_t)g->Npad, nr, g->Npad, X4 + r0 * ld4,
@@ -549,6 +550,7 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
           MMG_HIP(ctx, hipEventRecord(ev, ctx->stream2));
           evs.push_back(ev);
         }
+        if (nch == 1) MMG_HIP(ctx, hipEventRecord(ctx->ev[EV_PACK][1], ctx->stream2));
         rc = MMG_OK;
         {
           EvScope ev(ctx, EV_KIN);                                        // inclusive: image chunks + GEMMs
@@ -564,7 +566,7 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
         for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
         (void)hipEventDestroy(ev0);
         if (es != hipSuccess) return set_err(ctx, MMG_E_HIP, hipGetErrorString(es));
-        ctx->ev_set[EV_PACK] = false;                                     // its time is inside EV_KIN
+        ctx->ev_set[EV_PACK] = (nch == 1);                                // its time is inside EV_KIN as well
         if (rc == MMG_E_STATE) MMG_HIP(ctx, hipMemsetAsync(C32, 0, (size_t)g->Npad * g->Npad * sizeof(int), ctx->stream));
       } else {
         (void)hipGetLastError();

@@ -1,0 +1,420 @@
+// reml_band.hip -- the REML likelihood sums of EVERY variance ratio from ONE orthogonal reduction of K.
+//
+// reml_chol.hip pays a Cholesky factorisation and a triangular inverse (2/3 N^3 flop) per delta: 57 of them for the
+// 51-point grid + secant steps of get_estimates (linear_models.py:796-847) -- 91 s at N = 50,000, the largest stage of
+// config 5 on one GPU.  The sums depend on K only through functions of K + delta I, and those commute with any
+// orthogonal similarity: with K = Q B Q', B symmetric of bandwidth 64,
+//     log|K + dI| = log|B + dI|,  tr (K + dI)^-1 = tr (B + dI)^-1,  z'(K + dI)^-k z = (Q'z)'(B + dI)^-k (Q'z),
+// so K is reduced ONCE (blocked Householder band reduction, 4/3 N^3 flop of level-3 BLAS: one QR of the block column
+// below the band + one symmetric rank-2b update of the trailing matrix per 64 columns) and every delta afterwards costs
+// O(N b^2): a banded Cholesky factorisation, banded triangular solves for the q+1 rotated columns of [X y], and the
+// band of the inverse (Takahashi's recurrence) for the trace.  All deltas of a call run side by side, one wavefront
+// each; nothing per delta touches an N x N matrix.  The scan model at the chosen delta still comes from reml_chol.hip
+// (it needs P itself).
+//
+// Per-delta kernels (one 64-lane wave per delta; lane t owns the columns / unknowns whose index is t mod 64, so the
+// 64-column window that a step touches is spread over the lanes and never moves between registers):
+//   band_factor_kernel  right-looking Cholesky of B + dI; the pivot column goes through LDS to the other lanes
+//   band_solve_kernel   forward and backward substitution per column of Q'[X y], L streamed in 64-column chunks via LDS
+//   band_trace_kernel   Z = (B + dI)^-1 inside the band, from the last column up; the 64 x 64 window of Z lives in LDS
+// Roofline: the reduction is fp64 level-3 BLAS (rocBLAS); the per-delta kernels are latency chains of N steps
+// (N = 50,000: tens of ms for the whole grid) -- off the SNPs/s metric either way.
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "reml_common.h"
+
+namespace mmg {
+
+constexpr int BAND_B = 64;
+constexpr int BAND_LD = 72;        // doubles per stored band column: d = 0..64 the band, 65 = 1 / l_jj (factor only)
+
+// V [n x nr] (ld n) <- the Householder vectors below the diagonal of the factored panel P (ld lda), unit diagonal,
+// zeros above; the panel keeps only R
+__global__ void band_build_v_kernel(double* __restrict__ P, int64_t lda, int n, int nr, double* __restrict__ V) {
+  const int col = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = 0.0;
+  if (i == col) v = 1.0;
+  else if (i > col) { v = P[i + (int64_t)col * lda]; P[i + (int64_t)col * lda] = 0.0; }
+  V[i + (int64_t)col * n] = v;
+}
+
+// Bc[j][d] = A[j + d][j] (column-major A, lower triangle), zero beyond the matrix
+__global__ __launch_bounds__(64) void band_extract_kernel(const double* __restrict__ A, int64_t N, double* __restrict__ Bc) {
+  const int64_t j = blockIdx.x;
+  for (int d = threadIdx.x; d < BAND_LD; d += 64)
+    Bc[j * BAND_LD + d] = (d <= BAND_B && j + d < N) ? A[j * N + j + d] : 0.0;
+}
+
+// ---- per-delta kernels -------------------------------------------------------------------------------------------
+// L (same layout as Bc) <- Cholesky factor of B + delta I; logdet = sum log(pivot); fail = 1 + first non-positive pivot
+__global__ __launch_bounds__(64) void band_factor_kernel(const double* __restrict__ Bc, int N, const double* __restrict__ deltas,
+                                                         double* __restrict__ Lall, double* __restrict__ logdet,
+                                                         int* __restrict__ fail) {
+  const int t = threadIdx.x;
+  const double delta = deltas[blockIdx.x];
+  double* Lc = Lall + (size_t)blockIdx.x * N * BAND_LD;
+  __shared__ __attribute__((aligned(16))) double lbuf[2][2 * BAND_B + 8];   // [0..64] the raw pivot column, zeros above
+  // pre[p]: the column lane p takes over when its current one has been the pivot (index + 64), staged by all lanes with
+  // coalesced loads 64 steps ahead -- a lane fetching its own 65 values would issue 65 loads for the whole wave
+  constexpr int PS = BAND_B + 2;
+  __shared__ __attribute__((aligned(16))) double pre[64 * PS];
+  for (int i = t; i < 2 * (2 * BAND_B + 8); i += 64) (&lbuf[0][0])[i] = 0.0;
+  auto band_at = [&](int i, int d) { return i < N ? Bc[(size_t)i * BAND_LD + d] + (d == 0 ? delta : 0.0) : 0.0; };
+  double col[BAND_B + 1];
+#pragma unroll
+  for (int d = 0; d <= BAND_B; ++d) col[d] = band_at(t, d);
+  for (int i = 0; i < 64; ++i) {
+    pre[i * PS + t] = band_at(BAND_B + i, t);
+    if (t == 0) pre[i * PS + BAND_B] = band_at(BAND_B + i, BAND_B);
+  }
+  double ld = 0.0;
+  int bad = 0;
+  __syncthreads();
+  for (int j = 0; j < N; ++j) {
+    const int p = j & 63, buf = j & 1;
+    if (t == p) {
+#pragma unroll
+      for (int d = 0; d <= BAND_B; ++d) lbuf[buf][d] = col[d];
+    }
+    // column j + 128 for the slot this step frees (in flight while the step computes)
+    const double g0 = band_at(j + 2 * BAND_B, t);
+    const double g1 = t == 0 ? band_at(j + 2 * BAND_B, BAND_B) : 0.0;
+    __syncthreads();
+    const double piv = lbuf[buf][0];
+    if (!(piv > 0.0)) { bad = j + 1; break; }              // uniform: every lane reads the same pivot
+    const double rinv = 1.0 / sqrt(piv);
+    ld += log(piv);
+    const int c = (t - j) & 63;
+    // column j of L, one element per lane (lane 0 also the 65th), and 1 / l_jj beside it
+    Lc[(size_t)j * BAND_LD + t] = lbuf[buf][t] * rinv;
+    if (t == 0) {
+      Lc[(size_t)j * BAND_LD + BAND_B] = lbuf[buf][BAND_B] * rinv;
+      Lc[(size_t)j * BAND_LD + BAND_B + 1] = rinv;
+    }
+    if (c == 0) {
+      // the pivot's lane moves on to column j + 64: only its diagonal has met column j
+      const double x = lbuf[buf][BAND_B] * rinv;
+      const double* src = pre + p * PS;
+#pragma unroll
+      for (int d = 0; d <= BAND_B; ++d) col[d] = src[d];
+      col[0] -= x * x;
+    } else {
+      // column i = j + c:  A[i + d][i] -= l[c + d] l[c]   (lbuf is zero beyond 64: no bound to test)
+      const double lc = lbuf[buf][c] * (rinv * rinv);
+      const double* lb = &lbuf[buf][c];
+#pragma unroll
+      for (int d = 0; d <= BAND_B; ++d) col[d] = fma(-lb[d], lc, col[d]);
+    }
+    pre[p * PS + t] = g0;                                   // after the pivot lane has read the slot (same wave: in order)
+    if (t == 0) pre[p * PS + BAND_B] = g1;
+  }
+  if (t == 0) { logdet[blockIdx.x] = ld; fail[blockIdx.x] = bad; }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// F[r] = L^-1 z_r, G[r] = L^-T F[r] for the q1 columns z_r of Zr ([q1][N])
+__global__ __launch_bounds__(64) void band_solve_kernel(const double* __restrict__ Lall, int N, const double* __restrict__ Zr,
+                                                        int q1, double* __restrict__ Fall, double* __restrict__ Gall) {
+  const int t = threadIdx.x;
+  const double* Lc = Lall + (size_t)blockIdx.x * N * BAND_LD;
+  __shared__ double ch[64 * BAND_LD];
+  const int nchunk = (N + 63) / 64;
+  for (int r = 0; r < q1; ++r) {
+    const double* z0 = Zr + (size_t)r * N;
+    double* f = Fall + ((size_t)blockIdx.x * q1 + r) * N;
+    double* g = Gall + ((size_t)blockIdx.x * q1 + r) * N;
+    // ---- forward: lane t holds the running right-hand side of unknown i = t (mod 64) of the current window
+    double z = t < N ? z0[t] : 0.0;
+    for (int cb = 0; cb < nchunk; ++cb) {
+      const int j0 = cb * 64, nj = min(64, N - j0);
+      __syncthreads();
+      for (int i = t; i < nj * BAND_LD; i += 64) ch[i] = Lc[(size_t)j0 * BAND_LD + i];
+      __syncthreads();
+      const double znext = (j0 + 64 + t < N) ? z0[j0 + 64 + t] : 0.0;
+      double wkeep = 0.0;
+      for (int jj = 0; jj < nj; ++jj) {
+        const int c = (t - jj) & 63;
+        const double* lj = ch + jj * BAND_LD;
+        const double w = __shfl(z, jj) * lj[BAND_B + 1];
+        if (c == 0) { wkeep = w; z = fma(-lj[BAND_B], w, znext); }
+        else z = fma(-lj[c], w, z);
+      }
+      if (t < nj) f[j0 + t] = wkeep;
+    }
+    // ---- backward: lane t holds x_i of the window above the current column
+    double x = 0.0;
+    for (int cb = nchunk - 1; cb >= 0; --cb) {
+      const int j0 = cb * 64, nj = min(64, N - j0);
+      __syncthreads();
+      for (int i = t; i < nj * BAND_LD; i += 64) ch[i] = Lc[(size_t)j0 * BAND_LD + i];
+      __syncthreads();
+      const double wv = t < nj ? f[j0 + t] : 0.0;
+      if (t >= nj) x = 0.0;                                   // only the last chunk can be short: nothing above it
+      for (int jj = nj - 1; jj >= 0; --jj) {
+        const int c = (t - jj) & 63;
+        const double* lj = ch + jj * BAND_LD;
+        const double s = wave_sum(lj[c == 0 ? BAND_B : c] * x);
+        const double xj = (__shfl(wv, jj) - s) * lj[BAND_B + 1];
+        if (c == 0) x = xj;
+      }
+      if (t < nj) g[j0 + t] = x;
+    }
+  }
+}
+
+// trace of (L L')^-1 from the band of the inverse:  Z_ij = -(1/l_jj) sum_{k>j} Z_ik L_kj (i > j),
+// Z_jj = 1/l_jj^2 - (1/l_jj) sum_{k>j} L_kj Z_kj;  row / column i of the window lives at slot i mod 64
+__global__ __launch_bounds__(64) void band_trace_kernel(const double* __restrict__ Lall, int N, double* __restrict__ trace) {
+  const int t = threadIdx.x;
+  const double* Lc = Lall + (size_t)blockIdx.x * N * BAND_LD;
+  constexpr int ZS = 65;                                      // row stride of the window: column writes hit 64 banks
+  __shared__ double Zw[64 * ZS];
+  __shared__ double ch[64 * BAND_LD];
+  __shared__ double lrow[64];
+  for (int i = t; i < 64 * ZS; i += 64) Zw[i] = 0.0;
+  double tr = 0.0;
+  const int nchunk = (N + 63) / 64;
+  for (int cb = nchunk - 1; cb >= 0; --cb) {
+    const int j0 = cb * 64, nj = min(64, N - j0);
+    __syncthreads();
+    for (int i = t; i < nj * BAND_LD; i += 64) ch[i] = Lc[(size_t)j0 * BAND_LD + i];
+    __syncthreads();
+    for (int jj = nj - 1; jj >= 0; --jj) {
+      const int c = (t - jj) & 63;
+      const double* lj = ch + jj * BAND_LD;
+      const double rinv = lj[BAND_B + 1];
+      const double lv = lj[c == 0 ? BAND_B : c];              // L[i_t][j], i_t = j + (c ? c : 64)
+      lrow[t] = lv;
+      __syncthreads();
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+      for (int u = 0; u < 64; u += 2) {
+        s0 = fma(lrow[u], Zw[u * ZS + t], s0);
+        s1 = fma(lrow[u + 1], Zw[(u + 1) * ZS + t], s1);
+      }
+      const double zt = -(s0 + s1) * rinv;                    // Z[i_t][j]
+      const double dsum = wave_sum(lv * zt);
+      const double zjj = rinv * rinv - rinv * dsum;
+      tr += zjj;
+      __syncthreads();
+      const double put = (c == 0) ? zjj : zt;                 // slot jj changes owner: index j + 64 leaves, j enters
+      Zw[jj * ZS + t] = put;
+      Zw[t * ZS + jj] = put;
+      __syncthreads();
+    }
+  }
+  if (t == 0) trace[blockIdx.x] = tr;
+}
+
+// out[blk][a][b] = <F_a, F_b>, out2 likewise for G: one block per (delta, a, b), fixed summation order
+__global__ __launch_bounds__(256) void band_gram_kernel(const double* __restrict__ Fall, const double* __restrict__ Gall, int N,
+                                                        int q1, double* __restrict__ ff, double* __restrict__ gg) {
+  const int blk = blockIdx.x, a = blockIdx.y / q1, b = blockIdx.y % q1;
+  if (b > a) return;
+  const double* fa = Fall + ((size_t)blk * q1 + a) * N;
+  const double* fb = Fall + ((size_t)blk * q1 + b) * N;
+  const double* ga = Gall + ((size_t)blk * q1 + a) * N;
+  const double* gb = Gall + ((size_t)blk * q1 + b) * N;
+  double sf = 0.0, sg = 0.0;
+  for (int i = threadIdx.x; i < N; i += 256) { sf = fma(fa[i], fb[i], sf); sg = fma(ga[i], gb[i], sg); }
+  sf = wave_sum(sf); sg = wave_sum(sg);
+  __shared__ double w[8];
+  if ((threadIdx.x & 63) == 0) { w[threadIdx.x >> 6] = sf; w[4 + (threadIdx.x >> 6)] = sg; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double vf = (w[0] + w[1]) + (w[2] + w[3]), vg = (w[4] + w[5]) + (w[6] + w[7]);
+    ff[((size_t)blk * q1 + a) * q1 + b] = ff[((size_t)blk * q1 + b) * q1 + a] = vf;
+    gg[((size_t)blk * q1 + a) * q1 + b] = gg[((size_t)blk * q1 + b) * q1 + a] = vg;
+  }
+}
+
+// ---- the reduction ---------------------------------------------------------------------------------------------------
+static int band_reduce(mmg_ctx* ctx, mmg_reml* r) {
+  rocblas_handle h;
+  int rc = reml_handle(ctx, &h);
+  if (rc) return rc;
+  const int64_t N = r->N;
+  const int q1 = r->q + 1, b = BAND_B;
+  hipStream_t st = ctx->stream;
+  const auto t_start = std::chrono::steady_clock::now();
+  if (!r->dBand) RC_HIP(ctx, hipMalloc(&r->dBand, (size_t)N * BAND_LD * sizeof(double)));
+  if (!r->dZr) RC_HIP(ctx, hipMalloc(&r->dZr, (size_t)N * q1 * sizeof(double)));
+  double* A = r->dL;                                          // work copy of K, reduced in place (lower triangle)
+  RC_HIP(ctx, hipMemcpyAsync(A, r->dK, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, st));
+  RC_HIP(ctx, hipMemcpyAsync(r->dZr, r->dB, (size_t)N * q1 * sizeof(double), hipMemcpyDeviceToDevice, st));
+  Scratch sc;
+  double *V = nullptr, *W = nullptr, *T = nullptr, *tau = nullptr, *M1 = nullptr, *M2 = nullptr;
+  const int64_t nmax = std::max<int64_t>(N - b, 1);
+  RC_HIP(ctx, sc.alloc(&V, (size_t)nmax * b * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&W, (size_t)nmax * b * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&T, (size_t)b * b * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&tau, (size_t)b * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&M1, (size_t)b * b * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&M2, (size_t)b * q1 * sizeof(double)));
+  const double one = 1.0, zero = 0.0, mone = -1.0, mhalf = -0.5;
+  // MMG_BAND_UPDATE=gemm: products with the full matrix (both triangles kept current) instead of symm / syr2k
+  static const bool full = [] { const char* e = std::getenv("MMG_BAND_UPDATE"); return e && std::string(e) == "gemm"; }();
+  const bool verbose = std::getenv("MMG_REML_VERBOSE") != nullptr;
+  double tsec[4] = {0, 0, 0, 0};                              // panel QR + T, A22 V, small products, rank-2b update
+  auto lap = [&](int which, std::chrono::steady_clock::time_point& tp) {
+    if (!verbose) return;
+    (void)hipStreamSynchronize(st);
+    const auto now = std::chrono::steady_clock::now();
+    tsec[which] += std::chrono::duration<double>(now - tp).count();
+    tp = now;
+  };
+  for (int64_t k0 = 0; N - k0 - b >= 2; k0 += b) {
+    auto tp = std::chrono::steady_clock::now();
+    if (verbose) { (void)hipStreamSynchronize(st); tp = std::chrono::steady_clock::now(); }
+    const int64_t n = N - k0 - b;                             // rows below the band in this block column
+    const int nr = (int)std::min<int64_t>(n, b);              // reflectors
+    double* P = A + (k0 + b) + k0 * N;                        // [n x b] panel
+    double* A22 = A + (k0 + b) + (k0 + b) * N;                // [n x n] trailing matrix
+    RC_RB(ctx, rocsolver_dgeqrf(h, (rocblas_int)n, b, P, (rocblas_int)N, tau));
+    hipLaunchKernelGGL(band_build_v_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nr), dim3(256), 0, st, P, N, (int)n, nr, V);
+    RC_RB(ctx, rocsolver_dlarft(h, rocblas_forward_direction, rocblas_column_wise, (rocblas_int)n, nr, V, (rocblas_int)n, tau, T, b));
+    lap(0, tp);
+    // X = A22 V T;  Y = X - 1/2 V (T'V'X);  A22 <- A22 - Y V' - V Y'   ( = Q' A22 Q,  Q = I - V T V' )
+    if (full) {
+      RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_none, n, nr, n, &one, A22, N, V, n, &zero, W, n));
+    } else {
+      RC_RB(ctx, rocblas_dsymm_64(h, rocblas_side_left, rocblas_fill_lower, n, nr, &one, A22, N, V, n, &zero, W, n));
+    }
+    lap(1, tp);
+    RC_RB(ctx, rocblas_dtrmm_64(h, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, n, nr,
+                                &one, T, b, W, n, W, n));
+    RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_transpose, rocblas_operation_none, nr, nr, n, &one, V, n, W, n, &zero, M1, b));
+    RC_RB(ctx, rocblas_dtrmm_64(h, rocblas_side_left, rocblas_fill_upper, rocblas_operation_transpose, rocblas_diagonal_non_unit, nr,
+                                nr, &one, T, b, M1, b, M1, b));
+    RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_none, n, nr, nr, &mhalf, V, n, M1, b, &one, W, n));
+    lap(2, tp);
+    if (full) {
+      RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_transpose, n, n, nr, &mone, W, n, V, n, &one, A22, N));
+      RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_transpose, n, n, nr, &mone, V, n, W, n, &one, A22, N));
+    } else {
+      RC_RB(ctx, rocblas_dsyr2k_64(h, rocblas_fill_lower, rocblas_operation_none, n, nr, &mone, W, n, V, n, &one, A22, N));
+    }
+    lap(3, tp);
+    // the rotated columns of [X y]:  Z[k0+b:] <- Q' Z[k0+b:] = Z - V T' (V'Z)
+    double* Zs = r->dZr + (k0 + b);
+    RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_transpose, rocblas_operation_none, nr, q1, n, &one, V, n, Zs, N, &zero, M2, b));
+    RC_RB(ctx, rocblas_dtrmm_64(h, rocblas_side_left, rocblas_fill_upper, rocblas_operation_transpose, rocblas_diagonal_non_unit, nr,
+                                q1, &one, T, b, M2, b, M2, b));
+    RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_none, n, q1, nr, &mone, V, n, M2, b, &one, Zs, N));
+    lap(2, tp);
+  }
+  hipLaunchKernelGGL(band_extract_kernel, dim3((unsigned)N), dim3(64), 0, st, A, N, r->dBand);
+  RC_HIP(ctx, hipGetLastError());
+  RC_HIP(ctx, hipStreamSynchronize(st));
+  r->band_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  if (verbose)
+    fprintf(stderr, "[reml] N=%lld: band reduction (b = %d, %s) %.3f s: panel QR + T %.3f, A22 V %.3f, small products %.3f, rank-2b update %.3f\n",
+            (long long)N, b, full ? "gemm" : "symm / syr2k", r->band_s, tsec[0], tsec[1], tsec[2], tsec[3]);
+  r->band_ready = true;
+  return MMG_OK;
+}
+
+void reml_band_free(mmg_reml* r) {
+  hipFree(r->dBand); hipFree(r->dZr);
+  r->dBand = r->dZr = nullptr;
+  r->band_ready = false;
+}
+
+int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3, double* s4) {
+  if (!r->band_ready) {
+    int rc = band_reduce(ctx, r);
+    if (rc) return rc;
+  }
+  const int N = r->N, q = r->q, q1 = q + 1;
+  hipStream_t st = ctx->stream;
+  const bool verbose = std::getenv("MMG_REML_VERBOSE") != nullptr;
+  // deltas in groups: L of a group is group x N x 72 doubles
+  const int64_t per = (int64_t)N * BAND_LD * sizeof(double);
+  const int group = (int)std::max<int64_t>(1, std::min<int64_t>(128, (int64_t(8) << 30) / per));
+  for (int g0 = 0; g0 < nd; g0 += group) {
+    const int ng = std::min(group, nd - g0);
+    Scratch sc;
+    double *dd = nullptr, *L = nullptr, *F = nullptr, *G = nullptr, *sca = nullptr;
+    int* dfail = nullptr;
+    const size_t nsc = (size_t)ng * (2 + 2 * q1 * q1);
+    RC_HIP(ctx, sc.alloc(&dd, ng * sizeof(double)));
+    RC_HIP(ctx, sc.alloc(&L, (size_t)ng * per));
+    RC_HIP(ctx, sc.alloc(&F, (size_t)ng * q1 * N * sizeof(double)));
+    RC_HIP(ctx, sc.alloc(&G, (size_t)ng * q1 * N * sizeof(double)));
+    RC_HIP(ctx, sc.alloc(&sca, nsc * sizeof(double)));
+    RC_HIP(ctx, sc.alloc(&dfail, ng * sizeof(int)));
+    double* dlog = sca;
+    double* dtr = sca + ng;
+    double* dff = sca + 2 * ng;
+    double* dgg = dff + (size_t)ng * q1 * q1;
+    RC_HIP(ctx, hipMemcpyAsync(dd, deltas + g0, ng * sizeof(double), hipMemcpyHostToDevice, st));
+    RC_HIP(ctx, hipMemsetAsync(sca, 0, nsc * sizeof(double), st));
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(band_factor_kernel, dim3(ng), dim3(64), 0, st, r->dBand, N, dd, L, dlog, dfail);
+    std::vector<int> bad(ng);
+    RC_HIP(ctx, hipMemcpyAsync(bad.data(), dfail, ng * sizeof(int), hipMemcpyDeviceToHost, st));
+    RC_HIP(ctx, hipStreamSynchronize(st));
+    for (int k = 0; k < ng; ++k)
+      if (bad[k])
+        return set_err(ctx, MMG_E_LIB, "K + delta I is not positive definite (banded Cholesky, pivot " + std::to_string(bad[k]) + ")");
+    const auto t1 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(band_solve_kernel, dim3(ng), dim3(64), 0, st, L, N, r->dZr, q1, F, G);
+    hipLaunchKernelGGL(band_trace_kernel, dim3(ng), dim3(64), 0, st, L, N, dtr);
+    hipLaunchKernelGGL(band_gram_kernel, dim3(ng, q1 * q1), dim3(256), 0, st, F, G, N, q1, dff, dgg);
+    RC_HIP(ctx, hipGetLastError());
+    std::vector<double> hs(nsc);
+    RC_HIP(ctx, hipMemcpyAsync(hs.data(), sca, nsc * sizeof(double), hipMemcpyDeviceToHost, st));
+    RC_HIP(ctx, hipStreamSynchronize(st));
+    if (verbose) {
+      const auto t2 = std::chrono::steady_clock::now();
+      fprintf(stderr, "[reml] N=%d: %d deltas through the band: factor %.1f ms, solves + trace %.1f ms\n", N, ng,
+              std::chrono::duration<double>(t1 - t0).count() * 1e3, std::chrono::duration<double>(t2 - t1).count() * 1e3);
+    }
+    for (int k = 0; k < ng; ++k) {
+      const double* ff = hs.data() + 2 * ng + (size_t)k * q1 * q1;
+      const double* gg = hs.data() + 2 * ng + (size_t)ng * q1 * q1 + (size_t)k * q1 * q1;
+      std::vector<double> a((size_t)q * q), bvec((size_t)q), B2((size_t)q * q);
+      for (int i = 0; i < q; ++i) {
+        for (int j = 0; j < q; ++j) { a[i * q + j] = ff[i * q1 + j]; B2[i * q + j] = gg[i * q1 + j]; }
+        bvec[i] = ff[i * q1 + q];
+      }
+      const double c = ff[q * q1 + q];
+      std::vector<double> beta = bvec;
+      double logdet_a = 0.0;
+      if (!chol_solve_small(q, a, beta, 1, &logdet_a)) return set_err(ctx, MMG_E_LIB, "X'H^-1 X is not positive definite");
+      std::vector<double> aB2 = B2;
+      chol_solve_small(q, a, aB2, q, nullptr);
+      double tr_aB2 = 0.0, bb = 0.0, v3 = gg[q * q1 + q];
+      for (int i = 0; i < q; ++i) {
+        tr_aB2 += aB2[i * q + i];
+        bb += bvec[i] * beta[i];
+        v3 -= 2.0 * beta[i] * gg[i * q1 + q];
+        for (int j = 0; j < q; ++j) v3 += beta[i] * beta[j] * gg[i * q1 + j];
+      }
+      s1[g0 + k] = c - bb;
+      s2[g0 + k] = hs[k] + logdet_a - r->logdet_xtx;
+      s3[g0 + k] = v3;
+      s4[g0 + k] = hs[ng + k] - tr_aB2;
+    }
+  }
+  return MMG_OK;
+}
+
+}  // namespace mmg

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "mmg_internal.h"
+#include "reml_common.h"
 
 namespace mmg {
 
@@ -80,75 +81,6 @@ __global__ void note_info_kernel(const rocblas_int* __restrict__ info, long long
 
 }  // namespace mmg
 using namespace mmg;
-
-struct mmg_reml {
-  int32_t N = 0, q = 0;
-  double* dK = nullptr;     // [N x N] symmetric
-  double* dL = nullptr;     // [N x N] work: H -> L -> L^-1
-  double* dB = nullptr;     // [N x (q+1)] = [X y] (column-major: column c contiguous)
-  double* dZ = nullptr;     // [N x (q+1)]
-  double* dG = nullptr;     // [N x (q+1)]
-  double* dsc = nullptr;    // scalars / per-column partials [N + 8]
-  std::vector<double> X, y; // host copies (X row-major N x q)
-  double logdet_xtx = 0.0, sum_sq_etas = 0.0;
-  void* rocblas = nullptr;
-};
-
-#define RC_HIP(ctx, call)                                                                     \
-  do {                                                                                        \
-    hipError_t e__ = (call);                                                                  \
-    if (e__ != hipSuccess) return set_err(ctx, MMG_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
-  } while (0)
-#define RC_RB(ctx, call)                                                                      \
-  do {                                                                                        \
-    rocblas_status s__ = (call);                                                              \
-    if (s__ != rocblas_status_success)                                                        \
-      return set_err(ctx, MMG_E_LIB, std::string(#call) + ": rocblas status " + std::to_string((int)s__)); \
-  } while (0)
-
-// small dense helpers on the host (q x q, q <= 16)
-static bool chol_solve_small(int q, std::vector<double> a, std::vector<double>& b, int nrhs, double* logdet) {
-  // a: q x q SPD row-major (destroyed); b: q x nrhs row-major, overwritten with a^-1 b
-  double ld = 0.0;
-  for (int j = 0; j < q; ++j) {
-    double d = a[j * q + j];
-    for (int k = 0; k < j; ++k) d -= a[j * q + k] * a[j * q + k];
-    if (!(d > 0.0)) return false;
-    d = std::sqrt(d);
-    a[j * q + j] = d;
-    ld += 2.0 * std::log(d);
-    for (int i = j + 1; i < q; ++i) {
-      double v = a[i * q + j];
-      for (int k = 0; k < j; ++k) v -= a[i * q + k] * a[j * q + k];
-      a[i * q + j] = v / d;
-    }
-  }
-  for (int r = 0; r < nrhs; ++r) {
-    for (int i = 0; i < q; ++i) {
-      double v = b[i * nrhs + r];
-      for (int k = 0; k < i; ++k) v -= a[i * q + k] * b[k * nrhs + r];
-      b[i * nrhs + r] = v / a[i * q + i];
-    }
-    for (int i = q - 1; i >= 0; --i) {
-      double v = b[i * nrhs + r];
-      for (int k = i + 1; k < q; ++k) v -= a[k * q + i] * b[k * nrhs + r];
-      b[i * nrhs + r] = v / a[i * q + i];
-    }
-  }
-  if (logdet) *logdet = ld;
-  return true;
-}
-
-static int reml_handle(mmg_ctx* ctx, rocblas_handle* h) {
-  if (!ctx->rocblas) {
-    rocblas_handle hh;
-    RC_RB(ctx, rocblas_create_handle(&hh));
-    RC_RB(ctx, rocblas_set_stream(hh, ctx->stream));
-    ctx->rocblas = hh;
-  }
-  *h = (rocblas_handle)ctx->rocblas;
-  return MMG_OK;
-}
 
 // in-place inverse of the lower-triangular n x n block at L (leading dimension ld, column-major), recursive:
 // [[L11, 0], [L21, L22]]^-1 = [[X11, 0], [-X22 L21 X11, X22]] -- two trsm per level touch only the non-zero half.
@@ -388,16 +320,25 @@ int mmg_reml_destroy(mmg_ctx* ctx, mmg_reml* r) {
   if (!r) return MMG_OK;
   if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
   hipFree(r->dK); hipFree(r->dL); hipFree(r->dB); hipFree(r->dZ); hipFree(r->dG); hipFree(r->dsc);
+  reml_band_free(r);
   delete r;
   return MMG_OK;
 }
 
-int mmg_reml_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3,
-                  double* s4, double* sum_sq_etas) {
+int mmg_reml_sums_ex(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3,
+                     double* s4, double* sum_sq_etas, int32_t route) {
   if (!ctx) return MMG_E_ARG;
   RC_HIP(ctx, hipSetDevice(ctx->device));
-  if (!(r && deltas && s1 && s2 && s3 && s4 && nd >= 0)) return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_sums");
+  if (!(r && deltas && s1 && s2 && s3 && s4 && nd >= 0 && route >= 0 && route <= 2))
+    return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_sums");
   if (sum_sq_etas) *sum_sq_etas = r->sum_sq_etas;
+  if (route == MMG_REML_ROUTE_AUTO) {
+    // one band reduction costs about two factorisations + inverses and serves every later delta of this workspace
+    const char* e = std::getenv("MMG_REML_ROUTE");
+    const std::string es = e ? e : "";
+    route = es == "chol" ? MMG_REML_ROUTE_CHOL : (es == "band" || r->band_ready || r->N >= 256) ? MMG_REML_ROUTE_BAND : MMG_REML_ROUTE_CHOL;
+  }
+  if (route == MMG_REML_ROUTE_BAND) return reml_band_sums(ctx, r, nd, deltas, s1, s2, s3, s4);
   for (int k = 0; k < nd; ++k) {
     RemlPoint pt;
     int rc = reml_point(ctx, r, deltas[k], true, false, pt);
@@ -405,6 +346,11 @@ int mmg_reml_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, d
     s1[k] = pt.s1; s2[k] = pt.s2; s3[k] = pt.s3; s4[k] = pt.s4;
   }
   return MMG_OK;
+}
+
+int mmg_reml_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3,
+                  double* s4, double* sum_sq_etas) {
+  return mmg_reml_sums_ex(ctx, r, nd, deltas, s1, s2, s3, s4, sum_sq_etas, MMG_REML_ROUTE_AUTO);
 }
 
 int mmg_reml_scan_model(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, double* h0_rss, double* beta,

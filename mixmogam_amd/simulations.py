@@ -52,6 +52,19 @@ def synthetic_chunk(chunk_id, rows, num_indivs, seed=20240):
     return np.unpackbits(raw)[:nbits].view(np.int8).reshape(int(rows), int(num_indivs))
 
 
+def packed_chunk(chunk_id, rows, num_indivs, seed=20240):
+    """synthetic_chunk's twin for 1-bit storage: uint8 [rows x ceil(N/8)], bit i of a row (LSB first, the order of
+    _lib.pack_genotypes and PLINK .bed) = individual i's Bernoulli(0.5) genotype; pad bits are zero."""
+    rb = (int(num_indivs) + 7) // 8
+    nbytes = int(rows) * rb
+    gen = np.random.Generator(np.random.SFC64(int(seed) * 1000003 + int(chunk_id)))
+    raw = gen.integers(0, 2 ** 64, size=(nbytes + 7) // 8, dtype=np.uint64, endpoint=False).view(np.uint8)[:nbytes]
+    raw = raw.reshape(int(rows), rb)
+    if num_indivs % 8:
+        raw[:, -1] &= np.uint8((1 << (num_indivs % 8)) - 1)
+    return raw
+
+
 def _fill_rows(args):
     """Worker of write_synthetic_container: rows [r0, r0 + rows) of one chromosome's raw_snps <- synthetic_chunk."""
     npy_path, r0, rows, num_indivs, chunk_id, seed = args
@@ -119,8 +132,15 @@ class LazySyntheticGenotypes(object):
 
     dtype = np.dtype(np.int8)
 
-    def __init__(self, num_indivs, num_snps, gen_rows=6250, seed=20240, chunk_id0=0, threads=8):
-        self.shape = (int(num_snps), int(num_indivs))
+    def __init__(self, num_indivs, num_snps, gen_rows=6250, seed=20240, chunk_id0=0, threads=8, packed=False):
+        """packed: 1-bit rows (`raw_snps_packed`, LSB first: uint8 [M x ceil(N/8)]) that never exist expanded on the
+        host -- the generator's 64-bit words ARE the rows (numpy's SFC64, one stream per generation chunk: 2 GB/s of
+        packed bytes = 16 G genotypes/s per thread, where MT19937 `bytes` + unpackbits delivers 0.5 GB/s of int8).  A
+        different, equally distributed matrix than the int8 form (`packed_chunk` regenerates any part of it)."""
+        self.num_indivs, self.packed = int(num_indivs), bool(packed)
+        self.shape = (int(num_snps), (self.num_indivs + 7) // 8 if packed else self.num_indivs)
+        if packed:
+            self.dtype = np.dtype(np.uint8)
         self.gen_rows, self.seed, self.chunk_id0, self.threads = int(gen_rows), int(seed), int(chunk_id0), int(threads)
         self.num_gen_chunks = -(-self.shape[0] // self.gen_rows)
 
@@ -129,7 +149,9 @@ class LazySyntheticGenotypes(object):
 
     def _gen(self, k):
         rows = min(self.gen_rows, self.shape[0] - k * self.gen_rows)
-        return synthetic_chunk(self.chunk_id0 + k, rows, self.shape[1], self.seed)
+        if self.packed:
+            return packed_chunk(self.chunk_id0 + k, rows, self.num_indivs, self.seed)
+        return synthetic_chunk(self.chunk_id0 + k, rows, self.num_indivs, self.seed)
 
     def __getitem__(self, key):
         if isinstance(key, (int, np.integer)):
@@ -140,7 +162,7 @@ class LazySyntheticGenotypes(object):
         if step != 1:
             raise IndexError("LazySyntheticGenotypes supports contiguous row ranges only")
         if hi <= lo:
-            return np.zeros((0, self.shape[1]), dtype=np.int8)
+            return np.zeros((0, self.shape[1]), dtype=self.dtype)
         k0, k1 = lo // self.gen_rows, (hi - 1) // self.gen_rows
         if k1 > k0 and self.threads > 1:
             from concurrent.futures import ThreadPoolExecutor
@@ -156,7 +178,7 @@ class LazySyntheticGenotypes(object):
 
 
 def lazy_synthetic_source(num_indivs, num_snps, num_chroms=5, gen_rows=6250, seed=20240, pheno_seed=20241, h2=0.8,
-                          num_causals=100, threads=8):
+                          num_causals=100, threads=8, packed=False):
     """A genot_data tree + phenotype over LazySyntheticGenotypes: what hdf5_data.run_emmax takes in place of a file
     name when the matrix (500 GB at config 5) must never exist anywhere.  `freqs` is the generator's nominal 0.5
     (every SNP passes any MAF filter below 0.5 - 5 sigma/sqrt(N))."""
@@ -167,11 +189,18 @@ def lazy_synthetic_source(num_indivs, num_snps, num_chroms=5, gen_rows=6250, see
         m_c = min(per, num_snps - done)
         if m_c <= 0:
             break
-        tree["chrom_%d" % (c + 1)] = {
-            "raw_snps": LazySyntheticGenotypes(num_indivs, m_c, gen_rows, seed, chunk_id0=k0, threads=threads),
-            "freqs": np.full(m_c, 0.5), "positions": np.arange(1, m_c + 1, dtype=np.int64)}
+        ds = LazySyntheticGenotypes(num_indivs, m_c, gen_rows, seed, chunk_id0=k0, threads=threads, packed=packed)
+        tree["chrom_%d" % (c + 1)] = {"freqs": np.full(m_c, 0.5), "positions": np.arange(1, m_c + 1, dtype=np.int64)}
+        if packed:                                            # hdf5_data._raw_dataset's packed layout
+            tree["chrom_%d" % (c + 1)].update(raw_snps_packed=ds, packed_bits=np.array(1), num_indivs=np.array(num_indivs))
+        else:
+            tree["chrom_%d" % (c + 1)]["raw_snps"] = ds
         done += m_c
         k0 += -(-m_c // gen_rows)
-    first = synthetic_chunk(0, min(gen_rows, num_snps), num_indivs, seed)
+    if packed:
+        from ._lib import unpack_genotypes
+        first = unpack_genotypes(packed_chunk(0, min(gen_rows, num_snps), num_indivs, seed), num_indivs, 1)
+    else:
+        first = synthetic_chunk(0, min(gen_rows, num_snps), num_indivs, seed)
     y = simulate_phenotype(first, h2=h2, num_causals=min(num_causals, len(first)), seed=pheno_seed)
     return tree, y

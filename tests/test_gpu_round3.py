@@ -288,3 +288,65 @@ def test_indicator_counts_on_fp4_operands_bit_exact(ctx, lo, hi, n, m):
         want = (u.T @ u).astype(np.int64)                  # m < 2^24: exact in float32
         assert np.array_equal(ctx.kinship_indicator_counts(g, thr), want), thr
     g.close()
+
+
+# ------------------------------------------------------------------ REML sums through one band reduction
+def _reml_sums_f64(K, X, y, delta):
+    """s1..s4 of include/mixmogam_hip.h (linear_models.py:794-810 in closed form), dense float64 on the host."""
+    n = len(y)
+    Hi = np.linalg.inv(K + delta * np.eye(n))
+    HiX = Hi @ X
+    a = X.T @ HiX
+    P = Hi - HiX @ np.linalg.solve(a, HiX.T)
+    Py = P @ y
+    s2 = np.linalg.slogdet(K + delta * np.eye(n))[1] + np.linalg.slogdet(a)[1] - np.linalg.slogdet(X.T @ X)[1]
+    return float(y @ Py), float(s2), float(Py @ Py), float(np.trace(P))
+
+
+@pytest.mark.parametrize("n,q", [(40, 1), (65, 2), (66, 1), (128, 3), (129, 1), (191, 2), (300, 1), (777, 4), (2000, 2)])
+def test_reml_sums_band_route_vs_float64_and_the_cholesky_route(ctx, n, q):
+    """mmg_reml_sums_ex(route = BAND): K reduced once to bandwidth 64 (Householder panels + symmetric rank-2b updates),
+    every delta from banded Cholesky / solves / the band of the inverse -- against dense float64 on the host and
+    against the one-factorisation-per-delta route, at sizes around the band width and its multiples.  Tolerance 1e-9
+    relative (both routes are backward stable in float64; the sums are O(n) large)."""
+    rng = np.random.RandomState(n + q)
+    m = 3 * n
+    pop = rng.randint(0, 3, size=n)
+    f = np.clip(0.5 + 0.25 * rng.standard_normal((m, 3)), 0.05, 0.95)
+    S = (rng.random_sample((m, n)) < f[:, pop]).astype(np.float64)
+    S = S[S.std(1) > 0]
+    Z = (S - S.mean(1, keepdims=True)) / S.std(1, keepdims=True)
+    K = Z.T @ Z / len(Z)
+    X = np.column_stack([np.ones(n)] + [rng.standard_normal(n) for _ in range(q - 1)])
+    y = rng.standard_normal(n) + 2.0 * Z[0]
+    deltas = np.exp(np.linspace(-6, 6, 9))
+    reml = ctx.reml(K, X, y)
+    band = reml.sums(deltas, route="band")
+    again = reml.sums(deltas[3:5], route="band")            # the reduction is kept: later calls only run the band kernels
+    chol = reml.sums(deltas, route="chol")
+    reml.close()
+    for k, d in enumerate(deltas):
+        want = _reml_sums_f64(K, X, y, d)
+        for i in range(4):
+            assert abs(band[i][k] - want[i]) <= 1e-9 * max(abs(want[i]), 1.0), (n, q, d, i, band[i][k], want[i])
+            assert abs(band[i][k] - chol[i][k]) <= 1e-9 * max(abs(want[i]), 1.0), (n, q, d, i)
+    for i in range(4):
+        assert np.array_equal(again[i], band[i][3:5])        # deterministic: same kernels, same order
+    assert band[4] == chol[4]
+
+
+def test_reml_band_route_reports_an_indefinite_matrix(ctx):
+    from mixmogam_amd import _lib
+    rng = np.random.RandomState(5)
+    n = 300
+    B = rng.standard_normal((n, 40))
+    K = B @ B.T / 40 - 0.5 * np.outer(B[:, 0], B[:, 0]) / 40 * 8
+    K = 0.5 * (K + K.T)
+    assert np.linalg.eigvalsh(K).min() < -0.01
+    reml = ctx.reml(K, np.ones((n, 1)), rng.standard_normal(n))
+    for route in ("band", "chol"):
+        with pytest.raises(_lib.MixmogamHipError, match="positive definite"):
+            reml.sums([1e-3], route=route)
+    s = reml.sums([50.0], route="band")                       # large enough a delta makes it definite again
+    assert np.isfinite(s[0][0])
+    reml.close()

@@ -254,6 +254,24 @@ def test_run_emmax_over_a_never_resident_source(ctx):
         assert rel(a["chrom_results"][c]["ps"], b["chrom_results"][c]["ps"]) < 1e-9
 
 
+def test_run_emmax_over_a_never_resident_packed_source(ctx):
+    """The same with 1-bit rows that never exist expanded on the host (lazy_synthetic_source(packed=True): the
+    generator's words are the `raw_snps_packed` rows) == the run over the expanded int8 arrays; N not a multiple of 8."""
+    from mixmogam_amd import simulations, _lib
+    tree, y = simulations.lazy_synthetic_source(53, 900, num_chroms=3, gen_rows=64, num_causals=5, threads=3, packed=True)
+    ds = tree["chrom_2"]["raw_snps_packed"]
+    assert ds.shape == (len(ds), 7) and ds[:].dtype == np.uint8 and np.array_equal(ds[70:200], ds[:][70:200])
+    assert np.array_equal(ds[131], ds[:][131]) and not np.any(ds[:][:, -1] >> 5)          # pad bits are zero
+    mem = {c: {"raw_snps": _lib.unpack_genotypes(v["raw_snps_packed"][:], 53, 1), "freqs": v["freqs"],
+               "positions": v["positions"]} for c, v in tree.items()}
+    assert abs(np.concatenate([m["raw_snps"] for m in mem.values()]).mean() - 0.5) < 0.01
+    a = hdf5_data.run_emmax(tree, y, min_maf=0.1, chunk_size=100, ctx=ctx)
+    b = hdf5_data.run_emmax(mem, y, min_maf=0.1, chunk_size=10 ** 6, ctx=ctx)
+    assert a["num_snps"] == b["num_snps"] == 900
+    for c in mem:
+        assert rel(a["chrom_results"][c]["ps"], b["chrom_results"][c]["ps"]) < 1e-9
+
+
 def test_run_emmax_multi_equals_run_emmax_per_phenotype(ctx, tmp_path):
     """hdf5_data.run_emmax_multi (one pass over the chunks for all phenotypes) == run_emmax once per phenotype."""
     from mixmogam_amd import chunkstore, simulations

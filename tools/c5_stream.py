@@ -30,6 +30,8 @@ ap.add_argument("--keep", action="store_true")
 ap.add_argument("--lazy", action="store_true",
                 help="no container: every chunk is regenerated on each read (simulations.LazySyntheticGenotypes), "
                      "nothing but the current chunks is ever in host memory -- the whole 10 M SNPs on one GPU")
+ap.add_argument("--packed", action="store_true",
+                help="with --lazy: the same genotypes as 1-bit packed rows (raw_snps_packed), expanded on the device")
 ap.add_argument("--max-gb", type=float, default=80.0, help="largest container this run may put into the scratch directory")
 ap.add_argument("--writers", type=int, default=8, help="processes generating / writing the container")
 ap.add_argument("--eig", action="store_true", help="take the eigendecomposition route (eigh of K) even beyond N = 46,340")
@@ -63,7 +65,7 @@ try:
     GEN = 6250                                               # generation chunk of the lazy source (8 per 50,000-SNP read)
     if a.lazy:
         tree, y_lazy = simulations.lazy_synthetic_source(N, M, num_chroms=5, gen_rows=GEN, seed=20240, pheno_seed=20241,
-                                                         num_causals=100, threads=a.writers)
+                                                         num_causals=100, threads=a.writers, packed=a.packed)
     t0 = time.time()
     path = None if a.lazy else simulations.write_synthetic_container(os.path.join(root, "geno.mmg"), N, M, chunk_rows=CH, num_chroms=5,
                                                  seed=20240, pheno_seed=20241, num_causals=100, workers=a.writers)
@@ -77,9 +79,9 @@ try:
             cid, off = divmod(int(gi), CH)
             return simulations.synthetic_chunk(cid, CH, N, 20240)[off]
         for chrom in tree:
-            ds = tree[chrom]["raw_snps"]
+            ds = tree[chrom]["raw_snps_packed" if a.packed else "raw_snps"]
             if gi < len(ds):
-                return ds[int(gi)]
+                return _lib.unpack_genotypes(ds[int(gi)][None, :], N, 1)[0] if a.packed else ds[int(gi)]
             gi -= len(ds)
         raise IndexError(gi)
     plan = hdf5_data._chunk_plan(src["genot_data"], 0.1, CH)
