@@ -57,6 +57,12 @@ __global__ __launch_bounds__(64) void band_extract_kernel(const double* __restri
     Bc[j * BAND_LD + d] = (d <= BAND_B && j + d < N) ? A[j * N + j + d] : 0.0;
 }
 
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
 // ---- per-delta kernels -------------------------------------------------------------------------------------------
 // L (same layout as Bc) <- Cholesky factor of B + delta I; logdet = sum log(pivot); fail = 1 + first non-positive pivot
 __global__ __launch_bounds__(64) void band_factor_kernel(const double* __restrict__ Bc, int N, const double* __restrict__ deltas,
@@ -123,11 +129,6 @@ __global__ __launch_bounds__(64) void band_factor_kernel(const double* __restric
   if (t == 0) { logdet[blockIdx.x] = ld; fail[blockIdx.x] = bad; }
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
 
 // F[r] = L^-1 z_r, G[r] = L^-T F[r] for the q1 columns z_r of Zr ([q1][N])
 __global__ __launch_bounds__(64) void band_solve_kernel(const double* __restrict__ Lall, int N, const double* __restrict__ Zr,
@@ -245,6 +246,268 @@ __global__ __launch_bounds__(256) void band_gram_kernel(const double* __restrict
   }
 }
 
+// ---- kernels of the reduction -------------------------------------------------------------------------------------
+
+// Tall-skinny products  out [64 x kb] = A' B  (A [n x 64] ld lda, B [n x kb] ld ldb, kb <= 64): rocBLAS runs an output
+// this small on a handful of workgroups with the whole contraction inside each (0.4 ms at n = 20,000).  Stage 1: one
+// workgroup per slice of rows -> part[g][64 x 64]; stage 2 adds the slices in a fixed order.
+constexpr int TS_ROWS = 32;
+__global__ __launch_bounds__(256) void tsmm_tn_kernel(const double* __restrict__ A, int64_t lda, const double* __restrict__ B,
+                                                      int64_t ldb, int kb, int n, int rows_per, double* __restrict__ part) {
+  __shared__ double As[TS_ROWS][65], Bs[TS_ROWS][65];
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const int r_begin = blockIdx.x * rows_per, r_end = min(n, r_begin + rows_per);
+  double acc[4][4] = {};
+  for (int r0 = r_begin; r0 < r_end; r0 += TS_ROWS) {
+    const int rr = tid & 31, c0 = tid >> 5;
+    const bool in = r0 + rr < r_end;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = c0 + 8 * k;
+      As[rr][c] = in ? A[(r0 + rr) + (int64_t)c * lda] : 0.0;
+      Bs[rr][c] = (in && c < kb) ? B[(r0 + rr) + (int64_t)c * ldb] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int q = 0; q < TS_ROWS; ++q) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { av[i] = As[q][ty * 4 + i]; bv[i] = Bs[q][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[i][k] = fma(av[i], bv[k], acc[i][k]);
+    }
+    __syncthreads();
+  }
+  double* o = part + (size_t)blockIdx.x * 4096;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[(ty * 4 + i) + 64 * (tx * 4 + k)] = acc[i][k];
+}
+
+__global__ __launch_bounds__(256) void tsmm_reduce_kernel(const double* __restrict__ part, int G, double* __restrict__ out, int ldo) {
+  const int e = blockIdx.x * 256 + threadIdx.x;                // element of the 64 x 64 result, column-major
+  double s = 0.0;
+  for (int g = 0; g < G; ++g) s += part[(size_t)g * 4096 + e];
+  out[(e & 63) + ldo * (e >> 6)] = s;
+}
+
+// Householder QR of a tall panel P [n x 64], one launch per column (j = -1 prepares column 0).  Launch j
+//   * finishes reflector j from what launch j - 1 left behind: dots[c] = sum_{r > j} P[r][j] P[r][c] (summed per
+//     workgroup into part_in) and the pivot row (pivrow_in) give the norm, beta, tau and w_c = v'P[:, c] without
+//     another pass over the panel;
+//   * applies it to the workgroup's 256 rows, columns j+1..63, and in the same sweep accumulates the dots of column
+//     j + 1 of the UPDATED panel (part_out) and copies its pivot row (pivrow_out);
+//   * writes column j of V (explicit: zeros above, 1 on the diagonal) and zeroes P below the diagonal.
+// rocsolver_dgeqrf spends 13.8 ms per 50,000 x 64 panel (some 300 small launches); this is 65 launches that each read
+// and write the remaining columns once.
+constexpr int QR_ROWS = 256;
+__global__ __launch_bounds__(256) void panel_qr_step_kernel(double* __restrict__ P, int64_t lda, int n, int j,
+                                                            const double* __restrict__ part_in, double* __restrict__ part_out,
+                                                            const double* __restrict__ pivrow_in, double* __restrict__ pivrow_out,
+                                                            int G, double* __restrict__ V, double* __restrict__ tau,
+                                                            double* __restrict__ rdiag) {
+  __shared__ double sred[4][64], sdots[64], sw[64];
+  const int tid = threadIdx.x, rl = tid & 63, cg = tid >> 6;
+  const int r0 = blockIdx.x * QR_ROWS;
+  double scale = 0.0;
+  sw[rl] = 0.0;
+  if (j >= 0) {
+    double s = 0.0;
+    for (int g = cg; g < G; g += 4) s += part_in[(size_t)g * 64 + rl];
+    sred[cg][rl] = s;
+    __syncthreads();
+    if (tid < 64) sdots[tid] = (sred[0][tid] + sred[1][tid]) + (sred[2][tid] + sred[3][tid]);
+    __syncthreads();
+    const double x0 = pivrow_in[j], xn2 = sdots[j];
+    double tauj = 0.0, beta = x0;
+    if (xn2 > 0.0) {
+      beta = -copysign(sqrt(fma(x0, x0, xn2)), x0);
+      tauj = (beta - x0) / beta;
+      scale = 1.0 / (x0 - beta);
+    }
+    if (tid < 64) sw[tid] = tid > j ? tauj * fma(sdots[tid], scale, pivrow_in[tid]) : 0.0;     // tau w_c
+    if (blockIdx.x == 0 && tid == 0) { tau[j] = tauj; rdiag[j] = beta; }
+  }
+  __syncthreads();
+  const int jn = j + 1;
+  double acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+  // v_r and the updated element of column j + 1 of this thread's rows, read before any wave writes that column
+  double vrs[QR_ROWS / 64], pns[QR_ROWS / 64];
+#pragma unroll
+  for (int k = 0; k < QR_ROWS / 64; ++k) {
+    const int r = r0 + rl + 64 * k;
+    vrs[k] = pns[k] = 0.0;
+    if (r >= n || r < j) continue;
+    vrs[k] = j < 0 ? 0.0 : (r == j ? 1.0 : P[r + (int64_t)j * lda] * scale);
+    pns[k] = jn < 64 ? fma(-vrs[k], sw[jn], P[r + (int64_t)jn * lda]) : 0.0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < QR_ROWS / 64; ++k) {
+    const int r = r0 + rl + 64 * k;
+    if (r >= n || r < j) continue;
+    const double vr = vrs[k], pn = pns[k];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = jn + cg + 4 * i;
+      if (c < 64) {
+        const double val = fma(-vr, sw[c], P[r + (int64_t)c * lda]);
+        if (j >= 0) P[r + (int64_t)c * lda] = val;
+        if (r == jn) pivrow_out[c] = val;
+        if (r > jn) acc[i] = fma(pn, val, acc[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const double s = wave_sum(acc[i]);
+    const int c = jn + cg + 4 * i;
+    if (rl == 0 && c < 64) part_out[(size_t)blockIdx.x * 64 + c] = s;
+  }
+  __syncthreads();                                             // every wave has read column j of its rows
+  if (j >= 0 && cg == 0) {
+    for (int k = 0; k < QR_ROWS / 64; ++k) {
+      const int r = r0 + rl + 64 * k;
+      if (r >= n) continue;
+      double vr = 0.0;
+      if (r == j) vr = 1.0;
+      else if (r > j) { vr = P[r + (int64_t)j * lda] * scale; P[r + (int64_t)j * lda] = 0.0; }
+      V[r + (int64_t)j * n] = vr;
+    }
+  }
+}
+
+__global__ void panel_qr_finish_kernel(double* __restrict__ P, int64_t lda, const double* __restrict__ rdiag) {
+  const int j = threadIdx.x;
+  P[j + (int64_t)j * lda] = rdiag[j];
+}
+
+// T (upper triangular, ld 64) of the compact WY form Q = I - V T V' from S = V'V and tau (LAPACK dlarft, forward /
+// columnwise):  T[0:j, j] = -tau_j T[0:j, 0:j] S[0:j, j],  T[j][j] = tau_j
+__global__ __launch_bounds__(64) void form_t_kernel(const double* __restrict__ S, const double* __restrict__ tau, double* __restrict__ T) {
+  __shared__ double Ts[64][65];
+  const int i = threadIdx.x;
+  for (int c = 0; c < 64; ++c) Ts[i][c] = 0.0;
+  __syncthreads();
+  for (int j = 0; j < 64; ++j) {
+    const double tj = tau[j];
+    double v = 0.0;
+    if (i < j) {
+      for (int k = i; k < j; ++k) v = fma(Ts[i][k], S[k + 64 * j], v);
+      v *= -tj;
+    } else if (i == j) v = tj;
+    __syncthreads();
+    Ts[i][j] = v;
+    __syncthreads();
+  }
+  for (int c = 0; c < 64; ++c) T[i + 64 * c] = Ts[i][c];
+}
+
+// Cm [128 x 64] (ld 128) = [ -1/2 S2 ; T ]:  Y = [V | A22 V] Cm = A22 V T - 1/2 V (T'V'A22 V T)
+__global__ __launch_bounds__(256) void form_coef_kernel(const double* __restrict__ S2, const double* __restrict__ T, double* __restrict__ Cm) {
+  const int e = blockIdx.x * 256 + threadIdx.x;                // 0..4095
+  const int i = e & 63, c = e >> 6;
+  Cm[i + 128 * c] = -0.5 * S2[i + 64 * c];
+  Cm[64 + i + 128 * c] = T[i + 64 * c];
+}
+
+// W [n x 64] = A V for symmetric A [n x n] of which only the LOWER triangle is read (column-major, ld lda), V [n x 64]
+// (ld n), on v_mfma_f64_16x16x4_f64.  rocBLAS runs this shape (64 output columns) at 10-15 TFLOP/s (dsymm_64: 8.4 s of
+// the 32.7 s reduction at N = 50,000; the block-row dgemm form is slower still).  One workgroup per 64 output rows walks
+// the 64 x 64 tiles of its block row: left of the diagonal as stored, right of it the mirrored tile read transposed
+// (both contiguous in memory), the diagonal tile completed from its lower half.  Wave w owns output columns
+// 16 w .. 16 w + 15 (4 accumulator tiles of 16 rows).  Operand fragments (lane l: row / column l % 16, k = l / 16):
+//   stored tile      As[k][row], row stride 80 doubles  -> the four 16-lane groups of a ds_read_b64 start 640 B apart
+//   transposed tile  As[i][k],   row stride 66 doubles  -> bank (in 8-byte units) 2 i + k: distinct per half-wave
+//   V tile           Vt[col][k], row stride 66
+typedef double v4d __attribute__((ext_vector_type(4)));
+constexpr int SY_SA = 80, SY_ST = 66;
+__global__ __launch_bounds__(256, 2) void sym_skinny_kernel(const double* __restrict__ A, int64_t lda, int n,
+                                                            const double* __restrict__ V, double* __restrict__ W) {
+  __shared__ double As[64 * SY_SA];
+  __shared__ double Vt[64 * SY_ST];
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int I0 = blockIdx.x * 64;
+  const int lr = l & 15, lk = l >> 4;
+  v4d acc[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) acc[rt] = v4d{0.0, 0.0, 0.0, 0.0};
+  const int ntile = (n + 63) / 64;
+  // the next tile pair travels in registers while the current one is multiplied (element e = tid + 256 i of a tile)
+  double ra[16], rv[16];
+  // 32-bit element offsets from wave-uniform tile bases (scalar base + one VGPR per address)
+  const int lo = tid & 63, h0 = tid >> 6;
+  const int ldi = (int)lda;
+  auto fetch = [&](int kt) {
+    const int K0 = kt * 64;
+    const double* vb = V + K0;
+    const bool vin = K0 + lo < n;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) rv[i] = vin ? vb[lo + (h0 + 4 * i) * n] : 0.0;                            // k = lo, col = hi
+    if (K0 < I0) {
+      const double* ab = A + (int64_t)K0 * lda + I0;
+      const bool in = I0 + lo < n;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ra[i] = in ? ab[lo + (h0 + 4 * i) * ldi] : 0.0;                         // row = lo, k = hi
+    } else if (K0 > I0) {
+      const double* ab = A + (int64_t)I0 * lda + K0;
+      const bool in = K0 + lo < n;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ra[i] = (in && I0 + h0 + 4 * i < n) ? ab[lo + (h0 + 4 * i) * ldi] : 0.0;   // k = lo, i = hi
+    } else {
+      const double* ab = A + (int64_t)I0 * lda + I0;
+      const bool in = I0 + lo < n;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ra[i] = (in && lo >= h0 + 4 * i) ? ab[lo + (h0 + 4 * i) * ldi] : 0.0;   // lower half
+    }
+  };
+  fetch(0);
+  for (int kt = 0; kt < ntile; ++kt) {
+    const int K0 = kt * 64;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int hi = h0 + 4 * i;
+      Vt[hi * SY_ST + lo] = rv[i];
+      if (K0 < I0) As[hi * SY_SA + lo] = ra[i];
+      else if (K0 > I0) As[hi * SY_ST + lo] = ra[i];
+      else if (lo >= hi) { As[hi * SY_SA + lo] = ra[i]; As[lo * SY_SA + hi] = ra[i]; }
+    }
+    __syncthreads();
+    if (kt + 1 < ntile) fetch(kt + 1);
+    if (K0 <= I0) {
+#pragma unroll 4
+      for (int ks = 0; ks < 16; ++ks) {
+        const double bv = Vt[(16 * w + lr) * SY_ST + 4 * ks + lk];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+          acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(4 * ks + lk) * SY_SA + 16 * rt + lr], bv, acc[rt], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int ks = 0; ks < 16; ++ks) {
+        const double bv = Vt[(16 * w + lr) * SY_ST + 4 * ks + lk];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+          acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(16 * rt + lr) * SY_ST + 4 * ks + lk], bv, acc[rt], 0, 0, 0);
+      }
+    }
+  }
+  // D: lane l, register r = row 4 r + l / 16, column l % 16 of the 16 x 16 tile
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = I0 + 16 * rt + 4 * r + lk;
+      if (row < n) W[row + (int64_t)(16 * w + lr) * n] = acc[rt][r];
+    }
+}
+
 // ---- the reduction ---------------------------------------------------------------------------------------------------
 static int band_reduce(mmg_ctx* ctx, mmg_reml* r) {
   rocblas_handle h;
@@ -260,17 +523,27 @@ static int band_reduce(mmg_ctx* ctx, mmg_reml* r) {
   RC_HIP(ctx, hipMemcpyAsync(A, r->dK, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, st));
   RC_HIP(ctx, hipMemcpyAsync(r->dZr, r->dB, (size_t)N * q1 * sizeof(double), hipMemcpyDeviceToDevice, st));
   Scratch sc;
-  double *V = nullptr, *W = nullptr, *T = nullptr, *tau = nullptr, *M1 = nullptr, *M2 = nullptr;
+  double *VW = nullptr, *YV = nullptr, *T = nullptr, *tau = nullptr, *M1 = nullptr, *M2 = nullptr, *small = nullptr, *part = nullptr;
   const int64_t nmax = std::max<int64_t>(N - b, 1);
-  RC_HIP(ctx, sc.alloc(&V, (size_t)nmax * b * sizeof(double)));
-  RC_HIP(ctx, sc.alloc(&W, (size_t)nmax * b * sizeof(double)));
+  const int GQ = (int)((nmax + QR_ROWS - 1) / QR_ROWS);       // workgroups of a panel-QR step
+  const int GT = 128;                                         // row slices of a tall-skinny product
+  RC_HIP(ctx, sc.alloc(&VW, (size_t)nmax * 2 * b * sizeof(double)));      // [V | A22 V] -> [V | Y]
+  RC_HIP(ctx, sc.alloc(&YV, (size_t)nmax * 2 * b * sizeof(double)));      // [Y | V]
   RC_HIP(ctx, sc.alloc(&T, (size_t)b * b * sizeof(double)));
-  RC_HIP(ctx, sc.alloc(&tau, (size_t)b * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&tau, (size_t)2 * b * sizeof(double)));            // tau, diagonal of R
   RC_HIP(ctx, sc.alloc(&M1, (size_t)b * b * sizeof(double)));
-  RC_HIP(ctx, sc.alloc(&M2, (size_t)b * q1 * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&M2, (size_t)b * b * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&small, (size_t)(2 * b * b + 4 * b) * sizeof(double)));   // Cm [128 x 64], two pivot rows
+  RC_HIP(ctx, sc.alloc(&part, (size_t)std::max<int64_t>((int64_t)GT * 4096, 2 * (int64_t)GQ * 64) * sizeof(double)));
+  double* V = VW;
+  double* W = VW + (size_t)nmax * b;                          // second half at its largest; per panel: VW + n * b
+  double* Cm = small;
+  double* pivrow = small + 2 * b * b;
   const double one = 1.0, zero = 0.0, mone = -1.0, mhalf = -0.5;
-  // MMG_BAND_UPDATE=gemm: products with the full matrix (both triangles kept current) instead of symm / syr2k
-  static const bool full = [] { const char* e = std::getenv("MMG_BAND_UPDATE"); return e && std::string(e) == "gemm"; }();
+  // MMG_BAND_IMPL=lib: every panel through rocSOLVER / rocBLAS calls alone (geqrf, larft, symm, trmm, syr2k) -- the
+  // first version, kept for A/B runs and as the path of panels shorter than 256 rows
+  const bool lib_only = [] { const char* e = std::getenv("MMG_BAND_IMPL"); return e && std::string(e) == "lib"; }();
+  const int64_t bs = [] { const char* e = std::getenv("MMG_BAND_BS"); return e ? std::max<int64_t>(256, std::atoll(e) / 64 * 64) : int64_t(4096); }();
   const bool verbose = std::getenv("MMG_REML_VERBOSE") != nullptr;
   double tsec[4] = {0, 0, 0, 0};                              // panel QR + T, A22 V, small products, rank-2b update
   auto lap = [&](int which, std::chrono::steady_clock::time_point& tp) {
@@ -280,45 +553,84 @@ static int band_reduce(mmg_ctx* ctx, mmg_reml* r) {
     tsec[which] += std::chrono::duration<double>(now - tp).count();
     tp = now;
   };
+  auto tsmm = [&](const double* Am, int64_t lda, const double* Bm, int64_t ldb, int kb, int64_t n, double* out, int ldo) {
+    const int rows_per = (int)((((n + GT - 1) / GT) + TS_ROWS - 1) / TS_ROWS * TS_ROWS);
+    const int G = (int)((n + rows_per - 1) / rows_per);
+    hipLaunchKernelGGL(tsmm_tn_kernel, dim3(G), dim3(256), 0, st, Am, lda, Bm, ldb, kb, (int)n, rows_per, part);
+    hipLaunchKernelGGL(tsmm_reduce_kernel, dim3(16), dim3(256), 0, st, part, G, out, ldo);
+  };
   for (int64_t k0 = 0; N - k0 - b >= 2; k0 += b) {
     auto tp = std::chrono::steady_clock::now();
     if (verbose) { (void)hipStreamSynchronize(st); tp = std::chrono::steady_clock::now(); }
-    const int64_t n = N - k0 - b;                             // rows below the band in this block column
+    const int64_t a0 = k0 + b;                                // first row / column of the trailing matrix
+    const int64_t n = N - a0;                                 // rows below the band in this block column
     const int nr = (int)std::min<int64_t>(n, b);              // reflectors
-    double* P = A + (k0 + b) + k0 * N;                        // [n x b] panel
-    double* A22 = A + (k0 + b) + (k0 + b) * N;                // [n x n] trailing matrix
-    RC_RB(ctx, rocsolver_dgeqrf(h, (rocblas_int)n, b, P, (rocblas_int)N, tau));
-    hipLaunchKernelGGL(band_build_v_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nr), dim3(256), 0, st, P, N, (int)n, nr, V);
-    RC_RB(ctx, rocsolver_dlarft(h, rocblas_forward_direction, rocblas_column_wise, (rocblas_int)n, nr, V, (rocblas_int)n, tau, T, b));
-    lap(0, tp);
-    // X = A22 V T;  Y = X - 1/2 V (T'V'X);  A22 <- A22 - Y V' - V Y'   ( = Q' A22 Q,  Q = I - V T V' )
-    if (full) {
-      RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_none, n, nr, n, &one, A22, N, V, n, &zero, W, n));
-    } else {
+    double* P = A + a0 + k0 * N;                              // [n x b] panel
+    double* A22 = A + a0 + a0 * N;                            // [n x n] trailing matrix
+    double* Zs = r->dZr + a0;
+    W = VW + (size_t)n * b;
+    if (lib_only || n < 256) {
+      RC_RB(ctx, rocsolver_dgeqrf(h, (rocblas_int)n, b, P, (rocblas_int)N, tau));
+      hipLaunchKernelGGL(band_build_v_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nr), dim3(256), 0, st, P, N, (int)n, nr, V);
+      RC_RB(ctx, rocsolver_dlarft(h, rocblas_forward_direction, rocblas_column_wise, (rocblas_int)n, nr, V, (rocblas_int)n, tau, T, b));
+      lap(0, tp);
+      // X = A22 V T;  Y = X - 1/2 V (T'V'X);  A22 <- A22 - Y V' - V Y'   ( = Q' A22 Q,  Q = I - V T V' )
       RC_RB(ctx, rocblas_dsymm_64(h, rocblas_side_left, rocblas_fill_lower, n, nr, &one, A22, N, V, n, &zero, W, n));
-    }
-    lap(1, tp);
-    RC_RB(ctx, rocblas_dtrmm_64(h, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, n, nr,
-                                &one, T, b, W, n, W, n));
-    RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_transpose, rocblas_operation_none, nr, nr, n, &one, V, n, W, n, &zero, M1, b));
-    RC_RB(ctx, rocblas_dtrmm_64(h, rocblas_side_left, rocblas_fill_upper, rocblas_operation_transpose, rocblas_diagonal_non_unit, nr,
-                                nr, &one, T, b, M1, b, M1, b));
-    RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_none, n, nr, nr, &mhalf, V, n, M1, b, &one, W, n));
-    lap(2, tp);
-    if (full) {
-      RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_transpose, n, n, nr, &mone, W, n, V, n, &one, A22, N));
-      RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_transpose, n, n, nr, &mone, V, n, W, n, &one, A22, N));
-    } else {
+      lap(1, tp);
+      RC_RB(ctx, rocblas_dtrmm_64(h, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, n, nr,
+                                  &one, T, b, W, n, W, n));
+      RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_transpose, rocblas_operation_none, nr, nr, n, &one, V, n, W, n, &zero, M1, b));
+      RC_RB(ctx, rocblas_dtrmm_64(h, rocblas_side_left, rocblas_fill_upper, rocblas_operation_transpose, rocblas_diagonal_non_unit, nr,
+                                  nr, &one, T, b, M1, b, M1, b));
+      RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_none, n, nr, nr, &mhalf, V, n, M1, b, &one, W, n));
+      lap(2, tp);
       RC_RB(ctx, rocblas_dsyr2k_64(h, rocblas_fill_lower, rocblas_operation_none, n, nr, &mone, W, n, V, n, &one, A22, N));
+      lap(3, tp);
+      // the rotated columns of [X y]:  Z[a0:] <- Q' Z[a0:] = Z - V T' (V'Z)
+      RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_transpose, rocblas_operation_none, nr, q1, n, &one, V, n, Zs, N, &zero, M2, b));
+      RC_RB(ctx, rocblas_dtrmm_64(h, rocblas_side_left, rocblas_fill_upper, rocblas_operation_transpose, rocblas_diagonal_non_unit, nr,
+                                  q1, &one, T, b, M2, b, M2, b));
+      RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_none, n, q1, nr, &mone, V, n, M2, b, &one, Zs, N));
+      lap(2, tp);
+      continue;
+    }
+    // ---- panel QR: V, tau, R
+    {
+      const int G = (int)((n + QR_ROWS - 1) / QR_ROWS);
+      for (int j = -1; j < b; ++j) {
+        const int in = (j + 2) & 1, out = (j + 1) & 1;        // parity of the slice sums / pivot row a launch reads / writes
+        hipLaunchKernelGGL(panel_qr_step_kernel, dim3(G), dim3(256), 0, st, P, N, (int)n, j, part + (size_t)in * GQ * 64,
+                           part + (size_t)out * GQ * 64, pivrow + in * b, pivrow + out * b, G, V, tau, tau + b);
+      }
+      hipLaunchKernelGGL(panel_qr_finish_kernel, dim3(1), dim3(b), 0, st, P, N, tau + b);
+      tsmm(V, n, V, n, b, n, M1, b);                          // S = V'V
+      hipLaunchKernelGGL(form_t_kernel, dim3(1), dim3(64), 0, st, M1, tau, T);
+    }
+    lap(0, tp);
+    // ---- W = A22 V from the lower triangle alone
+    hipLaunchKernelGGL(sym_skinny_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, A22, N, (int)n, V, W);
+    lap(1, tp);
+    // ---- Y = [V | W] [ -1/2 T'(V'W)T ; T ]
+    tsmm(V, n, W, n, b, n, M1, b);                            // V'W
+    RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_none, b, b, b, &one, M1, b, T, b, &zero, M2, b));
+    RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_transpose, rocblas_operation_none, b, b, b, &one, T, b, M2, b, &zero, M1, b));
+    hipLaunchKernelGGL(form_coef_kernel, dim3(16), dim3(256), 0, st, M1, T, Cm);
+    double* Y = YV;
+    RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_none, n, b, 2 * b, &one, VW, n, Cm, 2 * b, &zero, Y, n));
+    RC_HIP(ctx, hipMemcpyAsync(YV + (size_t)n * b, V, (size_t)n * b * sizeof(double), hipMemcpyDeviceToDevice, st));   // [Y | V]
+    RC_HIP(ctx, hipMemcpyAsync(W, Y, (size_t)n * b * sizeof(double), hipMemcpyDeviceToDevice, st));                     // [V | Y]
+    // the rotated columns of [X y]
+    tsmm(V, n, Zs, N, q1, n, M2, b);
+    RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_transpose, rocblas_operation_none, b, q1, b, &one, T, b, M2, b, &zero, M1, b));
+    RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_none, n, q1, b, &mone, V, n, M1, b, &one, Zs, N));
+    lap(2, tp);
+    // ---- A22 <- A22 - [V | Y] [Y | V]' on the blocks on and below the diagonal of the absolute grid
+    for (int64_t rb = a0 / bs * bs; rb < N; rb += bs) {
+      const int64_t r_lo = std::max(rb, a0), r_hi = std::min(N, rb + bs), m = r_hi - r_lo;
+      RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_transpose, m, r_hi - a0, 2 * b, &mone, VW + (r_lo - a0), n,
+                                  YV, n, &one, A + r_lo + a0 * N, N));
     }
     lap(3, tp);
-    // the rotated columns of [X y]:  Z[k0+b:] <- Q' Z[k0+b:] = Z - V T' (V'Z)
-    double* Zs = r->dZr + (k0 + b);
-    RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_transpose, rocblas_operation_none, nr, q1, n, &one, V, n, Zs, N, &zero, M2, b));
-    RC_RB(ctx, rocblas_dtrmm_64(h, rocblas_side_left, rocblas_fill_upper, rocblas_operation_transpose, rocblas_diagonal_non_unit, nr,
-                                q1, &one, T, b, M2, b, M2, b));
-    RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_none, n, q1, nr, &mone, V, n, M2, b, &one, Zs, N));
-    lap(2, tp);
   }
   hipLaunchKernelGGL(band_extract_kernel, dim3((unsigned)N), dim3(64), 0, st, A, N, r->dBand);
   RC_HIP(ctx, hipGetLastError());
@@ -326,7 +638,7 @@ static int band_reduce(mmg_ctx* ctx, mmg_reml* r) {
   r->band_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
   if (verbose)
     fprintf(stderr, "[reml] N=%lld: band reduction (b = %d, %s) %.3f s: panel QR + T %.3f, A22 V %.3f, small products %.3f, rank-2b update %.3f\n",
-            (long long)N, b, full ? "gemm" : "symm / syr2k", r->band_s, tsec[0], tsec[1], tsec[2], tsec[3]);
+            (long long)N, b, lib_only ? "library calls" : "own panel QR, block-lower products", r->band_s, tsec[0], tsec[1], tsec[2], tsec[3]);
   r->band_ready = true;
   return MMG_OK;
 }

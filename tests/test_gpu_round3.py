@@ -335,6 +335,31 @@ def test_reml_sums_band_route_vs_float64_and_the_cholesky_route(ctx, n, q):
     assert band[4] == chol[4]
 
 
+@pytest.mark.parametrize("env", [{"MMG_BAND_BS": "512"}, {"MMG_BAND_BS": "256"}, {"MMG_BAND_IMPL": "lib"}])
+def test_reml_band_reduction_variants_agree(ctx, monkeypatch, env):
+    """The reduction's block-row grid at a size where it has several rows (MMG_BAND_BS: products and updates touch only
+    blocks on and below the diagonal of that grid) and the library-calls-only form (MMG_BAND_IMPL=lib: rocSOLVER geqrf /
+    larft, symm, syr2k) give the sums of the default form (own panel QR, one block row at this size) to 1e-10 -- different
+    orthogonal bases, same invariants."""
+    rng = np.random.RandomState(11)
+    n = 1500
+    B = rng.standard_normal((n, 300))
+    K = B @ B.T / 300 + 0.05 * np.diag(rng.random_sample(n))
+    X = np.column_stack([np.ones(n), rng.standard_normal(n)])
+    y = rng.standard_normal(n)
+    deltas = [1e-3, 0.3, 40.0]
+    reml = ctx.reml(K, X, y)
+    ref = reml.sums(deltas, route="band")
+    reml.close()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    reml = ctx.reml(K, X, y)
+    got = reml.sums(deltas, route="band")
+    reml.close()
+    for i in range(4):
+        assert np.max(np.abs(got[i] - ref[i]) / np.maximum(np.abs(ref[i]), 1.0)) < 1e-10, (env, i)
+
+
 def test_reml_band_route_reports_an_indefinite_matrix(ctx):
     from mixmogam_amd import _lib
     rng = np.random.RandomState(5)
