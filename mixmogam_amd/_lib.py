@@ -417,6 +417,13 @@ class Reml(object):
 
     ROUTES = {"auto": 0, "chol": 1, "band": 2}
 
+    def uses_band(self, route="auto"):
+        """Whether sums(route) goes through the band reduction (mirrors mmg_reml_sums_ex's AUTO rule)."""
+        if route != "auto":
+            return route == "band"
+        env = os.environ.get("MMG_REML_ROUTE", "")
+        return env != "chol" and (env == "band" or self.N >= 256)
+
     def sums(self, deltas, route="auto"):
         """s1..s4 for every delta, sum_sq_etas.  route: 'chol' = one Cholesky factorisation per delta, 'band' = K reduced
         once to a band matrix and every delta from that (csrc/reml_band.hip), 'auto' = band from N = 256 up."""

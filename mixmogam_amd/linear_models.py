@@ -153,16 +153,20 @@ class _SpectralSumsL(object):
 
 
 class _SpectralSumsChol(object):
-    """The same four sums with NO eigendecomposition: one Cholesky factorisation of K + delta I per delta on the
-    device (_lib.Reml / mmg_reml_sums; csrc/reml_chol.hip).  For N beyond rocSOLVER's syevd index range
-    (N > 46,340), where eigh falls back to block Jacobi (6.6 min at N = 50,000), this is the cheaper route: the
-    likelihood needs ~60 factorisations of N^3/3 + N^3/3 flops each.  coll: the grid values are dealt out to the ranks
-    (every rank holds K) and the sums all-gathered."""
+    """The same four sums with NO eigendecomposition, on the device (_lib.Reml / mmg_reml_sums).  For N beyond
+    rocSOLVER's syevd index range (N > 46,340), where eigh falls back to block Jacobi (6.6 min at N = 50,000), this is
+    the cheaper route.  Two forms (mmg_reml_sums_ex):
+      band  K is reduced once to an orthogonally similar band matrix (csrc/reml_band.hip: 6.5 s at N = 50,000) and
+            every delta of the ~57 the likelihood search asks for costs a banded factorisation (0.3 s per call for any
+            number of deltas).  Every rank does the same arithmetic on the same K: no exchange at all.
+      chol  one Cholesky factorisation + triangular inverse of K + delta I per delta (csrc/reml_chol.hip, 1.6 s each at
+            N = 50,000); coll: the grid values are dealt out to the ranks (every rank holds K), the sums all-gathered."""
 
-    def __init__(self, reml, coll=None):
-        self.reml, self.coll = reml, coll
+    def __init__(self, reml, coll=None, route="auto"):
+        self.reml, self.coll, self.route = reml, coll, route
+        self.band = reml.uses_band(route) if hasattr(reml, "uses_band") else False
         self.sum_sq_etas = None
-        self.n_factorisations = 0
+        self.n_factorisations = 0                                        # deltas evaluated on this rank
         self._memo = {}
 
     def at(self, deltas):
@@ -176,7 +180,7 @@ class _SpectralSumsChol(object):
 
     def _at(self, deltas):
         coll = self.coll
-        if coll is not None and coll.world > 1 and len(deltas) >= coll.world:
+        if coll is not None and coll.world > 1 and len(deltas) >= coll.world and not self.band:
             mine = np.arange(coll.rank, len(deltas), coll.world)
             # A factorisation may fail on SOME ranks only (an indefinite K: the smallest deltas sit on the low ranks).
             # Every rank must still enter the all-gather, so the failure travels as a flag row of the gathered block
@@ -207,7 +211,7 @@ class _SpectralSumsChol(object):
                     out[k][idx] = allb[r, k, :len(idx)]
             self.sum_sq_etas = part[4]
             return tuple(out)
-        s1, s2, s3, s4, sse = self.reml.sums(deltas)
+        s1, s2, s3, s4, sse = self.reml.sums(deltas, self.route) if self.route != "auto" else self.reml.sums(deltas)
         self.n_factorisations += len(deltas)
         self.sum_sq_etas = sse
         return s1, s2, s3, s4
