@@ -341,27 +341,55 @@ int kinship_pick_ksplit(int32_t Npad, int64_t Mk, bool f32) {
 }
 
 // dC (fp64 [N x N]) (+)= step * sum_d base^d C32[d] (upper tiles mirrored) + c1[i] + c1[j] + c0
-__global__ void grm_combine_kernel(const int* __restrict__ C32, int D, int32_t Npad, int32_t N, double step, double base,
-                                   const double* __restrict__ c1, double c0, double* __restrict__ C, int accumulate) {
-  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (int64_t)N * N) return;
-  const int i = (int)(gid / N), j = (int)(gid % N);
-  int a = i, b = j;
-  if ((i / TM) > (j / TN)) { a = j; b = i; }
-  double s = 0.0, pw = 1.0;
-  for (int d = 0; d < D; ++d) {
-    s = fma((double)C32[(int64_t)d * Npad * Npad + (int64_t)a * Npad + b], pw, s);   // exact: integers below 2^53
-    pw *= base;
+// One block per 64 x 64 sub-tile of a valid (upper) 256 x 256 tile of C32: the planes are read once, along rows; the
+// value goes to dC[i][j] and -- off the tile diagonal -- through LDS to dC[j][i], both along rows.  (The first version
+// took one thread per element of dC and read the mirrored half of every plane down its columns: 121 ms of a 388 ms
+// GRM chunk at N = 50,000.)
+__global__ __launch_bounds__(256) void grm_combine_kernel(const int* __restrict__ C32, int D, int32_t Npad, int32_t N, double step,
+                                                          double base, const double* __restrict__ c1, double c0,
+                                                          double* __restrict__ C, int accumulate) {
+  const int si = blockIdx.y, sj = blockIdx.x;
+  if ((si * 64) / TM > (sj * 64) / TN) return;                 // not a tile the GEMM wrote
+  const bool mirror = (si * 64) / TM < (sj * 64) / TN;        // diagonal tiles hold both halves themselves
+  __shared__ double tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int j = sj * 64 + tx;
+  const double c1j = j < N ? c1[j] : 0.0;
+#pragma unroll 4
+  for (int r = 0; r < 16; ++r) {
+    const int i = si * 64 + ty + 4 * r;
+    double sum = 0.0, pw = 1.0;
+    const int* src = C32 + (int64_t)i * Npad + j;
+    for (int d = 0; d < D; ++d) {
+      sum = fma((double)src[(int64_t)d * Npad * Npad], pw, sum);   // exact: integers below 2^53
+      pw *= base;
+    }
+    const double v = (i < N && j < N) ? fma(step, sum, c1[i] + c1j + c0) : 0.0;
+    tile[ty + 4 * r][tx] = v;
+    if (i < N && j < N) {
+      const int64_t at = (int64_t)i * N + j;
+      C[at] = accumulate ? C[at] + v : v;
+    }
   }
-  const double v = fma(step, s, c1[i] + c1[j] + c0);
-  C[gid] = accumulate ? C[gid] + v : v;
+  if (!mirror) return;
+  __syncthreads();
+  const int i2 = si * 64 + tx;                                 // column of the mirrored element
+#pragma unroll 4
+  for (int r = 0; r < 16; ++r) {
+    const int j2 = sj * 64 + ty + 4 * r;                       // its row
+    if (i2 < N && j2 < N) {
+      const int64_t at = (int64_t)j2 * N + i2;
+      const double v = tile[tx][ty + 4 * r];
+      C[at] = accumulate ? C[at] + v : v;
+    }
+  }
 }
 
 void launch_grm_combine(mmg_ctx* ctx, const int* C32, int D, int32_t Npad, int32_t N, double step, double base,
                         const double* c1, double c0, double* C, int accumulate) {
-  const int64_t total = (int64_t)N * N;
-  hipLaunchKernelGGL(grm_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, C32, D, Npad,
-                     N, step, base, c1, c0, C, accumulate);
+  const unsigned nS = (unsigned)(Npad / 64);
+  hipLaunchKernelGGL(grm_combine_kernel, dim3(nS, nS), dim3(256), 0, ctx->stream, C32, D, Npad, N, step, base, c1, c0, C,
+                     accumulate);
 }
 
 constexpr int KIN_PF_DEFAULT = 0;     // L2 prefetch distance of the transposed-read kinship kernel (see run_kinship_i8_tr)

@@ -211,9 +211,31 @@ def _dev_comm(coll):
     return getattr(coll, 'device_comm', None) if coll is not None else None
 
 
+KIN_MIN_ROWS = 65536       # SNPs per exact-GRM call from which the weights take 4 digit planes instead of 5 (api.hip)
+KIN_MAX_BYTES = 6e9        # ... as long as one chunk's int8 rows stay below this (two stores + two staging buffers)
+
+
+def _merge_plan(plan, n_indivs, min_rows=None, max_bytes=None):
+    """Neighbouring chunks of one chromosome joined until each has >= min_rows SNPs: the kinship sum does not depend
+    on how its SNPs are grouped, and mmg_kin_acc_add_grm is cheaper per SNP on larger groups (a fifth fewer digit-plane
+    GEMMs from 65,536 SNPs on, one N x N combine pass per call: 388 -> 272 ms per 50,000 SNPs at N = 50,000)."""
+    min_rows = KIN_MIN_ROWS if min_rows is None else min_rows
+    max_rows = max(1, int((KIN_MAX_BYTES if max_bytes is None else max_bytes) // max(1, n_indivs)))
+    out = []
+    for chrom, sel, pos in plan:
+        if (out and out[-1][0] == chrom and len(out[-1][1]) < min_rows and len(out[-1][1]) + len(sel) <= max_rows):
+            out[-1] = (chrom, np.concatenate([out[-1][1], sel]), np.concatenate([out[-1][2], pos]))
+        else:
+            out.append((chrom, sel, pos))
+    return out
+
+
 def _ibd_kinship(ctx, genot_data, n_indivs, plan, coll=None, prefetch=True):
     rank, world = (coll.rank, coll.world) if coll is not None else (0, 1)
     acc = ctx.kinship_accumulator(n_indivs)
+    merged = _merge_plan(plan, n_indivs)
+    if len(merged) >= 2 * world or world == 1:                           # else keep every rank busy with the finer plan
+        plan = merged
     for ci, chrom, g in _resident_chunks(ctx, genot_data, plan, rank, world, prefetch, reuse=True):
         acc.add_grm(g)                                                   # :99-106; a SNP with std == 0 is an error
         g.close()

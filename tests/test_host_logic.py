@@ -423,3 +423,19 @@ def test_chunk_plan_ramp_covers_every_row_once():
         assert max(sizes) <= 2048
         if ramp:
             assert sizes[:3] == [256, 512, 1024]
+
+
+def test_merge_plan_joins_neighbouring_chunks_of_a_chromosome():
+    """hdf5_data._merge_plan: the kinship pass groups the plan's chunks up to >= 65,536 SNPs per exact-GRM call (within a
+    byte budget, never across chromosomes); rows and positions keep their order."""
+    tree = {"c1": {"raw_snps": np.zeros((2500, 8), np.int8), "freqs": np.full(2500, 0.5), "positions": np.arange(2500)},
+            "c2": {"raw_snps": np.zeros((700, 8), np.int8), "freqs": np.full(700, 0.5), "positions": np.arange(700)}}
+    plan = hdf5_data._chunk_plan(tree, 0.1, 400)
+    assert [len(s) for _c, s, _p in plan] == [400] * 6 + [100] + [400, 300]
+    merged = hdf5_data._merge_plan(plan, 8, min_rows=1000)
+    assert [(c, len(s)) for c, s, _p in merged] == [("c1", 1200), ("c1", 1200), ("c1", 100), ("c2", 700)]
+    assert np.array_equal(np.concatenate([s for c, s, _p in merged if c == "c1"]), np.arange(2500))
+    assert np.array_equal(np.concatenate([p for c, _s, p in merged if c == "c2"]), np.arange(700))
+    capped = hdf5_data._merge_plan(plan, 8, min_rows=1000, max_bytes=8 * 900)     # at most 900 rows per chunk
+    assert max(len(s) for _c, s, _p in capped) <= 900 and sum(len(s) for _c, s, _p in capped) == 3200
+    assert hdf5_data._merge_plan(plan, 8, min_rows=1) == plan
