@@ -305,7 +305,7 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
     """hdf5_data.py:70-187 (and :191-351 when num_perm > 0).  fast_perm: the permutation test of a chunk reuses the
     quadratic forms of the scan that just ran over it (mmg_emmax_perm_after_scan) instead of recomputing them.
     eigen_free: REML and the scan model from Cholesky factorisations instead of eigh(K) (linear_models.
-    get_estimates_eigen_free); default: exactly when N is beyond rocSOLVER's syevd range (N > 46,340) and no
+    get_estimates_eigen_free); default: when N > linear_models.EIGEN_FREE_MIN_N (mandatory beyond rocSOLVER's syevd range, N > 46,340) and no
     permutation test is asked for (that one needs H_sqrt_inv itself).
 
     hdf5_filename: container path (chunkstore / HDF5) or an open genot_data tree / mapping.  For the reference's
@@ -342,7 +342,7 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
         raise ValueError("run_emmax: the permutation test needs H_sqrt_inv, which the eigendecomposition-free route "
                          "does not produce -- call with eigen_free=False (or None) when num_perm > 0")
     if eigen_free is None:
-        eigen_free = n > 46340 and not num_perm and isinstance(ctx, _lib.Context)
+        eigen_free = n > lm.EIGEN_FREE_MIN_N and not num_perm and isinstance(ctx, _lib.Context)
     res = lmm._try_eigen_free(coll=coll) if eigen_free else None         # :126-137 without either eigendecomposition
     if res is not None:
         prep = lmm.scan_model_eigen_free(res)

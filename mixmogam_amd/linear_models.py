@@ -96,9 +96,12 @@ class LinearModel(object):
 
 # Where get_estimates would compute eig_R itself, take the spectral sums from eig_L instead (no second eigh).
 REML_SUMS_FROM_EIG_L = True
-# above this many individuals emmax_f_test takes the eigendecomposition-free route (rocSOLVER's dsyevd indexes with 32
-# bits: N^2 < 2^31)
-EIGEN_FREE_MIN_N = 46340
+# above this many individuals emmax_f_test takes the eigendecomposition-free route when nothing needs H_sqrt_inv.
+# Mandatory beyond N = 46,340 (rocSOLVER's dsyevd indexes with 32 bits: N^2 < 2^31); already cheaper far below that since
+# the REML sums come from one band reduction of K (csrc/reml_band.hip): N = 20,000: 1.05 s + 0.3 s for the scan model
+# against 7.4 s of dsyevd + 2.9 s; at N = 5000 the two routes cost the same (0.2-0.3 s).
+EIGEN_FREE_MIN_N = 8191
+EIGH_MAX_N = 46340
 # emmax_f_test builds the scan model on the device from K and delta (mmg_reml_scan_model) when nothing needs H itself.
 DEVICE_SCAN_MODEL = True
 
