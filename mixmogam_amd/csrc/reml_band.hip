@@ -64,164 +64,237 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ---- per-delta kernels -------------------------------------------------------------------------------------------
-// L (same layout as Bc) <- Cholesky factor of B + delta I; logdet = sum log(pivot); fail = 1 + first non-positive pivot
-__global__ __launch_bounds__(64) void band_factor_kernel(const double* __restrict__ Bc, int N, const double* __restrict__ deltas,
-                                                         double* __restrict__ Lall, double* __restrict__ logdet,
-                                                         int* __restrict__ fail) {
-  const int t = threadIdx.x;
+// value of `v` in lane `lane` (wave-uniform lane index): two v_readlane_b32, no LDS round trip
+__device__ __forceinline__ double lane_value(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// L (same layout as Bc) <- Cholesky factor of B + delta I; logdet = sum log(pivot); fail = 1 + first non-positive pivot.
+// Four waves per delta: lane t of every wave owns column i = t (mod 64) of the 64-column window, wave w the rows
+// d = 16 w .. 16 w + 15 of it (wave 3 also d = 64), so a step is 16-17 multiply-adds per lane after one barrier.
+// The columns the lanes take over next (index + 64) wait in LDS (`pre`), staged a whole 64-step block ahead: all threads
+// fetch the block after next at the start of a block and store it at its end -- no global load sits inside a step (a
+// one-step-ahead fetch made every step as long as an HBM access: 1.2 us).
+__global__ __launch_bounds__(256) void band_factor_kernel(const double* __restrict__ Bc, int N, const double* __restrict__ deltas,
+                                                          double* __restrict__ Lall, double* __restrict__ logdet,
+                                                          int* __restrict__ fail) {
+  const int t = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int d0 = 16 * w, nd = w == 3 ? 17 : 16;
   const double delta = deltas[blockIdx.x];
   double* Lc = Lall + (size_t)blockIdx.x * N * BAND_LD;
   __shared__ __attribute__((aligned(16))) double lbuf[2][2 * BAND_B + 8];   // [0..64] the raw pivot column, zeros above
-  // pre[p]: the column lane p takes over when its current one has been the pivot (index + 64), staged by all lanes with
-  // coalesced loads 64 steps ahead -- a lane fetching its own 65 values would issue 65 loads for the whole wave
   constexpr int PS = BAND_B + 2;
-  __shared__ __attribute__((aligned(16))) double pre[64 * PS];
-  for (int i = t; i < 2 * (2 * BAND_B + 8); i += 64) (&lbuf[0][0])[i] = 0.0;
+  constexpr int NPRE = (64 * PS + 255) / 256;                 // elements of a staged block per thread
+  __shared__ __attribute__((aligned(16))) double pre[2][64 * PS];
+  for (int i = threadIdx.x; i < 2 * (2 * BAND_B + 8); i += 256) (&lbuf[0][0])[i] = 0.0;
   auto band_at = [&](int i, int d) { return i < N ? Bc[(size_t)i * BAND_LD + d] + (d == 0 ? delta : 0.0) : 0.0; };
-  double col[BAND_B + 1];
+  // element e of the staged image of columns [c0, c0 + 64): slot e / PS, row e % PS (rows 65 are padding)
+  auto stage_at = [&](int c0, int e) { const int sl = e / PS, d = e - sl * PS; return (e < 64 * PS && d <= BAND_B) ? band_at(c0 + sl, d) : 0.0; };
+  double col[17], hold[NPRE];
 #pragma unroll
-  for (int d = 0; d <= BAND_B; ++d) col[d] = band_at(t, d);
-  for (int i = 0; i < 64; ++i) {
-    pre[i * PS + t] = band_at(BAND_B + i, t);
-    if (t == 0) pre[i * PS + BAND_B] = band_at(BAND_B + i, BAND_B);
+  for (int k = 0; k < 17; ++k) col[k] = k < nd ? band_at(t, d0 + k) : 0.0;
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k) {
+    const int e = threadIdx.x + 256 * k;
+    if (e < 64 * PS) pre[0][e] = stage_at(BAND_B, e);          // columns 64..127: taken over during steps 0..63
   }
-  double ld = 0.0;
-  int bad = 0;
+  double mant = 1.0;                                          // prod of pivots = mant 2^expo
+  int expo = 0, bad = 0;
   __syncthreads();
-  for (int j = 0; j < N; ++j) {
-    const int p = j & 63, buf = j & 1;
-    if (t == p) {
+  for (int J0 = 0; J0 < N && !bad; J0 += 64) {
+    const int pb = (J0 >> 6) & 1;
 #pragma unroll
-      for (int d = 0; d <= BAND_B; ++d) lbuf[buf][d] = col[d];
-    }
-    // column j + 128 for the slot this step frees (in flight while the step computes)
-    const double g0 = band_at(j + 2 * BAND_B, t);
-    const double g1 = t == 0 ? band_at(j + 2 * BAND_B, BAND_B) : 0.0;
-    __syncthreads();
-    const double piv = lbuf[buf][0];
-    if (!(piv > 0.0)) { bad = j + 1; break; }              // uniform: every lane reads the same pivot
-    const double rinv = 1.0 / sqrt(piv);
-    ld += log(piv);
-    const int c = (t - j) & 63;
-    // column j of L, one element per lane (lane 0 also the 65th), and 1 / l_jj beside it
-    Lc[(size_t)j * BAND_LD + t] = lbuf[buf][t] * rinv;
-    if (t == 0) {
-      Lc[(size_t)j * BAND_LD + BAND_B] = lbuf[buf][BAND_B] * rinv;
-      Lc[(size_t)j * BAND_LD + BAND_B + 1] = rinv;
-    }
-    if (c == 0) {
-      // the pivot's lane moves on to column j + 64: only its diagonal has met column j
-      const double x = lbuf[buf][BAND_B] * rinv;
-      const double* src = pre + p * PS;
+    for (int k = 0; k < NPRE; ++k) hold[k] = stage_at(J0 + 2 * BAND_B, threadIdx.x + 256 * k);   // for the NEXT block of steps
+    const int jend = min(N, J0 + 64);
+    for (int j = J0; j < jend; ++j) {
+      const int p = j & 63, buf = j & 1;
+      if (t == p) {
 #pragma unroll
-      for (int d = 0; d <= BAND_B; ++d) col[d] = src[d];
-      col[0] -= x * x;
-    } else {
-      // column i = j + c:  A[i + d][i] -= l[c + d] l[c]   (lbuf is zero beyond 64: no bound to test)
-      const double lc = lbuf[buf][c] * (rinv * rinv);
-      const double* lb = &lbuf[buf][c];
+        for (int k = 0; k < 17; ++k)
+          if (k < nd) lbuf[buf][d0 + k] = col[k];
+      }
+      __syncthreads();
+      const double piv = lbuf[buf][0];
+      if (!(piv > 0.0)) { bad = j + 1; break; }             // uniform: every lane reads the same pivot
+      const double rinv = 1.0 / sqrt(piv);
+      const int c = (t - j) & 63;
+      if (w == 0) {
+        int e;
+        mant = frexp(mant * piv, &e);
+        expo += e;
+        // column j of L, one element per lane (lane 0 also the 65th), and 1 / l_jj beside it
+        Lc[(size_t)j * BAND_LD + t] = lbuf[buf][t] * rinv;
+        if (t == 0) {
+          Lc[(size_t)j * BAND_LD + BAND_B] = lbuf[buf][BAND_B] * rinv;
+          Lc[(size_t)j * BAND_LD + BAND_B + 1] = rinv;
+        }
+      }
+      if (c == 0) {
+        // the pivot's lanes move on to column j + 64: only its diagonal has met column j
+        const double* src = &pre[pb][p * PS + d0];
 #pragma unroll
-      for (int d = 0; d <= BAND_B; ++d) col[d] = fma(-lb[d], lc, col[d]);
+        for (int k = 0; k < 17; ++k)
+          if (k < nd) col[k] = src[k];
+        if (w == 0) { const double x = lbuf[buf][BAND_B] * rinv; col[0] -= x * x; }
+      } else {
+        // column i = j + c:  A[i + d][i] -= l[c + d] l[c]   (lbuf is zero beyond 64: no bound to test)
+        const double lc = lbuf[buf][c] * (rinv * rinv);
+        const double* lb = &lbuf[buf][c + d0];
+#pragma unroll
+        for (int k = 0; k < 17; ++k)
+          if (k < nd) col[k] = fma(-lb[k], lc, col[k]);
+      }
     }
-    pre[p * PS + t] = g0;                                   // after the pivot lane has read the slot (same wave: in order)
-    if (t == 0) pre[p * PS + BAND_B] = g1;
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      const int e = threadIdx.x + 256 * k;
+      if (e < 64 * PS) pre[pb ^ 1][e] = hold[k];              // read from the first step of the next block on (a barrier later)
+    }
   }
-  if (t == 0) { logdet[blockIdx.x] = ld; fail[blockIdx.x] = bad; }
+  if (threadIdx.x == 0) { logdet[blockIdx.x] = log(mant) + (double)expo * 0.6931471805599453094; fail[blockIdx.x] = bad; }
 }
 
+// sum over the wave, the same value in every lane: butterflies inside the 16-lane rows by DPP, the four row sums through
+// v_readlane (a ds_bpermute butterfly is six dependent LDS round trips)
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_fast(double v) {
+  v += dpp_move<0xB1>(v);                                     // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);                                     // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);                                    // row_half_mirror
+  v += dpp_move<0x140>(v);                                    // row_mirror
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
 
-// F[r] = L^-1 z_r, G[r] = L^-T F[r] for the q1 columns z_r of Zr ([q1][N])
-__global__ __launch_bounds__(64) void band_solve_kernel(const double* __restrict__ Lall, int N, const double* __restrict__ Zr,
-                                                        int q1, double* __restrict__ Fall, double* __restrict__ Gall) {
-  const int t = threadIdx.x;
+// F[r] = L^-1 z_r, G[r] = L^-T F[r] for the q1 columns z_r of Zr ([q1][N]).  Wave 0 does the arithmetic; both
+// substitutions are column sweeps (x_j leaves lane j mod 64 through v_readlane, every other lane subtracts its L entry
+// times it), so a step is one LDS read and one multiply-add per lane and there is no reduction.  The backward sweep needs
+// ROW j of L -- entries of the 64 columns before j -- hence two 64-column chunks of L at a time.  Waves 1-3 fetch the
+// chunk needed next into the third buffer of a ring meanwhile (one wave loading 36 KB per 64 steps by itself spent
+// more time fetching than solving).
+__global__ __launch_bounds__(256) void band_solve_kernel(const double* __restrict__ Lall, int N, const double* __restrict__ Zr,
+                                                         int q1, double* __restrict__ Fall, double* __restrict__ Gall) {
+  const int t = threadIdx.x & 63;
+  const bool loader = threadIdx.x >= 64;
+  const int lt = threadIdx.x - 64;
   const double* Lc = Lall + (size_t)blockIdx.x * N * BAND_LD;
-  __shared__ double ch[64 * BAND_LD];
+  __shared__ __attribute__((aligned(16))) double ch[3][64 * BAND_LD];
   const int nchunk = (N + 63) / 64;
+  auto ring = [](int cb) { return (cb + 3) % 3; };            // cb >= -2
+  auto load_chunk = [&](int cb) {                             // loaders: chunk cb (columns 64 cb ..) -> its ring slot; zeros beyond the matrix
+    double2* dst = (double2*)ch[ring(cb)];
+    const int nj = (cb < 0 || cb >= nchunk) ? 0 : min(64, N - cb * 64);
+    const double2* src = (const double2*)(Lc + (size_t)(cb < 0 ? 0 : cb) * 64 * BAND_LD);
+    for (int i = lt; i < 32 * BAND_LD; i += 192) dst[i] = 2 * i < nj * BAND_LD ? src[i] : double2{0.0, 0.0};
+  };
   for (int r = 0; r < q1; ++r) {
     const double* z0 = Zr + (size_t)r * N;
     double* f = Fall + ((size_t)blockIdx.x * q1 + r) * N;
     double* g = Gall + ((size_t)blockIdx.x * q1 + r) * N;
     // ---- forward: lane t holds the running right-hand side of unknown i = t (mod 64) of the current window
+    __syncthreads();
+    if (loader) load_chunk(0);
+    __syncthreads();
     double z = t < N ? z0[t] : 0.0;
     for (int cb = 0; cb < nchunk; ++cb) {
-      const int j0 = cb * 64, nj = min(64, N - j0);
-      __syncthreads();
-      for (int i = t; i < nj * BAND_LD; i += 64) ch[i] = Lc[(size_t)j0 * BAND_LD + i];
-      __syncthreads();
-      const double znext = (j0 + 64 + t < N) ? z0[j0 + 64 + t] : 0.0;
-      double wkeep = 0.0;
-      for (int jj = 0; jj < nj; ++jj) {
-        const int c = (t - jj) & 63;
-        const double* lj = ch + jj * BAND_LD;
-        const double w = __shfl(z, jj) * lj[BAND_B + 1];
-        if (c == 0) { wkeep = w; z = fma(-lj[BAND_B], w, znext); }
-        else z = fma(-lj[c], w, z);
+      if (loader) {
+        load_chunk(cb + 1);
+      } else {
+        const int j0 = cb * 64, nj = min(64, N - j0);
+        const double* cur = ch[ring(cb)];
+        const double znext = (j0 + 64 + t < N) ? z0[j0 + 64 + t] : 0.0;
+        double wkeep = 0.0;
+        for (int jj = 0; jj < nj; ++jj) {
+          const int c = (t - jj) & 63;
+          const double* lj = cur + jj * BAND_LD;
+          const double lval = lj[c == 0 ? BAND_B : c];
+          const double wv = lane_value(z, jj) * lj[BAND_B + 1];
+          if (c == 0) { wkeep = wv; z = fma(-lval, wv, znext); }
+          else z = fma(-lval, wv, z);
+        }
+        if (t < nj) f[j0 + t] = wkeep;
       }
-      if (t < nj) f[j0 + t] = wkeep;
+      __syncthreads();
     }
-    // ---- backward: lane t holds x_i of the window above the current column
+    // ---- backward: lane t holds the running right-hand side of unknown i = t (mod 64) of the window BELOW column j
+    // (f is read back by the thread that wrote it: index = t mod 64)
+    const int top = nchunk - 1, top0 = top * 64, ntop = N - top0;
+    if (loader) { load_chunk(top); load_chunk(top - 1); }
+    __syncthreads();
     double x = 0.0;
-    for (int cb = nchunk - 1; cb >= 0; --cb) {
-      const int j0 = cb * 64, nj = min(64, N - j0);
-      __syncthreads();
-      for (int i = t; i < nj * BAND_LD; i += 64) ch[i] = Lc[(size_t)j0 * BAND_LD + i];
-      __syncthreads();
-      const double wv = t < nj ? f[j0 + t] : 0.0;
-      if (t >= nj) x = 0.0;                                   // only the last chunk can be short: nothing above it
-      for (int jj = nj - 1; jj >= 0; --jj) {
-        const int c = (t - jj) & 63;
-        const double* lj = ch + jj * BAND_LD;
-        const double s = wave_sum(lj[c == 0 ? BAND_B : c] * x);
-        const double xj = (__shfl(wv, jj) - s) * lj[BAND_B + 1];
-        if (c == 0) x = xj;
+    if (!loader) x = t < ntop ? f[top0 + t] : (top0 + t - 64 >= 0 ? f[top0 + t - 64] : 0.0);
+    for (int cb = top; cb >= 0; --cb) {
+      if (loader) {
+        load_chunk(cb - 2);
+      } else {
+        const int j0 = cb * 64, nj = min(64, N - j0);
+        const double* cur = ch[ring(cb)];
+        const double* low = ch[ring(cb - 1)];
+        const double xnext = (cb >= 1 && t < nj) ? f[j0 - 64 + t] : 0.0;
+        double xkeep = 0.0;
+        for (int jj = nj - 1; jj >= 0; --jj) {
+          const int c = (jj - t) & 63;                        // j - i for the unknown i this lane holds
+          // L[j][i]: column i lives at local column t of its chunk (this one for t < jj, the one below otherwise)
+          const double lval = c == 0 ? low[jj * BAND_LD + BAND_B] : (t < jj ? cur : low)[t * BAND_LD + c];
+          const double xj = lane_value(x, jj) * cur[jj * BAND_LD + BAND_B + 1];
+          if (c == 0) { xkeep = xj; x = fma(-lval, xj, xnext); }
+          else x = fma(-lval, xj, x);
+        }
+        if (t < nj) g[j0 + t] = xkeep;
       }
-      if (t < nj) g[j0 + t] = x;
+      __syncthreads();
     }
   }
 }
 
 // trace of (L L')^-1 from the band of the inverse:  Z_ij = -(1/l_jj) sum_{k>j} Z_ik L_kj (i > j),
-// Z_jj = 1/l_jj^2 - (1/l_jj) sum_{k>j} L_kj Z_kj;  row / column i of the window lives at slot i mod 64
-__global__ __launch_bounds__(64) void band_trace_kernel(const double* __restrict__ Lall, int N, double* __restrict__ trace) {
-  const int t = threadIdx.x;
+// Z_jj = 1/l_jj^2 - (1/l_jj) sum_{k>j} L_kj Z_kj;  row / column i of the window lives at slot i mod 64.  Four waves: wave w
+// sums over the slots 16 w .. 16 w + 15 (L entries through v_readlane), the partial sums meet in LDS.
+__global__ __launch_bounds__(256) void band_trace_kernel(const double* __restrict__ Lall, int N, double* __restrict__ trace) {
+  const int t = threadIdx.x & 63, w = threadIdx.x >> 6;
   const double* Lc = Lall + (size_t)blockIdx.x * N * BAND_LD;
   constexpr int ZS = 65;                                      // row stride of the window: column writes hit 64 banks
   __shared__ double Zw[64 * ZS];
   __shared__ double ch[64 * BAND_LD];
-  __shared__ double lrow[64];
-  for (int i = t; i < 64 * ZS; i += 64) Zw[i] = 0.0;
+  __shared__ double psum[4][64];
+  for (int i = threadIdx.x; i < 64 * ZS; i += 256) Zw[i] = 0.0;
   double tr = 0.0;
   const int nchunk = (N + 63) / 64;
   for (int cb = nchunk - 1; cb >= 0; --cb) {
     const int j0 = cb * 64, nj = min(64, N - j0);
     __syncthreads();
-    for (int i = t; i < nj * BAND_LD; i += 64) ch[i] = Lc[(size_t)j0 * BAND_LD + i];
+    for (int i = threadIdx.x; i < nj * BAND_LD; i += 256) ch[i] = Lc[(size_t)j0 * BAND_LD + i];
     __syncthreads();
     for (int jj = nj - 1; jj >= 0; --jj) {
       const int c = (t - jj) & 63;
       const double* lj = ch + jj * BAND_LD;
       const double rinv = lj[BAND_B + 1];
       const double lv = lj[c == 0 ? BAND_B : c];              // L[i_t][j], i_t = j + (c ? c : 64)
-      lrow[t] = lv;
-      __syncthreads();
       double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-      for (int u = 0; u < 64; u += 2) {
-        s0 = fma(lrow[u], Zw[u * ZS + t], s0);
-        s1 = fma(lrow[u + 1], Zw[(u + 1) * ZS + t], s1);
+#pragma unroll
+      for (int u = 0; u < 16; u += 2) {
+        s0 = fma(lane_value(lv, 16 * w + u), Zw[(16 * w + u) * ZS + t], s0);
+        s1 = fma(lane_value(lv, 16 * w + u + 1), Zw[(16 * w + u + 1) * ZS + t], s1);
       }
-      const double zt = -(s0 + s1) * rinv;                    // Z[i_t][j]
-      const double dsum = wave_sum(lv * zt);
+      psum[w][t] = s0 + s1;
+      __syncthreads();                                        // every wave has read the window
+      const double zt = -((psum[0][t] + psum[1][t]) + (psum[2][t] + psum[3][t])) * rinv;   // Z[i_t][j]
+      const double dsum = wave_sum_fast(lv * zt);
       const double zjj = rinv * rinv - rinv * dsum;
       tr += zjj;
-      __syncthreads();
       const double put = (c == 0) ? zjj : zt;                 // slot jj changes owner: index j + 64 leaves, j enters
-      Zw[jj * ZS + t] = put;
-      Zw[t * ZS + jj] = put;
+      if (w == 0) Zw[jj * ZS + t] = put;
+      if (w == 1) Zw[t * ZS + jj] = put;
       __syncthreads();
     }
   }
-  if (t == 0) trace[blockIdx.x] = tr;
+  if (threadIdx.x == 0) trace[blockIdx.x] = tr;
 }
 
 // out[blk][a][b] = <F_a, F_b>, out2 likewise for G: one block per (delta, a, b), fixed summation order
@@ -679,7 +752,7 @@ int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, 
     RC_HIP(ctx, hipMemcpyAsync(dd, deltas + g0, ng * sizeof(double), hipMemcpyHostToDevice, st));
     RC_HIP(ctx, hipMemsetAsync(sca, 0, nsc * sizeof(double), st));
     const auto t0 = std::chrono::steady_clock::now();
-    hipLaunchKernelGGL(band_factor_kernel, dim3(ng), dim3(64), 0, st, r->dBand, N, dd, L, dlog, dfail);
+    hipLaunchKernelGGL(band_factor_kernel, dim3(ng), dim3(256), 0, st, r->dBand, N, dd, L, dlog, dfail);
     std::vector<int> bad(ng);
     RC_HIP(ctx, hipMemcpyAsync(bad.data(), dfail, ng * sizeof(int), hipMemcpyDeviceToHost, st));
     RC_HIP(ctx, hipStreamSynchronize(st));
@@ -687,8 +760,8 @@ int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, 
       if (bad[k])
         return set_err(ctx, MMG_E_LIB, "K + delta I is not positive definite (banded Cholesky, pivot " + std::to_string(bad[k]) + ")");
     const auto t1 = std::chrono::steady_clock::now();
-    hipLaunchKernelGGL(band_solve_kernel, dim3(ng), dim3(64), 0, st, L, N, r->dZr, q1, F, G);
-    hipLaunchKernelGGL(band_trace_kernel, dim3(ng), dim3(64), 0, st, L, N, dtr);
+    hipLaunchKernelGGL(band_solve_kernel, dim3(ng), dim3(256), 0, st, L, N, r->dZr, q1, F, G);
+    hipLaunchKernelGGL(band_trace_kernel, dim3(ng), dim3(256), 0, st, L, N, dtr);
     hipLaunchKernelGGL(band_gram_kernel, dim3(ng, q1 * q1), dim3(256), 0, st, F, G, N, q1, dff, dgg);
     RC_HIP(ctx, hipGetLastError());
     std::vector<double> hs(nsc);
