@@ -255,7 +255,7 @@ def main():
         res = bench_multi(args, ctx, coll, g, lmm, eig_L, N, M, Mtot, barrier, common)
     else:
         res = bench_scan(args, ctx, coll, comm_h, g, lmm, est, prep, N, M, Mtot, D, barrier, common, rank, world,
-                         kin_i8_ms, kin_i8_pack_ms, kin_f32_ms, kin_f32_pack_ms)
+                         kin_i8_ms, kin_i8_pack_ms, kin_f32_ms, kin_f32_pack_ms, fp4_kin, kin_i8_first_ms)
         if res is not None and grm is not None:
             res["roofline_kinship"]["grm_exact_i8"] = grm
     # What the timed region does not show: kinship is sharded, but eigh + REML + the scan model are
@@ -300,7 +300,7 @@ def main():
 
 # ----------------------------------------------------------------------------------------------- the BASELINE metric
 def bench_scan(args, ctx, coll, comm_h, g, lmm, est, prep, N, M, Mtot, D, barrier, common, rank, world, kin_i8_ms,
-               kin_i8_pack_ms, kin_f32_ms, kin_f32_pack_ms):
+               kin_i8_pack_ms, kin_f32_ms, kin_f32_pack_ms, fp4_kin=True, kin_i8_first_ms=None):
     from mixmogam_amd import dist as mdist
     n_p = prep["n_p"]
     # Result buffers are allocated once and page-locked (mmg_host_alloc).  Delivery is double buffered: the
