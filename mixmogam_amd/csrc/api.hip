@@ -98,6 +98,8 @@ int mmg_ctx_create(int device, mmg_ctx** out) {
 static void free_model(mmg_scan_model& m) {
   hipFree(m.Bq); hipFree(m.diag); hipFree(m.w); hipFree(m.job_off); hipFree(m.jobs);
   hipFree(m.job_off_hi); hipFree(m.jobs_hi); hipFree(m.job_off_lo); hipFree(m.jobs_lo);
+  for (int r = 0; r < 3; ++r)
+    for (int k = 0; k < 2; ++k) { hipFree(m.tail_off[r][k]); hipFree(m.tail_jobs[r][k]); }
   m = mmg_scan_model();
 }
 static void free_result(mmg_scan_result& r) {
@@ -1063,8 +1065,9 @@ static double ln_beta_half(double a) {  // ln B(a, 1/2)
 
 // LPT assignment of the (digit, J) jobs with digit in [d0, d1) to the G job groups of an XCD cohort
 static int build_schedule_range(mmg_ctx* ctx, const mmg_scan_model& md, int d0, int d1, int** job_off, int2** jobs_out,
-                                int* njobs) {
-  const int nJ = md.Npad / TM, G = md.G;
+                                int* njobs, int G = 0) {
+  const int nJ = md.Npad / TM;
+  if (G == 0) G = md.G;
   std::vector<std::pair<int, int>> all;  // (weight = J + 1 k-blocks, id)
   for (int d = d0; d < d1; ++d)
     for (int J = 0; J < nJ; ++J) all.push_back({J + 1, d * nJ + J});
@@ -1101,9 +1104,19 @@ static int build_schedule(mmg_ctx* ctx, mmg_scan_model& md) {
   if (AS != 1 && AS != 2 && AS != 4 && AS != 8 && AS != 16 && AS != 32) AS = 4;
   md.AS = AS; md.G = 32 / AS;
   int rc = build_schedule_range(ctx, md, 0, md.D, &md.job_off, &md.jobs, &md.njobs);
+  // tail cohorts: the same jobs over 2x / 4x as many groups
+  auto tails = [&](int range, int d0, int d1) {
+    int n = 0, rct = MMG_OK;
+    for (int k = 0; k < 2 && rct == MMG_OK; ++k)
+      if ((AS >> (k + 1)) >= 1) rct = build_schedule_range(ctx, md, d0, d1, &md.tail_off[range][k], &md.tail_jobs[range][k], &n, 32 / (AS >> (k + 1)));
+    return rct;
+  };
+  if (rc == MMG_OK) rc = tails(0, 0, md.D);
   if (rc || !md.adaptive) return rc;
   if ((rc = build_schedule_range(ctx, md, 1, md.D, &md.job_off_hi, &md.jobs_hi, &md.njobs_hi))) return rc;
-  return build_schedule_range(ctx, md, 0, 1, &md.job_off_lo, &md.jobs_lo, &md.njobs_lo);
+  if ((rc = build_schedule_range(ctx, md, 0, 1, &md.job_off_lo, &md.jobs_lo, &md.njobs_lo))) return rc;
+  if ((rc = tails(1, 1, md.D))) return rc;
+  return tails(2, 0, 1);
 }
 
 // Build a scan model from a DEVICE-resident fp64 matrix dA [N x N] and device vector dw [N].
@@ -1297,8 +1310,8 @@ static int scan_into(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, mmg_sc
   if (const char* e = std::getenv("MMG_SCAN_ADAPT_TARGET")) target = std::atof(e);
   const double sig_unit = md.step * (double)(1 << SCAN_DIGIT_BITS) / std::sqrt(12.0) / std::sqrt(2.0);   // sigma = sig_unit * sum s^2
   mmg_scan_model hi = md, lo = md;                        // shallow copies with the schedule swapped
-  hi.job_off = md.job_off_hi; hi.jobs = md.jobs_hi; hi.njobs = md.njobs_hi;
-  lo.job_off = md.job_off_lo; lo.jobs = md.jobs_lo; lo.njobs = md.njobs_lo;
+  hi.job_off = md.job_off_hi; hi.jobs = md.jobs_hi; hi.njobs = md.njobs_hi; hi.range = 1;
+  lo.job_off = md.job_off_lo; lo.jobs = md.jobs_lo; lo.njobs = md.njobs_lo; lo.range = 2;
   rc = run_scan_quad(ctx, g, hi, res.q, EV_QUAD, linp);
   if (rc) return rc;
   MMG_HIP(ctx, hipGetLastError());

@@ -135,7 +135,7 @@ struct LinArgs {
 template <int ABL, int N3, int N0, int N1, bool FAST, bool LIN = false>
 __global__ __launch_bounds__(W4_THREADS) void scan_quad_w4s_kernel(
     const int8_t* __restrict__ S, int64_t ldS, int nSb, const int8_t* __restrict__ Bq, int64_t ldB,
-    int64_t digit_stride, const int* __restrict__ job_off, const int2* __restrict__ jobs, int AS,
+    int64_t digit_stride, const int* __restrict__ job_off, const int2* __restrict__ jobs, int AS, int sb_base,
     unsigned long long* __restrict__ q, unsigned long long* __restrict__ dbg, LinArgs lin) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr bool LD = ABL != 2;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(W4_THREADS) void scan_quad_w4s_kernel(
   const int x = b & 7, bi = b >> 3;
   const int cohort = bi >> 5, within = bi & 31;
   const int a_ = within % AS, grp = within / AS;
-  const int sb = (cohort * 8 + x) * AS + a_;
+  const int sb = sb_base + (cohort * 8 + x) * AS + a_;
   if (sb >= nSb) return;
   const int j0 = job_off[grp], j1 = job_off[grp + 1];
   if (j1 <= j0) return;
@@ -337,7 +337,25 @@ void launch_scan_quad_w4s(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model&
                           const LinOut* lin) {
   const int nSb = (int)(g->Mpad / TN);
   const int per = 8 * md.AS;
-  const int ncoh = (nSb + per - 1) / per;
+  // full cohorts with the model's grouping; the remaining r < 8 AS blocks as a second launch with the jobs split over 2x or
+  // 4x as many groups wherever that takes fewer (shorter) rounds: ceil(r / (8 AS')) rounds of relative length AS' / AS.
+  // (N = 50,000, 50,000-SNP chunks = 196 blocks: 6 rounds + 1 round for 4 blocks was 144 ms; MMG_SCAN_TAIL=0 keeps that.)
+  int nfull = nSb / per, tail_k = -1;
+  {
+    const char* e = std::getenv("MMG_SCAN_TAIL");
+    const int r = nSb - nfull * per;
+    if (r > 0 && !(e && e[0] == '0') && std::getenv("MMG_W4S_ABL") == nullptr) {
+      double best = 1.0;
+      for (int k = 0; k < 2; ++k) {
+        const int as = md.AS >> (k + 1);
+        if (as < 1 || !md.tail_off[md.range][k]) continue;
+        const double cost = (double)((r + 8 * as - 1) / (8 * as)) * as / md.AS;
+        if (cost < best - 1e-9) { best = cost; tail_k = k; }
+      }
+    }
+    if (tail_k < 0) nfull = (nSb + per - 1) / per;          // one launch covers everything
+  }
+  const int ncoh = nfull;
   int abl = 0, dist = 0;
   const int64_t smax = g->smax;
   bool fast = smax * md.Npad < (1 << 16) && smax * smax * md.Npad < (1 << 18);
@@ -348,9 +366,18 @@ void launch_scan_quad_w4s(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model&
   do {                                                                                                                  \
     hipFuncSetAttribute((const void*)scan_quad_w4s_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                         LDS_BYTES);                                                                                     \
-    hipLaunchKernelGGL((scan_quad_w4s_kernel<__VA_ARGS__>), dim3((unsigned)(ncoh * 256)), dim3(W4_THREADS), LDS_BYTES, \
-                       ctx->stream, g->d, (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad,                               \
-                       (int64_t)md.Npad * md.Npad, md.job_off, md.jobs, md.AS, q, dbg, la);                             \
+    if (ncoh > 0)                                                                                                       \
+      hipLaunchKernelGGL((scan_quad_w4s_kernel<__VA_ARGS__>), dim3((unsigned)(ncoh * 256)), dim3(W4_THREADS), LDS_BYTES, \
+                         ctx->stream, g->d, (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad,                             \
+                         (int64_t)md.Npad * md.Npad, md.job_off, md.jobs, md.AS, 0, q, dbg, la);                        \
+    if (tail_k >= 0) {                                                                                                  \
+      const int as_t = md.AS >> (tail_k + 1), r_t = nSb - ncoh * per;                                                   \
+      const int ncoh_t = (r_t + 8 * as_t - 1) / (8 * as_t);                                                             \
+      hipLaunchKernelGGL((scan_quad_w4s_kernel<__VA_ARGS__>), dim3((unsigned)(ncoh_t * 256)), dim3(W4_THREADS),         \
+                         LDS_BYTES, ctx->stream, g->d, (int64_t)g->Npad, nSb, md.Bq, (int64_t)md.Npad,                  \
+                         (int64_t)md.Npad * md.Npad, md.tail_off[md.range][tail_k], md.tail_jobs[md.range][tail_k],     \
+                         as_t, ncoh * per, q, dbg, la);                                                                 \
+    }                                                                                                                   \
   } while (0)
   LinArgs la{nullptr, -1, -1};
   const bool use_lin = lin != nullptr && lin->raw != nullptr && scan_lin_usable(g, md);

@@ -42,6 +42,12 @@ struct mmg_scan_model {
   int *job_off_hi = nullptr, *job_off_lo = nullptr;
   int2 *jobs_hi = nullptr, *jobs_lo = nullptr;
   int njobs_hi = 0, njobs_lo = 0;
+  // The last, partly filled cohort of a launch runs with fewer SNP blocks per XCD and the jobs split over more groups
+  // (AS / 2, AS / 4): a round of it is 2x / 4x shorter.  Schedules per plane range (0 all planes, 1 upper planes,
+  // 2 plane 0) and halving (0: AS / 2, 1: AS / 4); `range` says which of them this (shallow copy of the) model runs.
+  int range = 0;
+  int* tail_off[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  int2* tail_jobs[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
   // linear rows (api.hip:add_linear_rows): rows Npad-16 .. Npad-1 of the top digit plane hold digit images of w and
   // diag(A) and a row of ones, so that the quadratic-form GEMM yields s.w, sum diag_i s_i and sum s_i of every SNP as
   // a by-product (binary stores) and the finalize pass need not read the genotype store a second time
