@@ -375,3 +375,33 @@ def test_reml_band_route_reports_an_indefinite_matrix(ctx):
     s = reml.sums([50.0], route="band")                       # large enough a delta makes it definite again
     assert np.isfinite(s[0][0])
     reml.close()
+
+
+def test_emmax_routes_agree_just_above_the_eigen_free_threshold(ctx, monkeypatch):
+    """linear_models.emmax() at N = 8,500 (> EIGEN_FREE_MIN_N: REML through the band reduction, scan model from one
+    Cholesky factorisation, no eigh) against the same call with the threshold raised (eigh of K, REML from eig_L, the
+    reference's route :1233-1267): variance components to 1e-8, p-values to 1e-7 relative -- with a cofactor, so that
+    q = 2 runs through the banded solves."""
+    from mixmogam_amd import linear_models as lm
+    n, m = 8500, 3000
+    assert n > lm.EIGEN_FREE_MIN_N
+    g = ctx.geno(M=m, N=n).fill_structured(77, npop=3)
+    rows = g.download()
+    acc = ctx.kinship_accumulator(n)
+    acc.add_grm(g)
+    K, cnt = acc.fetch()
+    acc.close()
+    K = K / cnt
+    rng = np.random.RandomState(3)
+    cof = rng.standard_normal(n)
+    y = rng.standard_normal(n) + 0.4 * cof + 0.8 * rows[5] - 0.7 * rows[99] + 2.0 * (K @ rng.standard_normal(n)) / np.sqrt(n)
+    a = lm.emmax(g, list(y), K, cofactors=[cof], ctx=ctx)
+    assert a["timings"]["eig_L"] == 0.0                       # the eigendecomposition-free branch ran
+    monkeypatch.setattr(lm, "EIGEN_FREE_MIN_N", 10 ** 9)
+    b = lm.emmax(g, list(y), K, cofactors=[cof], ctx=ctx)
+    assert b["timings"]["eig_L"] > 0.0
+    for k in ("pseudo_heritability", "ve", "vg", "max_ll"):
+        assert abs(a[k] - b[k]) <= 1e-8 * max(1.0, abs(b[k])), (k, a[k], b[k])
+    assert rel(a["ps"], b["ps"]) < 1e-7
+    assert rel(a["h0_rss"], b["h0_rss"]) < 1e-9
+    g.close()
