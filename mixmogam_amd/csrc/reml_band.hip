@@ -5,20 +5,23 @@
 // config 5 on one GPU.  The sums depend on K only through functions of K + delta I, and those commute with any
 // orthogonal similarity: with K = Q B Q', B symmetric of bandwidth 64,
 //     log|K + dI| = log|B + dI|,  tr (K + dI)^-1 = tr (B + dI)^-1,  z'(K + dI)^-k z = (Q'z)'(B + dI)^-k (Q'z),
-// so K is reduced ONCE (blocked Householder band reduction, 4/3 N^3 flop of level-3 BLAS: one QR of the block column
+// so K is reduced ONCE (blocked Householder band reduction, 4/3 N^3 flop of matrix-matrix work: one QR of the block column
 // below the band + one symmetric rank-2b update of the trailing matrix per 64 columns) and every delta afterwards costs
 // O(N b^2): a banded Cholesky factorisation, banded triangular solves for the q+1 rotated columns of [X y], and the
 // band of the inverse (Takahashi's recurrence) for the trace.  All deltas of a call run side by side, one wavefront
 // each; nothing per delta touches an N x N matrix.  The scan model at the chosen delta still comes from reml_chol.hip
 // (it needs P itself).
 //
-// Per-delta kernels (one 64-lane wave per delta; lane t owns the columns / unknowns whose index is t mod 64, so the
-// 64-column window that a step touches is spread over the lanes and never moves between registers):
-//   band_factor_kernel  right-looking Cholesky of B + dI; the pivot column goes through LDS to the other lanes
-//   band_solve_kernel   forward and backward substitution per column of Q'[X y], L streamed in 64-column chunks via LDS
+// Reduction kernels: panel_qr_step_kernel (Householder QR of a tall 64-column panel, one launch per column),
+// sym_skinny_kernel (A22 V from the lower triangle on the fp64 matrix pipe), tsmm_tn_kernel (tall-skinny products);
+// the rank-128 update of the trailing matrix and the small products are rocBLAS GEMMs.
+// Per-delta kernels (one workgroup per delta; lane t of a wave owns the columns / unknowns whose index is t mod 64, so
+// the 64-column window that a step touches is spread over the lanes and never moves between registers):
+//   band_factor_kernel  right-looking Cholesky of B + dI on four waves; the pivot column goes through LDS to the others
+//   band_solve_kernel   forward and backward substitution per column of Q'[X y] as column sweeps, L streamed through LDS
 //   band_trace_kernel   Z = (B + dI)^-1 inside the band, from the last column up; the 64 x 64 window of Z lives in LDS
-// Roofline: the reduction is fp64 level-3 BLAS (rocBLAS); the per-delta kernels are latency chains of N steps
-// (N = 50,000: tens of ms for the whole grid) -- off the SNPs/s metric either way.
+// Roofline: the reduction is fp64 matrix work (own kernel at 32 TFLOP/s + rocBLAS); the per-delta kernels are latency
+// chains of N steps (N = 50,000: ~0.1 s for the whole grid) -- off the SNPs/s metric either way.
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
