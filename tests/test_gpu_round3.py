@@ -405,3 +405,24 @@ def test_emmax_routes_agree_just_above_the_eigen_free_threshold(ctx, monkeypatch
     assert rel(a["ps"], b["ps"]) < 1e-7
     assert rel(a["h0_rss"], b["h0_rss"]) < 1e-9
     g.close()
+
+
+def test_reml_band_route_on_a_rank_deficient_kinship(ctx):
+    """Fewer SNPs than individuals (K of rank m - 1 = 299 at n = 600) and the whole grid of get_estimates,
+    delta = e^-10 .. e^10: K + delta I has condition 1e5 at the small end; the band route still meets 1e-9 against dense
+    float64 (measured 1e-11 there, 1e-15 from delta = 0.1 up)."""
+    rng = np.random.RandomState(1)
+    n, m = 600, 300
+    S = (rng.random_sample((m, n)) < 0.4).astype(np.float64)
+    Z = (S - S.mean(1, keepdims=True)) / S.std(1, keepdims=True)
+    K = Z.T @ Z / m
+    X = np.ones((n, 1))
+    y = rng.standard_normal(n)
+    deltas = np.exp(np.linspace(-10, 10, 11))
+    reml = ctx.reml(K, X, y)
+    band = reml.sums(deltas, route="band")
+    reml.close()
+    for k, d in enumerate(deltas):
+        want = _reml_sums_f64(K, X, y, d)
+        for i in range(4):
+            assert abs(band[i][k] - want[i]) <= 1e-9 * max(abs(want[i]), 1.0), (d, i, band[i][k], want[i])
