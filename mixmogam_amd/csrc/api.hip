@@ -754,11 +754,14 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
   // w8: the individual-major generations.
   static const bool tr_off = [] { const char* e = std::getenv("MMG_KIN_KERNEL"); return e && (std::string(e) == "w4" || std::string(e) == "w8"); }();
   const bool direct = !tr_off;
+  // binary store and four planes: ONE pass over the genotypes computes all four (gemm_i8_grm4.h: the scaled operands are
+  // formed in registers from the plain tiles) -- no digit images at all.  MMG_GRM_FUSED=0: one GEMM per plane.
+  const bool fused = [&] { const char* e = std::getenv("MMG_GRM_FUSED"); return direct && D == 4 && g->smax <= 1 && g->sneg == 0 && !(e && e[0] == '0'); }();
   const int64_t M = g->M, CH = kin_chunk();
   const int64_t Mk_max = std::min(round_up(M, BK), CH);
   // per-SNP mean / std in fp64 on the device, weights and digits on the host (M values)
   {
-    const size_t need_img = (size_t)g->Npad * Mk_max, need_c32 = (size_t)g->Npad * g->Npad;
+    const size_t need_img = fused ? 16 : (size_t)g->Npad * Mk_max, need_c32 = (size_t)g->Npad * g->Npad;
     if (ws.cap_img < need_img || ws.cap_c32 < need_c32 || ws.capD < D || ws.cap_m < (size_t)M || ws.cap_mk < (size_t)Mk_max ||
         ws.cap_n < (size_t)g->Npad || ws.direct != direct) {
       ws.release();
@@ -824,15 +827,20 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
     {
       EvScope ev(ctx, EV_PACK);
       if (direct)   // digit images + c1[i] = sum_m (a b)_m s_mi of the chunk in one pass over the store
-        launch_grm_scale_rows(ctx, Srow, std::min<int64_t>(Mk, g->Mpad - mb), Mk, g->Npad, g->sneg > 0, Xp, ddig, D, dcoef,
-                              ws.dpart, dc1);
+        launch_grm_scale_rows(ctx, Srow, std::min<int64_t>(Mk, g->Mpad - mb), Mk, g->Npad, g->sneg > 0, Xp, ddig, fused ? 0 : D,
+                              dcoef, ws.dpart, dc1);
       else
         launch_transpose_digits(ctx, g, Xq, Xp, Mk, mb, ddig, D);
     }
     MMG_HIP(ctx, hipGetLastError());
     const double tp1 = verbose ? now() : 0.0;
     tv_pack += tp1 - tp0;
-    for (int d = 0; d < D && rc == MMG_OK; ++d) {
+    if (fused) {
+      rc = run_kinship_grm4(ctx, Srow, g->Npad, g->Npad, Mk / BK, ddig, Mk, C32);
+      double a = 0.0;
+      if (rc == MMG_OK && mmg_last_kernel_ms(ctx, EV_KIN, &a) == MMG_OK) kin_ms += a;
+    }
+    for (int d = 0; d < D && rc == MMG_OK && !fused; ++d) {
       if (direct)
         rc = run_kinship_i8_tr(ctx, Xp + (size_t)d * g->Npad * Mk, Srow, g->Npad, g->Npad, Mk / BK,
                                C32 + (size_t)d * g->Npad * g->Npad);

@@ -1,0 +1,254 @@
+// gemm_i8_grm4.h -- the FOUR digit planes of the exact GRM of a binary store in one pass over the genotypes.
+//
+// api.hip writes the weighted Gram matrix sum_m omega_m s_m s_m' as sum_d 128^d C_d, C_d = (diag(dig_d) S)' S with the
+// 7-bit digits dig_d(m) of the weight of SNP m: four int8 GEMMs over the same 5 GB store, each with its own digit-scaled
+// image of it (round 3: SNP-major, read through the transposed LDS reads of gemm_i8_w4tr.h).  Those GEMMs are limited by
+// what goes INTO LDS as much as by the matrix pipe (DESIGN.md 4.1 "fill bandwidth"), and the four scaled images differ
+// from the store only by a factor per k row.  Here a workgroup fills LDS with the PLAIN genotype tiles once per K step
+// and forms the four scaled operands in registers: genotype bytes are 0 / 1, so (dword + 0x7f7f7f7f) ^ 0x7f7f7f7f turns them
+// into byte masks and one v_and with the digits of the lane's four k rows is the product -- 24 VALU ops per 16 MFMA, in the
+// shadow of the matrix pipe.  Per K step (128 SNP rows) a workgroup computes a 128 x 128 tile of ALL FOUR planes:
+//   LDS fill   32 KiB per 4 x 128 x 128 x 128 MAC   = half the bytes per MAC of the 256 x 256 single-plane tile
+//   LDS reads  4 fragments per 16 MFMA              = half of gemm_i8_w4tr.h's 8
+//   HBM        the store once instead of the store + four images (and no image pass: 6.6 ms at N = 5000 x M = 1e6)
+// Registers: wave tile 64 x 64 x 4 planes = 16 accumulator tiles of 32 x 32 (256 AGPR), as many as the 128 x 128 tile of
+// one plane.
+//
+// LDS image of an operand tile per K step: [128 k rows][128 cols] bytes (16 KiB), filled by lane-linear LDS-DMA (16 B per
+// lane, one instruction = 8 k rows x 128 B); the 16-byte chunks of row k sit at position chunk ^ (((k >> 1) & 3) << 1): a
+// transposed read of a 32-lane half covers 8 consecutive k rows x 32 bytes (an aligned chunk pair), rows k, k + 2 would
+// share banks (128 B apart) -- with the swizzle the 8 rows fall into the 8 different bank octets.  Behind the two tiles:
+// the digits of the step, [4 planes][128 k] bytes.
+//
+// Pipeline: the K step is 4 slices of 32 k rows; fragments and digits are read one slice ahead (inline asm, counted
+// lgkmcnt waits: LDS reads return in order); two LDS slots, one barrier per K step; the whole next-but-one stage is
+// issued behind the barrier, between the MFMAs of the slice that runs on registers.
+#pragma once
+#include "gemm_i8_w4tr.h"
+
+namespace mmg {
+
+constexpr int G4_T = 128;                               // tile edge (individuals)
+constexpr int G4_TILE = G4_T * BK;                      // 16 KiB per operand tile and K step
+constexpr int G4_DIG = 2 * G4_TILE;                     // offset of the digit block in a slot
+constexpr int G4_BUF = G4_DIG + 1024;                   // slot: P tile, Q tile, digits [4][128]
+constexpr int G4_LDS = 2 * G4_BUF;
+
+struct StageG4 {
+  __amdgpu_buffer_rsrc_t rs;
+  int voff;                                             // per-lane source offset (bytes)
+  int ld8;                                              // 8 * ld
+};
+
+__device__ __forceinline__ StageG4 make_stage_g4(const int8_t* base, int64_t ld, int lane) {
+  StageG4 s;
+  s.rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+  const int rp = lane >> 3, cp = lane & 7;              // k row within the 8-row piece, chunk POSITION in LDS
+  s.voff = rp * (int)ld + ((cp ^ (((rp >> 1) & 3) << 1)) << 4);
+  s.ld8 = 8 * (int)ld;
+  return s;
+}
+
+// piece i in 0..3 of this wave: k rows wave*32 + i*8 .. +8 (1 KiB of LDS)
+__device__ __forceinline__ void stage_piece_g4(const StageG4& s, char* lds_tile, int wave, int i) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rs, (MMG_AS3 void*)(lds_tile + (wave * 4 + i) * 1024), 16, s.voff,
+                                           (wave * 4 + i) * s.ld8, 0, 0);
+}
+
+// lane-constant part of a fragment address: operand columns tile_col0 + (lane & 31) .. , k half (lane >> 5)
+__device__ __forceinline__ int frag_base_g4(int tile_col0, int lane) {
+  const int i16 = lane & 15, g = lane >> 4, h = g >> 1, q = i16 >> 1;
+  const int chunk = (tile_col0 >> 4) + (g & 1);
+  return (h * 16 + q) * G4_T + ((chunk ^ (((q >> 1) & 3) << 1)) << 4) + (i16 & 1) * 8;
+}
+
+// fragment of a 32-column operand block for K slice `slice` (32 k rows): two transposed reads (k rows +0..7, +8..15)
+__device__ __forceinline__ void lds_frag_g4(v4i& f, uint32_t addr, int slice) {
+  v2i lo, hi;
+  switch (slice) {
+    case 0: asm volatile("ds_read_b64_tr_b8 %0, %2\n\tds_read_b64_tr_b8 %1, %2 offset:1024" : "=&v"(lo), "=&v"(hi) : "v"(addr)); break;
+    case 1: asm volatile("ds_read_b64_tr_b8 %0, %2 offset:4096\n\tds_read_b64_tr_b8 %1, %2 offset:5120" : "=&v"(lo), "=&v"(hi) : "v"(addr)); break;
+    case 2: asm volatile("ds_read_b64_tr_b8 %0, %2 offset:8192\n\tds_read_b64_tr_b8 %1, %2 offset:9216" : "=&v"(lo), "=&v"(hi) : "v"(addr)); break;
+    default: asm volatile("ds_read_b64_tr_b8 %0, %2 offset:12288\n\tds_read_b64_tr_b8 %1, %2 offset:13312" : "=&v"(lo), "=&v"(hi) : "v"(addr)); break;
+  }
+  f = v4i{lo.x, lo.y, hi.x, hi.y};
+}
+
+// digits of the lane's 16 k rows (k = 32 slice + 16 (lane >> 5) ..) for the four planes; addr = slot + 16 (lane >> 5)
+__device__ __forceinline__ void lds_digits_g4(v4i (&dg)[4], uint32_t addr, int slice) {
+#define MMG_G4_DIGS(O)                                                                                            \
+  asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t" \
+               "ds_read_b128 %3, %4 offset:%8"                                                                     \
+               : "=&v"(dg[0]), "=&v"(dg[1]), "=&v"(dg[2]), "=&v"(dg[3])                                            \
+               : "v"(addr), "n"(G4_DIG + (O)), "n"(G4_DIG + 128 + (O)), "n"(G4_DIG + 256 + (O)), "n"(G4_DIG + 384 + (O)))
+  switch (slice) {
+    case 0: MMG_G4_DIGS(0); break;
+    case 1: MMG_G4_DIGS(32); break;
+    case 2: MMG_G4_DIGS(64); break;
+    default: MMG_G4_DIGS(96); break;
+  }
+#undef MMG_G4_DIGS
+}
+
+struct FragG4 {
+  v4i a[2], b[2], dg[4];
+};
+
+template <int N>
+__device__ __forceinline__ void frag_wait_g4_first(FragG4& f) {
+  asm volatile("s_waitcnt lgkmcnt(%6)"
+               : "+v"(f.dg[0]), "+v"(f.dg[1]), "+v"(f.dg[2]), "+v"(f.dg[3]), "+v"(f.a[0]), "+v"(f.b[0])
+               : "n"(N));
+}
+
+struct G4Job {
+  const int8_t* P;     // column 0 of the job's 128-column P window at k row 0 of the job
+  const int8_t* Q;     // likewise for the Q window
+  const int8_t* dig;   // digit of plane 0 at k row 0 of the job; plane d at + d * dig_stride
+  int dig_stride;
+  int nks;             // K steps of 128 rows (>= 1)
+};
+
+// One slice: 16 MFMA (4 planes x 2 x 2 tiles) on `cur`; digits and fragments of (slot `src`, slice) into `nxt`;
+// with DMA: the whole stage the cursor points at into slot `dst`.
+// Counted waits.  On entry the 12 reads of `cur` are the only LDS operations in flight, in the order dg (4), a0 (2),
+// b0 (2), a1 (2), b1 (2); this slice issues its own 12 in the same order: dg right after the first wait, a0 and b0
+// during the first four MFMAs (r = 8 issued), a1 during the second four (r = 10), b1 during the third (r = 12).
+//   first MFMA: dg, a0, b0      -> at most a1, b1 = 4 outstanding        lgkmcnt(4)
+//   a1 (before MFMA 4):  b1 + r -> 2 + 8                                 lgkmcnt(10)
+//   b1 (before MFMA 8):  r      -> 10                                    lgkmcnt(10)
+template <bool DMA, bool ZERO>
+__device__ __forceinline__ void g4_slice(v16i (&acc)[4][2][2], FragG4& cur, FragG4& nxt, const char* src, const int (&ab)[2],
+                                         const int (&bb)[2], int dgb, int slice, const StageG4& sp, const StageG4& sq,
+                                         const __amdgpu_buffer_rsrc_t& rdig, int dig_voff, int dig_stride2, char* dst, int wave) {
+  const uint32_t s32 = (uint32_t)(uintptr_t)src;
+  frag_wait_g4_first<4>(cur);
+  lds_digits_g4(nxt.dg, s32 + (uint32_t)dgb, slice);
+  v4i as[4];
+  {
+    const v4i m = (cur.a[0] + 0x7f7f7f7f) ^ 0x7f7f7f7f;   // bytes 0 / 1 -> 0x00 / 0xff (no carry between bytes)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) as[d] = m & cur.dg[d];
+  }
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    acc[d][0][0] = mfma8(as[d], cur.b[0], ZERO ? v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[d][0][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (d == 0) lds_frag_g4(nxt.a[0], s32 + (uint32_t)ab[0], slice);
+    if (d == 2) lds_frag_g4(nxt.b[0], s32 + (uint32_t)bb[0], slice);
+    if (DMA) {
+      stage_piece_g4(sp, dst, wave, d);
+    }
+  }
+  frag_wait<10>(cur.a[1]);
+  v4i at[4];
+  {
+    const v4i m = (cur.a[1] + 0x7f7f7f7f) ^ 0x7f7f7f7f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) at[d] = m & cur.dg[d];
+  }
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    acc[d][1][0] = mfma8(at[d], cur.b[0], ZERO ? v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[d][1][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (d == 0) lds_frag_g4(nxt.a[1], s32 + (uint32_t)ab[1], slice);
+    if (DMA) {
+      stage_piece_g4(sq, dst + G4_TILE, wave, d);
+    }
+  }
+  frag_wait<10>(cur.b[1]);
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    acc[d][0][1] = mfma8(as[d], cur.b[1], ZERO ? v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[d][0][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (d == 0) lds_frag_g4(nxt.b[1], s32 + (uint32_t)bb[1], slice);
+    if (DMA && wave == 0 && d < 2)                        // digits: [plane 2 d + (lane >> 5)][4 (lane & 31) ..]
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdig, (MMG_AS3 void*)(dst + G4_DIG + d * 256), 4, dig_voff, d * dig_stride2, 0, 0);
+  }
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    acc[d][1][1] = mfma8(at[d], cur.b[1], ZERO ? v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[d][1][1]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Runs one job; epi(acc): acc[d][m][n] = plane d, rows = P columns wm*64 + m*32 .., columns = Q columns wn*64 + n*32 ..
+// (C layout of gemm_i8_core.h inside a 32 x 32 tile).
+template <class EpiFn>
+__device__ __forceinline__ void g4_stream(const G4Job& job, int64_t ld, char* lds, EpiFn&& epi) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int ab[2], bb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    ab[i] = frag_base_g4(wm * 64 + i * 32, lane);
+    bb[i] = frag_base_g4(wn * 64 + i * 32, lane) + G4_TILE;
+  }
+  const int dgb = (lane >> 5) * 16;
+  const int64_t kstep_bytes = (int64_t)BK * ld;
+  const int dig_voff = (lane >> 5) * job.dig_stride + (lane & 31) * 4, dig_stride2 = 2 * job.dig_stride;
+
+  // ---- issue cursor (wave-uniform): the descriptor bases move with the stage
+  int cks = 0;
+  StageG4 sp = make_stage_g4(job.P, ld, lane), sq = make_stage_g4(job.Q, ld, lane);
+  __amdgpu_buffer_rsrc_t rdig = __builtin_amdgcn_make_buffer_rsrc((void*)job.dig, 0, 0x7fffffff, 0x00020000);
+  auto rebase = [&]() {
+    sp.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(job.P + cks * kstep_bytes), 0, 0x7fffffff, 0x00020000);
+    sq.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(job.Q + cks * kstep_bytes), 0, 0x7fffffff, 0x00020000);
+    rdig = __builtin_amdgcn_make_buffer_rsrc((void*)(job.dig + (int64_t)cks * BK), 0, 0x7fffffff, 0x00020000);
+  };
+  auto advance = [&]() {
+    if (cks + 1 < job.nks) { ++cks; rebase(); }           // else: stay on the last stage (harmless re-issue)
+  };
+  auto issue_stage = [&](char* slot) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_piece_g4(sp, slot, wave, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_piece_g4(sq, slot + G4_TILE, wave, i);
+    if (wave == 0) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdig, (MMG_AS3 void*)(slot + G4_DIG), 4, dig_voff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdig, (MMG_AS3 void*)(slot + G4_DIG + 256), 4, dig_voff, dig_stride2, 0, 0);
+    }
+  };
+
+  // ---- prologue: stages 0 and 1 complete, fragments of step 0 slice 0
+  issue_stage(lds);
+  advance();
+  issue_stage(lds + G4_BUF);
+  advance();                                             // -> stage 2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  FragG4 f0, f1;
+  {
+    const uint32_t l32 = (uint32_t)(uintptr_t)lds;
+    lds_digits_g4(f0.dg, l32 + (uint32_t)dgb, 0);        // the order the counted waits assume
+    lds_frag_g4(f0.a[0], l32 + (uint32_t)ab[0], 0);
+    lds_frag_g4(f0.b[0], l32 + (uint32_t)bb[0], 0);
+    lds_frag_g4(f0.a[1], l32 + (uint32_t)ab[1], 0);
+    lds_frag_g4(f0.b[1], l32 + (uint32_t)bb[1], 0);
+  }
+
+  v16i acc[4][2][2];                                     // written (not accumulated) by the first slice of the job
+
+  for (int t = 0; t < job.nks; ++t) {
+    char* cur = lds + (t & 1) * G4_BUF;
+    char* oth = lds + ((t + 1) & 1) * G4_BUF;
+    if (t == 0) g4_slice<false, true>(acc, f0, f1, cur, ab, bb, dgb, 1, sp, sq, rdig, dig_voff, dig_stride2, oth, wave);
+    else g4_slice<false, false>(acc, f0, f1, cur, ab, bb, dgb, 1, sp, sq, rdig, dig_voff, dig_stride2, oth, wave);
+    g4_slice<false, false>(acc, f1, f0, cur, ab, bb, dgb, 2, sp, sq, rdig, dig_voff, dig_stride2, oth, wave);
+    g4_slice<false, false>(acc, f0, f1, cur, ab, bb, dgb, 3, sp, sq, rdig, dig_voff, dig_stride2, oth, wave);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // slice 3 runs on registers; slot `cur` is free: stage t+2 goes there; fragments of step t+1 slice 0 from `oth`
+    g4_slice<true, false>(acc, f1, f0, oth, ab, bb, dgb, 0, sp, sq, rdig, dig_voff, dig_stride2, cur, wave);
+    advance();                                           // -> stage t+3
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the re-issued tail stages must land before LDS is released
+  epi(acc);
+}
+
+}  // namespace mmg

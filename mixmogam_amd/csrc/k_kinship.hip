@@ -15,7 +15,7 @@
 #include <string>
 #include "gemm_i8_core.h"
 #include "gemm_i8_w4s.h"
-#include "gemm_i8_w4tr.h"
+#include "gemm_i8_grm4.h"
 #include "mmg_internal.h"
 
 namespace mmg {
@@ -118,6 +118,40 @@ __global__ __launch_bounds__(W4_THREADS) void kinship_i8_tr_kernel(const int8_t*
             }
           }
       });
+}
+
+// All four digit planes of the exact GRM of a binary store in one pass over the genotypes (gemm_i8_grm4.h): job = a
+// 128 x 128 tile pair (I, J) of individuals over SNP rows [ks0*128, ks1*128); C32[d] += (diag(dig_d) S)' S on that tile.
+__global__ __launch_bounds__(W4_THREADS) void kinship_grm4_kernel(const int8_t* __restrict__ S, int64_t ld, int32_t Npad,
+                                                                  const int8_t* __restrict__ dig, int dig_stride,
+                                                                  const KinJob* __restrict__ jobs, int* __restrict__ C32) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const KinJob job = jobs[xcd_job_index(blockIdx.x)];
+  if (job.ks1 <= job.ks0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;
+  G4Job gj;
+  gj.P = S + (int64_t)job.ks0 * BK * ld + (int64_t)job.I * G4_T;
+  gj.Q = S + (int64_t)job.ks0 * BK * ld + (int64_t)job.J * G4_T;
+  gj.dig = dig + (int64_t)job.ks0 * BK;
+  gj.dig_stride = dig_stride;
+  gj.nks = job.ks1 - job.ks0;
+  const int64_t plane = (int64_t)Npad * Npad;
+  g4_stream(gj, ld, lds, [&](v16i (&acc)[4][2][2]) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const int col = job.J * G4_T + wn * 64 + n * 32 + r;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = job.I * G4_T + wm * 64 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            atomicAdd(C32 + d * plane + (int64_t)row * Npad + col, acc[d][m][n][i]);
+          }
+        }
+  });
 }
 
 // The raw-genotype product of a BINARY store on FP4 operands (gemm_i8_w4tr.h FmtF4): v_mfma_scale_f32_32x32x64_f8f6f4
@@ -442,6 +476,40 @@ int run_kinship_f4_tr(mmg_ctx* ctx, Scratch& sc, const uint8_t* X4, int32_t Npad
   hipLaunchKernelGGL(kinship_f4_tr_kernel, dim3((unsigned)jobs.size()), dim3(W4_THREADS), LDS_BYTES, ctx->stream,
                      (const int8_t*)X4, (int64_t)(Npad / 2), Npad, djobs, C32);
   MMG_HIP(ctx, hipGetLastError());
+  return MMG_OK;
+}
+
+// C32[d] (tiles of the upper 256-tile triangle, d = 0..3) += (diag(dig_d) S)' S over rows [0, nk * 128) of the store;
+// dig: device [4][dig_stride] digit bytes.  Binary stores only (the scaling is a byte mask).
+int run_kinship_grm4(mmg_ctx* ctx, const int8_t* S, int64_t ld, int32_t Npad, int64_t nk, const int8_t* dig, int64_t dig_stride,
+                     int* C32) {
+  const int nT = Npad / G4_T;
+  std::vector<std::pair<int, int>> tiles;                 // every 128-tile of the 256-tiles (I <= J) the combine pass reads
+  const int PI = 8, PJ = 16;
+  for (int Ib = 0; Ib < nT; Ib += PI)
+    for (int Jb = 0; Jb < nT; Jb += PJ)
+      for (int I = Ib; I < std::min(Ib + PI, nT); ++I)
+        for (int J = Jb; J < std::min(Jb + PJ, nT); ++J)
+          if ((I >> 1) <= (J >> 1)) tiles.push_back({I, J});
+  const int ksplit = choose_ksplit((int)tiles.size(), (int)nk, 8, 64);
+  std::vector<KinJob> jobs;
+  for (int s = 0; s < ksplit; ++s) {
+    const int k0 = (int)((int64_t)nk * s / ksplit), k1 = (int)((int64_t)nk * (s + 1) / ksplit);
+    for (auto& t : tiles) jobs.push_back(KinJob{t.first, t.second, k0, k1, s, 0, 0, 0});
+  }
+  while (jobs.size() % 256) jobs.push_back(KinJob{0, 0, 0, 0, 0, 0, 0, 0});
+  KinJob* djobs = nullptr;
+  MMG_HIP(ctx, hipMalloc(&djobs, jobs.size() * sizeof(KinJob)));
+  MMG_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(KinJob), hipMemcpyHostToDevice, ctx->stream));
+  MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_grm4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
+  {
+    EvScope ev(ctx, EV_KIN);
+    hipLaunchKernelGGL(kinship_grm4_kernel, dim3((unsigned)jobs.size()), dim3(W4_THREADS), G4_LDS, ctx->stream, S, ld, Npad, dig,
+                       (int)dig_stride, djobs, C32);
+  }
+  MMG_HIP(ctx, hipGetLastError());
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MMG_HIP(ctx, hipFree(djobs));
   return MMG_OK;
 }
 

@@ -402,7 +402,8 @@ void launch_grm_scale_rows(mmg_ctx* ctx, const int8_t* S, int64_t rows_valid, in
 #define MMG_GS(D_, NEG_)                                                                                              \
   hipLaunchKernelGGL((grm_scale_rows_kernel<D_, NEG_>), grid, dim3(256), 0, ctx->stream, S, rows_valid, Mk, Npad, Xp, dig, \
                      coef, partial)
-  if (neg) { if (D == 4) MMG_GS(4, true); else if (D == 5) MMG_GS(5, true); else MMG_GS(6, true); }
+  if (D == 0) MMG_GS(0, false);                            // only the weighted column sums (the fused 4-plane GEMM scales in registers)
+  else if (neg) { if (D == 4) MMG_GS(4, true); else if (D == 5) MMG_GS(5, true); else MMG_GS(6, true); }
   else { if (D == 4) MMG_GS(4, false); else if (D == 5) MMG_GS(5, false); else MMG_GS(6, false); }
 #undef MMG_GS
   hipLaunchKernelGGL(grm_colsum_reduce_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, ctx->stream, partial,

@@ -163,6 +163,9 @@ void launch_pack_fp4_on(mmg_ctx*, hipStream_t stream, const int8_t* S, int64_t r
                         bool binary);   // [s >= thr] (the genotypes themselves for binary stores, thr 1) as E2M1 nibbles
 int run_kinship_f4_tr(mmg_ctx*, mmg::Scratch& sc, const uint8_t* X4, int32_t Npad, int64_t nk4, int* C32);   // enqueues, no sync
 int run_kinship_i8_tr(mmg_ctx*, const int8_t* Sp, const int8_t* Sq, int64_t ld, int32_t Npad, int64_t nk, int* C32);
+// all four digit planes of the exact GRM of a binary store in one pass (gemm_i8_grm4.h); dig: device [4][dig_stride]
+int run_kinship_grm4(mmg_ctx*, const int8_t* S, int64_t ld, int32_t Npad, int64_t nk, const int8_t* dig, int64_t dig_stride,
+                     int* C32);
 int run_kinship_i8(mmg_ctx*, const int8_t* Xt, int32_t Npad, int64_t Mk, int* C32);
 int run_kinship_i8_pq(mmg_ctx*, const int8_t* Xp, const int8_t* Xq, int32_t Npad, int64_t Mk, int* C32);
 void launch_grm_combine(mmg_ctx*, const int* C32, int D, int32_t Npad, int32_t N, double step, double base,
