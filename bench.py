@@ -222,8 +222,15 @@ def main():
             wall.append(1e3 * (time.time() - t0))
         grm = {"wall_ms": min(wall[1:]), "first_call_wall_ms": wall[0], "digit_plane_gemms_ms": ctx.kernel_ms("grm"),
                "pack_ms": pack_ms(),
+               # executed: 4 planes x the 128-tiles of the upper 256-tile triangle x 2 ops per MAC
+               "executed_int8_tops": (4.0 * 2.0 * 256.0 * 256.0 * ((-(-N // 256)) * (-(-N // 256) + 1) / 2) * M
+                                      / (ctx.kernel_ms("grm") * 1e-3) / 1e12),
+               "kernel": "kinship_grm4_kernel" if os.environ.get("MMG_GRM_FUSED", "1") != "0" else "kinship_i8_tr_kernel x 4",
                "note": "mmg_kin_acc_add_grm: z z' = a^2 s s' + ab(s 1' + 1 s') + b^2 1 1', the weighted Gram matrix as 4 "
-                       "exact int8-MFMA GEMMs (kinship_i8_w4_kernel, digit image x plain image); compare kinship_f32_kernel"}
+                       "exact int8 digit planes of the weights -- all four from ONE pass over the plain genotype tiles "
+                       "(kinship_grm4_kernel: the digit scaling is a byte mask in registers; pack_ms = the weighted column "
+                       "sums); MMG_GRM_FUSED=0: one transposed-read GEMM per plane over digit-scaled images; compare "
+                       "kinship_f32_kernel"}
         acc.close()
     K = kinship.scale_k(counts.astype(np.float64) / (2.0 * Mtot) + 0.5)
 

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "mmg_kin_acc_add": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mmg_kin_acc_add_grm": (C.c_int, [c_vp, c_vp, c_vp]),
     "mmg_kin_acc_fetch": (C.c_int, [c_vp, c_vp, c_vp, c_i64p]),
+    "mmg_kin_acc_scale_k": (C.c_int, [c_vp, c_vp, c_f64p]),
     "mmg_kin_acc_destroy": (C.c_int, [c_vp, c_vp]),
     "mmg_kinship_i8": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp, c_vp, c_vp]),
     "mmg_scan_last_stats": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -311,6 +312,13 @@ class KinshipAccumulator(object):
     def allreduce(self, comm):
         """Sum the device-resident accumulator (and its SNP count) over the ranks of `comm` in HBM."""
         self.ctx._check(self.ctx.lib.mmg_kin_acc_allreduce(self.ctx.h, comm, self.h))
+
+    def scale_k(self):
+        """kinship.scale_k (kinship.py:94-100) applied to the device-resident sum in place; returns the factor.  The
+        rule does not change under a prior division by the SNP count, so fetch() afterwards yields the scaled kinship."""
+        f = C.c_double(0.0)
+        self.ctx._check(self.ctx.lib.mmg_kin_acc_scale_k(self.ctx.h, self.h, C.byref(f)))
+        return f.value
 
     def fetch(self):
         out = np.empty((self.N, self.N))

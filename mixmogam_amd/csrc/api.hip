@@ -908,6 +908,29 @@ int mmg_kin_acc_fetch(mmg_ctx* ctx, mmg_kin_acc* a, double* C_out, int64_t* n_sn
   return MMG_OK;
 }
 
+int mmg_kin_acc_scale_k(mmg_ctx* ctx, mmg_kin_acc* a, double* scalar_out) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, a != nullptr);
+  Scratch sc;
+  const int64_t N = a->N;
+  double* drow = nullptr;
+  MMG_HIP(ctx, sc.alloc(&drow, 2 * N * sizeof(double)));
+  launch_row_sums_f64(ctx, a->dC, N, drow, drow + N);          // row sums and the diagonal, fixed summation order
+  std::vector<double> h((size_t)2 * N);
+  MMG_HIP(ctx, hipMemcpyAsync(h.data(), drow, 2 * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double total = 0.0, trace = 0.0;
+  for (int64_t i = 0; i < N; ++i) { total += h[i]; trace += h[N + i]; }
+  const double c = trace - total / (double)N;
+  if (!(c > 0.0) || !std::isfinite(c)) return set_err(ctx, MMG_E_ARG, "scale_k: tr K - sum K / N is not positive");
+  const double scalar = (double)(N - 1) / c;
+  launch_scale_f64(ctx, a->dC, N * N, scalar);
+  MMG_HIP(ctx, hipGetLastError());
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (scalar_out) *scalar_out = scalar;
+  return MMG_OK;
+}
+
 int mmg_kin_acc_allreduce(mmg_ctx* ctx, mmg_comm* comm, mmg_kin_acc* a) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, a != nullptr);

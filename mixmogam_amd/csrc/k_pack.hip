@@ -391,6 +391,35 @@ __global__ void grm_colsum_reduce_kernel(const double* __restrict__ partial, int
   c1[i] = s;
 }
 
+__global__ __launch_bounds__(256) void row_sums_f64_kernel(const double* __restrict__ A, int64_t N, double* __restrict__ rows,
+                                                           double* __restrict__ diag) {
+  const int64_t i = blockIdx.x;
+  const double* a = A + i * N;
+  double s = 0.0;
+  for (int64_t j = threadIdx.x; j < N; j += 256) s += a[j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  __shared__ double w[4];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { rows[i] = (w[0] + w[1]) + (w[2] + w[3]); diag[i] = a[i]; }
+}
+
+__global__ void scale_f64_kernel(double* __restrict__ x, int64_t n, double f) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (i + 1 < n) { double2 v = *(double2*)(x + i); v.x *= f; v.y *= f; *(double2*)(x + i) = v; }
+  else if (i < n) x[i] *= f;
+}
+
+void launch_row_sums_f64(mmg_ctx* ctx, const double* A, int64_t N, double* rows, double* diag) {
+  hipLaunchKernelGGL(row_sums_f64_kernel, dim3((unsigned)N), dim3(256), 0, ctx->stream, A, N, rows, diag);
+}
+
+void launch_scale_f64(mmg_ctx* ctx, double* x, int64_t n, double f) {
+  const int64_t pairs = (n + 1) / 2;
+  hipLaunchKernelGGL(scale_f64_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, ctx->stream, x, n, f);
+}
+
 int64_t grm_partial_doubles(int64_t Mk, int32_t Npad) { return (Mk + GRM_SLAB - 1) / GRM_SLAB * (int64_t)Npad; }
 
 // S: first row of the chunk in the store (row stride Npad); rows_valid: rows of the chunk that exist in the store

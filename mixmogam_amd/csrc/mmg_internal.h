@@ -156,6 +156,10 @@ void launch_transpose(mmg_ctx*, const mmg_geno*, int8_t* Xt, int64_t Mk, int mul
 void launch_snp_stats(mmg_ctx*, const mmg_geno*, double* mean, double* sd);
 void launch_absmax_i8(mmg_ctx*, const int8_t* p, int64_t bytes, int* d_out);   // d_out[0] = max(d_out[0], max |p[i]|), d_out[1] likewise for max(-p[i]); bytes % 16 == 0
 
+// row sums and diagonal of a row-major fp64 [N x N] matrix (one block per row, fixed order); x[i] *= f
+void launch_row_sums_f64(mmg_ctx*, const double* A, int64_t N, double* rows, double* diag);
+void launch_scale_f64(mmg_ctx*, double* x, int64_t n, double f);
+
 // ---- k_kinship.hip
 int kinship_pick_ksplit(int32_t Npad, int64_t Mk, bool f32);
 // C32 [Npad x Npad] int32 += Xt Xt^T (upper-triangular tiles only, mirrored by the caller).

@@ -426,3 +426,23 @@ def test_reml_band_route_on_a_rank_deficient_kinship(ctx):
         want = _reml_sums_f64(K, X, y, d)
         for i in range(4):
             assert abs(band[i][k] - want[i]) <= 1e-9 * max(abs(want[i]), 1.0), (d, i, band[i][k], want[i])
+
+
+def test_scale_k_on_the_device_equals_the_host_rule(ctx):
+    """mmg_kin_acc_scale_k: kinship.py:94-100 applied to the accumulated sum in HBM == kinship.scale_k(K / n_snps) on the
+    host (the rule is invariant under the division); 1e-13: summation order only."""
+    from mixmogam_amd import kinship
+    rng = np.random.RandomState(2)
+    for n, m in ((300, 4000), (2500, 3000)):                 # either branch of the host rule (n <= 2048 / beyond)
+        snps = (rng.random_sample((m, n)) < rng.uniform(0.1, 0.9, size=(m, 1))).astype(np.int8)
+        snps = snps[snps.std(1) > 0]
+        g = ctx.geno(snps)
+        acc = ctx.kinship_accumulator(n)
+        acc.add_grm(g)
+        raw, cnt = acc.fetch()
+        want = kinship.scale_k(raw / float(cnt))
+        f = acc.scale_k()
+        got, _ = acc.fetch()
+        acc.close(); g.close()
+        assert np.max(np.abs(got - want)) <= 1e-13 * np.max(np.abs(want)), n
+        assert abs(f * cnt / ((n - 1) / (np.trace(raw / cnt) - (raw / cnt).sum() / n)) - 1) < 1e-12
