@@ -485,7 +485,8 @@ int run_kinship_grm4(mmg_ctx* ctx, const int8_t* S, int64_t ld, int32_t Npad, in
                      int* C32) {
   const int nT = Npad / G4_T;
   std::vector<std::pair<int, int>> tiles;                 // every 128-tile of the 256-tiles (I <= J) the combine pass reads
-  const int PI = 8, PJ = 16;
+  int PI = 8, PJ = 16;                                    // patch of the tile order: consecutive jobs share operand panels in L2
+  if (const char* e = std::getenv("MMG_GRM4_PATCH")) { int a = 0, b = 0; if (std::sscanf(e, "%dx%d", &a, &b) == 2 && a > 0 && b > 0) { PI = a; PJ = b; } }
   for (int Ib = 0; Ib < nT; Ib += PI)
     for (int Jb = 0; Jb < nT; Jb += PJ)
       for (int I = Ib; I < std::min(Ib + PI, nT); ++I)
