@@ -20,11 +20,11 @@
 // share banks (128 B apart) -- with the swizzle the 8 rows fall into the 8 different bank octets.  Behind the two tiles:
 // the digits of the step, [4 planes][128 k] bytes.
 //
-// Pipeline: the K step is 4 slices of 32 k rows; fragments and digits are read one slice ahead (inline asm, counted
-// lgkmcnt waits: LDS reads return in order); two LDS slots, one barrier per K step; the whole next-but-one stage is
-// issued behind the barrier, between the MFMAs of the slice that runs on registers.  (Three slots with stage t + 3
-// issued at step t and a counted vmcnt at the barrier -- two K steps for a stage to arrive instead of one -- were
-// slower: 38.4 against 36.9 ms at N = 5000 x M = 1e6, 341 against 318 ms at N = 50,000 x 100,000.)
+// Pipeline: the K step is 4 slices of 32 k rows; raw fragments and digits are read two slices ahead and scaled one slice
+// ahead (inline asm reads, one lgkmcnt(0) per slice when only reads issued a whole slice ago are outstanding); two LDS
+// slots, one barrier per K step, stage t + 2 issued behind it.  Timing ablations at N = 5000 x M = 1e6 (MMG_GRM4_ABL):
+// 36.3 ms as is, 30.1 without the DMA, 28.8 without LDS reads and scaling -- the matrix pipe alone; a third slot (stage
+// t + 3 issued at step t, counted vmcnt at the barrier) made it slower (37.6): what the DMA costs is not its latency.
 #pragma once
 #include "gemm_i8_w4tr.h"
 
@@ -92,16 +92,14 @@ __device__ __forceinline__ void lds_digits_g4(v4i (&dg)[4], uint32_t addr, int s
 #undef MMG_G4_DIGS
 }
 
-struct FragG4 {
-  v4i a[2], b[2], dg[4];
+// operands of one slice, ready for the MFMAs: the digit-scaled A fragments of both 32-column blocks for the four
+// planes, the raw B fragments
+struct OpsG4 {
+  v4i as[4], at[4], b[2];
 };
 
-template <int N>
-__device__ __forceinline__ void frag_wait_g4_first(FragG4& f) {
-  asm volatile("s_waitcnt lgkmcnt(%6)"
-               : "+v"(f.dg[0]), "+v"(f.dg[1]), "+v"(f.dg[2]), "+v"(f.dg[3]), "+v"(f.a[0]), "+v"(f.b[0])
-               : "n"(N));
-}
+// bytes 0 / 1 -> 0x00 / 0xff (no carry between bytes)
+__device__ __forceinline__ v4i byte_mask_g4(v4i x) { return (x + 0x7f7f7f7f) ^ 0x7f7f7f7f; }
 
 struct G4Job {
   const int8_t* P;     // column 0 of the job's 128-column P window at k row 0 of the job
@@ -111,72 +109,67 @@ struct G4Job {
   int nks;             // K steps of 128 rows (>= 1)
 };
 
-// One slice: 16 MFMA (4 planes x 2 x 2 tiles) on `cur`; digits and fragments of (slot `src`, slice) into `nxt`;
-// with DMA: the whole stage the cursor points at into slot `dst`.
-// Counted waits.  On entry the 12 reads of `cur` are the only LDS operations in flight, in the order dg (4), a0 (2),
-// b0 (2), a1 (2), b1 (2); this slice issues its own 12 in the same order: dg right after the first wait, a0 and b0
-// during the first four MFMAs (r = 8 issued), a1 during the second four (r = 10), b1 during the third (r = 12).
-//   first MFMA: dg, a0, b0      -> at most a1, b1 = 4 outstanding        lgkmcnt(4)
-//   a1 (before MFMA 4):  b1 + r -> 2 + 8                                 lgkmcnt(10)
-//   b1 (before MFMA 8):  r      -> 10                                    lgkmcnt(10)
-template <bool DMA, bool ZERO>
-__device__ __forceinline__ void g4_slice(v16i (&acc)[4][2][2], FragG4& cur, FragG4& nxt, const char* src, const int (&ab)[2],
-                                         const int (&bb)[2], int dgb, int slice, const StageG4& sp, const StageG4& sq,
-                                         const __amdgpu_buffer_rsrc_t& rdig, int dig_voff, int dig_stride2, char* dst, int wave) {
+// raw operands of a slice as they come out of LDS
+struct RawG4 {
+  v4i dg[4], a[2], b[2];
+};
+
+__device__ __forceinline__ void wait_raw_g4(RawG4& r) {       // all LDS reads issued so far have landed
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(r.dg[0]), "+v"(r.dg[1]), "+v"(r.dg[2]), "+v"(r.dg[3]), "+v"(r.a[0]), "+v"(r.a[1]), "+v"(r.b[0]), "+v"(r.b[1]));
+}
+
+// One slice g: 16 MFMA (4 planes x 2 x 2 tiles) on `cur` = operands of slice g; the raw fragments of slice g + 1 (`rin`,
+// read during slice g - 1) become `nxt`; the raw fragments of slice g + 2 are read from (slot `src`, k-slice `slice`)
+// into `rout`; with DMA_P / DMA_Q: half of the stage the cursor points at goes into slot `dst`.
+// The matrix pipe takes a 32x32x32 int8 MFMA every 32 cycles = 8 issue slots per MFMA for everything else, the MFMA
+// itself included; the 48 VALU operations of the scaling, the 12 LDS reads and the DMA are dealt out over the 16 gaps,
+// at most 5 per gap: gaps 0-3 the byte masks of a0 / a1 (+ a DMA piece), 4-6 the LDS reads, 7-14 the eight scaled
+// fragments.  (With all of the scaling at the head of the slice that consumes it, or bunched in 8 per gap, the matrix
+// pipe stood at 64 % busy.)  Two slices of distance between a read and its use: ONE wait per slice, lgkmcnt(0) on entry,
+// when only reads issued a whole slice ago are outstanding.
+template <bool DMA_P, bool DMA_Q, bool ZERO, int ABL = 0>
+__device__ __forceinline__ void g4_slice(v16i (&acc)[4][2][2], const OpsG4& cur, OpsG4& nxt, RawG4& rin, RawG4& rout,
+                                         const char* src, const int (&ab)[2], const int (&bb)[2], int dgb, int slice,
+                                         const StageG4& sp, const StageG4& sq, const __amdgpu_buffer_rsrc_t& rdig, int dig_voff,
+                                         int dig_stride2, char* dst, int wave) {
   const uint32_t s32 = (uint32_t)(uintptr_t)src;
-  frag_wait_g4_first<4>(cur);
-  lds_digits_g4(nxt.dg, s32 + (uint32_t)dgb, slice);
-  v4i as[4];
-  {
-    const v4i m = (cur.a[0] + 0x7f7f7f7f) ^ 0x7f7f7f7f;   // bytes 0 / 1 -> 0x00 / 0xff (no carry between bytes)
+  const v16i zero = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  v4i m0, m1;
+  if (ABL != 2) wait_raw_g4(rin);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) as[d] = m & cur.dg[d];
-  }
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    acc[d][0][0] = mfma8(as[d], cur.b[0], ZERO ? v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[d][0][0]);
+  for (int i = 0; i < 16; ++i) {
+    const int m = (i >> 2) & 1, n = i >> 3, d = i & 3;    // (as, b0) x 4, (at, b0) x 4, (as, b1) x 4, (at, b1) x 4
+    acc[d][m][n] = mfma8(m ? cur.at[d] : cur.as[d], cur.b[n], ZERO ? zero : acc[d][m][n]);
     __builtin_amdgcn_sched_barrier(0);
-    if (d == 0) lds_frag_g4(nxt.a[0], s32 + (uint32_t)ab[0], slice);
-    if (d == 2) lds_frag_g4(nxt.b[0], s32 + (uint32_t)bb[0], slice);
-    if (DMA) {
-      stage_piece_g4(sp, dst, wave, d);
+    if (ABL != 2) {
+      if (i == 0) m0 = rin.a[0] + 0x7f7f7f7f;              // bytes 0 / 1 -> 0x7f / 0x80 -> (xor) 0x00 / 0xff
+      if (i == 1) m0 = m0 ^ 0x7f7f7f7f;
+      if (i == 2) m1 = rin.a[1] + 0x7f7f7f7f;
+      if (i == 3) m1 = m1 ^ 0x7f7f7f7f;
+      if (i == 4) lds_digits_g4(rout.dg, s32 + (uint32_t)dgb, slice);
+      if (i == 5) { lds_frag_g4(rout.a[0], s32 + (uint32_t)ab[0], slice); lds_frag_g4(rout.a[1], s32 + (uint32_t)ab[1], slice); }
+      if (i == 6) { lds_frag_g4(rout.b[0], s32 + (uint32_t)bb[0], slice); lds_frag_g4(rout.b[1], s32 + (uint32_t)bb[1], slice); }
+      if (i >= 7 && i <= 10) nxt.as[i - 7] = m0 & rin.dg[i - 7];
+      if (i >= 11 && i <= 14) nxt.at[i - 11] = m1 & rin.dg[i - 11];
+      if (i == 15) { nxt.b[0] = rin.b[0]; nxt.b[1] = rin.b[1]; }
     }
-  }
-  frag_wait<10>(cur.a[1]);
-  v4i at[4];
-  {
-    const v4i m = (cur.a[1] + 0x7f7f7f7f) ^ 0x7f7f7f7f;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) at[d] = m & cur.dg[d];
-  }
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    acc[d][1][0] = mfma8(at[d], cur.b[0], ZERO ? v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[d][1][0]);
-    __builtin_amdgcn_sched_barrier(0);
-    if (d == 0) lds_frag_g4(nxt.a[1], s32 + (uint32_t)ab[1], slice);
-    if (DMA) {
-      stage_piece_g4(sq, dst + G4_TILE, wave, d);
+    if (ABL != 1) {
+      if (DMA_P && i < 4) stage_piece_g4(sp, dst, wave, i);
+      if (DMA_Q && i < 4) stage_piece_g4(sq, dst + G4_TILE, wave, i);
+      if (DMA_Q && wave == 0 && (i == 4 || i == 5))        // digits: [plane 2 (i - 4) + (lane >> 5)][4 (lane & 31) ..]
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rdig, (MMG_AS3 void*)(dst + G4_DIG + (i - 4) * 256), 4, dig_voff,
+                                                 (i - 4) * dig_stride2, 0, 0);
     }
-  }
-  frag_wait<10>(cur.b[1]);
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    acc[d][0][1] = mfma8(as[d], cur.b[1], ZERO ? v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[d][0][1]);
-    __builtin_amdgcn_sched_barrier(0);
-    if (d == 0) lds_frag_g4(nxt.b[1], s32 + (uint32_t)bb[1], slice);
-    if (DMA && wave == 0 && d < 2)                        // digits: [plane 2 d + (lane >> 5)][4 (lane & 31) ..]
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdig, (MMG_AS3 void*)(dst + G4_DIG + d * 256), 4, dig_voff, d * dig_stride2, 0, 0);
-  }
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    acc[d][1][1] = mfma8(at[d], cur.b[1], ZERO ? v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0} : acc[d][1][1]);
     __builtin_amdgcn_sched_barrier(0);
   }
+  if (ABL == 2) nxt = cur;                                // ablation: no LDS reads, no scaling in the loop (wrong results)
 }
 
 // Runs one job; epi(acc): acc[d][m][n] = plane d, rows = P columns wm*64 + m*32 .., columns = Q columns wn*64 + n*32 ..
 // (C layout of gemm_i8_core.h inside a 32 x 32 tile).
-template <class EpiFn>
+// ABL (timing ablations, WRONG results): 1 = no DMA in the loop, 2 = no LDS reads in the loop, 3 = no barrier in the loop
+template <int ABL = 0, class EpiFn>
 __device__ __forceinline__ void g4_stream(const G4Job& job, int64_t ld, char* lds, EpiFn&& epi) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -223,30 +216,46 @@ __device__ __forceinline__ void g4_stream(const G4Job& job, int64_t ld, char* ld
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  FragG4 f0, f1;
+  OpsG4 f0, f1;
+  RawG4 r0, r1;
   {
     const uint32_t l32 = (uint32_t)(uintptr_t)lds;
-    lds_digits_g4(f0.dg, l32 + (uint32_t)dgb, 0);        // the order the counted waits assume
-    lds_frag_g4(f0.a[0], l32 + (uint32_t)ab[0], 0);
-    lds_frag_g4(f0.b[0], l32 + (uint32_t)bb[0], 0);
-    lds_frag_g4(f0.a[1], l32 + (uint32_t)ab[1], 0);
-    lds_frag_g4(f0.b[1], l32 + (uint32_t)bb[1], 0);
+    lds_digits_g4(r0.dg, l32 + (uint32_t)dgb, 0);        // slice 0 -> f0
+    lds_frag_g4(r0.a[0], l32 + (uint32_t)ab[0], 0);
+    lds_frag_g4(r0.a[1], l32 + (uint32_t)ab[1], 0);
+    lds_frag_g4(r0.b[0], l32 + (uint32_t)bb[0], 0);
+    lds_frag_g4(r0.b[1], l32 + (uint32_t)bb[1], 0);
+    lds_digits_g4(r1.dg, l32 + (uint32_t)dgb, 1);        // slice 1 stays raw: the first slice of the loop scales it
+    lds_frag_g4(r1.a[0], l32 + (uint32_t)ab[0], 1);
+    lds_frag_g4(r1.a[1], l32 + (uint32_t)ab[1], 1);
+    lds_frag_g4(r1.b[0], l32 + (uint32_t)bb[0], 1);
+    lds_frag_g4(r1.b[1], l32 + (uint32_t)bb[1], 1);
+    wait_raw_g4(r0);
+    const v4i m0 = byte_mask_g4(r0.a[0]), m1 = byte_mask_g4(r0.a[1]);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { f0.as[d] = m0 & r0.dg[d]; f0.at[d] = m1 & r0.dg[d]; }
+    f0.b[0] = r0.b[0]; f0.b[1] = r0.b[1];
   }
 
   v16i acc[4][2][2];                                     // written (not accumulated) by the first slice of the job
 
+  // Step t multiplies stage t (slot t & 1).  Slice s computes on the operands of k-slice s, scales the raw fragments of
+  // k-slice s + 1 and reads those of k-slice s + 2 -- for s = 2, 3 that is k-slice 0, 1 of stage t + 1 in the other slot,
+  // hence the barrier (and the vmcnt(0) for that stage) between slices 1 and 3.  Behind it every read of slot t & 1 has
+  // been issued and waited for: stage t + 2 is issued into it during slices 2 and 3.
   for (int t = 0; t < job.nks; ++t) {
     char* cur = lds + (t & 1) * G4_BUF;
     char* oth = lds + ((t + 1) & 1) * G4_BUF;
-    if (t == 0) g4_slice<false, true>(acc, f0, f1, cur, ab, bb, dgb, 1, sp, sq, rdig, dig_voff, dig_stride2, oth, wave);
-    else g4_slice<false, false>(acc, f0, f1, cur, ab, bb, dgb, 1, sp, sq, rdig, dig_voff, dig_stride2, oth, wave);
-    g4_slice<false, false>(acc, f1, f0, cur, ab, bb, dgb, 2, sp, sq, rdig, dig_voff, dig_stride2, oth, wave);
-    g4_slice<false, false>(acc, f0, f1, cur, ab, bb, dgb, 3, sp, sq, rdig, dig_voff, dig_stride2, oth, wave);
+#define MMG_G4_ARGS(SRC, SL) SRC, ab, bb, dgb, SL, sp, sq, rdig, dig_voff, dig_stride2, cur, wave
+    if (t == 0) g4_slice<false, false, true, ABL>(acc, f0, f1, r1, r0, MMG_G4_ARGS(cur, 2));
+    else g4_slice<false, false, false, ABL>(acc, f0, f1, r1, r0, MMG_G4_ARGS(cur, 2));
+    g4_slice<false, false, false, ABL>(acc, f1, f0, r0, r1, MMG_G4_ARGS(cur, 3));
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if (ABL != 3) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    // slice 3 runs on registers; slot `cur` is free: stage t+2 goes there; fragments of step t+1 slice 0 from `oth`
-    g4_slice<true, false>(acc, f1, f0, oth, ab, bb, dgb, 0, sp, sq, rdig, dig_voff, dig_stride2, cur, wave);
+    g4_slice<true, false, false, ABL>(acc, f0, f1, r1, r0, MMG_G4_ARGS(oth, 0));
+    g4_slice<false, true, false, ABL>(acc, f1, f0, r0, r1, MMG_G4_ARGS(oth, 1));
+#undef MMG_G4_ARGS
     advance();                                           // -> stage t+3
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the re-issued tail stages must land before LDS is released

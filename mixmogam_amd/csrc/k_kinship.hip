@@ -122,6 +122,7 @@ __global__ __launch_bounds__(W4_THREADS) void kinship_i8_tr_kernel(const int8_t*
 
 // All four digit planes of the exact GRM of a binary store in one pass over the genotypes (gemm_i8_grm4.h): job = a
 // 128 x 128 tile pair (I, J) of individuals over SNP rows [ks0*128, ks1*128); C32[d] += (diag(dig_d) S)' S on that tile.
+template <int ABL>
 __global__ __launch_bounds__(W4_THREADS) void kinship_grm4_kernel(const int8_t* __restrict__ S, int64_t ld, int32_t Npad,
                                                                   const int8_t* __restrict__ dig, int dig_stride,
                                                                   const KinJob* __restrict__ jobs, int* __restrict__ C32) {
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(W4_THREADS) void kinship_grm4_kernel(const int8_t* 
   gj.dig_stride = dig_stride;
   gj.nks = job.ks1 - job.ks0;
   const int64_t plane = (int64_t)Npad * Npad;
-  g4_stream(gj, ld, lds, [&](v16i (&acc)[4][2][2]) {
+  g4_stream<ABL>(gj, ld, lds, [&](v16i (&acc)[4][2][2]) {
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -502,12 +503,17 @@ int run_kinship_grm4(mmg_ctx* ctx, const int8_t* S, int64_t ld, int32_t Npad, in
   KinJob* djobs = nullptr;
   MMG_HIP(ctx, hipMalloc(&djobs, jobs.size() * sizeof(KinJob)));
   MMG_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(KinJob), hipMemcpyHostToDevice, ctx->stream));
-  MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_grm4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
-  {
-    EvScope ev(ctx, EV_KIN);
-    hipLaunchKernelGGL(kinship_grm4_kernel, dim3((unsigned)jobs.size()), dim3(W4_THREADS), G4_LDS, ctx->stream, S, ld, Npad, dig,
-                       (int)dig_stride, djobs, C32);
-  }
+  int abl = 0;                                            // MMG_GRM4_ABL=1|2|3: timing ablations (wrong results)
+  if (const char* e = std::getenv("MMG_GRM4_ABL")) abl = std::atoi(e);
+#define MMG_LAUNCH_G4(A)                                                                                                \
+  do {                                                                                                                 \
+    MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_grm4_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS)); \
+    EvScope ev(ctx, EV_KIN);                                                                                           \
+    hipLaunchKernelGGL(kinship_grm4_kernel<A>, dim3((unsigned)jobs.size()), dim3(W4_THREADS), G4_LDS, ctx->stream, S, ld, \
+                       Npad, dig, (int)dig_stride, djobs, C32);                                                        \
+  } while (0)
+  if (abl == 1) MMG_LAUNCH_G4(1); else if (abl == 2) MMG_LAUNCH_G4(2); else if (abl == 3) MMG_LAUNCH_G4(3); else MMG_LAUNCH_G4(0);
+#undef MMG_LAUNCH_G4
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   MMG_HIP(ctx, hipFree(djobs));
