@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 # round 3: the extras (structured data, host ingest, multi-phenotype: rot_gemm / scan_multi) stay ON so that their kernels
 # are in the same trace; `tools/gpu_profile.sh r3p --mode perm` profiles the permutation GEMM
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
-RE="scan_quad|scan_finalize|f_sf_kernel|kinship_i8|kinship_f32|transpose|perm_gemm|rot_gemm|scan_multi|grm_scale_rows|unpack_kernel|pitch_rows"
+RE="scan_quad|scan_finalize|f_sf_kernel|kinship_i8|kinship_f4|kinship_grm4|kinship_f32|transpose|perm_gemm|rot_gemm|scan_multi|grm_scale_rows|grm_combine|pack_fp4|unpack_kernel|pitch_rows"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $ROOT/bench.py $ARGS > $OUT/trace.log 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
