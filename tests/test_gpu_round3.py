@@ -446,3 +446,23 @@ def test_scale_k_on_the_device_equals_the_host_rule(ctx):
         acc.close(); g.close()
         assert np.max(np.abs(got - want)) <= 1e-13 * np.max(np.abs(want)), n
         assert abs(f * cnt / ((n - 1) / (np.trace(raw / cnt) - (raw / cnt).sum() / n)) - 1) < 1e-12
+
+
+def test_fused_grm_over_several_contraction_chunks(ctx, monkeypatch):
+    """The one-pass four-plane GRM (gemm_i8_grm4.h) when a call is split into several SNP ranges (MMG_KIN_CHUNK): each
+    range brings its own digit rows and weighted column sums; N is not a multiple of the 128-column tile, M not of the
+    128-row K step."""
+    rng = np.random.RandomState(42)
+    n, m = 333, 70001
+    snps = (rng.random_sample((m, n)) < rng.uniform(0.08, 0.92, size=(m, 1))).astype(np.int8)
+    snps = snps[snps.std(1) > 0]
+    assert len(snps) >= 65536
+    ref = _grm_f64(snps)
+    monkeypatch.setenv("MMG_KIN_CHUNK", "20000")
+    g = ctx.geno(snps)
+    acc = ctx.kinship_accumulator(n)
+    acc.add_grm(g)
+    k1, cnt = acc.fetch()
+    acc.close(); g.close()
+    assert cnt == len(snps)
+    assert np.max(np.abs(k1 - ref)) < 1e-9 * np.max(np.abs(ref))
