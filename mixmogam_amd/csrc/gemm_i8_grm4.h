@@ -6,7 +6,7 @@
 // what goes INTO LDS as much as by the matrix pipe (DESIGN.md 4.1 "fill bandwidth"), and the four scaled images differ
 // from the store only by a factor per k row.  Here a workgroup fills LDS with the PLAIN genotype tiles once per K step
 // and forms the four scaled operands in registers: genotype bytes are 0 / 1, so (dword + 0x7f7f7f7f) ^ 0x7f7f7f7f turns them
-// into byte masks and one v_and with the digits of the lane's four k rows is the product -- 24 VALU ops per 16 MFMA, in the
+// into byte masks and one v_and with the digits of the lane's four k rows is the product -- 48 VALU ops per 16 MFMA, in the
 // shadow of the matrix pipe.  Per K step (128 SNP rows) a workgroup computes a 128 x 128 tile of ALL FOUR planes:
 //   LDS fill   32 KiB per 4 x 128 x 128 x 128 MAC   = half the bytes per MAC of the 256 x 256 single-plane tile
 //   LDS reads  4 fragments per 16 MFMA              = half of gemm_i8_w4tr.h's 8
