@@ -85,6 +85,11 @@ def test_eigen_free_route_beyond_the_syevd_index_range(ctx):
     deltas = np.array([0.5, 2.0, 2.0 * (1 + 1e-3), 2.0 * (1 - 1e-3)])
     s1, s2, s3, s4, sse = reml.sums(deltas)
     T["reml_create+band_reduction+4_deltas"] = time.time() - t0
+    t0 = time.time()
+    c1, c2, c3, c4, _ = reml.sums(deltas[1:2], route="chol")          # one Cholesky factorisation + inverse at this width
+    T["one_delta_cholesky_route"] = time.time() - t0
+    for got, want in ((s1[1], c1[0]), (s2[1], c2[0]), (s3[1], c3[0]), (s4[1], c4[0])):
+        assert abs(got - want) <= 1e-9 * max(1.0, abs(want)), ("band vs cholesky route", got, want)
     assert abs(sse - float(y @ y - y.sum() ** 2 / N)) < 1e-9 * sse
     t0 = time.time()
     B = np.column_stack([np.ones(N), y])
