@@ -439,3 +439,28 @@ def test_merge_plan_joins_neighbouring_chunks_of_a_chromosome():
     capped = hdf5_data._merge_plan(plan, 8, min_rows=1000, max_bytes=8 * 900)     # at most 900 rows per chunk
     assert max(len(s) for _c, s, _p in capped) <= 900 and sum(len(s) for _c, s, _p in capped) == 3200
     assert hdf5_data._merge_plan(plan, 8, min_rows=1) == plan
+
+
+def test_band_route_sums_are_not_dealt_over_ranks():
+    """_SpectralSumsChol: with the band route every rank evaluates all deltas itself (one reduction of K serves them all);
+    only the one-factorisation-per-delta route deals the grid out and gathers."""
+    class Coll(object):
+        rank, world = 1, 4
+        def allgather(self, x):
+            raise AssertionError("no exchange on the band route")
+    class Reml(object):
+        N = 1000
+        calls = []
+        def uses_band(self, route="auto"):
+            return route != "chol"
+        def sums(self, deltas, route="auto"):
+            self.calls.append((len(deltas), route))
+            d = np.asarray(deltas, dtype=np.float64)
+            return d, 2 * d, 3 * d, 4 * d, 7.0
+    r = Reml()
+    s = lm._SpectralSumsChol(r, Coll())
+    out = s.at(np.arange(1.0, 9.0))
+    assert np.array_equal(out[1], 2 * np.arange(1.0, 9.0)) and s.sum_sq_etas == 7.0 and r.calls == [(8, "auto")]
+    assert s.n_factorisations == 8
+    with pytest.raises(AssertionError, match="no exchange"):
+        lm._SpectralSumsChol(r, Coll(), route="chol").at(np.arange(1.0, 9.0))      # this one does go through the collective
