@@ -378,7 +378,9 @@ __global__ __launch_bounds__(256) void tsmm_reduce_kernel(const double* __restri
 //     j + 1 of the UPDATED panel (part_out) and copies its pivot row (pivrow_out);
 //   * writes column j of V (explicit: zeros above, 1 on the diagonal) and zeroes P below the diagonal.
 // rocsolver_dgeqrf spends 13.8 ms per 50,000 x 64 panel (some 300 small launches); this is 65 launches that each read
-// and write the remaining columns once.
+// and write the remaining columns once.  (The same 65 steps as ONE cooperative launch with grid-wide barriers and
+// agent-scope loads of the exchanged sums were slower: panel QR + T 1.78 against 1.27 s at N = 50,000, 0.50 against 0.42
+// at 20,000 -- a grid barrier over ~200 workgroups costs more than the kernel boundary it replaces.)
 constexpr int QR_ROWS = 256;
 __global__ __launch_bounds__(256) void panel_qr_step_kernel(double* __restrict__ P, int64_t lda, int n, int j,
                                                             const double* __restrict__ part_in, double* __restrict__ part_out,
