@@ -466,3 +466,24 @@ def test_fused_grm_over_several_contraction_chunks(ctx, monkeypatch):
     acc.close(); g.close()
     assert cnt == len(snps)
     assert np.max(np.abs(k1 - ref)) < 1e-9 * np.max(np.abs(ref))
+
+
+def test_reml_sums_route_argument_is_checked(ctx):
+    """mmg_reml_sums_ex refuses a route outside {AUTO, CHOL, BAND} with MMG_E_ARG; Reml.uses_band mirrors the AUTO rule."""
+    from mixmogam_amd import _lib
+    import ctypes as C
+    rng = np.random.RandomState(0)
+    n = 300
+    B = rng.standard_normal((n, 50))
+    K = B @ B.T / 50 + 0.1 * np.eye(n)
+    reml = ctx.reml(K, np.ones((n, 1)), rng.standard_normal(n))
+    d = np.array([1.0])
+    out = [np.empty(1) for _ in range(4)]
+    sse = C.c_double(0.0)
+    rc = ctx.lib.mmg_reml_sums_ex(ctx.h, reml.h, 1, _lib._ptr(d), *[_lib._ptr(o) for o in out], C.byref(sse), 7)
+    assert rc != 0
+    assert reml.uses_band("band") and not reml.uses_band("chol") and reml.uses_band("auto")       # n = 300 >= 256
+    a = reml.sums(d)                                            # AUTO = band here
+    b = reml.sums(d, route="band")
+    assert all(np.array_equal(x, y) for x, y in zip(a[:4], b[:4]))
+    reml.close()
