@@ -176,17 +176,19 @@ def _resident_chunks(ctx, genot_data, plan, rank=0, world=1, prefetch=True, reus
     pool, host = [], [None, None]
     if reuse and mine:
         cap = max(len(plan[ci][1]) for ci in mine)
-        n_ind = _num_indivs(genot_data[plan[mine[0]][0]])
+        cg0 = genot_data[plan[mine[0]][0]]
+        n_ind = _num_indivs(cg0)
+        row_bytes = int(_raw_dataset(cg0)[0].shape[1])                  # host bytes per SNP: N, or ceil(N bits / 8) when packed
         # two HBM stores + two page-locked staging buffers, kept between calls (kinship pass, scan pass, the next
         # file ...): allocating them costs ~0.1 s, as much as streaming 5 GB
-        key = (ctx.device, n_ind)
+        key = (ctx.device, n_ind, row_bytes)
         cached = _POOLS.get(key)
         if cached is None or cached[0] < cap:
             if cached is not None:
                 for g in cached[1]:
                     g.close()
             cached = _POOLS[key] = (cap, [up.geno(M=cap, N=n_ind) for _ in range(2)],
-                                    [up.pinned_empty(cap * n_ind, dtype=np.int8) for _ in range(2)])
+                                    [up.pinned_empty(cap * row_bytes, dtype=np.int8) for _ in range(2)])
         pool, host = cached[1], cached[2]
 
     def load(ci, slot):
