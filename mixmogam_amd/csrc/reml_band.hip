@@ -34,6 +34,7 @@
 #include <string>
 #include <vector>
 
+#include "dense64.h"
 #include "reml_common.h"
 
 namespace mmg {
@@ -505,8 +506,10 @@ __global__ __launch_bounds__(256) void form_coef_kernel(const double* __restrict
 //   V tile           Vt[col][k], row stride 66
 typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int SY_SA = 80, SY_ST = 66;
+// blockIdx.y = slice of the contraction range (tiles [ntile y / S, ntile (y + 1) / S)) writing its own copy of W: at N = 5000
+// one workgroup per 64 output rows is 40-78 workgroups on 256 CUs, each a chain of ~40 tile steps
 __global__ __launch_bounds__(256, 2) void sym_skinny_kernel(const double* __restrict__ A, int64_t lda, int n,
-                                                            const double* __restrict__ V, double* __restrict__ W) {
+                                                            const double* __restrict__ V, double* __restrict__ Wout) {
   __shared__ double As[64 * SY_SA];
   __shared__ double Vt[64 * SY_ST];
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
@@ -516,6 +519,8 @@ __global__ __launch_bounds__(256, 2) void sym_skinny_kernel(const double* __rest
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) acc[rt] = v4d{0.0, 0.0, 0.0, 0.0};
   const int ntile = (n + 63) / 64;
+  const int kt0 = (int)((int64_t)ntile * blockIdx.y / gridDim.y), kt1 = (int)((int64_t)ntile * (blockIdx.y + 1) / gridDim.y);
+  double* __restrict__ W = Wout + (size_t)blockIdx.y * n * 64;
   // the next tile pair travels in registers while the current one is multiplied (element e = tid + 256 i of a tile)
   double ra[16], rv[16];
   // 32-bit element offsets from wave-uniform tile bases (scalar base + one VGPR per address)
@@ -544,8 +549,8 @@ __global__ __launch_bounds__(256, 2) void sym_skinny_kernel(const double* __rest
       for (int i = 0; i < 16; ++i) ra[i] = (in && lo >= h0 + 4 * i) ? ab[lo + (h0 + 4 * i) * ldi] : 0.0;   // lower half
     }
   };
-  fetch(0);
-  for (int kt = 0; kt < ntile; ++kt) {
+  if (kt0 < kt1) fetch(kt0);
+  for (int kt = kt0; kt < kt1; ++kt) {
     const int K0 = kt * 64;
     __syncthreads();
 #pragma unroll
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void sym_skinny_kernel(const double* __rest
       else if (lo >= hi) { As[hi * SY_SA + lo] = ra[i]; As[lo * SY_SA + hi] = ra[i]; }
     }
     __syncthreads();
-    if (kt + 1 < ntile) fetch(kt + 1);
+    if (kt + 1 < kt1) fetch(kt + 1);
     if (K0 <= I0) {
 #pragma unroll 4
       for (int ks = 0; ks < 16; ++ks) {
@@ -586,8 +591,237 @@ __global__ __launch_bounds__(256, 2) void sym_skinny_kernel(const double* __rest
     }
 }
 
+// W[e] = sum_s Wp[s][e] over the S contraction slices of sym_skinny_kernel, fixed order
+__global__ void wsum_kernel(const double* __restrict__ Wp, int S, int64_t count, double* __restrict__ W) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count) return;
+  double s = Wp[e];
+  for (int k = 1; k < S; ++k) s += Wp[(size_t)k * count + e];
+  W[e] = s;
+}
+
+// The last block column of the reduction, 2 <= n < 64 rows below the band: everything (the n x 64 panel, the n x n trailing
+// matrix, the rotated columns of [X y]) fits one workgroup's LDS.  Unblocked Householder: reflector j from column j of the
+// panel, applied to the rest of the panel, to both sides of the trailing matrix and to [X y].
+__global__ __launch_bounds__(256) void band_tail_kernel(double* __restrict__ A, int64_t N, int64_t k0, double* __restrict__ Zr, int q1) {
+  constexpr int LDT = 65;
+  __shared__ double Ps[64 * LDT], As[64 * LDT], Zs[17 * 64], v[64], u[64], dc[64 + 17];
+  __shared__ double sc[4];
+  const int tid = threadIdx.x;
+  const int64_t a0 = k0 + BAND_B;
+  const int n = (int)(N - a0);
+  for (int e = tid; e < 4096; e += 256) {
+    const int r = e & 63, c = e >> 6;
+    Ps[r * LDT + c] = r < n ? A[(a0 + r) + (k0 + c) * N] : 0.0;
+    double a = 0.0;
+    if (r < n && c < n) a = r >= c ? A[(a0 + r) + (a0 + c) * N] : A[(a0 + c) + (a0 + r) * N];
+    As[r * LDT + c] = a;
+  }
+  for (int e = tid; e < 64 * q1; e += 256) {
+    const int r = e & 63, c = e >> 6;
+    Zs[c * 64 + r] = r < n ? Zr[(size_t)c * N + a0 + r] : 0.0;
+  }
+  __syncthreads();
+  const int nref = n - 1 < 64 ? n - 1 : 64;
+  for (int j = 0; j < nref; ++j) {
+    if (tid < 64) {
+      // |x[j+1:]|^2 by one wave
+      double x = (tid > j && tid < n) ? Ps[tid * LDT + j] : 0.0;
+      double s2 = wave_sum(x * x);
+      if (tid == 0) {
+        const double x0 = Ps[j * LDT + j];
+        double tau = 0.0, beta = x0, scale = 0.0;
+        if (s2 > 0.0) {
+          beta = -copysign(sqrt(fma(x0, x0, s2)), x0);
+          tau = (beta - x0) / beta;
+          scale = 1.0 / (x0 - beta);
+        }
+        sc[0] = tau; sc[1] = beta; sc[2] = scale;
+      }
+    }
+    __syncthreads();
+    const double tau = sc[0], beta = sc[1], scale = sc[2];
+    if (tid < 64) v[tid] = tid < j || tid >= n ? 0.0 : (tid == j ? 1.0 : Ps[tid * LDT + j] * scale);
+    __syncthreads();
+    // dots of v with the remaining panel columns, with the columns of [X y], and u = A22 v
+    if (tid < 64) {
+      double d = 0.0;
+      if (tid > j) for (int r = j; r < n; ++r) d = fma(v[r], Ps[r * LDT + tid], d);
+      dc[tid] = d;
+    } else if (tid < 64 + q1) {
+      const int c = tid - 64;
+      double d = 0.0;
+      for (int r = j; r < n; ++r) d = fma(v[r], Zs[c * 64 + r], d);
+      dc[tid] = d;
+    } else if (tid >= 128 && tid < 192) {
+      const int r = tid - 128;
+      double d = 0.0;
+      if (r < n) for (int c = j; c < n; ++c) d = fma(As[r * LDT + c], v[c], d);
+      u[r] = d;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const double al = wave_sum(v[tid] * u[tid]);             // v'A22 v
+      u[tid] = tau * fma(-0.5 * tau * al, v[tid], u[tid]);     // w
+    }
+    __syncthreads();
+    for (int e = tid; e < 4096; e += 256) {
+      const int r = e & 63, c = e >> 6;
+      if (r < n) {
+        if (c > j) Ps[r * LDT + c] = fma(-tau * v[r], dc[c], Ps[r * LDT + c]);
+        if (c < n) As[r * LDT + c] -= v[r] * u[c] + u[r] * v[c];
+      }
+    }
+    for (int e = tid; e < 64 * q1; e += 256) {
+      const int r = e & 63, c = e >> 6;
+      if (r < n) Zs[c * 64 + r] = fma(-tau * v[r], dc[64 + c], Zs[c * 64 + r]);
+    }
+    if (tid < 64 && tid < n) Ps[tid * LDT + j] = tid == j ? beta : (tid > j ? 0.0 : Ps[tid * LDT + j]);
+    __syncthreads();
+  }
+  for (int e = tid; e < 4096; e += 256) {
+    const int r = e & 63, c = e >> 6;
+    if (r < n) {
+      A[(a0 + r) + (k0 + c) * N] = Ps[r * LDT + c];
+      if (c <= r) A[(a0 + r) + (a0 + c) * N] = As[r * LDT + c];
+    }
+  }
+  for (int e = tid; e < 64 * q1; e += 256) {
+    const int r = e & 63, c = e >> 6;
+    if (r < n) Zr[(size_t)c * N + a0 + r] = Zs[c * 64 + r];
+  }
+}
+
 // ---- the reduction ---------------------------------------------------------------------------------------------------
+// Round 4: panels by Cholesky-QR (two passes) with the orthogonal factor in basis-kernel form, own products throughout --
+// 16 launches per panel, none of them a library call, against ~85 (67 of them panel_qr_step_kernel) in band_reduce_hh
+// below: at N = 5000 the reduction was 128 ms of launch latency around 10 ms of arithmetic.  Per panel P [n x 64] (the rows
+// below the band), dense64.h:
+//   G = P'P -> R1 = chol(G)', R1^-1 -> Q1 = P R1^-1 -> G2 = Q1'Q1 -> R2, R2^-1, Qtop = Q1[0:64] R2^-1, signs S;
+//   H = I - V M V' with V = [I; 0] - Q S, M = (I - Qtop S)^-T (H orthogonal, H'P = [S R2 R1; 0]) -> W = A22 V ->
+//   Y = W M - 1/2 V M'(V'W) M -> A22 -= V Y' + Y V'   and   [X y] -= V M'(V'[X y]).
+// Cholesky-QR needs cond(P)^2 < 1/eps; a panel that is numerically rank deficient (duplicated individuals, an exactly
+// low-rank K) raises a device flag -- no host round trip per panel -- and the caller redoes the whole reduction with
+// Householder panels (band_reduce_hh), which has no such limit.
+static int band_reduce_hh(mmg_ctx* ctx, mmg_reml* r);
+
+static int band_reduce_cqr(mmg_ctx* ctx, mmg_reml* r, bool* suspect) {
+  rocblas_handle h;
+  int rc = reml_handle(ctx, &h);
+  if (rc) return rc;
+  if (dense64_init()) return set_err(ctx, MMG_E_HIP, "hipFuncSetAttribute (dense64 kernels)");
+  const int64_t N = r->N;
+  const int q1 = r->q + 1, b = BAND_B;
+  hipStream_t st = ctx->stream;
+  const auto t_start = std::chrono::steady_clock::now();
+  if (!r->dBand) RC_HIP(ctx, hipMalloc(&r->dBand, (size_t)N * BAND_LD * sizeof(double)));
+  if (!r->dZr) RC_HIP(ctx, hipMalloc(&r->dZr, (size_t)N * q1 * sizeof(double)));
+  double* A = r->dL;
+  RC_HIP(ctx, hipMemcpyAsync(A, r->dK, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, st));
+  RC_HIP(ctx, hipMemcpyAsync(r->dZr, r->dB, (size_t)N * q1 * sizeof(double), hipMemcpyDeviceToDevice, st));
+  const int64_t nmax = std::max<int64_t>(N - b, 1);
+  // contraction slices of W = A22 V so that a launch has >= ~256 workgroups
+  const int smax = (int)std::max<int64_t>(1, std::min<int64_t>(16, (nmax + 63) / 64 / 3));
+  Scratch sc;
+  double *V = nullptr, *W = nullptr, *Wp = nullptr, *Y = nullptr, *small = nullptr, *part = nullptr, *part2 = nullptr;
+  PanelFlags* flags = nullptr;
+  RC_HIP(ctx, sc.alloc(&V, (size_t)nmax * b * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&W, (size_t)nmax * b * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&Y, (size_t)nmax * b * sizeof(double)));
+  if (smax > 1) RC_HIP(ctx, sc.alloc(&Wp, (size_t)smax * nmax * b * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&small, (size_t)(6 * b * b + 17 * b) * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&part, (size_t)2 * D64_MAX_SLICES * 4096 * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&part2, (size_t)2 * 128 * 4096 * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&flags, sizeof(PanelFlags)));
+  RC_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(PanelFlags), st));
+  double *R1 = small, *R1inv = small + b * b, *Mk = small + 2 * b * b, *Cb = small + 3 * b * b, *Cm = small + 4 * b * b, *Cz = small + 5 * b * b;
+  double* partz = part + (size_t)D64_MAX_SLICES * 4096;
+  const bool verbose = std::getenv("MMG_REML_VERBOSE") != nullptr;
+  double tsec[4] = {0, 0, 0, 0};
+  auto lap = [&](int which, std::chrono::steady_clock::time_point& tp) {
+    if (!verbose) return;
+    (void)hipStreamSynchronize(st);
+    const auto now = std::chrono::steady_clock::now();
+    tsec[which] += std::chrono::duration<double>(now - tp).count();
+    tp = now;
+  };
+  // out (64 x 64) = A'B: Gram slices on the matrix pipe, summed by a second small launch (a head kernel that added 40
+  // slices itself spent 46 us reading 1.3 MB through one CU)
+  auto gram = [&](const double* Am, int64_t lda, const double* Bm, int64_t ldb, int kb, int64_t n, double* out) {
+    const int G = launch_gram_slices(st, Am, lda, Bm, ldb, kb, n, part2, 128);
+    launch_gram_reduce(st, part2, G, out, 64);
+  };
+  int64_t k0 = 0;
+  for (; N - k0 - b >= 2; k0 += b) {
+    auto tp = std::chrono::steady_clock::now();
+    if (verbose) { (void)hipStreamSynchronize(st); tp = std::chrono::steady_clock::now(); }
+    const int64_t a0 = k0 + b, n = N - a0;
+    if (n < b) {                                              // the last, short block column: one workgroup
+      hipLaunchKernelGGL(band_tail_kernel, dim3(1), dim3(256), 0, st, A, N, k0, r->dZr, q1);
+      lap(0, tp);
+      continue;
+    }
+    double* P = A + a0 + k0 * N;
+    double* A22 = A + a0 + a0 * N;
+    double* Zs = r->dZr + a0;
+    // ---- panel: V, M, R
+    gram(P, N, P, N, b, n, part);
+    launch_cholqr_head1(st, part, 1, R1, R1inv, flags);
+    launch_rows_gemm(st, P, N, V, n, n, R1inv);               // Q1 = P R1^-1
+    gram(V, n, V, n, b, n, part);
+    launch_cholqr_head2(st, part, 1, R1, V, n, Mk, Cb, P, N, flags);
+    launch_rows_gemm(st, V + b, n, V + b, n, n - b, Cb);      // V[64:] = Q1[64:] (-R2^-1 S)
+    lap(0, tp);
+    // ---- W = A22 V
+    // ~3 tile steps per workgroup while the launch stays within ~1024 workgroups
+    const int S = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)smax, 1024 / ((n + 63) / 64), (n + 63) / 64 / 3}));
+    hipLaunchKernelGGL(sym_skinny_kernel, dim3((unsigned)((n + 63) / 64), S), dim3(256), 0, st, A22, N, (int)n, V, S > 1 ? Wp : W);
+    if (S > 1) hipLaunchKernelGGL(wsum_kernel, dim3((unsigned)((n * b + 255) / 256)), dim3(256), 0, st, Wp, S, n * b, W);
+    lap(1, tp);
+    // ---- Y = W M - 1/2 V M'(V'W) M and the rotated columns of [X y]
+    {
+      const int G = launch_gram_slices2(st, V, n, n, W, n, b, part2, Zs, N, q1, part2 + (size_t)128 * 4096, 128);
+      launch_gram_reduce(st, part2, G, part, 64);
+      launch_gram_reduce(st, part2 + (size_t)128 * 4096, G, partz, 64);
+    }
+    launch_band_coef(st, part, 1, partz, 1, q1, Mk, Cm, Cz);
+    launch_band_y(st, V, W, n, Mk, Cm, Y, Zs, N, Cz, q1);
+    lap(2, tp);
+    // ---- A22 -= V Y' + Y V' (lower tiles)
+    launch_nt_update_lower(st, A22, N, n, V, Y, Y, V, n, n);
+    lap(3, tp);
+  }
+  RC_HIP(ctx, hipGetLastError());
+  PanelFlags hf;
+  RC_HIP(ctx, hipMemcpyAsync(&hf, flags, sizeof(hf), hipMemcpyDeviceToHost, st));
+  RC_HIP(ctx, hipStreamSynchronize(st));
+  if (verbose)
+    fprintf(stderr, "[reml] N=%lld: band reduction (Cholesky-QR panels, %d of them%s) %.3f s: panel %.3f, A22 V %.3f, coefficients + Y %.3f, rank-2b update %.3f\n",
+            (long long)N, hf.panels, hf.bad ? "; a panel was rank deficient -> Householder panels" : "",
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(), tsec[0], tsec[1], tsec[2], tsec[3]);
+  *suspect = hf.bad != 0;
+  r->band_k0 = k0;                                            // band_reduce_hh finishes the short panels from here
+  return MMG_OK;
+}
+
 static int band_reduce(mmg_ctx* ctx, mmg_reml* r) {
+  const char* e = std::getenv("MMG_BAND_IMPL");
+  const std::string impl = e ? e : "";
+  const auto t_start = std::chrono::steady_clock::now();
+  r->band_k0 = 0;
+  if (impl.empty() || impl == "cqr") {
+    bool suspect = false;
+    int rc = band_reduce_cqr(ctx, r, &suspect);
+    if (rc) return rc;
+    if (suspect) r->band_k0 = 0;                              // start over: dL is re-copied from K
+    r->band_fallback = suspect;
+  }
+  const int rc = band_reduce_hh(ctx, r);
+  r->band_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  return rc;
+}
+
+static int band_reduce_hh(mmg_ctx* ctx, mmg_reml* r) {
   rocblas_handle h;
   int rc = reml_handle(ctx, &h);
   if (rc) return rc;
@@ -598,11 +832,14 @@ static int band_reduce(mmg_ctx* ctx, mmg_reml* r) {
   if (!r->dBand) RC_HIP(ctx, hipMalloc(&r->dBand, (size_t)N * BAND_LD * sizeof(double)));
   if (!r->dZr) RC_HIP(ctx, hipMalloc(&r->dZr, (size_t)N * q1 * sizeof(double)));
   double* A = r->dL;                                          // work copy of K, reduced in place (lower triangle)
-  RC_HIP(ctx, hipMemcpyAsync(A, r->dK, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, st));
-  RC_HIP(ctx, hipMemcpyAsync(r->dZr, r->dB, (size_t)N * q1 * sizeof(double), hipMemcpyDeviceToDevice, st));
+  const int64_t k_first = r->band_k0;                         // > 0: band_reduce_cqr did the panels before this one
+  if (k_first == 0) {
+    RC_HIP(ctx, hipMemcpyAsync(A, r->dK, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    RC_HIP(ctx, hipMemcpyAsync(r->dZr, r->dB, (size_t)N * q1 * sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
   Scratch sc;
   double *VW = nullptr, *YV = nullptr, *T = nullptr, *tau = nullptr, *M1 = nullptr, *M2 = nullptr, *small = nullptr, *part = nullptr;
-  const int64_t nmax = std::max<int64_t>(N - b, 1);
+  const int64_t nmax = std::max<int64_t>(N - b - k_first, 1);
   const int GQ = (int)((nmax + QR_ROWS - 1) / QR_ROWS);       // workgroups of a panel-QR step
   const int GT = 128;                                         // row slices of a tall-skinny product
   RC_HIP(ctx, sc.alloc(&VW, (size_t)nmax * 2 * b * sizeof(double)));      // [V | A22 V] -> [V | Y]
@@ -637,7 +874,7 @@ static int band_reduce(mmg_ctx* ctx, mmg_reml* r) {
     hipLaunchKernelGGL(tsmm_tn_kernel, dim3(G), dim3(256), 0, st, Am, lda, Bm, ldb, kb, (int)n, rows_per, part);
     hipLaunchKernelGGL(tsmm_reduce_kernel, dim3(16), dim3(256), 0, st, part, G, out, ldo);
   };
-  for (int64_t k0 = 0; N - k0 - b >= 2; k0 += b) {
+  for (int64_t k0 = k_first; N - k0 - b >= 2; k0 += b) {
     auto tp = std::chrono::steady_clock::now();
     if (verbose) { (void)hipStreamSynchronize(st); tp = std::chrono::steady_clock::now(); }
     const int64_t a0 = k0 + b;                                // first row / column of the trailing matrix
@@ -715,8 +952,9 @@ static int band_reduce(mmg_ctx* ctx, mmg_reml* r) {
   RC_HIP(ctx, hipStreamSynchronize(st));
   r->band_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
   if (verbose)
-    fprintf(stderr, "[reml] N=%lld: band reduction (b = %d, %s) %.3f s: panel QR + T %.3f, A22 V %.3f, small products %.3f, rank-2b update %.3f\n",
-            (long long)N, b, lib_only ? "library calls" : "own panel QR, block-lower products", r->band_s, tsec[0], tsec[1], tsec[2], tsec[3]);
+    fprintf(stderr, "[reml] N=%lld: band reduction (b = %d, %s, panels from column %lld) %.3f s: panel QR + T %.3f, A22 V %.3f, small products %.3f, rank-2b update %.3f\n",
+            (long long)N, b, lib_only ? "library calls" : "Householder panels, block-lower products", (long long)k_first, r->band_s, tsec[0],
+            tsec[1], tsec[2], tsec[3]);
   r->band_ready = true;
   return MMG_OK;
 }

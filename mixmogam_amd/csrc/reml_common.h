@@ -27,6 +27,8 @@ struct mmg_reml {
   double* dBand = nullptr;  // [N][BAND_LD]: column j of the band, B[j + d][j] at d = 0..64
   double* dZr = nullptr;    // [q+1][N]: Q'[X y]
   double band_s = 0.0;      // seconds the reduction took
+  int64_t band_k0 = 0;      // first column the Householder-panel path still has to do (reml_band.hip:band_reduce)
+  bool band_fallback = false;   // a Cholesky-QR panel was rank deficient: the reduction was redone with Householder panels
 };
 
 #define RC_HIP(ctx, call)                                                                     \
