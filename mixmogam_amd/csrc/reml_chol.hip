@@ -24,6 +24,7 @@
 #include <string>
 #include <vector>
 
+#include "dense64.h"
 #include "mmg_internal.h"
 #include "reml_common.h"
 
@@ -160,6 +161,28 @@ static int potrf_blocked(mmg_ctx* ctx, rocblas_handle h, double* A, int64_t N, i
   return MMG_OK;
 }
 
+// The same factorisation on this library's own kernels (dense64.h), 64 columns at a time: the diagonal block in one
+// workgroup (with its inverse, so that the panel below is a product on the matrix pipe instead of a triangular solve), the
+// trailing matrix by the rank-64 update of its lower 64 x 64 tiles.  Three launches per 64 columns and no library call:
+// N = 5000 takes 79 x 3 launches where the blocked form above spent 17 ms in rocSOLVER's unblocked potf2 kernels and
+// forward substitutions (profiles/r4_*).
+static int potrf_own(mmg_ctx* ctx, double* A, int64_t N, double* LinvT /*device, 64 x 64*/, long long* dacc) {
+  if (dense64_init()) return set_err(ctx, MMG_E_HIP, "hipFuncSetAttribute (dense64 kernels)");
+  hipStream_t st = ctx->stream;
+  for (int64_t k0 = 0; k0 < N; k0 += 64) {
+    const int kb = (int)std::min<int64_t>(64, N - k0);
+    const int64_t rest = N - k0 - kb;
+    launch_potrf_head(st, A + k0 + k0 * N, N, kb, LinvT, dacc, (long long)k0);
+    if (rest > 0) {
+      double* panel = A + (k0 + kb) + k0 * N;
+      launch_rows_gemm(st, panel, N, panel, N, rest, LinvT);                  // X L' = A  <=>  X = A L^-T
+      launch_nt_update_lower(st, A + (k0 + kb) + (k0 + kb) * N, N, rest, panel, panel, nullptr, nullptr, N, N);
+    }
+  }
+  RC_HIP(ctx, hipGetLastError());
+  return MMG_OK;
+}
+
 struct RemlPoint {           // everything one delta yields
   double s1, s2, s3, s4;
   std::vector<double> beta;  // GLS estimate (q)
@@ -183,12 +206,20 @@ static int reml_point(mmg_ctx* ctx, mmg_reml* r, double delta, bool inverse, boo
   hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, r->dL, N, delta);
   {
     // measured at N = 50,000: rocsolver_dpotrf_64 1.31 s (32 TF); the blocked form over syrk_64 0.80 s (52 TF) at
-    // nb = 2048 (0.83 / 0.89 s at 4096 / 8192).  MMG_REML_POTRF=rocsolver | blocked:<nb> overrides.
+    // nb = 2048 (0.83 / 0.89 s at 4096 / 8192).  Default since round 4: potrf_own.  MMG_REML_POTRF=rocsolver | blocked:<nb> | own.
     const char* pe = std::getenv("MMG_REML_POTRF");
     const std::string ps = pe ? pe : "";
     long long* dacc = (long long*)(r->dsc + N + 6);
     RC_HIP(ctx, hipMemsetAsync(dinfo, 0, 4 * sizeof(int64_t), st));
-    if (ps != "rocsolver" && (N >= 4096 || ps.rfind("blocked", 0) == 0)) {
+    if (ps.empty() || ps == "own") {
+      Scratch scp;
+      double* LinvT = nullptr;
+      RC_HIP(ctx, scp.alloc(&LinvT, 4096 * sizeof(double)));
+      int rcb = potrf_own(ctx, r->dL, N, LinvT, dacc);
+      if (rcb) return rcb;
+      RC_HIP(ctx, hipMemcpyAsync(dinfo, dacc, sizeof(long long), hipMemcpyDeviceToDevice, st));
+      RC_HIP(ctx, hipStreamSynchronize(st));                  // LinvT is freed on leaving this scope
+    } else if (ps != "rocsolver" && (N >= 4096 || ps.rfind("blocked", 0) == 0)) {
       int64_t nb = 2048;
       if (ps.size() > 8) nb = std::max<int64_t>(256, std::atoll(ps.c_str() + 8));    // "blocked:<nb>"
       int rcb = potrf_blocked(ctx, h, r->dL, N, nb, (rocblas_int*)(r->dsc + N + 8), dacc);

@@ -97,10 +97,13 @@ class LinearModel(object):
 # Where get_estimates would compute eig_R itself, take the spectral sums from eig_L instead (no second eigh).
 REML_SUMS_FROM_EIG_L = True
 # above this many individuals emmax_f_test takes the eigendecomposition-free route when nothing needs H_sqrt_inv.
-# Mandatory beyond N = 46,340 (rocSOLVER's dsyevd indexes with 32 bits: N^2 < 2^31); already cheaper far below that since
-# the REML sums come from one band reduction of K (csrc/reml_band.hip): N = 20,000: 1.05 s + 0.3 s for the scan model
-# against 7.4 s of dsyevd + 2.9 s; at N = 5000 the two routes cost the same (0.2-0.3 s).
-EIGEN_FREE_MIN_N = 8191
+# Mandatory beyond N = 46,340 (rocSOLVER's dsyevd indexes with 32 bits: N^2 < 2^31).  Round 4: the route wins from the
+# smallest N at which the band reduction of K exists at all (csrc/reml_band.hip: Cholesky-QR panels on own kernels, the
+# secant search on an interpolant of the sums, own blocked Cholesky for the scan model) -- tools/reml_vs_eigh.py, emmax()
+# on resident genotypes, eigen route / this route: N = 300 9.9 / 5.6 ms, 1000 91 / 17 ms, 2000 100 / 48 ms, 5000 324 /
+# 126 ms, 8192 957 / 297 ms (profiles/r4_reml_vs_eigh.txt); round 3 had the crossover at 5000.  Below N = 256
+# mmg_reml_sums takes one Cholesky factorisation per delta and the eigen route stays.
+EIGEN_FREE_MIN_N = 255
 EIGH_MAX_N = 46340
 # emmax_f_test builds the scan model on the device from K and delta (mmg_reml_scan_model) when nothing needs H itself.
 DEVICE_SCAN_MODEL = True
@@ -165,24 +168,71 @@ class _SpectralSumsChol(object):
       chol  one Cholesky factorisation + triangular inverse of K + delta I per delta (csrc/reml_chol.hip, 1.6 s each at
             N = 50,000); coll: the grid values are dealt out to the ranks (every rank holds K), the sums all-gathered."""
 
+    # Chebyshev nodes of the local model of the sums over a bracket of the likelihood search (prepare_interval)
+    INTERP_NODES = 16
+    INTERP_MARGIN = 0.3                                                  # in log(delta), either side of the bracket
+
     def __init__(self, reml, coll=None, route="auto"):
         self.reml, self.coll, self.route = reml, coll, route
         self.band = reml.uses_band(route) if hasattr(reml, "uses_band") else False
         self.sum_sq_etas = None
         self.n_factorisations = 0                                        # deltas evaluated on this rank
+        self.n_calls = 0                                                 # device calls (each a latency chain of N steps)
         self._memo = {}
+        self._interp = None
+
+    def prepare_interval(self, d_lo, d_hi):
+        """The secant search of get_estimates (:847) asks for the sums at one delta after another inside the bracket
+        [d_lo, d_hi] -- on the band route every such question is a device call whose cost is a latency chain of N steps
+        (9 ms at N = 5000), the same for 1 or 51 deltas.  So ONE call evaluates the four sums at 16 Chebyshev nodes of
+        log(delta) over the bracket (+- 0.3), and the search runs on the interpolant: the sums are analytic in
+        u = log(delta) in the strip |Im u| < pi (their poles sit at delta = -lambda_i), the interval's half width is 0.5,
+        so the Bernstein ellipse through the nearest pole has rho = 12.6 and 16 nodes leave 12.6^-16 = 2e-18 -- below the
+        rounding noise of the evaluations themselves (1e-13).  Questions outside the interval, and the final
+        evaluation of the likelihood at the optimum (at_exact), go to the device."""
+        if not self.band:
+            return                                                       # the Cholesky route deals independent deltas over ranks
+        n = self.INTERP_NODES
+        lo, hi = np.log(d_lo) - self.INTERP_MARGIN, np.log(d_hi) + self.INTERP_MARGIN
+        k = np.arange(n)
+        x = np.cos(np.pi * (2 * k + 1) / (2 * n))                        # Chebyshev points of the first kind on [-1, 1]
+        w = (-1.0) ** k * np.sin(np.pi * (2 * k + 1) / (2 * n))          # their barycentric weights
+        u = 0.5 * (lo + hi) + 0.5 * (hi - lo) * x
+        vals = self._at(np.exp(u))
+        self._interp = (lo, hi, u, w, [np.asarray(v, dtype=np.float64) for v in vals])
+
+    def _from_model(self, delta):
+        lo, hi, u, w, vals = self._interp
+        t = np.log(delta)
+        d = t - u
+        hit = np.nonzero(d == 0.0)[0]
+        if len(hit):
+            return tuple(np.array([v[hit[0]]]) for v in vals)
+        c = w / d
+        return tuple(np.array([float(c @ v / c.sum())]) for v in vals)
 
     def at(self, deltas):
         deltas = np.asarray(deltas, dtype=np.float64).reshape(-1)
         if len(deltas) == 1:                                             # rell(opt), vg, ... ask for the same delta again
             key = float(deltas[0])
-            if key not in self._memo:
-                self._memo[key] = self._at(deltas)
+            if key in self._memo:
+                return self._memo[key]
+            if self._interp is not None and key > 0.0 and self._interp[0] <= np.log(key) <= self._interp[1]:
+                return self._from_model(key)
+            self._memo[key] = self._at(deltas)
             return self._memo[key]
         return self._at(deltas)
 
+    def at_exact(self, delta):
+        """The sums at one delta from the device, whatever prepare_interval set up (memoised)."""
+        key = float(delta)
+        if key not in self._memo:
+            self._memo[key] = self._at(np.array([key], dtype=np.float64))
+        return self._memo[key]
+
     def _at(self, deltas):
         coll = self.coll
+        self.n_calls += 1
         if coll is not None and coll.world > 1 and len(deltas) >= coll.world and not self.band:
             mine = np.arange(coll.rank, len(deltas), coll.world)
             # A factorisation may fail on SOME ranks only (an indefinite K: the smallest deltas sit on the low ranks).
@@ -394,8 +444,10 @@ class LinearMixedModel(object):
             a1, _a2, a3, a4 = sums.at(np.array([delta], dtype=np.float64))
             return float(p * a3[0] / a1[0] - a4[0])
 
+        exact = getattr(sums, 'at_exact', None) or (lambda d: sums.at(np.array([d], dtype=np.float64)))
+
         def rell(delta):                                                 # _rell_ (:618-623)
-            a1, a2, _a3, _a4 = sums.at(np.array([delta], dtype=np.float64))
+            a1, a2, _a3, _a4 = exact(delta)
             return float(0.5 * p * (np.log(p / (2.0 * np.pi)) - 1) - 0.5 * (p * np.log(a1[0]) + a2[0]))
 
         def dll(delta):                                                  # _dll_ (:643-649)
@@ -418,6 +470,8 @@ class LinearMixedModel(object):
         if len(zero_intervals) > 0:
             opt_ll, opt_i = max(zero_intervals)
             opt_delta = 0.5 * (deltas[opt_i - 1] + deltas[opt_i])
+            if hasattr(sums, 'prepare_interval'):
+                sums.prepare_interval(deltas[opt_i - 1], deltas[opt_i])   # band route: the search runs on a local model
             try:
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
@@ -441,13 +495,14 @@ class LinearMixedModel(object):
         # :894-896 -- the reference's (p,1)/(p,) broadcast makes vg = sum(sq_etas) *
         # sum(1/(lambda+delta)) / p ("BUG NEEDS TO BE FIXED HERE!!!" in its own words); the value
         # is reported as is so that results are identical; nothing on the scan path uses it.
-        opt_vg = sums.sum_sq_etas * sums.at(np.array([opt_delta], dtype=np.float64))[3][0] / p
+        opt_vg = sums.sum_sq_etas * exact(opt_delta)[3][0] / p
         opt_ve = opt_vg * opt_delta
         if isinstance(sums, _SpectralSumsChol):
             # no H_sqrt_inv without eigenvectors: the GLS estimate and the Mahalanobis RSS (= y'Py = s1) come with
             # the scan model (LinearMixedModel.scan_model_eigen_free)
             return {'max_ll': opt_ll, 'delta': opt_delta, 've': opt_ve, 'vg': opt_vg, 'H_sqrt_inv': None,
-                    'pseudo_heritability': 1.0 / (1 + opt_delta), 'n_factorisations': sums.n_factorisations}
+                    'pseudo_heritability': 1.0 / (1 + opt_delta), 'n_factorisations': sums.n_factorisations,
+                    'n_device_calls': sums.n_calls}
         # :898-907.  H_sqrt_inv = diag((lambda+delta)^-1/2) U'; its products with X and y are row scalings of the
         # rotated U'X, U'y that _SpectralSumsL already holds (O(N q) instead of O(N^2 q)); the N x N matrix itself
         # is only formed when the caller wants it (return_H; the exact-EMMA loop does not).

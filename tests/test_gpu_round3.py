@@ -377,13 +377,14 @@ def test_reml_band_route_reports_an_indefinite_matrix(ctx):
     reml.close()
 
 
-def test_emmax_routes_agree_just_above_the_eigen_free_threshold(ctx, monkeypatch):
-    """linear_models.emmax() at N = 8,500 (> EIGEN_FREE_MIN_N: REML through the band reduction, scan model from one
-    Cholesky factorisation, no eigh) against the same call with the threshold raised (eigh of K, REML from eig_L, the
-    reference's route :1233-1267): variance components to 1e-8, p-values to 1e-7 relative -- with a cofactor, so that
-    q = 2 runs through the banded solves."""
+@pytest.mark.parametrize("n", [5000, 8500])
+def test_emmax_routes_agree_just_above_the_eigen_free_threshold(ctx, monkeypatch, n):
+    """linear_models.emmax() at the headline N = 5,000 and at N = 8,500 (> EIGEN_FREE_MIN_N: REML through the band reduction,
+    scan model from one Cholesky factorisation, no eigh) against the same call with the threshold raised (eigh of K, REML
+    from eig_L, the reference's route :1233-1267): variance components to 1e-8, p-values to 1e-7 relative -- with a
+    cofactor, so that q = 2 runs through the banded solves."""
     from mixmogam_amd import linear_models as lm
-    n, m = 8500, 3000
+    m = 3000
     assert n > lm.EIGEN_FREE_MIN_N
     g = ctx.geno(M=m, N=n).fill_structured(77, npop=3)
     rows = g.download()

@@ -464,3 +464,55 @@ def test_band_route_sums_are_not_dealt_over_ranks():
     assert s.n_factorisations == 8
     with pytest.raises(AssertionError, match="no exchange"):
         lm._SpectralSumsChol(r, Coll(), route="chol").at(np.arange(1.0, 9.0))      # this one does go through the collective
+
+
+def test_reml_search_on_the_interpolated_sums_matches_the_exact_search():
+    """_SpectralSumsChol.prepare_interval (band route): the secant search of get_estimates (linear_models.py:847) runs on a
+    16-node Chebyshev model of the four likelihood sums over the bracket, so a whole search costs THREE device calls
+    (grid, nodes, optimum) instead of one per secant step.  With a stand-in workspace whose sums are exact functions of a
+    spectrum: the variance ratio agrees with the search on exact evaluations to 1e-11 relative, the likelihood at the
+    optimum is an exact evaluation, and the model itself is good to 1e-12 anywhere in its interval."""
+    rng = np.random.RandomState(3)
+    n = 400
+    pop = rng.randint(0, 3, size=n)
+    f = np.clip(0.5 + 0.2 * rng.standard_normal((1500, 3)), 0.05, 0.95)
+    S = (rng.random_sample((1500, n)) < f[:, pop]).astype(np.float64)
+    S = S[S.std(1) > 0]
+    Z = (S - S.mean(1, keepdims=True)) / S.std(1, keepdims=True)
+    K = Z.T @ Z / len(Z)
+    X = np.column_stack([np.ones(n), rng.standard_normal(n)])
+    y = 1.5 * (K @ rng.standard_normal(n)) / np.sqrt(n) + rng.standard_normal(n)
+    lam, U = np.linalg.eigh(K)
+    exact = lm._SpectralSumsL({'values': lam, 'vectors': U.T}, X, y)
+
+    class Reml(object):
+        N = n
+        calls = []
+        def uses_band(self, route="auto"):
+            return True
+        def sums(self, deltas, route="auto"):
+            self.calls.append(len(deltas))
+            return tuple(exact.at(np.asarray(deltas, dtype=np.float64))) + (exact.sum_sq_etas,)
+
+    model = lm.LinearMixedModel(list(y))
+    model.add_factor(X[:, 1])
+    r1 = Reml(); r1.calls = []
+    a = model.get_estimates(None, method='REML', _sums=lm._SpectralSumsChol(r1))
+    assert r1.calls == [51, lm._SpectralSumsChol.INTERP_NODES, 1], r1.calls       # grid, nodes, the optimum
+    assert a['n_device_calls'] == 3
+    r2 = Reml(); r2.calls = []
+    plain = lm._SpectralSumsChol(r2)
+    plain.prepare_interval = lambda lo, hi: None                                    # every secant step asks the workspace
+    b = model.get_estimates(None, method='REML', _sums=plain)
+    assert len(r2.calls) > 4 and 1e-3 < b['delta'] < 1e3                            # an interior optimum, several steps
+    assert abs(a['delta'] / b['delta'] - 1) < 1e-11, (a['delta'], b['delta'])
+    for k in ('max_ll', 've', 'vg', 'pseudo_heritability'):
+        assert abs(a[k] - b[k]) <= 1e-10 * max(1.0, abs(b[k])), (k, a[k], b[k])
+    # the model against exact evaluations across its interval
+    s = lm._SpectralSumsChol(Reml())
+    s.prepare_interval(0.5 * b['delta'], 1.5 * b['delta'])
+    for d in np.exp(np.linspace(s._interp[0], s._interp[1], 37)):
+        want = exact.at(np.array([d]))
+        got = s.at(np.array([d]))
+        for i in range(4):
+            assert abs(got[i][0] - want[i][0]) <= 1e-12 * max(1.0, abs(want[i][0])), (d, i)

@@ -1,30 +1,30 @@
-"""REML likelihood sums at size N: band route (one reduction + 57 deltas) against the eigendecomposition it replaces.
-   python tools/reml_vs_eigh.py N [N ...]"""
+#!/usr/bin/env python3
+"""Where the eigendecomposition-free route of emmax_f_test starts to pay: lm.emmax() on device-resident genotypes by both
+routes (rocSOLVER dsyevd + REML from eig_L  |  band reduction of K + banded REML + device scan model) over a range of N.
+    python tools/reml_vs_eigh.py [M] [N ...]        -> one line per N; linear_models.EIGEN_FREE_MIN_N is set from this"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mixmogam_amd import _lib
+from mixmogam_amd import _lib, kinship, linear_models as lm
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+Ns = [int(a) for a in sys.argv[2:]] or [300, 500, 1000, 1500, 2000, 3000, 4096, 5000, 8192]
 ctx = _lib.get_context()
-for N in [int(a) for a in sys.argv[1:]]:
-    rng = np.random.RandomState(0)
-    B = rng.standard_normal((N, 64))
-    K = B @ B.T / 64 + 0.5 * np.eye(N)
-    y = rng.standard_normal(N)
-    X = np.ones((N, 1))
-    deltas = np.exp(np.linspace(-10, 10, 51))
-    for rep in range(2):
-        reml = ctx.reml(K, X, y)
-        t0 = time.time()
-        reml.sums(deltas, route="band")
-        for k in range(6):
-            reml.sums(deltas[20 + k:21 + k], route="band")
-        t_band = time.time() - t0
-        t0 = time.time()
-        reml.scan_model(1.0)
-        t_model = time.time() - t0
-        reml.close()
-        t0 = time.time()
-        ctx.eigh(K)
-        t_eigh = time.time() - t0
-        print("N=%d rep %d: band route (reduction + 51 + 6 deltas) %.3f s, scan model %.3f s | eigh %.3f s (kernel %.1f ms)"
-              % (N, rep, t_band, t_model, t_eigh, ctx.kernel_ms("eigh")), flush=True)
+for N in Ns:
+    g = ctx.geno(M=M, N=N).fill_structured(7, npop=3)
+    K = kinship.calc_ibs_kinship(None, ctx=ctx, geno=g)
+    rng = np.random.RandomState(1)
+    y = rng.standard_normal(N) + g.download_rows([5])[0] + (K @ rng.standard_normal(N)) / np.sqrt(N)
+    out = {}
+    for name, min_n in (("eigen", 1 << 30), ("eigen_free", 0)):
+        lm.EIGEN_FREE_MIN_N = min_n
+        ts = []
+        for rep in range(4):
+            t0 = time.time()
+            res = lm.emmax(g, list(y), K, ctx=ctx)
+            ts.append(time.time() - t0)
+        out[name] = (min(ts[1:]), res)
+    a, b = out["eigen"][1], out["eigen_free"][1]
+    print("N=%5d M=%d: eigen %.4f s (eig_L %.4f)  eigen_free %.4f s (reml %.4f)  ratio %.2f   delta %.5e / %.5e  max rel p diff %.1e"
+          % (N, M, out["eigen"][0], a['timings']['eig_L'], out["eigen_free"][0], b['timings']['reml'], out["eigen"][0] / out["eigen_free"][0],
+             1 / a['pseudo_heritability'] - 1, 1 / b['pseudo_heritability'] - 1, float(np.max(np.abs(a['ps'] / b['ps'] - 1)))), flush=True)
+    g.close()
