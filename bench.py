@@ -475,7 +475,11 @@ def _profiled_traffic(N, M, D, adaptive):
     """HBM bytes per launch measured with rocprofv3 PMC passes of this same command (profiles/traffic_c3.json)."""
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_c3.json")))
-        if tj["config"] == {"n": N, "m": M, "digits": D} and tj.get("adaptive", False) == adaptive:
+        # `--digits 0` (the default model) runs four digit planes with the adaptive schedule: the profile's "digits": 4
+        # (rounds 2 and 3 both compared the dictionaries literally and shipped `traffic: null`; tests/test_host.py now
+        # loads the committed file with the default arguments)
+        cfg = tj["config"]
+        if (cfg["n"], cfg["m"], cfg.get("digits", 4)) == (N, M, D or 4) and tj.get("adaptive", False) == adaptive:
             return {k: v.get("hbm_bytes_corrected") for k, v in tj["kernels"].items()}
     except Exception:
         pass

@@ -140,16 +140,24 @@ static int lauum_lower(mmg_ctx* ctx, rocblas_handle h, const double* X, int64_t 
   return lauum_lower(ctx, h, X22, n2, ld, P + n1 + n1 * ldp, ldp);
 }
 
+static int potrf_own(mmg_ctx* ctx, double* A, int64_t N, int64_t lda, double* LinvT, long long* dacc, long long base);
+
 // Right-looking blocked Cholesky (lower, column-major, in place) over the 64-bit rocBLAS level-3 routines:
 // diagonal block by rocsolver_dpotrf, panel by trsm, trailing update by syrk -- the trailing update carries
 // N^3/3 of the flops at GEMM speed.  Selected with MMG_REML_POTRF=blocked (A/B against rocsolver_dpotrf_64).
-static int potrf_blocked(mmg_ctx* ctx, rocblas_handle h, double* A, int64_t N, int64_t nb, rocblas_int* dinfo, long long* dacc) {
+static int potrf_blocked(mmg_ctx* ctx, rocblas_handle h, double* A, int64_t N, int64_t nb, rocblas_int* dinfo, long long* dacc,
+                         double* LinvT = nullptr) {
   const double one = 1.0, mone = -1.0;
   for (int64_t k0 = 0; k0 < N; k0 += nb) {
     const int64_t kb = std::min(nb, N - k0), rest = N - k0 - kb;
     double* Akk = A + k0 + k0 * N;
-    RC_RB(ctx, rocsolver_dpotrf(h, rocblas_fill_lower, (rocblas_int)kb, Akk, (rocblas_int)N, dinfo));
-    hipLaunchKernelGGL(note_info_kernel, dim3(1), dim3(1), 0, ctx->stream, dinfo, dacc, (long long)k0);
+    if (LinvT) {                                             // diagonal block on this library's kernels (round 4)
+      int rc = potrf_own(ctx, Akk, kb, N, LinvT, dacc, (long long)k0);
+      if (rc) return rc;
+    } else {
+      RC_RB(ctx, rocsolver_dpotrf(h, rocblas_fill_lower, (rocblas_int)kb, Akk, (rocblas_int)N, dinfo));
+      hipLaunchKernelGGL(note_info_kernel, dim3(1), dim3(1), 0, ctx->stream, dinfo, dacc, (long long)k0);
+    }
     if (rest > 0) {
       double* Apk = A + (k0 + kb) + k0 * N;                 // panel below the diagonal block
       RC_RB(ctx, rocblas_dtrsm_64(h, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose,
@@ -166,17 +174,21 @@ static int potrf_blocked(mmg_ctx* ctx, rocblas_handle h, double* A, int64_t N, i
 // trailing matrix by the rank-64 update of its lower 64 x 64 tiles.  Three launches per 64 columns and no library call:
 // N = 5000 takes 79 x 3 launches where the blocked form above spent 17 ms in rocSOLVER's unblocked potf2 kernels and
 // forward substitutions (profiles/r4_*).
-static int potrf_own(mmg_ctx* ctx, double* A, int64_t N, double* LinvT /*device, 64 x 64*/, long long* dacc) {
+// At large N the rank-64 trailing updates stream the whole trailing matrix 64 columns at a time (N = 50,000: 1.76 s
+// against 0.80 s for 2048-column blocks over syrk_64), so beyond N = 8192 this factors the 2048-column diagonal blocks of
+// potrf_blocked and rocBLAS keeps the big updates.
+static int potrf_own(mmg_ctx* ctx, double* A, int64_t N, int64_t lda, double* LinvT /*device, 64 x 64*/, long long* dacc,
+                     long long base) {
   if (dense64_init()) return set_err(ctx, MMG_E_HIP, "hipFuncSetAttribute (dense64 kernels)");
   hipStream_t st = ctx->stream;
   for (int64_t k0 = 0; k0 < N; k0 += 64) {
     const int kb = (int)std::min<int64_t>(64, N - k0);
     const int64_t rest = N - k0 - kb;
-    launch_potrf_head(st, A + k0 + k0 * N, N, kb, LinvT, dacc, (long long)k0);
+    launch_potrf_head(st, A + k0 + k0 * lda, lda, kb, LinvT, dacc, base + (long long)k0);
     if (rest > 0) {
-      double* panel = A + (k0 + kb) + k0 * N;
-      launch_rows_gemm(st, panel, N, panel, N, rest, LinvT);                  // X L' = A  <=>  X = A L^-T
-      launch_nt_update_lower(st, A + (k0 + kb) + (k0 + kb) * N, N, rest, panel, panel, nullptr, nullptr, N, N);
+      double* panel = A + (k0 + kb) + k0 * lda;
+      launch_rows_gemm(st, panel, lda, panel, lda, rest, LinvT);              // X L' = A  <=>  X = A L^-T
+      launch_nt_update_lower(st, A + (k0 + kb) + (k0 + kb) * lda, lda, rest, panel, panel, nullptr, nullptr, lda, lda);
     }
   }
   RC_HIP(ctx, hipGetLastError());
@@ -215,7 +227,8 @@ static int reml_point(mmg_ctx* ctx, mmg_reml* r, double delta, bool inverse, boo
       Scratch scp;
       double* LinvT = nullptr;
       RC_HIP(ctx, scp.alloc(&LinvT, 4096 * sizeof(double)));
-      int rcb = potrf_own(ctx, r->dL, N, LinvT, dacc);
+      int rcb = N <= 8192 ? potrf_own(ctx, r->dL, N, N, LinvT, dacc, 0)
+                          : potrf_blocked(ctx, h, r->dL, N, 2048, (rocblas_int*)(r->dsc + N + 8), dacc, LinvT);
       if (rcb) return rcb;
       RC_HIP(ctx, hipMemcpyAsync(dinfo, dacc, sizeof(long long), hipMemcpyDeviceToDevice, st));
       RC_HIP(ctx, hipStreamSynchronize(st));                  // LinvT is freed on leaving this scope

@@ -1,0 +1,38 @@
+"""BASELINE config 5 AT ITS STATED SIZE under the GPU tests: N = 50,000 x M = 10,000,000 SNPs (500 GB of genotypes that are
+never stored: 1-bit packed rows regenerated chunk by chunk on each of the two reads), exact GRM kinship pass, REML from one
+band reduction of K, scan model from one Cholesky factorisation, EMMAX scan pass -- one GPU, the whole pipeline of
+hdf5_data.run_emmax (/root/reference/hdf5_data.py:70-187 is what it replaces).  The checker is float64 conjugate gradients
+on the host with H = K + delta I (no factorisation, no code shared with the device route): h0_rss to 1e-9, the p-values of 24
+SNPs (the 4 top hits + 20 random ones, rows regenerated from the generator) to 1e-6.
+
+Runs tools/c5_stream.py in its own process (the run wants ~130 GB of HBM and ~60 GB of host memory for itself) and prints
+its stage timings; round 3 had this run only as a builder-side log (profiles/r3an_*)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_config5_stated_size_one_gpu_streamed_pipeline_vs_float64_cg(capsys):
+    from mixmogam_amd import hdf5_data
+    hdf5_data.release_pools()                                 # HBM pools of earlier tests in this process
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "c5_stream.py"), "--world", "1", "--lazy", "--packed", "--samples", "24"]
+    env = dict(os.environ, MMG_REML_VERBOSE="1")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=840)
+    with capsys.disabled():
+        print("\n---- config 5, N = 50,000 x M = 10,000,000, one GPU (tools/c5_stream.py --world 1 --lazy --packed) ----")
+        print(r.stdout[-6000:])
+    assert r.returncode == 0, r.stdout[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["N"] == 50000 and rec["M_total"] == 10000000 and rec["M_share"] == 10000000
+    assert rec["n_sampled"] >= 24
+    assert rec["max_rel_p_err_vs_host_f64"] < 1e-6
+    assert rec["h0_rss_rel_err_vs_host_f64"] < 1e-9
+    assert "band reduction" in rec["route"]
+    assert not rec["adaptive_last_chunk"]["fell_back"]
+    assert rec["pipeline_s"] < 150.0                          # 76 s in round 3; 345 s in round 2

@@ -268,3 +268,20 @@ def test_bench_self_launch_fails_cleanly_without_devices(built):
     assert out.returncode != 0
     assert "needs 2 devices" in out.stderr
     assert not out.stdout.strip()
+
+
+def test_committed_traffic_profile_matches_the_default_bench_arguments(monkeypatch):
+    """bench.py fills roofline.traffic (scan GEMM), roofline_kinship.*.traffic and multi_phenotype.roofline.traffic from
+    profiles/traffic_c3.json when that file was taken on the workload being run.  Rounds 2 and 3 both shipped `null`
+    there because the file said "digits": 4 and the default run passes --digits 0: load the COMMITTED file with the
+    DEFAULT arguments and insist on numbers."""
+    import importlib, json, sys
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    bench = importlib.import_module("bench")
+    args = bench.parse()
+    t = bench._profiled_traffic(args.n, args.m, args.digits, True)
+    for kernel in (bench.QUAD_KERNEL, "kinship_f32_kernel", "kinship_f4_tr_kernel", "scan_multi_mfma_kernel", "rot_gemm_w4_kernel"):
+        assert t.get(kernel) and t[kernel] > 1e6, (kernel, t.get(kernel))
+    assert 2e10 < t[bench.QUAD_KERNEL] < 2e11                 # tens of GB per 1M-SNP launch (11.8x the algorithmic 5.2 GB in r3)
+    assert bench._profiled_traffic(args.n, args.m, 4, True) == t
+    assert bench._profiled_traffic(args.n + 1, args.m, 0, True) == {}          # another workload: no borrowed numbers

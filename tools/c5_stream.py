@@ -35,6 +35,7 @@ ap.add_argument("--packed", action="store_true",
 ap.add_argument("--max-gb", type=float, default=80.0, help="largest container this run may put into the scratch directory")
 ap.add_argument("--writers", type=int, default=8, help="processes generating / writing the container")
 ap.add_argument("--eig", action="store_true", help="take the eigendecomposition route (eigh of K) even beyond N = 46,340")
+ap.add_argument("--samples", type=int, default=12, help="SNPs whose p-values are recomputed in float64 on the host (4 top hits + random)")
 a = ap.parse_args()
 N, M, CH = a.n, a.m_total // a.world, a.chunk
 root = os.path.join(a.scratch, "mmg_c5_%d" % os.getpid())
@@ -168,7 +169,8 @@ try:
     rng = np.random.RandomState(3)
     hits = np.argsort(ps)
     hits = hits[ps[hits] > 1e-280][:4]
-    sample = np.unique(np.r_[hits, rng.choice(M, 8, replace=False)])
+    sample = np.unique(np.r_[hits, rng.choice(M, max(a.samples - len(hits), 1), replace=False)])
+    t_check = time.time()
     worst = 0.0
     for gi in sample:
         s = regenerate(gi).astype(np.float64)
@@ -184,8 +186,11 @@ try:
                       "chunks": len(plan), "timings": T, "pipeline_s": round(total, 1),
                       "snps_per_s_end_to_end": M / total, "min_p": float(ps.min()),
                       "route": "eigendecomposition-free (REML through %s)" % ("one band reduction" if eigen_free and _band else "Cholesky factorisations") if eigen_free else "eigh",
-                      "max_rel_p_err_vs_host_f64": worst, "adaptive_last_chunk": ctx.scan_last_stats()}))
+                      "max_rel_p_err_vs_host_f64": worst, "n_sampled": int(len(sample)),
+                      "h0_rss_rel_err_vs_host_f64": abs(prep["h0_rss"] / h0_rss - 1), "delta": delta,
+                      "host_check_s": round(time.time() - t_check, 1), "adaptive_last_chunk": ctx.scan_last_stats()}))
     assert worst < 1e-6
+    assert abs(prep["h0_rss"] / h0_rss - 1) < 1e-9
 finally:
     if not a.keep:
         shutil.rmtree(root, ignore_errors=True)
