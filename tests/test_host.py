@@ -151,8 +151,12 @@ from mixmogam_amd import hdf5_data
 src = {"chr%%d" %% c: {"raw_snps": snps[c * 167:(c + 1) * 167], "freqs": snps[c * 167:(c + 1) * 167].mean(1),
                      "positions": np.arange(167) + 1000 * c} for c in range(3)}
 pidx = [np.random.RandomState(9 + p).permutation(n) for p in range(5)]
-both = hdf5_data.run_emmax(src, y, min_maf=0.05, chunk_size=50, ctx=FakeContext(), coll=coll)
-solo = hdf5_data.run_emmax(src, y, min_maf=0.05, chunk_size=50, ctx=FakeContext(), coll=None)
+CHUNK = %(chunk)d                                                 # world 8: 6 chunks for 8 ranks -- two ranks own nothing
+plan = hdf5_data._chunk_plan(src, 0.05, CHUNK)
+owned = [ci for ci in range(len(plan)) if ci %% world == rank]
+assert (len(plan) < world) == (%(chunk)d == 100 and world == 8)
+both = hdf5_data.run_emmax(src, y, min_maf=0.05, chunk_size=CHUNK, ctx=FakeContext(), coll=coll)
+solo = hdf5_data.run_emmax(src, y, min_maf=0.05, chunk_size=CHUNK, ctx=FakeContext(), coll=None)
 assert both["num_snps"] == solo["num_snps"]
 assert np.allclose(both["kinship"], solo["kinship"], rtol=1e-12, atol=1e-12)
 assert abs(both["pseudo_heritability"] - solo["pseudo_heritability"]) < 1e-9
@@ -160,9 +164,9 @@ for c in solo["chrom_results"]:
     assert np.allclose(both["chrom_results"][c]["ps"], solo["chrom_results"][c]["ps"], rtol=1e-9)
 # permutations shuffle the elements of the ROTATED residual, so they depend on the sign LAPACK gives each
 # eigenvector (a 1e-16 difference in K can flip one): compare on the same kinship matrix
-bothp = hdf5_data.run_emmax(src, y, min_maf=0.05, chunk_size=50, ctx=FakeContext(), coll=coll, num_perm=5,
+bothp = hdf5_data.run_emmax(src, y, min_maf=0.05, chunk_size=CHUNK, ctx=FakeContext(), coll=coll, num_perm=5,
                             perm_idx=pidx, k=solo["kinship"])
-solop = hdf5_data.run_emmax(src, y, min_maf=0.05, chunk_size=50, ctx=FakeContext(), coll=None, num_perm=5,
+solop = hdf5_data.run_emmax(src, y, min_maf=0.05, chunk_size=CHUNK, ctx=FakeContext(), coll=None, num_perm=5,
                             perm_idx=pidx, k=solo["kinship"])
 assert np.allclose(bothp["perm_min_ps"], solop["perm_min_ps"], rtol=1e-9)
 assert np.allclose(bothp["perm_max_f_stats"], solop["perm_max_f_stats"], rtol=1e-9)
@@ -178,15 +182,16 @@ lmm_a = lm.LinearMixedModel(y, ctx=FakeContext()); lmm_a.add_random_effect(K)
 lmm_b = lm.LinearMixedModel(y, ctx=FakeContext()); lmm_b.add_random_effect(K)
 ra, rb = lmm_a.get_estimates_eigen_free(coll=coll), lmm_b.get_estimates_eigen_free()
 assert abs(ra["delta"] / rb["delta"] - 1) < 1e-12 and abs(ra["max_ll"] - rb["max_ll"]) < 1e-9
-assert ra["n_factorisations"] < rb["n_factorisations"]            # each rank factorised about half the grid
-# a factorisation that fails on ONE rank only (indefinite K: only the smallest delta, which rank 0 holds, breaks): every
-# rank still enters the all-gather, then all of them fall back together (advisor r2: the others used to hang)
+assert ra["n_factorisations"] < rb["n_factorisations"]            # each rank factorised about 1 / world of the grid
+assert ra["n_factorisations"] <= -(-51 // world) + 20
+# a factorisation that fails on ONE rank only (world 2: rank 0, which holds the smallest delta of an indefinite K; world 8:
+# rank 5): every rank still enters the all-gather, then all of them fall back together (advisor r2: the others used to hang)
 import warnings
 from mixmogam_amd import _lib
 from fake_ctx import FakeReml
 class BreakingReml(FakeReml):
     def sums(self, deltas):
-        if np.min(deltas) < 5e-5:
+        if rank == %(fail_rank)d:
             raise _lib.MixmogamHipError("libmixmogam_hip error -4: K + delta I is not positive definite (dpotrf info 3)")
         return FakeReml.sums(self, deltas)
 class BreakingCtx(FakeContext):
@@ -203,16 +208,36 @@ print("rank", rank, "ok")
 '''
 
 
-def test_sharding_world_size_2_gloo(tmp_path):
+def _run_gloo_workers(tmp_path, world, chunk, fail_rank, port):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"root": ROOT})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    script.write_text(WORKER % {"root": ROOT, "chunk": chunk, "fail_rank": fail_rank})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
+               OMP_NUM_THREADS="2" if world <= 2 else "1")
     procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=300)[0] for p in procs]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    try:
+        outs = [p.communicate(timeout=600)[0] for p in procs]
+    finally:
+        for p in procs:                                       # exact PIDs: a rank that died would leave the others in a collective
+            if p.poll() is None:
+                p.kill()
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "rank %d ok" % r in o
+
+
+def test_sharding_world_size_2_gloo(tmp_path):
+    _run_gloo_workers(tmp_path, 2, 50, 0, 29571)
+
+
+def test_sharding_world_size_8_gloo(tmp_path):
+    """The same sharding logic at the TARGET world size (BASELINE configs[3..4]: 8 GPUs of one node), over gloo on the CPU:
+    ragged SNP shards (501 SNPs over 8 ranks), a chunked driver with 6 chunks for 8 ranks (ranks 6 and 7 own nothing and
+    must still take part in every collective), the REML grid dealt 8 ways, and a Cholesky failure injected on rank 5
+    only (all ranks must raise together; nobody may be left inside the all-gather).  RCCL itself has only ever run with
+    one rank (one GPU per lease): this is the multi-rank evidence the pool allows."""
+    _run_gloo_workers(tmp_path, 8, 100, 5, 29581)
 
 
 def test_config1_plumbing_phenotypes_and_coordination():
