@@ -189,6 +189,11 @@ int mmg_reml_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, d
 #define MMG_REML_ROUTE_BAND 2
 int mmg_reml_sums_ex(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3,
                      double* s4, double* sum_sq_etas, int32_t route);
+/* The maximum-likelihood variant (get_ML, linear_models.py:672-683; _ll_ / _dll_ :634-649) sums log(lambda_i + delta) and
+ * 1 / (lambda_i + delta) over the spectrum of K itself: log|K + delta I| and tr (K + delta I)^-1, which the same
+ * factorisations yield; s1 and s3 as above.  Round 4 (the eigendecomposition-free route evaluated REML only). */
+int mmg_reml_sums_ml(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s3, double* logdet_h,
+                     double* tr_hinv, int32_t route);
 int mmg_reml_scan_model(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, double* h0_rss, double* beta,
                         double* mahalanobis_rss);
 
@@ -259,7 +264,7 @@ int mmg_emmax_perm_i8(mmg_ctx* ctx, const int8_t* snps, int64_t M, int32_t N, co
  * mmg_rot_create: evecs_rows host [N x N], ROWS are eigenvectors (mmg_eigh_f64's layout); digits them once and
  * allocates T for up to M_cap SNPs (8 N bytes per SNP; fp64, eigen-major inside blocks of 256 SNPs).
  * mmg_rot_load: T = S U' for the SNPs of g (exact int8-MFMA digit GEMM); g may be destroyed afterwards.
- * mmg_emmax_scan_multi: d, omega host [P x N]; G host [P x q x N]; h0_rss host [P]; 1 <= q <= 4; outputs host
+ * mmg_emmax_scan_multi: d, omega host [P x N]; G host [P x q x N]; h0_rss host [P]; 1 <= q <= 8 (q > 4: batches of 8 on the matrix-pipe kernel); outputs host
  * [P x M] (any may be NULL).  One HBM-bound pass over T per 8 phenotypes.
  * mmg_rot_fetch: out host [N x rows] = T[:, m0:m0+rows] (tests / diagnostics). */
 int mmg_rot_create(mmg_ctx* ctx, int32_t N, const double* evecs_rows, int64_t M_cap, mmg_rot** r);

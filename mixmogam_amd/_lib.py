@@ -82,6 +82,7 @@ PROTOTYPES = {
     "mmg_reml_destroy": (C.c_int, [c_vp, c_vp]),
     "mmg_reml_sums": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64p]),
     "mmg_reml_sums_ex": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64p, C.c_int32]),
+    "mmg_reml_sums_ml": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int32]),
     "mmg_reml_scan_model": (C.c_int, [c_vp, c_vp, C.c_double, C.c_int, c_f64p, c_vp, c_f64p]),
     "mmg_rot_create": (C.c_int, [c_vp, C.c_int32, c_vp, C.c_int64, C.POINTER(c_vp)]),
     "mmg_rot_destroy": (C.c_int, [c_vp, c_vp]),
@@ -441,6 +442,14 @@ class Reml(object):
         self.ctx._check(self.ctx.lib.mmg_reml_sums_ex(self.ctx.h, self.h, len(d), _ptr(d), *[_ptr(o) for o in out],
                                                       C.byref(sse), self.ROUTES[route]))
         return out[0], out[1], out[2], out[3], sse.value
+
+    def sums_ml(self, deltas, route="auto"):
+        """s1, s3, log|K + delta I|, tr (K + delta I)^-1 for every delta: what the ML likelihood needs (mmg_reml_sums_ml)."""
+        d = _arr(np.asarray(deltas).reshape(-1), np.float64)
+        out = [np.empty(len(d)) for _ in range(4)]
+        self.ctx._check(self.ctx.lib.mmg_reml_sums_ml(self.ctx.h, self.h, len(d), _ptr(d), *[_ptr(o) for o in out],
+                                                      self.ROUTES[route]))
+        return tuple(out)
 
     def scan_model(self, delta, ndigits=0):
         """Load the EMMAX scan model of `delta` into the context; returns (h0_rss, beta)."""

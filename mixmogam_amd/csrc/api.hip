@@ -1856,7 +1856,7 @@ int mmg_emmax_scan_multi(mmg_ctx* ctx, mmg_rot* r, int32_t P, int32_t q, const d
                          const double* G, const double* h0_rss, int32_t df2, double* rss, double* F, double* p) {
   Scratch sc;
   MMG_ENTER(ctx);
-  MMG_CHECK_ARG(ctx, r && d && omega && G && h0_rss && P > 0 && q >= 1 && q <= 4 && df2 > 0);
+  MMG_CHECK_ARG(ctx, r && d && omega && G && h0_rss && P > 0 && q >= 1 && q <= 8 && df2 > 0);
   const int64_t M = r->M;
   if (M == 0) return MMG_OK;
   const int N = r->N;
@@ -1904,7 +1904,7 @@ int mmg_emmax_scan_multi(mmg_ctx* ctx, mmg_rot* r, int32_t P, int32_t q, const d
   for (int b = 0; b < nbatch; ++b) {
     const int sI = b & (nset - 1), p0 = b * PBmax;
     const int nb = std::min(PBmax, P - p0);
-    int PB = 1;
+    int PB = q > 4 ? 8 : 1;                          // more than 4 fixed-effect columns: always the 8-wide matrix-pipe kernel
     while (PB < nb) PB *= 2;                         // 1, 2, 4, 8, 16: unused columns carry zero coefficients
     const int NC = PB * (2 + q);
     std::vector<double>& cf = coef[sI];

@@ -417,7 +417,7 @@ static void launch_multi(mmg_ctx* ctx, const double* T, int64_t nrows, int32_t N
   // MMG_MULTI_KERNEL=valu: the first-generation kernel (all columns on the VALU); default for batches of 8 and 16:
   // linear columns on the fp64 matrix pipe
   static const bool valu_only = [] { const char* e = std::getenv("MMG_MULTI_KERNEL"); return e && std::string(e) == "valu"; }();
-  if constexpr (PB >= 8) if (PB == 16 || !valu_only) {
+  if constexpr (PB >= 8) if (PB == 16 || !valu_only || Q > 4) {
     const int64_t nb = (M + 255) / 256;
     int ab = 0;
     if (const char* e = std::getenv("MMG_MULTI_ABL")) ab = std::atoi(e);
@@ -437,7 +437,7 @@ static void launch_multi(mmg_ctx* ctx, const double* T, int64_t nrows, int32_t N
 #undef MMG_LAUNCH_MFMA
     return;
   }
-  if constexpr (PB <= 8) {
+  if constexpr (PB <= 8 && Q <= 4) {
   constexpr int R = (PB * (2 + Q) <= 24) ? 2 : 1;            // accumulators: 2 R PB (2 + Q) VGPRs
   int rsel = R;
   if (const char* e = std::getenv("MMG_MULTI_R")) rsel = std::atoi(e) == 1 ? 1 : R;
@@ -471,8 +471,14 @@ int run_scan_multi(mmg_ctx* ctx, const double* T, int64_t nrows, int32_t N, int6
     else if (q == 3) MMG_MULTI(PB_, 3);                   \
     else MMG_MULTI(PB_, 4);                               \
   } while (0)
-  if (q < 1 || q > 4) return set_err(ctx, MMG_E_ARG, "multi-phenotype scan: 1 <= q <= 4 fixed-effect columns");
-  if (PB == 1) MMG_MULTI_Q(1);
+  if (q < 1 || q > 8) return set_err(ctx, MMG_E_ARG, "multi-phenotype scan: 1 <= q <= 8 fixed-effect columns");
+  if (q > 4) {
+    // wider models (round 4: more than 3 cofactors): 8 phenotypes per pass on the matrix-pipe kernel, whose tile count
+    // follows the column count (1 + ceil(8 (1 + q) / 16) tiles: 5 for q = 5, 6 for q = 8); smaller batches are padded
+    if (PB != 8) return set_err(ctx, MMG_E_ARG, "multi-phenotype scan: q > 4 runs in batches of 8");
+    if (q == 5) MMG_MULTI(8, 5); else if (q == 6) MMG_MULTI(8, 6); else if (q == 7) MMG_MULTI(8, 7); else MMG_MULTI(8, 8);
+  }
+  else if (PB == 1) MMG_MULTI_Q(1);
   else if (PB == 2) MMG_MULTI_Q(2);
   else if (PB == 4) MMG_MULTI_Q(4);
   else if (PB == 8) MMG_MULTI_Q(8);

@@ -965,7 +965,8 @@ void reml_band_free(mmg_reml* r) {
   r->band_ready = false;
 }
 
-int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3, double* s4) {
+int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3, double* s4,
+                   double* ldh, double* trh) {
   if (!r->band_ready) {
     int rc = band_reduce(ctx, r);
     if (rc) return rc;
@@ -1036,6 +1037,8 @@ int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, 
         v3 -= 2.0 * beta[i] * gg[i * q1 + q];
         for (int j = 0; j < q; ++j) v3 += beta[i] * beta[j] * gg[i * q1 + j];
       }
+      if (ldh) ldh[g0 + k] = hs[k];
+      if (trh) trh[g0 + k] = hs[ng + k];
       s1[g0 + k] = c - bb;
       s2[g0 + k] = hs[k] + logdet_a - r->logdet_xtx;
       s3[g0 + k] = v3;

@@ -197,6 +197,7 @@ static int potrf_own(mmg_ctx* ctx, double* A, int64_t N, int64_t lda, double* Li
 
 struct RemlPoint {           // everything one delta yields
   double s1, s2, s3, s4;
+  double ldh = 0.0, trh = 0.0;   // log|H|, tr H^-1
   std::vector<double> beta;  // GLS estimate (q)
   std::vector<double> Py;    // N (only when asked for)
   std::vector<double> GA;    // N x q row-major: H^-1 X (X'H^-1 X)^-1 (only when asked for)
@@ -309,6 +310,8 @@ static int reml_point(mmg_ctx* ctx, mmg_reml* r, double delta, bool inverse, boo
   pt.s2 = logdetH + logdet_a - r->logdet_xtx;
   pt.s3 = s3;
   pt.s4 = trHinv - tr_aB2;
+  pt.ldh = logdetH;
+  pt.trh = trHinv;
   pt.beta = beta;
   if (want_vectors) {
     pt.Py = Py;
@@ -408,6 +411,26 @@ int mmg_reml_sums_ex(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas
     int rc = reml_point(ctx, r, deltas[k], true, false, pt);
     if (rc) return rc;
     s1[k] = pt.s1; s2[k] = pt.s2; s3[k] = pt.s3; s4[k] = pt.s4;
+  }
+  return MMG_OK;
+}
+
+int mmg_reml_sums_ml(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s3, double* logdet_h,
+                     double* tr_hinv, int32_t route) {
+  if (!ctx) return MMG_E_ARG;
+  RC_HIP(ctx, hipSetDevice(ctx->device));
+  if (!(r && deltas && s1 && s3 && logdet_h && tr_hinv && nd >= 0 && route >= 0 && route <= 2))
+    return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_sums_ml");
+  if (route == MMG_REML_ROUTE_AUTO) route = (r->band_ready || r->N >= 256) ? MMG_REML_ROUTE_BAND : MMG_REML_ROUTE_CHOL;
+  if (route == MMG_REML_ROUTE_BAND) {
+    std::vector<double> s2((size_t)nd), s4((size_t)nd);
+    return reml_band_sums(ctx, r, nd, deltas, s1, s2.data(), s3, s4.data(), logdet_h, tr_hinv);
+  }
+  for (int k = 0; k < nd; ++k) {
+    RemlPoint pt;
+    int rc = reml_point(ctx, r, deltas[k], true, false, pt);
+    if (rc) return rc;
+    s1[k] = pt.s1; s3[k] = pt.s3; logdet_h[k] = pt.ldh; tr_hinv[k] = pt.trh;
   }
   return MMG_OK;
 }

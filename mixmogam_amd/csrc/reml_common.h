@@ -90,6 +90,8 @@ static inline int reml_handle(mmg_ctx* ctx, rocblas_handle* h) {
 
 namespace mmg {
 // reml_band.hip: the four sums for nd deltas through the band matrix (reduces K on first use)
-int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3, double* s4);
+// ldh / trh (optional): log|K + delta I| and tr (K + delta I)^-1 of every delta (what the ML likelihood adds, :634-649)
+int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3, double* s4,
+                   double* ldh = nullptr, double* trh = nullptr);
 void reml_band_free(mmg_reml* r);
 }

@@ -259,6 +259,38 @@ def _ibd_kinship(ctx, genot_data, n_indivs, plan, coll=None, prefetch=True):
     return kinship.scale_k(k_mat), n_all                                 # :108-111 (inline scale_k)
 
 
+def _ibd_kinship_normalised(ctx, genot_data, n_indivs, chunk_size, coll=None):
+    """hdf5_data.py:37-44 for trees that carry pre-normalised float `snps` datasets (a chromosome without one is
+    standardised per SNP as the reference does it, :40-43): K = sum_chunks x'x / n_snps over the rows x of each chunk --
+    a device fp64 GEMM per chunk (mmg_dgemm_f64: the values are arbitrary floats, so the exact int8 routes do not apply),
+    chunks dealt round-robin over the ranks and the partial sums all-reduced; then scale_k's rule (:46-49)."""
+    rank, world = (coll.rank, coll.world) if coll is not None else (0, 1)
+    k_sum = np.zeros((n_indivs, n_indivs))
+    n_snps, ci = 0, 0
+    for chrom in genot_data.keys():
+        cg = genot_data[chrom]
+        normalised = 'snps' in cg.keys()
+        ds = cg['snps'] if normalised else cg['raw_snps']
+        num = len(ds)
+        for i in range(0, num, chunk_size):
+            end = min(i + chunk_size, num)
+            n_snps += end - i
+            mine = ci % world == rank
+            ci += 1
+            if not mine:
+                continue
+            x = np.asarray(ds[i:end], dtype=np.float64)
+            if not normalised:
+                sd = x.std(1)
+                if np.any(sd == 0):
+                    raise ValueError("a SNP without variation cannot be standardised (std == 0)")
+                x = (x - x.mean(1, keepdims=True)) / sd[:, None]
+            k_sum += ctx.dgemm(x, x, ta=True)                            # x'x: [N x rows] [rows x N]
+    if coll is not None and world > 1:
+        k_sum = np.asarray(coll.allreduce(k_sum, "sum")).reshape(n_indivs, n_indivs)
+    return kinship.scale_k(k_sum / float(n_snps)), n_snps
+
+
 def calculate_ibd_kinship(hdf5_filename, n_indivs=None, min_maf=None, chunk_size=100000, overwrite=False, ctx=None,
                           coll=None):
     """hdf5_data.py:17-62: K = sum_m z_m z_m' / n_snps with z = (s - mean)/std per SNP, scaled with scale_k's rule.
@@ -272,17 +304,19 @@ def calculate_ibd_kinship(hdf5_filename, n_indivs=None, min_maf=None, chunk_size
         n = len(h5f['indiv_data']['indiv_ids'][...])
         if 'kinship' in h5f.keys() and not overwrite:
             return np.asarray(h5f['kinship'][...]), None
-        for chrom in h5f['genot_data'].keys():
-            if 'snps' in h5f['genot_data'][chrom].keys():
-                raise NotImplementedError("pre-normalised 'snps' datasets (:37,44) are not on the int8 device path")
-        plan = _chunk_plan(h5f['genot_data'], min_maf, chunk_size)
-        k, n_snps = _ibd_kinship(ctx, h5f['genot_data'], n, plan, coll)
+        if any('snps' in h5f['genot_data'][chrom].keys() for chrom in h5f['genot_data'].keys()):
+            k, n_snps = _ibd_kinship_normalised(ctx, h5f['genot_data'], n, chunk_size, coll)   # :37,44
+        else:
+            plan = _chunk_plan(h5f['genot_data'], min_maf, chunk_size)
+            k, n_snps = _ibd_kinship(ctx, h5f['genot_data'], n, plan, coll)
         if coll is None or coll.rank == 0:
             if 'kinship' in h5f.keys():
                 del h5f['kinship']
             h5f.create_dataset('kinship', data=k)
             h5f.flush()
         return k, n_snps
+    if any('snps' in hdf5_filename[chrom].keys() for chrom in hdf5_filename.keys()):
+        return _ibd_kinship_normalised(ctx, hdf5_filename, n_indivs, chunk_size, coll)
     plan = _chunk_plan(hdf5_filename, min_maf, chunk_size)
     return _ibd_kinship(ctx, hdf5_filename, n_indivs, plan, coll)
 

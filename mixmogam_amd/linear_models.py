@@ -71,9 +71,11 @@ class LinearModel(object):
 
     def fast_f_test(self, snps, verbose=True, Z=None, with_betas=False, ndigits=0):
         """:196-257 -- per-SNP F test of y ~ X + snp.  M = I - QQ' (:215-218) is idempotent, so
-        the closed form of the scan applies with A = M and w = M y."""
-        if with_betas or Z is not None:
-            raise NotImplementedError("fast_f_test(with_betas / Z) is not on the device path")
+        the closed form of the scan applies with A = M and w = M y.
+        with_betas (:220-221,:233-239): the reference regresses the RESIDUAL r = y - X b0 on [X, s] per SNP and reports those
+        coefficients -- in closed form b_snp = (s.r) / (s'Ms) and, for the covariates, -(X'X)^-1 X's b_snp (r is
+        orthogonal to X); a SNP that leaves the design rank deficient keeps h0_betas and rss = h0_rss (:236-239).
+        Z is accepted and, as in the reference (:196, never read in the body), ignored."""
         ctx = self.ctx
         y = self.Y.reshape(-1)
         (h0_betas, _r, h0_rank, h0_s) = linalg.lstsq(self.X, y)          # :210
@@ -84,14 +86,22 @@ class LinearModel(object):
         n_p = self.n - (self.X.shape[1] + 1)
         own = not isinstance(snps, _lib.Geno)
         g = ctx.geno(kinship._as_snp_matrix(snps)) if own else snps
+        res = None
         try:
             ctx.scan_set_model(A, r, ndigits)
-            out = ctx.scan(g, h0_rss, n_p)
+            out = ctx.scan(g, h0_rss, n_p, stats=with_betas)
+            res = {'ps': out['ps'], 'f_stats': out['f_stats'], 'rss': out['rss'], 'var_perc': 1 - out['rss'] / h0_rss,
+                   'h0_rss': np.array([h0_rss]), 'h0_betas': [float(b) for b in h0_betas]}
+            if with_betas:
+                ok = out['rss'] != h0_rss
+                b_snp = np.where(ok, out['dot'] / np.where(ok, out['den'], 1.0), 0.0)
+                Cs = g.matvec(linalg.solve_triangular(R, Q.T))           # (X'X)^-1 X' s for every SNP: q x M
+                res['betas'] = [([float(-Cs[k, j] * b_snp[j]) for k in range(Cs.shape[0])] + [float(b_snp[j])]) if ok[j]
+                                else list(res['h0_betas']) for j in range(g.M)]
         finally:
             if own:
                 g.close()
-        return {'ps': out['ps'], 'f_stats': out['f_stats'], 'rss': out['rss'], 'var_perc': 1 - out['rss'] / h0_rss,
-                'h0_rss': np.array([h0_rss]), 'h0_betas': [float(b) for b in h0_betas]}
+        return res
 
 
 # Where get_estimates would compute eig_R itself, take the spectral sums from eig_L instead (no second eigh).
@@ -222,6 +232,13 @@ class _SpectralSumsChol(object):
             self._memo[key] = self._at(deltas)
             return self._memo[key]
         return self._at(deltas)
+
+    def at_ml(self, deltas):
+        """(s1, s3, log|K + delta I|, tr (K + delta I)^-1) per delta: the sums of the ML likelihood (:634-649, :821-826)."""
+        deltas = np.asarray(deltas, dtype=np.float64).reshape(-1)
+        self.n_calls += 1
+        self.n_factorisations += len(deltas)
+        return self.reml.sums_ml(deltas, self.route) if self.route != "auto" else self.reml.sums_ml(deltas)
 
     def at_exact(self, delta):
         """The sums at one delta from the device, whatever prepare_interval set up (memoised)."""
@@ -419,23 +436,34 @@ class LinearMixedModel(object):
         # a caller-supplied eig_R that the reference would use (xs given) is used as is.
         if _sums is not None:
             sums = _sums                                                 # e.g. _SpectralSumsChol: no eigen-pairs at all
-            if method != 'REML':
-                raise NotImplementedError("the eigendecomposition-free route evaluates the restricted likelihood only")
+            if method != 'REML' and not hasattr(sums, 'at_ml'):
+                raise NotImplementedError("these sums evaluate the restricted likelihood only")
         elif eig_R and (xs is not None or use_eig_R):
             sums = _SpectralSumsR(eig_R, y, p)
         elif K is not None or not REML_SUMS_FROM_EIG_L:
             sums = _SpectralSumsR(self._get_eigen_R_(X=X, K=K), y, p)   # :787 (quirk kept)
         else:
             sums = _SpectralSumsL(eig_L, X, y, rot=_rot)
-        s1, s2, s3, s4 = sums.at(deltas)
+        # the ML likelihood sums log(lambda + delta), 1 / (lambda + delta) over the spectrum of K itself (:634-649): from the
+        # eigenvalues, or -- on the eigendecomposition-free route -- as log|K + delta I| and tr (K + delta I)^-1
+        if eig_vals_L is not None:
+            def h_terms(dd):
+                xis = eig_vals_L[:, None] + np.asarray(dd, dtype=np.float64).reshape(1, -1)
+                return np.sum(np.log(xis), axis=0), np.sum(1 / xis, axis=0)
+        elif method == 'ML':
+            def h_terms(dd):
+                return sums.at_ml(dd)[2:]
+        if method == 'ML' and eig_vals_L is None:
+            s1, s3, _ld, _tr = sums.at_ml(deltas)
+            s2 = s4 = None
+        else:
+            s1, s2, s3, s4 = sums.at(deltas)
         if method == 'REML':
             lls = 0.5 * (p * (np.log(p / (2.0 * np.pi)) - 1 - np.log(s1)) - s2)        # :807
             dlls = 0.5 * (p * s3 / s1 - s4)
         elif method == 'ML':
-            xis = eig_vals_L[:, None] + deltas[None, :]
-            s2 = np.sum(np.log(xis), axis=0)
+            s2, s4 = h_terms(deltas)
             lls = 0.5 * (n * (np.log(n / (2.0 * np.pi)) - 1 - np.log(s1)) - s2)        # :821
-            s4 = np.sum(1 / xis, axis=0)
             dlls = 0.5 * (n * s3 / s1 - s4)
         else:
             raise ValueError(method)
@@ -450,14 +478,22 @@ class LinearMixedModel(object):
             a1, a2, _a3, _a4 = exact(delta)
             return float(0.5 * p * (np.log(p / (2.0 * np.pi)) - 1) - 0.5 * (p * np.log(a1[0]) + a2[0]))
 
+        def ml_point(delta):                                             # (s1, s3, sum log, sum 1/.) at one delta
+            dd = np.array([delta], dtype=np.float64)
+            if eig_vals_L is None:
+                a1, a3, ld, tr = sums.at_ml(dd)
+                return a1[0], a3[0], ld[0], tr[0]
+            a1, _a2, a3, _a4 = sums.at(dd)
+            ld, tr = h_terms(dd)
+            return a1[0], a3[0], ld[0], tr[0]
+
         def dll(delta):                                                  # _dll_ (:643-649)
-            a1, _a2, a3, _a4 = sums.at(np.array([delta], dtype=np.float64))
-            return float(n * a3[0] / a1[0] - np.sum(1.0 / (eig_vals_L + delta)))
+            a1, a3, _ld, tr = ml_point(delta)
+            return float(n * a3 / a1 - tr)
 
         def ll(delta):                                                   # _ll_ (:634-640)
-            a1, _a2, _a3, _a4 = sums.at(np.array([delta], dtype=np.float64))
-            return float(0.5 * n * (np.log(n / (2.0 * np.pi)) - 1)
-                         - 0.5 * (n * np.log(a1[0]) + np.sum(np.log(eig_vals_L + delta))))
+            a1, _a3, ld, _tr = ml_point(delta)
+            return float(0.5 * n * (np.log(n / (2.0 * np.pi)) - 1) - 0.5 * (n * np.log(a1) + ld))
 
         max_ll_i = int(np.argmax(lls))
         max_ll = lls[max_ll_i]
@@ -470,7 +506,7 @@ class LinearMixedModel(object):
         if len(zero_intervals) > 0:
             opt_ll, opt_i = max(zero_intervals)
             opt_delta = 0.5 * (deltas[opt_i - 1] + deltas[opt_i])
-            if hasattr(sums, 'prepare_interval'):
+            if hasattr(sums, 'prepare_interval') and method == 'REML':
                 sums.prepare_interval(deltas[opt_i - 1], deltas[opt_i])   # band route: the search runs on a local model
             try:
                 with warnings.catch_warnings():
@@ -495,7 +531,12 @@ class LinearMixedModel(object):
         # :894-896 -- the reference's (p,1)/(p,) broadcast makes vg = sum(sq_etas) *
         # sum(1/(lambda+delta)) / p ("BUG NEEDS TO BE FIXED HERE!!!" in its own words); the value
         # is reported as is so that results are identical; nothing on the scan path uses it.
-        opt_vg = sums.sum_sq_etas * exact(opt_delta)[3][0] / p
+        if method == 'ML' and eig_vals_L is None:
+            # :894 needs sum 1 / (xi + delta) over the spectrum of S(K + delta I)S = s4 of the REML sums
+            s4_opt = sums.at(np.array([opt_delta], dtype=np.float64))[3][0]   # (also fills sums.sum_sq_etas)
+            opt_vg = sums.sum_sq_etas * s4_opt / p
+        else:
+            opt_vg = sums.sum_sq_etas * exact(opt_delta)[3][0] / p
         opt_ve = opt_vg * opt_delta
         if isinstance(sums, _SpectralSumsChol):
             # no H_sqrt_inv without eigenvectors: the GLS estimate and the Mahalanobis RSS (= y'Py = s1) come with
@@ -647,14 +688,14 @@ class LinearMixedModel(object):
             warnings.warn("K + delta*I is not positive definite on the REML grid; taking the eigendecomposition route")
             return None
 
-    def get_estimates_eigen_free(self, ngrids=50, llim=-10, ulim=10, esp=1e-6, coll=None):
+    def get_estimates_eigen_free(self, ngrids=50, llim=-10, ulim=10, esp=1e-6, coll=None, method='REML'):
         """get_estimates(method='REML') (:771-927) without eig_L / eig_R: the likelihood sums come from Cholesky
         factorisations on the device (_SpectralSumsChol).  Returns the same scalars (max_ll, delta, ve, vg,
         pseudo_heritability) plus 'reml': the device workspace to hand to scan_model_eigen_free.  No H_sqrt_inv:
         callers that need the matrix itself (permutation test, exact EMMA) take the eigen route."""
         K = self.random_effects[1][1]
         reml = self.ctx.reml(K, self.X, self.Y.reshape(-1))
-        res = self.get_estimates(None, ngrids=ngrids, llim=llim, ulim=ulim, esp=esp, method='REML',
+        res = self.get_estimates(None, ngrids=ngrids, llim=llim, ulim=ulim, esp=esp, method=method,
                                  _sums=_SpectralSumsChol(reml, coll))
         res['reml'] = reml
         return res
@@ -700,9 +741,8 @@ class LinearMixedModel(object):
         _delta (internal): build the scan model from K and this variance ratio on the device instead of from
         H_sqrt_inv on the host (same matrix: Mp Mp' = P(delta))."""
         ctx = self.ctx
-        if return_transformed_snps and (H_sqrt_inv is None or with_betas):
-            # the reference's M is H' itself under with_betas (:1305); only the projected form is on the device path
-            raise NotImplementedError("return_transformed_snps needs H_sqrt_inv and with_betas=False")
+        if return_transformed_snps and H_sqrt_inv is None:
+            raise NotImplementedError("return_transformed_snps needs H_sqrt_inv")
         prep = None
         if _delta is not None and Z is None and not with_betas:
             reml = _reml if _reml is not None else ctx.reml(self.random_effects[1][1], self.X, self.Y.reshape(-1))
@@ -746,7 +786,7 @@ class LinearMixedModel(object):
                         betas.append(list(prep['h0_betas']))
                 res_d['betas'] = betas
             if return_transformed_snps:                                  # :1309-1321,:1355-1356
-                res_d['t_snps'] = self._transformed_snps(g, H_sqrt_inv, Z)
+                res_d['t_snps'] = self._transformed_snps(g, H_sqrt_inv, Z, project=not with_betas)
             if snp_priors is not None:                                   # :1311-1314,:1357-1363
                 snp_priors = np.asarray(snp_priors, dtype=np.float64)
                 n = self.n
@@ -768,7 +808,7 @@ class LinearMixedModel(object):
                 g.close()
         return res_d
 
-    def _transformed_snps(self, g, H_sqrt_inv, Z=None):
+    def _transformed_snps(self, g, H_sqrt_inv, Z=None, project=True):
         """t_m = s_m Mp, Mp = H'(I - QQ') (:1300-1303,1318-1321): what the reference's loop regresses the residual
         on, returned as a list of M arrays like the reference's `t_snps`.  T = S Mp is the rotation GEMM of the
         multi-phenotype path with the rows of Mp' = (I - QQ')H in place of the eigenvectors (mmg_rot_load: exact int8
@@ -779,7 +819,8 @@ class LinearMixedModel(object):
         if Z is not None:
             H = H @ np.asarray(Z, dtype=np.float64)
         (Q, _R) = linalg.qr(h0_X, mode='economic')
-        MpT = H - Q @ (Q.T @ H)                                          # (I - QQ') H = Mp'   [n x n_geno]
+        # with_betas: the reference regresses on [h0_X, H s] and its M is H' itself (:1305); otherwise Mp' = (I - QQ') H
+        MpT = H - Q @ (Q.T @ H) if project else H                        # [n x n_geno]
         if MpT.shape[0] != MpT.shape[1] or g.M == 0:
             S = g.download().astype(np.float64)
             T = self.ctx.dgemm(MpT, S, tb=True) if g.M else np.zeros((MpT.shape[0], 0))
@@ -996,8 +1037,8 @@ def emmax_multi(snps, phenotypes, K, cofactors=None, ctx=None, coll=None, max_st
     ctx = lmm0.ctx
     X = lmm0.X
     q = X.shape[1]
-    if q > 4:
-        raise NotImplementedError("emmax_multi: at most 3 cofactors besides the intercept on the rotated path")
+    if q > 8:
+        raise NotImplementedError("emmax_multi: at most 7 cofactors besides the intercept on the rotated path")
     eig_L = lmm0._get_eigen_L_()
     models, d, omega, G = _multi_models(ys, X, eig_L, method=method)
     h0 = np.array([m['h0_rss'] for m in models])

@@ -45,3 +45,12 @@ def load_extras2():
     n = int(d["n"])
     d["snps"] = np.unpackbits(d["snps_packed"], axis=1)[:, :n].astype(np.int8)
     return d
+
+
+def load_extras3():
+    """tests/golden/extras3_n150.npz (round 4): LinearModel.fast_f_test(with_betas=True), _emmax_f_test_(with_betas=True,
+    return_transformed_snps=True) and the reference's loop of emmax() with four cofactors, all from the reference itself."""
+    d = dict(np.load(os.path.join(GOLDEN, "extras3_n150.npz")))
+    n = int(d["n"])
+    d["snps"] = np.unpackbits(d["snps_packed"], axis=1)[:, :n].astype(np.int8)
+    return d

@@ -264,6 +264,59 @@ def run_extras2(mods_by_mode):
     print('extras2_n150', snps.shape, '%.0f KB' % (os.path.getsize(path) / 1024.0))
 
 
+def run_extras3(mods_by_mode):
+    """Round-4 known answers (own file: the earlier fixtures stay bit-identical):
+    * LinearModel.fast_f_test(with_betas=True) (linear_models.py:196-257: the residual regressed on [X, s] per SNP), one
+      cofactor, the last SNP monomorphic (rank-deficient design: keeps h0_betas, :236-239);
+    * _emmax_f_test_(with_betas=True, return_transformed_snps=True): under with_betas the reference's M is H' itself
+      (:1305-1306), so t_snps are the unprojected rotated SNPs; `betas` per SNP (:1323-1326);
+    * the reference's loop of emmax() runs over three phenotypes with FOUR cofactors (q = 5 fixed-effect columns)."""
+    rng = np.random.RandomState(41)
+    n, m = 150, 400
+    snps = structured_genotypes(rng, n, m)
+    y = phenotype(rng, snps, h2=0.5, ncausal=6)
+    cofs = [rng.randn(n) + 0.4 * snps[3 + i] for i in range(4)]
+    ys = np.array([y, phenotype(rng, snps, h2=0.7, ncausal=9), phenotype(rng, snps, h2=0.3, ncausal=5)])
+    data = {'snps_packed': np.packbits(snps.astype(np.uint8), axis=1), 'n': np.int64(n), 'y': y, 'ys': ys,
+            'cofs': np.asarray(cofs)}
+    sub = [s for s in snps[:79]] + [np.ones(n, dtype=np.int8)]
+    for mode, mods in mods_by_mode.items():
+        lm, kin = mods['linear_models'], mods['kinship']
+        lin = lm.LinearModel(list(y))
+        lin.add_factor(cofs[0])
+        r = quiet(lin.fast_f_test, sub, with_betas=True)
+        for k in ('ps', 'f_stats', 'rss', 'var_perc'):
+            data['%s_lmwb_%s' % (mode, k)] = np.asarray(r[k], dtype=np.float64).reshape(-1)
+        data['%s_lmwb_h0_rss' % mode] = np.asarray(r['h0_rss'], dtype=np.float64).reshape(-1)
+        data['%s_lmwb_h0_betas' % mode] = np.asarray(list(r['h0_betas']), dtype=np.float64)
+        data['%s_lmwb_betas' % mode] = np.asarray([list(b) for b in r['betas']], dtype=np.float64)
+        k_ibs = np.asarray(quiet(kin.calc_ibs_kinship, list(snps)))
+        if mode == 'dbl':
+            data['ibs_scaled'] = k_ibs
+        lmm = lm.LinearMixedModel(list(y))
+        lmm.add_random_effect(k_ibs)
+        lmm.add_factor(cofs[0])
+        eig_L = lmm._get_eigen_L_()
+        est = quiet(lmm.get_estimates, eig_L, method='REML')
+        H = np.asarray(est['H_sqrt_inv'], dtype=np.float64)
+        r = quiet(lmm._emmax_f_test_, list(snps[:64]), est['H_sqrt_inv'], return_transformed_snps=True, with_betas=True,
+                  emma_num=0)
+        data['%s_twb_H' % mode] = H if mode == 'dbl' else H.astype(np.float32)
+        data['%s_twb_snps' % mode] = np.asarray(r['t_snps'], dtype=np.float64)
+        data['%s_twb_ps' % mode] = np.asarray(r['ps'], dtype=np.float64).reshape(-1)
+        data['%s_twb_betas' % mode] = np.asarray([list(b) for b in r['betas']], dtype=np.float64)
+        ps, deltas = [], []
+        for yy in ys:
+            rr = quiet(lm.emmax, list(snps), list(yy), k_ibs, cofactors=[list(c) for c in cofs])
+            ps.append(np.asarray(rr['ps'], dtype=np.float64).reshape(-1))
+            deltas.append(1.0 / float(rr['pseudo_heritability']) - 1.0)
+        data['%s_mc4_ps' % mode] = np.asarray(ps)
+        data['%s_mc4_delta' % mode] = np.asarray(deltas)
+    path = os.path.join(HERE, 'extras3_n150.npz')
+    np.savez_compressed(path, **data)
+    print('extras3_n150', snps.shape, '%.0f KB' % (os.path.getsize(path) / 1024.0))
+
+
 CASES = [
     # name, kind, N, M, seed, n_cofactors, nperm
     ('struct_n150_s0', 'struct', 150, 600, 0, 0, 20),
@@ -283,7 +336,9 @@ def main():
         run_extras(mods)
     if os.environ.get('MMG_GOLDEN_ONLY', '') in ('', 'extras2'):
         run_extras2(mods)
-    if os.environ.get('MMG_GOLDEN_ONLY', '') in ('extras', 'extras2'):
+    if os.environ.get('MMG_GOLDEN_ONLY', '') in ('', 'extras3'):
+        run_extras3(mods)
+    if os.environ.get('MMG_GOLDEN_ONLY', '') in ('extras', 'extras2', 'extras3'):
         return
     for name, kind, n, m, seed, ncof, nperm in CASES:
         rng = np.random.RandomState(seed)

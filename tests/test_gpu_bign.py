@@ -61,19 +61,16 @@ def test_eigen_free_route_beyond_the_syevd_index_range(ctx):
     assert cnt == M and K.shape == (N, N)
     cols = np.r_[0:24, N - 24:N]                            # both ends of the index range
     sub = np.ascontiguousarray(g.download()[:, cols]).astype(np.float64)
-    z = (sub - sub.mean(0)) / sub.std(0)
     mean_all, std_all = g.snp_stats()
     rows = np.r_[0:8, M - 8:M]
     s_rows = g.download_rows(rows).astype(np.float64)
     assert np.allclose(mean_all[rows], s_rows.mean(1), rtol=0, atol=1e-14) and np.allclose(std_all[rows], s_rows.std(1), rtol=1e-13)
-    # z above standardises over the 48 sampled individuals' SNP values per SNP?  No: per SNP over ALL individuals.
-    zs = (sub - mean_all[:, None]) / std_all[:, None]
+    zs = (sub - mean_all[:, None]) / std_all[:, None]       # every SNP standardised over ALL individuals (hdf5_data.py:101)
     ref = zs.T @ zs
     got = K[np.ix_(cols, cols)]
     assert np.max(np.abs(got - ref)) < 1e-9 * np.max(np.abs(ref)), "GRM corner (first / last 24 individuals)"
     stride = 1499
     assert np.array_equal(K[cols][:, ::stride], K[::stride][:, cols].T)       # symmetric across the whole index range
-    del z
     K /= float(M)
 
     rng = np.random.RandomState(7)
@@ -123,7 +120,7 @@ def test_eigen_free_route_beyond_the_syevd_index_range(ctx):
     U, it = _cg(K, delta, np.column_stack([np.ones(N), y, S]))
     T["host_cg_pvalues"] = time.time() - t0
     a = float(U[:, 0].sum())
-    proj = lambda V: V - np.outer(U[:, 0], U[:, 0].T @ np.ones(N) * 0 + V.sum(0) / a) if False else V - np.outer(U[:, 0], (np.ones(N) @ V) / a)
+    proj = lambda V: V - np.outer(U[:, 0], (np.ones(N) @ V) / a)     # H^-1 V -> P V for X = 1:  P = H^-1 - H^-1 1 1'H^-1 / (1'H^-1 1)
     Py = proj(U[:, 1:2])[:, 0]
     PS = proj(U[:, 2:])
     h0 = float(y @ Py)

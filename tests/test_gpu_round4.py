@@ -1,0 +1,117 @@
+"""GPU tests of round 4: the surface closures of tests/_round4_cases.py on the device, the Cholesky-QR band reduction of K
+against the Householder one, the interpolated REML search against the step-by-step one."""
+import numpy as np
+import pytest
+
+import _round4_cases as r4
+from conftest import load_extras, load_extras3
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from mixmogam_amd import _lib
+    return _lib.get_context()
+
+
+@pytest.fixture(scope="module")
+def ex3():
+    return load_extras3()
+
+
+def test_fast_f_test_with_betas_vs_the_reference(ctx, ex3):
+    r4.fast_f_test_with_betas(ctx, ex3)
+
+
+def test_transformed_snps_with_betas_vs_the_reference(ctx, ex3):
+    r4.transformed_snps_with_betas(ctx, ex3)
+
+
+def test_emmax_multi_with_four_cofactors_vs_the_reference_loop(ctx, ex3):
+    r4.emmax_multi_four_cofactors(ctx, ex3)
+
+
+def test_ml_estimates_without_an_eigendecomposition_vs_the_reference(ctx):
+    r4.ml_without_an_eigendecomposition(ctx, load_extras())
+
+
+def test_ibd_kinship_from_pre_normalised_snps_datasets(ctx):
+    r4.ibd_kinship_from_normalised_snps(ctx)
+
+
+@pytest.mark.parametrize("n", [129, 300, 1000])
+def test_band_reduction_cholesky_qr_panels_vs_householder_panels(ctx, monkeypatch, n):
+    """reml_band.hip: the round-4 reduction (Cholesky-QR panels, basis-kernel orthogonal factor, own products) and the
+    round-3 one (MMG_BAND_IMPL=hh: Householder panel steps + rocBLAS updates) are different orthogonal similarities of the
+    same K: every likelihood sum agrees to 1e-10, at sizes with 1, 3 and 14 full panels plus the short tail block."""
+    rng = np.random.RandomState(n)
+    m = 4 * n
+    f = np.clip(0.5 + 0.25 * rng.standard_normal((m, 3)), 0.05, 0.95)
+    S = (rng.random_sample((m, n)) < f[:, rng.randint(0, 3, size=n)]).astype(np.float64)
+    S = S[S.std(1) > 0]
+    Z = (S - S.mean(1, keepdims=True)) / S.std(1, keepdims=True)
+    K = Z.T @ Z / len(Z)
+    X = np.column_stack([np.ones(n), rng.standard_normal(n)])
+    y = rng.standard_normal(n) + Z[3]
+    deltas = np.exp(np.linspace(-8, 8, 7))
+    reml = ctx.reml(K, X, y)
+    new = reml.sums(deltas, route="band")
+    reml.close()
+    monkeypatch.setenv("MMG_BAND_IMPL", "hh")
+    reml = ctx.reml(K, X, y)
+    old = reml.sums(deltas, route="band")
+    reml.close()
+    for i in range(4):
+        assert np.max(np.abs(new[i] - old[i]) / np.maximum(np.abs(old[i]), 1.0)) < 1e-10, (n, i)
+
+
+def test_band_reduction_falls_back_on_duplicated_individuals(ctx):
+    """Two identical individuals make a panel of the reduction exactly rank deficient: Cholesky-QR cannot factor it, the
+    device flag sends the whole reduction through the Householder path, and the sums still match dense float64."""
+    from test_gpu_round3 import _reml_sums_f64
+    rng = np.random.RandomState(12)
+    n, m = 400, 900
+    S = (rng.random_sample((m, n)) < 0.4).astype(np.float64)
+    S[:, 7] = S[:, 3]                                          # individuals 3 and 7: the same genotypes
+    S[:, 250] = S[:, 3]
+    Z = (S - S.mean(1, keepdims=True)) / S.std(1, keepdims=True)
+    K = Z.T @ Z / m
+    X = np.ones((n, 1))
+    y = rng.standard_normal(n)
+    reml = ctx.reml(K, X, y)
+    deltas = [0.05, 2.0]
+    got = reml.sums(deltas, route="band")
+    reml.close()
+    for k, d in enumerate(deltas):
+        want = _reml_sums_f64(K, X, y, d)
+        for i in range(4):
+            assert abs(got[i][k] - want[i]) <= 1e-9 * max(abs(want[i]), 1.0), (d, i, got[i][k], want[i])
+
+
+def test_reml_search_on_the_interpolant_vs_step_by_step_on_the_device(ctx, monkeypatch):
+    """get_estimates_eigen_free at N = 1,500: three device calls (grid, 16 Chebyshev nodes, optimum) against one call per
+    secant step -- the variance ratio to 1e-10, the likelihood at the optimum an exact evaluation either way."""
+    from mixmogam_amd import linear_models as lm
+    n, m = 1500, 4000
+    g = ctx.geno(M=m, N=n).fill_structured(5, npop=3)
+    acc = ctx.kinship_accumulator(n)
+    acc.add_grm(g)
+    K, cnt = acc.fetch()
+    acc.close()
+    K = K / cnt
+    rng = np.random.RandomState(0)
+    y = rng.standard_normal(n) + 1.5 * (K @ rng.standard_normal(n)) / np.sqrt(n) + g.download_rows([11])[0]
+    g.close()
+    lmm = lm.LinearMixedModel(list(y), ctx=ctx)
+    lmm.add_random_effect(K)
+    a = lmm.get_estimates_eigen_free()
+    a.pop("reml").close()
+    assert a["n_device_calls"] == 3
+    monkeypatch.setattr(lm._SpectralSumsChol, "prepare_interval", lambda self, lo, hi: None)
+    b = lmm.get_estimates_eigen_free()
+    b.pop("reml").close()
+    assert b["n_device_calls"] > 4 and 1e-3 < b["delta"] < 1e3
+    assert abs(a["delta"] / b["delta"] - 1) < 1e-10
+    for k in ("max_ll", "ve", "vg"):
+        assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), k

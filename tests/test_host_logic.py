@@ -516,3 +516,19 @@ def test_reml_search_on_the_interpolated_sums_matches_the_exact_search():
         got = s.at(np.array([d]))
         for i in range(4):
             assert abs(got[i][0] - want[i][0]) <= 1e-12 * max(1.0, abs(want[i][0])), (d, i)
+
+
+# ---------------------------------------------------------------------- round 4: surface closures on the numpy stand-in
+def test_round4_surface_closures_against_the_reference_numbers():
+    """fast_f_test(with_betas / Z), t_snps under with_betas, emmax_multi with four cofactors, ML without eigh and IBD
+    kinship from pre-normalised `snps` datasets -- host logic through the numpy stand-in context (the same cases run on
+    the device in tests/test_gpu_round4.py)."""
+    import _round4_cases as r4
+    from conftest import load_extras, load_extras3
+    from fake_ctx import FakeContext
+    ex3, ex = load_extras3(), load_extras()
+    r4.fast_f_test_with_betas(FakeContext(), ex3, tol=1e-8)
+    r4.transformed_snps_with_betas(FakeContext(), ex3, tol_t=1e-10, tol=1e-7)
+    r4.emmax_multi_four_cofactors(FakeContext(), ex3, tol=1e-7)
+    r4.ml_without_an_eigendecomposition(FakeContext(), ex, tol=1e-7)
+    r4.ibd_kinship_from_normalised_snps(FakeContext())
