@@ -136,8 +136,15 @@ int mmg_kin_acc_add(mmg_ctx* ctx, mmg_kin_acc* acc, mmg_geno* g, const float* sc
 /* GRM chunk (kinship.py:66-69, hdf5_data.py:99-106): acc += sum_m z_m z_m' with z = (s - mean)/std computed per SNP on
  * the device in fp64 -- EXACT route: z z' = a^2 s s' + a b (s 1' + 1 s') + b^2 1 1'; the weighted Gram matrix
  * sum_m s s'/std^2 is 4-5 int8-MFMA GEMMs of the IBS kind (the weight 1/std^2 split into non-negative digits folded into
- * one operand), the rank-one terms fp64 dot products.  ~5x faster than the fp32-MFMA kernel and good to ~1e-9; falls
- * back to that kernel for genotype alphabets beyond -4..4.  A SNP with std == 0 is an error (kinship.py:67). */
+ * one operand), the rank-one terms fp64 dot products.  ~5x faster than the fp32-MFMA kernel; falls back to that kernel for
+ * genotype alphabets beyond -4..4.  A SNP with std == 0 is an error (kinship.py:67).
+ * Precision: every weight is rounded to 2^-30 of the call's LARGEST weight (five planes; 2^-35 / 2^-30 for alphabets beyond
+ * 0/1), entries good to ~1e-9 of the float64 result.  Binary stores of >= 65,536 SNPs whose weights span less than a
+ * factor 64 (any MAF filter >= 0.004) take FOUR planes, 2^-28 of the largest weight -- the per-SNP roundings are
+ * independent and average down as 1/sqrt(M).  The digits are relative to the largest weight OF THE CALL, so the sum
+ * depends (at that level, ~1e-10) on how the SNPs are grouped into calls: a multi-rank or differently chunked run is
+ * equal to a single-rank one to rounding, not bit for bit (the IBS counts of mmg_kinship_ibs_i8 are).
+ * One call may hold at most (2^31 - 1) / (127 smax^2) SNPs (16.9 M binary ones): the digit planes are 32-bit sums. */
 int mmg_kin_acc_add_grm(mmg_ctx* ctx, mmg_kin_acc* acc, mmg_geno* g);
 int mmg_kin_acc_fetch(mmg_ctx* ctx, mmg_kin_acc* acc, double* C_out, int64_t* n_snps);
 /* scale_k of the reference (kinship.py:94-100, inlined at hdf5_data.py:108-111) on the device-resident matrix, in place:
@@ -194,6 +201,10 @@ int mmg_reml_sums_ex(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas
  * factorisations yield; s1 and s3 as above.  Round 4 (the eigendecomposition-free route evaluated REML only). */
 int mmg_reml_sums_ml(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s3, double* logdet_h,
                      double* tr_hinv, int32_t route);
+/* State of the workspace's band reduction: *band_ready = 1 once K has been reduced (every later AUTO call then takes the
+ * band route, whatever N); *householder_fallback = 1 if a Cholesky-QR panel was numerically rank deficient and the
+ * reduction was redone with Householder panels (csrc/reml_band.hip); *seconds = what the reduction took.  NULLs allowed. */
+int mmg_reml_band_info(mmg_ctx* ctx, mmg_reml* r, int32_t* band_ready, int32_t* householder_fallback, double* seconds);
 int mmg_reml_scan_model(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, double* h0_rss, double* beta,
                         double* mahalanobis_rss);
 

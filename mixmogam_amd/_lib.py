@@ -83,6 +83,7 @@ PROTOTYPES = {
     "mmg_reml_sums": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64p]),
     "mmg_reml_sums_ex": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64p, C.c_int32]),
     "mmg_reml_sums_ml": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int32]),
+    "mmg_reml_band_info": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mmg_reml_scan_model": (C.c_int, [c_vp, c_vp, C.c_double, C.c_int, c_f64p, c_vp, c_f64p]),
     "mmg_rot_create": (C.c_int, [c_vp, C.c_int32, c_vp, C.c_int64, C.POINTER(c_vp)]),
     "mmg_rot_destroy": (C.c_int, [c_vp, c_vp]),
@@ -426,12 +427,20 @@ class Reml(object):
 
     ROUTES = {"auto": 0, "chol": 1, "band": 2}
 
+    def band_info(self):
+        """{'ready': K has been reduced, 'householder_fallback': a Cholesky-QR panel was rank deficient and the reduction
+        was redone with Householder panels, 'seconds': what the reduction took} (mmg_reml_band_info)."""
+        ready, fb, sec = C.c_int32(0), C.c_int32(0), C.c_double(0.0)
+        self.ctx._check(self.ctx.lib.mmg_reml_band_info(self.ctx.h, self.h, C.byref(ready), C.byref(fb), C.byref(sec)))
+        return {"ready": bool(ready.value), "householder_fallback": bool(fb.value), "seconds": sec.value}
+
     def uses_band(self, route="auto"):
-        """Whether sums(route) goes through the band reduction (mirrors mmg_reml_sums_ex's AUTO rule)."""
+        """Whether sums(route) goes through the band reduction: mmg_reml_sums_ex's AUTO rule, including its 'a workspace
+        that has been reduced stays on the band route' term (advisor r3)."""
         if route != "auto":
             return route == "band"
         env = os.environ.get("MMG_REML_ROUTE", "")
-        return env != "chol" and (env == "band" or self.N >= 256)
+        return env != "chol" and (env == "band" or self.N >= 256 or self.band_info()["ready"])
 
     def sums(self, deltas, route="auto"):
         """s1..s4 for every delta, sum_sq_etas.  route: 'chol' = one Cholesky factorisation per delta, 'band' = K reduced

@@ -118,6 +118,7 @@ int mmg_ctx_destroy(mmg_ctx* ctx) {
   if (ctx->sel_geno) { hipFree(ctx->sel_geno->d); hipFree(ctx->sel_geno->bits); hipFree(ctx->sel_geno->d_smax); delete ctx->sel_geno; }
   hipFree(ctx->dstage);
   hipFree(ctx->grp_tab);
+  hipFree(ctx->jobs);
   hipFree(ctx->ingest);
   if (ctx->rocblas) rocblas_destroy_handle((rocblas_handle)ctx->rocblas);
   for (int i = 0; i < EV_COUNT; ++i) { hipEventDestroy(ctx->ev[i][0]); hipEventDestroy(ctx->ev[i][1]); }
@@ -749,6 +750,11 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
   if (bd == 7 && g->M >= 65536) D = 4;
   if (const char* e = std::getenv("MMG_GRM_PLANES")) { const int v = std::atoi(e); if (v >= 4 && v <= 6) D = v; }
   const double base = (double)(1 << bd);
+  // every int32 plane sums digit * s_i * s_j over ALL SNPs of the call (one combine at the end): the digits are non-negative,
+  // so a plane only grows -- (2^bd - 1) smax^2 M must stay below 2^31 (advisor r3; 16.9 M binary SNPs per call, 8.5 M for
+  // alphabets within +-2; the chunked drivers pass far fewer per call)
+  if ((double)((1 << bd) - 1) * g->smax * g->smax * (double)g->M >= 2147483648.0)
+    return set_err(ctx, MMG_E_ARG, "exact GRM: too many SNPs in one call for the 32-bit digit planes (split the call)");
   // Round 3: the digit images are SNP-major like the store (row m scaled by the digit of SNP m) and the GEMM reads both
   // through transposed LDS reads (kinship_i8_tr_kernel) -- no transposition pass, no plain image.  MMG_KIN_KERNEL=w4 /
   // w8: the individual-major generations.
@@ -756,11 +762,11 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
   const bool direct = !tr_off;
   // binary store and four planes: ONE pass over the genotypes computes all four (gemm_i8_grm4.h: the scaled operands are
   // formed in registers from the plain tiles) -- no digit images at all.  MMG_GRM_FUSED=0: one GEMM per plane.
-  const bool fused = [&] { const char* e = std::getenv("MMG_GRM_FUSED"); return direct && D == 4 && g->smax <= 1 && g->sneg == 0 && !(e && e[0] == '0'); }();
+  bool fused = [&] { const char* e = std::getenv("MMG_GRM_FUSED"); return direct && D == 4 && g->smax <= 1 && g->sneg == 0 && !(e && e[0] == '0'); }();
   const int64_t M = g->M, CH = kin_chunk();
   const int64_t Mk_max = std::min(round_up(M, BK), CH);
   // per-SNP mean / std in fp64 on the device, weights and digits on the host (M values)
-  {
+  auto ensure_ws = [&](int D, bool fused) -> int {
     const size_t need_img = fused ? 16 : (size_t)g->Npad * Mk_max, need_c32 = (size_t)g->Npad * g->Npad;
     if (ws.cap_img < need_img || ws.cap_c32 < need_c32 || ws.capD < D || ws.cap_m < (size_t)M || ws.cap_mk < (size_t)Mk_max ||
         ws.cap_n < (size_t)g->Npad || ws.direct != direct) {
@@ -780,16 +786,16 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
       ws.cap_img = need_img; ws.cap_c32 = need_c32; ws.capD = D; ws.cap_m = (size_t)M; ws.cap_mk = (size_t)Mk_max;
       ws.cap_n = (size_t)g->Npad;
     }
-  }
-  double *dm = ws.dm, *ds = ws.ds, *dcoef = ws.dcoef, *dc1 = ws.dc1, *dc1acc = ws.dc1acc;
-  int8_t *ddig = ws.ddig, *Xq = ws.Xq, *Xp = ws.Xp;
-  int* C32 = ws.C32;
+    return MMG_OK;
+  };
+  { int rcw = ensure_ws(D, fused); if (rcw) return rcw; }
+  double *dm = ws.dm, *ds = ws.ds;
   launch_snp_stats(ctx, g, dm, ds);
   std::vector<double> mean((size_t)M), sd((size_t)M);
   MMG_HIP(ctx, hipMemcpyAsync(mean.data(), dm, M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MMG_HIP(ctx, hipMemcpyAsync(sd.data(), ds, M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  double wmax = 0.0, c0 = 0.0;
+  double wmax = 0.0, wmin = 1e300, c0 = 0.0;
   std::vector<double> omega((size_t)M), coef((size_t)M);
   for (int64_t m = 0; m < M; ++m) {
     if (!(sd[m] > 0.0)) return set_err(ctx, MMG_E_ARG, "monomorphic SNP (std == 0) in the GRM kinship");
@@ -797,7 +803,21 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
     coef[m] = -mean[m] * omega[m];                         // a b
     c0 += mean[m] * mean[m] * omega[m];                    // b^2
     wmax = std::max(wmax, omega[m]);
+    wmin = std::min(wmin, omega[m]);
   }
+  // Four planes quantise a weight to 2^-28 of the LARGEST one: fine while the weights are of one size (a MAF filter of
+  // 0.1 keeps wmax / wmin below 2.8), not when rare variants stretch the range (no filter: wmax / wmin ~ N / 4) -- then
+  // the fifth plane stays (advisor r3).  The fused one-pass kernel computes four planes; five take one GEMM per plane.
+  if (D == 4 && wmax > 64.0 * wmin && !std::getenv("MMG_GRM_PLANES")) {
+    D = 5;
+    fused = false;
+    int rcw = ensure_ws(D, fused);
+    if (rcw) return rcw;
+    dm = ws.dm; ds = ws.ds;
+  }
+  double *dcoef = ws.dcoef, *dc1 = ws.dc1, *dc1acc = ws.dc1acc;
+  int8_t *ddig = ws.ddig, *Xq = ws.Xq, *Xp = ws.Xp;
+  int* C32 = ws.C32;
   // D unsigned digits reach B^D - 1: the largest weight is scaled onto exactly that
   const double step = wmax / (std::pow(base, D) - 1.0);
   MMG_HIP(ctx, hipMemsetAsync(C32, 0, (size_t)D * g->Npad * g->Npad * sizeof(int), ctx->stream));

@@ -430,13 +430,29 @@ void launch_grm_combine(mmg_ctx* ctx, const int* C32, int D, int32_t Npad, int32
 constexpr int KIN_PF_DEFAULT = 0;     // L2 prefetch distance of the transposed-read kinship kernel (see run_kinship_i8_tr)
 
 // C32 (upper tiles) += Sp' Sq over rows [0, nk * 128) of two SNP-major images with row stride ld (Sp == Sq: the store)
+// Device copy of a launch's job list in the context's cached buffer (no hipMalloc / hipFree per launch: those serialise
+// the device against the upload stream, and an early return between them leaked the list -- advisor r3).  The copy is
+// asynchronous on the library stream; the callers synchronise before `jobs` goes out of scope.
+static int job_buffer(mmg_ctx* ctx, const std::vector<KinJob>& jobs, KinJob** out) {
+  const size_t bytes = jobs.size() * sizeof(KinJob);
+  if (ctx->jobs_cap < bytes) {
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));        // an earlier launch may still read the old buffer
+    (void)hipFree(ctx->jobs);
+    ctx->jobs = nullptr; ctx->jobs_cap = 0;
+    MMG_HIP(ctx, hipMalloc(&ctx->jobs, bytes + bytes / 2));
+    ctx->jobs_cap = bytes + bytes / 2;
+  }
+  MMG_HIP(ctx, hipMemcpyAsync(ctx->jobs, jobs.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+  *out = (KinJob*)ctx->jobs;
+  return MMG_OK;
+}
+
 int run_kinship_i8_tr(mmg_ctx* ctx, const int8_t* Sp, const int8_t* Sq, int64_t ld, int32_t Npad, int64_t nk, int* C32) {
   const int nT = Npad / TM;
   const int ksplit = kinship_pick_ksplit(Npad, nk * BK, false);
   std::vector<KinJob> jobs = build_jobs(nT, (int)nk, ksplit);
   KinJob* djobs = nullptr;
-  MMG_HIP(ctx, hipMalloc(&djobs, jobs.size() * sizeof(KinJob)));
-  MMG_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(KinJob), hipMemcpyHostToDevice, ctx->stream));
+  { int rcj = job_buffer(ctx, jobs, &djobs); if (rcj) return rcj; }
   // MMG_KIN_N3 = 8 | 16: DMA pieces issued right behind the barrier; MMG_KIN_PF = 0 | 1 | 2: L2 prefetch distance
   // (gemm_i8_w4tr.h) -- A/B timing
   static const int n3 = [] { const char* e = std::getenv("MMG_KIN_N3"); return e && std::atoi(e) == 16 ? 16 : 8; }();
@@ -457,7 +473,6 @@ int run_kinship_i8_tr(mmg_ctx* ctx, const int8_t* Sp, const int8_t* Sq, int64_t 
   }
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  MMG_HIP(ctx, hipFree(djobs));
   return MMG_OK;
 }
 
@@ -501,8 +516,7 @@ int run_kinship_grm4(mmg_ctx* ctx, const int8_t* S, int64_t ld, int32_t Npad, in
   }
   while (jobs.size() % 256) jobs.push_back(KinJob{0, 0, 0, 0, 0, 0, 0, 0});
   KinJob* djobs = nullptr;
-  MMG_HIP(ctx, hipMalloc(&djobs, jobs.size() * sizeof(KinJob)));
-  MMG_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(KinJob), hipMemcpyHostToDevice, ctx->stream));
+  { int rcj = job_buffer(ctx, jobs, &djobs); if (rcj) return rcj; }
   int abl = 0;                                            // MMG_GRM4_ABL=1|2|3: timing ablations (wrong results)
   if (const char* e = std::getenv("MMG_GRM4_ABL")) abl = std::atoi(e);
 #define MMG_LAUNCH_G4(A)                                                                                                \
@@ -516,7 +530,6 @@ int run_kinship_grm4(mmg_ctx* ctx, const int8_t* S, int64_t ld, int32_t Npad, in
 #undef MMG_LAUNCH_G4
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  MMG_HIP(ctx, hipFree(djobs));
   return MMG_OK;
 }
 
@@ -529,8 +542,7 @@ int run_kinship_i8_pq(mmg_ctx* ctx, const int8_t* Xp, const int8_t* Xq, int32_t 
   const int ksplit = kinship_pick_ksplit(Npad, Mk, false);
   std::vector<KinJob> jobs = build_jobs(nT, nk, ksplit);
   KinJob* djobs = nullptr;
-  MMG_HIP(ctx, hipMalloc(&djobs, jobs.size() * sizeof(KinJob)));
-  MMG_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(KinJob), hipMemcpyHostToDevice, ctx->stream));
+  { int rcj = job_buffer(ctx, jobs, &djobs); if (rcj) return rcj; }
   // MMG_KIN_KERNEL=w8: the first-generation 8-wave kernel (A/B runs; same bits)
   static const bool w8 = [] { const char* e = std::getenv("MMG_KIN_KERNEL"); return e && std::string(e) == "w8"; }();
   const void* fn = w8 ? (const void*)kinship_i8_kernel : (const void*)kinship_i8_w4_kernel;
@@ -546,7 +558,6 @@ int run_kinship_i8_pq(mmg_ctx* ctx, const int8_t* Xp, const int8_t* Xq, int32_t 
   }
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  MMG_HIP(ctx, hipFree(djobs));
   return MMG_OK;
 }
 
@@ -555,8 +566,7 @@ int run_kinship_f32(mmg_ctx* ctx, const int8_t* Xt, int32_t Npad, int64_t Mk, co
   const int nT = Npad / TM, nk = (int)(Mk / BK);
   std::vector<KinJob> jobs = build_jobs(nT, nk, ksplit);
   KinJob* djobs = nullptr;
-  MMG_HIP(ctx, hipMalloc(&djobs, jobs.size() * sizeof(KinJob)));
-  MMG_HIP(ctx, hipMemcpyAsync(djobs, jobs.data(), jobs.size() * sizeof(KinJob), hipMemcpyHostToDevice, ctx->stream));
+  { int rcj = job_buffer(ctx, jobs, &djobs); if (rcj) return rcj; }
   MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   {
     EvScope ev(ctx, EV_KIN);
@@ -565,7 +575,6 @@ int run_kinship_f32(mmg_ctx* ctx, const int8_t* Xt, int32_t Npad, int64_t Mk, co
   }
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  MMG_HIP(ctx, hipFree(djobs));
   return MMG_OK;
 }
 

@@ -102,6 +102,8 @@ struct mmg_ctx {
   int2* grp_tab = nullptr;      // workgroup-group table of the perm / rotation GEMM launches (gemm_i8_w4s.h)
   size_t grp_cap = 0;
   std::vector<int2> grp_host;   // host image of grp_tab (source of the asynchronous upload: must outlive it)
+  void* jobs = nullptr;         // device job lists of the kinship GEMM launches (k_kinship.hip:job_buffer), grown on demand:
+  size_t jobs_cap = 0;          // a hipMalloc / hipFree per launch serialised the streams and leaked on an early return
   void* ingest = nullptr;       // device staging of the genotype ingest paths (packed rows, pageable int8 rows); kept:
   size_t ingest_cap = 0;        // hipMalloc / hipFree per chunk would serialise the upload stream with the compute stream
 };

@@ -415,6 +415,15 @@ int mmg_reml_sums_ex(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas
   return MMG_OK;
 }
 
+int mmg_reml_band_info(mmg_ctx* ctx, mmg_reml* r, int32_t* band_ready, int32_t* householder_fallback, double* seconds) {
+  if (!ctx) return MMG_E_ARG;
+  if (!r) return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_band_info");
+  if (band_ready) *band_ready = r->band_ready ? 1 : 0;
+  if (householder_fallback) *householder_fallback = r->band_fallback ? 1 : 0;
+  if (seconds) *seconds = r->band_s;
+  return MMG_OK;
+}
+
 int mmg_reml_sums_ml(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s3, double* logdet_h,
                      double* tr_hinv, int32_t route) {
   if (!ctx) return MMG_E_ARG;

@@ -178,7 +178,16 @@ def _resident_chunks(ctx, genot_data, plan, rank=0, world=1, prefetch=True, reus
         cap = max(len(plan[ci][1]) for ci in mine)
         cg0 = genot_data[plan[mine[0]][0]]
         n_ind = _num_indivs(cg0)
-        row_bytes = int(_raw_dataset(cg0)[0].shape[1])                  # host bytes per SNP: N, or ceil(N bits / 8) when packed
+        # host bytes per SNP: N, or ceil(N bits / 8) when packed -- the LARGEST over the plan's chromosomes, and every
+        # chromosome must hold the same individuals (a tree mixing raw_snps and raw_snps_packed chromosomes used to fail
+        # inside _read_chunk's reshape in the middle of the stream; advisor r3)
+        row_bytes = 0
+        for chrom in dict.fromkeys(plan[ci][0] for ci in mine):
+            cg = genot_data[chrom]
+            if _num_indivs(cg) != n_ind:
+                raise ValueError("chromosome %r holds %d individuals, %r holds %d: one stream needs one set of individuals"
+                                 % (chrom, _num_indivs(cg), plan[mine[0]][0], n_ind))
+            row_bytes = max(row_bytes, int(_raw_dataset(cg)[0].shape[1]))
         # two HBM stores + two page-locked staging buffers, kept between calls (kinship pass, scan pass, the next
         # file ...): allocating them costs ~0.1 s, as much as streaming 5 GB
         key = (ctx.device, n_ind, row_bytes)
@@ -357,7 +366,13 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
     phenotype vector.  out_file: result container to write (:142-184: pseudo_heritability, ve, vg, max_ll,
     num_snps, chrom_results/<chrom>/{ps, positions}; perm: kinship, perm_min_ps, perm_max_f_stats, five_perc_*).
     Returns {'pseudo_heritability','ve','vg','max_ll','num_snps','kinship','chrom_results': {chrom: {'ps',
-    'positions'}}} plus 'perm_min_ps', 'perm_max_f_stats', 'threshold_05' for the permutation variant."""
+    'positions'}}} plus 'perm_min_ps', 'perm_max_f_stats', 'threshold_05' for the permutation variant.
+
+    Footprint of the streaming pools (kept between calls until release_pools()): two HBM chunk stores and two page-locked
+    host staging buffers of the largest chunk each -- chunk_size SNPs for the scan pass, and up to KIN_MAX_BYTES (6 GB) of
+    int8 rows per buffer for the kinship pass, whose chunks are merged to >= 65,536 SNPs (_merge_plan): at most 2 x 6 GB
+    of pinned host memory and 2 x 6 GB of HBM.  All chromosomes of a stream must hold the same individuals; the buffers
+    are sized by the largest row (raw int8 or bit-packed) over the plan."""
     ctx = ctx or _lib.get_context()
     if out_file is not None and not isinstance(out_file, str):           # run_emmax(genot_data, phenotypes, ...)
         phenotypes, out_file = out_file, None

@@ -812,7 +812,7 @@ class LinearMixedModel(object):
         """t_m = s_m Mp, Mp = H'(I - QQ') (:1300-1303,1318-1321): what the reference's loop regresses the residual
         on, returned as a list of M arrays like the reference's `t_snps`.  T = S Mp is the rotation GEMM of the
         multi-phenotype path with the rows of Mp' = (I - QQ')H in place of the eigenvectors (mmg_rot_load: exact int8
-        digit GEMM, 2^-31 of each row's largest entry).  With replicates (Z: n values x n_geno individuals) Mp' is
+        digit GEMM: four unsigned 7-bit digits per entry, 2^-27 of each row's largest entry).  With replicates (Z: n values x n_geno individuals) Mp' is
         not square and the product is a device dgemm instead."""
         H = np.asarray(H_sqrt_inv, dtype=np.float64)
         h0_X = H @ self.X

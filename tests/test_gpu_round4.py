@@ -81,8 +81,16 @@ def test_band_reduction_falls_back_on_duplicated_individuals(ctx):
     y = rng.standard_normal(n)
     reml = ctx.reml(K, X, y)
     deltas = [0.05, 2.0]
+    assert not reml.band_info()["ready"]
     got = reml.sums(deltas, route="band")
+    info = reml.band_info()
+    assert info["ready"] and info["householder_fallback"] and info["seconds"] > 0
     reml.close()
+    small = ctx.reml(K[:100, :100], X[:100], y[:100])          # N < 256: AUTO is the Cholesky route until a band call was made
+    assert not small.uses_band("auto")
+    small.sums([1.0], route="band")
+    assert small.uses_band("auto")
+    small.close()
     for k, d in enumerate(deltas):
         want = _reml_sums_f64(K, X, y, d)
         for i in range(4):
