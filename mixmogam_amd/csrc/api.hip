@@ -115,7 +115,7 @@ int mmg_ctx_destroy(mmg_ctx* ctx) {
   hipStreamSynchronize(ctx->stream2);
   free_model(ctx->model);
   free_result(ctx->res);
-  if (ctx->sel_geno) { hipFree(ctx->sel_geno->d); hipFree(ctx->sel_geno->bits); hipFree(ctx->sel_geno->d_smax); delete ctx->sel_geno; }
+  if (ctx->sel_geno) { hipFree(ctx->sel_geno->d); hipFree(ctx->sel_geno->bits); hipFree(ctx->sel_geno->fp4); hipFree(ctx->sel_geno->d_smax); delete ctx->sel_geno; }
   hipFree(ctx->dstage);
   hipFree(ctx->grp_tab);
   hipFree(ctx->jobs);
@@ -194,7 +194,12 @@ int mmg_host_unpin(mmg_ctx* ctx, void* p) {
 }
 
 // ------------------------------------------------------------------------- genotype store
-int mmg_geno_create(mmg_ctx* ctx, int64_t M, int32_t N, mmg_geno** out) {
+static int geno_create(mmg_ctx* ctx, int64_t M, int32_t N, mmg_geno** out, bool twin);
+int mmg_geno_create(mmg_ctx* ctx, int64_t M, int32_t N, mmg_geno** out) { return geno_create(ctx, M, N, out, true); }
+
+// twin = false: stores the library keeps for itself and writes with kernels that do not maintain the FP4 twin (the
+// compact store of the refined SNPs of an adaptive scan)
+static int geno_create(mmg_ctx* ctx, int64_t M, int32_t N, mmg_geno** out, bool twin) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, out != nullptr && M >= 0 && N > 0);
   *out = nullptr;
@@ -209,6 +214,14 @@ int mmg_geno_create(mmg_ctx* ctx, int64_t M, int32_t N, mmg_geno** out) {
   if (e != hipSuccess) { hipFree(g->d); delete g; return set_err(ctx, MMG_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e)); }
   MMG_HIP(ctx, hipMemsetAsync(g->d_smax, 0, 2 * sizeof(int), ctx->stream));
   MMG_HIP(ctx, hipMemsetAsync(g->d, 0, (size_t)g->Mpad * g->Npad, ctx->stream));
+  // E2M1 twin for the FP4 kinship GEMM: half the store's bytes again, kept in step by the write paths (mmg_internal.h).
+  // A failed allocation is not an error: the kinship call then writes its own scratch image.
+  static const bool twin_off = [] { const char* e = std::getenv("MMG_FP4_TWIN"); return e && e[0] == '0'; }();
+  if (twin && !twin_off) {
+    if (hipMalloc(&g->fp4, (size_t)g->Mpad * (g->Npad / 2)) == hipSuccess)
+      MMG_HIP(ctx, hipMemsetAsync(g->fp4, 0, (size_t)g->Mpad * (g->Npad / 2), ctx->stream));
+    else { g->fp4 = nullptr; (void)hipGetLastError(); }
+  }
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   *out = g;
   return MMG_OK;
@@ -221,8 +234,10 @@ int mmg_geno_reset(mmg_ctx* ctx, mmg_geno* g, int64_t M) {
   if (Mpad > g->Mcap) return set_err(ctx, MMG_E_ARG, "mmg_geno_reset: M exceeds the capacity the store was created with");
   // rows [M, Mpad) must read as zeros (every kernel walks whole 256-row blocks); the columns beyond N of the rows an
   // upload rewrites stay zero because uploads only touch the first N bytes of a row
-  if (Mpad > M)
+  if (Mpad > M) {
     MMG_HIP(ctx, hipMemsetAsync(g->d + M * (int64_t)g->Npad, 0, (size_t)(Mpad - M) * g->Npad, ctx->stream));
+    if (g->fp4) MMG_HIP(ctx, hipMemsetAsync(g->fp4 + M * (int64_t)(g->Npad / 2), 0, (size_t)(Mpad - M) * (g->Npad / 2), ctx->stream));
+  }
   MMG_HIP(ctx, hipMemsetAsync(g->d_smax, 0, 2 * sizeof(int), ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   g->M = M; g->Mpad = Mpad; g->smax = 0; g->sneg = 0; g->bits_valid = false; ++g->version;
@@ -234,6 +249,7 @@ int mmg_geno_destroy(mmg_ctx* ctx, mmg_geno* g) {
   if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
   hipFree(g->d);
   hipFree(g->bits);
+  hipFree(g->fp4);
   hipFree(g->d_smax);
   delete g;
   return MMG_OK;
@@ -259,7 +275,8 @@ static bool upload_2d() {
 
 // every write path ends here: fold max |s| of the written rows into the store's running bound
 static int refresh_smax(mmg_ctx* ctx, mmg_geno* g, int64_t m0, int64_t rows) {
-  launch_absmax_i8(ctx, g->d + m0 * (int64_t)g->Npad, rows * (int64_t)g->Npad, g->d_smax);
+  launch_absmax_i8(ctx, g->d + m0 * (int64_t)g->Npad, rows * (int64_t)g->Npad, g->d_smax,
+                   g->fp4 ? g->fp4 + m0 * (int64_t)(g->Npad / 2) : nullptr);     // ... and keep the FP4 twin of these rows in step
   MMG_HIP(ctx, hipGetLastError());
   int v[2] = {0, 0};
   MMG_HIP(ctx, hipMemcpyAsync(v, g->d_smax, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -303,6 +320,7 @@ int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, i
     // just written and put the bounds (host and device copies) back, or every later upload into this store would fail
     // the same check on valid data (advisor r2).
     MMG_HIP(ctx, hipMemsetAsync(g->d + m0 * (int64_t)g->Npad, 0, (size_t)rows * g->Npad, ctx->stream));
+    if (g->fp4) MMG_HIP(ctx, hipMemsetAsync(g->fp4 + m0 * (int64_t)(g->Npad / 2), 0, (size_t)rows * (g->Npad / 2), ctx->stream));
     MMG_HIP(ctx, hipMemcpyAsync(g->d_smax, prev, 2 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     g->smax = prev[0]; g->sneg = prev[1];
@@ -338,7 +356,8 @@ int mmg_geno_upload_packed(mmg_ctx* ctx, mmg_geno* g, const uint8_t* packed, int
   for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
     const int64_t nr = std::min(chunk, rows - r0);
     MMG_HIP(ctx, hipMemcpyAsync(tmp, packed + r0 * row_bytes, (size_t)nr * row_bytes, hipMemcpyHostToDevice, ctx->stream));
-    launch_unpack(ctx, tmp, row_bytes, g->d + (m0 + r0) * (int64_t)g->Npad, nr, g->N, g->Npad, bits, lut32);
+    launch_unpack(ctx, tmp, row_bytes, g->d + (m0 + r0) * (int64_t)g->Npad, nr, g->N, g->Npad, bits, lut32,
+                  g->fp4 ? g->fp4 + (m0 + r0) * (int64_t)(g->Npad / 2) : nullptr);
     MMG_HIP(ctx, hipGetLastError());
     if (r0 + chunk < rows) MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));   // tmp is reused by the next piece
   }
@@ -527,7 +546,17 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
   double kin_ms = 0.0, pack_ms = 0.0;
   if (direct) {
     rc = MMG_E_STATE;
-    if (fp4) {
+    if (fp4 && ibs && binary && g->fp4) {
+      // the store's own E2M1 twin (kept in step by the write paths): no image pass at all
+      rc = MMG_OK;
+      {
+        EvScope ev(ctx, EV_KIN);
+        rc = run_kinship_f4_tr(ctx, sc, g->fp4, g->Npad, g->Mpad / 256, C32);
+      }
+      MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->ev_set[EV_PACK] = false;
+      if (rc == MMG_E_STATE) MMG_HIP(ctx, hipMemsetAsync(C32, 0, (size_t)g->Npad * g->Npad * sizeof(int), ctx->stream));
+    } else if (fp4) {
       uint8_t* X4 = nullptr;
       if (sc.alloc(&X4, (size_t)g->Mpad * (g->Npad / 2)) == hipSuccess) {
         // The nibble image can be written in SNP chunks on the second stream while the GEMM of the previous chunk runs on
@@ -538,8 +567,13 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
         int nch = 1;
         if (const char* e = std::getenv("MMG_KIN_FP4_CHUNKS")) nch = std::max(1, std::min(16, std::atoi(e)));
         const int64_t rows_ch = round_up((g->Mpad + nch - 1) / nch, 256);
-        std::vector<hipEvent_t> evs;
-        hipEvent_t ev0 = nullptr;
+        struct EvGuard {                                   // destroyed on every path out of this block (advisor r3)
+          std::vector<hipEvent_t> v;
+          hipEvent_t first = nullptr;
+          ~EvGuard() { for (hipEvent_t e : v) (void)hipEventDestroy(e); if (first) (void)hipEventDestroy(first); }
+        } guard;
+        std::vector<hipEvent_t>& evs = guard.v;
+        hipEvent_t& ev0 = guard.first;
         MMG_HIP(ctx, hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
         MMG_HIP(ctx, hipEventRecord(ev0, ctx->stream));                  // the store's writers are on the first stream
         MMG_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ev0, 0));
@@ -566,8 +600,6 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
         }
         hipError_t es = hipStreamSynchronize(ctx->stream);
         if (es == hipSuccess) es = hipStreamSynchronize(ctx->stream2);
-        for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
-        (void)hipEventDestroy(ev0);
         if (es != hipSuccess) return set_err(ctx, MMG_E_HIP, hipGetErrorString(es));
         ctx->ev_set[EV_PACK] = (nch == 1);                                // its time is inside EV_KIN as well
         if (rc == MMG_E_STATE) MMG_HIP(ctx, hipMemsetAsync(C32, 0, (size_t)g->Npad * g->Npad * sizeof(int), ctx->stream));
@@ -1381,7 +1413,7 @@ static int scan_into(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, mmg_sc
     const int64_t cpad = round_up(cnt, 256);
     if (!ctx->sel_geno || ctx->sel_geno->Mpad < cpad || ctx->sel_geno->N != g->N) {
       if (ctx->sel_geno) { mmg_geno_destroy(ctx, ctx->sel_geno); ctx->sel_geno = nullptr; }
-      rc = mmg_geno_create(ctx, cpad + cpad / 4, g->N, &ctx->sel_geno);
+      rc = geno_create(ctx, cpad + cpad / 4, g->N, &ctx->sel_geno, false);
       if (rc) return rc;
     }
     if (res.q2_cap < ctx->sel_geno->Mpad) {

@@ -16,22 +16,24 @@ __device__ __forceinline__ uint64_t hash3(uint64_t seed, uint64_t snp, uint64_t 
 
 // grid.x = Npad/16 chunks (x 256 threads -> rows), one thread = 16 individuals of one SNP.
 __global__ void fill_hash_kernel(int8_t* __restrict__ S, int64_t M, int32_t N, int32_t Npad,
-                                 uint64_t seed, int64_t m0g, uint32_t thr16) {
+                                 uint64_t seed, int64_t m0g, uint32_t thr16, uint8_t* __restrict__ X4) {
   const int chunks = Npad >> 4;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t m = gid / chunks;
   const int c = (int)(gid % chunks);
   if (m >= M) return;
-  uint32_t wds[4] = {0, 0, 0, 0};
+  uint32_t wds[4] = {0, 0, 0, 0}, nib[2] = {0, 0};
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int i = c * 16 + j;
     uint32_t bit = 0;
     if (i < N) bit = ((uint32_t)(hash3(seed, (uint64_t)(m0g + m), (uint64_t)i) >> 48) < thr16) ? 1u : 0u;
     wds[j >> 2] |= bit << (8 * (j & 3));
+    nib[j >> 3] |= (bit << 1) << (4 * (j & 7));           // E2M1 twin: 1 -> 0x2 (= 1.0), nibble j = individual 16 c + j
   }
   uint4 v = make_uint4(wds[0], wds[1], wds[2], wds[3]);
   *(uint4*)(S + m * (int64_t)Npad + c * 16) = v;
+  if (X4) *(uint2*)(X4 + m * (int64_t)(Npad >> 1) + c * 8) = make_uint2(nib[0], nib[1]);
 }
 
 // Structured synthetic genotypes (population structure, so that the REML optimum is interior and a scan has many
@@ -52,13 +54,13 @@ __device__ __forceinline__ uint32_t struct_thr16(uint64_t seed, uint64_t snp, in
 }
 
 __global__ void fill_struct_kernel(int8_t* __restrict__ S, int64_t M, int32_t N, int32_t Npad, uint64_t seed,
-                                   int64_t m0g, int npop, uint32_t spread_q16) {
+                                   int64_t m0g, int npop, uint32_t spread_q16, uint8_t* __restrict__ X4) {
   const int chunks = Npad >> 4;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t m = gid / chunks;
   const int c = (int)(gid % chunks);
   if (m >= M) return;
-  uint32_t wds[4] = {0, 0, 0, 0};
+  uint32_t wds[4] = {0, 0, 0, 0}, nib[2] = {0, 0};
   int kcur = -1;
   uint32_t thr = 0;
 #pragma unroll
@@ -71,14 +73,16 @@ __global__ void fill_struct_kernel(int8_t* __restrict__ S, int64_t M, int32_t N,
       bit = ((uint32_t)(hash3(seed, (uint64_t)(m0g + m), (uint64_t)i) >> 48) < thr) ? 1u : 0u;
     }
     wds[j >> 2] |= bit << (8 * (j & 3));
+    nib[j >> 3] |= (bit << 1) << (4 * (j & 7));
   }
   *(uint4*)(S + m * (int64_t)Npad + c * 16) = make_uint4(wds[0], wds[1], wds[2], wds[3]);
+  if (X4) *(uint2*)(X4 + m * (int64_t)(Npad >> 1) + c * 8) = make_uint2(nib[0], nib[1]);
 }
 
 void launch_fill_struct(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_global0, int npop, uint32_t spread_q16) {
   const int64_t total = g->M * (int64_t)(g->Npad >> 4);
   hipLaunchKernelGGL(fill_struct_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, g->d, g->M,
-                     g->N, g->Npad, seed, m_global0, npop, spread_q16);
+                     g->N, g->Npad, seed, m_global0, npop, spread_q16, g->fp4);
 }
 
 void launch_fill_hash(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_global0, uint32_t thr16) {
@@ -86,7 +90,7 @@ void launch_fill_hash(mmg_ctx* ctx, mmg_geno* g, uint64_t seed, int64_t m_global
   const int bs = 256;
   const int64_t nb = (total + bs - 1) / bs;
   hipLaunchKernelGGL(fill_hash_kernel, dim3((unsigned)nb), dim3(bs), 0, ctx->stream, g->d, g->M, g->N,
-                     g->Npad, seed, m_global0, thr16);
+                     g->Npad, seed, m_global0, thr16, g->fp4);
 }
 
 template <typename T>
@@ -124,7 +128,7 @@ void launch_cvt_f64(mmg_ctx* ctx, const double* src, int8_t* dst, int64_t rows, 
 template <int BITS>
 __global__ __launch_bounds__(256) void unpack_kernel(const uint8_t* __restrict__ src, int64_t row_bytes,
                                                      int8_t* __restrict__ dst, int64_t rows, int32_t N, int32_t Npad,
-                                                     uint32_t lut) {
+                                                     uint32_t lut, uint8_t* __restrict__ x4) {
   const int nchunk = Npad >> 4;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= rows * nchunk) return;
@@ -138,14 +142,16 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint8_t* __restrict__
     const int64_t o = (int64_t)c * NB + b;
     if (o < row_bytes) bits |= (uint32_t)row[o] << (8 * b);
   }
-  uint32_t w[4] = {0, 0, 0, 0};
+  uint32_t w[4] = {0, 0, 0, 0}, nib[2] = {0, 0};
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const uint32_t code = (bits >> (BITS * j)) & ((1u << BITS) - 1u);
     const uint32_t v = (c * 16 + j < N) ? ((lut >> (8 * code)) & 0xffu) : 0u;
     w[j >> 2] |= v << (8 * (j & 3));
+    nib[j >> 3] |= ((v & 1u) << 1) << (4 * (j & 7));        // the store's E2M1 twin: bit 0 of the value as 0x0 / 0x2
   }
   *(uint4*)(dst + r * (int64_t)Npad + c * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+  if (x4) *(uint2*)(x4 + r * (int64_t)(Npad >> 1) + c * 8) = make_uint2(nib[0], nib[1]);
 }
 
 // [rows x N] contiguous int8 -> rows of the padded store (columns >= N zero): the device half of a staged upload.
@@ -189,15 +195,15 @@ void launch_pitch_rows(mmg_ctx* ctx, const int8_t* src, int8_t* dst, int64_t row
 }
 
 void launch_unpack(mmg_ctx* ctx, const uint8_t* src, int64_t row_bytes, int8_t* dst, int64_t rows, int32_t N,
-                   int32_t Npad, int bits, uint32_t lut) {
+                   int32_t Npad, int bits, uint32_t lut, uint8_t* x4) {
   const int64_t total = rows * (Npad >> 4);
   if (total <= 0) return;
   if (bits == 1)
     hipLaunchKernelGGL(unpack_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, src, row_bytes,
-                       dst, rows, N, Npad, lut);
+                       dst, rows, N, Npad, lut, x4);
   else
     hipLaunchKernelGGL(unpack_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, src, row_bytes,
-                       dst, rows, N, Npad, lut);
+                       dst, rows, N, Npad, lut, x4);
 }
 
 // 64 SNPs x 64 individuals per block; out[i][m] = valid ? mul * s + add : 0.
@@ -526,8 +532,11 @@ void launch_snp_stats(mmg_ctx* ctx, const mmg_geno* g, double* mean, double* sd)
 }
 
 // max |s| over a 16-byte aligned range (write paths of the genotype store keep an upper bound of it)
-// out[0] = max |s|, out[1] = max(-s) (0 for a store without negative values)
-__global__ __launch_bounds__(256) void absmax_i8_kernel(const int8_t* __restrict__ p, int64_t n16, int* __restrict__ out) {
+// out[0] = max |s|, out[1] = max(-s) (0 for a store without negative values).  PACK: the same pass writes the E2M1 twin of
+// the bytes it reads (bit 0 of byte i -> nibble i, 0x0 / 0x2): 8 bytes out per 16 in, no second sweep over the store.
+template <bool PACK>
+__global__ __launch_bounds__(256) void absmax_i8_kernel(const int8_t* __restrict__ p, int64_t n16, int* __restrict__ out,
+                                                        uint8_t* __restrict__ x4) {
   int mx = 0, ng = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
     const uint4 v = *(const uint4*)(p + i * 16);
@@ -538,6 +547,17 @@ __global__ __launch_bounds__(256) void absmax_i8_kernel(const int8_t* __restrict
       mx = max(mx, x < 0 ? -x : x);
       ng = max(ng, -x);
     }
+    if (PACK) {
+      uint32_t o[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {                        // dwords 2q, 2q+1 = 8 genotype bytes -> 8 nibbles (pack_fp4_kernel)
+        const uint32_t lo = wds[2 * q] & 0x01010101u, hi = wds[2 * q + 1] & 0x01010101u;
+        const uint32_t l4 = (lo | (lo >> 4)) & 0x00110011u, h4 = (hi | (hi >> 4)) & 0x00110011u;
+        const uint32_t l2 = (l4 | (l4 >> 8)) & 0x0000ffffu, h2 = (h4 | (h4 >> 8)) & 0x0000ffffu;
+        o[q] = ((l2 & 0x1111u) | ((h2 & 0x1111u) << 16)) << 1;
+      }
+      *(uint2*)(x4 + i * 8) = make_uint2(o[0], o[1]);
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { mx = max(mx, __shfl_xor(mx, o)); ng = max(ng, __shfl_xor(ng, o)); }
@@ -545,11 +565,12 @@ __global__ __launch_bounds__(256) void absmax_i8_kernel(const int8_t* __restrict
   if ((threadIdx.x & 63) == 0 && ng > 0) atomicMax(out + 1, ng);
 }
 
-void launch_absmax_i8(mmg_ctx* ctx, const int8_t* p, int64_t bytes, int* d_out) {
+void launch_absmax_i8(mmg_ctx* ctx, const int8_t* p, int64_t bytes, int* d_out, uint8_t* x4) {
   const int64_t n16 = bytes >> 4;
   if (n16 <= 0) return;
   const int64_t nb = std::min<int64_t>((n16 + 255) / 256, 4096);
-  hipLaunchKernelGGL(absmax_i8_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, p, n16, d_out);
+  if (x4) hipLaunchKernelGGL(absmax_i8_kernel<true>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, p, n16, d_out, x4);
+  else hipLaunchKernelGGL(absmax_i8_kernel<false>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, p, n16, d_out, x4);
 }
 
 }  // namespace mmg

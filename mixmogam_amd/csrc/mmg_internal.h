@@ -20,6 +20,12 @@ struct mmg_geno {
   int smax = 0;                 // running bound of max |s| over everything written to the store
   int sneg = 0;                 // ... and of max(-s): 0 = no negative value was ever written
   int* d_smax = nullptr;        // device pair {max |s|, max(-s)}
+  // E2M1 twin of the store for the FP4 kinship GEMM (k_kinship.hip:kinship_f4_tr_kernel): [Mcap x Npad / 2] nibbles, bit 0 of
+  // every genotype byte as 0x0 / 0x2 (= 0.0 / 1.0), kept in step by every write path -- the pass that folds max |s| of the
+  // written rows reads them anyway (k_pack.hip:absmax_i8_kernel<true>), the synthetic generators emit both forms.  Usable
+  // as long as the store is binary (smax <= 1, sneg == 0).  nullptr: MMG_FP4_TWIN=0, or the allocation failed (then the
+  // kinship call writes a scratch image itself, as in round 3: 1.3 ms of a 6.6 ms call at N = 5000 x M = 1e6).
+  uint8_t* fp4 = nullptr;
 };
 
 enum { EV_KIN = 0, EV_QUAD = 1, EV_FIN = 2, EV_PERM = 3, EV_EIGH = 4, EV_PACK = 5, EV_QUAD2 = 6, EV_ROT = 7, EV_MULTI = 8, EV_GRM = 9, EV_COUNT = 10 };
@@ -142,11 +148,11 @@ struct EvScope {  // records the two events of slot `which` around a region on c
 };
 
 // ---- k_pack.hip
-void launch_fill_hash(mmg_ctx*, mmg_geno*, uint64_t seed, int64_t m_global0, uint32_t thr16);
+void launch_fill_hash(mmg_ctx*, mmg_geno*, uint64_t seed, int64_t m_global0, uint32_t thr16);     // (+ the store's FP4 twin)
 void launch_fill_struct(mmg_ctx*, mmg_geno*, uint64_t seed, int64_t m_global0, int npop, uint32_t spread_q16);
 // fp32 / fp64 genotype ingest -> int8; *d_bad |= 1 if any value is not an integer in [-127, 127]
 void launch_unpack(mmg_ctx*, const uint8_t* src, int64_t row_bytes, int8_t* dst, int64_t rows, int32_t N, int32_t Npad,
-                   int bits, uint32_t lut);              // 1- / 2-bit packed rows -> int8 store rows (k_pack.hip)
+                   int bits, uint32_t lut, uint8_t* x4 = nullptr);   // 1- / 2-bit packed rows -> int8 store rows (+ FP4 twin rows)
 void launch_pitch_rows(mmg_ctx*, const int8_t* src, int8_t* dst, int64_t rows, int32_t N, int32_t Npad);   // [rows x N] -> [rows x Npad], zero padded
 void launch_cvt_f32(mmg_ctx*, const float* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld, int* d_bad);
 void launch_cvt_f64(mmg_ctx*, const double* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld, int* d_bad);
@@ -156,7 +162,9 @@ void launch_cvt_f64(mmg_ctx*, const double* src, int8_t* dst, int64_t rows, int3
 void launch_transpose(mmg_ctx*, const mmg_geno*, int8_t* Xt, int64_t Mk, int mul, int add, int64_t m_begin,
                       int thr = 0);
 void launch_snp_stats(mmg_ctx*, const mmg_geno*, double* mean, double* sd);
-void launch_absmax_i8(mmg_ctx*, const int8_t* p, int64_t bytes, int* d_out);   // d_out[0] = max(d_out[0], max |p[i]|), d_out[1] likewise for max(-p[i]); bytes % 16 == 0
+// d_out[0] = max(d_out[0], max |p[i]|), d_out[1] likewise for max(-p[i]); bytes % 16 == 0.  x4 (optional): the E2M1 twin of the
+// same bytes (bit 0 of byte i -> nibble i of x4, value 0x0 / 0x2), written in the same pass
+void launch_absmax_i8(mmg_ctx*, const int8_t* p, int64_t bytes, int* d_out, uint8_t* x4 = nullptr);
 
 // row sums and diagonal of a row-major fp64 [N x N] matrix (one block per row, fixed order); x[i] *= f
 void launch_row_sums_f64(mmg_ctx*, const double* A, int64_t N, double* rows, double* diag);

@@ -123,3 +123,51 @@ def test_reml_search_on_the_interpolant_vs_step_by_step_on_the_device(ctx, monke
     assert abs(a["delta"] / b["delta"] - 1) < 1e-10
     for k in ("max_ll", "ve", "vg"):
         assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), k
+
+
+def test_fp4_twin_of_the_store_follows_every_write_path(ctx, monkeypatch):
+    """The IBS counts of a binary store run on its E2M1 twin (no image pass inside the call).  The twin must be in step
+    after every way of writing a store: the synthetic generators, int8 / float / bit-packed uploads, partial uploads, a reset
+    to fewer rows and a refill -- each time the counts equal the int64 numpy product, and they equal what the round-3 path
+    (scratch image per call, MMG_FP4_TWIN=0 stores) gives."""
+    from mixmogam_amd import _lib
+    rng = np.random.RandomState(4)
+    n, m = 333, 2100
+
+    def counts_ref(S):
+        x = 2 * S.astype(np.int64) - 1
+        return x.T @ x
+
+    S = (rng.random_sample((m, n)) < rng.uniform(0.1, 0.9, size=(m, 1))).astype(np.int8)
+    g = ctx.geno(S)                                            # int8 upload
+    assert np.array_equal(ctx.kinship_ibs_counts(g), counts_ref(S))
+    with pytest.raises(_lib.MixmogamHipError):                 # no image pass ran in that call
+        ctx.kernel_ms("pack")
+    S2 = S.copy()
+    S2[700:1300] = (rng.random_sample((600, n)) < 0.3).astype(np.int8)
+    g.upload(S2[700:1300], 700)                                # partial rewrite
+    assert np.array_equal(ctx.kinship_ibs_counts(g), counts_ref(S2))
+    g.reset(1500)                                              # fewer rows: the tail must read as zeros in the twin too
+    g.upload(S2[:1500], 0)
+    assert np.array_equal(ctx.kinship_ibs_counts(g), counts_ref(S2[:1500]))
+    g.close()
+    for dt in (np.float32, np.float64):
+        g = ctx.geno(S.astype(dt))
+        assert np.array_equal(ctx.kinship_ibs_counts(g), counts_ref(S))
+        g.close()
+    g = ctx.geno(M=m, N=n)
+    g.upload_packed(_lib.pack_genotypes(S, 1), 1)              # bit-packed rows, expanded on the device
+    assert np.array_equal(ctx.kinship_ibs_counts(g), counts_ref(S))
+    g.close()
+    for filler in ("hash", "structured"):
+        g = ctx.geno(M=m, N=n)
+        g.fill_hash(11) if filler == "hash" else g.fill_structured(11, npop=3)
+        assert np.array_equal(ctx.kinship_ibs_counts(g), counts_ref(g.download())), filler
+        g.close()
+    # a store that stops being binary: the twin is ignored, the int8 kernel runs
+    T = S.copy()
+    T[5, 7] = 2
+    g = ctx.geno(T)
+    x = 2 * T.astype(np.int64) - 1
+    assert np.array_equal(ctx.kinship_ibs_counts(g), x.T @ x)
+    g.close()
