@@ -269,19 +269,36 @@ def main():
     # REPLICATED on every rank, and a caller of linear_models.emmax() pays for them.  end_to_end_emmax_s = one
     # lm.emmax()-equivalent call (LinearMixedModel -> emmax_f_test: eigh, REML, device scan model, scan of this rank's
     # resident SNPs, results on the host) per rank; both are gathered so a scaling curve can be read against them.
-    e2e = None
+    e2e = e2e_eig = None
     if mode in ("weak", "strong"):
         e2e_first = None
-        for _ in range(2):                                 # the first call pays rocSOLVER / rocBLAS start-up of the
-            t0 = time.time()                               # Cholesky route (reported as ..._first_call_s)
+        for _ in range(3):                                 # the first call pays library start-up (reported as
+            t0 = time.time()                               # ..._first_call_s); best of the two after it
             lmm2 = lm.LinearMixedModel(y, ctx=ctx)
             lmm2.add_random_effect(K)
             r2 = lmm2.emmax_f_test(g, emma_num=0)
-            e2e = time.time() - t0
+            dt = time.time() - t0
             if e2e_first is None:
-                e2e_first = e2e
+                e2e_first = dt
+            else:
+                e2e = dt if e2e is None else min(e2e, dt)
             e2e_timings = r2.get("timings")
             del r2, lmm2
+        # the same call on the eigendecomposition route (rocSOLVER dsyevd + REML from eig_L): what round 3's default was
+        keep = lm.EIGEN_FREE_MIN_N
+        lm.EIGEN_FREE_MIN_N = 1 << 30
+        try:
+            for _ in range(2):
+                t0 = time.time()
+                lmm2 = lm.LinearMixedModel(y, ctx=ctx)
+                lmm2.add_random_effect(K)
+                r2 = lmm2.emmax_f_test(g, emma_num=0)
+                dt = time.time() - t0
+                e2e_eig = dt if e2e_eig is None else min(e2e_eig, dt)
+                e2e_eig_timings = r2.get("timings")
+                del r2, lmm2
+        finally:
+            lm.EIGEN_FREE_MIN_N = keep
     setup_per_rank = [t_setup]
     e2e_per_rank = [e2e]
     if coll is not None:
@@ -295,7 +312,16 @@ def main():
                                   "(replicated on every rank), outside the timed region"})
         if e2e is not None:
             res.update({"end_to_end_emmax_s": max(e2e_per_rank), "end_to_end_emmax_s_per_rank": e2e_per_rank,
-                        "end_to_end_emmax_first_call_s": e2e_first, "end_to_end_emmax_phases_s": e2e_timings})
+                        "end_to_end_emmax_first_call_s": e2e_first, "end_to_end_emmax_phases_s": e2e_timings,
+                        "end_to_end_emmax_route": "eigendecomposition-free: band reduction of K on own kernels, REML "
+                                                  "search on an interpolant of the sums (3 device calls), own blocked "
+                                                  "Cholesky for the scan model" if e2e_timings and e2e_timings.get("eig_L") == 0.0
+                                                  else "eigh (rocSOLVER dsyevd)",
+                        "end_to_end_emmax_eigen_route_s": e2e_eig,
+                        "end_to_end_emmax_eigen_route_phases_s": e2e_eig_timings,
+                        "end_to_end_note": "one lm.emmax()-equivalent call on resident genotypes (LinearMixedModel -> "
+                                           "emmax_f_test -> results on the host), best of two warm calls; the eigen "
+                                           "route is the same call with linear_models.EIGEN_FREE_MIN_N raised"})
     if coll is not None:
         coll.barrier()
         coll.close()
@@ -399,7 +425,8 @@ def bench_scan(args, ctx, coll, comm_h, g, lmm, est, prep, N, M, Mtot, D, barrie
                      "(kinship.py:44): `vs_reference_full_product` is that figure over the same time, a speed-up "
                      "statement, not a roofline fraction; executed = the lower triangle of 256^2 tiles actually run; "
                      "`ms` includes every device pass the call needs (ms_gemm + the image pass: the individual-major "
-                     "copy of the fp32 kernel, the FP4 nibble image of the exact-count kernel)"}
+                     "copy of the fp32 kernel; the exact-count kernel reads the store's own E2M1 twin, written by the "
+                     "ingest / generator kernels -- round 4 -- so its call has no image pass unless MMG_FP4_TWIN=0)"}
         if pass_name is not None:
             d[pass_name] = pass_ms
         return d
@@ -432,7 +459,8 @@ def bench_scan(args, ctx, coll, comm_h, g, lmm, est, prep, N, M, Mtot, D, barrie
                                         if fp4_kin else
                                         kin_roof("kinship_i8_tr_kernel", kin_i8_ms, I8_MFMA_PEAK_TOPS, "TOP/s",
                                                  kin_i8_pack_ms, "transpose_pass_ms"),
-                                        first_call_ms=kin_i8_first_ms)},
+                                        first_call_ms=kin_i8_first_ms,
+                                        fp4_twin_store=os.environ.get("MMG_FP4_TWIN", "1") != "0")},
         "adaptive_scan": scan_stats, "all_planes_reference": all_planes, "min_p": float(np.nanmin(ps)),
     })
     if world == 1 and not args.no_extras:
