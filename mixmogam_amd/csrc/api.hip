@@ -780,7 +780,7 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
   if (bd == 0) return MMG_E_STATE;
   int D = (30 + bd - 1) / bd;                              // 5, 5, 6 planes
   if (bd == 7 && g->M >= 65536) D = 4;
-  if (const char* e = std::getenv("MMG_GRM_PLANES")) { const int v = std::atoi(e); if (v >= 4 && v <= 6) D = v; }
+  if (const char* e = std::getenv("MMG_GRM_PLANES")) { const int v = std::atoi(e); if (v >= 3 && v <= 6) D = v; }   // 3: experiments only
   const double base = (double)(1 << bd);
   // every int32 plane sums digit * s_i * s_j over ALL SNPs of the call (one combine at the end): the digits are non-negative,
   // so a plane only grows -- (2^bd - 1) smax^2 M must stay below 2^31 (advisor r3; 16.9 M binary SNPs per call, 8.5 M for

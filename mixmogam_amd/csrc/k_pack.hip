@@ -438,8 +438,10 @@ void launch_grm_scale_rows(mmg_ctx* ctx, const int8_t* S, int64_t rows_valid, in
   hipLaunchKernelGGL((grm_scale_rows_kernel<D_, NEG_>), grid, dim3(256), 0, ctx->stream, S, rows_valid, Mk, Npad, Xp, dig, \
                      coef, partial)
   if (D == 0) MMG_GS(0, false);                            // only the weighted column sums (the fused 4-plane GEMM scales in registers)
-  else if (neg) { if (D == 4) MMG_GS(4, true); else if (D == 5) MMG_GS(5, true); else MMG_GS(6, true); }
-  else { if (D == 4) MMG_GS(4, false); else if (D == 5) MMG_GS(5, false); else MMG_GS(6, false); }
+  else if (neg) { if (D == 3) MMG_GS(3, true); else if (D == 4) MMG_GS(4, true); else if (D == 5) MMG_GS(5, true); else if (D == 6) MMG_GS(6, true); }
+  else { if (D == 3) MMG_GS(3, false); else if (D == 4) MMG_GS(4, false); else if (D == 5) MMG_GS(5, false); else if (D == 6) MMG_GS(6, false); }
+  // (any other plane count launches nothing: api.hip admits 3..6 -- a count that fell through to the 6-plane kernel wrote
+  // six images into a buffer sized for fewer)
 #undef MMG_GS
   hipLaunchKernelGGL(grm_colsum_reduce_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, ctx->stream, partial,
                      nslab, Npad, c1);
@@ -451,9 +453,10 @@ void launch_transpose_digits(mmg_ctx* ctx, const mmg_geno* g, int8_t* Xq, int8_t
 #define MMG_TD(D_)                                                                                                  \
   hipLaunchKernelGGL(transpose_digits_kernel<D_>, grid, dim3(256), 0, ctx->stream, g->d, g->M, g->N, g->Npad, Xq, Xp, \
                      Mk, m_begin, dig)
-  if (D == 4) MMG_TD(4);
+  if (D == 3) MMG_TD(3);
+  else if (D == 4) MMG_TD(4);
   else if (D == 5) MMG_TD(5);
-  else MMG_TD(6);
+  else if (D == 6) MMG_TD(6);
 #undef MMG_TD
 }
 
