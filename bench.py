@@ -314,7 +314,7 @@ def main():
             res.update({"end_to_end_emmax_s": max(e2e_per_rank), "end_to_end_emmax_s_per_rank": e2e_per_rank,
                         "end_to_end_emmax_first_call_s": e2e_first, "end_to_end_emmax_phases_s": e2e_timings,
                         "end_to_end_emmax_route": "eigendecomposition-free: band reduction of K on own kernels, REML "
-                                                  "search on an interpolant of the sums (3 device calls), own blocked "
+                                                  "search on an interpolant of the sums, own blocked "
                                                   "Cholesky for the scan model" if e2e_timings and e2e_timings.get("eig_L") == 0.0
                                                   else "eigh (rocSOLVER dsyevd)",
                         "end_to_end_emmax_eigen_route_s": e2e_eig,

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace mmg {
 
@@ -416,9 +417,105 @@ __global__ __launch_bounds__(256, 2) void nt_update_lower_kernel(double* __restr
   }
 }
 
+// The same update on 128 x 128 tiles, 8 waves per workgroup (2 along i x 4 along j: wave tile 64 x 32, two waves per SIMD --
+// the fp64 matrix pipe sustains 48 TFLOP/s with two waves per SIMD against 35 with one, tools/probe/fp64_rate.hip): a tile
+// side's operands are read from L2 once per 128 columns of output instead of once per 64, 6 loads per 8 MFMAs instead of 5
+// per 4.  Taken for large trailing matrices (launch_nt_update_lower), where the 64 x 64 form ran at 30 TFLOP/s.
+template <int NP>
+__global__ __launch_bounds__(512, 1) void nt_update_lower128_kernel(double* __restrict__ C, int64_t ldc, int64_t n,
+                                                                   const double* __restrict__ A0, const double* __restrict__ B0,
+                                                                   const double* __restrict__ A1, const double* __restrict__ B1,
+                                                                   int64_t lda, int64_t ldb) {
+  const int64_t t = blockIdx.x;
+  int64_t I = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while (I * (I + 1) / 2 > t) --I;
+  while ((I + 1) * (I + 2) / 2 <= t) ++I;
+  const int64_t J = t - I * (I + 1) / 2;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+  const int wi = w & 1, wj = w >> 1;
+  const int64_t I0 = I * 128 + 64 * wi, J0 = J * 128 + 32 * wj;
+  int64_t irow[4], jrow[2];
+  bool iin[4], jin[2];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int64_t i = I0 + 16 * it + lr;
+    iin[it] = i < n;
+    irow[it] = iin[it] ? i : n - 1;
+  }
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    const int64_t j = J0 + 16 * jt + lr;
+    jin[jt] = j < n;
+    jrow[jt] = jin[jt] ? j : n - 1;
+  }
+  constexpr int NCH = 4 * NP;                                // chunks of 16 contraction columns (4 k-steps = 24 loads per lane)
+  double fa[2][4][4], fb[2][4][2];
+  auto load_chunk = [&](int ch, int buf) {
+    const double* __restrict__ A = (ch >> 2) ? A1 : A0;
+    const double* __restrict__ B = (ch >> 2) ? B1 : B0;
+    const int kb = (ch & 3) * 16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int k = kb + 4 * ks + lk;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) fa[buf][ks][it] = A[irow[it] + (int64_t)k * lda];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) fb[buf][ks][jt] = B[jrow[jt] + (int64_t)k * ldb];
+    }
+  };
+  load_chunk(0, 0);
+  v4d acc[2][4];
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t cj = J0 + 16 * jt + 4 * r + lk;
+        acc[jt][it][r] = C[irow[it] + (cj < n ? cj : n - 1) * ldc];
+      }
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    if (ch + 1 < NCH) load_chunk(ch + 1, (ch + 1) & 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const double bop = iin[it] ? -fa[ch & 1][ks][it] : 0.0;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          const double aop = jin[jt] ? fb[ch & 1][ks][jt] : 0.0;
+          acc[jt][it] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc[jt][it], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      if (iin[it]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t cj = J0 + 16 * jt + 4 * r + lk;
+          if (cj < n) C[irow[it] + cj * ldc] = acc[jt][it][r];
+        }
+      }
+}
+
 void launch_nt_update_lower(hipStream_t st, double* C, int64_t ldc, int64_t n, const double* A0, const double* B0,
                             const double* A1, const double* B1, int64_t lda, int64_t ldb) {
   if (n <= 0) return;
+  // large trailing matrices: 128 x 128 tiles (MMG_NT_TILE=64 | 128 overrides; default 128 from n = 4096, where a launch
+  // still has >= 528 workgroups)
+  static const int forced = [] { const char* e = std::getenv("MMG_NT_TILE"); return e ? std::atoi(e) : 0; }();
+  if (forced == 128 || (forced != 64 && n >= 4096)) {
+    const int64_t nt = (n + 127) / 128;
+    const dim3 grid((unsigned)(nt * (nt + 1) / 2));
+    if (A1) hipLaunchKernelGGL(nt_update_lower128_kernel<2>, grid, dim3(512), 0, st, C, ldc, n, A0, B0, A1, B1, lda, ldb);
+    else hipLaunchKernelGGL(nt_update_lower128_kernel<1>, grid, dim3(512), 0, st, C, ldc, n, A0, B0, A0, B0, lda, ldb);
+    return;
+  }
   const int64_t nt = (n + 63) / 64;
   const dim3 grid((unsigned)(nt * (nt + 1) / 2));
   if (A1) hipLaunchKernelGGL(nt_update_lower_kernel<2>, grid, dim3(256), 0, st, C, ldc, n, A0, B0, A1, B1, lda, ldb);

@@ -468,8 +468,8 @@ def test_band_route_sums_are_not_dealt_over_ranks():
 
 def test_reml_search_on_the_interpolated_sums_matches_the_exact_search():
     """_SpectralSumsChol.prepare_interval (band route): the secant search of get_estimates (linear_models.py:847) runs on a
-    16-node Chebyshev model of the four likelihood sums over the bracket, so a whole search costs THREE device calls
-    (grid, nodes, optimum) instead of one per secant step.  With a stand-in workspace whose sums are exact functions of a
+    16-node Chebyshev model of the four likelihood sums over the bracket, so a whole search costs TWO device calls
+    (grid, nodes; the likelihood at the optimum comes from the model too) instead of one per secant step.  With a stand-in workspace whose sums are exact functions of a
     spectrum: the variance ratio agrees with the search on exact evaluations to 1e-11 relative, the likelihood at the
     optimum is an exact evaluation, and the model itself is good to 1e-12 anywhere in its interval."""
     rng = np.random.RandomState(3)
@@ -498,8 +498,14 @@ def test_reml_search_on_the_interpolated_sums_matches_the_exact_search():
     model.add_factor(X[:, 1])
     r1 = Reml(); r1.calls = []
     a = model.get_estimates(None, method='REML', _sums=lm._SpectralSumsChol(r1))
-    assert r1.calls == [51, lm._SpectralSumsChol.INTERP_NODES, 1], r1.calls       # grid, nodes, the optimum
-    assert a['n_device_calls'] == 3
+    assert r1.calls == [51, lm._SpectralSumsChol.INTERP_NODES], r1.calls           # grid, nodes (the optimum: from the model)
+    assert a['n_device_calls'] == 2
+    r3 = Reml(); r3.calls = []
+    exact_final = lm._SpectralSumsChol(r3)
+    exact_final.FINAL_FROM_MODEL = False                                           # the likelihood at the optimum from the workspace
+    c = model.get_estimates(None, method='REML', _sums=exact_final)
+    assert r3.calls == [51, lm._SpectralSumsChol.INTERP_NODES, 1]
+    assert abs(a['max_ll'] - c['max_ll']) <= 1e-11 * abs(c['max_ll']) and abs(a['vg'] / c['vg'] - 1) < 1e-11
     r2 = Reml(); r2.calls = []
     plain = lm._SpectralSumsChol(r2)
     plain.prepare_interval = lambda lo, hi: None                                    # every secant step asks the workspace
