@@ -284,6 +284,24 @@ def main():
                 e2e = dt if e2e is None else min(e2e, dt)
             e2e_timings = r2.get("timings")
             del r2, lmm2
+        # the O(N^3) stage of that route on its own: band reduction of K (csrc/reml_band.hip + dense64.hip), 4 N^3 / 3 flop
+        band_rec = None
+        try:
+            rw = ctx.reml(K, np.ones((N, 1)), y)
+            for _ in range(2):                                 # (a second workspace: the first reduction of a process loads code)
+                rw.close()
+                rw = ctx.reml(K, np.ones((N, 1)), y)
+                rw.sums(np.array([1.0]), route="band")
+            bi = rw.band_info()
+            rw.close()
+            flop = 4.0 * N ** 3 / 3.0
+            band_rec = {"kernel": "band_reduce_cqr (gram_slices / cholqr_head1|2 / rows_gemm / sym_skinny / nt_update_lower kernels)",
+                        "n": N, "seconds": bi["seconds"], "householder_fallback": bi["householder_fallback"],
+                        "algorithmic_flop": flop, "achieved": flop / bi["seconds"] / 1e12, "peak": 78.6, "unit": "TFLOP/s",
+                        "frac": flop / bi["seconds"] / 1e12 / 78.6, "bound": "launch latency at this N (77 panels x 16 dependent "
+                        "launches; 30-33 TFLOP/s at N = 50,000, DESIGN 4.6c)"}
+        except Exception as e:                                 # never let an extra break the line
+            band_rec = {"error": str(e)}
         # the same call on the eigendecomposition route (rocSOLVER dsyevd + REML from eig_L): what round 3's default was
         keep = lm.EIGEN_FREE_MIN_N
         lm.EIGEN_FREE_MIN_N = 1 << 30
@@ -317,6 +335,7 @@ def main():
                                                   "search on an interpolant of the sums, own blocked "
                                                   "Cholesky for the scan model" if e2e_timings and e2e_timings.get("eig_L") == 0.0
                                                   else "eigh (rocSOLVER dsyevd)",
+                        "reml_band_reduction": band_rec,
                         "end_to_end_emmax_eigen_route_s": e2e_eig,
                         "end_to_end_emmax_eigen_route_phases_s": e2e_eig_timings,
                         "end_to_end_note": "one lm.emmax()-equivalent call on resident genotypes (LinearMixedModel -> "

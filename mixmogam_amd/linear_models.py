@@ -307,6 +307,26 @@ class _SpectralSumsChol(object):
         return s1, s2, s3, s4
 
 
+class _LazyIdentity(object):
+    """The identity random effect of :574 (`random_effects[0] = ('normal', I)`): an N x N matrix nothing on the EMMAX path
+    reads (only _get_eigen_R_ adds it to K), built when someone does -- np.eye(5000) is 7 ms of a 0.12 s emmax() call."""
+
+    def __init__(self, n):
+        self.n, self._m = n, None
+        self.shape = (n, n)
+
+    def __array__(self, dtype=None, copy=None):
+        if self._m is None:
+            self._m = np.eye(self.n)
+        return self._m if dtype is None else self._m.astype(dtype, copy=False)
+
+    def __getitem__(self, idx):
+        return np.asarray(self)[idx]
+
+    def __len__(self):
+        return self.n
+
+
 class LinearMixedModel(object):
     """linear_models.py:554 (and the parts of LinearModel :81 it inherits on this path)."""
 
@@ -318,7 +338,7 @@ class LinearMixedModel(object):
         self.p = 1
         self.beta_est = None
         self.cofactors = []
-        self.random_effects = [('normal', np.eye(self.n))]              # :574
+        self.random_effects = [('normal', _LazyIdentity(self.n))]       # :574
         self._ctx = ctx
 
     @property
@@ -334,7 +354,7 @@ class LinearMixedModel(object):
         self.random_effects.append((effect_type, kinship.scale_k(cov_matrix)))   # :580
 
     def set_random_effect(self, cov_matrix_list, effect_types=None):
-        self.random_effects = [('normal', np.eye(self.n))]
+        self.random_effects = [('normal', _LazyIdentity(self.n))]
         for cov_matrix in cov_matrix_list:
             self.add_random_effect(cov_matrix=kinship.scale_k(cov_matrix))       # :586
 
@@ -380,7 +400,7 @@ class LinearMixedModel(object):
         q = X.shape[1]
         if K is None:
             K = self.random_effects[1][1]
-        B = np.asarray(K, dtype=np.float64) + self.random_effects[0][1]
+        B = np.asarray(K, dtype=np.float64) + np.asarray(self.random_effects[0][1])
         Q = linalg.orth(X)
         QtB = Q.T @ B
         M = B - Q @ QtB - (B @ Q) @ Q.T + Q @ (QtB @ Q) @ Q.T
