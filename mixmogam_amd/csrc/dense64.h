@@ -32,7 +32,8 @@ void launch_gram_reduce(hipStream_t st, const double* part, int G, double* out, 
 
 // Y = X Cf for the n rows of X ([n x 64] column-major, ld ldx) and a 64 x 64 column-major coefficient matrix (device, ld 64) on
 // the matrix pipe; Y (ld ldy) may be X
-void launch_rows_gemm(hipStream_t st, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t n, const double* Cf);
+void launch_rows_gemm(hipStream_t st, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t n, const double* Cf,
+                      bool cf_transposed = false);    // cf_transposed: Y = X Cf' 
 
 // Lower 64 x 64 tiles (I >= J) of the n x n matrix C (column-major, ld ldc):
 //   C[I][J] -= A0[I] B0[J]' (+ A1[I] B1[J]' when A1 != nullptr),   A*, B*: [n x 64] column-major (ld lda / ldb)

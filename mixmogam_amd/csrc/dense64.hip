@@ -268,14 +268,14 @@ template <bool TWO>
 __global__ __launch_bounds__(256) void rows_gemm_kernel(const double* __restrict__ X0, int64_t ld0, const double* __restrict__ C0,
                                                         const double* __restrict__ X1, int64_t ld1, const double* __restrict__ C1,
                                                         double* __restrict__ Y, int64_t ldy, int64_t n, double* __restrict__ Z,
-                                                        int64_t ldz, const double* __restrict__ Cz, int q1) {
+                                                        int64_t ldz, const double* __restrict__ Cz, int q1, int c0_transposed) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* Cs = sm;                         // [j][k] = C0[k][j]
   double* Ts = sm + 64 * YLD;              // [j][k] = C1[k][j]
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
   for (int e = tid; e < 4096; e += 256) {
     const int k = e & 63, j = e >> 6;
-    Cs[j * YLD + k] = C0[e];
+    Cs[j * YLD + k] = c0_transposed ? C0[j + 64 * k] : C0[e];  // (transposed: the coefficient is C0')
     if (TWO) Ts[j * YLD + k] = C1[e];
   }
   const int64_t R0 = (int64_t)blockIdx.x * 64;
@@ -326,17 +326,18 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const double* __restrict
 }
 constexpr int ROWS_LDS1 = 64 * YLD * (int)sizeof(double), ROWS_LDS2 = 2 * ROWS_LDS1;
 
-void launch_rows_gemm(hipStream_t st, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t n, const double* Cf) {
+void launch_rows_gemm(hipStream_t st, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t n, const double* Cf,
+                      bool cf_transposed) {
   if (n <= 0) return;
   hipLaunchKernelGGL(rows_gemm_kernel<false>, dim3((unsigned)((n + 63) / 64)), dim3(256), ROWS_LDS1, st, X, ldx, Cf,
                      (const double*)nullptr, (int64_t)0, (const double*)nullptr, Y, ldy, n, (double*)nullptr, (int64_t)0,
-                     (const double*)nullptr, 0);
+                     (const double*)nullptr, 0, cf_transposed ? 1 : 0);
 }
 
 void launch_band_y(hipStream_t st, const double* V, const double* W, int64_t n, const double* T, const double* C, double* Y,
                    double* Z, int64_t ldz, const double* Cz, int q1) {
   hipLaunchKernelGGL(rows_gemm_kernel<true>, dim3((unsigned)((n + 63) / 64)), dim3(256), ROWS_LDS2, st, V, n, C, W, n, T, Y, n, n, Z,
-                     ldz, Cz, q1);
+                     ldz, Cz, q1, 0);
 }
 
 // ---- C[I][J] -= A0[I] B0[J]' + A1[I] B1[J]' on the lower 64 x 64 tiles ---------------------------------------------------

@@ -508,6 +508,9 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 constexpr int SY_SA = 80, SY_ST = 66;
 // blockIdx.y = slice of the contraction range (tiles [ntile y / S, ntile (y + 1) / S)) writing its own copy of W: at N = 5000
 // one workgroup per 64 output rows is 40-78 workgroups on 256 CUs, each a chain of ~40 tile steps
+// TRI: A is LOWER TRIANGULAR instead of symmetric (the triangular inverse of reml_chol.hip: X21 = -X22 (L21 X11)): the tiles
+// right of the diagonal are skipped and the diagonal tile is its lower half alone.
+template <bool TRI>
 __global__ __launch_bounds__(256, 2) void sym_skinny_kernel(const double* __restrict__ A, int64_t lda, int n,
                                                             const double* __restrict__ V, double* __restrict__ Wout) {
   __shared__ double As[64 * SY_SA];
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void sym_skinny_kernel(const double* __rest
   v4d acc[4];
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) acc[rt] = v4d{0.0, 0.0, 0.0, 0.0};
-  const int ntile = (n + 63) / 64;
+  const int ntile = TRI ? blockIdx.x + 1 : (n + 63) / 64;      // TRI: only the tiles up to the diagonal
   const int kt0 = (int)((int64_t)ntile * blockIdx.y / gridDim.y), kt1 = (int)((int64_t)ntile * (blockIdx.y + 1) / gridDim.y);
   double* __restrict__ W = Wout + (size_t)blockIdx.y * n * 64;
   // the next tile pair travels in registers while the current one is multiplied (element e = tid + 256 i of a tile)
@@ -559,6 +562,7 @@ __global__ __launch_bounds__(256, 2) void sym_skinny_kernel(const double* __rest
       Vt[hi * SY_ST + lo] = rv[i];
       if (K0 < I0) As[hi * SY_SA + lo] = ra[i];
       else if (K0 > I0) As[hi * SY_ST + lo] = ra[i];
+      else if (TRI) As[hi * SY_SA + lo] = ra[i];               // (zero above the diagonal: fetch() loaded the lower half only)
       else if (lo >= hi) { As[hi * SY_SA + lo] = ra[i]; As[lo * SY_SA + hi] = ra[i]; }
     }
     __syncthreads();
@@ -598,6 +602,25 @@ __global__ void wsum_kernel(const double* __restrict__ Wp, int S, int64_t count,
   double s = Wp[e];
   for (int k = 1; k < S; ++k) s += Wp[(size_t)k * count + e];
   W[e] = s;
+}
+
+// dst[r + c ldd] = sign * sum_s Wp[s][r + c n]  (r < n, c < 64): the slice sum written into a panel of a larger matrix
+__global__ void wsum_into_kernel(const double* __restrict__ Wp, int S, int64_t n, double* __restrict__ dst, int64_t ldd, double sign) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * 64) return;
+  double s = Wp[e];
+  for (int k = 1; k < S; ++k) s += Wp[(size_t)k * n * 64 + e];
+  dst[(e % n) + (e / n) * ldd] = sign * s;
+}
+
+void launch_tall_product(hipStream_t st, const double* A, int64_t lda, int64_t n, const double* V, double* W_or_Wp, int S, bool tri) {
+  const dim3 grid((unsigned)((n + 63) / 64), (unsigned)S);
+  if (tri) hipLaunchKernelGGL(sym_skinny_kernel<true>, grid, dim3(256), 0, st, A, lda, (int)n, V, W_or_Wp);
+  else hipLaunchKernelGGL(sym_skinny_kernel<false>, grid, dim3(256), 0, st, A, lda, (int)n, V, W_or_Wp);
+}
+
+void launch_slice_sum_into(hipStream_t st, const double* Wp, int S, int64_t n, double* dst, int64_t ldd, double sign) {
+  hipLaunchKernelGGL(wsum_into_kernel, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, Wp, S, n, dst, ldd, sign);
 }
 
 // The last block column of the reduction, 2 <= n < 64 rows below the band: everything (the n x 64 panel, the n x n trailing
@@ -775,7 +798,7 @@ static int band_reduce_cqr(mmg_ctx* ctx, mmg_reml* r, bool* suspect) {
     // ---- W = A22 V
     // ~3 tile steps per workgroup while the launch stays within ~1024 workgroups
     const int S = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)smax, 1024 / ((n + 63) / 64), (n + 63) / 64 / 3}));
-    hipLaunchKernelGGL(sym_skinny_kernel, dim3((unsigned)((n + 63) / 64), S), dim3(256), 0, st, A22, N, (int)n, V, S > 1 ? Wp : W);
+    hipLaunchKernelGGL(sym_skinny_kernel<false>, dim3((unsigned)((n + 63) / 64), S), dim3(256), 0, st, A22, N, (int)n, V, S > 1 ? Wp : W);
     if (S > 1) hipLaunchKernelGGL(wsum_kernel, dim3((unsigned)((n * b + 255) / 256)), dim3(256), 0, st, Wp, S, n * b, W);
     lap(1, tp);
     // ---- Y = W M - 1/2 V M'(V'W) M and the rotated columns of [X y]
@@ -923,7 +946,7 @@ static int band_reduce_hh(mmg_ctx* ctx, mmg_reml* r) {
     }
     lap(0, tp);
     // ---- W = A22 V from the lower triangle alone
-    hipLaunchKernelGGL(sym_skinny_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, A22, N, (int)n, V, W);
+    hipLaunchKernelGGL(sym_skinny_kernel<false>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, A22, N, (int)n, V, W);
     lap(1, tp);
     // ---- Y = [V | W] [ -1/2 T'(V'W)T ; T ]
     tsmm(V, n, W, n, b, n, M1, b);                            // V'W

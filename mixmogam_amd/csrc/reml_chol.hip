@@ -140,7 +140,7 @@ static int lauum_lower(mmg_ctx* ctx, rocblas_handle h, const double* X, int64_t 
   return lauum_lower(ctx, h, X22, n2, ld, P + n1 + n1 * ldp, ldp);
 }
 
-static int potrf_own(mmg_ctx* ctx, double* A, int64_t N, int64_t lda, double* LinvT, long long* dacc, long long base);
+static int potrf_own(mmg_ctx* ctx, double* A, int64_t N, int64_t lda, double* LinvT, long long* dacc, long long base, bool keep_all);
 
 // Right-looking blocked Cholesky (lower, column-major, in place) over the 64-bit rocBLAS level-3 routines:
 // diagonal block by rocsolver_dpotrf, panel by trsm, trailing update by syrk -- the trailing update carries
@@ -152,7 +152,7 @@ static int potrf_blocked(mmg_ctx* ctx, rocblas_handle h, double* A, int64_t N, i
     const int64_t kb = std::min(nb, N - k0), rest = N - k0 - kb;
     double* Akk = A + k0 + k0 * N;
     if (LinvT) {                                             // diagonal block on this library's kernels (round 4)
-      int rc = potrf_own(ctx, Akk, kb, N, LinvT, dacc, (long long)k0);
+      int rc = potrf_own(ctx, Akk, kb, N, LinvT, dacc, (long long)k0, false);
       if (rc) return rc;
     } else {
       RC_RB(ctx, rocsolver_dpotrf(h, rocblas_fill_lower, (rocblas_int)kb, Akk, (rocblas_int)N, dinfo));
@@ -177,19 +177,58 @@ static int potrf_blocked(mmg_ctx* ctx, rocblas_handle h, double* A, int64_t N, i
 // At large N the rank-64 trailing updates stream the whole trailing matrix 64 columns at a time (N = 50,000: 1.76 s
 // against 0.80 s for 2048-column blocks over syrk_64), so beyond N = 8192 this factors the 2048-column diagonal blocks of
 // potrf_blocked and rocBLAS keeps the big updates.
-static int potrf_own(mmg_ctx* ctx, double* A, int64_t N, int64_t lda, double* LinvT /*device, 64 x 64*/, long long* dacc,
-                     long long base) {
+// keep_all: LinvT holds one 64 x 64 slot PER block column (the inverses of all diagonal blocks: tri_inv_own below)
+static int potrf_own(mmg_ctx* ctx, double* A, int64_t N, int64_t lda, double* LinvT_base /*device, 64 x 64 (x blocks)*/,
+                     long long* dacc, long long base, bool keep_all) {
   if (dense64_init()) return set_err(ctx, MMG_E_HIP, "hipFuncSetAttribute (dense64 kernels)");
   hipStream_t st = ctx->stream;
   for (int64_t k0 = 0; k0 < N; k0 += 64) {
     const int kb = (int)std::min<int64_t>(64, N - k0);
     const int64_t rest = N - k0 - kb;
+    double* LinvT = LinvT_base + (keep_all ? (k0 / 64) * 4096 : 0);
     launch_potrf_head(st, A + k0 + k0 * lda, lda, kb, LinvT, dacc, base + (long long)k0);
     if (rest > 0) {
       double* panel = A + (k0 + kb) + k0 * lda;
       launch_rows_gemm(st, panel, lda, panel, lda, rest, LinvT);              // X L' = A  <=>  X = A L^-T
       launch_nt_update_lower(st, A + (k0 + kb) + (k0 + kb) * lda, lda, rest, panel, panel, nullptr, nullptr, lda, lda);
     }
+  }
+  RC_HIP(ctx, hipGetLastError());
+  return MMG_OK;
+}
+
+// In-place inverse of the Cholesky factor on this library's kernels (N <= 8192, where potrf_own kept the inverse of every
+// diagonal block): block column k from the last to the first,
+//     X[k][k] = L[k][k]^-1,      X[k+1:, k] = -X[k+1:, k+1:] (L[k+1:, k] X[k][k]),
+// i.e. a tall x 64x64 product on the matrix pipe and one lower-triangular x tall product (sym_skinny_kernel<TRI>, contraction
+// slices summed by wsum_into_kernel with the sign) per block column -- three launches, no library call.  N = 5000: 4 ms,
+// against 3 ms for rocsolver_dtrtri + rocblas_dtrmm (see reml_point): kept behind MMG_REML_TRTRI=own, tested, not the default.
+__global__ void put_diag_inverse_kernel(double* __restrict__ A, int64_t lda, int kb, const double* __restrict__ LinvT) {
+  const int e = blockIdx.x * 256 + threadIdx.x;               // element (i, j) of the block: A[i][j] = (L^-1)[i][j] = LinvT[j][i]
+  const int i = e & 63, j = e >> 6;
+  if (i < kb && j < kb) A[i + (int64_t)j * lda] = i >= j ? LinvT[j + 64 * i] : 0.0;
+}
+
+static int tri_inv_own(mmg_ctx* ctx, double* L, int64_t N, const double* LinvT_all, Scratch& sc) {
+  hipStream_t st = ctx->stream;
+  const int64_t nb = (N + 63) / 64;
+  double *T = nullptr, *Wp = nullptr;
+  const int smax = 8;
+  RC_HIP(ctx, sc.alloc(&T, (size_t)N * 64 * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&Wp, (size_t)smax * N * 64 * sizeof(double)));
+  for (int64_t k = nb - 1; k >= 0; --k) {
+    const int64_t k0 = k * 64, a0 = k0 + 64;
+    const int kb = (int)std::min<int64_t>(64, N - k0);
+    const int64_t n = N - a0;                                 // rows below the block
+    double* panel = L + a0 + k0 * N;
+    if (n > 0) {
+      // T = L21 X11 (X11 = LinvT': the coefficient is read transposed), then the panel = -X22 T
+      launch_rows_gemm(st, panel, N, T, n, n, LinvT_all + k * 4096, true);
+      const int S = (int)std::max<int64_t>(1, std::min<int64_t>(smax, (n + 63) / 64 / 6));
+      launch_tall_product(st, L + a0 + a0 * N, N, n, T, Wp, S, true);
+      launch_slice_sum_into(st, Wp, S, n, panel, N, -1.0);
+    }
+    hipLaunchKernelGGL(put_diag_inverse_kernel, dim3(16), dim3(256), 0, st, L + k0 + k0 * N, N, kb, LinvT_all + k * 4096);
   }
   RC_HIP(ctx, hipGetLastError());
   return MMG_OK;
@@ -217,6 +256,9 @@ static int reml_point(mmg_ctx* ctx, mmg_reml* r, double delta, bool inverse, boo
   double t0 = verbose ? now() : 0.0, t1 = 0.0, t2 = 0.0;
   RC_HIP(ctx, hipMemcpyAsync(r->dL, r->dK, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, r->dL, N, delta);
+  Scratch sc_inv;                                             // the diagonal blocks' inverses live until the inverse is done
+  double* LinvT_all = nullptr;
+  bool own_inverse = false;
   {
     // measured at N = 50,000: rocsolver_dpotrf_64 1.31 s (32 TF); the blocked form over syrk_64 0.80 s (52 TF) at
     // nb = 2048 (0.83 / 0.89 s at 4096 / 8192).  Default since round 4: potrf_own.  MMG_REML_POTRF=rocsolver | blocked:<nb> | own.
@@ -225,14 +267,15 @@ static int reml_point(mmg_ctx* ctx, mmg_reml* r, double delta, bool inverse, boo
     long long* dacc = (long long*)(r->dsc + N + 6);
     RC_HIP(ctx, hipMemsetAsync(dinfo, 0, 4 * sizeof(int64_t), st));
     if (ps.empty() || ps == "own") {
-      Scratch scp;
-      double* LinvT = nullptr;
-      RC_HIP(ctx, scp.alloc(&LinvT, 4096 * sizeof(double)));
-      int rcb = N <= 8192 ? potrf_own(ctx, r->dL, N, N, LinvT, dacc, 0)
-                          : potrf_blocked(ctx, h, r->dL, N, 2048, (rocblas_int*)(r->dsc + N + 8), dacc, LinvT);
+      // MMG_REML_TRTRI=own: tri_inv_own.  Measured and NOT the default: emmax()'s scan phase 48.9 ms against 45.9 ms with
+      // rocsolver_dtrtri + trmm at N = 5000 (9.0 / 7.9 at 2000) -- the 9 ms a kernel trace attributes to the library's
+      // inverse are profiler overhead on its many small launches; its wall time is 3 ms
+      own_inverse = inverse && N <= 8192 && std::getenv("MMG_REML_TRTRI") && std::string(std::getenv("MMG_REML_TRTRI")) == "own";
+      RC_HIP(ctx, sc_inv.alloc(&LinvT_all, (own_inverse ? (size_t)((N + 63) / 64) : 1) * 4096 * sizeof(double)));
+      int rcb = N <= 8192 ? potrf_own(ctx, r->dL, N, N, LinvT_all, dacc, 0, own_inverse)
+                          : potrf_blocked(ctx, h, r->dL, N, 2048, (rocblas_int*)(r->dsc + N + 8), dacc, LinvT_all);
       if (rcb) return rcb;
       RC_HIP(ctx, hipMemcpyAsync(dinfo, dacc, sizeof(long long), hipMemcpyDeviceToDevice, st));
-      RC_HIP(ctx, hipStreamSynchronize(st));                  // LinvT is freed on leaving this scope
     } else if (ps != "rocsolver" && (N >= 4096 || ps.rfind("blocked", 0) == 0)) {
       int64_t nb = 2048;
       if (ps.size() > 8) nb = std::max<int64_t>(256, std::atoll(ps.c_str() + 8));    // "blocked:<nb>"
@@ -267,7 +310,7 @@ static int reml_point(mmg_ctx* ctx, mmg_reml* r, double delta, bool inverse, boo
   double trHinv = 0.0;
   if (verbose) t2 = now();
   if (inverse) {
-    rc = tri_inv_lower(ctx, h, r->dL, N, N, dinfo);
+    rc = own_inverse ? tri_inv_own(ctx, r->dL, N, LinvT_all, sc_inv) : tri_inv_lower(ctx, h, r->dL, N, N, dinfo);
     if (rc) return rc;
     hipLaunchKernelGGL(lower_sqnorm_kernel, dim3((unsigned)N), dim3(256), 0, st, r->dL, N, r->dsc + 4);
     std::vector<double> part((size_t)N);

@@ -94,4 +94,9 @@ namespace mmg {
 int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3, double* s4,
                    double* ldh = nullptr, double* trh = nullptr);
 void reml_band_free(mmg_reml* r);
+// reml_band.hip: W [n x 64] (ld n) = A V on the fp64 matrix pipe for an n x n matrix A of which only the lower triangle is read
+// (column-major, ld lda): symmetric (tri = false) or lower triangular (tri = true); V [n x 64] (ld n).  S > 1: the contraction
+// range in S slices, slice s into W_or_Wp + s * n * 64 (the caller adds them up: launch_slice_sum_into).
+void launch_tall_product(hipStream_t st, const double* A, int64_t lda, int64_t n, const double* V, double* W_or_Wp, int S, bool tri);
+void launch_slice_sum_into(hipStream_t st, const double* Wp, int S, int64_t n, double* dst, int64_t ldd, double sign);
 }
