@@ -141,11 +141,18 @@ int mmg_kin_acc_add(mmg_ctx* ctx, mmg_kin_acc* acc, mmg_geno* g, const float* sc
  * Precision: every weight is rounded to 2^-30 of the call's LARGEST weight (five planes; 2^-35 / 2^-30 for alphabets beyond
  * 0/1), entries good to ~1e-9 of the float64 result.  Binary stores of >= 65,536 SNPs whose weights span less than a
  * factor 64 (any MAF filter >= 0.004) take FOUR planes, 2^-28 of the largest weight -- the per-SNP roundings are
- * independent and average down as 1/sqrt(M).  The digits are relative to the largest weight OF THE CALL, so the sum
- * depends (at that level, ~1e-10) on how the SNPs are grouped into calls: a multi-rank or differently chunked run is
- * equal to a single-rank one to rounding, not bit for bit (the IBS counts of mmg_kinship_ibs_i8 are).
- * One call may hold at most (2^31 - 1) / (127 smax^2) SNPs (16.9 M binary ones): the digit planes are 32-bit sums. */
+ * independent and average down as 1/sqrt(M).  The digits are relative to the largest weight of a RUN of calls (below), so
+ * the sum depends (at that level, ~1e-10) on how the SNPs are grouped into calls: a multi-rank or differently chunked run
+ * is equal to a single-rank one to rounding, not bit for bit (the IBS counts of mmg_kinship_ibs_i8 are).
+ * One call may hold at most (2^31 - 1) / (127 smax^2) SNPs (16.9 M binary ones): the digit planes are 32-bit sums.
+ * Runs (round 4): the int32 planes of a call stay where they are and the next call adds into them while its largest
+ * weight is below the run's cap (the first call's largest weight + 1/16) and above half of it, it needs the same number
+ * of planes, and the 32-bit bound holds for the run; otherwise -- and before fetch / scale_k / allreduce read the
+ * accumulator -- the planes are combined into the fp64 sum (at N = 50,000 clearing and combining them is 33 ms next to
+ * 208 ms of GEMMs per 65,536 SNPs).  A joining call loses at most one bit against a step of its own.  MMG_GRM_DEFER=0:
+ * every call is a run of its own.  mmg_kin_acc_pending: SNPs whose sums are still in the planes (0: none). */
 int mmg_kin_acc_add_grm(mmg_ctx* ctx, mmg_kin_acc* acc, mmg_geno* g);
+int mmg_kin_acc_pending(mmg_ctx* ctx, mmg_kin_acc* acc, int64_t* n_snps_pending);
 int mmg_kin_acc_fetch(mmg_ctx* ctx, mmg_kin_acc* acc, double* C_out, int64_t* n_snps);
 /* scale_k of the reference (kinship.py:94-100, inlined at hdf5_data.py:108-111) on the device-resident matrix, in place:
  * K *= (N - 1) / (tr K - sum K / N).  The rule is invariant under a prior division of K by the SNP count, so the

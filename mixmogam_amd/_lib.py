@@ -57,6 +57,7 @@ PROTOTYPES = {
     "mmg_kin_acc_create": (C.c_int, [c_vp, C.c_int32, C.POINTER(c_vp)]),
     "mmg_kin_acc_add": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mmg_kin_acc_add_grm": (C.c_int, [c_vp, c_vp, c_vp]),
+    "mmg_kin_acc_pending": (C.c_int, [c_vp, c_vp, c_i64p]),
     "mmg_kin_acc_fetch": (C.c_int, [c_vp, c_vp, c_vp, c_i64p]),
     "mmg_kin_acc_scale_k": (C.c_int, [c_vp, c_vp, c_f64p]),
     "mmg_kin_acc_destroy": (C.c_int, [c_vp, c_vp]),
@@ -310,6 +311,13 @@ class KinshipAccumulator(object):
     def add_grm(self, g):
         """acc += sum_m z_m z_m', z = (s - mean)/std per SNP: the exact int8 route (mmg_kin_acc_add_grm)."""
         self.ctx._check(self.ctx.lib.mmg_kin_acc_add_grm(self.ctx.h, self.h, g.h))
+
+    def pending(self):
+        """SNPs of the last add_grm calls whose sums still sit in the int32 digit planes (combined into the fp64 sum by
+        the next fetch / scale_k / allreduce, or when a call cannot join the run): mmg_kin_acc_pending."""
+        n = C.c_int64(0)
+        self.ctx._check(self.ctx.lib.mmg_kin_acc_pending(self.ctx.h, self.h, C.byref(n)))
+        return n.value
 
     def allreduce(self, comm):
         """Sum the device-resident accumulator (and its SNP count) over the ranks of `comm` in HBM."""

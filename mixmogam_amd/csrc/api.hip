@@ -722,13 +722,22 @@ int mmg_kinship_affine_f32(mmg_ctx* ctx, mmg_geno* g, const float* scale, const 
 struct GrmWorkspace {
   int8_t *Xq = nullptr, *Xp = nullptr, *ddig = nullptr;
   int* C32 = nullptr;
-  double *dm = nullptr, *ds = nullptr, *dcoef = nullptr, *dc1 = nullptr, *dc1acc = nullptr, *dpart = nullptr;
+  double *dm = nullptr, *ds = nullptr, *dcoef = nullptr, *dc1 = nullptr, *dc1acc = nullptr, *dpart = nullptr, *dwst = nullptr;
   size_t cap_img = 0, cap_c32 = 0, cap_m = 0, cap_mk = 0, cap_n = 0;
   int capD = 0;
   bool direct = false;            // SNP-major images for the transposed-read GEMM (no plain image Xq)
+  // Sums that have not reached the fp64 accumulator yet (round 4): successive calls whose weights fit the digit step
+  // already in use keep adding into the SAME int32 planes, and the combine pass (40 GB of planes + 40 GB of fp64 read /
+  // written at N = 50,000: 20 ms, plus 13 ms of clearing the planes) runs once per run of such calls, not once per call.
+  bool pending = false;
+  int p_D = 0, p_bd = 0;
+  bool p_fused = false;
+  double p_step = 0.0, p_wcap = 0.0, p_c0 = 0.0, p_smax = 0.0;
+  int64_t p_M = 0;
+  int32_t p_Npad = 0, p_N = 0;
   void release() {
     hipFree(Xq); hipFree(Xp); hipFree(ddig); hipFree(C32); hipFree(dm); hipFree(ds); hipFree(dcoef); hipFree(dc1); hipFree(dc1acc);
-    hipFree(dpart);
+    hipFree(dpart); hipFree(dwst);
     *this = GrmWorkspace();
   }
 };
@@ -764,7 +773,18 @@ int mmg_kin_acc_add(mmg_ctx* ctx, mmg_kin_acc* a, mmg_geno* g, const float* scal
 // fp32-MFMA rate instead of the fp32 GEMM, and entries good to ~1e-9 instead of fp32 products.  The rank-one terms
 // are two dot-product passes in fp64.  Returns MMG_E_STATE (caller falls back to the fp32 kernel) when the genotype
 // alphabet is too wide for int8 digit products.
-static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accumulate, GrmWorkspace& ws) {
+// dC += the sums the int32 planes hold (see GrmWorkspace::pending)
+static int grm_flush(mmg_ctx* ctx, GrmWorkspace& ws, double* dC) {
+  if (!ws.pending) return MMG_OK;
+  launch_grm_combine(ctx, ws.C32, ws.p_D, ws.p_Npad, ws.p_N, ws.p_step, (double)(1 << ws.p_bd), ws.dc1acc, ws.p_c0, dC, 1);
+  ws.pending = false;
+  ws.p_M = 0;
+  MMG_HIP(ctx, hipGetLastError());
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MMG_OK;
+}
+
+static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspace& ws) {
   const bool verbose = std::getenv("MMG_KIN_VERBOSE") != nullptr;
   auto now = [&]() { (void)hipStreamSynchronize(ctx->stream); return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double tv0 = verbose ? now() : 0.0;
@@ -780,28 +800,33 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
   if (bd == 0) return MMG_E_STATE;
   int D = (30 + bd - 1) / bd;                              // 5, 5, 6 planes
   if (bd == 7 && g->M >= 65536) D = 4;
-  if (const char* e = std::getenv("MMG_GRM_PLANES")) { const int v = std::atoi(e); if (v >= 3 && v <= 6) D = v; }   // 3: experiments only
+  const bool planes_env = std::getenv("MMG_GRM_PLANES") != nullptr;
+  if (planes_env) { const int v = std::atoi(std::getenv("MMG_GRM_PLANES")); if (v >= 3 && v <= 6) D = v; }   // 3: experiments only
   const double base = (double)(1 << bd);
-  // every int32 plane sums digit * s_i * s_j over ALL SNPs of the call (one combine at the end): the digits are non-negative,
-  // so a plane only grows -- (2^bd - 1) smax^2 M must stay below 2^31 (advisor r3; 16.9 M binary SNPs per call, 8.5 M for
-  // alphabets within +-2; the chunked drivers pass far fewer per call)
-  if ((double)((1 << bd) - 1) * g->smax * g->smax * (double)g->M >= 2147483648.0)
+  // every int32 plane sums digit * s_i * s_j over ALL SNPs between two combine passes: the digits are non-negative, so a
+  // plane only grows -- (2^bd - 1) smax^2 M must stay below 2^31 (advisor r3; 16.9 M binary SNPs, 8.5 M for alphabets
+  // within +-2; the chunked drivers pass far fewer per call, and a run of calls is cut where the bound would be reached)
+  auto planes_hold = [&](double smax, int64_t m) { return (double)((1 << bd) - 1) * smax * smax * (double)m < 2147483648.0; };
+  if (!planes_hold(g->smax, g->M))
     return set_err(ctx, MMG_E_ARG, "exact GRM: too many SNPs in one call for the 32-bit digit planes (split the call)");
   // Round 3: the digit images are SNP-major like the store (row m scaled by the digit of SNP m) and the GEMM reads both
   // through transposed LDS reads (kinship_i8_tr_kernel) -- no transposition pass, no plain image.  MMG_KIN_KERNEL=w4 /
   // w8: the individual-major generations.
   static const bool tr_off = [] { const char* e = std::getenv("MMG_KIN_KERNEL"); return e && (std::string(e) == "w4" || std::string(e) == "w8"); }();
   const bool direct = !tr_off;
+  // MMG_GRM_DEFER=0: combine at the end of every call with the step taken from the call's own largest weight (round 3)
+  static const bool defer = [] { const char* e = std::getenv("MMG_GRM_DEFER"); return !(e && e[0] == '0'); }();
   // binary store and four planes: ONE pass over the genotypes computes all four (gemm_i8_grm4.h: the scaled operands are
   // formed in registers from the plain tiles) -- no digit images at all.  MMG_GRM_FUSED=0: one GEMM per plane.
   bool fused = [&] { const char* e = std::getenv("MMG_GRM_FUSED"); return direct && D == 4 && g->smax <= 1 && g->sneg == 0 && !(e && e[0] == '0'); }();
   const int64_t M = g->M, CH = kin_chunk();
   const int64_t Mk_max = std::min(round_up(M, BK), CH);
-  // per-SNP mean / std in fp64 on the device, weights and digits on the host (M values)
   auto ensure_ws = [&](int D, bool fused) -> int {
     const size_t need_img = fused ? 16 : (size_t)g->Npad * Mk_max, need_c32 = (size_t)g->Npad * g->Npad;
     if (ws.cap_img < need_img || ws.cap_c32 < need_c32 || ws.capD < D || ws.cap_m < (size_t)M || ws.cap_mk < (size_t)Mk_max ||
         ws.cap_n < (size_t)g->Npad || ws.direct != direct) {
+      int rcf = grm_flush(ctx, ws, dC);                       // the planes are about to be freed
+      if (rcf) return rcf;
       ws.release();
       ws.direct = direct;
       hipError_t e = direct ? hipMalloc(&ws.dpart, (size_t)grm_partial_doubles(Mk_max, g->Npad) * sizeof(double))
@@ -814,6 +839,7 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
       if (e == hipSuccess) e = hipMalloc(&ws.dc1acc, g->Npad * sizeof(double));
       if (e == hipSuccess) e = hipMalloc(&ws.dm, M * sizeof(double));
       if (e == hipSuccess) e = hipMalloc(&ws.ds, M * sizeof(double));
+      if (e == hipSuccess) e = hipMalloc(&ws.dwst, (size_t)grm_weight_blocks(M) * 4 * sizeof(double));
       if (e != hipSuccess) { ws.release(); return set_err(ctx, MMG_E_NOMEM, std::string("hipMalloc GRM workspace: ") + hipGetErrorString(e)); }
       ws.cap_img = need_img; ws.cap_c32 = need_c32; ws.capD = D; ws.cap_m = (size_t)M; ws.cap_mk = (size_t)Mk_max;
       ws.cap_n = (size_t)g->Npad;
@@ -821,59 +847,60 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
     return MMG_OK;
   };
   { int rcw = ensure_ws(D, fused); if (rcw) return rcw; }
-  double *dm = ws.dm, *ds = ws.ds;
-  launch_snp_stats(ctx, g, dm, ds);
-  std::vector<double> mean((size_t)M), sd((size_t)M);
-  MMG_HIP(ctx, hipMemcpyAsync(mean.data(), dm, M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  MMG_HIP(ctx, hipMemcpyAsync(sd.data(), ds, M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  // per-SNP mean / std in fp64 on the device; of the weights only four numbers per 4096 SNPs come to the host
+  launch_snp_stats(ctx, g, ws.dm, ws.ds);
+  const int64_t nwb = grm_weight_blocks(M);
+  launch_grm_weight_stats(ctx, ws.dm, ws.ds, M, ws.dwst);
+  std::vector<double> wst((size_t)nwb * 4);
+  MMG_HIP(ctx, hipMemcpyAsync(wst.data(), ws.dwst, wst.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  double wmax = 0.0, wmin = 1e300, c0 = 0.0;
-  std::vector<double> omega((size_t)M), coef((size_t)M);
-  for (int64_t m = 0; m < M; ++m) {
-    if (!(sd[m] > 0.0)) return set_err(ctx, MMG_E_ARG, "monomorphic SNP (std == 0) in the GRM kinship");
-    omega[m] = 1.0 / (sd[m] * sd[m]);
-    coef[m] = -mean[m] * omega[m];                         // a b
-    c0 += mean[m] * mean[m] * omega[m];                    // b^2
-    wmax = std::max(wmax, omega[m]);
-    wmin = std::min(wmin, omega[m]);
+  double wmax = 0.0, wmin = 1e300, c0 = 0.0, bad = 0.0;
+  for (int64_t b = 0; b < nwb; ++b) {
+    wmax = std::max(wmax, wst[4 * b]); wmin = std::min(wmin, wst[4 * b + 1]); c0 += wst[4 * b + 2]; bad += wst[4 * b + 3];
   }
+  if (bad > 0.0) return set_err(ctx, MMG_E_ARG, "monomorphic SNP (std == 0) in the GRM kinship");
+  // The step of a run of calls is set by its first call with 1/16 of headroom (0.09 bit); a later call joins the run
+  // while its largest weight fits under that cap and is within a factor two of it (at most one bit less than a step of its
+  // own would give), the plane count it needs is the run's, and the planes stay inside int32.
   // Four planes quantise a weight to 2^-28 of the LARGEST one: fine while the weights are of one size (a MAF filter of
   // 0.1 keeps wmax / wmin below 2.8), not when rare variants stretch the range (no filter: wmax / wmin ~ N / 4) -- then
   // the fifth plane stays (advisor r3).  The fused one-pass kernel computes four planes; five take one GEMM per plane.
-  if (D == 4 && wmax > 64.0 * wmin && !std::getenv("MMG_GRM_PLANES")) {
-    D = 5;
-    fused = false;
-    int rcw = ensure_ws(D, fused);
-    if (rcw) return rcw;
-    dm = ws.dm; ds = ws.ds;
+  auto plan_for = [&](double wcap, int& Dn, bool& fn) {
+    Dn = D; fn = fused;
+    if (Dn == 4 && wcap > 64.0 * wmin && !planes_env) { Dn = 5; fn = false; }
+  };
+  int Dn = D; bool fn = fused;
+  if (ws.pending) {
+    plan_for(ws.p_wcap, Dn, fn);
+    const bool joins = defer && Dn == ws.p_D && fn == ws.p_fused && bd == ws.p_bd && g->Npad == ws.p_Npad && g->N == ws.p_N &&
+                       wmax <= ws.p_wcap && 2.0 * wmax > ws.p_wcap && planes_hold(std::max(ws.p_smax, (double)g->smax), ws.p_M + M);
+    if (!joins) { int rcf = grm_flush(ctx, ws, dC); if (rcf) return rcf; }
   }
-  double *dcoef = ws.dcoef, *dc1 = ws.dc1, *dc1acc = ws.dc1acc;
+  if (!ws.pending) {
+    const double wcap = defer ? wmax * 1.0625 : wmax;
+    plan_for(wcap, Dn, fn);
+    const double* dm_before = ws.dm;
+    { int rcw = ensure_ws(Dn, fn); if (rcw) return rcw; }
+    if (ws.dm != dm_before) launch_snp_stats(ctx, g, ws.dm, ws.ds);   // a fifth plane re-allocated the workspace
+    ws.p_D = Dn; ws.p_fused = fn; ws.p_bd = bd; ws.p_wcap = wcap; ws.p_Npad = g->Npad; ws.p_N = g->N;
+    // D unsigned digits reach B^D - 1: the cap is scaled onto exactly that
+    ws.p_step = wcap / (std::pow(base, Dn) - 1.0);
+    ws.p_c0 = 0.0; ws.p_M = 0; ws.p_smax = 0.0;
+    MMG_HIP(ctx, hipMemsetAsync(ws.C32, 0, (size_t)Dn * g->Npad * g->Npad * sizeof(int), ctx->stream));
+    MMG_HIP(ctx, hipMemsetAsync(ws.dc1acc, 0, g->Npad * sizeof(double), ctx->stream));
+  }
+  D = Dn; fused = fn;
+  const double step = ws.p_step;
+  double *dm = ws.dm, *ds = ws.ds, *dcoef = ws.dcoef, *dc1 = ws.dc1;
   int8_t *ddig = ws.ddig, *Xq = ws.Xq, *Xp = ws.Xp;
   int* C32 = ws.C32;
-  // D unsigned digits reach B^D - 1: the largest weight is scaled onto exactly that
-  const double step = wmax / (std::pow(base, D) - 1.0);
-  MMG_HIP(ctx, hipMemsetAsync(C32, 0, (size_t)D * g->Npad * g->Npad * sizeof(int), ctx->stream));
   if (verbose) tv_alloc = now();
-  std::vector<double> c1((size_t)g->Npad, 0.0), c1part((size_t)g->Npad);
-  std::vector<int8_t> dig((size_t)D * Mk_max);
-  std::vector<double> cf((size_t)Mk_max);
-  const long long mask = (1ll << bd) - 1;
   int rc = MMG_OK;
   double kin_ms = 0.0;
+  ws.pending = true;                                          // from here on the planes hold part of the sum
   for (int64_t mb = 0; mb < M && rc == MMG_OK; mb += CH) {
     const int64_t Mk = round_up(std::min(CH, M - mb), BK);
-    std::fill(dig.begin(), dig.end(), (int8_t)0);
-    std::fill(cf.begin(), cf.end(), 0.0);
-    for (int64_t k = 0; k < Mk && mb + k < M; ++k) {
-      long long Z = std::llrint(omega[mb + k] / step);       // in [0, B^D - 1]
-      for (int d = 0; d < D; ++d) {
-        dig[(size_t)d * Mk + k] = (int8_t)(Z & mask);
-        Z >>= bd;
-      }
-      cf[k] = coef[mb + k];
-    }
-    MMG_HIP(ctx, hipMemcpyAsync(ddig, dig.data(), (size_t)D * Mk, hipMemcpyHostToDevice, ctx->stream));
-    MMG_HIP(ctx, hipMemcpyAsync(dcoef, cf.data(), Mk * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    launch_grm_digits(ctx, dm, ds, mb, M, Mk, step, bd, D, ddig, dcoef);
     const double tp0 = verbose ? now() : 0.0;
     const int8_t* Srow = g->d + mb * (int64_t)g->Npad;     // the chunk's rows in the store (rows M..Mpad are zero)
     {
@@ -905,22 +932,22 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, bool accum
     if (verbose) tv_gemm += now() - tp1;
     // c1[i] += sum_m (a b)_m s_mi: one dot product per row of the plain image (the direct path has it already)
     if (!direct) launch_snp_dot_raw(ctx, Xq, Mk, g->Npad, (int32_t)Mk, dcoef, dc1);
-    MMG_HIP(ctx, hipMemcpyAsync(c1part.data(), dc1, g->Npad * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < g->Npad; ++i) c1[i] += c1part[i];
+    launch_add_into_f64(ctx, ws.dc1acc, dc1, g->Npad);         // chunk after chunk, in order: deterministic
   }
-  if (rc) return rc;
+  if (rc) { ws.pending = false; ws.p_M = 0; return rc; }       // the planes are not to be trusted: the run is dropped
   ctx->grm_ms_total = kin_ms;
-  MMG_HIP(ctx, hipMemcpyAsync(dc1acc, c1.data(), g->Npad * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ws.p_c0 += c0;
+  ws.p_M += M;
+  ws.p_smax = std::max(ws.p_smax, (double)g->smax);
   const double tt0 = verbose ? now() : 0.0;
-  launch_grm_combine(ctx, C32, D, g->Npad, g->N, step, base, dc1acc, c0, dC, accumulate ? 1 : 0);
+  if (!defer) { int rcf = grm_flush(ctx, ws, dC); if (rcf) return rcf; }
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (verbose) {
     tv_tail = now() - tt0;
     fprintf(stderr, "[grm] N=%d M=%lld D=%d: stats+alloc+memset %.3f s, pack %.3f s, gemms(+launch) %.3f s (kernels %.3f s), "
-                    "combine %.3f s, total %.3f s\n", g->N, (long long)M, D, tv_alloc - tv0, tv_pack, tv_gemm, kin_ms * 1e-3,
-            tv_tail, now() - tv0);
+                    "combine %.3f s%s, total %.3f s\n", g->N, (long long)M, D, tv_alloc - tv0, tv_pack, tv_gemm, kin_ms * 1e-3,
+            tv_tail, defer ? " (deferred)" : "", now() - tv0);
   }
   return MMG_OK;
 }
@@ -929,7 +956,7 @@ int mmg_kin_acc_add_grm(mmg_ctx* ctx, mmg_kin_acc* a, mmg_geno* g) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, a && g && g->N == a->N);
   if (g->M == 0) return MMG_OK;
-  int rc = kinship_grm_i8_into(ctx, g, a->dC, true, a->ws);
+  int rc = kinship_grm_i8_into(ctx, g, a->dC, a->ws);
   if (rc == MMG_E_STATE) {                                  // genotype alphabet too wide for int8 digit products
     Scratch sc;
     double *dm = nullptr, *ds = nullptr;
@@ -951,9 +978,17 @@ int mmg_kin_acc_add_grm(mmg_ctx* ctx, mmg_kin_acc* a, mmg_geno* g) {
   return rc;
 }
 
+int mmg_kin_acc_pending(mmg_ctx* ctx, mmg_kin_acc* a, int64_t* n_snps_pending) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, a && n_snps_pending);
+  *n_snps_pending = a->ws.pending ? a->ws.p_M : 0;
+  return MMG_OK;
+}
+
 int mmg_kin_acc_fetch(mmg_ctx* ctx, mmg_kin_acc* a, double* C_out, int64_t* n_snps) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, a && C_out);
+  { int rcf = grm_flush(ctx, a->ws, a->dC); if (rcf) return rcf; }
   MMG_HIP(ctx, hipMemcpyAsync(C_out, a->dC, (size_t)a->N * a->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (n_snps) *n_snps = a->n_snps;
@@ -963,6 +998,7 @@ int mmg_kin_acc_fetch(mmg_ctx* ctx, mmg_kin_acc* a, double* C_out, int64_t* n_sn
 int mmg_kin_acc_scale_k(mmg_ctx* ctx, mmg_kin_acc* a, double* scalar_out) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, a != nullptr);
+  { int rcf = grm_flush(ctx, a->ws, a->dC); if (rcf) return rcf; }
   Scratch sc;
   const int64_t N = a->N;
   double* drow = nullptr;
@@ -986,6 +1022,7 @@ int mmg_kin_acc_scale_k(mmg_ctx* ctx, mmg_kin_acc* a, double* scalar_out) {
 int mmg_kin_acc_allreduce(mmg_ctx* ctx, mmg_comm* comm, mmg_kin_acc* a) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, a != nullptr);
+  { int rcf = grm_flush(ctx, a->ws, a->dC); if (rcf) return rcf; }
   if (!comm || comm->world <= 1) return MMG_OK;
   Scratch sc;
   long long* dn = nullptr;

@@ -534,6 +534,93 @@ void launch_snp_stats(mmg_ctx* ctx, const mmg_geno* g, double* mean, double* sd)
                      g->M, g->N, g->Npad, mean, sd);
 }
 
+// Weights of the exact GRM from the per-SNP statistics, on the device (round 4: the host loops over M means / stds and
+// their 16 B per SNP of download were 5 ms of a 43 ms call at C3).  Pass 1: per block of GRM_WB SNPs the largest and the
+// smallest weight 1 / sd^2, the block's share of c0 = sum mean^2 / sd^2 (summed in a fixed tree: deterministic) and the
+// number of SNPs without variation -- 4 doubles per block go to the host, which picks the digit step.
+constexpr int GRM_WB = 4096;
+
+__global__ __launch_bounds__(256) void grm_weight_stats_kernel(const double* __restrict__ mean, const double* __restrict__ sd,
+                                                               int64_t M, double* __restrict__ out /*[blocks][4]*/) {
+  const int64_t m0 = (int64_t)blockIdx.x * GRM_WB;
+  double wmax = 0.0, wmin = 1e300, c0 = 0.0, bad = 0.0;
+  for (int k = threadIdx.x; k < GRM_WB; k += 256) {
+    const int64_t m = m0 + k;
+    if (m >= M) break;
+    const double s = sd[m];
+    if (!(s > 0.0)) { bad += 1.0; continue; }
+    const double w = 1.0 / (s * s), mu = mean[m];
+    wmax = fmax(wmax, w);
+    wmin = fmin(wmin, w);
+    c0 += mu * mu * w;
+  }
+  __shared__ double red[4][256];
+  red[0][threadIdx.x] = wmax; red[1][threadIdx.x] = wmin; red[2][threadIdx.x] = c0; red[3][threadIdx.x] = bad;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      red[0][threadIdx.x] = fmax(red[0][threadIdx.x], red[0][threadIdx.x + o]);
+      red[1][threadIdx.x] = fmin(red[1][threadIdx.x], red[1][threadIdx.x + o]);
+      red[2][threadIdx.x] += red[2][threadIdx.x + o];
+      red[3][threadIdx.x] += red[3][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) out[(int64_t)blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+int64_t grm_weight_blocks(int64_t M) { return (M + GRM_WB - 1) / GRM_WB; }
+
+void launch_grm_weight_stats(mmg_ctx* ctx, const double* mean, const double* sd, int64_t M, double* out) {
+  hipLaunchKernelGGL(grm_weight_stats_kernel, dim3((unsigned)grm_weight_blocks(M)), dim3(256), 0, ctx->stream, mean, sd, M, out);
+}
+
+// Pass 2, per chunk of Mk SNPs starting at SNP mb: the D digits (bd bits each) of llrint(weight / step) and the
+// coefficient -mean * weight of the rank-one terms; rows past M are zero.  The same IEEE operations the host loop did.
+__global__ __launch_bounds__(256) void grm_digits_kernel(const double* __restrict__ mean, const double* __restrict__ sd,
+                                                         int64_t mb, int64_t M, int64_t Mk, double step, int bd, int D,
+                                                         int8_t* __restrict__ dig /*[D][Mk]*/, double* __restrict__ coef) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= Mk) return;
+  long long Z = 0;
+  double cf = 0.0;
+  if (mb + k < M) {
+    const double s = sd[mb + k];
+    const double w = 1.0 / (s * s);
+    // dithered rounding: floor(w / step + u) with u in [0, 1) a hash of the SNP's index.  Round-to-nearest gives SNPs of
+    // equal weight the SAME rounding error, and with weights 1 / (p (1 - p)), p = count / N, few distinct weights carry most
+    // SNPs -- the errors added up like M instead of sqrt(M) (4.8e-5 on entries of 7e4 over 70,000 SNPs of frequency one
+    // half, test_gpu_round3).  Dithered, the errors of different SNPs are independent and unbiased whatever the weights.
+    unsigned long long h = (unsigned long long)(mb + k) * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+    h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 27; h *= 0x94D049BB133111EBull; h ^= h >> 31;
+    const double u = (double)(h >> 11) * 0x1.0p-53;
+    Z = (long long)floor(w / step + u);
+    cf = -mean[mb + k] * w;
+  }
+  const long long mask = (1ll << bd) - 1, zmax = (1ll << (bd * D)) - 1;
+  Z = Z > zmax ? zmax : Z;
+  for (int d = 0; d < D; ++d) {
+    dig[(int64_t)d * Mk + k] = (int8_t)(Z & mask);
+    Z >>= bd;
+  }
+  coef[k] = cf;
+}
+
+void launch_grm_digits(mmg_ctx* ctx, const double* mean, const double* sd, int64_t mb, int64_t M, int64_t Mk, double step,
+                       int bd, int D, int8_t* dig, double* coef) {
+  hipLaunchKernelGGL(grm_digits_kernel, dim3((unsigned)((Mk + 255) / 256)), dim3(256), 0, ctx->stream, mean, sd, mb, M, Mk,
+                     step, bd, D, dig, coef);
+}
+
+__global__ void add_into_f64_kernel(double* __restrict__ dst, const double* __restrict__ src, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
+void launch_add_into_f64(mmg_ctx* ctx, double* dst, const double* src, int64_t n) {
+  hipLaunchKernelGGL(add_into_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, dst, src, n);
+}
+
 // max |s| over a 16-byte aligned range (write paths of the genotype store keep an upper bound of it)
 // out[0] = max |s|, out[1] = max(-s) (0 for a store without negative values).  PACK: the same pass writes the E2M1 twin of
 // the bytes it reads (bit 0 of byte i -> nibble i, 0x0 / 0x2): 8 bytes out per 16 in, no second sweep over the store.

@@ -186,6 +186,11 @@ void launch_grm_combine(mmg_ctx*, const int* C32, int D, int32_t Npad, int32_t N
                         const double* c1, double c0, double* C, int accumulate);
 // SNP-major digit images for the transposed-read kinship GEMM + the weighted column sums of the chunk (k_pack.hip)
 int64_t grm_partial_doubles(int64_t Mk, int32_t Npad);
+int64_t grm_weight_blocks(int64_t M);
+void launch_grm_weight_stats(mmg_ctx*, const double* mean, const double* sd, int64_t M, double* out /*[blocks][4]*/);
+void launch_grm_digits(mmg_ctx*, const double* mean, const double* sd, int64_t mb, int64_t M, int64_t Mk, double step, int bd,
+                       int D, int8_t* dig, double* coef);
+void launch_add_into_f64(mmg_ctx*, double* dst, const double* src, int64_t n);
 void launch_grm_scale_rows(mmg_ctx*, const int8_t* S, int64_t rows_valid, int64_t Mk, int32_t Npad, bool neg, int8_t* Xp,
                            const int8_t* dig, int D, const double* coef, double* partial, double* c1);
 void launch_transpose_digits(mmg_ctx*, const mmg_geno*, int8_t* Xq, int8_t* Xp, int64_t Mk, int64_t m_begin,

@@ -193,3 +193,53 @@ def test_own_triangular_inverse_equals_the_library_one(ctx, monkeypatch):
     reml.close()
     for i in range(4):
         assert np.max(np.abs(got[i] - ref[i]) / np.maximum(np.abs(ref[i]), 1.0)) < 1e-12, i
+
+
+def _grm_f64(s):
+    """kinship.py:63-69 in float64 on the host: sum_m z_m z_m', z = (s - mean) / std (population std)."""
+    x = s.astype(np.float64)
+    z = (x - x.mean(1, keepdims=True)) / x.std(1, keepdims=True)
+    return z.T @ z
+
+
+def test_grm_accumulator_runs_of_calls_share_the_digit_planes(ctx):
+    """mmg_kin_acc_add_grm keeps a run of calls in the int32 planes (one combine per run, include/mixmogam_hip.h): calls with
+    like weights join, a call whose weights do not fit ends the run, readers of the accumulator see everything."""
+    n, m = 200, 65536                                           # >= 65,536 binary SNPs: the one-pass four-plane kernel
+    rng = np.random.RandomState(11)
+
+    def chunk(lo, hi, rows=m):
+        f = rng.uniform(lo, hi, rows)
+        s = (rng.random_sample((rows, n)) < f[:, None]).astype(np.int8)
+        s[:, 0] = 0; s[:, 1] = 1                                # no SNP without variation
+        return s
+
+    a, b, c = chunk(0.2, 0.8), chunk(0.2, 0.8), chunk(0.2, 0.8, 3000)
+    rare = chunk(0.004, 0.5, 3000)                              # weights up to ~ 1 / 0.004: beyond the run's cap
+    acc = ctx.kinship_accumulator(n)
+    try:
+        for s in (a, b):
+            g = ctx.geno(s)
+            acc.add_grm(g)
+            g.close()
+        assert acc.pending() == 2 * m                           # the second call joined the first one's run
+        k_ab, cnt = acc.fetch()
+        assert cnt == 2 * m and acc.pending() == 0
+        want = _grm_f64(a) + _grm_f64(b)
+        assert np.abs(k_ab - want).max() <= 2e-9 * np.abs(want).max()
+        # a small call (five planes, one GEMM per plane) after a fetch starts a run of its own; rare variants end it
+        for s in (c, rare):
+            g = ctx.geno(s)
+            acc.add_grm(g)
+            g.close()
+        assert acc.pending() == len(rare)
+        f = acc.scale_k()                                       # reads the accumulator: combines first
+        assert acc.pending() == 0
+        k_all, cnt = acc.fetch()
+        assert cnt == 2 * m + len(c) + len(rare)
+        want = want + _grm_f64(c) + _grm_f64(rare)
+        scalar = (n - 1) / (np.trace(want) - want.sum() / n)
+        assert abs(f / scalar - 1) < 1e-9
+        assert np.abs(k_all - want * scalar).max() <= 2e-9 * np.abs(want * scalar).max()
+    finally:
+        acc.close()
