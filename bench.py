@@ -49,9 +49,14 @@ PCIE_GBPS = 64.0               # host link of the box (gen5 x16), the roof of an
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mode", choices=("weak", "strong", "perm", "multi"), default="weak")
+    ap.add_argument("--steps", type=int, default=None, help="default 3 (c5 mode: 1)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 1 (c5 mode: 0)")
+    ap.add_argument("--mode", choices=("weak", "strong", "perm", "multi", "c5"), default="weak")
+    ap.add_argument("--c5-n", type=int, default=50000, help="c5 mode: individuals")
+    ap.add_argument("--c5-m", type=int, default=10000000, help="c5 mode: SNPs in total, dealt chunk-wise over the ranks")
+    ap.add_argument("--c5-chunk", type=int, default=50000, help="c5 mode: SNPs per chunk")
+    ap.add_argument("--c5-share-of", type=int, default=0,
+                    help="c5 mode on ONE GPU: time the share one rank of this many would own (c5-m / share-of SNPs, no peers)")
     ap.add_argument("--n", type=int, default=5000, help="individuals")
     ap.add_argument("--m", type=int, default=1000000, help="SNPs per GPU (weak, multi) / in total (strong, perm)")
     ap.add_argument("--perms", type=int, default=1000, help="permutations (perm mode)")
@@ -68,7 +73,12 @@ def parse():
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher check: every rank prints its rendezvous environment as JSON and exits without "
                          "loading the HIP library or touching a GPU")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 1 if args.mode == "c5" else 3
+    if args.warmup is None:
+        args.warmup = 0 if args.mode == "c5" else 1
+    return args
 
 
 # ------------------------------------------------------------------------------------------------- self-launch
@@ -165,6 +175,8 @@ def main():
             raise SystemExit("RCCL reports %d ranks, launcher %d" % (rccl_nranks, world))
     comm_h = coll.device_comm if coll is not None else None
 
+    if args.mode == "c5":
+        return bench_c5(args, ctx, coll, rank, world, info, rccl_nranks)
     N, D, mode = args.n, args.digits, args.mode
     if mode in ("weak", "multi"):
         M, Mtot, m_global0 = args.m, args.m * world, rank * args.m
@@ -895,6 +907,72 @@ def bench_multi(args, ctx, coll, g, lmm, eig_L, N, M, Mtot, barrier, common):
                 "rotation_gemm_ms": rot_ms, "host_model_ms_per_phenotype": 1e3 * t_models / P,
                 "min_p": float(out["ps"].min())})
     return res
+
+
+def bench_c5(args, ctx, coll, rank, world, info, rccl_nranks):
+    """BASELINE config 5 as a job: N = 50,000 individuals x M = 10,000,000 SNPs streamed chunk-wise, the chunks dealt
+    round-robin over the ranks -- hdf5_data.run_emmax (hdf5_data.py:70-187 of the reference) on a lazily generated,
+    1-bit packed genotype tree (simulations.lazy_synthetic_source: every chunk is regenerated on each read, the 500 GB
+    matrix exists nowhere), kinship partial sums all-reduced in HBM, REML + scan model replicated, scan results
+    all-gathered.  A step is the whole pipeline; the line carries the stage times of every rank.  On one GPU
+    --c5-share-of W times the share one rank of W would own (no peers: its kinship is that share's)."""
+    from mixmogam_amd import hdf5_data, simulations
+    N, share_of = args.c5_n, args.c5_share_of
+    if share_of and world > 1:
+        raise SystemExit("--c5-share-of is the one-GPU stand-in for a multi-rank run")
+    Mtot = args.c5_m // share_of if share_of else args.c5_m
+    tree, y = simulations.lazy_synthetic_source(N, Mtot, num_chroms=5, gen_rows=6250, seed=20240, pheno_seed=20241,
+                                                num_causals=100, threads=int(os.environ.get("MMG_BENCH_GEN_THREADS", "8")),
+                                                packed=True)
+
+    def barrier():                                             # every library call blocks on its HIP stream: the device is idle here
+        if coll is not None:
+            coll.barrier()
+
+    stage_keys = ("kinship_pass_s", "grm_kernel_s", "reml_s", "scan_model_s", "scan_pass_s", "scan_kernel_s", "gather_s")
+    out = T = None
+    for _ in range(args.warmup):
+        hdf5_data.run_emmax(tree, y, min_maf=0.1, chunk_size=args.c5_chunk, ctx=ctx, coll=coll)
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        T = {}
+        out = hdf5_data.run_emmax(tree, y, min_maf=0.1, chunk_size=args.c5_chunk, ctx=ctx, coll=coll, timings=T)
+    barrier()
+    dt = time.time() - t0
+    mine = np.array([dt] + [float(T.get(k, 0.0)) for k in stage_keys])
+    if coll is not None:
+        allv = np.asarray(coll.allgather(mine)).reshape(world, len(mine))
+    else:
+        allv = mine[None, :]
+    dt_max = float(allv[:, 0].max())
+    if rank != 0:
+        return
+    ps = np.concatenate([out["chrom_results"][c]["ps"] for c in out["chrom_results"]])
+    n_snps = int(out["num_snps"])
+    nt = -(-N // 256)
+    grm_ops = 4.0 * 2.0 * 256.0 * 256.0 * (nt * (nt + 1) / 2)          # per SNP: 4 planes over the 256-tile triangle
+    grm_s = float(allv[:, 2].sum())                                      # all ranks' GEMM seconds for all SNPs
+    rec = {"metric": "SNPs/sec EMMAX end to end (kinship + REML + scan, streamed)", "unit": "SNPs/s",
+           "value": n_snps * args.steps / dt_max, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "i8", "data": "synthetic", "rccl_nranks": rccl_nranks, "mode": "c5",
+           "config": {"workload": "BASELINE configs[4]: N=%d individuals x M=%d SNPs streamed in chunks of %d from a lazily "
+                                  "generated 1-bit packed source%s" % (N, Mtot, args.c5_chunk,
+                                  " -- the share of ONE rank of %d, timed alone on one GPU" % share_of if share_of else ""),
+                      "n_individuals": N, "snps_total": n_snps, "chunk": args.c5_chunk, "share_of": share_of or None,
+                      "parallelism": "chunks round-robin x%d; kinship all-reduce in HBM, REML + scan model replicated" % world},
+           "stage_s_per_rank": {k: [round(float(v), 3) for v in allv[:, 1 + i]] for i, k in enumerate(stage_keys)},
+           "route": T.get("route"),
+           "roofline": {"bound": "mfma", "kernel": "kinship_grm4_kernel", "unit": "TOP/s", "peak": 5000.0,
+                        "achieved": None, "frac": grm_ops * n_snps / max(grm_s, 1e-9) / 1e12 / 5000.0,
+                        "note": "executed int8 ops of the kinship pass (its GEMM kernels are the largest stage) over their "
+                                "summed kernel time on all ranks; the scan's kernel time is scan_kernel_s", "traffic": None},
+           "cpu_baseline": None,
+           "pseudo_heritability": float(out["pseudo_heritability"]), "min_p": float(ps.min()),
+           "n_p_below_1e-8": int((ps < 1e-8).sum()), "device": info}
+    rec["roofline"]["achieved"] = rec["roofline"]["frac"] * 5000.0
+    print(json.dumps(rec))
 
 
 def _device_rows(ctx, rows, n, seed):

@@ -799,7 +799,10 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
   if (g->smax <= 1) bd = 7; else if (g->smax <= 2) bd = 6; else if (g->smax <= 4) bd = 5;
   if (bd == 0) return MMG_E_STATE;
   int D = (30 + bd - 1) / bd;                              // 5, 5, 6 planes
-  if (bd == 7 && g->M >= 65536) D = 4;
+  // ... the SNPs of the whole run count: a short call that can join a four-plane run of >= 2^16 SNPs takes four as well
+  // (the tail group of a chromosome; five planes there meant one GEMM per plane and a workspace of another shape)
+  const int D_alone = (bd == 7 && g->M >= 65536) ? 4 : D;
+  if (bd == 7 && (g->M >= 65536 || (ws.pending && ws.p_D == 4 && ws.p_M + g->M >= 65536))) D = 4;
   const bool planes_env = std::getenv("MMG_GRM_PLANES") != nullptr;
   if (planes_env) { const int v = std::atoi(std::getenv("MMG_GRM_PLANES")); if (v >= 3 && v <= 6) D = v; }   // 3: experiments only
   const double base = (double)(1 << bd);
@@ -818,31 +821,37 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
   static const bool defer = [] { const char* e = std::getenv("MMG_GRM_DEFER"); return !(e && e[0] == '0'); }();
   // binary store and four planes: ONE pass over the genotypes computes all four (gemm_i8_grm4.h: the scaled operands are
   // formed in registers from the plain tiles) -- no digit images at all.  MMG_GRM_FUSED=0: one GEMM per plane.
-  bool fused = [&] { const char* e = std::getenv("MMG_GRM_FUSED"); return direct && D == 4 && g->smax <= 1 && g->sneg == 0 && !(e && e[0] == '0'); }();
+  auto fused_for = [&](int d) { const char* e = std::getenv("MMG_GRM_FUSED"); return direct && d == 4 && g->smax <= 1 && g->sneg == 0 && !(e && e[0] == '0'); };
+  bool fused = fused_for(D);
   const int64_t M = g->M, CH = kin_chunk();
   const int64_t Mk_max = std::min(round_up(M, BK), CH);
+  // grow-only: a stream that alternates between call shapes (100,000-SNP groups and a chromosome's 50,000-SNP tail, four
+  // and five planes) re-allocated 50 GB at every change -- 3-5 s each at N = 50,000
   auto ensure_ws = [&](int D, bool fused) -> int {
     const size_t need_img = fused ? 16 : (size_t)g->Npad * Mk_max, need_c32 = (size_t)g->Npad * g->Npad;
     if (ws.cap_img < need_img || ws.cap_c32 < need_c32 || ws.capD < D || ws.cap_m < (size_t)M || ws.cap_mk < (size_t)Mk_max ||
         ws.cap_n < (size_t)g->Npad || ws.direct != direct) {
       int rcf = grm_flush(ctx, ws, dC);                       // the planes are about to be freed
       if (rcf) return rcf;
+      const size_t c_img = std::max(ws.cap_img, need_img), c_c32 = std::max(ws.cap_c32, need_c32),
+                   c_m = std::max(ws.cap_m, (size_t)M), c_mk = std::max(ws.cap_mk, (size_t)Mk_max),
+                   c_n = std::max(ws.cap_n, (size_t)g->Npad);
+      const int c_D = std::max(ws.capD, D);
       ws.release();
       ws.direct = direct;
-      hipError_t e = direct ? hipMalloc(&ws.dpart, (size_t)grm_partial_doubles(Mk_max, g->Npad) * sizeof(double))
-                            : hipMalloc(&ws.Xq, need_img);
-      if (e == hipSuccess) e = hipMalloc(&ws.Xp, (size_t)D * need_img);
-      if (e == hipSuccess) e = hipMalloc(&ws.C32, (size_t)D * need_c32 * sizeof(int));
-      if (e == hipSuccess) e = hipMalloc(&ws.ddig, (size_t)D * Mk_max);
-      if (e == hipSuccess) e = hipMalloc(&ws.dcoef, Mk_max * sizeof(double));
-      if (e == hipSuccess) e = hipMalloc(&ws.dc1, g->Npad * sizeof(double));
-      if (e == hipSuccess) e = hipMalloc(&ws.dc1acc, g->Npad * sizeof(double));
-      if (e == hipSuccess) e = hipMalloc(&ws.dm, M * sizeof(double));
-      if (e == hipSuccess) e = hipMalloc(&ws.ds, M * sizeof(double));
-      if (e == hipSuccess) e = hipMalloc(&ws.dwst, (size_t)grm_weight_blocks(M) * 4 * sizeof(double));
+      hipError_t e = direct ? hipMalloc(&ws.dpart, (size_t)grm_partial_doubles((int64_t)c_mk, (int32_t)c_n) * sizeof(double))
+                            : hipMalloc(&ws.Xq, c_img);
+      if (e == hipSuccess) e = hipMalloc(&ws.Xp, (size_t)c_D * c_img);
+      if (e == hipSuccess) e = hipMalloc(&ws.C32, (size_t)c_D * c_c32 * sizeof(int));
+      if (e == hipSuccess) e = hipMalloc(&ws.ddig, (size_t)c_D * c_mk);
+      if (e == hipSuccess) e = hipMalloc(&ws.dcoef, c_mk * sizeof(double));
+      if (e == hipSuccess) e = hipMalloc(&ws.dc1, c_n * sizeof(double));
+      if (e == hipSuccess) e = hipMalloc(&ws.dc1acc, c_n * sizeof(double));
+      if (e == hipSuccess) e = hipMalloc(&ws.dm, c_m * sizeof(double));
+      if (e == hipSuccess) e = hipMalloc(&ws.ds, c_m * sizeof(double));
+      if (e == hipSuccess) e = hipMalloc(&ws.dwst, (size_t)grm_weight_blocks((int64_t)c_m) * 4 * sizeof(double));
       if (e != hipSuccess) { ws.release(); return set_err(ctx, MMG_E_NOMEM, std::string("hipMalloc GRM workspace: ") + hipGetErrorString(e)); }
-      ws.cap_img = need_img; ws.cap_c32 = need_c32; ws.capD = D; ws.cap_m = (size_t)M; ws.cap_mk = (size_t)Mk_max;
-      ws.cap_n = (size_t)g->Npad;
+      ws.cap_img = c_img; ws.cap_c32 = c_c32; ws.capD = c_D; ws.cap_m = c_m; ws.cap_mk = c_mk; ws.cap_n = c_n;
     }
     return MMG_OK;
   };
@@ -874,7 +883,11 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
     plan_for(ws.p_wcap, Dn, fn);
     const bool joins = defer && Dn == ws.p_D && fn == ws.p_fused && bd == ws.p_bd && g->Npad == ws.p_Npad && g->N == ws.p_N &&
                        wmax <= ws.p_wcap && 2.0 * wmax > ws.p_wcap && planes_hold(std::max(ws.p_smax, (double)g->smax), ws.p_M + M);
-    if (!joins) { int rcf = grm_flush(ctx, ws, dC); if (rcf) return rcf; }
+    if (!joins) {
+      int rcf = grm_flush(ctx, ws, dC);
+      if (rcf) return rcf;
+      if (!planes_env) { D = D_alone; fused = fused_for(D); }   // a run of its own: the call's own SNP count decides
+    }
   }
   if (!ws.pending) {
     const double wcap = defer ? wmax * 1.0625 : wmax;

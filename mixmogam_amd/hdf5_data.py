@@ -17,6 +17,8 @@ Multi-GPU (`coll`, mixmogam_amd.dist): chunks are dealt round-robin to the ranks
 all-reduced in HBM (RCCL SUM), eigh/REML are replicated, every rank scans its chunks and the OWNED p-value blocks
 are all-gathered; permutation minima are combined with a MIN/MAX all-reduce of P values.  Rank 0 writes the results.
 """
+import time
+
 import numpy as np
 
 from . import _lib, chunkstore, kinship
@@ -241,7 +243,7 @@ def _merge_plan(plan, n_indivs, min_rows=None, max_bytes=None):
     return out
 
 
-def _ibd_kinship(ctx, genot_data, n_indivs, plan, coll=None, prefetch=True):
+def _ibd_kinship(ctx, genot_data, n_indivs, plan, coll=None, prefetch=True, timings=None):
     rank, world = (coll.rank, coll.world) if coll is not None else (0, 1)
     acc = ctx.kinship_accumulator(n_indivs)
     merged = _merge_plan(plan, n_indivs)
@@ -249,6 +251,8 @@ def _ibd_kinship(ctx, genot_data, n_indivs, plan, coll=None, prefetch=True):
         plan = merged
     for ci, chrom, g in _resident_chunks(ctx, genot_data, plan, rank, world, prefetch, reuse=True):
         acc.add_grm(g)                                                   # :99-106; a SNP with std == 0 is an error
+        if timings is not None:
+            timings['grm_kernel_s'] = timings.get('grm_kernel_s', 0.0) + 1e-3 * ctx.kernel_ms("grm")
         g.close()
     if coll is not None and world > 1:
         acc.allreduce(_dev_comm(coll))                                   # N x N partial sums never leave HBM
@@ -354,7 +358,7 @@ def _gather_owned(parts, plan, coll):
 
 def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=True, chunk_size=100000, k=None,
               ctx=None, coll=None, num_perm=0, perm_idx=None, phenotypes=None, prefetch=True, fast_perm=True,
-              eigen_free=None):
+              eigen_free=None, timings=None):
     """hdf5_data.py:70-187 (and :191-351 when num_perm > 0).  fast_perm: the permutation test of a chunk reuses the
     quadratic forms of the scan that just ran over it (mmg_emmax_perm_after_scan) instead of recomputing them.
     eigen_free: REML and the scan model from Cholesky factorisations instead of eigh(K) (linear_models.
@@ -372,8 +376,18 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
     host staging buffers of the largest chunk each -- chunk_size SNPs for the scan pass, and up to KIN_MAX_BYTES (6 GB) of
     int8 rows per buffer for the kinship pass, whose chunks are merged to >= 65,536 SNPs (_merge_plan): at most 2 x 6 GB
     of pinned host memory and 2 x 6 GB of HBM.  All chromosomes of a stream must hold the same individuals; the buffers
-    are sized by the largest row (raw int8 or bit-packed) over the plan."""
+    are sized by the largest row (raw int8 or bit-packed) over the plan.
+
+    timings: a dict that receives the wall seconds of the stages (kinship_pass_s, reml_s, scan_model_s, scan_pass_s,
+    gather_s) and the route taken -- what bench.py --mode c5 reports per rank."""
     ctx = ctx or _lib.get_context()
+    _t = [time.time()]
+
+    def _lap(key):
+        if timings is not None:
+            now = time.time()
+            timings[key] = timings.get(key, 0.0) + now - _t[0]
+            _t[0] = now
     if out_file is not None and not isinstance(out_file, str):           # run_emmax(genot_data, phenotypes, ...)
         phenotypes, out_file = out_file, None
     ih5f = None
@@ -392,9 +406,10 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
     rank, world = (coll.rank, coll.world) if coll is not None else (0, 1)
     plan = _chunk_plan(genot_data, min_maf, chunk_size)
     if k is None:
-        k, n_snps = _ibd_kinship(ctx, genot_data, n, plan, coll, prefetch)
+        k, n_snps = _ibd_kinship(ctx, genot_data, n, plan, coll, prefetch, timings)
     else:
         n_snps = sum(len(sel) for _c, sel, _p in plan)
+    _lap('kinship_pass_s')
     lmm = lm.LinearMixedModel(phenotypes, ctx=ctx)                       # :121
     lmm.add_random_effect(k)
     if eigen_free and num_perm:
@@ -404,13 +419,21 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
         eigen_free = n > lm.EIGEN_FREE_MIN_N and not num_perm and isinstance(ctx, _lib.Context)
     res = lmm._try_eigen_free(coll=coll) if eigen_free else None         # :126-137 without either eigendecomposition
     if res is not None:
+        _lap('reml_s')
+        if timings is not None:
+            timings['route'] = 'eigendecomposition-free (REML through %s)' % (
+                'one band reduction of K' if res['reml'].uses_band() else 'a Cholesky factorisation per delta')
         prep = lmm.scan_model_eigen_free(res)
         res.pop('reml').close()
     else:
         eig_L = lmm._get_eigen_L_()                                      # :126
         res = lmm.get_estimates(eig_L, method='REML')                    # :131-137 (no eig_R: linear_models._SpectralSumsL)
+        _lap('reml_s')
+        if timings is not None:
+            timings['route'] = 'eigh'
         prep = lmm.scan_prepare(res['H_sqrt_inv'])
         ctx.scan_set_model(prep['A'], prep['w'], 0)
+    _lap('scan_model_s')
     out = {'pseudo_heritability': res['pseudo_heritability'], 've': res['ve'], 'vg': res['vg'],
            'max_ll': res['max_ll'], 'num_snps': n_snps, 'chrom_results': {}, 'kinship': k}
     chroms = list(genot_data.keys())
@@ -424,6 +447,8 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
         plan_p = ctx.perm_plan(pp['H'], pp['Ys'], pp['h0_rss'])          # operand images of the test, once for all chunks
     for ci, chrom, g in _resident_chunks(ctx, genot_data, plan, rank, world, prefetch, reuse=True):
         parts[ci] = ctx.scan(g, prep['h0_rss'], prep['n_p'])['ps']       # :174 _emmax_f_test_(emma_num=0)
+        if timings is not None and isinstance(ctx, _lib.Context):
+            timings['scan_kernel_s'] = timings.get('scan_kernel_s', 0.0) + 1e-3 * ctx.kernel_ms("scan_quad")
         # :294-311,330 -- the permutation test runs on every chromosome but the LAST (`chr12_snps`); here chunk by
         # chunk right behind the scan of the same chunk, whose quadratic forms it reuses (same H; t.t needs only
         # 1 + q dot products per SNP on top of them)
@@ -431,8 +456,10 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
             mr = plan_p.run(g, after_scan_HtQ=prep['HtQ'] if (fast_perm and isinstance(ctx, _lib.Context)) else None)
             min_rss = np.minimum(min_rss, mr)
         g.close()
+    _lap('scan_pass_s')
     if coll is not None and world > 1:
         parts = _gather_owned(parts, plan, coll)                         # every SNP was scanned by exactly one rank
+    _lap('gather_s')
     for ci, (chrom, _sel, pos) in enumerate(plan):
         d = out['chrom_results'].setdefault(chrom, {'ps': [], 'positions': []})
         d['ps'].append(parts[ci])

@@ -218,14 +218,16 @@ def test_grm_accumulator_runs_of_calls_share_the_digit_planes(ctx):
     rare = chunk(0.004, 0.5, 3000)                              # weights up to ~ 1 / 0.004: beyond the run's cap
     acc = ctx.kinship_accumulator(n)
     try:
-        for s in (a, b):
+        for s in (a, b, c):
             g = ctx.geno(s)
             acc.add_grm(g)
             g.close()
-        assert acc.pending() == 2 * m                           # the second call joined the first one's run
+        # the second call joined the first one's run, and so did the short one (a chromosome's tail group: four planes
+        # like the run it joins, not the five a short call takes on its own)
+        assert acc.pending() == 2 * m + len(c)
         k_ab, cnt = acc.fetch()
-        assert cnt == 2 * m and acc.pending() == 0
-        want = _grm_f64(a) + _grm_f64(b)
+        assert cnt == 2 * m + len(c) and acc.pending() == 0
+        want = _grm_f64(a) + _grm_f64(b) + _grm_f64(c)
         assert np.abs(k_ab - want).max() <= 2e-9 * np.abs(want).max()
         # a small call (five planes, one GEMM per plane) after a fetch starts a run of its own; rare variants end it
         for s in (c, rare):
@@ -236,7 +238,7 @@ def test_grm_accumulator_runs_of_calls_share_the_digit_planes(ctx):
         f = acc.scale_k()                                       # reads the accumulator: combines first
         assert acc.pending() == 0
         k_all, cnt = acc.fetch()
-        assert cnt == 2 * m + len(c) + len(rare)
+        assert cnt == 2 * m + 2 * len(c) + len(rare)
         want = want + _grm_f64(c) + _grm_f64(rare)
         scalar = (n - 1) / (np.trace(want) - want.sum() / n)
         assert abs(f / scalar - 1) < 1e-9
