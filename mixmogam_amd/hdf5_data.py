@@ -251,7 +251,7 @@ def _ibd_kinship(ctx, genot_data, n_indivs, plan, coll=None, prefetch=True, timi
         plan = merged
     for ci, chrom, g in _resident_chunks(ctx, genot_data, plan, rank, world, prefetch, reuse=True):
         acc.add_grm(g)                                                   # :99-106; a SNP with std == 0 is an error
-        if timings is not None:
+        if timings is not None and isinstance(ctx, _lib.Context):
             timings['grm_kernel_s'] = timings.get('grm_kernel_s', 0.0) + 1e-3 * ctx.kernel_ms("grm")
         g.close()
     if coll is not None and world > 1:

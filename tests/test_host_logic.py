@@ -77,7 +77,11 @@ def test_chunked_driver_host_logic(ctx):
     src = {"c1": {"raw_snps": snps[:400], "freqs": snps[:400].mean(1), "positions": np.arange(400)},
            "c2": {"raw_snps": snps[400:], "freqs": snps[400:].mean(1), "positions": np.arange(len(snps) - 400)}}
     y = rng.randn(n) + snps[3]
-    a = hdf5_data.run_emmax(src, y, min_maf=0.1, chunk_size=64, ctx=ctx)
+    stages = {}
+    a = hdf5_data.run_emmax(src, y, min_maf=0.1, chunk_size=64, ctx=ctx, timings=stages)
+    # what bench.py --mode c5 prints per rank: every stage of the pipeline, and the route the REML took
+    assert {"kinship_pass_s", "reml_s", "scan_model_s", "scan_pass_s", "gather_s", "route"} <= set(stages)
+    assert all(stages[k] >= 0.0 for k in stages if k.endswith("_s"))
     b = hdf5_data.run_emmax(src, y, min_maf=0.1, chunk_size=10 ** 6, ctx=ctx)
     for c in ("c1", "c2"):
         assert rel(a["chrom_results"][c]["ps"], b["chrom_results"][c]["ps"]) < 1e-9
