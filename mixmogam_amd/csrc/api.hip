@@ -268,9 +268,14 @@ static int ensure_ingest(mmg_ctx* ctx, size_t bytes) {
 
 
 // MMG_UPLOAD_PATH=staged: contiguous copy into device staging + pitch kernel instead of the strided hipMemcpy2DAsync
+// The strided hipMemcpy2DAsync pays per ROW whenever the row width is not a multiple of four bytes: 7.3 us each, from 199 to
+// 20,001 individuals alike -- 0.03 / 0.67 / 2.6 GB/s at N = 199 / 4999 / 20,001, 1.5 s for the 43 MB of the bundled A. thaliana
+// set (199 x 214,000; tools/upload_width_check.py, profiles/r4_upload_width_check.txt).  Round 3 measured it at N = 5000
+// only, where it runs at the link's 54 GB/s.  Contiguous copy into device staging + pitch_rows_kernel: 43-52 GB/s at every
+// width, so that is the path; MMG_UPLOAD_PATH=2d forces the strided copy (A/B runs).
 static bool upload_2d() {
-  static const bool staged = [] { const char* e = std::getenv("MMG_UPLOAD_PATH"); return e && std::string(e) == "staged"; }();
-  return !staged;
+  static const bool forced = [] { const char* e = std::getenv("MMG_UPLOAD_PATH"); return e && std::string(e) == "2d"; }();
+  return forced;
 }
 
 // every write path ends here: fold max |s| of the written rows into the store's running bound
@@ -291,10 +296,7 @@ int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, i
   MMG_CHECK_ARG(ctx, g && snps && m0 >= 0 && rows >= 0 && m0 + rows <= g->M);
   if (rows == 0) return MMG_OK;
   g->bits_valid = false; ++g->version;
-  // Strided DMA straight into the padded store: 54-56 GB/s from pageable and page-locked memory alike
-  // (tools/h2d_check.py).  MMG_UPLOAD_PATH=staged: contiguous copies into device staging + pitch_rows_kernel (the same
-  // rate; kept for A/B runs -- what looked like a slow 2-D copy in round 3 was a host-side min() over the block in the
-  // Python binding, since removed).
+  // individual counts that are multiples of 16 land in place; others through device staging + pitch_rows_kernel (see upload_2d)
   if (g->N == g->Npad) {
     MMG_HIP(ctx, hipMemcpyAsync(g->d + m0 * (int64_t)g->Npad, snps, (size_t)rows * g->N, hipMemcpyHostToDevice, ctx->stream));
   } else if (upload_2d()) {
@@ -417,9 +419,21 @@ int mmg_geno_download(mmg_ctx* ctx, mmg_geno* g, int8_t* snps, int64_t m0, int64
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, g && snps && m0 >= 0 && rows >= 0 && m0 + rows <= g->M);
   if (rows == 0) return MMG_OK;
-  MMG_HIP(ctx, hipMemcpy2DAsync(snps, g->N, g->d + m0 * (int64_t)g->Npad, g->Npad, g->N, rows,
-                                hipMemcpyDeviceToHost, ctx->stream));
-  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (g->N == g->Npad) {
+    MMG_HIP(ctx, hipMemcpyAsync(snps, g->d + m0 * (int64_t)g->Npad, (size_t)rows * g->N, hipMemcpyDeviceToHost, ctx->stream));
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MMG_OK;
+  }
+  const int64_t chunk = std::max<int64_t>(1, INGEST_STAGE_BYTES / g->N);   // rows packed on the device, one transfer per piece
+  int rc0 = ensure_ingest(ctx, (size_t)std::min(chunk, rows) * g->N + 32);
+  if (rc0) return rc0;
+  for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
+    const int64_t nr = std::min(chunk, rows - r0);
+    launch_unpitch_rows(ctx, g->d + (m0 + r0) * (int64_t)g->Npad, (int8_t*)ctx->ingest, nr, g->N, g->Npad);
+    MMG_HIP(ctx, hipGetLastError());
+    MMG_HIP(ctx, hipMemcpyAsync(snps + r0 * g->N, ctx->ingest, (size_t)nr * g->N, hipMemcpyDeviceToHost, ctx->stream));
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   return MMG_OK;
 }
 
@@ -436,7 +450,13 @@ int mmg_geno_download_rows(mmg_ctx* ctx, mmg_geno* g, const int64_t* idx, int64_
   MMG_HIP(ctx, hipMemcpyAsync(didx, idx, cnt * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
   launch_gather_rows(ctx, g, didx, cnt, dS);
   MMG_HIP(ctx, hipGetLastError());
-  MMG_HIP(ctx, hipMemcpy2DAsync(snps, g->N, dS, g->Npad, g->N, cnt, hipMemcpyDeviceToHost, ctx->stream));
+  int8_t* dP = dS;
+  if (g->N != g->Npad) {
+    MMG_HIP(ctx, sc.alloc(&dP, (size_t)cnt * g->N));
+    launch_unpitch_rows(ctx, dS, dP, cnt, g->N, g->Npad);
+    MMG_HIP(ctx, hipGetLastError());
+  }
+  MMG_HIP(ctx, hipMemcpyAsync(snps, dP, (size_t)cnt * g->N, hipMemcpyDeviceToHost, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MMG_OK;
 }

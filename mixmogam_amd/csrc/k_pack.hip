@@ -194,6 +194,23 @@ void launch_pitch_rows(mmg_ctx* ctx, const int8_t* src, int8_t* dst, int64_t row
                      N, Npad);
 }
 
+// the reverse for downloads: rows of the padded store, packed N bytes apiece (one byte per thread: downloads are test /
+// diagnostic traffic; what matters is that the copy behind it is ONE contiguous transfer)
+__global__ __launch_bounds__(256) void unpitch_rows_kernel(const int8_t* __restrict__ src, int8_t* __restrict__ dst,
+                                                           int64_t rows, int32_t N, int32_t Npad) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= rows * N) return;
+  const int64_t r = gid / N;
+  dst[gid] = src[r * (int64_t)Npad + (gid - r * N)];
+}
+
+void launch_unpitch_rows(mmg_ctx* ctx, const int8_t* src, int8_t* dst, int64_t rows, int32_t N, int32_t Npad) {
+  const int64_t total = rows * N;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(unpitch_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, src, dst, rows,
+                     N, Npad);
+}
+
 void launch_unpack(mmg_ctx* ctx, const uint8_t* src, int64_t row_bytes, int8_t* dst, int64_t rows, int32_t N,
                    int32_t Npad, int bits, uint32_t lut, uint8_t* x4) {
   const int64_t total = rows * (Npad >> 4);

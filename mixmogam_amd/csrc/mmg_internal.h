@@ -153,7 +153,8 @@ void launch_fill_struct(mmg_ctx*, mmg_geno*, uint64_t seed, int64_t m_global0, i
 // fp32 / fp64 genotype ingest -> int8; *d_bad |= 1 if any value is not an integer in [-127, 127]
 void launch_unpack(mmg_ctx*, const uint8_t* src, int64_t row_bytes, int8_t* dst, int64_t rows, int32_t N, int32_t Npad,
                    int bits, uint32_t lut, uint8_t* x4 = nullptr);   // 1- / 2-bit packed rows -> int8 store rows (+ FP4 twin rows)
-void launch_pitch_rows(mmg_ctx*, const int8_t* src, int8_t* dst, int64_t rows, int32_t N, int32_t Npad);   // [rows x N] -> [rows x Npad], zero padded
+void launch_pitch_rows(mmg_ctx*, const int8_t* src, int8_t* dst, int64_t rows, int32_t N, int32_t Npad);
+void launch_unpitch_rows(mmg_ctx*, const int8_t* src, int8_t* dst, int64_t rows, int32_t N, int32_t Npad);   // [rows x N] -> [rows x Npad], zero padded
 void launch_cvt_f32(mmg_ctx*, const float* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld, int* d_bad);
 void launch_cvt_f64(mmg_ctx*, const double* src, int8_t* dst, int64_t rows, int32_t N, int64_t ld, int* d_bad);
 // Xt [Npad x Mk] = transpose of S with value map v -> mul*v + add for valid cells, 0 elsewhere.
