@@ -818,12 +818,16 @@ class LinearMixedModel(object):
                 ok = rss_list != h0_rss
                 b_snp = np.where(ok, out['dot'] / np.where(ok, out['den'], 1.0), 0.0)
                 Cs = g.matvec(prep['C'])                                 # q x M
-                betas = []
-                for j in range(num_snps):
-                    if ok[j]:
-                        betas.append([float(-Cs[k, j] * b_snp[j]) for k in range(Cs.shape[0])] + [float(b_snp[j])])
-                    else:
-                        betas.append(list(prep['h0_betas']))
+                q = Cs.shape[0]
+                B = np.empty((num_snps, q + 1))
+                B[:, :q] = -(Cs * b_snp).T
+                B[:, q] = b_snp
+                B[~ok] = np.asarray(prep['h0_betas'], dtype=np.float64)[None, :] if q + 1 == len(prep['h0_betas']) else np.nan
+                betas = list(B)                                          # per SNP the q + 1 coefficients (rows of one array:
+                                                                         # 1.5 M Python floats cost 0.2 s at M = 500,000)
+                if q + 1 != len(prep['h0_betas']):                       # (:1305: a rank-deficient SNP keeps the null model's q values)
+                    for j in np.nonzero(~ok)[0]:
+                        betas[j] = list(prep['h0_betas'])
                 res_d['betas'] = betas
             if return_transformed_snps:                                  # :1309-1321,:1355-1356
                 res_d['t_snps'] = self._transformed_snps(g, H_sqrt_inv, Z, project=not with_betas)
@@ -835,7 +839,13 @@ class LinearMixedModel(object):
                 pos = bfs * snp_priors / (1 - snp_priors)
                 res_d.update(bfs=bfs, pos=pos, ppas=pos / (1 + pos))
             if emma_num > 0 and num_snps > 0:                            # :1365-1377
-                order = np.argsort(p_vals, kind='stable')[:emma_num]
+                # the emma_num smallest p-values in the order of a stable argsort, without sorting all M of them
+                kth = np.partition(p_vals, emma_num - 1)[emma_num - 1] if emma_num < num_snps else np.nan
+                if kth == kth:                                           # (a NaN among the smallest: sort them all)
+                    cand = np.nonzero(p_vals <= kth)[0]
+                    order = cand[np.argsort(p_vals[cand], kind='stable')][:emma_num]
+                else:
+                    order = np.argsort(p_vals, kind='stable')[:emma_num]
                 top = g.download_rows(order) if not own else kinship._as_snp_matrix(snps)[order]
                 top_res = self.expedited_REML_t_test(list(top), eig_L=eig_L)
                 for k, pi in enumerate(order):
@@ -889,11 +899,14 @@ class LinearMixedModel(object):
         h0_rss = float(r @ r)
         r = r - h0_X @ h0_betas                                          # :1147 (second subtraction, kept)
         if perm_idx is None:
-            idx = np.asmatrix(np.arange(n).reshape(n, 1))
+            # the reference shuffles an n x 1 matrix in place; a 1-D array draws the same Fisher-Yates sequence from the
+            # same generator state (checked: identical permutations) without numpy.matrix's per-element row swaps --
+            # 0.6 of 0.75 s of a 100-permutation test at N = 1000
+            idx = np.arange(n)
             perm_idx = []
             for _ in range(num_perm):
                 np.random.shuffle(idx)
-                perm_idx.append(np.asarray(idx).reshape(-1).copy())
+                perm_idx.append(idx.copy())
         perm_idx = np.asarray(perm_idx)
         return {'H': H, 'Ys': np.ascontiguousarray(r[perm_idx].T), 'h0_rss': h0_rss,   # n x P: column p = r[perm_idx[p]]
                 'n_p': n - (self.X.shape[1] + 1)}
@@ -945,11 +958,11 @@ class LinearMixedModel(object):
         r = Yt - h0_X @ h0_betas                                         # :1198
         h0_rss = float(r @ r)
         if perm_idx is None:                                             # :1202-1205
-            idx = np.asmatrix(np.arange(n).reshape(n, 1))
+            idx = np.arange(n)                                           # see perm_prepare: the same draws as the n x 1 matrix
             perm_idx = []
             for _ in range(num_perm):
                 np.random.shuffle(idx)
-                perm_idx.append(np.asarray(idx).reshape(-1).copy())
+                perm_idx.append(idx.copy())
         perm_idx = np.asarray(perm_idx)
         Ys = np.ascontiguousarray(r[perm_idx].T)                         # n x P
         CH = H - H.mean(axis=0, keepdims=True)                           # C H: the transformed SNP minus its mean (:1211)
@@ -985,6 +998,16 @@ class LinearMixedModel(object):
 
 
 # ---------------------------------------------------------------------- module-level entry points
+def _cofactor_list(cofactors):
+    """The reference's callers pass a list of length-N vectors and its code tests it with `if cofactors:` (:1797-1803), which
+    raises on an ndarray.  Here None / empty -> no cofactors, a 2-D array -> its rows, a 1-D array -> one cofactor."""
+    if cofactors is None:
+        return []
+    if isinstance(cofactors, np.ndarray):
+        return [cofactors] if cofactors.ndim == 1 else list(cofactors)
+    return list(cofactors)
+
+
 def get_emma_reml_estimates(y, K, K2=None, cofactors=None, include_intercept=True, ctx=None):
     """:1690-1706."""
     if K2 is not None:
@@ -1006,14 +1029,12 @@ def emmax(snps, phenotypes, K, cofactors=None, Z=None, with_betas=False, emma_nu
     if Z is not None:
         Z = np.asarray(Z, dtype=np.float64)
         lmm.add_random_effect(Z @ np.asarray(K) @ Z.T)                  # :1796
-        if cofactors:
-            for cofactor in cofactors:
-                lmm.add_factor(Z @ _col(cofactor))
+        for cofactor in _cofactor_list(cofactors):
+            lmm.add_factor(Z @ _col(cofactor))
     else:
         lmm.add_random_effect(K)
-        if cofactors:
-            for cofactor in cofactors:
-                lmm.add_factor(cofactor)
+        for cofactor in _cofactor_list(cofactors):
+            lmm.add_factor(cofactor)
     s1 = time.time()
     res = lmm.emmax_f_test(snps, Z=Z, with_betas=with_betas, emma_num=emma_num, verbose=verbose)
     if verbose:
@@ -1071,9 +1092,8 @@ def emmax_multi(snps, phenotypes, K, cofactors=None, ctx=None, coll=None, max_st
     P, n = ys.shape
     lmm0 = LinearMixedModel(ys[0], ctx=ctx)
     lmm0.add_random_effect(K)                                            # scale_k once (:580): same K for every phenotype
-    if cofactors:
-        for cofactor in cofactors:
-            lmm0.add_factor(cofactor)                                    # dependence on X only: same for every phenotype
+    for cofactor in _cofactor_list(cofactors):
+        lmm0.add_factor(cofactor)                                        # dependence on X only: same for every phenotype
     ctx = lmm0.ctx
     X = lmm0.X
     q = X.shape[1]
@@ -1131,18 +1151,16 @@ def emma(snps, phenotypes, K, cofactors=None, ctx=None):
     """:1725-1745 -- exact EMMA per SNP (one N x N device eigh per SNP; short lists only)."""
     lmm = LinearMixedModel(phenotypes, ctx=ctx)
     lmm.add_random_effect(K)
-    if cofactors:
-        for cofactor in cofactors:
-            lmm.add_factor(cofactor)
+    for cofactor in _cofactor_list(cofactors):
+        lmm.add_factor(cofactor)
     return lmm.expedited_REML_t_test(list(np.asarray(snps)))
 
 
 def linear_model(snps, phenotypes, cofactors=None, ctx=None):
     """:3168-3183 -- standard linear model GWAS (no kinship)."""
     lm_ = LinearModel(phenotypes, ctx=ctx)
-    if cofactors:
-        for cofactor in cofactors:
-            lm_.add_factor(cofactor)
+    for cofactor in _cofactor_list(cofactors):
+        lm_.add_factor(cofactor)
     return lm_.fast_f_test(snps)
 
 

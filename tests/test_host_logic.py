@@ -28,6 +28,11 @@ def test_emmax_and_reml_host_logic_vs_golden(case, ctx):
     assert rel(res["h0_rss"], case["dbl_emmax_h0_rss"]) < 1e-9
     for k in ("pseudo_heritability", "ve", "vg", "max_ll"):
         assert rel(res[k], case["dbl_emmax_" + k]) < 1e-8, k
+    # cofactors as one array (rows = cofactors): the reference's `if cofactors:` raises on that; here it is the list again
+    if case["cof"] is not None:
+        as_rows = np.asarray([np.asarray(c, dtype=np.float64).reshape(-1) for c in case["cof"]])
+        res2 = lm.emmax(list(case["snps"]), list(case["y"]), case["dbl_ibs_scaled"], cofactors=as_rows, ctx=ctx)
+        assert np.array_equal(res2["ps"], res["ps"])
     reml = lm.get_emma_reml_estimates(list(case["y"]), case["dbl_ibs_scaled"], cofactors=case["cof"], ctx=ctx)
     for k in ("max_ll", "delta", "ve", "vg", "pseudo_heritability"):
         assert rel(reml[k], case["dbl_reml_" + k]) < 1e-8, k
