@@ -151,13 +151,19 @@ class _SpectralSumsL(object):
         self.logdet_xtx = np.linalg.slogdet(XtX)[1]
         xty = X.T @ y
         self.sum_sq_etas = float(y @ y - xty @ np.linalg.solve(XtX, xty))   # |Sy|^2
+        q = self.Xt.shape[1]
+        # the per-delta contractions as plain products with d' (m x N): einsum(..., optimize=True) spent 0.4 ms per call on
+        # its path search -- half of the per-SNP cost of the exact-EMMA refinement (emma_num), which builds one of these per SNP
+        self._xx = (self.Xt[:, :, None] * self.Xt[:, None, :]).reshape(len(self.Xt), q * q)
+        self._xy = self.Xt * self.yt[:, None]
 
     def at(self, deltas):
         d = 1.0 / (self.lam[:, None] + deltas[None, :])                  # N x m
         Xt, yt = self.Xt, self.yt
-        a = np.einsum('ni,nj,nm->mij', Xt, Xt, d, optimize=True)         # X'H^-1 X
-        a2 = np.einsum('ni,nj,nm->mij', Xt, Xt, d * d, optimize=True)    # X'H^-2 X
-        b = np.einsum('ni,nm->mi', Xt, d * yt[:, None])                  # X'H^-1 y
+        q = Xt.shape[1]
+        a = (d.T @ self._xx).reshape(-1, q, q)                           # X'H^-1 X
+        a2 = ((d * d).T @ self._xx).reshape(-1, q, q)                    # X'H^-2 X
+        b = d.T @ self._xy                                               # X'H^-1 y
         c = (yt * yt) @ d                                                # y'H^-1 y
         x = np.linalg.solve(a, b[:, :, None])[:, :, 0]                   # m x q
         s1 = c - np.einsum('mi,mi->m', b, x)
