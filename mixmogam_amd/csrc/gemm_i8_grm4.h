@@ -145,13 +145,15 @@ __device__ __forceinline__ void g4_slice(v16i (&acc)[4][2][2], const OpsG4& cur,
     if (ABL != 2) {
       if (i == 0) m0 = rin.a[0] + 0x7f7f7f7f;              // bytes 0 / 1 -> 0x7f / 0x80 -> (xor) 0x00 / 0xff
       if (i == 1) m0 = m0 ^ 0x7f7f7f7f;
-      if (i == 2) m1 = rin.a[1] + 0x7f7f7f7f;
-      if (i == 3) m1 = m1 ^ 0x7f7f7f7f;
+      if (i == 2 && ABL != 4 && ABL != 5 && ABL != 6) m1 = rin.a[1] + 0x7f7f7f7f;
+      if (i == 3 && ABL != 4 && ABL != 5 && ABL != 6) m1 = m1 ^ 0x7f7f7f7f;
+      if (i == 3 && (ABL == 4 || ABL == 5)) m1 = rin.a[1];  // ablations 4 / 5: half / none of the scaling VALU work
       if (i == 4) lds_digits_g4(rout.dg, s32 + (uint32_t)dgb, slice);
       if (i == 5) { lds_frag_g4(rout.a[0], s32 + (uint32_t)ab[0], slice); lds_frag_g4(rout.a[1], s32 + (uint32_t)ab[1], slice); }
       if (i == 6) { lds_frag_g4(rout.b[0], s32 + (uint32_t)bb[0], slice); lds_frag_g4(rout.b[1], s32 + (uint32_t)bb[1], slice); }
-      if (i >= 7 && i <= 10) nxt.as[i - 7] = m0 & rin.dg[i - 7];
-      if (i >= 11 && i <= 14) nxt.at[i - 11] = m1 & rin.dg[i - 11];
+      if (i >= 7 && i <= 10) { if (ABL == 5) { if (i == 7) { nxt.as[0] = m0; nxt.as[1] = m0; nxt.as[2] = rin.dg[0]; nxt.as[3] = rin.dg[1] | rin.dg[2] | rin.dg[3]; } } else nxt.as[i - 7] = m0 & rin.dg[i - 7]; }
+      if (i >= 11 && i <= 14 && ABL == 6) nxt.at[i - 11] = nxt.as[i - 11];   // ablation 6: the second row block reuses the first one's scaled operands
+      else if (i >= 11 && i <= 14) { if (ABL == 4 || ABL == 5) { if (i == 11) { nxt.at[0] = m1; nxt.at[1] = m1; nxt.at[2] = m1; nxt.at[3] = m1; } } else nxt.at[i - 11] = m1 & rin.dg[i - 11]; }
       if (i == 15) { nxt.b[0] = rin.b[0]; nxt.b[1] = rin.b[1]; }
     }
     if (ABL != 1) {
@@ -257,6 +259,182 @@ __device__ __forceinline__ void g4_stream(const G4Job& job, int64_t ld, char* ld
     g4_slice<false, true, false, ABL>(acc, f1, f0, r0, r1, MMG_G4_ARGS(oth, 1));
 #undef MMG_G4_ARGS
     advance();                                           // -> stage t+3
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the re-issued tail stages must land before LDS is released
+  epi(acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 4: the same product with the waves as four ROW STRIPS of the 128 x 128 tile (wave w: P columns 32 w .. + 32 against
+// all 128 Q columns) instead of 2 x 2 quadrants.  In the quadrant layout the two waves of a tile row scale the SAME two A
+// fragments: 8 mask + 32 and-operations per slice and wave, and halving them (MMG_GRM4_ABL=6: the second A block reuses the
+// first one's scaled fragments -- wrong results, same operand statistics) takes 34.1 -> 30.9 ms at C3: the slice is bound
+// by what ONE wave per SIMD can issue between 16 MFMAs.  A strip has one A fragment to scale for its 16 MFMAs (4 + 16 VALU
+// operations) and reads 4 raw B fragments instead of 2 (14 LDS reads per slice instead of 12).  B needs no scaling, so it is
+// read ONE slice ahead straight into the other half of a register double buffer (no copies); A and the digits keep their two
+// slices of lookahead (read, scale, use).  That puts the last read of a stage's Q tile (k slice 3, read in slice 2) BEHIND the
+// barrier of its step, so the Q tiles rotate through THREE LDS slots (stage t + 2 lands in the slot stage t - 1 left a whole
+// barrier ago); P tiles and digits keep two.  LDS: 2 x 16 + 3 x 16 KiB + 2 x 1 KiB = 82 KiB, one workgroup per CU as before.
+constexpr int G4R_P = 0;                                 // P slots at 0, 16 KiB
+constexpr int G4R_Q = 2 * G4_TILE;                       // Q slots at 32, 48, 64 KiB
+constexpr int G4R_D = 5 * G4_TILE;                       // digit slots [4 planes][128 k] at 80 KiB, + 1 KiB
+constexpr int G4R_LDS = G4R_D + 2 * 1024;
+
+__device__ __forceinline__ void lds_digits_g4r(v4i (&dg)[4], uint32_t addr, int slice) {
+#define MMG_G4R_DIGS(O)                                                                                           \
+  asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t" \
+               "ds_read_b128 %3, %4 offset:%8"                                                                     \
+               : "=&v"(dg[0]), "=&v"(dg[1]), "=&v"(dg[2]), "=&v"(dg[3])                                            \
+               : "v"(addr), "n"(O), "n"(128 + (O)), "n"(256 + (O)), "n"(384 + (O)))
+  switch (slice) {
+    case 0: MMG_G4R_DIGS(0); break;
+    case 1: MMG_G4R_DIGS(32); break;
+    case 2: MMG_G4R_DIGS(64); break;
+    default: MMG_G4R_DIGS(96); break;
+  }
+#undef MMG_G4R_DIGS
+}
+
+struct RawG4R { v4i dg[4], a; };                         // what comes out of LDS for the A side of a slice
+struct BufG4R { v4i b[4]; };                             // the raw B fragments of a slice
+
+__device__ __forceinline__ void wait_lds_g4r(RawG4R& r, BufG4R& b) {   // every LDS read issued so far has landed
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(r.dg[0]), "+v"(r.dg[1]), "+v"(r.dg[2]), "+v"(r.dg[3]), "+v"(r.a), "+v"(b.b[0]), "+v"(b.b[1]), "+v"(b.b[2]), "+v"(b.b[3]));
+}
+
+// Slice g: 16 MFMA (4 planes x 4 column blocks) on as_cur (scaled during slice g - 1) x bcur (read during slice g - 1);
+// rin (raw A + digits of slice g + 1, read during g - 1) is scaled into as_nxt; the raw A + digits of slice g + 2 are read
+// from (pa, da, k-slice sa) into rout, the B fragments of slice g + 1 from (qa[], k-slice sb) into bnxt.
+template <bool DMA_P, bool DMA_Q, bool ZERO, int ABL = 0>
+__device__ __forceinline__ void g4r_slice(v16i (&acc)[4][4], const v4i (&as_cur)[4], v4i (&as_nxt)[4], const BufG4R& bcur,
+                                          BufG4R& bnxt, RawG4R& rin, RawG4R& rout, uint32_t pa, uint32_t da, int sa,
+                                          const uint32_t (&qa)[4], int sb, const StageG4& sp, const StageG4& sq,
+                                          const __amdgpu_buffer_rsrc_t& rdig, int dig_voff, int dig_stride2, char* dst_p,
+                                          char* dst_q, char* dst_d, int wave) {
+  const v16i zero = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  v4i m;
+  wait_lds_g4r(rin, const_cast<BufG4R&>(bcur));
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int n = i >> 2, d = i & 3;                      // column block by column block: (b0: 4 planes), (b1: ...), ...
+    acc[d][n] = mfma8(as_cur[d], bcur.b[n], ZERO ? zero : acc[d][n]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (i < 4) lds_frag_g4(bnxt.b[i], qa[i], sb);          // B first: it is wanted one slice from now, A / digits two
+    if (i == 4) m = rin.a + 0x7f7f7f7f;                   // bytes 0 / 1 -> 0x7f / 0x80; the xor below makes them 0x00 / 0xff
+    if (i == 5) { if (ABL == 7) { rout.dg[0] = rin.dg[0]; rout.dg[1] = rin.dg[1]; rout.dg[2] = rin.dg[2]; rout.dg[3] = rin.dg[3]; } else lds_digits_g4r(rout.dg, da, sa); }   // ablation 7: no digit reads (wrong results)
+    if (i == 6) lds_frag_g4(rout.a, pa, sa);
+    if (i >= 8 && i <= 11) as_nxt[i - 8] = (m ^ 0x7f7f7f7f) & rin.dg[i - 8];
+    if (DMA_P && i < 4) stage_piece_g4(sp, dst_p, wave, i);
+    if (DMA_Q && i < 4) stage_piece_g4(sq, dst_q, wave, i);
+    if (DMA_Q && wave == 0 && (i == 12 || i == 13))
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdig, (MMG_AS3 void*)(dst_d + (i - 12) * 256), 4, dig_voff, (i - 12) * dig_stride2, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// epi(acc): acc[d][n] = plane d, rows = P columns wave*32 .., columns = Q columns n*32 .. (C layout of a 32 x 32 tile)
+template <int ABL = 0, class EpiFn>
+__device__ __forceinline__ void g4r_stream(const G4Job& job, int64_t ld, char* lds, EpiFn&& epi) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t l32 = (uint32_t)(uintptr_t)lds;
+  const uint32_t fa = (uint32_t)frag_base_g4(wave * 32, lane);
+  uint32_t fb[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) fb[n] = (uint32_t)frag_base_g4(n * 32, lane);
+  const uint32_t dgb = (uint32_t)((lane >> 5) * 16);
+  const int64_t kstep_bytes = (int64_t)BK * ld;
+  const int dig_voff = (lane >> 5) * job.dig_stride + (lane & 31) * 4, dig_stride2 = 2 * job.dig_stride;
+
+  // ---- issue cursor (wave-uniform): the descriptor bases move with the stage
+  int cks = 0, cst = 0;                                   // K step the descriptors point at, stages issued so far
+  StageG4 sp = make_stage_g4(job.P, ld, lane), sq = make_stage_g4(job.Q, ld, lane);
+  __amdgpu_buffer_rsrc_t rdig = __builtin_amdgcn_make_buffer_rsrc((void*)job.dig, 0, 0x7fffffff, 0x00020000);
+  auto advance = [&]() {
+    ++cst;
+    if (cks + 1 < job.nks) {                              // else: stay on the last stage (harmless re-issue into a free slot)
+      ++cks;
+      sp.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(job.P + cks * kstep_bytes), 0, 0x7fffffff, 0x00020000);
+      sq.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(job.Q + cks * kstep_bytes), 0, 0x7fffffff, 0x00020000);
+      rdig = __builtin_amdgcn_make_buffer_rsrc((void*)(job.dig + (int64_t)cks * BK), 0, 0x7fffffff, 0x00020000);
+    }
+  };
+  auto p_slot = [&](int st) { return lds + G4R_P + (st & 1) * G4_TILE; };
+  auto d_slot = [&](int st) { return lds + G4R_D + (st & 1) * 1024; };
+  auto q_slot = [&](int st) { return lds + G4R_Q + (st % 3) * G4_TILE; };
+  auto issue_stage = [&]() {                              // the whole stage `cst` at once (prologue)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_piece_g4(sp, p_slot(cst), wave, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_piece_g4(sq, q_slot(cst), wave, i);
+    if (wave == 0) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdig, (MMG_AS3 void*)(d_slot(cst)), 4, dig_voff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdig, (MMG_AS3 void*)(d_slot(cst) + 256), 4, dig_voff, dig_stride2, 0, 0);
+    }
+  };
+
+  // ---- prologue: stages 0 and 1 complete; raw A of k-slices 0 and 1, B of k-slice 0
+  issue_stage();
+  advance();
+  issue_stage();
+  advance();                                             // -> stage 2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // LDS addresses of this lane's reads in the CURRENT slots; they move on by adds once per step (below)
+  uint32_t pa = l32 + G4R_P + fa, da = l32 + G4R_D + dgb;
+  uint32_t qa[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) qa[n] = l32 + G4R_Q + fb[n];
+  int pst = 0, qst = 0;                                   // slot index the addresses point at (stage mod 2 / mod 3)
+
+  v4i f0[4], f1[4];
+  RawG4R r0, r1;
+  BufG4R b0, b1;
+  lds_digits_g4r(r0.dg, da, 0);
+  lds_frag_g4(r0.a, pa, 0);
+  lds_digits_g4r(r1.dg, da, 1);
+  lds_frag_g4(r1.a, pa, 1);
+#pragma unroll
+  for (int n = 0; n < 4; ++n) lds_frag_g4(b0.b[n], qa[n], 0);
+  wait_lds_g4r(r0, b0);
+  {
+    const v4i m = byte_mask_g4(r0.a);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) f0[d] = m & r0.dg[d];
+  }
+
+  v16i acc[4][4];                                        // written (not accumulated) by the first slice of the job
+
+  // Step t (stage t: P / digit slot t & 1, Q slot t % 3).  Slice s multiplies k-slice s, scales k-slice s + 1, reads raw A +
+  // digits of k-slice s + 2 and B of k-slice s + 1: slices 2, 3 read A / digits of stage t + 1, slice 3 its B -- behind the
+  // barrier, in front of which this wave's DMA of stage t + 1 has landed (vmcnt(0)) and every read of the P / digit slot of
+  // stage t has been waited for (lgkmcnt(0)): stage t + 2's P tile and digits go into that slot in slices 2 / 3, its Q tile
+  // into the slot stage t - 1 used (last read in slice 2 of step t - 1).
+  for (int t = 0; t < job.nks; ++t) {
+#define MMG_G4R_DMA sp, sq, rdig, dig_voff, dig_stride2, p_slot(cst), q_slot(cst), d_slot(cst), wave
+    if (t == 0) g4r_slice<false, false, true, ABL>(acc, f0, f1, b0, b1, r1, r0, pa, da, 2, qa, 1, MMG_G4R_DMA);
+    else g4r_slice<false, false, false, ABL>(acc, f0, f1, b0, b1, r1, r0, pa, da, 2, qa, 1, MMG_G4R_DMA);
+    g4r_slice<false, false, false, ABL>(acc, f1, f0, b1, b0, r0, r1, pa, da, 3, qa, 2, MMG_G4R_DMA);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {                                                     // A / digit reads move to the slot of stage t + 1
+      const int dlt = pst ? -1 : 1;
+      pa += (uint32_t)(dlt * G4_TILE); da += (uint32_t)(dlt * 1024); pst ^= 1;
+    }
+    g4r_slice<true, false, false, ABL>(acc, f0, f1, b0, b1, r1, r0, pa, da, 0, qa, 3, MMG_G4R_DMA);
+    {                                                     // B reads move to the Q slot of stage t + 1
+      const int dlt = qst == 2 ? -2 : 1;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) qa[n] += (uint32_t)(dlt * G4_TILE);
+      qst = qst == 2 ? 0 : qst + 1;
+    }
+    g4r_slice<false, true, false, ABL>(acc, f1, f0, b1, b0, r0, r1, pa, da, 1, qa, 0, MMG_G4R_DMA);
+#undef MMG_G4R_DMA
+    advance();                                           // -> stage t + 3
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the re-issued tail stages must land before LDS is released
   epi(acc);

@@ -155,6 +155,38 @@ __global__ __launch_bounds__(W4_THREADS) void kinship_grm4_kernel(const int8_t* 
   });
 }
 
+// The same product with the four waves as row strips of the tile (gemm_i8_grm4.h, round 4): half the digit-scaling VALU work.
+template <int ABL>
+__global__ __launch_bounds__(W4_THREADS) void kinship_grm4r_kernel(const int8_t* __restrict__ S, int64_t ld, int32_t Npad,
+                                                                   const int8_t* __restrict__ dig, int dig_stride,
+                                                                   const KinJob* __restrict__ jobs, int* __restrict__ C32) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const KinJob job = jobs[xcd_job_index(blockIdx.x)];
+  if (job.ks1 <= job.ks0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, r = lane & 31;
+  G4Job gj;
+  gj.P = S + (int64_t)job.ks0 * BK * ld + (int64_t)job.I * G4_T;
+  gj.Q = S + (int64_t)job.ks0 * BK * ld + (int64_t)job.J * G4_T;
+  gj.dig = dig + (int64_t)job.ks0 * BK;
+  gj.dig_stride = dig_stride;
+  gj.nks = job.ks1 - job.ks0;
+  const int64_t plane = (int64_t)Npad * Npad;
+  g4r_stream<ABL>(gj, ld, lds, [&](v16i (&acc)[4][4]) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int col = job.J * G4_T + n * 32 + r;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = job.I * G4_T + wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+          atomicAdd(C32 + d * plane + (int64_t)row * Npad + col, acc[d][n][i]);
+        }
+      }
+  });
+}
+
 // The raw-genotype product of a BINARY store on FP4 operands (gemm_i8_w4tr.h FmtF4): v_mfma_scale_f32_32x32x64_f8f6f4
 // runs 0/1 x 0/1 at 9.05 POP/s under the power cap against 4.85 for int8 bytes (tools/probe/mfma_f8f6f4_rate.hip) and
 // every LDS fill carries half the bytes -- both bounds of the int8 kernel move.  X4: the FP4 image
@@ -526,7 +558,19 @@ int run_kinship_grm4(mmg_ctx* ctx, const int8_t* S, int64_t ld, int32_t Npad, in
     hipLaunchKernelGGL(kinship_grm4_kernel<A>, dim3((unsigned)jobs.size()), dim3(W4_THREADS), G4_LDS, ctx->stream, S, ld, \
                        Npad, dig, (int)dig_stride, djobs, C32);                                                        \
   } while (0)
-  if (abl == 1) MMG_LAUNCH_G4(1); else if (abl == 2) MMG_LAUNCH_G4(2); else if (abl == 3) MMG_LAUNCH_G4(3); else MMG_LAUNCH_G4(0);
+  static const bool quad = [] { const char* e = std::getenv("MMG_GRM4_LAYOUT"); return !(e && std::string(e) == "strips"); }();
+  if (!quad && abl == 0) {                                // MMG_GRM4_LAYOUT=strips: four row strips (round 4; not faster)
+    MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_grm4r_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G4R_LDS));
+    EvScope ev(ctx, EV_KIN);
+    hipLaunchKernelGGL(kinship_grm4r_kernel<0>, dim3((unsigned)jobs.size()), dim3(W4_THREADS), G4R_LDS, ctx->stream, S, ld, Npad,
+                       dig, (int)dig_stride, djobs, C32);
+  } else if (abl == 7) {                                  // strips without the digit reads (timing only)
+    MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_grm4r_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, G4R_LDS));
+    EvScope ev(ctx, EV_KIN);
+    hipLaunchKernelGGL(kinship_grm4r_kernel<7>, dim3((unsigned)jobs.size()), dim3(W4_THREADS), G4R_LDS, ctx->stream, S, ld, Npad,
+                       dig, (int)dig_stride, djobs, C32);
+  } else
+  if (abl == 1) MMG_LAUNCH_G4(1); else if (abl == 2) MMG_LAUNCH_G4(2); else if (abl == 3) MMG_LAUNCH_G4(3); else if (abl == 4) MMG_LAUNCH_G4(4); else if (abl == 5) MMG_LAUNCH_G4(5); else if (abl == 6) MMG_LAUNCH_G4(6); else MMG_LAUNCH_G4(0);
 #undef MMG_LAUNCH_G4
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));

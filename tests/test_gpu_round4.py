@@ -245,3 +245,16 @@ def test_grm_accumulator_runs_of_calls_share_the_digit_planes(ctx):
         assert np.abs(k_all - want * scalar).max() <= 2e-9 * np.abs(want * scalar).max()
     finally:
         acc.close()
+
+
+def test_grm_row_strip_layout_equals_the_quadrant_layout_bit_for_bit():
+    """kinship_grm4r_kernel (MMG_GRM4_LAYOUT=strips: four row strips per tile, Q tiles in three LDS slots) against the shipped
+    quadrant layout: every plane is an exact integer sum, so the accumulated matrices must be identical.  The switch is read
+    once per process: tools/grm4_layouts.py runs each layout in a process of its own."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "grm4_layouts.py"), "1000", "140000"], capture_output=True,
+                         text=True, timeout=300, check=True).stdout
+    digests = re.findall(r"layout (\w+)\s*:.*sha1 ([0-9a-f]+)", out)
+    assert [d[0] for d in digests] == ["quad", "strips"], out
+    assert digests[0][1] == digests[1][1], out
