@@ -255,7 +255,8 @@ int mmg_geno_destroy(mmg_ctx* ctx, mmg_geno* g) {
   return MMG_OK;
 }
 
-constexpr int64_t INGEST_STAGE_BYTES = (int64_t)256 << 20;
+// device staging of the upload / download paths that repack rows; MMG_INGEST_STAGE_MB overrides (A/B runs)
+static const int64_t INGEST_STAGE_BYTES = [] { const char* e = std::getenv("MMG_INGEST_STAGE_MB"); const long v = e ? std::atol(e) : 0; return (int64_t)(v > 0 ? v : 256) << 20; }();
 
 static int ensure_ingest(mmg_ctx* ctx, size_t bytes) {
   if (ctx->ingest_cap >= bytes) return MMG_OK;
@@ -267,15 +268,18 @@ static int ensure_ingest(mmg_ctx* ctx, size_t bytes) {
 }
 
 
-// MMG_UPLOAD_PATH=staged: contiguous copy into device staging + pitch kernel instead of the strided hipMemcpy2DAsync
 // The strided hipMemcpy2DAsync pays per ROW whenever the row width is not a multiple of four bytes: 7.3 us each, from 199 to
 // 20,001 individuals alike -- 0.03 / 0.67 / 2.6 GB/s at N = 199 / 4999 / 20,001, 1.5 s for the 43 MB of the bundled A. thaliana
 // set (199 x 214,000; tools/upload_width_check.py, profiles/r4_upload_width_check.txt).  Round 3 measured it at N = 5000
-// only, where it runs at the link's 54 GB/s.  Contiguous copy into device staging + pitch_rows_kernel: 43-52 GB/s at every
-// width, so that is the path; MMG_UPLOAD_PATH=2d forces the strided copy (A/B runs).
-static bool upload_2d() {
-  static const bool forced = [] { const char* e = std::getenv("MMG_UPLOAD_PATH"); return e && std::string(e) == "2d"; }();
-  return forced;
+// only, where it runs at the link's 54 GB/s.  Contiguous copy into device staging + pitch_rows_kernel: 43-54 GB/s at every
+// width in isolation -- but 30 GB/s in bench.py's ingest record (N = 5000, after a download through the same staging buffer and
+// the release of a 7.5 GB store; seen twice, not reproduced at N = 4999 on its own), where the single strided call keeps 55.
+// So: rows of a multiple of four bytes, at least UPLOAD_2D_MIN_ROW wide (28 GB/s at 200 bytes, 50 at 1000) take the
+// strided copy, everything else the staging buffer.  MMG_UPLOAD_PATH=2d / staged force either.
+constexpr int32_t UPLOAD_2D_MIN_ROW = 1000;
+static bool upload_2d(int32_t row_bytes) {
+  static const int forced = [] { const char* e = std::getenv("MMG_UPLOAD_PATH"); return !e ? 0 : std::string(e) == "staged" ? 1 : std::string(e) == "2d" ? 2 : 0; }();
+  return forced == 2 || (forced == 0 && row_bytes % 4 == 0 && row_bytes >= UPLOAD_2D_MIN_ROW);
 }
 
 // every write path ends here: fold max |s| of the written rows into the store's running bound
@@ -296,10 +300,10 @@ int mmg_geno_upload(mmg_ctx* ctx, mmg_geno* g, const int8_t* snps, int64_t m0, i
   MMG_CHECK_ARG(ctx, g && snps && m0 >= 0 && rows >= 0 && m0 + rows <= g->M);
   if (rows == 0) return MMG_OK;
   g->bits_valid = false; ++g->version;
-  // individual counts that are multiples of 16 land in place; others through device staging + pitch_rows_kernel (see upload_2d)
+  // individual counts that are multiples of 16 land in place; others by the strided copy or through device staging (see upload_2d)
   if (g->N == g->Npad) {
     MMG_HIP(ctx, hipMemcpyAsync(g->d + m0 * (int64_t)g->Npad, snps, (size_t)rows * g->N, hipMemcpyHostToDevice, ctx->stream));
-  } else if (upload_2d()) {
+  } else if (upload_2d(g->N)) {
     MMG_HIP(ctx, hipMemcpy2DAsync(g->d + m0 * (int64_t)g->Npad, g->Npad, snps, g->N, g->N, rows,
                                   hipMemcpyHostToDevice, ctx->stream));
   } else {

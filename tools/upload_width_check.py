@@ -14,8 +14,10 @@ if len(sys.argv) == 1:
 from mixmogam_amd import _lib
 ctx = _lib.Context(0)
 rng = np.random.RandomState(0)
-for n in (199, 499, 1001, 2001, 4999, 9999, 20001):
-    m = max(2000, min(250000, int(2.5e8 // n)))
+seen5000 = False
+for n in (199, 200, 1001, 1000, 4999, 5000, 5000, 20001, 20000):
+    m = max(2000, min(250000, int(2.5e8 // n))) if n != 5000 or seen5000 else 250000
+    seen5000 = seen5000 or n == 5000
     host = rng.randint(0, 2, size=(m, n)).astype(np.int8)
     g = ctx.geno(M=m, N=n)
     g.upload(host, 0)
