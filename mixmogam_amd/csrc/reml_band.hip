@@ -383,6 +383,7 @@ __global__ __launch_bounds__(256) void tsmm_reduce_kernel(const double* __restri
 // agent-scope loads of the exchanged sums were slower: panel QR + T 1.78 against 1.27 s at N = 50,000, 0.50 against 0.42
 // at 20,000 -- a grid barrier over ~200 workgroups costs more than the kernel boundary it replaces.)
 constexpr int QR_ROWS = 256;
+constexpr double HH_TINY2 = 1e-200;                          // (norm below which a Householder column counts as zero)^2
 __global__ __launch_bounds__(256) void panel_qr_step_kernel(double* __restrict__ P, int64_t lda, int n, int j,
                                                             const double* __restrict__ part_in, double* __restrict__ part_out,
                                                             const double* __restrict__ pivrow_in, double* __restrict__ pivrow_out,
@@ -402,7 +403,12 @@ __global__ __launch_bounds__(256) void panel_qr_step_kernel(double* __restrict__
     __syncthreads();
     const double x0 = pivrow_in[j], xn2 = sdots[j];
     double tauj = 0.0, beta = x0;
-    if (xn2 > 0.0) {
+    // A column whose norm is below HH_TINY is left alone (H = I; what lies below its diagonal is dropped: an error of
+    // 1e-100 on a matrix of O(1) entries).  In a rank-deficient panel every column past the rank is the rounding noise
+    // of the one before it -- 1e-13, 1e-26, ... -- and past 1e-154 the squares of its entries underflow: the norm that
+    // defines tau no longer matches the column that defines v, and the "reflector" stops being orthogonal (a kinship of
+    // rank 3 at N = 1024: tau |v|^2 = 2.59 at column 61, REML sums off by 2e-5; LAPACK's dlarfg rescales instead).
+    if (fma(x0, x0, xn2) > HH_TINY2) {
       beta = -copysign(sqrt(fma(x0, x0, xn2)), x0);
       tauj = (beta - x0) / beta;
       scale = 1.0 / (x0 - beta);
@@ -654,7 +660,7 @@ __global__ __launch_bounds__(256) void band_tail_kernel(double* __restrict__ A, 
       if (tid == 0) {
         const double x0 = Ps[j * LDT + j];
         double tau = 0.0, beta = x0, scale = 0.0;
-        if (s2 > 0.0) {
+        if (fma(x0, x0, s2) > HH_TINY2) {                      // see panel_qr_step_kernel
           beta = -copysign(sqrt(fma(x0, x0, s2)), x0);
           tau = (beta - x0) / beta;
           scale = 1.0 / (x0 - beta);
@@ -897,7 +903,18 @@ static int band_reduce_hh(mmg_ctx* ctx, mmg_reml* r) {
     hipLaunchKernelGGL(tsmm_tn_kernel, dim3(G), dim3(256), 0, st, Am, lda, Bm, ldb, kb, (int)n, rows_per, part);
     hipLaunchKernelGGL(tsmm_reduce_kernel, dim3(16), dim3(256), 0, st, part, G, out, ldo);
   };
+  const bool dbg = std::getenv("MMG_BAND_DEBUG") != nullptr;  // column norms of the rotated [X y] panel by panel (orthogonality)
+  auto dbg_norms = [&](long long at) {
+    if (!dbg) return;
+    std::vector<double> hz((size_t)N * q1);
+    (void)hipMemcpyAsync(hz.data(), r->dZr, hz.size() * sizeof(double), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    fprintf(stderr, "[band dbg] before panel at column %lld: |Z_c|^2 =", at);
+    for (int c = 0; c < q1; ++c) { double t = 0; for (int64_t i = 0; i < N; ++i) t += hz[(size_t)c * N + i] * hz[(size_t)c * N + i]; fprintf(stderr, " %.15g", t); }
+    fprintf(stderr, "\n");
+  };
   for (int64_t k0 = k_first; N - k0 - b >= 2; k0 += b) {
+    dbg_norms((long long)k0);
     auto tp = std::chrono::steady_clock::now();
     if (verbose) { (void)hipStreamSynchronize(st); tp = std::chrono::steady_clock::now(); }
     const int64_t a0 = k0 + b;                                // first row / column of the trailing matrix
@@ -907,7 +924,15 @@ static int band_reduce_hh(mmg_ctx* ctx, mmg_reml* r) {
     double* A22 = A + a0 + a0 * N;                            // [n x n] trailing matrix
     double* Zs = r->dZr + a0;
     W = VW + (size_t)n * b;
-    if (lib_only || n < 256) {
+    if (!lib_only && n < b) {                                 // the last block column: one workgroup (as in band_reduce_cqr)
+      hipLaunchKernelGGL(band_tail_kernel, dim3(1), dim3(256), 0, st, A, N, k0, r->dZr, q1);
+      lap(0, tp);
+      continue;
+    }
+    // (round 4: panels shorter than 256 rows took the library path too; rocSOLVER's geqrf loses orthogonality on the noise
+    // columns of a rank-deficient panel the way the own kernel did before HH_TINY2 -- 1e-6 on the REML sums -- so they are
+    // the own kernels' now)
+    if (lib_only) {
       RC_RB(ctx, rocsolver_dgeqrf(h, (rocblas_int)n, b, P, (rocblas_int)N, tau));
       hipLaunchKernelGGL(band_build_v_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)nr), dim3(256), 0, st, P, N, (int)n, nr, V);
       RC_RB(ctx, rocsolver_dlarft(h, rocblas_forward_direction, rocblas_column_wise, (rocblas_int)n, nr, V, (rocblas_int)n, tau, T, b));
@@ -945,6 +970,32 @@ static int band_reduce_hh(mmg_ctx* ctx, mmg_reml* r) {
       hipLaunchKernelGGL(form_t_kernel, dim3(1), dim3(64), 0, st, M1, tau, T);
     }
     lap(0, tp);
+    if (dbg && k0 == k_first) {                               // is (V, T) an orthogonal Q = I - V T V'?  D = T + T' - T' (V'V) T must vanish
+      std::vector<double> hv((size_t)n * b), ht((size_t)b * b), htau(b);
+      (void)hipMemcpyAsync(hv.data(), V, hv.size() * sizeof(double), hipMemcpyDeviceToHost, st);
+      (void)hipMemcpyAsync(ht.data(), T, ht.size() * sizeof(double), hipMemcpyDeviceToHost, st);
+      (void)hipMemcpyAsync(htau.data(), tau, b * sizeof(double), hipMemcpyDeviceToHost, st);
+      (void)hipStreamSynchronize(st);
+      std::vector<double> g((size_t)b * b, 0.0);
+      for (int a = 0; a < b; ++a) for (int c = 0; c < b; ++c) { double t = 0; for (int64_t i = 0; i < n; ++i) t += hv[i + (size_t)a * n] * hv[i + (size_t)c * n]; g[a + (size_t)c * b] = t; }
+      double worst_tau = 0, vmax = 0;
+      for (int a = 0; a < b; ++a) worst_tau = std::max(worst_tau, std::fabs(htau[a] * g[a + (size_t)a * b] - 2.0) * (htau[a] != 0.0));
+      for (double x : hv) vmax = std::max(vmax, std::fabs(x));
+      // D = T + T' - T' G T
+      std::vector<double> gt((size_t)b * b, 0.0);
+      for (int a = 0; a < b; ++a) for (int c = 0; c < b; ++c) { double t = 0; for (int k = 0; k < b; ++k) t += g[a + (size_t)k * b] * ht[k + (size_t)c * b]; gt[a + (size_t)c * b] = t; }
+      double dmax = 0; int da = 0, dc = 0;
+      for (int a = 0; a < b; ++a) for (int c = 0; c < b; ++c) {
+        double t = ht[a + (size_t)c * b] + ht[c + (size_t)a * b];
+        for (int k = 0; k < b; ++k) t -= ht[k + (size_t)a * b] * gt[k + (size_t)c * b];
+        if (std::fabs(t) > dmax) { dmax = std::fabs(t); da = a; dc = c; }
+      }
+      fprintf(stderr, "[band dbg] first panel: max |V| %.3g, max |tau_j |v_j|^2 - 2| %.3g, max |T + T' - T'(V'V)T| %.3g at (%d, %d); tau[0..7] =", vmax, worst_tau, dmax, da, dc);
+      for (int a = 0; a < 8; ++a) fprintf(stderr, " %.6g", htau[a]);
+      fprintf(stderr, "\n[band dbg] j: tau_j |v_j|^2 tau|v|^2:");
+      for (int a = 0; a < b; ++a) if (std::fabs(htau[a] * g[a + (size_t)a * b] - 2.0) > 1e-9) fprintf(stderr, "  %d: %.6g %.6g %.6g;", a, htau[a], g[a + (size_t)a * b], htau[a] * g[a + (size_t)a * b]);
+      fprintf(stderr, "\n");
+    }
     // ---- W = A22 V from the lower triangle alone
     hipLaunchKernelGGL(sym_skinny_kernel<false>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, A22, N, (int)n, V, W);
     lap(1, tp);
@@ -970,6 +1021,7 @@ static int band_reduce_hh(mmg_ctx* ctx, mmg_reml* r) {
     }
     lap(3, tp);
   }
+  dbg_norms(-1);
   hipLaunchKernelGGL(band_extract_kernel, dim3((unsigned)N), dim3(64), 0, st, A, N, r->dBand);
   RC_HIP(ctx, hipGetLastError());
   RC_HIP(ctx, hipStreamSynchronize(st));

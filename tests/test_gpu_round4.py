@@ -258,3 +258,45 @@ def test_grm_row_strip_layout_equals_the_quadrant_layout_bit_for_bit():
     digests = re.findall(r"layout (\w+)\s*:.*sha1 ([0-9a-f]+)", out)
     assert [d[0] for d in digests] == ["quad", "strips"], out
     assert digests[0][1] == digests[1][1], out
+
+
+@pytest.mark.parametrize("n,m", [(504, 2), (1024, 3), (2048, 3)])
+def test_band_route_on_a_kinship_of_rank_three(ctx, n, m):
+    """A kinship from two or three SNPs has rank <= 4: every panel of the band reduction is rank deficient (the Cholesky-QR
+    panels hand over to the Householder ones), and every column past the rank is the rounding noise of the one before it,
+    down to 1e-160 -- where the squares that make up a column norm underflow.  Before reml_band.hip's HH_TINY2 guard the
+    reflectors of such columns stopped being orthogonal (tau |v|^2 = 2.59) and the sums involving y were off by 2e-5, p-values
+    by up to 6e-3 (found by tools/random_parity.py).  Sums against the spectral form on the host, p-values against the oracle."""
+    from mixmogam_amd import kinship, linear_models as lm
+    from oracle import emmax_oracle as orc
+    rng = np.random.RandomState(n + m)
+    snps = (rng.random_sample((m, n)) < rng.uniform(0.2, 0.8, m)[:, None]).astype(np.int8)
+    y = rng.standard_normal(n) + snps[0]
+    K = kinship.calc_ibs_kinship(snps, ctx=ctx)
+    Ks = kinship.scale_k(K)
+    X = np.ones((n, 1))
+    lam, U = np.linalg.eigh(Ks)
+    want = lm._SpectralSumsL({"values": lam[::-1], "vectors": U.T[::-1]}, X, y).at(np.array([1e-3, 1.0, 50.0]))
+    r = ctx.reml(Ks, X, y)
+    try:
+        got = r.sums(np.array([1e-3, 1.0, 50.0]), route="band")
+        assert r.band_info()["householder_fallback"]
+    finally:
+        r.close()
+    for k in range(4):
+        assert np.max(np.abs(got[k] / want[k] - 1)) < 1e-8, k
+    res = lm.emmax(snps, list(y), K, ctx=ctx)
+    ref = orc.emmax(snps, y, K)
+    assert abs(res["pseudo_heritability"] - ref["pseudo_heritability"]) < 1e-6
+    assert np.max(np.abs(res["ps"] / ref["ps"] - 1)) < 1e-6
+
+
+def test_random_shapes_against_the_oracle():
+    """tools/random_parity.py: 40 random small problems (3..700 individuals, 1..3000 SNPs, binary / 0-1-2 / signed genotypes,
+    0..2 cofactors) through kinship, emmax(), linear_model() and emmax_multi() against the float64 oracle -- the sweep that
+    found the rank-deficient-kinship failure above."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "random_parity.py"), "40", "3"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "failures: 0" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
