@@ -239,6 +239,11 @@ int mmg_emmax_scan(mmg_ctx* ctx, mmg_geno* g, double h0_rss, int32_t df2,
  * eps_max = max relative change of den over the refined SNPs.  adaptive = 0 for models with an explicit ndigits. */
 int mmg_scan_last_stats(mmg_ctx* ctx, int32_t* adaptive, int64_t* n_refined, double* eps_max,
                         double* sigma_ratio_max, int32_t* fell_back);
+/* The exact tier of the last scan: SNPs whose quadratic form was recomputed from the fp64 matrix because the digit planes could
+ * not pin it down to the 2.5e-7 target on p (a denominator far below sum s^2 max |A|: a SNP in the span of the kinship's large
+ * eigenvalues); -1: more SNPs wanted it than MMG_SCAN_EXACT_MAX_FLOP (4e13) allows -- those keep the planes' values.
+ * MMG_SCAN_EXACT=0 turns the tier off (the model then does not keep its fp64 matrix: N^2 doubles). */
+int mmg_scan_last_exact(mmg_ctx* ctx, int64_t* n_exact);
 
 /* Same, leaving results in device memory (for RCCL gathers / benchmarking); fetch with
  * mmg_scan_fetch.  Blocks until the kernels finish. */

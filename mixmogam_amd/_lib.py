@@ -63,6 +63,7 @@ PROTOTYPES = {
     "mmg_kin_acc_destroy": (C.c_int, [c_vp, c_vp]),
     "mmg_kinship_i8": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp, c_vp, c_vp]),
     "mmg_scan_last_stats": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mmg_scan_last_exact": (C.c_int, [c_vp, c_i64p]),
     "mmg_scan_deliver_begin": (C.c_int, [c_vp, c_vp, C.c_int64, c_vp, c_vp, c_vp]),
     "mmg_scan_deliver_wait": (C.c_int, [c_vp]),
     "mmg_eigh_f64": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp]),
@@ -656,11 +657,14 @@ class Context(object):
         return {k: v for k, v in outs.items() if v is not None}
 
     def scan_last_stats(self):
-        """{'adaptive', 'n_refined', 'eps_max', 'fell_back'} of the last scan (adaptive digit schedule)."""
+        """{'adaptive', 'n_refined', 'eps_max', 'fell_back'} of the last scan (adaptive digit schedule); 'n_exact': SNPs
+        recomputed from the fp64 matrix (mmg_scan_last_exact; -1: over budget)."""
         a, n, e, r, f = C.c_int32(0), C.c_int64(0), C.c_double(0.0), C.c_double(0.0), C.c_int32(0)
         self._check(self.lib.mmg_scan_last_stats(self.h, C.byref(a), C.byref(n), C.byref(e), C.byref(r), C.byref(f)))
+        x = C.c_int64(0)
+        self._check(self.lib.mmg_scan_last_exact(self.h, C.byref(x)))
         return {"adaptive": bool(a.value), "n_refined": n.value, "eps_max": e.value, "sigma_ratio_max": r.value,
-                "fell_back": bool(f.value)}
+                "fell_back": bool(f.value), "n_exact": x.value}
 
     def scan_deliver_begin(self, outs, count=None, comm=None):
         """Background delivery of the last scan's (rss, F, p) into the three host arrays `outs`

@@ -96,7 +96,7 @@ int mmg_ctx_create(int device, mmg_ctx** out) {
 }
 
 static void free_model(mmg_scan_model& m) {
-  hipFree(m.Bq); hipFree(m.diag); hipFree(m.w); hipFree(m.job_off); hipFree(m.jobs);
+  hipFree(m.Bq); hipFree(m.A64); hipFree(m.diag); hipFree(m.w); hipFree(m.job_off); hipFree(m.jobs);
   hipFree(m.job_off_hi); hipFree(m.jobs_hi); hipFree(m.job_off_lo); hipFree(m.jobs_lo);
   for (int r = 0; r < 3; ++r)
     for (int k = 0; k < 2; ++k) { hipFree(m.tail_off[r][k]); hipFree(m.tail_jobs[r][k]); }
@@ -1369,9 +1369,19 @@ static int model_from_device(mmg_ctx* ctx, mmg_scan_model& md, int32_t N, const 
         if (dev > 8.0) { md.adaptive = false; break; }
       }
   }
+  // the fp64 matrix stays with the model for the exact tier of the scan (exact_tier below): N^2 doubles next to D N^2 / 2 bytes
+  // of digits.  MMG_SCAN_EXACT=0, or a failed allocation: the tier is off and the scan is what its planes give.
+  // Only the default model has the tier: an explicit digit count asks for what that many planes give.
+  const bool exact_on = [] { const char* e = std::getenv("MMG_SCAN_EXACT"); return !(e && e[0] == '0'); }();   // read per model
+  md.coherent = adaptive && ndigits == 4 && !md.adaptive;
+  if (exact_on && adaptive && ndigits == 4 && hipMalloc(&md.A64, (size_t)N * N * sizeof(double)) == hipSuccess)
+    MMG_HIP(ctx, hipMemcpyAsync(md.A64, dA, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  else { (void)hipGetLastError(); md.A64 = nullptr; }
   int rcl = add_linear_rows(ctx, md);
   if (rcl) return rcl;
-  return build_schedule(ctx, md);
+  rcl = build_schedule(ctx, md);
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));           // dA is the caller's scratch
+  return rcl;
 }
 
 }  // extern "C"
@@ -1424,6 +1434,79 @@ static int ensure_result(mmg_ctx* ctx, mmg_scan_result& r, int64_t Mpad) {
   return MMG_OK;
 }
 
+// The exact tier: SNPs whose den the digit planes cannot pin down to the target (k_scan.hip: scan_select_exact_kernel) get
+// s'As from the fp64 matrix itself (scan_exact_den_kernel), in batches of gathered rows.  Budget: MMG_SCAN_EXACT_MAX_FLOP
+// (default 4e13, ~1-2 s) -- a data set in which MOST SNPs need it is reported (n_exact = -1) rather than served.
+static int exact_tier(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, mmg_scan_result& res, double h0_rss, int32_t df2,
+                      bool f_free, double target, bool full_planes) {
+  res.n_exact = 0;
+  if (!md.A64 || g->M == 0) return MMG_OK;
+  const int N = md.N, nJB = (N + 255) / 256;
+  const double sig_full = md.step / std::sqrt(12.0) / std::sqrt(2.0);   // every plane in: entries rounded to +-step / 2
+  // what the SNPs that were not refined carry when the adaptive schedule ran: three planes (one digit coarser)
+  const double coarse = full_planes ? 1.0 : (double)(1 << SCAN_DIGIT_BITS);
+  auto ensure_rows = [&](int64_t rows) -> int {
+    const int64_t bpad = round_up(rows, 256);
+    if (!ctx->sel_geno || ctx->sel_geno->Mpad < bpad || ctx->sel_geno->N != g->N) {
+      if (ctx->sel_geno) { mmg_geno_destroy(ctx, ctx->sel_geno); ctx->sel_geno = nullptr; }
+      int rc = geno_create(ctx, bpad, g->N, &ctx->sel_geno, false);
+      if (rc) return rc;
+    }
+    return MMG_OK;
+  };
+  Scratch sc;
+  // ---- once per model: is the error model (independent roundings) true of THIS matrix?  64 SNPs spread over the store,
+  // the planes' den against the fp64 one.  A kinship of a dozen genotype classes passes the tile test of the adaptive schedule
+  // (the classes are interleaved) and is 100 x six sigma off: equal entries round alike.
+  if (!md.exact_checked) {
+    md.exact_checked = true;
+    const int64_t ns = std::min<int64_t>(64, g->M);
+    int rc = ensure_rows(ns);
+    if (rc) return rc;
+    double *Sd = nullptr, *part = nullptr;
+    MMG_HIP(ctx, sc.alloc(&Sd, (size_t)ns * N * sizeof(double)));
+    MMG_HIP(ctx, sc.alloc(&part, (size_t)ns * nJB * sizeof(double)));
+    MMG_HIP(ctx, hipMemsetAsync(res.scal + 3, 0, sizeof(unsigned long long), ctx->stream));
+    launch_scan_sample_idx(ctx, g->M, ns, res.idx);
+    launch_gather_rows(ctx, g, res.idx, ns, ctx->sel_geno->d);
+    launch_rows_to_f64(ctx, ctx->sel_geno->d, g->Npad, N, ns, Sd);
+    launch_scan_exact_den(ctx, Sd, N, ns, md.A64, part);
+    launch_scan_exact_check(ctx, res.idx, ns, part, N, res, sig_full * coarse, res.scal + 3);
+    unsigned long long rb = 0;
+    MMG_HIP(ctx, hipMemcpyAsync(&rb, res.scal + 3, sizeof(rb), hipMemcpyDeviceToHost, ctx->stream));
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double ratio;
+    std::memcpy(&ratio, &rb, sizeof(double));
+    if (ratio > 1.0) md.coherent = true;
+  }
+  MMG_HIP(ctx, hipMemsetAsync(res.scal + 3, 0, sizeof(unsigned long long), ctx->stream));
+  // independent roundings: a SNP the adaptive schedule left at three planes passed this very test at the coarser sigma, so the
+  // full-plane sigma is the one that can still flag anything (the refined ones); coherent: the bound of what each SNP carries
+  launch_scan_select_exact(ctx, res, g->M, sig_full, 0.5 * md.step * coarse, md.coherent, target, res.scal + 3, !f_free);
+  unsigned long long hc = 0;
+  MMG_HIP(ctx, hipMemcpyAsync(&hc, res.scal + 3, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int64_t cnt = (int64_t)hc;
+  if (cnt == 0) return MMG_OK;
+  static const double max_flop = [] { const char* e = std::getenv("MMG_SCAN_EXACT_MAX_FLOP"); return e ? std::atof(e) : 4e13; }();
+  if (2.0 * (double)cnt * md.N * md.N > max_flop) { res.n_exact = -1; return MMG_OK; }
+  const int64_t batch = std::max<int64_t>(8, std::min<int64_t>(cnt, ((int64_t)2 << 30) / ((int64_t)N * 8)));   // <= 2 GB of fp64 rows
+  { int rc = ensure_rows(batch); if (rc) return rc; }
+  double *Sd = nullptr, *part = nullptr;
+  MMG_HIP(ctx, sc.alloc(&Sd, (size_t)batch * N * sizeof(double)));
+  MMG_HIP(ctx, sc.alloc(&part, (size_t)batch * nJB * sizeof(double)));
+  for (int64_t b0 = 0; b0 < cnt; b0 += batch) {
+    const int64_t nb = std::min(batch, cnt - b0);
+    launch_gather_rows(ctx, g, res.idx + b0, nb, ctx->sel_geno->d);
+    launch_rows_to_f64(ctx, ctx->sel_geno->d, g->Npad, N, nb, Sd);
+    launch_scan_exact_den(ctx, Sd, N, nb, md.A64, part);
+    launch_scan_exact_apply(ctx, res.idx + b0, nb, part, N, res, h0_rss, df2);
+    MMG_HIP(ctx, hipGetLastError());
+  }
+  res.n_exact = cnt;
+  return MMG_OK;
+}
+
 // The scan of g against model md into res: all planes for an explicit digit count, else the adaptive schedule.
 // f_free: the refinement criterion ignores F (a quadratic form wanted for its own sake -- the permutation test's t.t --
 // is refined wherever six sigma of the first pass exceed `target` of the form itself); with_p: p-values at the end.
@@ -1443,14 +1526,20 @@ static int scan_into(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, mmg_sc
     if (lin) launch_scan_finalize_lin(ctx, g, md, res, h0_rss, df2, lnb, with_p, bias);
     else launch_scan_finalize(ctx, g, md, res, h0_rss, df2, lnb, with_p, bias);
   };
+  double target = 2.5e-7;                                  // a quarter of the 1e-6 bar on p
+  if (const char* e = std::getenv("MMG_SCAN_ADAPT_TARGET")) target = std::atof(e);
   if (!md.adaptive) {
     rc = run_scan_quad(ctx, g, md, res.q, EV_QUAD, linp);
     if (rc) return rc;
     MMG_HIP(ctx, hipGetLastError());
     {
       EvScope ev(ctx, EV_FIN);
-      finalize(with_p, 0.0);
+      finalize(false, 0.0);
     }
+    MMG_HIP(ctx, hipGetLastError());
+    rc = exact_tier(ctx, g, md, res, h0_rss, df2, f_free, target, true);
+    if (rc) return rc;
+    if (with_p && res.p && g->M > 0) launch_f_sf(ctx, res.F, g->M, df2, lnb, res.p);
     MMG_HIP(ctx, hipGetLastError());
     MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MMG_OK;
@@ -1463,8 +1552,6 @@ static int scan_into(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, mmg_sc
   // lowest plane added to the same exact integer in pass 2, which makes it bit-identical to a full 4-plane scan.
   // The refined SNPs double as a check of the error model: if any of them moved by more than its six-sigma
   // prediction, everything is redone with all planes.
-  double target = 2.5e-7;                                  // a quarter of the 1e-6 bar on p
-  if (const char* e = std::getenv("MMG_SCAN_ADAPT_TARGET")) target = std::atof(e);
   const double sig_unit = md.step * (double)(1 << SCAN_DIGIT_BITS) / std::sqrt(12.0) / std::sqrt(2.0);   // sigma = sig_unit * sum s^2
   mmg_scan_model hi = md, lo = md;                        // shallow copies with the schedule swapped
   hi.job_off = md.job_off_hi; hi.jobs = md.jobs_hi; hi.njobs = md.njobs_hi; hi.range = 1;
@@ -1526,6 +1613,8 @@ static int scan_into(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, mmg_sc
     res.fell_back = 1;
     finalize(false, 0.0);
   }
+  rc = exact_tier(ctx, g, md, res, h0_rss, df2, f_free, target, all);
+  if (rc) return rc;
   if (with_p && res.p && g->M > 0) launch_f_sf(ctx, res.F, g->M, df2, lnb, res.p);
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1554,6 +1643,13 @@ int mmg_scan_last_stats(mmg_ctx* ctx, int32_t* adaptive, int64_t* n_refined, dou
   if (eps_max) *eps_max = ctx->res.eps_max;
   if (sigma_ratio_max) *sigma_ratio_max = ctx->res.sigma_ratio_max;
   if (fell_back) *fell_back = ctx->res.fell_back;
+  return MMG_OK;
+}
+
+int mmg_scan_last_exact(mmg_ctx* ctx, int64_t* n_exact) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, n_exact != nullptr);
+  *n_exact = ctx->res.n_exact;
   return MMG_OK;
 }
 

@@ -307,6 +307,136 @@ __global__ void scan_refine_kernel(const int64_t* __restrict__ idx, int64_t cnt,
   }
 }
 
+// ---- the exact tier (round 4).  D digit planes carry 7 D - 1 bits of the LARGEST entry of the matrix, so den = s'As is good to
+// step / sqrt(24) * sum s^2 in absolute terms -- and a SNP that lies in the span of the kinship's large eigenvalues (few
+// distinct genotype vectors, population-structure markers) has a den that is orders of magnitude below sum s^2 * max |A|:
+// p moves by (F / 2 + 1) |d den| / den, 6e-6 at F = 7 on a kinship of 12 genotype classes with all four planes
+// (tools/random_parity2.py).  After the planes are in, a SNP whose six-sigma bound still exceeds the target is recomputed from
+// the fp64 matrix itself.  scan_select_exact_kernel: the same criterion as scan_select_kernel at the full-plane sigma, no sample.
+// coherent: the matrix failed the noise test of the adaptive schedule (blocks that are constant to the last digit: a kinship of a
+// few genotype classes) -- equal entries round the same way, the errors of a SNP's (sum s)^2 / 2 products add up instead of
+// averaging, and the bound is the worst case step / 2 per product, not six sigma of independent ones (measured: 100 x six sigma).
+__global__ void scan_select_exact_kernel(const double* __restrict__ F, const double* __restrict__ den,
+                                         const double* __restrict__ ssq, const double* __restrict__ sumv, int64_t M,
+                                         double sig_full, double half_step, int coherent, double target, int use_F,
+                                         int64_t* __restrict__ idx, unsigned long long* __restrict__ cnt) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const double d = den[m];
+  const double six_sigma = coherent ? half_step * 0.5 * fabs(sumv[m] * sumv[m] - ssq[m]) : 6.0 * sig_full * ssq[m];
+  const double Fm = use_F ? F[m] : 0.0;
+  const bool exact = !(d > 0.0) ? six_sigma > 0.0 : (0.5 * Fm + 1.0) * six_sigma > target * d;
+  if (exact) idx[atomicAdd(cnt, 1ull)] = m;
+}
+
+// Sd[i][c] = (double) Sc[i][c] for the gathered rows (N columns, ld N): the uniform operand of scan_exact_den_kernel
+__global__ void rows_to_f64_kernel(const int8_t* __restrict__ Sc, int32_t Npad, int32_t N, int64_t rows, double* __restrict__ Sd) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * N) return;
+  const int64_t i = e / N;
+  Sd[e] = (double)Sc[i * Npad + (e - i * N)];
+}
+
+// part[m][jb] = sum over the 256 columns j of block jb of s_mj (sum_i A_ij s_mi) for EX_SB gathered SNPs per workgroup: thread
+// t owns column j = 256 jb + t, walks the rows of A (coalesced over the threads), and the SNPs' values s_mi are the same for
+// every thread -- uniform loads (scalar cache) feeding v_fma_f64 as its SGPR operand, no LDS.  A is read once per EX_SB SNPs.
+constexpr int EX_SB = 8;
+__global__ __launch_bounds__(256) void scan_exact_den_kernel(const double* __restrict__ Sd, int32_t N, int64_t cnt,
+                                                             const double* __restrict__ A64, double* __restrict__ part, int nJB) {
+  const int tid = threadIdx.x, jb = blockIdx.x;
+  const int64_t m0 = (int64_t)blockIdx.y * EX_SB;
+  const int j = jb * 256 + tid;
+  const bool valid = j < N;
+  const int jc = valid ? j : N - 1;
+  double acc[EX_SB];
+#pragma unroll
+  for (int m = 0; m < EX_SB; ++m) acc[m] = 0.0;
+  const double* srow[EX_SB];
+#pragma unroll
+  for (int m = 0; m < EX_SB; ++m) srow[m] = Sd + (size_t)(m0 + m < cnt ? m0 + m : cnt - 1) * N;   // (rows past cnt: a valid row, result unused)
+#pragma unroll 4
+  for (int i = 0; i < N; ++i) {
+    const double a = A64[(size_t)i * N + jc];
+#pragma unroll
+    for (int m = 0; m < EX_SB; ++m) acc[m] = fma(a, srow[m][i], acc[m]);
+  }
+  __shared__ double red[4][EX_SB];
+#pragma unroll
+  for (int m = 0; m < EX_SB; ++m) {
+    double v = valid ? acc[m] * srow[m][jc] : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((tid & 63) == 0) red[tid >> 6][m] = v;
+  }
+  __syncthreads();
+  if (tid < EX_SB && m0 + tid < cnt) part[(size_t)(m0 + tid) * nJB + jb] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// den[idx[i]] = sum_jb part[i][jb] (fixed order: deterministic); rss and F as the finalize kernels compute them
+__global__ void scan_exact_apply_kernel(const int64_t* __restrict__ idx, int64_t cnt, const double* __restrict__ part, int nJB,
+                                        const double* __restrict__ dd, const double* __restrict__ dot, double h0_rss, double nu,
+                                        double* __restrict__ den, double* __restrict__ rss, double* __restrict__ Fst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  double d = 0.0;
+  for (int b = 0; b < nJB; ++b) d += part[(size_t)i * nJB + b];
+  const int64_t m = idx[i];
+  const double my_dd = dd[m], my_dw = dot[m];
+  double r = h0_rss;
+  if (d > 1e-7 * my_dd && d > 0.0) r = h0_rss - my_dw * my_dw / d;
+  den[m] = d;
+  rss[m] = r;
+  Fst[m] = (h0_rss / r - 1.0) * nu;
+}
+
+// The check behind the tier's error model: for a sample of gathered SNPs, |den from the planes - den from the fp64 matrix| over
+// the six-sigma bound of independent roundings.  max over the sample (bits of a non-negative double order like integers).
+__global__ void scan_exact_check_kernel(const int64_t* __restrict__ idx, int64_t cnt, const double* __restrict__ part, int nJB,
+                                        const double* __restrict__ den, const double* __restrict__ ssq, double sig_used,
+                                        unsigned long long* __restrict__ ratio_bits) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt) return;
+  double d = 0.0;
+  for (int b = 0; b < nJB; ++b) d += part[(size_t)i * nJB + b];
+  const int64_t m = idx[i];
+  const double six_sigma = 6.0 * sig_used * ssq[m];
+  if (six_sigma > 0.0) atomicMax(ratio_bits, (unsigned long long)__double_as_longlong(fabs(den[m] - d) / six_sigma));
+}
+__global__ void scan_sample_idx_kernel(int64_t M, int64_t cnt, int64_t* __restrict__ idx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cnt) idx[i] = i * M / cnt;
+}
+void launch_scan_sample_idx(mmg_ctx* ctx, int64_t M, int64_t cnt, int64_t* idx) {
+  hipLaunchKernelGGL(scan_sample_idx_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, M, cnt, idx);
+}
+void launch_scan_exact_check(mmg_ctx* ctx, const int64_t* idx, int64_t cnt, const double* part, int32_t N, const mmg_scan_result& res,
+                             double sig_used, unsigned long long* ratio_bits) {
+  hipLaunchKernelGGL(scan_exact_check_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, idx, cnt, part,
+                     (N + 255) / 256, res.den, res.ssq, sig_used, ratio_bits);
+}
+
+void launch_scan_select_exact(mmg_ctx* ctx, const mmg_scan_result& res, int64_t M, double sig_full, double half_step,
+                              bool coherent, double target, unsigned long long* cnt, bool use_F) {
+  hipLaunchKernelGGL(scan_select_exact_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, res.F, res.den,
+                     res.ssq, res.sum, M, sig_full, half_step, coherent ? 1 : 0, target, use_F ? 1 : 0, res.idx, cnt);
+}
+void launch_rows_to_f64(mmg_ctx* ctx, const int8_t* Sc, int32_t Npad, int32_t N, int64_t rows, double* Sd) {
+  const int64_t total = rows * N;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(rows_to_f64_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, Sc, Npad, N, rows, Sd);
+}
+void launch_scan_exact_den(mmg_ctx* ctx, const double* Sd, int32_t N, int64_t cnt, const double* A64, double* part) {
+  const int nJB = (N + 255) / 256;
+  hipLaunchKernelGGL(scan_exact_den_kernel, dim3((unsigned)nJB, (unsigned)((cnt + EX_SB - 1) / EX_SB)), dim3(256), 0, ctx->stream,
+                     Sd, N, cnt, A64, part, nJB);
+}
+void launch_scan_exact_apply(mmg_ctx* ctx, const int64_t* idx, int64_t cnt, const double* part, int32_t N, mmg_scan_result& res,
+                             double h0_rss, int32_t df2) {
+  if (cnt <= 0) return;
+  hipLaunchKernelGGL(scan_exact_apply_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, idx, cnt, part,
+                     (N + 255) / 256, res.dd, res.dot, h0_rss, (double)df2, res.den, res.rss, res.F);
+}
+
 void launch_scan_select(mmg_ctx* ctx, const mmg_scan_result& res, int64_t M, double sig_unit, double target,
                         unsigned long long* cnt, bool use_F) {
   hipLaunchKernelGGL(scan_select_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, res.F, res.den,

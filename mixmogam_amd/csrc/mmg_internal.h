@@ -33,6 +33,9 @@ enum { EV_KIN = 0, EV_QUAD = 1, EV_FIN = 2, EV_PERM = 3, EV_EIGH = 4, EV_PACK = 
 struct mmg_scan_model {
   int32_t N = 0, Npad = 0, D = 0;
   int8_t* Bq = nullptr;         // [D][Npad][Npad] digits of the strictly-lower triangle of 2A
+  double* A64 = nullptr;        // [N][N] the fp64 matrix itself, for the exact tier (api.hip:exact_tier); null: tier off
+  mutable bool coherent = false;   // rounding errors of equal entries add up (refused the adaptive schedule, or seen by the
+  mutable bool exact_checked = false;   // exact tier's sample check on the first scan of the model: api.hip:exact_tier)
   double* diag = nullptr;       // [Npad] diagonal of A (0 padded)
   double* w = nullptr;          // [Npad] (0 padded)
   double step = 0.0;            // den = step * (q' - offset * sum_{j>k} s_j s_k) + sum_i diag_i s_i^2
@@ -84,6 +87,7 @@ struct mmg_scan_result {
   int64_t n_refined = 0;
   double eps_max = 0.0, sigma_ratio_max = 0.0;
   int fell_back = 0, adaptive = 0;
+  int64_t n_exact = 0;           // SNPs recomputed from the fp64 matrix (exact tier); -1: wanted for more SNPs than its budget
 };
 
 struct mmg_ctx {
@@ -227,6 +231,15 @@ void launch_scan_finalize_lin(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, 
 void launch_scan_select(mmg_ctx*, const mmg_scan_result&, int64_t M, double sig_unit, double target, unsigned long long* cnt,
                         bool use_F = true);
 void launch_gather_rows(mmg_ctx*, const mmg_geno*, const int64_t* idx, int64_t cnt, int8_t* Sc);
+void launch_scan_select_exact(mmg_ctx*, const mmg_scan_result&, int64_t M, double sig_full, double half_step, bool coherent,
+                              double target, unsigned long long* cnt, bool use_F);
+void launch_rows_to_f64(mmg_ctx*, const int8_t* Sc, int32_t Npad, int32_t N, int64_t rows, double* Sd);
+void launch_scan_exact_den(mmg_ctx*, const double* Sd, int32_t N, int64_t cnt, const double* A64, double* part);
+void launch_scan_sample_idx(mmg_ctx*, int64_t M, int64_t cnt, int64_t* idx);
+void launch_scan_exact_check(mmg_ctx*, const int64_t* idx, int64_t cnt, const double* part, int32_t N, const mmg_scan_result&,
+                             double sig_used, unsigned long long* ratio_bits);
+void launch_scan_exact_apply(mmg_ctx*, const int64_t* idx, int64_t cnt, const double* part, int32_t N, mmg_scan_result&,
+                             double h0_rss, int32_t df2);
 void launch_scan_refine(mmg_ctx*, const int64_t* idx, int64_t cnt, const mmg_scan_model&, mmg_scan_result&,
                         const unsigned long long* q2, double sig_unit, double h0_rss, int32_t df2,
                         unsigned long long* eps_bits);

@@ -1106,13 +1106,40 @@ def emmax_multi(snps, phenotypes, K, cofactors=None, ctx=None, coll=None, max_st
     if q > 8:
         raise NotImplementedError("emmax_multi: at most 7 cofactors besides the intercept on the rotated path")
     eig_L = lmm0._get_eigen_L_()
-    models, d, omega, G = _multi_models(ys, X, eig_L, method=method)
-    h0 = np.array([m['h0_rss'] for m in models])
-    n_p = n - (q + 1)
     own = not isinstance(snps, _lib.Geno)
     if own:
         snps = kinship._as_snp_matrix(snps)
     M = snps.M if not own else len(snps)
+    lam = np.asarray(eig_L['values'], dtype=np.float64)
+    if coll is None and method == 'REML' and isinstance(ctx, _lib.Context) and \
+            int(np.sum(lam > 1e-9 * max(float(lam.max()), 1e-300))) < n // 2:
+        # A kinship of numerical rank below N / 2 (a handful of SNPs or of genotype classes): SNPs that lie in its span have
+        # quadratic forms far below what the 27-bit rows of the rotation carry (p off by 1.4e-6 at N = 263 on a kinship of two
+        # 0/1/2 SNPs, tools/random_parity.py).  The single-phenotype scan has an fp64 tier for exactly these SNPs
+        # (mmg_scan_last_exact), so such a kinship takes the loop the rotated path replaces -- with ONE eigendecomposition
+        # and one resident genotype store for all phenotypes.
+        g = ctx.geno(snps) if own else snps
+        try:
+            per = []
+            for p_ in range(P):
+                lmm_p = LinearMixedModel(ys[p_], ctx=ctx)
+                lmm_p.add_random_effect(K)
+                for cofactor in _cofactor_list(cofactors):
+                    lmm_p.add_factor(cofactor)
+                per.append(lmm_p.emmax_f_test(g, eig_L=eig_L, emma_num=0))
+        finally:
+            if own:
+                g.close()
+        res = {k: np.asarray([r_[k] for r_ in per]) for k in ('ps', 'f_stats', 'rss', 'var_perc')}
+        res['h0_rss'] = np.asarray([float(np.asarray(r_['h0_rss']).reshape(-1)[0]) for r_ in per])
+        res['h0_betas'] = [r_['h0_betas'] for r_ in per]
+        for k in ('pseudo_heritability', 've', 'vg', 'max_ll'):
+            res[k] = np.array([r_[k] for r_ in per])
+        res['delta'] = np.array([r_['delta'] if 'delta' in r_ else 1.0 / r_['pseudo_heritability'] - 1.0 for r_ in per])
+        return res
+    models, d, omega, G = _multi_models(ys, X, eig_L, method=method)
+    h0 = np.array([m['h0_rss'] for m in models])
+    n_p = n - (q + 1)
     rank, world = (coll.rank, coll.world) if coll is not None else (0, 1)
     from . import dist as mdist
     m0, m1 = mdist.shard_range(M, rank, world)

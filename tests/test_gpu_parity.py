@@ -678,10 +678,13 @@ def test_adaptive_digit_schedule(ctx, monkeypatch):
     ctx.scan_set_model(prep["A"], prep["w"], 4)
     full = ctx.scan(g, prep["h0_rss"], n - 3, stats=True)
     assert not ctx.scan_last_stats()["adaptive"]
+    # the digit planes on their own (round 4 adds an fp64 tier behind them: off for the bit-for-bit statements)
+    monkeypatch.setenv("MMG_SCAN_EXACT", "0")
     ctx.scan_set_model(prep["A"], prep["w"], 0)
     ada = ctx.scan(g, prep["h0_rss"], n - 3, stats=True)
     st = ctx.scan_last_stats()
     assert st["adaptive"] and not st["fell_back"] and 0 < st["n_refined"] < m // 2 and st["sigma_ratio_max"] < 1.0
+    assert st["n_exact"] == 0
     same = ada["den"] == full["den"]
     assert int(same.sum()) >= st["n_refined"] and same[18]
     for k in ("rss", "f_stats", "ps"):
@@ -692,6 +695,17 @@ def test_adaptive_digit_schedule(ctx, monkeypatch):
     everything = ctx.scan(g, prep["h0_rss"], n - 3, stats=True)
     assert ctx.scan_last_stats()["fell_back"]
     monkeypatch.delenv("MMG_SCAN_ADAPT_TARGET")
+    # ... and with the tier: the SNPs whose den four planes cannot pin down (the one collinear with the covariate among
+    # them) come from the fp64 matrix and sit on the oracle's values; everything else is what the planes gave
+    monkeypatch.delenv("MMG_SCAN_EXACT")
+    ctx.scan_set_model(prep["A"], prep["w"], 0)
+    tier = ctx.scan(g, prep["h0_rss"], n - 3, stats=True)
+    st2 = ctx.scan_last_stats()
+    moved = tier["den"] != ada["den"]
+    assert 0 < st2["n_exact"] < m // 4 and int(moved.sum()) <= st2["n_exact"] and moved[18]
+    assert np.max(np.abs(tier["den"][moved] - ref["den"][moved])) <= 1e-11 * ref["den"].max()
+    assert np.max(np.abs(tier["den"][moved] - ref["den"][moved])) <= np.max(np.abs(ada["den"][moved] - ref["den"][moved]))
+    assert rel(tier["ps"][ok], ref["ps"][ok]) < 1e-6
     monkeypatch.setenv("MMG_SCAN_ADAPTIVE", "0")
     ctx.scan_set_model(prep["A"], prep["w"], 0)
     off = ctx.scan(g, prep["h0_rss"], n - 3, stats=True)

@@ -300,3 +300,34 @@ def test_random_shapes_against_the_oracle():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "random_parity.py"), "40", "3"], capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and "failures: 0" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def test_scan_exact_tier_on_a_kinship_of_twelve_genotype_classes(ctx):
+    """Every individual is one of 12 genotype vectors: K has rank <= 12 and every SNP lies in its span, so den = s'P s is
+    orders of magnitude below sum s^2 max |P| -- what 27 bits of the LARGEST entry cannot resolve (p off by 6e-6 at F = 7 with
+    all four digit planes; tools/random_parity2.py found it).  Equal entries of P also round alike, so the errors of a SNP's
+    products add up instead of averaging: the tier's sample check must notice that the independent-roundings model is 100 x
+    off and switch to the worst-case bound.  With the tier: p <= 1e-6 of the oracle; the SNPs it recomputed are reported."""
+    from mixmogam_amd import kinship, linear_models as lm
+    from oracle import emmax_oracle as orc
+    rng = np.random.RandomState(5)
+    n, m = 1888, 2298
+    base = (rng.random_sample((m, 12)) < rng.uniform(0.05, 0.95, m)[:, None]).astype(np.int8)
+    snps = base[:, rng.randint(0, 12, n)]
+    snps = snps[snps.std(1) > 0]
+    y = rng.standard_normal(n) + 0.8 * snps[3] + 0.5 * snps[10]
+    K = kinship.calc_ibs_kinship(snps, ctx=ctx)
+    ref = orc.emmax(snps, y, K)
+    res = lm.emmax(snps, list(y), K, ctx=ctx)
+    st = ctx.scan_last_stats()
+    assert st["n_exact"] > len(snps) // 2, st
+    assert np.max(np.abs(res["ps"] / ref["ps"] - 1)) < 1e-6
+    wb = lm.emmax(snps, list(y), K, with_betas=True, ctx=ctx)             # the eigen route's model takes the same tier
+    assert np.max(np.abs(wb["ps"] / ref["ps"] - 1)) < 1e-6
+    # several phenotypes on such a kinship: the rotated path's 27-bit rows have the same limit; emmax_multi hands over to the
+    # per-phenotype scans (one eigendecomposition, one resident store)
+    ys = np.vstack([y, rng.standard_normal(n) + snps[7]])
+    mr = lm.emmax_multi(snps, ys, K, ctx=ctx)
+    mo = orc.emmax_multi(snps, ys, K)
+    assert np.max(np.abs(mr["ps"] / mo["ps"] - 1)) < 1e-6
+    assert np.max(np.abs(mr["pseudo_heritability"] - mo["pseudo_heritability"])) < 1e-6
