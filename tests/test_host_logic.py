@@ -547,3 +547,14 @@ def test_round4_surface_closures_against_the_reference_numbers():
     r4.emmax_multi_four_cofactors(FakeContext(), ex3, tol=1e-7)
     r4.ml_without_an_eigendecomposition(FakeContext(), ex, tol=1e-7)
     r4.ibd_kinship_from_normalised_snps(FakeContext())
+
+
+def test_random_shapes_through_the_host_mirror():
+    """tools/random_parity.py on the numpy stand-ins of the C ABI (tests/fake_ctx.py): the host side of kinship, emmax(),
+    linear_model() and emmax_multi() -- dispatch by size, REML search, cofactors, genotype alphabets -- on 40 random small
+    problems against the oracle.  (The GPU suite runs the same sweep on the device.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "random_parity.py"), "40", "3"], capture_output=True, text=True,
+                         timeout=600, env=dict(os.environ, MMG_PARITY_HOST="1"))
+    assert out.returncode == 0 and "failures: 0" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]

@@ -11,7 +11,12 @@ from mixmogam_amd import _lib, kinship, linear_models as lm
 from oracle import emmax_oracle as orc
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-ctx = _lib.get_context()
+if os.environ.get("MMG_PARITY_HOST"):                          # the host mirror alone (tests/fake_ctx.py: numpy stand-ins of the C ABI)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fake_ctx import FakeContext
+    ctx = FakeContext()
+else:
+    ctx = _lib.get_context()
 rng = np.random.RandomState(seed)
 worst = {}
 fails = 0
