@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Fifth randomised sweep: mlmm (the reference's multi-locus mixed model, :2543-2923) has golden cases only; here random data
+-- plain, with duplicated individuals, with planted effects -- run it on the device and on the host mirror
+(tests/fake_ctx.py: numpy stand-ins of the C ABI, every scan from H_sqrt_inv in float64) and the two must tell the same story:
+the same cofactors in the same order, the same criteria, p-values to 1e-6.  Checker only.
+    python tools/random_parity5.py [cases] [seed]"""
+import os, sys, traceback
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from mixmogam_amd import _lib, kinship, linear_models as lm
+from fake_ctx import FakeContext
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+ctx = _lib.get_context()
+fake = FakeContext()
+rng = np.random.RandomState(seed)
+fails = 0
+worst = 0.0
+for c in range(cases):
+    n = int(rng.choice([rng.randint(60, 250), rng.randint(256, 700)]))
+    m = int(rng.randint(100, 1500))
+    snps = (rng.random_sample((m, n)) < rng.uniform(0.1, 0.9, m)[:, None]).astype(np.int8)
+    kind = rng.choice(["plain", "duplicates"])
+    if kind == "duplicates":
+        dst = rng.choice(n, n // 5, replace=False)
+        snps[:, dst] = snps[:, rng.randint(0, n, n // 5)]
+    snps = snps[snps.std(1) > 0]
+    m = len(snps)
+    causal = rng.choice(m, 3, replace=False)
+    y = rng.standard_normal(n) + snps[causal].T @ np.array([1.2, 0.9, 0.6])
+    steps = int(rng.randint(2, 5))
+    what = "case %d: n=%d m=%d %s steps=%d" % (c, n, m, kind, steps)
+    try:
+        K = kinship.calc_ibs_kinship(snps, ctx=ctx)
+        kw = dict(snps=snps, positions=np.arange(m), chromosomes=np.ones(m, dtype=int), num_steps=steps)
+        a = lm.mlmm(list(y), K, ctx=ctx, **kw)
+        b = lm.mlmm(list(y), K, ctx=fake, **kw)
+        ca = [[t[1] for t in si["cofactors"]] for si in a["step_info_list"]]
+        cb = [[t[1] for t in si["cofactors"]] for si in b["step_info_list"]]
+        if ca != cb:
+            fails += 1
+            print("  FAIL cofactor paths differ  %s\n     device %s\n     host   %s" % (what, ca, cb), flush=True)
+            continue
+        for sa, sb in zip(a["step_info_list"], b["step_info_list"]):
+            for key in ("mbonf", "bic", "e_bic", "m_bic", "pseudo_heritability", "max_cof_pval", "min_pval"):
+                if key in sa and sa[key] is not None and sb[key] is not None and np.isfinite(sb[key]):
+                    d = abs(sa[key] - sb[key]) / max(abs(sb[key]), 1e-300 if "pval" in key or key == "mbonf" else 1.0)
+                    worst = max(worst, d)
+                    if d > (1e-5 if "pval" in key or key == "mbonf" else 1e-8):
+                        fails += 1
+                        print("  FAIL %s %.3e  %s (device %r host %r)" % (key, d, what, sa[key], sb[key]), flush=True)
+    except Exception as e:                                     # noqa: report and continue
+        fails += 1
+        print("  EXCEPTION %s: %s: %s" % (what, type(e).__name__, str(e)[:300]), flush=True)
+        traceback.print_exc(limit=4)
+print("worst relative difference over %d cases: %.2e" % (cases, worst))
+print("failures: %d" % fails)
+sys.exit(1 if fails else 0)
