@@ -135,7 +135,7 @@ __device__ __forceinline__ void g4_slice(v16i (&acc)[4][2][2], const OpsG4& cur,
                                          int dig_stride2, char* dst, int wave) {
   const uint32_t s32 = (uint32_t)(uintptr_t)src;
   const v16i zero = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  v4i m0, m1;
+  v4i m0 = v4i{0, 0, 0, 0}, m1 = v4i{0, 0, 0, 0};   // (dead stores outside the ablations that skip a mask)
   if (ABL != 2) wait_raw_g4(rin);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {

@@ -549,7 +549,7 @@ int run_kinship_grm4(mmg_ctx* ctx, const int8_t* S, int64_t ld, int32_t Npad, in
   while (jobs.size() % 256) jobs.push_back(KinJob{0, 0, 0, 0, 0, 0, 0, 0});
   KinJob* djobs = nullptr;
   { int rcj = job_buffer(ctx, jobs, &djobs); if (rcj) return rcj; }
-  int abl = 0;                                            // MMG_GRM4_ABL=1|2|3: timing ablations (wrong results)
+  int abl = 0;                                            // MMG_GRM4_ABL=1..7: timing ablations (wrong results; tools/grm4_abl.py)
   if (const char* e = std::getenv("MMG_GRM4_ABL")) abl = std::atoi(e);
 #define MMG_LAUNCH_G4(A)                                                                                                \
   do {                                                                                                                 \
