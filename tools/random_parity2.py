@@ -82,6 +82,13 @@ for c in range(cases):
             got = lm.emmax_perm_test(snps, list(y), K, num_perm=P, perm_idx=idx, H_sqrt_inv=est["H_sqrt_inv"], ctx=ctx)
             want = orc.perm_public(snps, y, np.ones((n, 1)), est["H_sqrt_inv"], idx, reference_indexing=False)
             note("perm max F", rel(got["max_f_stats"], want["max_f_stats"]), 1e-6, what + " P=%d" % P)
+        if rng.rand() < 0.5 and n <= 900:
+            ys = np.vstack([y, rng.standard_normal(n) + snps[rng.randint(m)], rng.standard_normal(n)])
+            os.environ.get("RP_VERBOSE") and print("   -> emmax_multi", flush=True)
+            mr = lm.emmax_multi(snps, ys, K, ctx=ctx)
+            mo = orc.emmax_multi(snps, ys, K)
+            okm = mo["ps"] > 1e-290
+            note("emmax_multi p", rel(np.asarray(mr["ps"])[okm], mo["ps"][okm]), 1e-6, what)
         if rng.rand() < 0.6:
             cuts = sorted(set([0, m] + list(rng.randint(1, m, 2))))
             tree = {"c%d" % i: {"raw_snps": snps[a:b], "freqs": snps[a:b].mean(1), "positions": np.arange(b - a)}
