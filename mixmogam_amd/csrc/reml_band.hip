@@ -780,6 +780,14 @@ static int band_reduce_cqr(mmg_ctx* ctx, mmg_reml* r, bool* suspect) {
     const int G = launch_gram_slices(st, Am, lda, Bm, ldb, kb, n, part2, 128);
     launch_gram_reduce(st, part2, G, out, 64);
   };
+  // MMG_BAND_GRAPH=1 (A/B): the whole panel loop -- ~16 dependent launches per panel, 1200 at N = 5000, none of them a
+  // library call -- captured into ONE hipGraph and replayed, instead of 1200 stream launches.  Measured at N = 5000
+  // (tools/reml_time.py): the host enqueues a launch in ~4 us and the kernels average 23 us, so the stream never
+  // waits for the host; what a panel costs is the dependent-kernel latency on the device, which a graph does not remove.
+  static const bool use_graph = [] { const char* e = std::getenv("MMG_BAND_GRAPH"); return e && e[0] == '1'; }();
+  const bool capture = use_graph && !verbose;
+  const auto t_cap0 = std::chrono::steady_clock::now();
+  if (capture) RC_HIP(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
   int64_t k0 = 0;
   for (; N - k0 - b >= 2; k0 += b) {
     auto tp = std::chrono::steady_clock::now();
@@ -819,6 +827,23 @@ static int band_reduce_cqr(mmg_ctx* ctx, mmg_reml* r, bool* suspect) {
     // ---- A22 -= V Y' + Y V' (lower tiles)
     launch_nt_update_lower(st, A22, N, n, V, Y, Y, V, n, n);
     lap(3, tp);
+  }
+  if (capture) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    RC_HIP(ctx, hipStreamEndCapture(st, &graph));
+    const auto t_cap1 = std::chrono::steady_clock::now();
+    RC_HIP(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    const auto t_cap2 = std::chrono::steady_clock::now();
+    RC_HIP(ctx, hipGraphLaunch(exec, st));
+    RC_HIP(ctx, hipStreamSynchronize(st));
+    const auto t_cap3 = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) { return std::chrono::duration<double>(b2 - a).count() * 1e3; };
+    if (std::getenv("MMG_BAND_GRAPH_VERBOSE"))
+      fprintf(stderr, "[reml] N=%lld: band reduction as a hipGraph: capture %.2f ms, instantiate %.2f ms, launch + run %.2f ms\n", (long long)N,
+              ms(t_cap0, t_cap1), ms(t_cap1, t_cap2), ms(t_cap2, t_cap3));
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
   }
   RC_HIP(ctx, hipGetLastError());
   PanelFlags hf;
