@@ -805,6 +805,8 @@ class LinearMixedModel(object):
                 if _reml is None:
                     reml.close()
         if prep is None:
+            if callable(H_sqrt_inv):                                     # a caller that holds delta and eig_L, not the matrix (mlmm)
+                H_sqrt_inv = H_sqrt_inv()
             prep = self.scan_prepare(H_sqrt_inv, Z=Z, with_betas=with_betas)
         own = not isinstance(snps, _lib.Geno)
         g = ctx.geno(kinship._as_snp_matrix(snps)) if own else snps
@@ -1298,10 +1300,19 @@ def mlmm(phenotypes, K, sd=None, num_steps=10, forward_backwards=True, sign_thre
         return reml_res['delta'] if (DEVICE_SCAN_MODEL and isinstance(ctx, _lib.Context)) else None
 
     def reestimate():
-        # get_REML / get_ML use 100 grid points; no eig_R: every step would need a fresh N^3 eigh for its X
-        reml = lmm.get_estimates(eig_L, method='REML', ngrids=100)
-        ml = lmm.get_estimates(eig_L, method='ML', ngrids=100)
+        # get_REML / get_ML use 100 grid points; no eig_R: every step would need a fresh N^3 eigh for its X.
+        # H_sqrt_inv (N x N, 0.07 s per estimate at N = 5000: half of an mlmm step) is formed only where a scan needs it
+        # (lazy_H): with the scan model built on the device from delta that is the indefinite-kinship fallback alone
+        device = DEVICE_SCAN_MODEL and isinstance(ctx, _lib.Context)
+        reml = lmm.get_estimates(eig_L, method='REML', ngrids=100, return_H=not device)
+        ml = lmm.get_estimates(eig_L, method='ML', ngrids=100, return_H=False)
         return reml, ml
+
+    def lazy_H():
+        if reml_res.get('H_sqrt_inv') is None:
+            wts = 1.0 / np.sqrt(np.asarray(eig_L['values'], dtype=np.float64) + reml_res['delta'])   # :898
+            reml_res['H_sqrt_inv'] = wts[:, None] * np.asarray(eig_L['vectors'])
+        return reml_res['H_sqrt_inv']
 
     def cofactor_stats():
         pvals, ppas, fstats = [], [], []
@@ -1320,7 +1331,7 @@ def mlmm(phenotypes, K, sd=None, num_steps=10, forward_backwards=True, sign_thre
         num_pher_0 = 0
         eig_L = lmm._get_eigen_L_()
         reml_res, ml_res = reestimate()
-        H_sqrt_inv = reml_res['H_sqrt_inv']
+        H_sqrt_inv = lazy_H
         ll, rss = ml_res['max_ll'], float(reml_res['rss'])
         criterias = {'ebics': [], 'mbics': [], 'bonf': [], 'mbonf': []}
         bic, extended_bic, modified_bic = _calc_bic_(ll, num_snps, num_par, lmm.n)
@@ -1357,7 +1368,7 @@ def mlmm(phenotypes, K, sd=None, num_steps=10, forward_backwards=True, sign_thre
             lmm.add_factor(all_snps[gid])                                # :2686
             cofactor_ids.append(gid)
             reml_res, ml_res = reestimate()
-            H_sqrt_inv = reml_res['H_sqrt_inv']
+            H_sqrt_inv = lazy_H
             ll, rss = ml_res['max_ll'], float(reml_res['rss'])
             num_par += 1
             cof_snp_priors.append(all_priors[gid])
@@ -1397,7 +1408,7 @@ def mlmm(phenotypes, K, sd=None, num_steps=10, forward_backwards=True, sign_thre
                 num_snps += 1
                 reml_res, ml_res = reestimate()
                 ll, rss = ml_res['max_ll'], float(reml_res['rss'])
-                H_sqrt_inv = reml_res['H_sqrt_inv']
+                H_sqrt_inv = lazy_H
                 num_par -= 1
                 pvals, ppas, _f = cofactor_stats()
                 for i, pv in enumerate(pvals):

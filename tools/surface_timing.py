@@ -8,7 +8,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mixmogam_amd import _lib, kinship, linear_models as lm
 ctx = _lib.get_context()
 prof = sys.argv[sys.argv.index("--profile") + 1].split(",") if "--profile" in sys.argv else []
-for n, m in ((199, 214000), (1000, 500000)):
+shapes = [(199, 214000), (1000, 500000)]
+if "--big" in sys.argv:
+    shapes = [(5000, 200000)]
+for n, m in shapes:
     rng = np.random.RandomState(n)
     freq = rng.uniform(0.1, 0.9, m)
     snps = (rng.random_sample((m, n)) < freq[:, None]).astype(np.int8)
