@@ -117,6 +117,12 @@ int mmg_geno_matvec(mmg_ctx* ctx, mmg_geno* g, const double* V, int32_t nv, doub
  * C_out: host int64 [N x N].  Bit-exact with kinship.py:43-44 (whose entries are exact
  * integers carried in float64). */
 int mmg_kinship_ibs_i8(mmg_ctx* ctx, mmg_geno* g, int64_t* C_out);
+/* The IBS kinship itself (kinship.py:44-51): K = counts / (2 m_total) + 0.5 from the exact counts, scaled != 0: times
+ * (N - 1) / (tr K - sum K / N) (scale_k, :94-100), converted and scaled in HBM -- one download of N^2 doubles instead of the
+ * int64 counts and three host passes over the matrix (50 of 92 ms of calc_ibs_kinship at N = 5000).  comm != NULL: the counts
+ * of all ranks' SNP blocks (m_total = their SNPs together) are summed in HBM first.  The unscaled matrix is bit-identical to
+ * the host expression; the scaled one differs from kinship.scale_k by summation order (1e-16). */
+int mmg_kinship_ibs_f64(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int64_t m_total, int32_t scaled, double* K_out);
 /* Indicator co-occurrence counts C = U U^T, U = [s >= thr] (exact, same kernel).  Two calls
  * (thr = 1, 2) give the 'diploid_int' IBS kinship of kinship.py:33-41:
  * sum_m |a_m - b_m| = r_a + r_b - 2 (C1_ab + C2_ab), r = diag(C1 + C2). */

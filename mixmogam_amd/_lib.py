@@ -94,6 +94,7 @@ PROTOTYPES = {
     "mmg_emmax_scan_multi": (C.c_int, [c_vp, c_vp, C.c_int32, C.c_int32, c_vp, c_vp, c_vp, c_vp, C.c_int32,
                                        c_vp, c_vp, c_vp]),
     "mmg_kinship_ibs_i8_sharded": (C.c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "mmg_kinship_ibs_f64": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int32, c_vp]),
     "mmg_kin_acc_allreduce": (C.c_int, [c_vp, c_vp, c_vp]),
     "mmg_emmax_perm_sharded": (C.c_int, [c_vp, c_vp, c_vp, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, C.c_int,
                                          c_vp]),
@@ -564,6 +565,14 @@ class Context(object):
         """comm: RCCL communicator handle -- the counts then cover the SNP blocks of all ranks (summed in HBM)."""
         out = np.empty((g.N, g.N), dtype=np.int64)
         self._check(self.lib.mmg_kinship_ibs_i8_sharded(self.h, comm, g.h, _ptr(out)))
+        return out
+
+    def kinship_ibs(self, g, scaled=True, comm=None, m_total=None):
+        """The IBS kinship counts / (2 M) + 0.5 (scale_k'd when scaled) converted and scaled on the device
+        (mmg_kinship_ibs_f64); comm / m_total: all ranks' SNP blocks."""
+        out = np.empty((g.N, g.N), dtype=np.float64)
+        self._check(self.lib.mmg_kinship_ibs_f64(self.h, comm, g.h, int(g.M if m_total is None else m_total), 1 if scaled else 0,
+                                                 _ptr(out)))
         return out
 
     def kinship_indicator_counts(self, g, thr):

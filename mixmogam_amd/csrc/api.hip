@@ -521,8 +521,10 @@ static int64_t kin_chunk() {
   return std::min<int64_t>(ch, MAX_LD / 128 * 128);
 }
 
+// f64: the IBS kinship itself instead of the counts (mmg_kinship_ibs_f64): K = counts / (2 m_total) + 0.5, scale_k on request
+struct IbsF64 { double* K_out; int64_t m_total; bool scaled; };
 static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int thr, int64_t* C_out,
-                             mmg_comm* comm = nullptr);
+                             mmg_comm* comm = nullptr, const IbsF64* f64 = nullptr);
 
 int mmg_kinship_ibs_i8(mmg_ctx* ctx, mmg_geno* g, int64_t* C_out) {
   return kinship_counts_i8(ctx, g, 2, -1, 0, C_out);    // X = 2S - 1 (kinship.py:43)
@@ -538,10 +540,10 @@ int mmg_kinship_indicator_i8(mmg_ctx* ctx, mmg_geno* g, int32_t thr, int64_t* C_
   return kinship_counts_i8(ctx, g, 0, 0, thr, C_out);   // X = [S >= thr]
 }
 
-static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int thr, int64_t* C_out, mmg_comm* comm) {
+static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int thr, int64_t* C_out, mmg_comm* comm, const IbsF64* f64) {
   Scratch sc;
   MMG_ENTER(ctx);
-  MMG_CHECK_ARG(ctx, g && C_out && g->M > 0);
+  MMG_CHECK_ARG(ctx, g && (C_out || (f64 && f64->K_out)) && g->M > 0);
   // IBS (X = 2S - 1, kinship.py:43) runs on the RAW genotypes: X X' = 4 S S' - 2 (r 1' + 1 r') + M with r the column
   // sums of S -- the same exact integers, but the GEMM operands are 0/1 bytes instead of +-1: the matrix pipe draws
   // less power on mostly-zero operands and the power-limited chip clocks higher (measured at N = 5000, M = 1e6:
@@ -673,11 +675,42 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
       ncclResult_t r = ncclAllReduce(C64, C64, (size_t)g->N * g->N, ncclInt64, ncclSum, comm->comm, ctx->stream);
       if (r != ncclSuccess) return set_err(ctx, MMG_E_LIB, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
     }
+    if (f64) {
+      // the kinship leaves the device as the matrix the caller wants: conversion and scale_k's rule (kinship.py:94-100; the
+      // sums of mmg_kin_acc_scale_k) in HBM instead of three host passes over N^2 doubles
+      const int64_t N = g->N;
+      double *dK = nullptr, *drow = nullptr;
+      MMG_HIP(ctx, sc.alloc(&dK, (size_t)N * N * sizeof(double)));
+      launch_ibs_counts_to_f64(ctx, C64, N * N, 2.0 * (double)f64->m_total, dK);
+      if (f64->scaled) {
+        MMG_HIP(ctx, sc.alloc(&drow, 2 * N * sizeof(double)));
+        launch_row_sums_f64(ctx, dK, N, drow, drow + N);
+        std::vector<double> hsum((size_t)2 * N);
+        MMG_HIP(ctx, hipMemcpyAsync(hsum.data(), drow, 2 * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        double total = 0.0, trace = 0.0;
+        for (int64_t i = 0; i < N; ++i) { total += hsum[i]; trace += hsum[N + i]; }
+        const double c = trace - total / (double)N;
+        if (!(c > 0.0) || !std::isfinite(c)) return set_err(ctx, MMG_E_ARG, "scale_k: tr K - sum K / N is not positive");
+        launch_scale_f64(ctx, dK, N * N, (double)(N - 1) / c);
+      }
+      hipError_t e3 = hipMemcpyAsync(f64->K_out, dK, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+      if (e3 == hipSuccess) e3 = hipStreamSynchronize(ctx->stream);
+      if (e3 != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e3));
+      return rc;
+    }
     hipError_t e2 = hipMemcpyAsync(C_out, C64, (size_t)g->N * g->N * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
     if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
     if (e2 != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e2));
   }
   return rc;
+}
+
+int mmg_kinship_ibs_f64(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int64_t m_total, int32_t scaled, double* K_out) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, g && K_out && m_total >= g->M);
+  const IbsF64 f{K_out, m_total, scaled != 0};
+  return kinship_counts_i8(ctx, g, 2, -1, 0, nullptr, comm, &f);
 }
 
 // dC [N x N] (device, fp64) (+)= sum_m x_m x_m', x_m = scale[m] s_m + shift[m]

@@ -357,6 +357,15 @@ void launch_reduce_slabs(mmg_ctx* ctx, const float* slabs, int ksplit, int32_t N
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                      slabs, ksplit, Npad, N, C, accumulate);
 }
+// K[e] = counts[e] / (2 M) + 0.5 (kinship.py:44-46 on the exact counts): the same two IEEE operations the host mirror does
+__global__ void ibs_counts_to_f64_kernel(const int64_t* __restrict__ C, int64_t n, double two_m, double* __restrict__ K) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) K[e] = (double)C[e] / two_m + 0.5;
+}
+void launch_ibs_counts_to_f64(mmg_ctx* ctx, const int64_t* C, int64_t n, double two_m, double* K) {
+  hipLaunchKernelGGL(ibs_counts_to_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, C, n, two_m, K);
+}
+
 void launch_mirror_i32_to_i64(mmg_ctx* ctx, const int* C32, int32_t Npad, int32_t N, int64_t* C) {
   const int64_t total = (int64_t)N * N;
   hipLaunchKernelGGL(mirror_i32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, C32,

@@ -80,6 +80,11 @@ def calc_ibs_kinship(snps, snps_data_format='binary', snp_dtype='int8', dtype='s
             np.fill_diagonal(k_mat, 0.0)                   # the reference only fills i != j (:34-41)
             k_mat = k_mat / float(num_snps) + np.eye(g.N)  # :51
             return scale_k(k_mat) if scaled else k_mat
+        if g.N > 2048 and hasattr(ctx, 'kinship_ibs'):
+            # counts -> K -> scale_k in HBM, one download of doubles (mmg_kinship_ibs_f64): the host passes over N^2 values cost
+            # more than the exact-count GEMM (50 of 92 ms at N = 5000 on 256 cores, seconds on a laptop's).  Below 2049 the
+            # host keeps the reference's own expression of scale_k (bit for bit; 13 ms at N = 1000)
+            return ctx.kinship_ibs(g, scaled=scaled)
         counts = ctx.kinship_ibs_counts(g)
     finally:
         if own:
@@ -104,6 +109,11 @@ def calc_ibd_kinship(snps, dtype='single', scaled=True, ctx=None, geno=None):
         acc = ctx.kinship_accumulator(g.N)
         try:
             acc.add_grm(g)
+            if scaled and g.N > 2048 and hasattr(acc, 'scale_k'):
+                # scale_k(K / n) = scale_k(K): scaled where the sum lies, one download (as hdf5_data._ibd_kinship does);
+                # below 2049 individuals the host keeps the reference's own expression of scale_k
+                acc.scale_k()
+                return acc.fetch()[0]
             k_mat, num_snps = acc.fetch()
         finally:
             acc.close()

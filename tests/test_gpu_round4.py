@@ -331,3 +331,23 @@ def test_scan_exact_tier_on_a_kinship_of_twelve_genotype_classes(ctx):
     mo = orc.emmax_multi(snps, ys, K)
     assert np.max(np.abs(mr["ps"] / mo["ps"] - 1)) < 1e-6
     assert np.max(np.abs(mr["pseudo_heritability"] - mo["pseudo_heritability"])) < 1e-6
+
+
+def test_ibs_kinship_converted_and_scaled_on_the_device(ctx):
+    """mmg_kinship_ibs_f64 (calc_ibs_kinship above 2048 individuals): unscaled, bit for bit the host expression on the exact
+    counts; scaled, kinship.scale_k to rounding."""
+    from mixmogam_amd import kinship
+    rng = np.random.RandomState(9)
+    n, m = 2500, 3000
+    snps = (rng.random_sample((m, n)) < rng.uniform(0.1, 0.9, m)[:, None]).astype(np.int8)
+    g = ctx.geno(snps)
+    try:
+        counts = ctx.kinship_ibs_counts(g)
+        host = counts.astype(np.float64) / (2 * float(m)) + 0.5
+        assert np.array_equal(ctx.kinship_ibs(g, scaled=False), host)
+        want = kinship.scale_k(host)
+        got = ctx.kinship_ibs(g, scaled=True)
+        assert np.max(np.abs(got - want)) <= 1e-13 * np.max(np.abs(want))
+        assert np.array_equal(kinship.calc_ibs_kinship(None, ctx=ctx, geno=g), got)
+    finally:
+        g.close()
