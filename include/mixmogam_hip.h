@@ -123,6 +123,10 @@ int mmg_kinship_ibs_i8(mmg_ctx* ctx, mmg_geno* g, int64_t* C_out);
  * of all ranks' SNP blocks (m_total = their SNPs together) are summed in HBM first.  The unscaled matrix is bit-identical to
  * the host expression; the scaled one differs from kinship.scale_k by summation order (1e-16). */
 int mmg_kinship_ibs_f64(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int64_t m_total, int32_t scaled, double* K_out);
+/* The same for 0/1/2 genotypes ('diploid_int', kinship.py:33-41,51): k_ij = (M - 1/2 sum_m |a_m - b_m|) / M off the diagonal,
+ * 1 on it, from two exact indicator products ([s >= 1], [s >= 2]: |a - b| = a + b - 2 min(a, b)), combined and -- scaled != 0 --
+ * scale_k'd in HBM. */
+int mmg_kinship_ibs_diploid_f64(mmg_ctx* ctx, mmg_geno* g, int32_t scaled, double* K_out);
 /* Indicator co-occurrence counts C = U U^T, U = [s >= thr] (exact, same kernel).  Two calls
  * (thr = 1, 2) give the 'diploid_int' IBS kinship of kinship.py:33-41:
  * sum_m |a_m - b_m| = r_a + r_b - 2 (C1_ab + C2_ab), r = diag(C1 + C2). */

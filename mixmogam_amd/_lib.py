@@ -95,6 +95,7 @@ PROTOTYPES = {
                                        c_vp, c_vp, c_vp]),
     "mmg_kinship_ibs_i8_sharded": (C.c_int, [c_vp, c_vp, c_vp, c_vp]),
     "mmg_kinship_ibs_f64": (C.c_int, [c_vp, c_vp, c_vp, C.c_int64, C.c_int32, c_vp]),
+    "mmg_kinship_ibs_diploid_f64": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp]),
     "mmg_kin_acc_allreduce": (C.c_int, [c_vp, c_vp, c_vp]),
     "mmg_emmax_perm_sharded": (C.c_int, [c_vp, c_vp, c_vp, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, C.c_int,
                                          c_vp]),
@@ -573,6 +574,12 @@ class Context(object):
         out = np.empty((g.N, g.N), dtype=np.float64)
         self._check(self.lib.mmg_kinship_ibs_f64(self.h, comm, g.h, int(g.M if m_total is None else m_total), 1 if scaled else 0,
                                                  _ptr(out)))
+        return out
+
+    def kinship_ibs_diploid(self, g, scaled=True):
+        """'diploid_int' IBS kinship of a 0/1/2 store, combined and scaled on the device (mmg_kinship_ibs_diploid_f64)."""
+        out = np.empty((g.N, g.N), dtype=np.float64)
+        self._check(self.lib.mmg_kinship_ibs_diploid_f64(self.h, g.h, 1 if scaled else 0, _ptr(out)))
         return out
 
     def kinship_indicator_counts(self, g, thr):

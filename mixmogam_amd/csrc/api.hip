@@ -522,7 +522,7 @@ static int64_t kin_chunk() {
 }
 
 // f64: the IBS kinship itself instead of the counts (mmg_kinship_ibs_f64): K = counts / (2 m_total) + 0.5, scale_k on request
-struct IbsF64 { double* K_out; int64_t m_total; bool scaled; };
+struct IbsF64 { double* K_out; int64_t m_total; bool scaled; int64_t* dev64 = nullptr; };   // dev64: the counts stay in HBM (device buffer)
 static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int thr, int64_t* C_out,
                              mmg_comm* comm = nullptr, const IbsF64* f64 = nullptr);
 
@@ -543,7 +543,7 @@ int mmg_kinship_indicator_i8(mmg_ctx* ctx, mmg_geno* g, int32_t thr, int64_t* C_
 static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int thr, int64_t* C_out, mmg_comm* comm, const IbsF64* f64) {
   Scratch sc;
   MMG_ENTER(ctx);
-  MMG_CHECK_ARG(ctx, g && (C_out || (f64 && f64->K_out)) && g->M > 0);
+  MMG_CHECK_ARG(ctx, g && (C_out || (f64 && (f64->K_out || f64->dev64))) && g->M > 0);
   // IBS (X = 2S - 1, kinship.py:43) runs on the RAW genotypes: X X' = 4 S S' - 2 (r 1' + 1 r') + M with r the column
   // sums of S -- the same exact integers, but the GEMM operands are 0/1 bytes instead of +-1: the matrix pipe draws
   // less power on mostly-zero operands and the power-limited chip clocks higher (measured at N = 5000, M = 1e6:
@@ -675,6 +675,11 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
       ncclResult_t r = ncclAllReduce(C64, C64, (size_t)g->N * g->N, ncclInt64, ncclSum, comm->comm, ctx->stream);
       if (r != ncclSuccess) return set_err(ctx, MMG_E_LIB, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
     }
+    if (f64 && f64->dev64) {
+      MMG_HIP(ctx, hipMemcpyAsync(f64->dev64, C64, (size_t)g->N * g->N * sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+      MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      return rc;
+    }
     if (f64) {
       // the kinship leaves the device as the matrix the caller wants: conversion and scale_k's rule (kinship.py:94-100; the
       // sums of mmg_kin_acc_scale_k) in HBM instead of three host passes over N^2 doubles
@@ -704,6 +709,51 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
     if (e2 != hipSuccess) rc = set_err(ctx, MMG_E_HIP, hipGetErrorString(e2));
   }
   return rc;
+}
+
+// scale_k's rule on a device-resident N x N matrix, then its download
+static int scale_and_fetch(mmg_ctx* ctx, double* dK, int64_t N, bool scaled, double* K_out) {
+  if (scaled) {
+    Scratch sc;
+    double* drow = nullptr;
+    MMG_HIP(ctx, sc.alloc(&drow, 2 * N * sizeof(double)));
+    launch_row_sums_f64(ctx, dK, N, drow, drow + N);
+    std::vector<double> hsum((size_t)2 * N);
+    MMG_HIP(ctx, hipMemcpyAsync(hsum.data(), drow, 2 * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double total = 0.0, trace = 0.0;
+    for (int64_t i = 0; i < N; ++i) { total += hsum[i]; trace += hsum[N + i]; }
+    const double c = trace - total / (double)N;
+    if (!(c > 0.0) || !std::isfinite(c)) return set_err(ctx, MMG_E_ARG, "scale_k: tr K - sum K / N is not positive");
+    launch_scale_f64(ctx, dK, N * N, (double)(N - 1) / c);
+  }
+  MMG_HIP(ctx, hipMemcpyAsync(K_out, dK, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MMG_OK;
+}
+
+// 'diploid_int' IBS (kinship.py:33-41,51): k_ij = (M - 1/2 sum_m |a_m - b_m|) / M off the diagonal, 1 on it;
+// |a - b| = a + b - 2 min(a, b), min(a, b) = [a >= 1][b >= 1] + [a >= 2][b >= 2] for 0/1/2: two exact indicator products, their
+// sum c12 with diagonal r, combined and scaled in HBM
+int mmg_kinship_ibs_diploid_f64(mmg_ctx* ctx, mmg_geno* g, int32_t scaled, double* K_out) {
+  Scratch sc;
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, g && K_out && g->M > 0);
+  const int64_t N = g->N;
+  int64_t *c1 = nullptr, *c2 = nullptr;
+  double* dK = nullptr;
+  MMG_HIP(ctx, sc.alloc(&c1, (size_t)N * N * sizeof(int64_t)));
+  MMG_HIP(ctx, sc.alloc(&c2, (size_t)N * N * sizeof(int64_t)));
+  MMG_HIP(ctx, sc.alloc(&dK, (size_t)N * N * sizeof(double)));
+  IbsF64 f{nullptr, g->M, false, c1};
+  int rc = kinship_counts_i8(ctx, g, 0, 0, 1, nullptr, nullptr, &f);
+  if (rc) return rc;
+  f.dev64 = c2;
+  rc = kinship_counts_i8(ctx, g, 0, 0, 2, nullptr, nullptr, &f);
+  if (rc) return rc;
+  launch_ibs_diploid_combine(ctx, c1, c2, N, (double)g->M, dK);
+  MMG_HIP(ctx, hipGetLastError());
+  return scale_and_fetch(ctx, dK, N, scaled != 0, K_out);
 }
 
 int mmg_kinship_ibs_f64(mmg_ctx* ctx, mmg_comm* comm, mmg_geno* g, int64_t m_total, int32_t scaled, double* K_out) {

@@ -362,6 +362,23 @@ __global__ void ibs_counts_to_f64_kernel(const int64_t* __restrict__ C, int64_t 
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < n) K[e] = (double)C[e] / two_m + 0.5;
 }
+// K_ij = 1 - (r_i + r_j - 2 c12_ij) / (2 M) off the diagonal (= (M - 1/2 sum |a - b|) / M, evaluated as the host mirror does:
+// M - 0.5 * absdiff, then / M), 1 on it; c12 = c1 + c2, r its diagonal
+__global__ void ibs_diploid_combine_kernel(const int64_t* __restrict__ c1, const int64_t* __restrict__ c2, int64_t N, double M,
+                                           double* __restrict__ K) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * N) return;
+  const int64_t i = e / N, j = e - i * N;
+  if (i == j) { K[e] = 1.0; return; }
+  const double c12 = (double)(c1[e] + c2[e]);
+  const double ri = (double)(c1[i * N + i] + c2[i * N + i]), rj = (double)(c1[j * N + j] + c2[j * N + j]);
+  const double absdiff = ri + rj - 2.0 * c12;
+  K[e] = (M - 0.5 * absdiff) / M;
+}
+void launch_ibs_diploid_combine(mmg_ctx* ctx, const int64_t* c1, const int64_t* c2, int64_t N, double M, double* K) {
+  hipLaunchKernelGGL(ibs_diploid_combine_kernel, dim3((unsigned)((N * N + 255) / 256)), dim3(256), 0, ctx->stream, c1, c2, N, M, K);
+}
+
 void launch_ibs_counts_to_f64(mmg_ctx* ctx, const int64_t* C, int64_t n, double two_m, double* K) {
   hipLaunchKernelGGL(ibs_counts_to_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, C, n, two_m, K);
 }

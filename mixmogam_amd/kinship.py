@@ -73,6 +73,8 @@ def calc_ibs_kinship(snps, snps_data_format='binary', snp_dtype='int8', dtype='s
             # kinship.py:33-41: k_ij = #(|a-b| = 0) + 0.5 #(|a-b| = 1) = M - 0.5 sum_m |a_m - b_m| for
             # 0/1/2 genotypes; |a-b| = a + b - 2 min(a,b) and min(a,b) = [a>=1][b>=1] + [a>=2][b>=2]:
             # two exact indicator GEMMs on the int8 matrix cores replace the O(N^2 M) bincount loop.
+            if g.N > 2048 and hasattr(ctx, 'kinship_ibs_diploid'):
+                return ctx.kinship_ibs_diploid(g, scaled=scaled)         # the same arithmetic in HBM (see the binary case below)
             c12 = ctx.kinship_indicator_counts(g, 1) + ctx.kinship_indicator_counts(g, 2)
             r = np.diag(c12).astype(np.float64)
             absdiff = r[:, None] + r[None, :] - 2.0 * c12

@@ -351,3 +351,26 @@ def test_ibs_kinship_converted_and_scaled_on_the_device(ctx):
         assert np.array_equal(kinship.calc_ibs_kinship(None, ctx=ctx, geno=g), got)
     finally:
         g.close()
+
+
+def test_diploid_ibs_kinship_combined_on_the_device(ctx):
+    """mmg_kinship_ibs_diploid_f64 (calc_ibs_kinship(snps_data_format='diploid_int') above 2048 individuals) against the host
+    mirror's arithmetic on the two indicator products: unscaled bit for bit, scaled to rounding."""
+    from mixmogam_amd import kinship
+    rng = np.random.RandomState(10)
+    n, m = 2300, 1500
+    f = rng.uniform(0.1, 0.9, m)
+    snps = ((rng.random_sample((m, n)) < f[:, None]).astype(np.int8) + (rng.random_sample((m, n)) < f[:, None]).astype(np.int8))
+    g = ctx.geno(snps)
+    try:
+        c12 = ctx.kinship_indicator_counts(g, 1) + ctx.kinship_indicator_counts(g, 2)
+        r = np.diag(c12).astype(np.float64)
+        k = float(m) - 0.5 * (r[:, None] + r[None, :] - 2.0 * c12)
+        np.fill_diagonal(k, 0.0)
+        k = k / float(m) + np.eye(n)
+        assert np.array_equal(ctx.kinship_ibs_diploid(g, scaled=False), k)
+        want = kinship.scale_k(k)
+        got = kinship.calc_ibs_kinship(None, snps_data_format='diploid_int', ctx=ctx, geno=g)
+        assert np.max(np.abs(got - want)) <= 1e-13 * np.max(np.abs(want))
+    finally:
+        g.close()
