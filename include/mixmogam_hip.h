@@ -163,6 +163,7 @@ int mmg_kin_acc_add(mmg_ctx* ctx, mmg_kin_acc* acc, mmg_geno* g, const float* sc
  * every call is a run of its own.  mmg_kin_acc_pending: SNPs whose sums are still in the planes (0: none). */
 int mmg_kin_acc_add_grm(mmg_ctx* ctx, mmg_kin_acc* acc, mmg_geno* g);
 int mmg_kin_acc_pending(mmg_ctx* ctx, mmg_kin_acc* acc, int64_t* n_snps_pending);
+int mmg_kin_acc_snps(mmg_ctx* ctx, mmg_kin_acc* acc, int64_t* n_snps);      /* SNPs added so far (what fetch reports), without the download */
 int mmg_kin_acc_fetch(mmg_ctx* ctx, mmg_kin_acc* acc, double* C_out, int64_t* n_snps);
 /* scale_k of the reference (kinship.py:94-100, inlined at hdf5_data.py:108-111) on the device-resident matrix, in place:
  * K *= (N - 1) / (tr K - sum K / N).  The rule is invariant under a prior division of K by the SNP count, so the
@@ -205,6 +206,10 @@ int mmg_dgemm_f64(mmg_ctx* ctx, int ta, int tb, int32_t M, int32_t N, int32_t K,
  * h0_rss = y'Py (= the Mahalanobis RSS of the null model, :906) and the GLS estimate beta [q] (:902).
  * K: host [N x N] symmetric (scaled as the model holds it); X: host [N x q] row-major (intercept first), q <= 16. */
 int mmg_reml_create(mmg_ctx* ctx, int32_t N, int32_t q, const double* K, const double* X, const double* y, mmg_reml** r);
+/* The same workspace with K taken from a kinship accumulator as it lies in HBM (a device-to-device copy): the kinship of a
+ * streamed pass (mmg_kin_acc_add_grm ... mmg_kin_acc_scale_k) goes into the likelihood search without visiting the host -- at
+ * N = 50,000 the download, the host's scale_k and the upload of 20 GB each were ~2 s of a 7.5 s REML stage. */
+int mmg_reml_create_from_acc(mmg_ctx* ctx, mmg_kin_acc* acc, int32_t q, const double* X, const double* y, mmg_reml** r);
 int mmg_reml_destroy(mmg_ctx* ctx, mmg_reml* r);
 int mmg_reml_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3,
                   double* s4, double* sum_sq_etas);

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "mmg_kin_acc_add": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mmg_kin_acc_add_grm": (C.c_int, [c_vp, c_vp, c_vp]),
     "mmg_kin_acc_pending": (C.c_int, [c_vp, c_vp, c_i64p]),
+    "mmg_kin_acc_snps": (C.c_int, [c_vp, c_vp, c_i64p]),
     "mmg_kin_acc_fetch": (C.c_int, [c_vp, c_vp, c_vp, c_i64p]),
     "mmg_kin_acc_scale_k": (C.c_int, [c_vp, c_vp, c_f64p]),
     "mmg_kin_acc_destroy": (C.c_int, [c_vp, c_vp]),
@@ -81,6 +82,7 @@ PROTOTYPES = {
     "mmg_emmax_perm_i8": (C.c_int, [c_vp, c_vp, C.c_int64, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, c_vp]),
     "mmg_emmax_perm": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, C.c_int32, C.c_double, C.c_int, c_vp]),
     "mmg_reml_create": (C.c_int, [c_vp, C.c_int32, C.c_int32, c_vp, c_vp, c_vp, C.POINTER(c_vp)]),
+    "mmg_reml_create_from_acc": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, C.POINTER(c_vp)]),
     "mmg_reml_destroy": (C.c_int, [c_vp, c_vp]),
     "mmg_reml_sums": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64p]),
     "mmg_reml_sums_ex": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64p, C.c_int32]),
@@ -333,11 +335,19 @@ class KinshipAccumulator(object):
         self.ctx._check(self.ctx.lib.mmg_kin_acc_scale_k(self.ctx.h, self.h, C.byref(f)))
         return f.value
 
-    def fetch(self):
+    def fetch(self, via=None):
+        """(matrix, SNP count).  via: another Context of the same device whose stream carries the download (a helper thread
+        fetching while this accumulator's own context computes)."""
         out = np.empty((self.N, self.N))
         n = C.c_int64(0)
-        self.ctx._check(self.ctx.lib.mmg_kin_acc_fetch(self.ctx.h, self.h, _ptr(out), C.byref(n)))
+        c = via if via is not None else self.ctx
+        c._check(c.lib.mmg_kin_acc_fetch(c.h, self.h, _ptr(out), C.byref(n)))
         return out, n.value
+
+    def snps(self):
+        n = C.c_int64(0)
+        self.ctx._check(self.ctx.lib.mmg_kin_acc_snps(self.ctx.h, self.h, C.byref(n)))
+        return n.value
 
     def close(self):
         if self.h is not None:
@@ -422,18 +432,51 @@ class PermPlan(object):
             pass
 
 
+class DeviceKinship(object):
+    """A kinship matrix that lives in HBM: the accumulator a streamed kinship pass filled (and scaled).  Stands in for the
+    N x N array where the next consumer is on the device too (Context.reml, kinship.scale_k); numpy sees it through
+    __array__ / host(), which download it once.  `host_future`: a concurrent.futures future of the downloaded matrix, when
+    a helper thread is fetching it in the background (hdf5_data.run_emmax)."""
+
+    def __init__(self, acc, scaled=False, host_future=None):
+        self.acc, self.N, self.shape, self.ndim = acc, acc.N, (acc.N, acc.N), 2
+        self._host, self.host_future, self.scaled = None, host_future, scaled
+
+    def host(self):
+        if self._host is None:
+            self._host = self.host_future.result() if self.host_future is not None else self.acc.fetch()[0]
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.host()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __len__(self):
+        return self.N
+
+    def close(self):
+        if self.acc is not None:
+            self.acc.close()
+            self.acc = None
+
+
 class Reml(object):
     """Eigendecomposition-free REML workspace (mmg_reml_*): K, X, y resident; the four likelihood sums per delta from
     one Cholesky factorisation each; the scan model P(delta), P y built on the device."""
 
     def __init__(self, ctx, K, X, y):
-        K = _arr(K, np.float64)
         X = _arr(X, np.float64)
         y = _arr(np.asarray(y).reshape(-1), np.float64)
-        self.ctx, self.N, self.q = ctx, K.shape[0], X.shape[1]
-        assert K.shape == (self.N, self.N) and X.shape[0] == self.N and len(y) == self.N
         h = c_vp()
-        ctx._check(ctx.lib.mmg_reml_create(ctx.h, self.N, self.q, _ptr(K), _ptr(X), _ptr(y), C.byref(h)))
+        if isinstance(K, DeviceKinship):                       # the kinship as a streamed pass left it in HBM: no host visit
+            self.ctx, self.N, self.q = ctx, K.N, X.shape[1]
+            assert X.shape[0] == self.N and len(y) == self.N
+            ctx._check(ctx.lib.mmg_reml_create_from_acc(ctx.h, K.acc.h, self.q, _ptr(X), _ptr(y), C.byref(h)))
+        else:
+            K = _arr(K, np.float64)
+            self.ctx, self.N, self.q = ctx, K.shape[0], X.shape[1]
+            assert K.shape == (self.N, self.N) and X.shape[0] == self.N and len(y) == self.N
+            ctx._check(ctx.lib.mmg_reml_create(ctx.h, self.N, self.q, _ptr(K), _ptr(X), _ptr(y), C.byref(h)))
         self.h = h
 
     ROUTES = {"auto": 0, "chol": 1, "band": 2}

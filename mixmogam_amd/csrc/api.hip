@@ -1098,6 +1098,22 @@ int mmg_kin_acc_add_grm(mmg_ctx* ctx, mmg_kin_acc* a, mmg_geno* g) {
   return rc;
 }
 
+extern "C" int mmg_reml_create_dev(mmg_ctx* ctx, int32_t N, int32_t q, const double* dK, const double* X, const double* y, mmg_reml** out);
+
+int mmg_reml_create_from_acc(mmg_ctx* ctx, mmg_kin_acc* a, int32_t q, const double* X, const double* y, mmg_reml** out) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, a && X && y && out);
+  { int rcf = grm_flush(ctx, a->ws, a->dC); if (rcf) return rcf; }
+  return mmg_reml_create_dev(ctx, a->N, q, a->dC, X, y, out);
+}
+
+int mmg_kin_acc_snps(mmg_ctx* ctx, mmg_kin_acc* a, int64_t* n_snps) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, a && n_snps);
+  *n_snps = a->n_snps;
+  return MMG_OK;
+}
+
 int mmg_kin_acc_pending(mmg_ctx* ctx, mmg_kin_acc* a, int64_t* n_snps_pending) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, a && n_snps_pending);

@@ -379,7 +379,8 @@ int model_from_device_public(mmg_ctx* ctx, int32_t N, const double* dA, const do
 
 extern "C" {
 
-int mmg_reml_create(mmg_ctx* ctx, int32_t N, int32_t q, const double* K, const double* X, const double* y, mmg_reml** out) {
+// K: host matrix, or (K_on_device) a device pointer -- the kinship a streamed pass left in HBM (mmg_reml_create_from_acc)
+static int reml_create(mmg_ctx* ctx, int32_t N, int32_t q, const double* K, bool K_on_device, const double* X, const double* y, mmg_reml** out) {
   if (!ctx) return MMG_E_ARG;
   RC_HIP(ctx, hipSetDevice(ctx->device));
   if (!(out && K && X && y && N > 0 && q >= 1 && q <= 16 && q < N)) return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_create");
@@ -404,7 +405,7 @@ int mmg_reml_create(mmg_ctx* ctx, int32_t N, int32_t q, const double* K, const d
     for (int c = 0; c < q; ++c) B[(size_t)c * N + i] = X[(size_t)i * q + c];
     B[(size_t)q * N + i] = y[i];
   }
-  RC_HIP(ctx, hipMemcpyAsync(r->dK, K, nn, hipMemcpyHostToDevice, ctx->stream));
+  RC_HIP(ctx, hipMemcpyAsync(r->dK, K, nn, K_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
   RC_HIP(ctx, hipMemcpyAsync(r->dB, B.data(), nq, hipMemcpyHostToDevice, ctx->stream));
   RC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   // log|X'X| and |Sy|^2 = y'y - y'X (X'X)^-1 X'y
@@ -424,6 +425,14 @@ int mmg_reml_create(mmg_ctx* ctx, int32_t N, int32_t q, const double* K, const d
   r->sum_sq_etas = yy - t;
   *out = r;
   return MMG_OK;
+}
+
+int mmg_reml_create(mmg_ctx* ctx, int32_t N, int32_t q, const double* K, const double* X, const double* y, mmg_reml** out) {
+  return reml_create(ctx, N, q, K, false, X, y, out);
+}
+
+int mmg_reml_create_dev(mmg_ctx* ctx, int32_t N, int32_t q, const double* dK, const double* X, const double* y, mmg_reml** out) {
+  return reml_create(ctx, N, q, dK, true, X, y, out);
 }
 
 int mmg_reml_destroy(mmg_ctx* ctx, mmg_reml* r) {

@@ -17,6 +17,7 @@ Multi-GPU (`coll`, mixmogam_amd.dist): chunks are dealt round-robin to the ranks
 all-reduced in HBM (RCCL SUM), eigh/REML are replicated, every rank scans its chunks and the OWNED p-value blocks
 are all-gathered; permutation minima are combined with a MIN/MAX all-reduce of P values.  Rank 0 writes the results.
 """
+import os
 import time
 
 import numpy as np
@@ -224,6 +225,8 @@ def _dev_comm(coll):
     return getattr(coll, 'device_comm', None) if coll is not None else None
 
 
+KINSHIP_ON_DEVICE_MIN_N = 8192   # run_emmax: from here the kinship goes accumulator -> REML workspace in HBM (see there; below,
+                                 # the host round trip is milliseconds and keeps results bit-identical to passing k=)
 KIN_MIN_ROWS = 65536       # SNPs per exact-GRM call from which the weights take 4 digit planes instead of 5 (api.hip)
 KIN_MAX_BYTES = 6e9        # ... as long as one chunk's int8 rows stay below this (two stores + two staging buffers)
 
@@ -243,7 +246,9 @@ def _merge_plan(plan, n_indivs, min_rows=None, max_bytes=None):
     return out
 
 
-def _ibd_kinship(ctx, genot_data, n_indivs, plan, coll=None, prefetch=True, timings=None):
+def _ibd_kinship(ctx, genot_data, n_indivs, plan, coll=None, prefetch=True, timings=None, keep_device=False):
+    """keep_device: return (_lib.DeviceKinship, n) -- the scaled kinship stays in HBM for the likelihood search
+    (mmg_reml_create_from_acc); .host() downloads it when the caller wants the array."""
     rank, world = (coll.rank, coll.world) if coll is not None else (0, 1)
     acc = ctx.kinship_accumulator(n_indivs)
     merged = _merge_plan(plan, n_indivs)
@@ -261,6 +266,12 @@ def _ibd_kinship(ctx, genot_data, n_indivs, plan, coll=None, prefetch=True, timi
         # :107-111 on the device: scale_k(K / n) = scale_k(K) (the rule is homogeneous of degree 0 in K), so the sum is
         # scaled as it lies in HBM and crosses PCIe once -- three host passes over 20 GB less at N = 50,000
         acc.scale_k()
+        if keep_device and isinstance(ctx, _lib.Context):
+            assert acc.snps() == n_all, (acc.snps(), n_all)
+            # (a helper thread downloading the 20 GB on a third context's stream while the reduction runs was tried:
+            # the download's host side -- first touch of 20 GB, the runtime's staging copies -- holds the launches of the
+            # 12,000-kernel band reduction back: REML 6.0 -> 6.6 s, scan model 2.4 -> 3.6 s on the share-of-8 run)
+            return _lib.DeviceKinship(acc, scaled=True), n_all
         k_mat, n_snps = acc.fetch()
         acc.close()
         assert n_snps == n_all, (n_snps, n_all)                          # after the all-reduce: every rank's chunks counted
@@ -406,7 +417,12 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
     rank, world = (coll.rank, coll.world) if coll is not None else (0, 1)
     plan = _chunk_plan(genot_data, min_maf, chunk_size)
     if k is None:
-        k, n_snps = _ibd_kinship(ctx, genot_data, n, plan, coll, prefetch, timings)
+        # the kinship goes from the accumulator into the likelihood search without visiting the host (and comes down in the
+        # background for the result) when the route that follows is the device's: at N = 50,000 the download, the host's
+        # second scale_k (:121 -> linear_models.py:580) and the upload, 20 GB each, were ~2 s of the REML stage
+        on_device = (os.environ.get('MMG_KINSHIP_ON_DEVICE', '1') != '0' and isinstance(ctx, _lib.Context) and not num_perm and eigen_free is not False
+                     and n >= KINSHIP_ON_DEVICE_MIN_N and n > lm.EIGEN_FREE_MIN_N)
+        k, n_snps = _ibd_kinship(ctx, genot_data, n, plan, coll, prefetch, timings, keep_device=on_device)
     else:
         n_snps = sum(len(sel) for _c, sel, _p in plan)
     _lap('kinship_pass_s')
@@ -436,6 +452,7 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
     _lap('scan_model_s')
     out = {'pseudo_heritability': res['pseudo_heritability'], 've': res['ve'], 'vg': res['vg'],
            'max_ll': res['max_ll'], 'num_snps': n_snps, 'chrom_results': {}, 'kinship': k}
+    k_dev = k if isinstance(k, _lib.DeviceKinship) else None
     chroms = list(genot_data.keys())
     parts = {}
     pp = None
@@ -478,6 +495,9 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
         five = num_perm // 20                                            # :342
         out.update(perm_min_ps=min_ps, perm_max_f_stats=max_f,
                    threshold_05=(float(min_ps[order][five]), float(max_f[order][five])))
+    if k_dev is not None:                                                # the result carries the array, as always
+        out['kinship'] = k_dev.host()
+        k_dev.close()
     if out_file is not None and rank == 0:
         _write_results(out_file, out, ih5f, num_perm)
     return out

@@ -32,6 +32,11 @@ def _pool():
 
 def scale_k(k, verbose=False):
     """kinship.py:94-100 -- c = tr(K) - sum(K)/n, K * (n-1)/c.  Host fp64, O(N^2)."""
+    if isinstance(k, _lib.DeviceKinship):                  # in HBM: scaled where it lies (mmg_kin_acc_scale_k), once --
+        if not k.scaled:                                   # the rule maps a scaled matrix onto itself (factor 1 +- 1e-16)
+            k.acc.scale_k()
+            k.scaled = True
+        return k
     k = np.asarray(k, dtype=np.float64)
     n = len(k)
     if n <= 2048:
