@@ -45,7 +45,8 @@ def release_pools():
             g.close()
     _POOLS.clear()
 
-_READ_THREADS = 4          # parallel readinto() streams per chunk (a single page-cache copy runs at 5-8 GB/s)
+# parallel readinto() streams per chunk (a single page-cache copy runs at 5-8 GB/s): a quarter of the host's cores, 4..16
+_READ_THREADS = int(os.environ.get('MMG_READ_THREADS', 0)) or max(4, min(16, (os.cpu_count() or 8) // 4))
 
 
 def _maf_filter(cg, min_maf):
@@ -105,7 +106,7 @@ def _read_chunk(genot_data, chrom, sel, out=None):
     n_ind = raw.shape[1]                                                 # bytes per row (packed: ceil(N*bits/8))
     want = np.uint8 if bits else np.int8
     if (out is not None and isinstance(raw, np.memmap) and raw.dtype == want and raw.flags['C_CONTIGUOUS']
-            and len(sel) == hi - lo and getattr(raw, 'filename', None) is not None):
+            and out.nbytes >= (hi - lo) * n_ind and getattr(raw, 'filename', None) is not None):
         block = out.view(want)[:(hi - lo) * n_ind].reshape(hi - lo, n_ind)
         mv = memoryview(block).cast('B')
         base = raw.offset + lo * n_ind
@@ -121,7 +122,7 @@ def _read_chunk(genot_data, chrom, sel, out=None):
                     got += k
 
         nbytes = len(mv)
-        nthr = min(_READ_THREADS, max(1, nbytes >> 26))                  # one reader per 64 MB, a page-cache copy each
+        nthr = min(_READ_THREADS, max(1, nbytes >> 25))                  # one reader per 32 MB, a page-cache copy each
         if nthr == 1:
             part(0, nbytes)
         else:
@@ -129,6 +130,23 @@ def _read_chunk(genot_data, chrom, sel, out=None):
             cuts = [nbytes * t // nthr // 4096 * 4096 for t in range(nthr)] + [nbytes]
             with ThreadPoolExecutor(max_workers=nthr) as ex:
                 list(ex.map(lambda ab: part(*ab), zip(cuts[:-1], cuts[1:])))
+        if len(sel) != hi - lo:
+            # a MAF filter dropped rows: the kept ones move up inside the buffer, run by run (sel is ascending, so a row only
+            # ever moves towards the front: memmove).  Before: the span was faulted in through the mapping and the subset
+            # copied out by fancy indexing -- 5 GB/s of an int8 container against 50 through the page-locked buffer
+            import ctypes
+            rel_idx = np.asarray(sel, dtype=np.int64) - lo
+            breaks = np.nonzero(np.diff(rel_idx) != 1)[0] + 1
+            starts = np.concatenate(([0], breaks))
+            ends = np.concatenate((breaks, [len(rel_idx)]))
+            addr = block.ctypes.data
+            dst = 0
+            for s0, e0 in zip(starts.tolist(), ends.tolist()):
+                src, cnt = int(rel_idx[s0]), e0 - s0
+                if src != dst:
+                    ctypes.memmove(addr + dst * n_ind, addr + src * n_ind, cnt * n_ind)
+                dst += cnt
+            block = block[:len(sel)]
         return block
     block = np.asarray(raw[lo:hi])                                       # one contiguous read ...
     if len(sel) != hi - lo:
@@ -179,6 +197,7 @@ def _resident_chunks(ctx, genot_data, plan, rank=0, world=1, prefetch=True, reus
     pool, host = [], [None, None]
     if reuse and mine:
         cap = max(len(plan[ci][1]) for ci in mine)
+        span = max(int(plan[ci][1][-1]) + 1 - int(plan[ci][1][0]) for ci in mine if len(plan[ci][1]))   # rows read per chunk
         cg0 = genot_data[plan[mine[0]][0]]
         n_ind = _num_indivs(cg0)
         # host bytes per SNP: N, or ceil(N bits / 8) when packed -- the LARGEST over the plan's chromosomes, and every
@@ -195,12 +214,13 @@ def _resident_chunks(ctx, genot_data, plan, rank=0, world=1, prefetch=True, reus
         # file ...): allocating them costs ~0.1 s, as much as streaming 5 GB
         key = (ctx.device, n_ind, row_bytes)
         cached = _POOLS.get(key)
-        if cached is None or cached[0] < cap:
+        if cached is None or cached[0] < cap or cached[2][0].nbytes < span * row_bytes:
             if cached is not None:
                 for g in cached[1]:
                     g.close()
+            # the staging buffers hold the SPAN of a chunk (first to last selected row: read contiguously, filtered in place)
             cached = _POOLS[key] = (cap, [up.geno(M=cap, N=n_ind) for _ in range(2)],
-                                    [up.pinned_empty(cap * row_bytes, dtype=np.int8) for _ in range(2)])
+                                    [up.pinned_empty(max(cap, span) * row_bytes, dtype=np.int8) for _ in range(2)])
         pool, host = cached[1], cached[2]
 
     def load(ci, slot):
