@@ -122,7 +122,7 @@ def _read_chunk(genot_data, chrom, sel, out=None):
                     got += k
 
         nbytes = len(mv)
-        nthr = min(_READ_THREADS, max(1, nbytes >> 25))                  # one reader per 32 MB, a page-cache copy each
+        nthr = min(_READ_THREADS, max(1, nbytes >> 23))                  # one reader per 8 MB, a page-cache copy each
         if nthr == 1:
             part(0, nbytes)
         else:
