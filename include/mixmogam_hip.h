@@ -229,6 +229,11 @@ int mmg_reml_sums_ml(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas
 int mmg_reml_band_info(mmg_ctx* ctx, mmg_reml* r, int32_t* band_ready, int32_t* householder_fallback, double* seconds);
 int mmg_reml_scan_model(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, double* h0_rss, double* beta,
                         double* mahalanobis_rss);
+/* The same, plus C = (X'V^-1 X)^-1 X'V^-1 (q x N, row-major; V = K + delta I): the matrix the with_betas form of the scan applies to
+ * every SNP for the covariates' coefficients (linear_models.py:1300-1303,1323) -- with it emmax(with_betas=True) needs no
+ * eigendecomposition either. */
+int mmg_reml_scan_model_c(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, double* h0_rss, double* beta,
+                          double* mahalanobis_rss, double* C_out);
 
 /* ---- EMMAX scan (replaces the loop of linear_models.py:1316-1349) ------------------------- */
 /* Loads the SNP-independent model onto the device:

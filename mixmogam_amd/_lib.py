@@ -89,6 +89,7 @@ PROTOTYPES = {
     "mmg_reml_sums_ml": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int32]),
     "mmg_reml_band_info": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mmg_reml_scan_model": (C.c_int, [c_vp, c_vp, C.c_double, C.c_int, c_f64p, c_vp, c_f64p]),
+    "mmg_reml_scan_model_c": (C.c_int, [c_vp, c_vp, C.c_double, C.c_int, c_f64p, c_vp, c_f64p, c_vp]),
     "mmg_rot_create": (C.c_int, [c_vp, C.c_int32, c_vp, C.c_int64, C.POINTER(c_vp)]),
     "mmg_rot_destroy": (C.c_int, [c_vp, c_vp]),
     "mmg_rot_load": (C.c_int, [c_vp, c_vp, c_vp]),
@@ -514,13 +515,15 @@ class Reml(object):
                                                       self.ROUTES[route]))
         return tuple(out)
 
-    def scan_model(self, delta, ndigits=0):
-        """Load the EMMAX scan model of `delta` into the context; returns (h0_rss, beta)."""
+    def scan_model(self, delta, ndigits=0, want_C=False):
+        """Load the EMMAX scan model of `delta` into the context; returns (h0_rss, beta) -- and, want_C, the q x N matrix
+        (X'V^-1 X)^-1 X'V^-1 of the with_betas form (mmg_reml_scan_model_c)."""
         h0, mah = C.c_double(0.0), C.c_double(0.0)
         beta = np.empty(self.q)
-        self.ctx._check(self.ctx.lib.mmg_reml_scan_model(self.ctx.h, self.h, float(delta), int(ndigits), C.byref(h0),
-                                                         _ptr(beta), C.byref(mah)))
-        return h0.value, beta
+        Cm = np.empty((self.q, self.N)) if want_C else None
+        self.ctx._check(self.ctx.lib.mmg_reml_scan_model_c(self.ctx.h, self.h, float(delta), int(ndigits), C.byref(h0),
+                                                           _ptr(beta), C.byref(mah), _ptr(Cm)))
+        return (h0.value, beta, Cm) if want_C else (h0.value, beta)
 
     def close(self):
         if self.h is not None:

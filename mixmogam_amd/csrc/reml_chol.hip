@@ -501,8 +501,18 @@ int mmg_reml_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, d
   return mmg_reml_sums_ex(ctx, r, nd, deltas, s1, s2, s3, s4, sum_sq_etas, MMG_REML_ROUTE_AUTO);
 }
 
+int mmg_reml_scan_model_c(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, double* h0_rss, double* beta,
+                          double* mahalanobis_rss, double* C_out);
+
 int mmg_reml_scan_model(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, double* h0_rss, double* beta,
                         double* mahalanobis_rss) {
+  return mmg_reml_scan_model_c(ctx, r, delta, ndigits, h0_rss, beta, mahalanobis_rss, nullptr);
+}
+
+// C_out (q x N, row-major; NULL: not wanted): (X'V^-1 X)^-1 X'V^-1, V = K + delta I -- what _emmax_f_test_(with_betas=True)
+// multiplies every SNP with for the covariates' coefficients (linear_models.py:1300-1303,1323: R^-1 Q'H of the QR of H X)
+int mmg_reml_scan_model_c(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, double* h0_rss, double* beta,
+                          double* mahalanobis_rss, double* C_out) {
   if (!ctx) return MMG_E_ARG;
   RC_HIP(ctx, hipSetDevice(ctx->device));
   if (!r) return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_scan_model");
@@ -548,6 +558,9 @@ int mmg_reml_scan_model(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, do
   if (h0_rss) *h0_rss = pt.s1;
   if (mahalanobis_rss) *mahalanobis_rss = pt.s1;
   if (beta) std::memcpy(beta, pt.beta.data(), q * sizeof(double));
+  if (C_out)                                                  // GA (N x q, row-major) = V^-1 X (X'V^-1 X)^-1 = C'
+    for (int64_t i = 0; i < N; ++i)
+      for (int c = 0; c < q; ++c) C_out[(size_t)c * N + i] = pt.GA[(size_t)i * q + c];
   return MMG_OK;
 }
 

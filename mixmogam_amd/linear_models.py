@@ -674,7 +674,7 @@ class LinearMixedModel(object):
         """:1233-1267."""
         t = {}
         s0 = time.time()
-        if (self.n > EIGEN_FREE_MIN_N and not eig_L and not eig_R and Z is None and not with_betas and emma_num == 0
+        if (self.n > EIGEN_FREE_MIN_N and not eig_L and not eig_R and Z is None and emma_num == 0
                 and method == 'REML' and isinstance(self.ctx, _lib.Context) and len(self.random_effects) == 2):
             # beyond rocSOLVER's syevd index range: REML and the scan model from Cholesky factorisations of K + delta I
             # (get_estimates_eigen_free) instead of the block-Jacobi eigendecomposition (6.6 min at N = 50,000)
@@ -688,7 +688,7 @@ class LinearMixedModel(object):
             reml = res.pop('reml')
             try:
                 r = self._emmax_f_test_(snps, None, snp_priors=snp_priors, emma_num=0, verbose=verbose,
-                                        _delta=res['delta'], _reml=reml)
+                                        with_betas=with_betas, _delta=res['delta'], _reml=reml)
             finally:
                 reml.close()
             t['scan'] = time.time() - s0
@@ -807,12 +807,17 @@ class LinearMixedModel(object):
         if return_transformed_snps and H_sqrt_inv is None:
             raise NotImplementedError("return_transformed_snps needs H_sqrt_inv")
         prep = None
-        if _delta is not None and Z is None and not with_betas:
+        if _delta is not None and Z is None:
             reml = _reml if _reml is not None else ctx.reml(self.random_effects[1][1], self.X, self.Y.reshape(-1))
             try:
-                h0_rss_d, beta_d = reml.scan_model(_delta, ndigits)
+                if with_betas:                                           # + C = (X'V^-1 X)^-1 X'V^-1 = R^-1 Q'H of :1300-1303
+                    h0_rss_d, beta_d, c_d = reml.scan_model(_delta, ndigits, want_C=True)
+                else:
+                    (h0_rss_d, beta_d), c_d = reml.scan_model(_delta, ndigits), None
                 prep = {'h0_rss': h0_rss_d, 'h0_betas': [float(b) for b in beta_d],
                         'n_p': self.n - (self.X.shape[1] + 1)}
+                if c_d is not None:
+                    prep['C'] = c_d
             except _lib.MixmogamHipError as e:
                 # an indefinite kinship has no Cholesky factor of K + delta I: callers that hold H_sqrt_inv (mlmm,
                 # the chunked drivers) get the model built from it instead; without it the error stands

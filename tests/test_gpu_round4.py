@@ -374,3 +374,27 @@ def test_diploid_ibs_kinship_combined_on_the_device(ctx):
         assert np.max(np.abs(got - want)) <= 1e-13 * np.max(np.abs(want))
     finally:
         g.close()
+
+
+def test_with_betas_without_an_eigendecomposition(ctx, monkeypatch):
+    """emmax(with_betas=True) from N = 256 up: the covariates' matrix C = (X'V^-1 X)^-1 X'V^-1 comes with the device-built scan
+    model (mmg_reml_scan_model_c) instead of R^-1 Q'H from H_sqrt_inv -- same p-values and coefficients as the eigen route."""
+    from mixmogam_amd import kinship, linear_models as lm
+    rng = np.random.RandomState(12)
+    n, m = 600, 3000
+    snps = (rng.random_sample((m, n)) < rng.uniform(0.1, 0.9, m)[:, None]).astype(np.int8)
+    y = rng.standard_normal(n) + snps[4] - 0.6 * snps[40]
+    cof = [list(rng.standard_normal(n)), list(snps[7].astype(float))]
+    K = kinship.calc_ibs_kinship(snps, ctx=ctx)
+    free = lm.emmax(snps, list(y), K, cofactors=cof, with_betas=True, ctx=ctx)
+    assert free["timings"]["eig_L"] == 0.0
+    monkeypatch.setattr(lm, "EIGEN_FREE_MIN_N", 1 << 30)
+    eig = lm.emmax(snps, list(y), K, cofactors=cof, with_betas=True, ctx=ctx)
+    assert eig["timings"]["eig_L"] > 0.0
+    assert np.max(np.abs(free["ps"] / eig["ps"] - 1)) < 1e-6
+    # SNP 7 is one of the cofactors: the design loses rank with it and the SNP keeps the null model's three coefficients (:236-239)
+    assert list(free["betas"][7]) == list(free["h0_betas"]) and list(eig["betas"][7]) == list(eig["h0_betas"])
+    rest = [j for j in range(m) if j != 7]
+    bf, be = np.asarray([free["betas"][j] for j in rest]), np.asarray([eig["betas"][j] for j in rest])
+    assert bf.shape == be.shape == (m - 1, 4)
+    assert np.max(np.abs(bf - be)) < 1e-7 * max(1.0, np.max(np.abs(be)))
