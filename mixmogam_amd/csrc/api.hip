@@ -1589,7 +1589,8 @@ static int exact_tier(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, mmg_s
   if (cnt == 0) return MMG_OK;
   static const double max_flop = [] { const char* e = std::getenv("MMG_SCAN_EXACT_MAX_FLOP"); return e ? std::atof(e) : 4e13; }();
   if (2.0 * (double)cnt * md.N * md.N > max_flop) { res.n_exact = -1; return MMG_OK; }
-  const int64_t batch = std::max<int64_t>(8, std::min<int64_t>(cnt, ((int64_t)2 << 30) / ((int64_t)N * 8)));   // <= 2 GB of fp64 rows
+  // <= 2 GB of fp64 rows and <= 65,535 groups of 8 SNPs (grid.y of scan_exact_den_kernel)
+  const int64_t batch = std::max<int64_t>(8, std::min<int64_t>({cnt, ((int64_t)2 << 30) / ((int64_t)N * 8), (int64_t)65535 * 8}));
   { int rc = ensure_rows(batch); if (rc) return rc; }
   double *Sd = nullptr, *part = nullptr;
   MMG_HIP(ctx, sc.alloc(&Sd, (size_t)batch * N * sizeof(double)));
