@@ -14,7 +14,7 @@
 #include "gemm_i8_core.h"
 #include "mmg_internal.h"
 
-static std::string g_last_error;
+static thread_local std::string g_last_error;            // (the chunk prefetcher calls in from a thread of its own)
 
 namespace mmg {
 int set_err(mmg_ctx* ctx, int code, const std::string& msg) {
