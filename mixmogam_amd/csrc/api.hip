@@ -934,6 +934,7 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
   const int64_t Mk_max = std::min(round_up(M, BK), CH);
   // grow-only: a stream that alternates between call shapes (100,000-SNP groups and a chromosome's 50,000-SNP tail, four
   // and five planes) re-allocated 50 GB at every change -- 3-5 s each at N = 50,000
+  int reallocs = 0;
   auto ensure_ws = [&](int D, bool fused) -> int {
     const size_t need_img = fused ? 16 : (size_t)g->Npad * Mk_max, need_c32 = (size_t)g->Npad * g->Npad;
     if (ws.cap_img < need_img || ws.cap_c32 < need_c32 || ws.capD < D || ws.cap_m < (size_t)M || ws.cap_mk < (size_t)Mk_max ||
@@ -945,6 +946,7 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
                    c_n = std::max(ws.cap_n, (size_t)g->Npad);
       const int c_D = std::max(ws.capD, D);
       ws.release();
+      ++reallocs;
       ws.direct = direct;
       hipError_t e = direct ? hipMalloc(&ws.dpart, (size_t)grm_partial_doubles((int64_t)c_mk, (int32_t)c_n) * sizeof(double))
                             : hipMalloc(&ws.Xq, c_img);
@@ -988,20 +990,28 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
   int Dn = D; bool fn = fused;
   if (ws.pending) {
     plan_for(ws.p_wcap, Dn, fn);
-    const bool joins = defer && Dn == ws.p_D && fn == ws.p_fused && bd == ws.p_bd && g->Npad == ws.p_Npad && g->N == ws.p_N &&
-                       wmax <= ws.p_wcap && 2.0 * wmax > ws.p_wcap && planes_hold(std::max(ws.p_smax, (double)g->smax), ws.p_M + M);
-    if (!joins) {
+    bool joins = defer && Dn == ws.p_D && fn == ws.p_fused && bd == ws.p_bd && g->Npad == ws.p_Npad && g->N == ws.p_N &&
+                 wmax <= ws.p_wcap && 2.0 * wmax > ws.p_wcap && planes_hold(std::max(ws.p_smax, (double)g->smax), ws.p_M + M);
+    if (joins) {
+      // the run's plan (Dn, fn) can differ from the one the workspace was sized for above (a >= 2^16-SNP call that falls back
+      // to five planes because of its weight range needs digit IMAGES, which the fused plan does not allocate): size it for
+      // the plan that runs.  A re-allocation flushes the run, and the call then starts one of its own.
+      const int before = reallocs;
+      int rcw = ensure_ws(Dn, fn);
+      if (rcw) return rcw;
+      if (reallocs != before) { launch_snp_stats(ctx, g, ws.dm, ws.ds); joins = false; }
+    } else {
       int rcf = grm_flush(ctx, ws, dC);
       if (rcf) return rcf;
-      if (!planes_env) { D = D_alone; fused = fused_for(D); }   // a run of its own: the call's own SNP count decides
     }
+    if (!joins && !planes_env) { D = D_alone; fused = fused_for(D); }   // a run of its own: the call's own SNP count decides
   }
   if (!ws.pending) {
     const double wcap = defer ? wmax * 1.0625 : wmax;
     plan_for(wcap, Dn, fn);
-    const double* dm_before = ws.dm;
+    const int before = reallocs;
     { int rcw = ensure_ws(Dn, fn); if (rcw) return rcw; }
-    if (ws.dm != dm_before) launch_snp_stats(ctx, g, ws.dm, ws.ds);   // a fifth plane re-allocated the workspace
+    if (reallocs != before) launch_snp_stats(ctx, g, ws.dm, ws.ds);   // a fifth plane re-allocated the workspace
     ws.p_D = Dn; ws.p_fused = fn; ws.p_bd = bd; ws.p_wcap = wcap; ws.p_Npad = g->Npad; ws.p_N = g->N;
     // D unsigned digits reach B^D - 1: the cap is scaled onto exactly that
     ws.p_step = wcap / (std::pow(base, Dn) - 1.0);

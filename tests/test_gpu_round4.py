@@ -247,6 +247,40 @@ def test_grm_accumulator_runs_of_calls_share_the_digit_planes(ctx):
         acc.close()
 
 
+def test_grm_run_of_five_plane_calls_after_a_longer_one_pass_call(ctx):
+    """A >= 2^16-SNP call whose weight range forces the fifth plane JOINS a five-plane run: its digit images are larger than
+    the ones the run's first call allocated, while the per-SNP buffers (sized by an earlier, longer one-pass call) already
+    fit -- the workspace has to grow for the plan that runs, not the one the SNP count alone suggests (api.hip,
+    kinship_grm_i8_into: until round 4 the images of the third call here overran their buffer)."""
+    n = 200
+    rng = np.random.RandomState(12)
+
+    def chunk(lo, hi, rows):
+        f = rng.uniform(lo, hi, rows)
+        s = (rng.random_sample((rows, n)) < f[:, None]).astype(np.int8)
+        s[:, 0] = 0; s[:, 1] = 1
+        return s
+
+    even = chunk(0.2, 0.8, 140000)                              # one pass, four planes, no images
+    wide1 = chunk(0.004, 0.5, 70000)                            # wmax / wmin > 64: five planes, one GEMM per plane
+    wide2 = chunk(0.004, 0.5, 100000)
+    wide2[0] = wide1[0]                                         # the same largest weight: the third call joins the second's run
+    acc = ctx.kinship_accumulator(n)
+    try:
+        want = 0.0
+        for s in (even, wide1, wide2):
+            g = ctx.geno(s)
+            acc.add_grm(g)
+            g.close()
+            want = want + _grm_f64(s)
+        assert acc.pending() == len(wide1) + len(wide2)         # the third call joined the second one's run
+        k, cnt = acc.fetch()
+        assert cnt == len(even) + len(wide1) + len(wide2)
+        assert np.abs(k - want).max() <= 2e-9 * np.abs(want).max()
+    finally:
+        acc.close()
+
+
 def test_grm_row_strip_layout_equals_the_quadrant_layout_bit_for_bit():
     """kinship_grm4r_kernel (MMG_GRM4_LAYOUT=strips: four row strips per tile, Q tiles in three LDS slots) against the shipped
     quadrant layout: every plane is an exact integer sum, so the accumulated matrices must be identical.  The switch is read
