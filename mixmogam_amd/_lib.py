@@ -6,6 +6,7 @@ test infrastructure only; nothing in this package imports it.)
 """
 import ctypes as C
 import os
+import sys
 import threading
 
 import numpy as np
@@ -140,6 +141,10 @@ def load():
             fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if hasattr(lib, "mmg_guard_check"):  # diagnostic build (make GUARD=1, MMG_LIB=...): live buffers are checked at exit
+            import atexit
+            lib.mmg_guard_check.restype = C.c_long
+            atexit.register(lambda: sys.stderr.write("[mmg guard] damaged guard bands: %d\n" % lib.mmg_guard_check()))
         _lib = lib
         return lib
 

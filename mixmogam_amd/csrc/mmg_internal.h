@@ -6,6 +6,18 @@
 #include <vector>
 #include "../../include/mixmogam_hip.h"
 
+#ifdef MMG_GUARD
+// Diagnostic build (make GUARD=1, guard.hip): the library's device buffers get guard bands that are checked when they are freed.
+hipError_t mmg_guard_malloc(void** p, size_t bytes, const char* file, int line);
+hipError_t mmg_guard_free(void* p);
+template <typename T>
+static inline hipError_t mmg_guard_malloc_t(T** p, size_t bytes, const char* file, int line) {
+  return mmg_guard_malloc((void**)p, bytes, file, line);
+}
+#define hipMalloc(p, bytes) mmg_guard_malloc_t(p, bytes, __FILE__, __LINE__)
+#define hipFree(p) mmg_guard_free((void*)(p))
+#endif
+
 struct mmg_geno {
   int64_t M = 0, Mpad = 0;      // SNPs, padded to 256
   uint64_t version = 0;         // bumped by every write path

@@ -1,0 +1,17 @@
+#!/bin/bash
+# The whole GPU suite on the GUARD build (see tools/guard_sweeps.sh) -> gpurun_out/guard_suite.log
+set -u
+cd "$(dirname "$0")/.."
+export MMG_LIB="$PWD/mixmogam_amd/lib/libmixmogam_hip_guard.so"
+[ -f "$MMG_LIB" ] || make -C mixmogam_amd/csrc GUARD=1 -j8 > /dev/null || exit 1
+out=gpurun_out/guard_suite.log
+mkdir -p gpurun_out
+python - > $out 2>&1 <<'PY'
+import ctypes, os
+lib = ctypes.CDLL(os.environ["MMG_LIB"])
+lib.mmg_guard_selftest.restype = ctypes.c_long
+print("guard self-test (2 = both overruns seen):", lib.mmg_guard_selftest())
+PY
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q -p no:cacheprovider >> $out 2>&1
+echo "-- exit $?" >> $out
+grep -n "mmg guard\|self-test\|-- exit\|passed\|failed" $out
