@@ -148,8 +148,9 @@ int mmg_kin_acc_add(mmg_ctx* ctx, mmg_kin_acc* acc, mmg_geno* g, const float* sc
  * sum_m s s'/std^2 is 4-5 int8-MFMA GEMMs of the IBS kind (the weight 1/std^2 split into non-negative digits folded into
  * one operand), the rank-one terms fp64 dot products.  ~5x faster than the fp32-MFMA kernel; falls back to that kernel for
  * genotype alphabets beyond -4..4.  A SNP with std == 0 is an error (kinship.py:67).
- * Precision: every weight is rounded to 2^-30 of the call's LARGEST weight (five planes; 2^-35 / 2^-30 for alphabets beyond
- * 0/1), entries good to ~1e-9 of the float64 result.  Binary stores of >= 65,536 SNPs whose weights span less than a
+ * Precision: every weight is rounded to 2^-35 of the call's LARGEST weight for 0/1 stores and for 0/1/2 stores (five
+ * planes of 7 bits; a 0/1/2 store is read as s - 1 in {-1, 0, 1}, which leaves z unchanged), 2^-30 for wider alphabets;
+ * entries good to ~1e-9 of the float64 result.  0/1 and 0/1/2 stores of >= 65,536 SNPs whose weights span less than a
  * factor 64 (any MAF filter >= 0.004) take FOUR planes, 2^-28 of the largest weight -- the per-SNP roundings are
  * independent and average down as 1/sqrt(M).  The digits are relative to the largest weight of a RUN of calls (below), so
  * the sum depends (at that level, ~1e-10) on how the SNPs are grouped into calls: a multi-rank or differently chunked run

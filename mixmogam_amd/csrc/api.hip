@@ -831,7 +831,7 @@ struct GrmWorkspace {
   int* C32 = nullptr;
   double *dm = nullptr, *ds = nullptr, *dcoef = nullptr, *dc1 = nullptr, *dc1acc = nullptr, *dpart = nullptr, *dwst = nullptr;
   size_t cap_img = 0, cap_c32 = 0, cap_m = 0, cap_mk = 0, cap_n = 0;
-  int capD = 0;
+  int capD = 0, cap_nimg = 0;     // planes of C32 / images of Xp (one more than planes for a centred 0 / 1 / 2 store)
   bool direct = false;            // SNP-major images for the transposed-read GEMM (no plain image Xq)
   // Sums that have not reached the fp64 accumulator yet (round 4): successive calls whose weights fit the digit step
   // already in use keep adding into the SAME int32 planes, and the combine pass (40 GB of planes + 40 GB of fp64 read /
@@ -902,8 +902,16 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
   // negative genotype wrapped (advisor r2), and two's-complement negatives cost ~6 % of the power-limited MFMA rate
   // (tools/probe/mfma_digit_range.hip).  >= 30 bits of the largest weight; binary stores of >= 2^16 SNPs take 4
   // planes (28 bits: the roundings are independent per SNP and average down as 1/sqrt(M)).
+  // Round 4: a store of 0 / 1 / 2 (diploid counts, plink2hdf5.py's output) is read as s - 1 in {-1, 0, 1} -- K only sees
+  // s - mean, so the shift changes nothing, and 7-bit digits fit again: the plane counts of a binary store (4 from 2^16
+  // SNPs on) instead of five 6-bit planes.  The images are written shifted (grm_scale_rows_kernel<.., SHIFT>) together with
+  // a plain shifted image that replaces the store as the GEMMs' second operand.  MMG_GRM_CENTRE=0: the 6-bit planes.
+  static const bool tr_off0 = [] { const char* e = std::getenv("MMG_KIN_KERNEL"); return e && (std::string(e) == "w4" || std::string(e) == "w8"); }();
+  static const bool centre_off = [] { const char* e = std::getenv("MMG_GRM_CENTRE"); return e && e[0] == '0'; }();
+  const bool centre = g->smax == 2 && g->sneg == 0 && !tr_off0 && !centre_off;
+  const int smax_eff = centre ? 1 : g->smax;
   int bd = 0;
-  if (g->smax <= 1) bd = 7; else if (g->smax <= 2) bd = 6; else if (g->smax <= 4) bd = 5;
+  if (smax_eff <= 1) bd = 7; else if (smax_eff <= 2) bd = 6; else if (smax_eff <= 4) bd = 5;
   if (bd == 0) return MMG_E_STATE;
   int D = (30 + bd - 1) / bd;                              // 5, 5, 6 planes
   // ... the SNPs of the whole run count: a short call that can join a four-plane run of >= 2^16 SNPs takes four as well
@@ -917,7 +925,7 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
   // plane only grows -- (2^bd - 1) smax^2 M must stay below 2^31 (advisor r3; 16.9 M binary SNPs, 8.5 M for alphabets
   // within +-2; the chunked drivers pass far fewer per call, and a run of calls is cut where the bound would be reached)
   auto planes_hold = [&](double smax, int64_t m) { return (double)((1 << bd) - 1) * smax * smax * (double)m < 2147483648.0; };
-  if (!planes_hold(g->smax, g->M))
+  if (!planes_hold(smax_eff, g->M))
     return set_err(ctx, MMG_E_ARG, "exact GRM: too many SNPs in one call for the 32-bit digit planes (split the call)");
   // Round 3: the digit images are SNP-major like the store (row m scaled by the digit of SNP m) and the GEMM reads both
   // through transposed LDS reads (kinship_i8_tr_kernel) -- no transposition pass, no plain image.  MMG_KIN_KERNEL=w4 /
@@ -937,20 +945,21 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
   int reallocs = 0;
   auto ensure_ws = [&](int D, bool fused) -> int {
     const size_t need_img = fused ? 16 : (size_t)g->Npad * Mk_max, need_c32 = (size_t)g->Npad * g->Npad;
-    if (ws.cap_img < need_img || ws.cap_c32 < need_c32 || ws.capD < D || ws.cap_m < (size_t)M || ws.cap_mk < (size_t)Mk_max ||
-        ws.cap_n < (size_t)g->Npad || ws.direct != direct) {
+    const int need_nimg = D + (centre ? 1 : 0);               // + the plain shifted image of a 0 / 1 / 2 store
+    if (ws.cap_img < need_img || ws.cap_c32 < need_c32 || ws.capD < D || ws.cap_nimg < need_nimg || ws.cap_m < (size_t)M ||
+        ws.cap_mk < (size_t)Mk_max || ws.cap_n < (size_t)g->Npad || ws.direct != direct) {
       int rcf = grm_flush(ctx, ws, dC);                       // the planes are about to be freed
       if (rcf) return rcf;
       const size_t c_img = std::max(ws.cap_img, need_img), c_c32 = std::max(ws.cap_c32, need_c32),
                    c_m = std::max(ws.cap_m, (size_t)M), c_mk = std::max(ws.cap_mk, (size_t)Mk_max),
                    c_n = std::max(ws.cap_n, (size_t)g->Npad);
-      const int c_D = std::max(ws.capD, D);
+      const int c_D = std::max(ws.capD, D), c_nimg = std::max(ws.cap_nimg, need_nimg);
       ws.release();
       ++reallocs;
       ws.direct = direct;
       hipError_t e = direct ? hipMalloc(&ws.dpart, (size_t)grm_partial_doubles((int64_t)c_mk, (int32_t)c_n) * sizeof(double))
                             : hipMalloc(&ws.Xq, c_img);
-      if (e == hipSuccess) e = hipMalloc(&ws.Xp, (size_t)c_D * c_img);
+      if (e == hipSuccess) e = hipMalloc(&ws.Xp, (size_t)c_nimg * c_img);
       if (e == hipSuccess) e = hipMalloc(&ws.C32, (size_t)c_D * c_c32 * sizeof(int));
       if (e == hipSuccess) e = hipMalloc(&ws.ddig, (size_t)c_D * c_mk);
       if (e == hipSuccess) e = hipMalloc(&ws.dcoef, c_mk * sizeof(double));
@@ -960,13 +969,17 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
       if (e == hipSuccess) e = hipMalloc(&ws.ds, c_m * sizeof(double));
       if (e == hipSuccess) e = hipMalloc(&ws.dwst, (size_t)grm_weight_blocks((int64_t)c_m) * 4 * sizeof(double));
       if (e != hipSuccess) { ws.release(); return set_err(ctx, MMG_E_NOMEM, std::string("hipMalloc GRM workspace: ") + hipGetErrorString(e)); }
-      ws.cap_img = c_img; ws.cap_c32 = c_c32; ws.capD = c_D; ws.cap_m = c_m; ws.cap_mk = c_mk; ws.cap_n = c_n;
+      ws.cap_img = c_img; ws.cap_c32 = c_c32; ws.capD = c_D; ws.cap_nimg = c_nimg; ws.cap_m = c_m; ws.cap_mk = c_mk; ws.cap_n = c_n;
     }
     return MMG_OK;
   };
   { int rcw = ensure_ws(D, fused); if (rcw) return rcw; }
   // per-SNP mean / std in fp64 on the device; of the weights only four numbers per 4096 SNPs come to the host
-  launch_snp_stats(ctx, g, ws.dm, ws.ds);
+  auto snp_stats = [&]() {
+    launch_snp_stats(ctx, g, ws.dm, ws.ds);
+    if (centre) launch_add_scalar_f64(ctx, ws.dm, M, -1.0);    // the mean of s - 1
+  };
+  snp_stats();
   const int64_t nwb = grm_weight_blocks(M);
   launch_grm_weight_stats(ctx, ws.dm, ws.ds, M, ws.dwst);
   std::vector<double> wst((size_t)nwb * 4);
@@ -991,7 +1004,7 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
   if (ws.pending) {
     plan_for(ws.p_wcap, Dn, fn);
     bool joins = defer && Dn == ws.p_D && fn == ws.p_fused && bd == ws.p_bd && g->Npad == ws.p_Npad && g->N == ws.p_N &&
-                 wmax <= ws.p_wcap && 2.0 * wmax > ws.p_wcap && planes_hold(std::max(ws.p_smax, (double)g->smax), ws.p_M + M);
+                 wmax <= ws.p_wcap && 2.0 * wmax > ws.p_wcap && planes_hold(std::max(ws.p_smax, (double)smax_eff), ws.p_M + M);
     if (joins) {
       // the run's plan (Dn, fn) can differ from the one the workspace was sized for above (a >= 2^16-SNP call that falls back
       // to five planes because of its weight range needs digit IMAGES, which the fused plan does not allocate): size it for
@@ -999,7 +1012,7 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
       const int before = reallocs;
       int rcw = ensure_ws(Dn, fn);
       if (rcw) return rcw;
-      if (reallocs != before) { launch_snp_stats(ctx, g, ws.dm, ws.ds); joins = false; }
+      if (reallocs != before) { snp_stats(); joins = false; }
     } else {
       int rcf = grm_flush(ctx, ws, dC);
       if (rcf) return rcf;
@@ -1011,7 +1024,7 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
     plan_for(wcap, Dn, fn);
     const int before = reallocs;
     { int rcw = ensure_ws(Dn, fn); if (rcw) return rcw; }
-    if (reallocs != before) launch_snp_stats(ctx, g, ws.dm, ws.ds);   // a fifth plane re-allocated the workspace
+    if (reallocs != before) snp_stats();                              // a fifth plane re-allocated the workspace
     ws.p_D = Dn; ws.p_fused = fn; ws.p_bd = bd; ws.p_wcap = wcap; ws.p_Npad = g->Npad; ws.p_N = g->N;
     // D unsigned digits reach B^D - 1: the cap is scaled onto exactly that
     ws.p_step = wcap / (std::pow(base, Dn) - 1.0);
@@ -1037,7 +1050,7 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
       EvScope ev(ctx, EV_PACK);
       if (direct)   // digit images + c1[i] = sum_m (a b)_m s_mi of the chunk in one pass over the store
         launch_grm_scale_rows(ctx, Srow, std::min<int64_t>(Mk, g->Mpad - mb), Mk, g->Npad, g->sneg > 0, Xp, ddig, fused ? 0 : D,
-                              dcoef, ws.dpart, dc1);
+                              dcoef, ws.dpart, dc1, centre ? g->N : 0);
       else
         launch_transpose_digits(ctx, g, Xq, Xp, Mk, mb, ddig, D);
     }
@@ -1051,8 +1064,8 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
     }
     for (int d = 0; d < D && rc == MMG_OK && !fused; ++d) {
       if (direct)
-        rc = run_kinship_i8_tr(ctx, Xp + (size_t)d * g->Npad * Mk, Srow, g->Npad, g->Npad, Mk / BK,
-                               C32 + (size_t)d * g->Npad * g->Npad);
+        rc = run_kinship_i8_tr(ctx, Xp + (size_t)d * g->Npad * Mk, centre ? Xp + (size_t)D * g->Npad * Mk : Srow, g->Npad, g->Npad,
+                               Mk / BK, C32 + (size_t)d * g->Npad * g->Npad);
       else
         rc = run_kinship_i8_pq(ctx, Xp + (size_t)d * g->Npad * Mk, Xq, g->Npad, Mk, C32 + (size_t)d * g->Npad * g->Npad);
       double a = 0.0;
@@ -1068,7 +1081,7 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
   ctx->grm_ms_total = kin_ms;
   ws.p_c0 += c0;
   ws.p_M += M;
-  ws.p_smax = std::max(ws.p_smax, (double)g->smax);
+  ws.p_smax = std::max(ws.p_smax, (double)smax_eff);
   const double tt0 = verbose ? now() : 0.0;
   if (!defer) { int rcf = grm_flush(ctx, ws, dC); if (rcf) return rcf; }
   MMG_HIP(ctx, hipGetLastError());

@@ -357,12 +357,15 @@ void launch_pack_fp4_on(mmg_ctx* ctx, hipStream_t stream, const int8_t* S, int64
 // version with its byte-wise LDS reads).
 constexpr int GRM_SLAB = 512;
 
-template <int D, bool NEG>
+// SHIFT (round 4): a store of 0 / 1 / 2 is read as s - 1 in {-1, 0, 1} (the GRM does not change when a constant is added
+// to a SNP: only s - mean enters), whose products with a 7-bit digit fit int8 -- four planes of 7 bits instead of five of 6.
+// Columns >= N stay zero.  Image D is then the plain shifted store, the GEMM's second operand (api.hip).
+template <int D, bool NEG, bool SHIFT = false>
 __global__ __launch_bounds__(256) void grm_scale_rows_kernel(const int8_t* __restrict__ S, int64_t rows_valid, int64_t Mk,
                                                              int32_t Npad, int8_t* __restrict__ Xp,
                                                              const int8_t* __restrict__ dig /*[D][Mk]*/,
                                                              const double* __restrict__ coef /*[Mk]*/,
-                                                             double* __restrict__ partial /*[slabs][Npad]*/) {
+                                                             double* __restrict__ partial /*[slabs][Npad]*/, int32_t N) {
   const int nchunk = Npad >> 4;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t nslab = (Mk + GRM_SLAB - 1) / GRM_SLAB;
@@ -376,15 +379,26 @@ __global__ __launch_bounds__(256) void grm_scale_rows_kernel(const int8_t* __res
   for (int64_t r = r0; r < r1; ++r) {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (r < rows_valid) v = *(const uint4*)(S + r * (int64_t)Npad + c * 16);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    if (SHIFT) {
+      // byte-wise s - 1 without borrows between bytes: (s | 0x80) - 1 never crosses a byte, and ^ 0x80 puts the sign back
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint32_t one = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) one |= (c * 16 + q * 4 + b < N ? 1u : 0u) << (8 * b);
+        w[q] = ((w[q] | 0x80808080u) - one) ^ 0x80808080u;
+      }
+    }
     const double cf = coef[r];
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = fma(cf, (double)(int)(int8_t)((w[e >> 2] >> (8 * (e & 3))) & 0xff), acc[e]);
+    if (SHIFT) *(uint4*)(Xp + ((int64_t)D * Mk + r) * Npad + c * 16) = make_uint4(w[0], w[1], w[2], w[3]);
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int dg = (int)dig[(int64_t)d * Mk + r];       // 0 .. 127, digit * |s| <= 127
       uint32_t o[4];
-      if (!NEG) {
+      if (!NEG && !SHIFT) {
         // non-negative genotype bytes: every byte product stays below 128, so one dword multiply does four of them
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = w[q] * (uint32_t)dg;
@@ -434,6 +448,14 @@ __global__ void scale_f64_kernel(double* __restrict__ x, int64_t n, double f) {
   else if (i < n) x[i] *= f;
 }
 
+__global__ void add_scalar_f64_kernel(double* __restrict__ x, int64_t n, double v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] += v;
+}
+void launch_add_scalar_f64(mmg_ctx* ctx, double* x, int64_t n, double v) {
+  if (n > 0) hipLaunchKernelGGL(add_scalar_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, x, n, v);
+}
+
 void launch_row_sums_f64(mmg_ctx* ctx, const double* A, int64_t N, double* rows, double* diag) {
   hipLaunchKernelGGL(row_sums_f64_kernel, dim3((unsigned)N), dim3(256), 0, ctx->stream, A, N, rows, diag);
 }
@@ -446,20 +468,27 @@ void launch_scale_f64(mmg_ctx* ctx, double* x, int64_t n, double f) {
 int64_t grm_partial_doubles(int64_t Mk, int32_t Npad) { return (Mk + GRM_SLAB - 1) / GRM_SLAB * (int64_t)Npad; }
 
 // S: first row of the chunk in the store (row stride Npad); rows_valid: rows of the chunk that exist in the store
+// n_shift > 0: the store holds 0 / 1 / 2 and is read as s - 1 over its n_shift individuals; image D is the shifted store
 void launch_grm_scale_rows(mmg_ctx* ctx, const int8_t* S, int64_t rows_valid, int64_t Mk, int32_t Npad, bool neg,
-                           int8_t* Xp, const int8_t* dig, int D, const double* coef, double* partial, double* c1) {
+                           int8_t* Xp, const int8_t* dig, int D, const double* coef, double* partial, double* c1,
+                           int32_t n_shift) {
   const int64_t nslab = (Mk + GRM_SLAB - 1) / GRM_SLAB;
   const int64_t total = nslab * (Npad >> 4);
   const dim3 grid((unsigned)((total + 255) / 256));
 #define MMG_GS(D_, NEG_)                                                                                              \
   hipLaunchKernelGGL((grm_scale_rows_kernel<D_, NEG_>), grid, dim3(256), 0, ctx->stream, S, rows_valid, Mk, Npad, Xp, dig, \
-                     coef, partial)
-  if (D == 0) MMG_GS(0, false);                            // only the weighted column sums (the fused 4-plane GEMM scales in registers)
+                     coef, partial, 0)
+#define MMG_GSS(D_)                                                                                                   \
+  hipLaunchKernelGGL((grm_scale_rows_kernel<D_, true, true>), grid, dim3(256), 0, ctx->stream, S, rows_valid, Mk, Npad, Xp, \
+                     dig, coef, partial, n_shift)
+  if (n_shift > 0) { if (D == 3) MMG_GSS(3); else if (D == 4) MMG_GSS(4); else if (D == 5) MMG_GSS(5); else if (D == 6) MMG_GSS(6); }
+  else if (D == 0) MMG_GS(0, false);                       // only the weighted column sums (the fused 4-plane GEMM scales in registers)
   else if (neg) { if (D == 3) MMG_GS(3, true); else if (D == 4) MMG_GS(4, true); else if (D == 5) MMG_GS(5, true); else if (D == 6) MMG_GS(6, true); }
   else { if (D == 3) MMG_GS(3, false); else if (D == 4) MMG_GS(4, false); else if (D == 5) MMG_GS(5, false); else if (D == 6) MMG_GS(6, false); }
   // (any other plane count launches nothing: api.hip admits 3..6 -- a count that fell through to the 6-plane kernel wrote
   // six images into a buffer sized for fewer)
 #undef MMG_GS
+#undef MMG_GSS
   hipLaunchKernelGGL(grm_colsum_reduce_kernel, dim3((unsigned)((Npad + 255) / 256)), dim3(256), 0, ctx->stream, partial,
                      nslab, Npad, c1);
 }

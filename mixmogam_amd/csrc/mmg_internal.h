@@ -209,7 +209,8 @@ void launch_grm_digits(mmg_ctx*, const double* mean, const double* sd, int64_t m
                        int D, int8_t* dig, double* coef);
 void launch_add_into_f64(mmg_ctx*, double* dst, const double* src, int64_t n);
 void launch_grm_scale_rows(mmg_ctx*, const int8_t* S, int64_t rows_valid, int64_t Mk, int32_t Npad, bool neg, int8_t* Xp,
-                           const int8_t* dig, int D, const double* coef, double* partial, double* c1);
+                           const int8_t* dig, int D, const double* coef, double* partial, double* c1, int32_t n_shift = 0);
+void launch_add_scalar_f64(mmg_ctx*, double* x, int64_t n, double v);
 void launch_transpose_digits(mmg_ctx*, const mmg_geno*, int8_t* Xq, int8_t* Xp, int64_t Mk, int64_t m_begin,
                              const int8_t* dig, int D);
 void launch_snp_dot_raw(mmg_ctx*, const int8_t* S, int64_t ldS, int64_t rows, int32_t len16, const double* v, double* out);

@@ -281,6 +281,35 @@ def test_grm_run_of_five_plane_calls_after_a_longer_one_pass_call(ctx):
         acc.close()
 
 
+@pytest.mark.parametrize("m", [3000, 70000])
+def test_grm_of_a_diploid_store_through_the_centred_alphabet(ctx, m):
+    """0 / 1 / 2 stores are read as s - 1 in the exact GRM (api.hip, kinship_grm_i8_into: 7-bit digits, the plane counts of a
+    binary store): five planes for a short call, four from 2^16 SNPs on; K against the float64 product of the UNSHIFTED
+    genotypes (kinship.py:63-69), packed 2-bit upload and int8 upload alike."""
+    from mixmogam_amd import _lib
+    n = 203                                                     # 53 padding individuals: they must stay out of the sums
+    rng = np.random.RandomState(m)
+    f = rng.uniform(0.1, 0.9, m)
+    s = ((rng.random_sample((m, n)) < f[:, None]).astype(np.int8) + (rng.random_sample((m, n)) < f[:, None]).astype(np.int8))
+    s[:, 0] = 0; s[:, 1] = 2
+    want = _grm_f64(s)
+    for packed in (False, True):
+        if packed:
+            g = ctx.geno(M=m, N=n)
+            g.upload_packed(_lib.pack_genotypes(s, 2), 2)
+        else:
+            g = ctx.geno(s)
+        acc = ctx.kinship_accumulator(n)
+        try:
+            acc.add_grm(g)
+            k, cnt = acc.fetch()
+        finally:
+            acc.close()
+            g.close()
+        assert cnt == m
+        assert np.abs(k - want).max() <= 2e-9 * np.abs(want).max(), packed
+
+
 def test_grm_row_strip_layout_equals_the_quadrant_layout_bit_for_bit():
     """kinship_grm4r_kernel (MMG_GRM4_LAYOUT=strips: four row strips per tile, Q tiles in three LDS slots) against the shipped
     quadrant layout: every plane is an exact integer sum, so the accumulated matrices must be identical.  The switch is read
