@@ -906,9 +906,10 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
   // s - mean, so the shift changes nothing, and 7-bit digits fit again: the plane counts of a binary store (4 from 2^16
   // SNPs on) instead of five 6-bit planes.  The images are written shifted (grm_scale_rows_kernel<.., SHIFT>) together with
   // a plain shifted image that replaces the store as the GEMMs' second operand.  MMG_GRM_CENTRE=0: the 6-bit planes.
-  static const bool tr_off0 = [] { const char* e = std::getenv("MMG_KIN_KERNEL"); return e && (std::string(e) == "w4" || std::string(e) == "w8"); }();
+  // (MMG_KIN_KERNEL=w4 / w8: the individual-major generations of the GEMM, which read transposed images -- no centring there)
+  static const bool tr_off = [] { const char* e = std::getenv("MMG_KIN_KERNEL"); return e && (std::string(e) == "w4" || std::string(e) == "w8"); }();
   static const bool centre_off = [] { const char* e = std::getenv("MMG_GRM_CENTRE"); return e && e[0] == '0'; }();
-  const bool centre = g->smax == 2 && g->sneg == 0 && !tr_off0 && !centre_off;
+  const bool centre = g->smax == 2 && g->sneg == 0 && !tr_off && !centre_off;
   const int smax_eff = centre ? 1 : g->smax;
   int bd = 0;
   if (smax_eff <= 1) bd = 7; else if (smax_eff <= 2) bd = 6; else if (smax_eff <= 4) bd = 5;
@@ -928,9 +929,7 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
   if (!planes_hold(smax_eff, g->M))
     return set_err(ctx, MMG_E_ARG, "exact GRM: too many SNPs in one call for the 32-bit digit planes (split the call)");
   // Round 3: the digit images are SNP-major like the store (row m scaled by the digit of SNP m) and the GEMM reads both
-  // through transposed LDS reads (kinship_i8_tr_kernel) -- no transposition pass, no plain image.  MMG_KIN_KERNEL=w4 /
-  // w8: the individual-major generations.
-  static const bool tr_off = [] { const char* e = std::getenv("MMG_KIN_KERNEL"); return e && (std::string(e) == "w4" || std::string(e) == "w8"); }();
+  // through transposed LDS reads (kinship_i8_tr_kernel) -- no transposition pass, no plain image.
   const bool direct = !tr_off;
   // MMG_GRM_DEFER=0: combine at the end of every call with the step taken from the call's own largest weight (round 3)
   static const bool defer = [] { const char* e = std::getenv("MMG_GRM_DEFER"); return !(e && e[0] == '0'); }();
