@@ -838,7 +838,7 @@ struct GrmWorkspace {
   // written at N = 50,000: 20 ms, plus 13 ms of clearing the planes) runs once per run of such calls, not once per call.
   bool pending = false;
   int p_D = 0, p_bd = 0;
-  bool p_fused = false;
+  int p_fused = 0;                // 0: one image GEMM per plane, 1: the one-pass kernel (4 planes), 2: one-pass for planes 1-4 + image GEMM for plane 0
   double p_step = 0.0, p_wcap = 0.0, p_c0 = 0.0, p_smax = 0.0;
   int64_t p_M = 0;
   int32_t p_Npad = 0, p_N = 0;
@@ -935,16 +935,24 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
   static const bool defer = [] { const char* e = std::getenv("MMG_GRM_DEFER"); return !(e && e[0] == '0'); }();
   // binary store and four planes: ONE pass over the genotypes computes all four (gemm_i8_grm4.h: the scaled operands are
   // formed in registers from the plain tiles) -- no digit images at all.  MMG_GRM_FUSED=0: one GEMM per plane.
-  auto fused_for = [&](int d) { const char* e = std::getenv("MMG_GRM_FUSED"); return direct && d == 4 && g->smax <= 1 && g->sneg == 0 && !(e && e[0] == '0'); };
-  bool fused = fused_for(D);
+  // Five planes of a binary store (a short call, or rare variants stretching the weight range -- calc_ibd_kinship has no MAF
+  // filter): the one-pass kernel takes planes 1-4 and only the lowest plane goes through a digit image and a GEMM of its own
+  // (mode 2; 60 -> 48 ms at the C3 shape, where five image GEMMs cost 10.6 ms each and the one pass 35).  MMG_GRM_HYBRID=0.
+  auto fused_for = [&](int d) -> int {
+    const char* e = std::getenv("MMG_GRM_FUSED");
+    const char* h = std::getenv("MMG_GRM_HYBRID");
+    if (!(direct && g->smax <= 1 && g->sneg == 0) || (e && e[0] == '0')) return 0;
+    return d == 4 ? 1 : (d == 5 && !(h && h[0] == '0')) ? 2 : 0;
+  };
+  int fused = fused_for(D);
   const int64_t M = g->M, CH = kin_chunk();
   const int64_t Mk_max = std::min(round_up(M, BK), CH);
   // grow-only: a stream that alternates between call shapes (100,000-SNP groups and a chromosome's 50,000-SNP tail, four
   // and five planes) re-allocated 50 GB at every change -- 3-5 s each at N = 50,000
   int reallocs = 0;
-  auto ensure_ws = [&](int D, bool fused) -> int {
-    const size_t need_img = fused ? 16 : (size_t)g->Npad * Mk_max, need_c32 = (size_t)g->Npad * g->Npad;
-    const int need_nimg = D + (centre ? 1 : 0);               // + the plain shifted image of a 0 / 1 / 2 store
+  auto ensure_ws = [&](int D, int fused) -> int {
+    const size_t need_img = fused == 1 ? 16 : (size_t)g->Npad * Mk_max, need_c32 = (size_t)g->Npad * g->Npad;
+    const int need_nimg = fused == 2 ? 1 : D + (centre ? 1 : 0);   // + the plain shifted image of a 0 / 1 / 2 store
     if (ws.cap_img < need_img || ws.cap_c32 < need_c32 || ws.capD < D || ws.cap_nimg < need_nimg || ws.cap_m < (size_t)M ||
         ws.cap_mk < (size_t)Mk_max || ws.cap_n < (size_t)g->Npad || ws.direct != direct) {
       int rcf = grm_flush(ctx, ws, dC);                       // the planes are about to be freed
@@ -995,11 +1003,11 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
   // Four planes quantise a weight to 2^-28 of the LARGEST one: fine while the weights are of one size (a MAF filter of
   // 0.1 keeps wmax / wmin below 2.8), not when rare variants stretch the range (no filter: wmax / wmin ~ N / 4) -- then
   // the fifth plane stays (advisor r3).  The fused one-pass kernel computes four planes; five take one GEMM per plane.
-  auto plan_for = [&](double wcap, int& Dn, bool& fn) {
+  auto plan_for = [&](double wcap, int& Dn, int& fn) {
     Dn = D; fn = fused;
-    if (Dn == 4 && wcap > 64.0 * wmin && !planes_env) { Dn = 5; fn = false; }
+    if (Dn == 4 && wcap > 64.0 * wmin && !planes_env) { Dn = 5; fn = fused_for(5); }
   };
-  int Dn = D; bool fn = fused;
+  int Dn = D, fn = fused;
   if (ws.pending) {
     plan_for(ws.p_wcap, Dn, fn);
     bool joins = defer && Dn == ws.p_D && fn == ws.p_fused && bd == ws.p_bd && g->Npad == ws.p_Npad && g->N == ws.p_N &&
@@ -1048,20 +1056,22 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
     {
       EvScope ev(ctx, EV_PACK);
       if (direct)   // digit images + c1[i] = sum_m (a b)_m s_mi of the chunk in one pass over the store
-        launch_grm_scale_rows(ctx, Srow, std::min<int64_t>(Mk, g->Mpad - mb), Mk, g->Npad, g->sneg > 0, Xp, ddig, fused ? 0 : D,
-                              dcoef, ws.dpart, dc1, centre ? g->N : 0);
+        launch_grm_scale_rows(ctx, Srow, std::min<int64_t>(Mk, g->Mpad - mb), Mk, g->Npad, g->sneg > 0, Xp, ddig,
+                              fused == 1 ? 0 : fused == 2 ? 1 : D, dcoef, ws.dpart, dc1, centre ? g->N : 0);
       else
         launch_transpose_digits(ctx, g, Xq, Xp, Mk, mb, ddig, D);
     }
     MMG_HIP(ctx, hipGetLastError());
     const double tp1 = verbose ? now() : 0.0;
     tv_pack += tp1 - tp0;
-    if (fused) {
-      rc = run_kinship_grm4(ctx, Srow, g->Npad, g->Npad, Mk / BK, ddig, Mk, C32);
+    if (fused) {                                             // planes 0-3 of four, or 1-4 of five
+      const size_t up = fused == 2 ? 1 : 0;
+      rc = run_kinship_grm4(ctx, Srow, g->Npad, g->Npad, Mk / BK, ddig + up * Mk, Mk, C32 + up * g->Npad * g->Npad);
       double a = 0.0;
       if (rc == MMG_OK && mmg_last_kernel_ms(ctx, EV_KIN, &a) == MMG_OK) kin_ms += a;
     }
-    for (int d = 0; d < D && rc == MMG_OK && !fused; ++d) {
+    const int n_img_gemms = fused == 1 ? 0 : fused == 2 ? 1 : D;
+    for (int d = 0; d < n_img_gemms && rc == MMG_OK; ++d) {
       if (direct)
         rc = run_kinship_i8_tr(ctx, Xp + (size_t)d * g->Npad * Mk, centre ? Xp + (size_t)D * g->Npad * Mk : Srow, g->Npad, g->Npad,
                                Mk / BK, C32 + (size_t)d * g->Npad * g->Npad);

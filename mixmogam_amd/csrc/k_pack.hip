@@ -484,7 +484,7 @@ void launch_grm_scale_rows(mmg_ctx* ctx, const int8_t* S, int64_t rows_valid, in
   if (n_shift > 0) { if (D == 3) MMG_GSS(3); else if (D == 4) MMG_GSS(4); else if (D == 5) MMG_GSS(5); else if (D == 6) MMG_GSS(6); }
   else if (D == 0) MMG_GS(0, false);                       // only the weighted column sums (the fused 4-plane GEMM scales in registers)
   else if (neg) { if (D == 3) MMG_GS(3, true); else if (D == 4) MMG_GS(4, true); else if (D == 5) MMG_GS(5, true); else if (D == 6) MMG_GS(6, true); }
-  else { if (D == 3) MMG_GS(3, false); else if (D == 4) MMG_GS(4, false); else if (D == 5) MMG_GS(5, false); else if (D == 6) MMG_GS(6, false); }
+  else { if (D == 1) MMG_GS(1, false); else if (D == 3) MMG_GS(3, false); else if (D == 4) MMG_GS(4, false); else if (D == 5) MMG_GS(5, false); else if (D == 6) MMG_GS(6, false); }
   // (any other plane count launches nothing: api.hip admits 3..6 -- a count that fell through to the 6-plane kernel wrote
   // six images into a buffer sized for fewer)
 #undef MMG_GS
