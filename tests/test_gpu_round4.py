@@ -323,6 +323,20 @@ def test_grm_row_strip_layout_equals_the_quadrant_layout_bit_for_bit():
     assert digests[0][1] == digests[1][1], out
 
 
+def test_grm_five_planes_one_pass_plus_one_image_equals_five_images_bit_for_bit():
+    """Five weight planes of a binary store: the one-pass kernel on planes 1-4 + an image GEMM for plane 0 (api.hip, mode 2)
+    against five image GEMMs (MMG_GRM_HYBRID=0) -- exact integer planes, the same combine pass: identical matrices.  N = 1000
+    has padding individuals; 3,000 SNPs is a call shorter than the kernel's pipeline was ever given before (24 K steps)."""
+    import os, re, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "grm_five_planes.py"), "1000", "140000", "300", "3000",
+                          "77", "100"], capture_output=True, text=True, timeout=300, check=True).stdout
+    got = re.findall(r"mode (\w+)\s+N=(\d+) M=(\d+):.*sha1 ([0-9a-f]+)", out)
+    assert [g[0] for g in got] == ["hybrid"] * 3 + ["images"] * 3, out
+    for a, b in zip(got[:3], got[3:]):
+        assert a[1:] == b[1:], out
+
+
 @pytest.mark.parametrize("n,m", [(504, 2), (1024, 3), (2048, 3)])
 def test_band_route_on_a_kinship_of_rank_three(ctx, n, m):
     """A kinship from two or three SNPs has rank <= 4: every panel of the band reduction is rank deficient (the Cholesky-QR
