@@ -34,6 +34,7 @@ using namespace mmg;
 // chunk prefetcher of hdf5_data.py) or beside contexts of other devices in the same process.
 #define MMG_ENTER(ctx)                                                              \
   do {                                                                              \
+    MMG_NOTE_ENTRY();                                                               \
     if (!(ctx)) return set_err(nullptr, MMG_E_ARG, "bad argument: ctx != nullptr"); \
     hipError_t e_dev__ = hipSetDevice((ctx)->device);                               \
     if (e_dev__ != hipSuccess)                                                      \
@@ -246,6 +247,7 @@ int mmg_geno_reset(mmg_ctx* ctx, mmg_geno* g, int64_t M) {
 
 int mmg_geno_destroy(mmg_ctx* ctx, mmg_geno* g) {
   if (!g) return MMG_OK;
+  MMG_NOTE_ENTRY();
   if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
   hipFree(g->d);
   hipFree(g->bits);
@@ -1209,6 +1211,7 @@ int mmg_kin_acc_allreduce(mmg_ctx* ctx, mmg_comm* comm, mmg_kin_acc* a) {
 
 int mmg_kin_acc_destroy(mmg_ctx* ctx, mmg_kin_acc* a) {
   if (!a) return MMG_OK;
+  MMG_NOTE_ENTRY();
   if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
   hipFree(a->dC);
   a->ws.release();
@@ -2026,6 +2029,7 @@ int mmg_perm_plan_create_ex(mmg_ctx* ctx, int32_t N, const double* Ht, const dou
 
 int mmg_perm_plan_destroy(mmg_ctx* ctx, mmg_perm_plan* p) {
   if (!p) return MMG_OK;
+  MMG_NOTE_ENTRY();
   if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
   perm_plan_free(p);
   return MMG_OK;
@@ -2166,6 +2170,7 @@ int mmg_rot_create(mmg_ctx* ctx, int32_t N, const double* evecs_rows, int64_t M_
 
 int mmg_rot_destroy(mmg_ctx* ctx, mmg_rot* r) {
   if (!r) return MMG_OK;
+  MMG_NOTE_ENTRY();
   if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
   hipFree(r->T); hipFree(r->Vq); hipFree(r->dstep); hipFree(r->dssum); hipFree(r->dones);
   delete r;
@@ -2324,6 +2329,7 @@ int mmg_comm_create(mmg_ctx* ctx, const unsigned char id[128], int rank, int wor
 
 int mmg_comm_destroy(mmg_ctx* ctx, mmg_comm* c) {
   if (!c) return MMG_OK;
+  MMG_NOTE_ENTRY();
   if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); hipStreamSynchronize(ctx->stream2); ctx->deliver_pending = false; }
   if (c->comm) ncclCommDestroy(c->comm);
   fflush(stdout);

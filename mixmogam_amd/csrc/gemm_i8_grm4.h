@@ -261,6 +261,8 @@ __device__ __forceinline__ void g4_stream(const G4Job& job, int64_t ld, char* ld
     advance();                                           // -> stage t+3
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the re-issued tail stages must land before LDS is released
+  wait_raw_g4(r0);                                       // ... and the raw fragments read for slices that do not exist stay
+  wait_raw_g4(r1);                                       // live up to here (gemm_i8_w4tr.h: frag_drain)
   epi(acc);
 }
 
@@ -437,6 +439,8 @@ __device__ __forceinline__ void g4r_stream(const G4Job& job, int64_t ld, char* l
     advance();                                           // -> stage t + 3
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the re-issued tail stages must land before LDS is released
+  wait_lds_g4r(r0, b0);                                  // ... and the registers of the reads for slices that do not exist
+  wait_lds_g4r(r1, b1);                                  // stay live up to here (gemm_i8_w4tr.h: frag_drain)
   epi(acc);
 }
 

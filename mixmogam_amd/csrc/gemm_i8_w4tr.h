@@ -76,6 +76,19 @@ __device__ __forceinline__ void frag_wait2(v4i& f, v4i& g) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f), "+v"(g) : "n"(N));
 }
 
+// End of a job: EVERY transposed read issued so far has landed, and until here the compiler must treat their destination
+// registers as live.  The last slice of a job reads the fragments of a slice that does not exist (the stream has no "last
+// slice" form); to the compiler those asm outputs are dead the moment they are written, so it handed their VGPRs to the
+// epilogue's address arithmetic -- and a read that returned late overwrote a row / column index: a wild atomicAdd.  Alone
+// on a CU the reads are back long before the epilogue starts; beside another kernel's LDS traffic (the upload stream of
+// the chunk prefetcher) they sometimes were not: the GPU memory fault of round 4 (tools/stress_two_threads.py, 2 s to fault;
+// DESIGN.md section 9).
+__device__ __forceinline__ void frag_drain(Frag4& f, Frag4& g) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.b[2]), "+v"(f.b[3]),
+                 "+v"(g.a[0]), "+v"(g.a[1]), "+v"(g.a[2]), "+v"(g.a[3]), "+v"(g.b[0]), "+v"(g.b[1]), "+v"(g.b[2]), "+v"(g.b[3]));
+}
+
 // lane-constant part of a fragment address: operand rows tile_row0 + (lane & 31) .. , k half (lane >> 5)
 __device__ __forceinline__ int frag_base_tr(int tile_row0, int lane) {
   const int i16 = lane & 15, g = lane >> 4, h = g >> 1;
@@ -302,6 +315,7 @@ __device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* ld
     for (int ks = 0; ks < nks - 1; ++ks) step(ks == 0);
     pre(jj);
     step(nks == 1);
+    frag_drain(f0, f1);                                  // the reads of the slice after the last one (see there)
     epi(jj, acc);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the re-issued tail stages must land before LDS is released

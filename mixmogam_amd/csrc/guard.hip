@@ -1,69 +1,202 @@
 // guard.hip -- diagnostic build only (make GUARD=1 -> ../lib/libmixmogam_hip_guard.so; select it with MMG_LIB=<path>).
-// There is no GPU address sanitizer on this pool (xnack+ code objects are refused), so the guard build gives every device
-// buffer the library allocates GUARD_BYTES of 0xA5 on both sides and checks them when the buffer is freed and whenever
-// mmg_guard_check() is called: a kernel (or copy) that WRITES past either end of a buffer is named by the file:line of
-// the allocation it ran over.  Reads past an end land in the padding instead of a neighbour's pages.  Never part of the
-// shipped library: mmg_internal.h routes hipMalloc / hipFree here only under -DMMG_GUARD.
+// There is no GPU address sanitizer on this pool (xnack+ code objects are refused), so the guard build routes every device
+// allocation of the library through here (mmg_internal.h, only under -DMMG_GUARD).  Three modes, MMG_GUARD_MODE=
+//   bands (default)  GUARD_BYTES of 0xA5 on both sides of every buffer, checked when the buffer is freed and whenever
+//                    mmg_guard_check() is called: a kernel (or copy) that WRITES past either end is named by the file:line of the
+//                    allocation it ran over.  Freed buffers are filled with 0xA5 and held back from hipFree in a quarantine
+//                    (MMG_GUARD_QUARANTINE_MB, default 1024): a use-after-free READ returns poison that a checked result shows.
+//   fence            (round 5) every buffer is a virtual-memory mapping of its own whose END sits on the last mapped byte
+//                    (rounded up to MMG_GUARD_ALIGN, default 256) with unmapped address space behind it, and a freed buffer is
+//                    unmapped while its addresses stay reserved for the life of the process: a READ or write past the end, or
+//                    of a freed buffer, is a GPU memory fault at that access instead of a silent neighbour read.  The slack in
+//                    front of the buffer (same mapping) is 0xA5 and checked at free; the buffer itself starts as 0xA5 too, so
+//                    reads of never-written memory are poison, not the zeros a fresh page happens to hold.
+//   fence_left       the mirror image: the buffer starts on the first mapped byte, unmapped space in front (underruns fault).
+// On SIGABRT (what the runtime raises after a GPU memory fault) the handler prints the last entry points the library was
+// called through (MMG_GUARD_TRACE=1: every one as it happens) and writes the table of live and freed buffers to the file
+// MMG_GUARD_DUMP names (default stderr), so that the faulting address the runtime printed can be matched to the file:line of
+// the allocation it lies behind, in front of, or in.  Never part of the shipped library.
 #include <hip/hip_runtime.h>
+#include <signal.h>
 #include <stdint.h>
+#include <unistd.h>
 
+#include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
 namespace {
 constexpr size_t GUARD_BYTES = 256 << 10;
-struct Rec { size_t bytes; const char* file; int line; };
+enum Mode { BANDS = 0, FENCE = 1, FENCE_LEFT = 2 };
+struct Rec {
+  size_t bytes; const char* file; int line;
+  // fence modes: the reservation [va, va + span) and the mapping [map, map + map_bytes) inside it
+  unsigned char* va; size_t span; unsigned char* map; size_t map_bytes; hipMemGenericAllocationHandle_t h;
+};
+struct Freed { void* user; Rec r; };
 std::mutex g_mu;
 std::unordered_map<void*, Rec> g_live;        // user pointer -> record
+std::deque<Freed> g_quarantine;               // bands: poisoned, not yet hipFree'd;  fence: unmapped for good (table only)
+size_t g_quarantine_bytes = 0;
 long g_bad = 0;
 
+Mode mode() {
+  static const Mode m = [] {
+    const char* e = std::getenv("MMG_GUARD_MODE");
+    const Mode v = !e ? BANDS : std::string(e) == "fence" ? FENCE : std::string(e) == "fence_left" ? FENCE_LEFT : BANDS;
+    fprintf(stderr, "[mmg guard] mode: %s\n", v == BANDS ? "bands" : v == FENCE ? "fence" : "fence_left");
+    return v;
+  }();
+  return m;
+}
+size_t fence_align() {
+  static const size_t a = [] { const char* e = std::getenv("MMG_GUARD_ALIGN"); const long v = e ? std::atol(e) : 0; return (size_t)(v >= 1 ? v : 256); }();
+  return a;
+}
+size_t quarantine_cap() {
+  static const size_t c = [] { const char* e = std::getenv("MMG_GUARD_QUARANTINE_MB"); const long v = e ? std::atol(e) : -1; return (size_t)(v >= 0 ? v : 1024) << 20; }();
+  return c;
+}
+
+// ---- the last entry points the library was called through (mmg_guard_note, from MMG_ENTER)
+constexpr int RING = 384;
+struct Note { const char* fn; unsigned long tid; };
+Note g_ring[RING];
+std::atomic<unsigned long> g_ring_n{0};
+
+void dump_record(FILE* f, const char* state, void* user, const Rec& r) {
+  fprintf(f, "[mmg guard]   %-6s %p .. %p  (%zu bytes)  %s:%d", state, user, (void*)((unsigned char*)user + r.bytes), r.bytes, r.file, r.line);
+  if (r.va) fprintf(f, "  mapped %p .. %p", (void*)r.map, (void*)(r.map + r.map_bytes));
+  fputc('\n', f);
+}
+
+void on_abort(int) {
+  // diagnostics only: not async-signal-safe, the process is going down anyway
+  const unsigned long n = g_ring_n.load();
+  fprintf(stderr, "[mmg guard] SIGABRT -- last entry points (oldest first):\n");
+  for (unsigned long i = n > RING ? n - RING : 0; i < n; ++i)
+    fprintf(stderr, "[mmg guard]   #%lu thread %lx %s\n", i, g_ring[i % RING].tid, g_ring[i % RING].fn);
+  const char* dump = std::getenv("MMG_GUARD_DUMP");
+  FILE* f = dump ? fopen(dump, "w") : stderr;
+  if (!f) f = stderr;
+  if (g_mu.try_lock()) {
+    fprintf(f, "[mmg guard] %zu live buffers, %zu freed ones on record:\n", g_live.size(), g_quarantine.size());
+    for (auto& kv : g_live) dump_record(f, "live", kv.first, kv.second);
+    for (auto& q : g_quarantine) dump_record(f, "freed", q.user, q.r);
+    g_mu.unlock();
+  }
+  if (f != stderr) fclose(f);
+  signal(SIGABRT, SIG_DFL);
+  abort();
+}
+void install_handler() {
+  static const bool once = [] { signal(SIGABRT, on_abort); return true; }();
+  (void)once;
+}
+
 // first / last damaged byte of a guard region (host copy), -1 if intact
-static bool damaged(const std::vector<unsigned char>& h, size_t* first, size_t* last) {
+bool damaged(const std::vector<unsigned char>& h, size_t* first, size_t* last) {
   bool any = false;
   for (size_t i = 0; i < h.size(); ++i)
     if (h[i] != 0xA5) { if (!any) *first = i; *last = i; any = true; }
   return any;
 }
 
-static int check_one(void* user, const Rec& r, const char* when) {
-  std::vector<unsigned char> lo(GUARD_BYTES), hi(GUARD_BYTES);
-  unsigned char* base = (unsigned char*)user - GUARD_BYTES;
-  (void)hipDeviceSynchronize();
-  if (hipMemcpy(lo.data(), base, GUARD_BYTES, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-  if (hipMemcpy(hi.data(), base + GUARD_BYTES + r.bytes, GUARD_BYTES, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-  int bad = 0;
+int check_region(const unsigned char* p, size_t n, const char* when, const char* side, const Rec& r, bool before) {
+  if (!n) return 0;
+  std::vector<unsigned char> h(n);
+  if (hipMemcpy(h.data(), p, n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   size_t a = 0, b = 0;
-  if (damaged(lo, &a, &b)) {
-    fprintf(stderr, "[mmg guard] %s: bytes %zu..%zu BEFORE the %zu-byte buffer of %s:%d were written\n", when,
-            GUARD_BYTES - b, GUARD_BYTES - a, r.bytes, r.file, r.line);
-    ++bad;
-  }
-  if (damaged(hi, &a, &b)) {
-    fprintf(stderr, "[mmg guard] %s: bytes %zu..%zu PAST the end of the %zu-byte buffer of %s:%d were written\n", when, a, b,
-            r.bytes, r.file, r.line);
-    ++bad;
-  }
-  if (bad) {   // report an overrun once: restore the pattern
-    (void)hipMemset(base, 0xA5, GUARD_BYTES);
-    (void)hipMemset(base + GUARD_BYTES + r.bytes, 0xA5, GUARD_BYTES);
-  }
-  return bad;
+  if (!damaged(h, &a, &b)) return 0;
+  if (before) fprintf(stderr, "[mmg guard] %s: bytes %zu..%zu BEFORE the %zu-byte buffer of %s:%d were written\n", when, n - b, n - a, r.bytes, r.file, r.line);
+  else fprintf(stderr, "[mmg guard] %s: bytes %zu..%zu %s of the %zu-byte buffer of %s:%d were written\n", when, a, b, side, r.bytes, r.file, r.line);
+  (void)hipMemset((void*)p, 0xA5, n);   // report an overrun once: restore the pattern
+  return 1;
+}
+
+int check_one(void* user, const Rec& r, const char* when) {
+  (void)hipDeviceSynchronize();
+  unsigned char* u = (unsigned char*)user;
+  if (!r.va)
+    return check_region(u - GUARD_BYTES, GUARD_BYTES, when, "", r, true) + check_region(u + r.bytes, GUARD_BYTES, when, "PAST the end", r, false);
+  // fence modes: the slack of the mapping on the side that is not fenced (at most 256 KiB of it)
+  const size_t lo = std::min<size_t>((size_t)(u - r.map), GUARD_BYTES);
+  const size_t hi = std::min<size_t>((size_t)(r.map + r.map_bytes - (u + r.bytes)), GUARD_BYTES);
+  return check_region(u - lo, lo, when, "", r, true) + check_region(u + r.bytes, hi, when, "PAST the end", r, false);
+}
+
+hipError_t fence_malloc(void** p, size_t bytes, Rec& r) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  size_t gran = 0;
+  e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+  if (e != hipSuccess) return e;
+  if (gran < 4096) gran = 4096;
+  const size_t al = fence_align();
+  const size_t padded = (bytes + al - 1) / al * al;
+  const size_t map_bytes = (std::max<size_t>(padded, 1) + gran - 1) / gran * gran;
+  // unmapped address space on either side (MMG_GUARD_VA_MB, default 64 MiB): an access that far off still lands in THIS
+  // buffer's reservation and not in a neighbour's, so the table names the right allocation
+  static const size_t va_guard = [] { const char* e = std::getenv("MMG_GUARD_VA_MB"); const long v = e ? std::atol(e) : 0; return (size_t)(v > 0 ? v : 64) << 20; }();
+  const size_t vg = (va_guard + gran - 1) / gran * gran;
+  const size_t span = map_bytes + 2 * vg;
+  void* va = nullptr;
+  e = hipMemAddressReserve(&va, span, gran, nullptr, 0);
+  if (e != hipSuccess) return e;
+  hipMemGenericAllocationHandle_t h;
+  e = hipMemCreate(&h, map_bytes, &prop, 0);
+  if (e != hipSuccess) { (void)hipMemAddressFree(va, span); return e; }
+  unsigned char* map = (unsigned char*)va + vg;
+  e = hipMemMap(map, map_bytes, 0, h, 0);
+  if (e != hipSuccess) { (void)hipMemRelease(h); (void)hipMemAddressFree(va, span); return e; }
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  e = hipMemSetAccess(map, map_bytes, &acc, 1);
+  if (e != hipSuccess) { (void)hipMemUnmap(map, map_bytes); (void)hipMemRelease(h); (void)hipMemAddressFree(va, span); return e; }
+  (void)hipMemset(map, 0xA5, map_bytes);
+  (void)hipDeviceSynchronize();
+  r.va = (unsigned char*)va; r.span = span; r.map = map; r.map_bytes = map_bytes; r.h = h;
+  *p = mode() == FENCE ? map + (map_bytes - padded) : map;
+  return hipSuccess;
 }
 }  // namespace
 
 hipError_t mmg_guard_malloc(void** p, size_t bytes, const char* file, int line) {
-  void* raw = nullptr;
-  hipError_t e = hipMalloc(&raw, bytes + 2 * GUARD_BYTES);
-  if (e != hipSuccess) { *p = nullptr; return e; }
-  (void)hipMemset(raw, 0xA5, GUARD_BYTES);
-  (void)hipMemset((unsigned char*)raw + GUARD_BYTES + bytes, 0xA5, GUARD_BYTES);
-  (void)hipDeviceSynchronize();
-  *p = (unsigned char*)raw + GUARD_BYTES;
+  install_handler();
+  Rec r{bytes, file, line, nullptr, 0, nullptr, 0, {}};
+  if (mode() != BANDS) {
+    hipError_t e = fence_malloc(p, bytes, r);
+    if (e != hipSuccess) { *p = nullptr; return e == hipErrorOutOfMemory ? e : hipErrorOutOfMemory; }
+  } else {
+    void* raw = nullptr;
+    hipError_t e = hipMalloc(&raw, bytes + 2 * GUARD_BYTES);
+    if (e != hipSuccess) {                                      // the quarantine holds memory the library has given back
+      std::vector<Freed> q;
+      { std::lock_guard<std::mutex> lk(g_mu); q.assign(g_quarantine.begin(), g_quarantine.end()); g_quarantine.clear(); g_quarantine_bytes = 0; }
+      (void)hipGetLastError();
+      for (auto& f : q) (void)hipFree((unsigned char*)f.user - GUARD_BYTES);
+      e = hipMalloc(&raw, bytes + 2 * GUARD_BYTES);
+    }
+    if (e != hipSuccess) { *p = nullptr; return e; }
+    (void)hipMemset(raw, 0xA5, GUARD_BYTES);
+    (void)hipMemset((unsigned char*)raw + GUARD_BYTES + bytes, 0xA5, GUARD_BYTES);
+    (void)hipDeviceSynchronize();
+    *p = (unsigned char*)raw + GUARD_BYTES;
+  }
   std::lock_guard<std::mutex> lk(g_mu);
-  g_live[*p] = Rec{bytes, file, line};
+  g_live[*p] = r;
   return hipSuccess;
 }
 
@@ -81,9 +214,48 @@ hipError_t mmg_guard_free(void* p) {
     r = it->second;
     g_live.erase(it);
   }
-  const int bad = check_one(p, r, "at hipFree");
+  const int bad = check_one(p, r, "at hipFree");   // (synchronises the device, as hipFree does)
   if (bad) { std::lock_guard<std::mutex> lk(g_mu); g_bad += bad; }
-  return hipFree((unsigned char*)p - GUARD_BYTES);
+  if (r.va) {
+    // unmapped and released, the addresses stay reserved: whatever still reads or writes the buffer faults from here on
+    (void)hipMemUnmap(r.map, r.map_bytes);
+    (void)hipMemRelease(r.h);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_quarantine.push_back(Freed{p, r});
+    // every reservation is a mapping of the host's address space too (vm.max_map_count, 65,530 by default): the oldest go
+    while (g_quarantine.size() > 20000) {
+      (void)hipMemAddressFree(g_quarantine.front().r.va, g_quarantine.front().r.span);
+      g_quarantine.pop_front();
+    }
+    return hipSuccess;
+  }
+  (void)hipMemset(p, 0xA5, r.bytes);             // poison: a later read through a stale pointer does not see plausible data
+  (void)hipDeviceSynchronize();
+  std::vector<Freed> out;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_quarantine.push_back(Freed{p, r});
+    g_quarantine_bytes += r.bytes + 2 * GUARD_BYTES;
+    while (g_quarantine_bytes > quarantine_cap() && !g_quarantine.empty()) {
+      out.push_back(g_quarantine.front());
+      g_quarantine_bytes -= g_quarantine.front().r.bytes + 2 * GUARD_BYTES;
+      g_quarantine.pop_front();
+    }
+  }
+  hipError_t e = hipSuccess;
+  for (auto& f : out) {
+    // a write into a freed buffer while it sat in the quarantine shows as damaged poison
+    std::vector<unsigned char> h(std::min<size_t>(f.r.bytes, 1 << 20));
+    size_t a = 0, b = 0;
+    if (!h.empty() && hipMemcpy(h.data(), f.user, h.size(), hipMemcpyDeviceToHost) == hipSuccess && damaged(h, &a, &b)) {
+      fprintf(stderr, "[mmg guard] bytes %zu..%zu of the FREED %zu-byte buffer of %s:%d were written after hipFree\n", a, b, f.r.bytes, f.r.file, f.r.line);
+      std::lock_guard<std::mutex> lk(g_mu);
+      ++g_bad;
+    }
+    hipError_t e1 = hipFree((unsigned char*)f.user - GUARD_BYTES);
+    if (e1 != hipSuccess) e = e1;
+  }
+  return e;
 }
 
 // Checks every live buffer; returns the number of damaged guards found since the library was loaded.
@@ -100,18 +272,49 @@ extern "C" long mmg_guard_check(void) {
   return g_bad;
 }
 extern "C" long mmg_guard_live(void) { std::lock_guard<std::mutex> lk(g_mu); return (long)g_live.size(); }
+extern "C" int mmg_guard_mode(void) { return (int)mode(); }
 
-// Proof that the bands work: one byte written past a 100-byte buffer and one before it must be reported (returns 2).
+// entry-point breadcrumbs (MMG_ENTER): the abort handler prints the last ones; MMG_GUARD_TRACE=1 prints every one as it happens
+extern "C" void mmg_guard_note(const char* fn) {
+  static const bool live_trace = std::getenv("MMG_GUARD_TRACE") != nullptr;
+  const unsigned long i = g_ring_n.fetch_add(1);
+  g_ring[i % RING] = Note{fn, (unsigned long)pthread_self()};
+  if (live_trace) fprintf(stderr, "[mmg] %lx %s\n", (unsigned long)pthread_self(), fn);
+}
+
+extern "C" void mmg_guard_launched(hipStream_t s) {
+  static const bool sync = [] { const char* e = std::getenv("MMG_GUARD_SYNC"); return e && e[0] == '1'; }();
+  if (sync) (void)hipStreamSynchronize(s);
+}
+
+// Proof that the bands work: one byte written past a 100-byte buffer and one before it must be reported (returns 2; 1 in the
+// fence modes for the side whose neighbour byte is unmapped: fence_left always, fence when MMG_GUARD_ALIGN leaves no padding).
 extern "C" long mmg_guard_selftest(void) {
   void* p = nullptr;
   if (mmg_guard_malloc(&p, 100, "guard.hip(selftest)", 0) != hipSuccess) return -1;
   long before;
   { std::lock_guard<std::mutex> lk(g_mu); before = g_bad; }
-  (void)hipMemset((unsigned char*)p + 100, 0, 1);
-  (void)hipMemset((unsigned char*)p - 1, 0, 1);
+  if (mode() != FENCE || fence_align() >= 128) (void)hipMemset((unsigned char*)p + 100, 0, 1);   // (fence: inside the alignment padding)
+  if (mode() != FENCE_LEFT) (void)hipMemset((unsigned char*)p - 1, 0, 1);
   (void)mmg_guard_free(p);
   std::lock_guard<std::mutex> lk(g_mu);
   const long found = g_bad - before;
   g_bad = before;                       // the self-test's own damage does not count
   return found;
+}
+
+// Proof that the fence works (fence modes only; ENDS THE PROCESS with a GPU memory fault when it does): a kernel reads one
+// byte past the end (fence) / before the start (fence_left) of a 1000-byte buffer, or, which = 1, a byte of a freed buffer.
+__global__ void guard_probe_kernel(const unsigned char* p, unsigned* out) { out[0] = p[0]; }
+extern "C" long mmg_guard_fault_selftest(int which) {
+  if (mode() == BANDS) return -1;
+  void *p = nullptr, *o = nullptr;
+  if (mmg_guard_malloc(&p, 1024, "guard.hip(fault selftest)", 0) != hipSuccess) return -2;
+  if (mmg_guard_malloc(&o, 256, "guard.hip(fault selftest out)", 0) != hipSuccess) return -2;
+  const unsigned char* target = mode() == FENCE ? (unsigned char*)p + 1024 : (unsigned char*)p - 1;
+  if (which == 1) { target = (unsigned char*)p; (void)mmg_guard_free(p); }
+  fprintf(stderr, "[mmg guard] fault self-test: reading %p\n", (const void*)target);
+  guard_probe_kernel<<<1, 1>>>(target, (unsigned*)o);
+  (void)hipDeviceSynchronize();
+  return 0;                             // reached only if the access did NOT fault
 }

@@ -16,6 +16,18 @@ static inline hipError_t mmg_guard_malloc_t(T** p, size_t bytes, const char* fil
 }
 #define hipMalloc(p, bytes) mmg_guard_malloc_t(p, bytes, __FILE__, __LINE__)
 #define hipFree(p) mmg_guard_free((void*)(p))
+extern "C" void mmg_guard_note(const char* fn);    // breadcrumb: the guard's abort handler prints the last entry points
+extern "C" void mmg_guard_launched(hipStream_t s); // MMG_GUARD_SYNC=1: wait for the kernel just launched (a fault then names it)
+#define MMG_NOTE_ENTRY() mmg_guard_note(__func__)
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                                   \
+  do {                                                                                                                      \
+    mmg_guard_note(#kernelName);                                                                                            \
+    hipLaunchKernelGGLInternal((kernelName), numBlocks, numThreads, memPerBlock, streamId, ##__VA_ARGS__);                  \
+    mmg_guard_launched(streamId);                                                                                           \
+  } while (0)
+#else
+#define MMG_NOTE_ENTRY() ((void)0)
 #endif
 
 struct mmg_geno {

@@ -382,6 +382,7 @@ extern "C" {
 // K: host matrix, or (K_on_device) a device pointer -- the kinship a streamed pass left in HBM (mmg_reml_create_from_acc)
 static int reml_create(mmg_ctx* ctx, int32_t N, int32_t q, const double* K, bool K_on_device, const double* X, const double* y, mmg_reml** out) {
   if (!ctx) return MMG_E_ARG;
+  MMG_NOTE_ENTRY();
   RC_HIP(ctx, hipSetDevice(ctx->device));
   if (!(out && K && X && y && N > 0 && q >= 1 && q <= 16 && q < N)) return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_create");
   *out = nullptr;
@@ -437,6 +438,7 @@ int mmg_reml_create_dev(mmg_ctx* ctx, int32_t N, int32_t q, const double* dK, co
 
 int mmg_reml_destroy(mmg_ctx* ctx, mmg_reml* r) {
   if (!r) return MMG_OK;
+  MMG_NOTE_ENTRY();
   if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
   hipFree(r->dK); hipFree(r->dL); hipFree(r->dB); hipFree(r->dZ); hipFree(r->dG); hipFree(r->dsc);
   reml_band_free(r);
@@ -447,6 +449,7 @@ int mmg_reml_destroy(mmg_ctx* ctx, mmg_reml* r) {
 int mmg_reml_sums_ex(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3,
                      double* s4, double* sum_sq_etas, int32_t route) {
   if (!ctx) return MMG_E_ARG;
+  MMG_NOTE_ENTRY();
   RC_HIP(ctx, hipSetDevice(ctx->device));
   if (!(r && deltas && s1 && s2 && s3 && s4 && nd >= 0 && route >= 0 && route <= 2))
     return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_sums");
@@ -479,6 +482,7 @@ int mmg_reml_band_info(mmg_ctx* ctx, mmg_reml* r, int32_t* band_ready, int32_t* 
 int mmg_reml_sums_ml(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s3, double* logdet_h,
                      double* tr_hinv, int32_t route) {
   if (!ctx) return MMG_E_ARG;
+  MMG_NOTE_ENTRY();
   RC_HIP(ctx, hipSetDevice(ctx->device));
   if (!(r && deltas && s1 && s3 && logdet_h && tr_hinv && nd >= 0 && route >= 0 && route <= 2))
     return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_sums_ml");
@@ -514,6 +518,7 @@ int mmg_reml_scan_model(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, do
 int mmg_reml_scan_model_c(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, double* h0_rss, double* beta,
                           double* mahalanobis_rss, double* C_out) {
   if (!ctx) return MMG_E_ARG;
+  MMG_NOTE_ENTRY();
   RC_HIP(ctx, hipSetDevice(ctx->device));
   if (!r) return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_scan_model");
   rocblas_handle h;
