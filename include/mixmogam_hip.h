@@ -161,7 +161,11 @@ int mmg_kin_acc_add(mmg_ctx* ctx, mmg_kin_acc* acc, mmg_geno* g, const float* sc
  * of planes, and the 32-bit bound holds for the run; otherwise -- and before fetch / scale_k / allreduce read the
  * accumulator -- the planes are combined into the fp64 sum (at N = 50,000 clearing and combining them is 33 ms next to
  * 208 ms of GEMMs per 65,536 SNPs).  A joining call loses at most one bit against a step of its own.  MMG_GRM_DEFER=0:
- * every call is a run of its own.  mmg_kin_acc_pending: SNPs whose sums are still in the planes (0: none). */
+ * every call is a run of its own.  mmg_kin_acc_pending: SNPs whose sums are still in the planes (0: none).
+ * Errors: a call rejected before it adds anything (a monomorphic SNP: MMG_E_ARG) leaves the accumulator as it was; a call that
+ * fails AFTER it has begun to add (a launch or stream error) leaves it unusable -- every later add / fetch / scale_k /
+ * allreduce / mmg_reml_create_from_acc on it returns MMG_E_STATE (round 5; before, the earlier calls' sums were dropped
+ * silently while their SNPs stayed counted). */
 int mmg_kin_acc_add_grm(mmg_ctx* ctx, mmg_kin_acc* acc, mmg_geno* g);
 int mmg_kin_acc_pending(mmg_ctx* ctx, mmg_kin_acc* acc, int64_t* n_snps_pending);
 int mmg_kin_acc_snps(mmg_ctx* ctx, mmg_kin_acc* acc, int64_t* n_snps);      /* SNPs added so far (what fetch reports), without the download */

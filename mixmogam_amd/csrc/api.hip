@@ -844,13 +844,27 @@ struct GrmWorkspace {
   double p_step = 0.0, p_wcap = 0.0, p_c0 = 0.0, p_smax = 0.0;
   int64_t p_M = 0;
   int32_t p_Npad = 0, p_N = 0;
+  int64_t stream_M = 0;           // SNPs of every successful exact-GRM call so far (the dither of the digit rounding indexes the stream)
+  bool in_call = false;           // a call has started writing into the planes and has not finished: see mmg_kin_acc_add_grm
   void release() {
     hipFree(Xq); hipFree(Xp); hipFree(ddig); hipFree(C32); hipFree(dm); hipFree(ds); hipFree(dcoef); hipFree(dc1); hipFree(dc1acc);
     hipFree(dpart); hipFree(dwst);
+    const int64_t sm = stream_M;
+    const bool ic = in_call;
     *this = GrmWorkspace();
+    stream_M = sm; in_call = ic;
   }
 };
-struct mmg_kin_acc { int32_t N = 0; double* dC = nullptr; int64_t n_snps = 0; GrmWorkspace ws; };
+struct mmg_kin_acc {
+  int32_t N = 0; double* dC = nullptr; int64_t n_snps = 0; GrmWorkspace ws;
+  bool broken = false;            // a call failed after it had begun to add: the sum is neither with nor without its SNPs
+};
+#define MMG_ACC_USABLE(ctx, a)                                                                                         \
+  do {                                                                                                                 \
+    if ((a)->broken)                                                                                                   \
+      return set_err(ctx, MMG_E_STATE, "the kinship accumulator is unusable: an earlier mmg_kin_acc_add_grm failed "    \
+                                       "part-way through (its SNPs are partly in the sum); create a new accumulator"); \
+  } while (0)
 
 int mmg_kin_acc_create(mmg_ctx* ctx, int32_t N, mmg_kin_acc** out) {
   MMG_ENTER(ctx);
@@ -868,6 +882,7 @@ int mmg_kin_acc_create(mmg_ctx* ctx, int32_t N, mmg_kin_acc** out) {
 int mmg_kin_acc_add(mmg_ctx* ctx, mmg_kin_acc* a, mmg_geno* g, const float* scale, const float* shift) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, a && g && g->N == a->N && (scale == nullptr) == (shift == nullptr));
+  MMG_ACC_USABLE(ctx, a);
   if (g->M == 0) return MMG_OK;
   int rc = kinship_affine_into(ctx, g, scale, shift, a->dC, true);
   if (rc == MMG_OK) a->n_snps += g->M;
@@ -1050,9 +1065,10 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
   int rc = MMG_OK;
   double kin_ms = 0.0;
   ws.pending = true;                                          // from here on the planes hold part of the sum
+  ws.in_call = true;                                          // ... and a return before the end leaves a partial call in them
   for (int64_t mb = 0; mb < M && rc == MMG_OK; mb += CH) {
     const int64_t Mk = round_up(std::min(CH, M - mb), BK);
-    launch_grm_digits(ctx, dm, ds, mb, M, Mk, step, bd, D, ddig, dcoef);
+    launch_grm_digits(ctx, dm, ds, mb, M, Mk, step, bd, D, ddig, dcoef, ws.stream_M);
     const double tp0 = verbose ? now() : 0.0;
     const int8_t* Srow = g->d + mb * (int64_t)g->Npad;     // the chunk's rows in the store (rows M..Mpad are zero)
     {
@@ -1088,7 +1104,7 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
     if (!direct) launch_snp_dot_raw(ctx, Xq, Mk, g->Npad, (int32_t)Mk, dcoef, dc1);
     launch_add_into_f64(ctx, ws.dc1acc, dc1, g->Npad);         // chunk after chunk, in order: deterministic
   }
-  if (rc) { ws.pending = false; ws.p_M = 0; return rc; }       // the planes are not to be trusted: the run is dropped
+  if (rc) return rc;                                          // in_call stays set: the caller marks the accumulator broken
   ctx->grm_ms_total = kin_ms;
   ws.p_c0 += c0;
   ws.p_M += M;
@@ -1097,6 +1113,8 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
   if (!defer) { int rcf = grm_flush(ctx, ws, dC); if (rcf) return rcf; }
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ws.in_call = false;
+  ws.stream_M += M;
   if (verbose) {
     tv_tail = now() - tt0;
     fprintf(stderr, "[grm] N=%d M=%lld D=%d: stats+alloc+memset %.3f s, pack %.3f s, gemms(+launch) %.3f s (kernels %.3f s), "
@@ -1109,8 +1127,13 @@ static int kinship_grm_i8_into(mmg_ctx* ctx, mmg_geno* g, double* dC, GrmWorkspa
 int mmg_kin_acc_add_grm(mmg_ctx* ctx, mmg_kin_acc* a, mmg_geno* g) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, a && g && g->N == a->N);
+  MMG_ACC_USABLE(ctx, a);
   if (g->M == 0) return MMG_OK;
   int rc = kinship_grm_i8_into(ctx, g, a->dC, a->ws);
+  // A failure behind the point where the call began to add (a GEMM launch, a stream error) leaves the int32 planes with part
+  // of this call on top of the earlier calls of the run: neither dropping the run (the earlier calls' SNPs stay counted in
+  // n_snps: advisor r4) nor keeping it gives a sum that matches a count.  The accumulator says so from here on.
+  if (rc != MMG_OK && a->ws.in_call) { a->broken = true; return rc; }
   if (rc == MMG_E_STATE) {                                  // genotype alphabet too wide for int8 digit products
     Scratch sc;
     double *dm = nullptr, *ds = nullptr;
@@ -1137,6 +1160,7 @@ extern "C" int mmg_reml_create_dev(mmg_ctx* ctx, int32_t N, int32_t q, const dou
 int mmg_reml_create_from_acc(mmg_ctx* ctx, mmg_kin_acc* a, int32_t q, const double* X, const double* y, mmg_reml** out) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, a && X && y && out);
+  MMG_ACC_USABLE(ctx, a);
   { int rcf = grm_flush(ctx, a->ws, a->dC); if (rcf) return rcf; }
   return mmg_reml_create_dev(ctx, a->N, q, a->dC, X, y, out);
 }
@@ -1158,6 +1182,7 @@ int mmg_kin_acc_pending(mmg_ctx* ctx, mmg_kin_acc* a, int64_t* n_snps_pending) {
 int mmg_kin_acc_fetch(mmg_ctx* ctx, mmg_kin_acc* a, double* C_out, int64_t* n_snps) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, a && C_out);
+  MMG_ACC_USABLE(ctx, a);
   { int rcf = grm_flush(ctx, a->ws, a->dC); if (rcf) return rcf; }
   MMG_HIP(ctx, hipMemcpyAsync(C_out, a->dC, (size_t)a->N * a->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1168,6 +1193,7 @@ int mmg_kin_acc_fetch(mmg_ctx* ctx, mmg_kin_acc* a, double* C_out, int64_t* n_sn
 int mmg_kin_acc_scale_k(mmg_ctx* ctx, mmg_kin_acc* a, double* scalar_out) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, a != nullptr);
+  MMG_ACC_USABLE(ctx, a);
   { int rcf = grm_flush(ctx, a->ws, a->dC); if (rcf) return rcf; }
   Scratch sc;
   const int64_t N = a->N;
@@ -1192,6 +1218,7 @@ int mmg_kin_acc_scale_k(mmg_ctx* ctx, mmg_kin_acc* a, double* scalar_out) {
 int mmg_kin_acc_allreduce(mmg_ctx* ctx, mmg_comm* comm, mmg_kin_acc* a) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, a != nullptr);
+  MMG_ACC_USABLE(ctx, a);
   { int rcf = grm_flush(ctx, a->ws, a->dC); if (rcf) return rcf; }
   if (!comm || comm->world <= 1) return MMG_OK;
   Scratch sc;

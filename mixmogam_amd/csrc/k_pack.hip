@@ -625,7 +625,8 @@ void launch_grm_weight_stats(mmg_ctx* ctx, const double* mean, const double* sd,
 // coefficient -mean * weight of the rank-one terms; rows past M are zero.  The same IEEE operations the host loop did.
 __global__ __launch_bounds__(256) void grm_digits_kernel(const double* __restrict__ mean, const double* __restrict__ sd,
                                                          int64_t mb, int64_t M, int64_t Mk, double step, int bd, int D,
-                                                         int8_t* __restrict__ dig /*[D][Mk]*/, double* __restrict__ coef) {
+                                                         int8_t* __restrict__ dig /*[D][Mk]*/, double* __restrict__ coef,
+                                                         int64_t stream_pos) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= Mk) return;
   long long Z = 0;
@@ -637,7 +638,10 @@ __global__ __launch_bounds__(256) void grm_digits_kernel(const double* __restric
     // equal weight the SAME rounding error, and with weights 1 / (p (1 - p)), p = count / N, few distinct weights carry most
     // SNPs -- the errors added up like M instead of sqrt(M) (4.8e-5 on entries of 7e4 over 70,000 SNPs of frequency one
     // half, test_gpu_round3).  Dithered, the errors of different SNPs are independent and unbiased whatever the weights.
-    unsigned long long h = (unsigned long long)(mb + k) * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+    // The index is the SNP's position in the accumulator's whole stream (stream_pos = SNPs of the earlier calls): hashed from
+    // the in-call index alone, every call of a chunked pass drew the same u sequence and a position's bias (u - 1/2) added up
+    // coherently over the ~100 calls of a streamed kinship (advisor r4) -- and a stream now rounds the same however it is cut.
+    unsigned long long h = (unsigned long long)(stream_pos + mb + k) * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
     h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 27; h *= 0x94D049BB133111EBull; h ^= h >> 31;
     const double u = (double)(h >> 11) * 0x1.0p-53;
     Z = (long long)floor(w / step + u);
@@ -653,9 +657,9 @@ __global__ __launch_bounds__(256) void grm_digits_kernel(const double* __restric
 }
 
 void launch_grm_digits(mmg_ctx* ctx, const double* mean, const double* sd, int64_t mb, int64_t M, int64_t Mk, double step,
-                       int bd, int D, int8_t* dig, double* coef) {
+                       int bd, int D, int8_t* dig, double* coef, int64_t stream_pos) {
   hipLaunchKernelGGL(grm_digits_kernel, dim3((unsigned)((Mk + 255) / 256)), dim3(256), 0, ctx->stream, mean, sd, mb, M, Mk,
-                     step, bd, D, dig, coef);
+                     step, bd, D, dig, coef, stream_pos);
 }
 
 __global__ void add_into_f64_kernel(double* __restrict__ dst, const double* __restrict__ src, int64_t n) {

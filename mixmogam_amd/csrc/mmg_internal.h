@@ -218,7 +218,7 @@ int64_t grm_partial_doubles(int64_t Mk, int32_t Npad);
 int64_t grm_weight_blocks(int64_t M);
 void launch_grm_weight_stats(mmg_ctx*, const double* mean, const double* sd, int64_t M, double* out /*[blocks][4]*/);
 void launch_grm_digits(mmg_ctx*, const double* mean, const double* sd, int64_t mb, int64_t M, int64_t Mk, double step, int bd,
-                       int D, int8_t* dig, double* coef);
+                       int D, int8_t* dig, double* coef, int64_t stream_pos = 0);   // stream_pos: SNPs of the accumulator's earlier calls
 void launch_add_into_f64(mmg_ctx*, double* dst, const double* src, int64_t n);
 void launch_grm_scale_rows(mmg_ctx*, const int8_t* S, int64_t rows_valid, int64_t Mk, int32_t Npad, bool neg, int8_t* Xp,
                            const int8_t* dig, int D, const double* coef, double* partial, double* c1, int32_t n_shift = 0);

@@ -106,14 +106,16 @@ def _read_chunk(genot_data, chrom, sel, out=None):
     n_ind = raw.shape[1]                                                 # bytes per row (packed: ceil(N*bits/8))
     want = np.uint8 if bits else np.int8
     if (out is not None and isinstance(raw, np.memmap) and raw.dtype == want and raw.flags['C_CONTIGUOUS']
-            and out.nbytes >= (hi - lo) * n_ind and getattr(raw, 'filename', None) is not None):
-        block = out.view(want)[:(hi - lo) * n_ind].reshape(hi - lo, n_ind)
-        mv = memoryview(block).cast('B')
+            and out.nbytes >= len(sel) * n_ind and getattr(raw, 'filename', None) is not None):
         base = raw.offset + lo * n_ind
+        whole = out.nbytes >= (hi - lo) * n_ind                          # the span fits: one contiguous read, filtered in place
+        rows_in = hi - lo if whole else len(sel)
+        block = out.view(want)[:rows_in * n_ind].reshape(rows_in, n_ind)
+        mv = memoryview(block).cast('B')
 
-        def part(a, b):                                                  # bytes [a, b) of the block; GIL released in readinto
-            with open(raw.filename, 'rb', buffering=0) as f:
-                f.seek(base + a)
+        def part(a, b, src=None):                                        # file bytes [src, src + b - a) -> buffer bytes [a, b)
+            with open(raw.filename, 'rb', buffering=0) as f:             # (GIL released in readinto)
+                f.seek(base + (a if src is None else src))
                 got = a
                 while got < b:
                     k = f.readinto(mv[got:b])
@@ -121,8 +123,35 @@ def _read_chunk(genot_data, chrom, sel, out=None):
                         raise IOError("short read from %s" % raw.filename)
                     got += k
 
+        rel_idx = np.asarray(sel, dtype=np.int64) - lo
+        if len(sel) != hi - lo:
+            breaks = np.nonzero(np.diff(rel_idx) != 1)[0] + 1
+            starts = np.concatenate(([0], breaks)).tolist()
+            ends = np.concatenate((breaks, [len(rel_idx)])).tolist()
         nbytes = len(mv)
         nthr = min(_READ_THREADS, max(1, nbytes >> 23))                  # one reader per 8 MB, a page-cache copy each
+        if not whole:
+            # a MAF filter that keeps few rows stretches the span far beyond the chunk (chunk_size / kept fraction): the
+            # page-locked buffers are bounded (_resident_chunks), so the kept runs are read one by one, each straight to
+            # its place -- no row that the filter drops is read at all (advisor r4: 2 x 60 GB pinned at N = 50,000, 10 % kept)
+            def runs(r0, r1):
+                with open(raw.filename, 'rb', buffering=0) as f:
+                    for s0, e0 in zip(starts[r0:r1], ends[r0:r1]):
+                        f.seek(base + int(rel_idx[s0]) * n_ind)
+                        got, end = s0 * n_ind, e0 * n_ind
+                        while got < end:
+                            k = f.readinto(mv[got:end])
+                            if not k:
+                                raise IOError("short read from %s" % raw.filename)
+                            got += k
+            if nthr == 1 or len(starts) < 2 * nthr:
+                runs(0, len(starts))
+            else:
+                from concurrent.futures import ThreadPoolExecutor
+                cuts = [len(starts) * t // nthr for t in range(nthr + 1)]
+                with ThreadPoolExecutor(max_workers=nthr) as ex:
+                    list(ex.map(lambda ab: runs(*ab), zip(cuts[:-1], cuts[1:])))
+            return block
         if nthr == 1:
             part(0, nbytes)
         else:
@@ -135,13 +164,9 @@ def _read_chunk(genot_data, chrom, sel, out=None):
             # ever moves towards the front: memmove).  Before: the span was faulted in through the mapping and the subset
             # copied out by fancy indexing -- 5 GB/s of an int8 container against 50 through the page-locked buffer
             import ctypes
-            rel_idx = np.asarray(sel, dtype=np.int64) - lo
-            breaks = np.nonzero(np.diff(rel_idx) != 1)[0] + 1
-            starts = np.concatenate(([0], breaks))
-            ends = np.concatenate((breaks, [len(rel_idx)]))
             addr = block.ctypes.data
             dst = 0
-            for s0, e0 in zip(starts.tolist(), ends.tolist()):
+            for s0, e0 in zip(starts, ends):
                 src, cnt = int(rel_idx[s0]), e0 - s0
                 if src != dst:
                     ctypes.memmove(addr + dst * n_ind, addr + src * n_ind, cnt * n_ind)
@@ -214,13 +239,16 @@ def _resident_chunks(ctx, genot_data, plan, rank=0, world=1, prefetch=True, reus
         # file ...): allocating them costs ~0.1 s, as much as streaming 5 GB
         key = (ctx.device, n_ind, row_bytes)
         cached = _POOLS.get(key)
-        if cached is None or cached[0] < cap or cached[2][0].nbytes < span * row_bytes:
+        # the staging buffers hold the SPAN of a chunk (first to last selected row: read contiguously, filtered in place) as long
+        # as that is no more than the chunk's own rows or KIN_MAX_BYTES, whichever is larger; a sparser selection is read run by
+        # run (_read_chunk), so a MAF filter cannot stretch the page-locked memory beyond 2 x max(chunk, 6 GB) (advisor r4)
+        stage_rows = max(cap, min(span, int(KIN_MAX_BYTES) // max(1, row_bytes)))
+        if cached is None or cached[0] < cap or cached[2][0].nbytes < stage_rows * row_bytes:
             if cached is not None:
                 for g in cached[1]:
                     g.close()
-            # the staging buffers hold the SPAN of a chunk (first to last selected row: read contiguously, filtered in place)
             cached = _POOLS[key] = (cap, [up.geno(M=cap, N=n_ind) for _ in range(2)],
-                                    [up.pinned_empty(max(cap, span) * row_bytes, dtype=np.int8) for _ in range(2)])
+                                    [up.pinned_empty(stage_rows * row_bytes, dtype=np.int8) for _ in range(2)])
         pool, host = cached[1], cached[2]
 
     def load(ci, slot):
@@ -406,7 +434,8 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
     Footprint of the streaming pools (kept between calls until release_pools()): two HBM chunk stores and two page-locked
     host staging buffers of the largest chunk each -- chunk_size SNPs for the scan pass, and up to KIN_MAX_BYTES (6 GB) of
     int8 rows per buffer for the kinship pass, whose chunks are merged to >= 65,536 SNPs (_merge_plan): at most 2 x 6 GB
-    of pinned host memory and 2 x 6 GB of HBM.  All chromosomes of a stream must hold the same individuals; the buffers
+    of HBM, and 2 x max(largest chunk, 6 GB) of pinned host memory whatever the MAF filter keeps (a chunk whose span of
+    file rows exceeds that is read run by run: _read_chunk).  All chromosomes of a stream must hold the same individuals; the buffers
     are sized by the largest row (raw int8 or bit-packed) over the plan.
 
     timings: a dict that receives the wall seconds of the stages (kinship_pass_s, reml_s, scan_model_s, scan_pass_s,
