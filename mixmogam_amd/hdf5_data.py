@@ -363,6 +363,13 @@ def _ibd_kinship_normalised(ctx, genot_data, n_indivs, chunk_size, coll=None):
     return kinship.scale_k(k_sum / float(n_snps)), n_snps
 
 
+def _warn_maf_ignored(min_maf):
+    if min_maf is not None:
+        import warnings
+        warnings.warn("calculate_ibd_kinship: min_maf is ignored for trees with pre-normalised `snps` datasets (the "
+                      "reference's own function has no filter, hdf5_data.py:17-62)")
+
+
 def calculate_ibd_kinship(hdf5_filename, n_indivs=None, min_maf=None, chunk_size=100000, overwrite=False, ctx=None,
                           coll=None):
     """hdf5_data.py:17-62: K = sum_m z_m z_m' / n_snps with z = (s - mean)/std per SNP, scaled with scale_k's rule.
@@ -377,6 +384,7 @@ def calculate_ibd_kinship(hdf5_filename, n_indivs=None, min_maf=None, chunk_size
         if 'kinship' in h5f.keys() and not overwrite:
             return np.asarray(h5f['kinship'][...]), None
         if any('snps' in h5f['genot_data'][chrom].keys() for chrom in h5f['genot_data'].keys()):
+            _warn_maf_ignored(min_maf)
             k, n_snps = _ibd_kinship_normalised(ctx, h5f['genot_data'], n, chunk_size, coll)   # :37,44
         else:
             plan = _chunk_plan(h5f['genot_data'], min_maf, chunk_size)
@@ -388,6 +396,7 @@ def calculate_ibd_kinship(hdf5_filename, n_indivs=None, min_maf=None, chunk_size
             h5f.flush()
         return k, n_snps
     if any('snps' in hdf5_filename[chrom].keys() for chrom in hdf5_filename.keys()):
+        _warn_maf_ignored(min_maf)
         return _ibd_kinship_normalised(ctx, hdf5_filename, n_indivs, chunk_size, coll)
     plan = _chunk_plan(hdf5_filename, min_maf, chunk_size)
     return _ibd_kinship(ctx, hdf5_filename, n_indivs, plan, coll)

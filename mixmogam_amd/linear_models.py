@@ -852,12 +852,12 @@ class LinearMixedModel(object):
                 B = np.empty((num_snps, q + 1))
                 B[:, :q] = -(Cs * b_snp).T
                 B[:, q] = b_snp
-                B[~ok] = np.asarray(prep['h0_betas'], dtype=np.float64)[None, :] if q + 1 == len(prep['h0_betas']) else np.nan
-                betas = list(B)                                          # per SNP the q + 1 coefficients (rows of one array:
-                                                                         # 1.5 M Python floats cost 0.2 s at M = 500,000)
-                if q + 1 != len(prep['h0_betas']):                       # (:1305: a rank-deficient SNP keeps the null model's q values)
-                    for j in np.nonzero(~ok)[0]:
-                        betas[j] = list(prep['h0_betas'])
+                # 'betas': per SNP the q + 1 coefficients as a ROW OF ONE ARRAY (q + 1 numpy floats; the reference builds a list
+                # of Python floats per SNP -- 1.5 M of them cost 0.2 s at M = 500,000); a rank-deficient SNP keeps the null
+                # model's q values as a plain list, as in the reference (:1305)
+                betas = list(B)
+                for j in np.nonzero(~ok)[0]:
+                    betas[j] = list(prep['h0_betas'])
                 res_d['betas'] = betas
             if return_transformed_snps:                                  # :1309-1321,:1355-1356
                 res_d['t_snps'] = self._transformed_snps(g, H_sqrt_inv, Z, project=not with_betas)

@@ -6,7 +6,7 @@
 set -u
 cd "$(dirname "$0")/.."
 export MMG_LIB="$PWD/mixmogam_amd/lib/libmixmogam_hip_guard.so"
-[ -f "$MMG_LIB" ] || { echo "build the guard library first: make -C mixmogam_amd/csrc GUARD=1"; exit 1; }
+make -q -C mixmogam_amd/csrc GUARD=1 || { echo "libmixmogam_hip_guard.so is missing or older than its sources: make -C mixmogam_amd/csrc GUARD=1"; exit 1; }
 export MMG_GUARD_MODE=$1 MMG_GUARD_ALIGN=$2
 log=gpurun_out/$3.log
 shift 3

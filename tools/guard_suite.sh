@@ -3,7 +3,10 @@
 set -u
 cd "$(dirname "$0")/.."
 export MMG_LIB="$PWD/mixmogam_amd/lib/libmixmogam_hip_guard.so"
-[ -f "$MMG_LIB" ] || make -C mixmogam_amd/csrc GUARD=1 -j8 > /dev/null || exit 1   # run `make -C mixmogam_amd/csrc GUARD=1` before gpurun: the built library travels, a rebuild on the box costs GPU minutes
+# the library must be current with its sources (build it on the build host first: it travels with the snapshot, a rebuild
+# on the box costs GPU minutes); `make -q` answers without building
+make -q -C mixmogam_amd/csrc GUARD=1 || { echo "libmixmogam_hip_guard.so is missing or older than its sources: make -C mixmogam_amd/csrc GUARD=1"; exit 1; }
+echo "guard library: $(stat -c %y "$MMG_LIB")"
 out=gpurun_out/guard_suite.log
 mkdir -p gpurun_out
 python - > $out 2>&1 <<'PY'
