@@ -246,17 +246,21 @@ def main():
         acc.close()
     K = kinship.scale_k(counts.astype(np.float64) / (2.0 * Mtot) + 0.5)
 
-    # ---- eigh + REML (replicated), model -> device
+    # ---- eigh + REML (replicated), model -> device.  --mode perm (round 5): no eigendecomposition anywhere -- REML through the
+    # band reduction, the scan model and the permutation plan from the Cholesky factor in HBM (bench_perm)
     lmm = lm.LinearMixedModel(y, ctx=ctx)
     lmm.add_random_effect(K)
     t0 = time.time()
-    eig_L = lmm._get_eigen_L_()
-    eigh_ms = ctx.kernel_ms("eigh")
-    est = lmm.get_estimates(eig_L, method="REML")       # REML sums from eig_L alone: no second eigh
-    prep = lmm.scan_prepare(est["H_sqrt_inv"])
-    ctx.scan_set_model(prep["A"], prep["w"], D)
+    eig_L = est = prep = None
+    eigh_ms = None
+    if mode != "perm":
+        eig_L = lmm._get_eigen_L_()
+        eigh_ms = ctx.kernel_ms("eigh")
+        est = lmm.get_estimates(eig_L, method="REML")       # REML sums from eig_L alone: no second eigh
+        prep = lmm.scan_prepare(est["H_sqrt_inv"])
+        ctx.scan_set_model(prep["A"], prep["w"], D)
+        n_p = prep["n_p"]
     model_s = time.time() - t0
-    n_p = prep["n_p"]
     t_setup = time.time() - t_setup
 
     def barrier():
@@ -269,7 +273,7 @@ def main():
               "vs_baseline": None, "data": "synthetic", "rccl_nranks": rccl_nranks, "mode": mode}
 
     if mode == "perm":
-        res = bench_perm(args, ctx, coll, comm_h, g, lmm, est, N, M, Mtot, barrier, common)
+        res = bench_perm(args, ctx, coll, comm_h, g, lmm, y, N, M, Mtot, barrier, common)
     elif mode == "multi":
         res = bench_multi(args, ctx, coll, g, lmm, eig_L, N, M, Mtot, barrier, common)
     else:
@@ -336,10 +340,13 @@ def main():
         if e2e is not None:
             e2e_per_rank = [float(v) for v in coll.allgather(np.array([e2e]))]
     if rank == 0:
-        res.update({"eigh_ms": eigh_ms, "model_setup_s": model_s, "setup_s": t_setup, "delta": float(est["delta"]),
-                    "device": info, "setup_s_per_rank": setup_per_rank,
+        res.update({"model_setup_s": model_s, "setup_s": t_setup, "device": info, "setup_s_per_rank": setup_per_rank,
                     "setup_note": "genotype fill + kinship (SNP-sharded, all-reduced) + eigh + REML + scan model "
-                                  "(replicated on every rank), outside the timed region"})
+                                  "(replicated on every rank), outside the timed region" if mode != "perm" else
+                                  "genotype fill + kinship (SNP-sharded, all-reduced), outside the timed region; REML, the scan "
+                                  "model and the permutation plan are in model_and_plan_s (no eigendecomposition)"})
+        if est is not None:
+            res.update({"eigh_ms": eigh_ms, "delta": float(est["delta"])})
         if e2e is not None:
             res.update({"end_to_end_emmax_s": max(e2e_per_rank), "end_to_end_emmax_s_per_rank": e2e_per_rank,
                         "end_to_end_emmax_first_call_s": e2e_first, "end_to_end_emmax_phases_s": e2e_timings,
@@ -746,23 +753,41 @@ def multi_record(ctx, g, lmm, N, M, P=16):
 
 
 # ----------------------------------------------------------------------------------------------- C4: permutation test
-def bench_perm(args, ctx, coll, comm_h, g, lmm, est, N, M, Mtot, barrier, common):
-    P = args.perms
-    H = np.asarray(est["H_sqrt_inv"])
-    y = lmm.Y.reshape(-1) - lmm.Y.mean()                                  # linear_models.py:1140
-    h0_X = H @ lmm.X
-    Yt = H @ y
-    b0 = np.linalg.lstsq(h0_X, Yt, rcond=None)[0]
-    r = Yt - h0_X @ b0
-    h0_rss = float(r @ r)
-    r = r - h0_X @ b0                                                     # :1147 (kept)
-    idx = np.array([np.random.RandomState(20242 + p).permutation(N) for p in range(P)])
-    Ys = np.ascontiguousarray(r[idx].T)
+def perm_model_and_plan(ctx, lm, y, K_or_lmm, idx):
+    """REML, scan model (loaded into the context) and permutation plan of hdf5_data.run_emmax_perm's flow without an
+    eigendecomposition: the variance ratio from the band reduction of K, H_sqrt_inv := L^-1 of K + delta I = L L' where the
+    scan model left it in HBM (linear_models.perm_h_from_cholesky).  Returns (prep, pp, plan, reml) -- the caller closes reml."""
+    from scipy import linalg as _la
+    if isinstance(K_or_lmm, lm.LinearMixedModel):
+        lmm = K_or_lmm
+    else:
+        lmm = lm.LinearMixedModel(y, ctx=ctx)
+        lmm.add_random_effect(K_or_lmm)
+    est = lmm.get_estimates_eigen_free()
+    reml, delta = est["reml"], est["delta"]
+    prep = lmm.scan_model_eigen_free(est)
+    prep["delta"] = delta
+    lmm_p = lm.LinearMixedModel(y, ctx=ctx)                               # perm_prepare centres Y in place (:1140)
+    lmm_p.random_effects = lmm.random_effects
+    pp = lmm_p.perm_prepare(None, num_perm=len(idx), perm_idx=idx, reml=reml, delta=delta)
+    plan = reml.perm_plan(delta, pp["Ys"], pp["h0_rss"])
+    Qc = _la.qr(pp["h0_X"], mode="economic")[0]
+    prep["HtQ"] = np.ascontiguousarray(reml.linv_apply(delta, Qc, trans=True).T)
+    return prep, pp, plan, reml
 
-    # the SNP-independent half (H'H digit planes, W' = Ys'H digit image, v, Ys.Ys) is model setup, like scan_set_model
+
+def bench_perm(args, ctx, coll, comm_h, g, lmm, y, N, M, Mtot, barrier, common):
+    from mixmogam_amd import kinship, linear_models as lm
+    P = args.perms
+    idx = np.array([np.random.RandomState(20242 + p).permutation(N) for p in range(P)])
+    # the SNP-independent half (REML, the scan model, H'H digit planes, W' = Ys'H digit image, v, Ys.Ys) is model setup
+    perm_model_and_plan(ctx, lm, y, lmm, idx)[3].close()                  # (the first call of a process loads code objects)
     t0 = time.time()
-    plan = ctx.perm_plan(H, Ys, h0_rss)
+    prep, pp, plan, reml = perm_model_and_plan(ctx, lm, y, lmm, idx)
     plan_s = time.time() - t0
+    H = reml.linv(prep["delta"]) if (not args.no_cpu_baseline and common["n_gpus"] == 1) else None
+    reml.close()
+    Ys, h0_rss = pp["Ys"], pp["h0_rss"]
 
     def step():
         return plan.run(g, comm=comm_h)                                    # min over the SNP blocks of ALL ranks, in HBM
@@ -790,8 +815,6 @@ def bench_perm(args, ctx, coll, comm_h, g, lmm, est, N, M, Mtot, barrier, common
         if not np.array_equal(chk, min_rss):
             raise SystemExit("ranks disagree on the permutation minima")
     # the flow of hdf5_data.run_emmax_perm: the scan of the SNPs, then the test rebuilt from the scan's quadratic forms
-    prep = lmm.scan_prepare(est["H_sqrt_inv"])
-    ctx.scan_set_model(prep["A"], prep["w"], 0)
     ctx.scan(g, prep["h0_rss"], prep["n_p"], fetch=False)
     plan.run(g, comm=comm_h, after_scan_HtQ=prep["HtQ"])
     barrier()
@@ -803,6 +826,31 @@ def bench_perm(args, ctx, coll, comm_h, g, lmm, est, N, M, Mtot, barrier, common
     fast_elapsed = time.time() - t0
     if coll is not None:
         fast_elapsed = float(coll.allreduce(np.array([fast_elapsed]), "max")[0])
+    # ---- the whole job, kinship -> 5 % threshold, on the resident genotypes: IBS counts of every rank's SNP
+    # block summed over RCCL and scaled on the device, REML + scan model + plan (replicated), scan + after-scan test of this
+    # rank's block with the RCCL MAX of the statistics, thresholds on the host
+    def whole_job():
+        t0 = time.time()
+        K2 = ctx.kinship_ibs(g, scaled=True, comm=comm_h, m_total=Mtot)
+        tk = time.time()
+        prep2, pp2, plan2, reml2 = perm_model_and_plan(ctx, lm, y, K2, idx)
+        reml2.close()
+        tm = time.time()
+        ps = ctx.scan(g, prep2["h0_rss"], prep2["n_p"])["ps"]
+        mr = plan2.run(g, comm=comm_h, after_scan_HtQ=prep2["HtQ"])
+        plan2.close()
+        mf = (pp2["h0_rss"] / mr - 1.0) * pp2["n_p"]
+        mp = ctx.f_sf(mf, pp2["n_p"])
+        thr = float(np.sort(mp)[P // 20])
+        t1 = time.time()
+        return t1 - t0, {"kinship": tk - t0, "reml_model_plan": tm - tk, "scan_test_threshold": t1 - tm}, thr, float(ps.min())
+    whole_job()
+    barrier()
+    e2e = [whole_job() for _ in range(2)]
+    barrier()
+    e2e_s, e2e_phases, e2e_thr, _mp = min(e2e, key=lambda v: v[0])
+    if coll is not None:
+        e2e_s = float(coll.allreduce(np.array([e2e_s]), "max")[0])
     if (coll.rank if coll is not None else 0) != 0:
         return None
     n_p = N - 2
@@ -833,7 +881,12 @@ def bench_perm(args, ctx, coll, comm_h, g, lmm, est, N, M, Mtot, barrier, common
                                        "frac": (2.0 * N * N + 4.0 * N) * M / (float(np.mean(tt_ms)) * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
                                        "note": "the same kernel and algorithmic work as the headline scan (roofline of --mode weak)"}
                                       if tt_ms else None),
-                "perm_gemm_ms_per_rank": per_rank, "plan_setup_s": plan_s,
+                "perm_gemm_ms_per_rank": per_rank, "model_and_plan_s": plan_s,
+                "end_to_end_perm_s": e2e_s, "end_to_end_perm_phases_s": e2e_phases, "end_to_end_threshold_05_min_p": e2e_thr,
+                "end_to_end_note": "kinship (IBS counts of the resident SNPs, RCCL sum, scale_k on the device) -> REML "
+                                   "(band reduction) -> scan model + permutation plan from the Cholesky factor in HBM "
+                                   "(H_sqrt_inv := L^-1, no eigendecomposition) -> EMMAX scan + after-scan permutation test "
+                                   "-> 5 % threshold on the host; best of two warm runs, max over the ranks",
                 "scan_plus_test_after_scan": {
                     "ms_per_step": 1e3 * fast_elapsed / args.steps,
                     "note": "EMMAX scan of the SNPs + permutation test rebuilt from the scan's quadratic forms "

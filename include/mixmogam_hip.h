@@ -239,6 +239,16 @@ int mmg_reml_scan_model(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, do
  * eigendecomposition either. */
 int mmg_reml_scan_model_c(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, double* h0_rss, double* beta,
                           double* mahalanobis_rss, double* C_out);
+/* H_sqrt_inv without an eigendecomposition (round 5).  The reference's H_sqrt_inv = diag((lambda + delta)^-1/2) U'
+ * (linear_models.py:898) is one matrix H with H'H = (K + delta I)^-1; every consumer of it -- the null fit H X, H y
+ * (:1141-1147, :1195-1198), the transformed SNPs H s (:1160, :1210), the scan model -- works with any such H (the reference's
+ * own is fixed only up to LAPACK's eigenvector signs).  L^-1 of K + delta I = L L' is one: it is what the scan model of the
+ * same delta has left in the workspace, else one factorisation + triangular inverse (N = 5000: ~10 ms against 265 ms of
+ * rocSOLVER's dsyevd).
+ * mmg_reml_linv_apply: out [N x k] = L^-1 V (trans = 0) or L^-T V (trans = 1); V, out column-major N x k on the host.
+ * mmg_reml_linv_fetch: H_out [N x N] row-major = L^-1 (lower triangular), for callers that want the matrix itself. */
+int mmg_reml_linv_apply(mmg_ctx* ctx, mmg_reml* r, double delta, int32_t trans, const double* V, int32_t k, double* out);
+int mmg_reml_linv_fetch(mmg_ctx* ctx, mmg_reml* r, double delta, double* H_out);
 
 /* ---- EMMAX scan (replaces the loop of linear_models.py:1316-1349) ------------------------- */
 /* Loads the SNP-independent model onto the device:
@@ -374,6 +384,13 @@ int mmg_perm_plan_create(mmg_ctx* ctx, int32_t N, const double* Ht, const double
  * (Xs - mean(Xs), :1211): t_m = C H s_m with C = I - 11'/n, i.e. this plan built on Ht = C H.  Stand-alone runs only. */
 int mmg_perm_plan_create_ex(mmg_ctx* ctx, int32_t N, const double* Ht, const double* Ys, int32_t P, double h0_rss,
                             int flags, mmg_perm_plan** plan);
+/* The plan with H = L^-1 of K + delta I = L L' taken from a REML workspace as it lies in HBM (mmg_reml_linv_apply above): the
+ * permutation test of _emmax_permutations_ / emmax_permutations / hdf5_data.run_emmax_perm without rocSOLVER's dsyevd and
+ * without an N x N matrix crossing PCIe.  Ys must be shuffles of residuals computed in the same basis (H X, H y from
+ * mmg_reml_linv_apply of this workspace and delta).  flags bit 0 as above; bit 1 (both entry points): H <- C H on the device
+ * (the public test's centring of the transformed SNP), so that the caller need not form C H. */
+int mmg_perm_plan_create_from_reml(mmg_ctx* ctx, mmg_reml* r, double delta, const double* Ys, int32_t P, double h0_rss,
+                                   int flags, mmg_perm_plan** plan);
 int mmg_perm_plan_run(mmg_ctx* ctx, mmg_comm* comm, mmg_perm_plan* plan, mmg_geno* g, const double* HtQ, int32_t q,
                       double* min_rss);
 int mmg_perm_plan_destroy(mmg_ctx* ctx, mmg_perm_plan* plan);

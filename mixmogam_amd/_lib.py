@@ -91,6 +91,9 @@ PROTOTYPES = {
     "mmg_reml_band_info": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mmg_reml_scan_model": (C.c_int, [c_vp, c_vp, C.c_double, C.c_int, c_f64p, c_vp, c_f64p]),
     "mmg_reml_scan_model_c": (C.c_int, [c_vp, c_vp, C.c_double, C.c_int, c_f64p, c_vp, c_f64p, c_vp]),
+    "mmg_reml_linv_apply": (C.c_int, [c_vp, c_vp, C.c_double, C.c_int32, c_vp, C.c_int32, c_vp]),
+    "mmg_reml_linv_fetch": (C.c_int, [c_vp, c_vp, C.c_double, c_vp]),
+    "mmg_perm_plan_create_from_reml": (C.c_int, [c_vp, c_vp, C.c_double, c_vp, C.c_int32, C.c_double, C.c_int, C.POINTER(c_vp)]),
     "mmg_rot_create": (C.c_int, [c_vp, C.c_int32, c_vp, C.c_int64, C.POINTER(c_vp)]),
     "mmg_rot_destroy": (C.c_int, [c_vp, c_vp]),
     "mmg_rot_load": (C.c_int, [c_vp, c_vp, c_vp]),
@@ -406,14 +409,23 @@ class PermPlan(object):
     """SNP-independent half of the EMMAX permutation test on the device (mmg_perm_plan_*): built once per (H, Ys),
     run over any number of genotype stores."""
 
-    def __init__(self, ctx, H, Ys, h0_rss, centre_snps=True):
-        H = _arr(H, np.float64)
+    def __init__(self, ctx, H, Ys, h0_rss, centre_snps=True, reml=None, delta=None, centre_H=False):
+        """H: the N x N matrix, or None with reml= / delta=: H = L^-1 of K + delta I = L L' as the REML workspace holds it in
+        HBM (mmg_perm_plan_create_from_reml).  centre_H: H <- C H on the device (the public test, flags bit 1)."""
         Ys = _arr(Ys, np.float64)
-        self.ctx, self.N, self.P = ctx, H.shape[0], Ys.shape[1]
-        assert H.shape == (self.N, self.N) and Ys.shape[0] == self.N
+        flags = (0 if centre_snps else 1) | (2 if centre_H else 0)
         h = c_vp()
-        ctx._check(ctx.lib.mmg_perm_plan_create_ex(ctx.h, self.N, _ptr(H), _ptr(Ys), self.P, float(h0_rss),
-                                                   0 if centre_snps else 1, C.byref(h)))
+        if reml is not None:
+            self.ctx, self.N, self.P = ctx, reml.N, Ys.shape[1]
+            assert H is None and Ys.shape[0] == self.N
+            ctx._check(ctx.lib.mmg_perm_plan_create_from_reml(ctx.h, reml.h, float(delta), _ptr(Ys), self.P, float(h0_rss),
+                                                              flags, C.byref(h)))
+        else:
+            H = _arr(H, np.float64)
+            self.ctx, self.N, self.P = ctx, H.shape[0], Ys.shape[1]
+            assert H.shape == (self.N, self.N) and Ys.shape[0] == self.N
+            ctx._check(ctx.lib.mmg_perm_plan_create_ex(ctx.h, self.N, _ptr(H), _ptr(Ys), self.P, float(h0_rss), flags,
+                                                       C.byref(h)))
         self.h = h
 
     def run(self, g, comm=None, after_scan_HtQ=None):
@@ -529,6 +541,26 @@ class Reml(object):
         self.ctx._check(self.ctx.lib.mmg_reml_scan_model_c(self.ctx.h, self.h, float(delta), int(ndigits), C.byref(h0),
                                                            _ptr(beta), C.byref(mah), _ptr(Cm)))
         return (h0.value, beta, Cm) if want_C else (h0.value, beta)
+
+    def linv_apply(self, delta, V, trans=False):
+        """L^-1 V (or L^-T V) for K + delta I = L L': H V for the square root H = L^-1 of (K + delta I)^-1 that stands in for
+        the reference's H_sqrt_inv (mmg_reml_linv_apply).  V: [N] or [N x k]; returns the same shape."""
+        V = np.asarray(V, dtype=np.float64)
+        one = V.ndim == 1
+        Vc = np.asfortranarray(V.reshape(self.N, -1))
+        out = np.empty(Vc.shape, order='F')
+        self.ctx._check(self.ctx.lib.mmg_reml_linv_apply(self.ctx.h, self.h, float(delta), 1 if trans else 0, _ptr(Vc), Vc.shape[1],
+                                                         _ptr(out)))
+        return out[:, 0].copy() if one else out
+
+    def linv(self, delta):
+        """L^-1 itself, [N x N] lower triangular: a matrix H with H'H = (K + delta I)^-1 (mmg_reml_linv_fetch)."""
+        H = np.empty((self.N, self.N))
+        self.ctx._check(self.ctx.lib.mmg_reml_linv_fetch(self.ctx.h, self.h, float(delta), _ptr(H)))
+        return H
+
+    def perm_plan(self, delta, Ys, h0_rss, centre_snps=True, centre_H=False):
+        return PermPlan(self.ctx, None, Ys, h0_rss, centre_snps=centre_snps, reml=self, delta=delta, centre_H=centre_H)
 
     def close(self):
         if self.h is not None:

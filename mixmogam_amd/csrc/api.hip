@@ -1994,11 +1994,12 @@ int mmg_perm_plan_create(mmg_ctx* ctx, int32_t N, const double* Ht, const double
   return mmg_perm_plan_create_ex(ctx, N, Ht, Ys, P, h0_rss, 0, out);
 }
 
-int mmg_perm_plan_create_ex(mmg_ctx* ctx, int32_t N, const double* Ht, const double* Ys, int32_t P, double h0_rss,
-                            int flags, mmg_perm_plan** out) {
+// The plan from H on the device.  dH: [N x N]; h_transposed: the buffer is H' row-major (= H column-major: the L^-1 a REML
+// workspace holds).  flags bit 0: no SNP centring; bit 1: H <- C H first (the public permutation test centres the TRANSFORMED
+// SNP, linear_models.py:1211 -- column-centring of H; dH is modified).
+static int perm_plan_build(mmg_ctx* ctx, int32_t N, double* dH, bool h_transposed, const double* Ys, int32_t P, double h0_rss,
+                           int flags, mmg_perm_plan** out) {
   Scratch sc;
-  MMG_ENTER(ctx);
-  MMG_CHECK_ARG(ctx, out && Ht && Ys && N > 0 && P > 0 && (flags & ~1) == 0);
   *out = nullptr;
   mmg_perm_plan* p = new mmg_perm_plan();
   p->centred = !(flags & 1);
@@ -2006,14 +2007,13 @@ int mmg_perm_plan_create_ex(mmg_ctx* ctx, int32_t N, const double* Ht, const dou
   p->yy.assign((size_t)P, 0.0);
   for (int i = 0; i < N; ++i)
     for (int k = 0; k < P; ++k) p->yy[k] += Ys[(size_t)i * P + k] * Ys[(size_t)i * P + k];
-  double *dH = nullptr, *dYs = nullptr, *dA = nullptr, *dWt = nullptr, *dones = nullptr, *dh1 = nullptr;
+  double *dYs = nullptr, *dA = nullptr, *dWt = nullptr, *dones = nullptr, *dh1 = nullptr;
   const int nPT = p->Ppad / 64;
   hipError_t e = hipMalloc(&p->Wq, (size_t)nPT * TM * p->Npad);
   if (e == hipSuccess) e = hipMalloc(&p->dstep, p->Ppad * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&p->dcsum, p->Ppad * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&p->dv, p->Npad * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&p->dmax, p->Ppad * sizeof(double));
-  if (e == hipSuccess) e = sc.alloc(&dH, (size_t)N * N * sizeof(double));
   if (e == hipSuccess) e = sc.alloc(&dYs, (size_t)N * P * sizeof(double));
   if (e == hipSuccess) e = sc.alloc(&dA, (size_t)N * N * sizeof(double));
   if (e == hipSuccess) e = sc.alloc(&dWt, (size_t)P * N * sizeof(double));
@@ -2023,15 +2023,26 @@ int mmg_perm_plan_create_ex(mmg_ctx* ctx, int32_t N, const double* Ht, const dou
   int rc = MMG_OK;
   auto fail = [&](int code) { perm_plan_free(p); return code; };
   std::vector<double> ones((size_t)N, 1.0), h1((size_t)N);
-  if (hipMemcpyAsync(dH, Ht, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-      hipMemcpyAsync(dYs, Ys, (size_t)N * P * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+  if (hipMemcpyAsync(dYs, Ys, (size_t)N * P * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
       hipMemcpyAsync(dones, ones.data(), N * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
       hipMemsetAsync(p->dv, 0, p->Npad * sizeof(double), ctx->stream) != hipSuccess)
     return fail(set_err(ctx, MMG_E_HIP, "permutation plan: upload"));
-  rc = dgemm_dev(ctx, 1, 0, N, N, N, dH, dH, dA);                          // A' = H'H      (t.t = s~' A' s~, :1160,1163)
-  if (rc == MMG_OK) rc = dgemm_dev(ctx, 1, 0, P, N, N, dYs, dH, dWt);      // W' = Ys'H [P x N]  (t.Ys_p = s~ . W_p)
-  if (rc == MMG_OK) rc = dgemm_dev(ctx, 0, 0, N, 1, N, dH, dones, dh1);    // H 1
-  if (rc == MMG_OK) rc = dgemm_dev(ctx, 1, 0, N, 1, N, dH, dh1, p->dv);    // v = H'(H 1) = A' 1
+  const int T = h_transposed ? 1 : 0;                                      // op(dH) = H either way
+  if (flags & 2) {
+    // C H: every column of H minus its mean = every ROW of the transposed buffer; of the plain one, the mean row is taken off
+    if (h_transposed) launch_center_rows(ctx, dH, N, N);
+    else {
+      double* dmean = nullptr;
+      if (sc.alloc(&dmean, N * sizeof(double)) != hipSuccess) return fail(set_err(ctx, MMG_E_NOMEM, "hipMalloc permutation plan"));
+      rc = dgemm_dev(ctx, 1, 0, N, 1, N, dH, dones, dmean);                  // H'1 = column sums
+      if (rc) return fail(rc);
+      launch_sub_row_mean(ctx, dH, N, dmean);
+    }
+  }
+  rc = dgemm_dev(ctx, 1 - T, T, N, N, N, dH, dH, dA);                       // A' = H'H      (t.t = s~' A' s~, :1160,1163)
+  if (rc == MMG_OK) rc = dgemm_dev(ctx, 1, T, P, N, N, dYs, dH, dWt);      // W' = Ys'H [P x N]  (t.Ys_p = s~ . W_p)
+  if (rc == MMG_OK) rc = dgemm_dev(ctx, T, 0, N, 1, N, dH, dones, dh1);    // H 1
+  if (rc == MMG_OK) rc = dgemm_dev(ctx, 1 - T, 0, N, 1, N, dH, dh1, p->dv);   // v = H'(H 1) = A' 1
   if (rc) return fail(rc);
   if (hipMemcpyAsync(h1.data(), dh1, N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess)
@@ -2052,6 +2063,41 @@ int mmg_perm_plan_create_ex(mmg_ctx* ctx, int32_t N, const double* Ht, const dou
   if (rc) return fail(rc);
   *out = p;
   return MMG_OK;
+}
+
+int mmg_perm_plan_create_ex(mmg_ctx* ctx, int32_t N, const double* Ht, const double* Ys, int32_t P, double h0_rss,
+                            int flags, mmg_perm_plan** out) {
+  Scratch sc;
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, out && Ht && Ys && N > 0 && P > 0 && (flags & ~3) == 0);
+  double* dH = nullptr;
+  if (sc.alloc(&dH, (size_t)N * N * sizeof(double)) != hipSuccess) return set_err(ctx, MMG_E_NOMEM, "hipMalloc permutation plan");
+  MMG_HIP(ctx, hipMemcpyAsync(dH, Ht, (size_t)N * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  return perm_plan_build(ctx, N, dH, false, Ys, P, h0_rss, flags, out);
+}
+
+}  // extern "C" (reopened below)
+namespace mmg { int reml_linv_device_opaque(mmg_ctx* ctx, mmg_reml* r, double delta, const double** dLinv, int32_t* N); }
+extern "C" {
+
+// The same plan with H = L^-1 of K + delta I = L L', taken from a REML workspace as it lies in HBM (what the scan model of the
+// same delta left there, or one factorisation + triangular inverse): the permutation test without an eigendecomposition and
+// without an N x N matrix crossing PCIe.  Any H with H'H = (K + delta I)^-1 is a valid H_sqrt_inv (linear_models.py:898 is fixed
+// only up to LAPACK's eigenvector signs); the shuffled residuals Ys live in the basis of the H that is used, so they come from
+// mmg_reml_linv_apply of the same workspace.
+int mmg_perm_plan_create_from_reml(mmg_ctx* ctx, mmg_reml* r, double delta, const double* Ys, int32_t P, double h0_rss,
+                                   int flags, mmg_perm_plan** out) {
+  Scratch sc;
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, out && r && Ys && P > 0 && (flags & ~3) == 0);
+  const double* dLinv = nullptr;
+  int32_t N = 0;
+  int rc = reml_linv_device_opaque(ctx, r, delta, &dLinv, &N);
+  if (rc) return rc;
+  double* dH = nullptr;                                                      // a copy: the builder may centre it
+  if (sc.alloc(&dH, (size_t)N * N * sizeof(double)) != hipSuccess) return set_err(ctx, MMG_E_NOMEM, "hipMalloc permutation plan");
+  MMG_HIP(ctx, hipMemcpyAsync(dH, dLinv, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  return perm_plan_build(ctx, N, dH, true, Ys, P, h0_rss, flags, out);
 }
 
 int mmg_perm_plan_destroy(mmg_ctx* ctx, mmg_perm_plan* p) {

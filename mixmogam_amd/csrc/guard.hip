@@ -259,7 +259,7 @@ hipError_t mmg_guard_free(void* p) {
 }
 
 // Checks every live buffer; returns the number of damaged guards found since the library was loaded.
-extern "C" long mmg_guard_check(void) {
+extern "C" __attribute__((visibility("default"))) long mmg_guard_check(void) {
   std::vector<std::pair<void*, Rec>> live;
   {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -271,25 +271,25 @@ extern "C" long mmg_guard_check(void) {
   g_bad += bad;
   return g_bad;
 }
-extern "C" long mmg_guard_live(void) { std::lock_guard<std::mutex> lk(g_mu); return (long)g_live.size(); }
-extern "C" int mmg_guard_mode(void) { return (int)mode(); }
+extern "C" __attribute__((visibility("default"))) long mmg_guard_live(void) { std::lock_guard<std::mutex> lk(g_mu); return (long)g_live.size(); }
+extern "C" __attribute__((visibility("default"))) int mmg_guard_mode(void) { return (int)mode(); }
 
 // entry-point breadcrumbs (MMG_ENTER): the abort handler prints the last ones; MMG_GUARD_TRACE=1 prints every one as it happens
-extern "C" void mmg_guard_note(const char* fn) {
+extern "C" __attribute__((visibility("default"))) void mmg_guard_note(const char* fn) {
   static const bool live_trace = std::getenv("MMG_GUARD_TRACE") != nullptr;
   const unsigned long i = g_ring_n.fetch_add(1);
   g_ring[i % RING] = Note{fn, (unsigned long)pthread_self()};
   if (live_trace) fprintf(stderr, "[mmg] %lx %s\n", (unsigned long)pthread_self(), fn);
 }
 
-extern "C" void mmg_guard_launched(hipStream_t s) {
+extern "C" __attribute__((visibility("default"))) void mmg_guard_launched(hipStream_t s) {
   static const bool sync = [] { const char* e = std::getenv("MMG_GUARD_SYNC"); return e && e[0] == '1'; }();
   if (sync) (void)hipStreamSynchronize(s);
 }
 
 // Proof that the bands work: one byte written past a 100-byte buffer and one before it must be reported (returns 2; 1 in the
 // fence modes for the side whose neighbour byte is unmapped: fence_left always, fence when MMG_GUARD_ALIGN leaves no padding).
-extern "C" long mmg_guard_selftest(void) {
+extern "C" __attribute__((visibility("default"))) long mmg_guard_selftest(void) {
   void* p = nullptr;
   if (mmg_guard_malloc(&p, 100, "guard.hip(selftest)", 0) != hipSuccess) return -1;
   long before;
@@ -306,7 +306,7 @@ extern "C" long mmg_guard_selftest(void) {
 // Proof that the fence works (fence modes only; ENDS THE PROCESS with a GPU memory fault when it does): a kernel reads one
 // byte past the end (fence) / before the start (fence_left) of a 1000-byte buffer, or, which = 1, a byte of a freed buffer.
 __global__ void guard_probe_kernel(const unsigned char* p, unsigned* out) { out[0] = p[0]; }
-extern "C" long mmg_guard_fault_selftest(int which) {
+extern "C" __attribute__((visibility("default"))) long mmg_guard_fault_selftest(int which) {
   if (mode() == BANDS) return -1;
   void *p = nullptr, *o = nullptr;
   if (mmg_guard_malloc(&p, 1024, "guard.hip(fault selftest)", 0) != hipSuccess) return -2;

@@ -72,6 +72,16 @@ __global__ __launch_bounds__(256) void center_rows_kernel(double* __restrict__ W
   const double mean = s / (double)N;
   for (int k = lane; k < N; k += 64) Wt[(int64_t)p * N + k] -= mean;
 }
+// A [N x N] row-major: every row minus colsum / N (the column-centring C A of a matrix held row by row)
+__global__ void sub_row_mean_kernel(double* __restrict__ A, int32_t N, const double* __restrict__ colsum) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < (int64_t)N * N) A[e] -= colsum[e % N] / (double)N;
+}
+void launch_sub_row_mean(mmg_ctx* ctx, double* A, int32_t N, const double* colsum) {
+  const int64_t total = (int64_t)N * N;
+  hipLaunchKernelGGL(sub_row_mean_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, A, N, colsum);
+}
+
 void launch_center_rows(mmg_ctx* ctx, double* Wt, int32_t N, int32_t P) {
   hipLaunchKernelGGL(center_rows_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, ctx->stream, Wt, N, P);
 }

@@ -4,7 +4,12 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+// The library is built with -fvisibility=hidden (Makefile): what include/mixmogam_hip.h declares is the whole export list --
+// `nm -D` of the built library equals the header (tests/test_host.py) -- and helpers shared between the source files
+// (mmg_reml_create_dev, the mmg:: namespace) stay inside the shared object.
+#pragma GCC visibility push(default)
 #include "../../include/mixmogam_hip.h"
+#pragma GCC visibility pop
 
 #ifdef MMG_GUARD
 // Diagnostic build (make GUARD=1, guard.hip): the library's device buffers get guard bands that are checked when they are freed.
@@ -16,8 +21,8 @@ static inline hipError_t mmg_guard_malloc_t(T** p, size_t bytes, const char* fil
 }
 #define hipMalloc(p, bytes) mmg_guard_malloc_t(p, bytes, __FILE__, __LINE__)
 #define hipFree(p) mmg_guard_free((void*)(p))
-extern "C" void mmg_guard_note(const char* fn);    // breadcrumb: the guard's abort handler prints the last entry points
-extern "C" void mmg_guard_launched(hipStream_t s); // MMG_GUARD_SYNC=1: wait for the kernel just launched (a fault then names it)
+extern "C" __attribute__((visibility("default"))) void mmg_guard_note(const char* fn);    // breadcrumb: the guard's abort handler prints the last entry points
+extern "C" __attribute__((visibility("default"))) void mmg_guard_launched(hipStream_t s); // MMG_GUARD_SYNC=1: wait for the kernel just launched (a fault then names it)
 #define MMG_NOTE_ENTRY() mmg_guard_note(__func__)
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                                   \
@@ -291,6 +296,7 @@ void launch_mirror_ibs(mmg_ctx*, const int* C32, int32_t Npad, int32_t N, const 
 // ---- k_perm.hip: centring of the permutation test's operands, 1 / t.t from a centred quadratic form
 void launch_center_sym(mmg_ctx*, double* A, int32_t N, const double* v, double c0);   // A <- C A C given v = A 1, c0 = 1'A 1
 void launch_center_rows(mmg_ctx*, double* Wt, int32_t N, int32_t P);                  // rows of Wt [P x N] <- row - mean(row)
+void launch_sub_row_mean(mmg_ctx*, double* A, int32_t N, const double* colsum);       // A [N x N] row-major: rows minus colsum / N
 void launch_perm_inv(mmg_ctx*, const mmg_geno*, const mmg_scan_result&, double* d_mu, double* d_inv);
 int upload_group_table(mmg_ctx*, const std::vector<int2>& tab);   // k_perm.hip; into ctx->grp_tab
 int quantize_rows_4digits(mmg_ctx*, const double* dWt, int32_t N, int32_t Npad, int32_t P, int8_t* Wq, double* dstep,

@@ -746,6 +746,7 @@ static int band_reduce_cqr(mmg_ctx* ctx, mmg_reml* r, bool* suspect) {
   if (!r->dBand) RC_HIP(ctx, hipMalloc(&r->dBand, (size_t)N * BAND_LD * sizeof(double)));
   if (!r->dZr) RC_HIP(ctx, hipMalloc(&r->dZr, (size_t)N * q1 * sizeof(double)));
   double* A = r->dL;
+  r->linv_delta = NAN;                                         // the work copy of K takes dL over
   RC_HIP(ctx, hipMemcpyAsync(A, r->dK, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, st));
   RC_HIP(ctx, hipMemcpyAsync(r->dZr, r->dB, (size_t)N * q1 * sizeof(double), hipMemcpyDeviceToDevice, st));
   const int64_t nmax = std::max<int64_t>(N - b, 1);

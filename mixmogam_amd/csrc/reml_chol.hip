@@ -254,6 +254,7 @@ static int reml_point(mmg_ctx* ctx, mmg_reml* r, double delta, bool inverse, boo
   const bool verbose = std::getenv("MMG_REML_VERBOSE") != nullptr;
   auto now = [&]() { (void)hipStreamSynchronize(st); return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t0 = verbose ? now() : 0.0, t1 = 0.0, t2 = 0.0;
+  r->linv_delta = NAN;                                        // dL is about to be overwritten
   RC_HIP(ctx, hipMemcpyAsync(r->dL, r->dK, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, st));
   hipLaunchKernelGGL(add_diag_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, r->dL, N, delta);
   Scratch sc_inv;                                             // the diagonal blocks' inverses live until the inverse is done
@@ -375,6 +376,28 @@ static int reml_point(mmg_ctx* ctx, mmg_reml* r, double delta, bool inverse, boo
 
 namespace mmg {
 int model_from_device_public(mmg_ctx* ctx, int32_t N, const double* dA, const double* dw, int ndigits, bool adaptive);
+
+// L^-1 of K + delta I = L L' in r->dL as a dense lower-triangular matrix (column-major, upper triangle zero): what the scan
+// model has just left there for the same delta, or one factorisation + triangular inverse (N = 5000: ~10 ms).
+// Any H with H'H = (K + delta I)^-1 serves as the reference's H_sqrt_inv (linear_models.py:898 takes diag((lambda +
+// delta)^-1/2) U', fixed only up to LAPACK's eigenvector signs); L^-1 is one that needs no eigendecomposition.
+int reml_linv_device(mmg_ctx* ctx, mmg_reml* r, double delta, const double** dLinv) {
+  if (!(r->linv_delta == delta)) {
+    RemlPoint pt;
+    int rc = reml_point(ctx, r, delta, true, false, pt);
+    if (rc) return rc;
+    const int64_t N = r->N;
+    hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)N), dim3(256), 0, ctx->stream, r->dL, N);
+    RC_HIP(ctx, hipGetLastError());
+    r->linv_delta = delta;
+  }
+  *dLinv = r->dL;
+  return MMG_OK;
+}
+int reml_linv_device_opaque(mmg_ctx* ctx, mmg_reml* r, double delta, const double** dLinv, int32_t* N) {   // for api.hip
+  *N = r->N;
+  return reml_linv_device(ctx, r, delta, dLinv);
+}
 }
 
 extern "C" {
@@ -537,6 +560,7 @@ int mmg_reml_scan_model_c(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, 
   RC_HIP(ctx, sc.alloc(&dGA, (size_t)N * q * sizeof(double)));
   // H^-1 = L^-T L^-1: syrk on the triangular factor used as a dense matrix (upper triangle zeroed first)
   hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)N), dim3(256), 0, st, r->dL, N);
+  r->linv_delta = delta;                                      // (reml_linv_device: the permutation test of the same delta reuses it)
   const double one = 1.0, zero = 0.0, mone = -1.0;
   {
     static const bool dense = [] { const char* e = std::getenv("MMG_REML_LAUUM"); return e && e[0] == '0'; }();   // A/B: dense syrk on the factor
@@ -566,6 +590,56 @@ int mmg_reml_scan_model_c(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, 
   if (C_out)                                                  // GA (N x q, row-major) = V^-1 X (X'V^-1 X)^-1 = C'
     for (int64_t i = 0; i < N; ++i)
       for (int c = 0; c < q; ++c) C_out[(size_t)c * N + i] = pt.GA[(size_t)i * q + c];
+  return MMG_OK;
+}
+
+
+// out [N x k] = L^-1 V (trans = 0) or L^-T V (trans = 1) for K + delta I = L L'; V, out: column-major N x k on the host.
+// With V = [X y]: H X and H y of linear_models.py:1290-1291 for H = L^-1.
+int mmg_reml_linv_apply(mmg_ctx* ctx, mmg_reml* r, double delta, int32_t trans, const double* V, int32_t k, double* out) {
+  if (!ctx) return MMG_E_ARG;
+  MMG_NOTE_ENTRY();
+  RC_HIP(ctx, hipSetDevice(ctx->device));
+  if (!(r && V && out && k >= 1 && (trans == 0 || trans == 1))) return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_linv_apply");
+  rocblas_handle h;
+  int rc = reml_handle(ctx, &h);
+  if (rc) return rc;
+  const double* dLinv = nullptr;
+  if ((rc = reml_linv_device(ctx, r, delta, &dLinv))) return rc;
+  const int64_t N = r->N;
+  Scratch sc;
+  double *dV = nullptr, *dO = nullptr;
+  RC_HIP(ctx, sc.alloc(&dV, (size_t)N * k * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&dO, (size_t)N * k * sizeof(double)));
+  RC_HIP(ctx, hipMemcpyAsync(dV, V, (size_t)N * k * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const double one = 1.0, zero = 0.0;
+  RC_RB(ctx, rocblas_dgemm_64(h, trans ? rocblas_operation_transpose : rocblas_operation_none, rocblas_operation_none, N, k, N, &one,
+                              dLinv, N, dV, N, &zero, dO, N));
+  RC_HIP(ctx, hipMemcpyAsync(out, dO, (size_t)N * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MMG_OK;
+}
+
+// H_out [N x N] row-major = L^-1 (lower triangular): a square root of (K + delta I)^-1 for callers that want the matrix itself
+int mmg_reml_linv_fetch(mmg_ctx* ctx, mmg_reml* r, double delta, double* H_out) {
+  if (!ctx) return MMG_E_ARG;
+  MMG_NOTE_ENTRY();
+  RC_HIP(ctx, hipSetDevice(ctx->device));
+  if (!(r && H_out)) return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_linv_fetch");
+  rocblas_handle h;
+  int rc = reml_handle(ctx, &h);
+  if (rc) return rc;
+  const double* dLinv = nullptr;
+  if ((rc = reml_linv_device(ctx, r, delta, &dLinv))) return rc;
+  const int64_t N = r->N;
+  Scratch sc;
+  double* dT = nullptr;
+  RC_HIP(ctx, sc.alloc(&dT, (size_t)N * N * sizeof(double)));
+  const double one = 1.0, zero = 0.0;                          // out-of-place transpose: column-major L^-1 -> row-major L^-1
+  RC_RB(ctx, rocblas_dgeam(h, rocblas_operation_transpose, rocblas_operation_none, (rocblas_int)N, (rocblas_int)N, &one, dLinv,
+                           (rocblas_int)N, &zero, dT, (rocblas_int)N, dT, (rocblas_int)N));
+  RC_HIP(ctx, hipMemcpyAsync(H_out, dT, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  RC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MMG_OK;
 }
 

@@ -15,6 +15,7 @@ struct mmg_reml {
   int32_t N = 0, q = 0;
   double* dK = nullptr;     // [N x N] symmetric
   double* dL = nullptr;     // [N x N] work: H -> L -> L^-1
+  double linv_delta = NAN;  // dL holds L^-1 of K + linv_delta I = L L' as a dense lower-triangular matrix (upper triangle zero); NaN: it does not
   double* dB = nullptr;     // [N x (q+1)] = [X y] (column-major: column c contiguous)
   double* dZ = nullptr;     // [N x (q+1)]
   double* dG = nullptr;     // [N x (q+1)]
@@ -94,6 +95,8 @@ namespace mmg {
 int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3, double* s4,
                    double* ldh = nullptr, double* trh = nullptr);
 void reml_band_free(mmg_reml* r);
+// reml_chol.hip: makes r->dL hold L^-1 of K + delta I = L L' (column-major, upper triangle zero) and hands the pointer out
+int reml_linv_device(mmg_ctx* ctx, mmg_reml* r, double delta, const double** dLinv);
 // reml_band.hip: W [n x 64] (ld n) = A V on the fp64 matrix pipe for an n x n matrix A of which only the lower triangle is read
 // (column-major, ld lda): symmetric (tri = false) or lower triangular (tri = true); V [n x 64] (ld n).  S > 1: the contraction
 // range in S slices, slice s into W_or_Wp + s * n * 64 (the caller adds them up: launch_slice_sum_into).

@@ -430,8 +430,9 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
     """hdf5_data.py:70-187 (and :191-351 when num_perm > 0).  fast_perm: the permutation test of a chunk reuses the
     quadratic forms of the scan that just ran over it (mmg_emmax_perm_after_scan) instead of recomputing them.
     eigen_free: REML and the scan model from Cholesky factorisations instead of eigh(K) (linear_models.
-    get_estimates_eigen_free); default: when N > linear_models.EIGEN_FREE_MIN_N (mandatory beyond rocSOLVER's syevd range, N > 46,340) and no
-    permutation test is asked for (that one needs H_sqrt_inv itself).
+    get_estimates_eigen_free); default: when N > linear_models.EIGEN_FREE_MIN_N (mandatory beyond rocSOLVER's syevd range,
+    N > 46,340) -- since round 5 with a permutation test too, whose H_sqrt_inv is then L^-1 of K + delta I = L L'
+    (linear_models.perm_h_from_cholesky; MMG_PERM_H=eigen: the eigendecomposition's matrix).
 
     hdf5_filename: container path (chunkstore / HDF5) or an open genot_data tree / mapping.  For the reference's
     call shape `run_emmax(genot_data, phenotypes, ...)` of round 1 the second positional argument may be the
@@ -478,7 +479,8 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
         # the kinship goes from the accumulator into the likelihood search without visiting the host (and comes down in the
         # background for the result) when the route that follows is the device's: at N = 50,000 the download, the host's
         # second scale_k (:121 -> linear_models.py:580) and the upload, 20 GB each, were ~2 s of the REML stage
-        on_device = (os.environ.get('MMG_KINSHIP_ON_DEVICE', '1') != '0' and isinstance(ctx, _lib.Context) and not num_perm and eigen_free is not False
+        on_device = (os.environ.get('MMG_KINSHIP_ON_DEVICE', '1') != '0' and isinstance(ctx, _lib.Context)
+                     and (not num_perm or lm.perm_h_from_cholesky(ctx)) and eigen_free is not False
                      and n >= KINSHIP_ON_DEVICE_MIN_N and n > lm.EIGEN_FREE_MIN_N)
         k, n_snps = _ibd_kinship(ctx, genot_data, n, plan, coll, prefetch, timings, keep_device=on_device)
     else:
@@ -486,19 +488,27 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
     _lap('kinship_pass_s')
     lmm = lm.LinearMixedModel(phenotypes, ctx=ctx)                       # :121
     lmm.add_random_effect(k)
-    if eigen_free and num_perm:
-        raise ValueError("run_emmax: the permutation test needs H_sqrt_inv, which the eigendecomposition-free route "
-                         "does not produce -- call with eigen_free=False (or None) when num_perm > 0")
+    # Round 5: the permutation test no longer forces the eigendecomposition -- its H_sqrt_inv is L^-1 of K + delta I = L L' as
+    # the REML workspace holds it (linear_models.perm_h_from_cholesky; MMG_PERM_H=eigen or eigen_free=False: the literal
+    # route through eigh(K), 265 ms of rocSOLVER at N = 5000 on every rank)
+    perm_chol = bool(num_perm) and lm.perm_h_from_cholesky(ctx)
+    if eigen_free and num_perm and not perm_chol:
+        raise ValueError("run_emmax: MMG_PERM_H=eigen asks for the eigendecomposition's H_sqrt_inv, which the "
+                         "eigendecomposition-free route does not produce -- call with eigen_free=False (or None)")
     if eigen_free is None:
-        eigen_free = n > lm.EIGEN_FREE_MIN_N and not num_perm and isinstance(ctx, _lib.Context)
+        eigen_free = n > lm.EIGEN_FREE_MIN_N and (not num_perm or perm_chol) and hasattr(ctx, 'reml')
     res = lmm._try_eigen_free(coll=coll) if eigen_free else None         # :126-137 without either eigendecomposition
+    reml_ws = None
     if res is not None:
         _lap('reml_s')
         if timings is not None:
             timings['route'] = 'eigendecomposition-free (REML through %s)' % (
                 'one band reduction of K' if res['reml'].uses_band() else 'a Cholesky factorisation per delta')
         prep = lmm.scan_model_eigen_free(res)
-        res.pop('reml').close()
+        reml_ws = res.pop('reml')
+        if not num_perm:
+            reml_ws.close()
+            reml_ws = None
     else:
         eig_L = lmm._get_eigen_L_()                                      # :126
         res = lmm.get_estimates(eig_L, method='REML')                    # :131-137 (no eig_R: linear_models._SpectralSumsL)
@@ -517,9 +527,22 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
     if num_perm:                                                         # :262-330: SNP-independent part, once
         lmm_p = lm.LinearMixedModel(phenotypes, ctx=ctx)                 # perm_prepare centres Y in place
         lmm_p.add_random_effect(k)
-        pp = lmm_p.perm_prepare(res['H_sqrt_inv'], num_perm=num_perm, perm_idx=perm_idx)
+        if reml_ws is not None:
+            try:
+                # the scan model has left L^-1 of this delta in the workspace: H X, H y are two triangular products, the
+                # plan's operand images are built from the matrix where it lies, and the rows H'Q_c of the after-scan
+                # form (A = H'H - sum_c u_c u_c') are L^-T Q
+                pp = lmm_p.perm_prepare(None, num_perm=num_perm, perm_idx=perm_idx, reml=reml_ws, delta=res['delta'])
+                plan_p = reml_ws.perm_plan(res['delta'], pp['Ys'], pp['h0_rss'])
+                from scipy import linalg as _la
+                Qc = _la.qr(reml_ws.linv_apply(res['delta'], lmm.X), mode='economic')[0]
+                prep['HtQ'] = np.ascontiguousarray(reml_ws.linv_apply(res['delta'], Qc, trans=True).T)
+            finally:
+                reml_ws.close()
+        else:
+            pp = lmm_p.perm_prepare(res['H_sqrt_inv'], num_perm=num_perm, perm_idx=perm_idx)
+            plan_p = ctx.perm_plan(pp['H'], pp['Ys'], pp['h0_rss'])      # operand images of the test, once for all chunks
         min_rss = np.full(num_perm, pp['h0_rss'])
-        plan_p = ctx.perm_plan(pp['H'], pp['Ys'], pp['h0_rss'])          # operand images of the test, once for all chunks
     for ci, chrom, g in _resident_chunks(ctx, genot_data, plan, rank, world, prefetch, reuse=True):
         parts[ci] = ctx.scan(g, prep['h0_rss'], prep['n_p'])['ps']       # :174 _emmax_f_test_(emma_num=0)
         if timings is not None and isinstance(ctx, _lib.Context):

@@ -11,6 +11,7 @@ Arithmetic is float64 end to end (the "double-promoted" reading of the reference
 its literal 'single' storage limits its own p-values to ~1e-3 relative).
 """
 import time
+import os
 import warnings
 
 import numpy as np
@@ -134,6 +135,13 @@ EIGEN_FREE_MIN_N = 255
 EIGH_MAX_N = 46340
 # emmax_f_test builds the scan model on the device from K and delta (mmg_reml_scan_model) when nothing needs H itself.
 DEVICE_SCAN_MODEL = True
+
+
+def perm_h_from_cholesky(ctx):
+    """Whether the callers that need `H_sqrt_inv` and were not handed one take H = L^-1 of K + delta I = L L' from the device
+    (round 5) instead of diag((lambda + delta)^-1/2) U' from eigh(K): the default; MMG_PERM_H=eigen keeps the literal matrix
+    (identical in distribution, not draw by draw: the shuffled residuals live in the basis of the H that is used)."""
+    return os.environ.get('MMG_PERM_H', '') != 'eigen' and hasattr(ctx, 'reml')
 
 
 class _SpectralSumsR(object):
@@ -740,6 +748,16 @@ class LinearMixedModel(object):
         """get_estimates on a PRECOMPUTED eig_R (the reference's own route, :787-799)."""
         return self.get_estimates(eig_L, method=method, eig_R=eig_R, ngrids=ngrids, use_eig_R=True)
 
+    def _try_eigen_free_method(self, method='REML'):
+        """get_estimates_eigen_free(method=...) or None (K + delta I not positive definite on the grid: eigen route)."""
+        try:
+            return self.get_estimates_eigen_free(method=method)
+        except _lib.MixmogamHipError as e:
+            if "positive definite" not in str(e):
+                raise
+            warnings.warn("K + delta*I is not positive definite on the likelihood grid; taking the eigendecomposition route")
+            return None
+
     def _try_eigen_free(self, coll=None):
         """get_estimates_eigen_free, or None when K + delta I is not positive definite somewhere on the grid (an
         indefinite user-supplied kinship: the eigen route copes with that, Cholesky cannot)."""
@@ -913,17 +931,23 @@ class LinearMixedModel(object):
         return list(np.ascontiguousarray(T.T))
 
     # ------------------------------------------------------------------ permutations
-    def perm_prepare(self, H_sqrt_inv, num_perm=100, perm_idx=None):
+    def perm_prepare(self, H_sqrt_inv, num_perm=100, perm_idx=None, reml=None, delta=None):
         """SNP-independent part of _emmax_permutations_ (:1135-1156): centred Y (mutated, as the reference does),
         null fit, the N x P matrix of permuted residuals.  perm_idx: optional [num_perm x n] index matrix (column p
         of Ys is r[perm_idx[p]]); when None the permutations are drawn exactly as the reference draws them --
-        successive in-place numpy.random.shuffle calls on the global RNG (:1151-1154)."""
-        H = np.asarray(H_sqrt_inv, dtype=np.float64)
+        successive in-place numpy.random.shuffle calls on the global RNG (:1151-1154).
+        reml / delta (H_sqrt_inv None): H = L^-1 of K + delta I = L L' from the device workspace (_lib.Reml.linv_apply) --
+        H X and H y without an eigendecomposition and without the N x N matrix on the host."""
         n = self.n
         self.Y = self.Y - np.mean(self.Y)                                # :1140 (mutates, as the reference)
         y = self.Y.reshape(-1)
-        h0_X = H @ self.X
-        Yt = H @ y
+        if H_sqrt_inv is None:
+            Zt = reml.linv_apply(delta, np.column_stack([self.X, y]))
+            H, h0_X, Yt = None, Zt[:, :-1], Zt[:, -1]
+        else:
+            H = np.asarray(H_sqrt_inv, dtype=np.float64)
+            h0_X = H @ self.X
+            Yt = H @ y
         (h0_betas, _r, h0_rank, h0_s) = linalg.lstsq(h0_X, Yt)           # :1143
         r = Yt - h0_X @ h0_betas                                         # :1144
         h0_rss = float(r @ r)
@@ -939,7 +963,7 @@ class LinearMixedModel(object):
                 perm_idx.append(idx.copy())
         perm_idx = np.asarray(perm_idx)
         return {'H': H, 'Ys': np.ascontiguousarray(r[perm_idx].T), 'h0_rss': h0_rss,   # n x P: column p = r[perm_idx[p]]
-                'n_p': n - (self.X.shape[1] + 1)}
+                'n_p': n - (self.X.shape[1] + 1), 'h0_X': h0_X}
 
     def _emmax_permutations_(self, snps, K, H_sqrt_inv, num_perm=100, perm_idx=None, ndigits=0):
         """:1125-1175 (perm_idx: see perm_prepare)."""
@@ -974,16 +998,28 @@ class LinearMixedModel(object):
         in-place numpy.random.shuffle calls as the reference does (:1202-1205).  H_sqrt_inv: optional, the matrix the
         estimates would give (its row signs are LAPACK's choice and the shuffled vector lives in that basis)."""
         ctx = self.ctx
-        if H_sqrt_inv is None:
-            K = self.random_effects[1][1]
-            eig_L = self._get_eigen_L_(K)
-            H_sqrt_inv = self.get_estimates(eig_L=eig_L, method=method)['H_sqrt_inv']   # :1184-1186
-        H = np.asarray(H_sqrt_inv, dtype=np.float64)
         n = self.n
         n_p = n - (self.X.shape[1] + 1)                                  # :1190-1193
         y = self.Y.reshape(-1)
-        Yt = H @ y                                                       # :1195
-        h0_X = H @ self.X                                                # :1196
+        reml = None
+        if H_sqrt_inv is None and perm_h_from_cholesky(ctx):
+            # H := L^-1 of K + delta I = L L' (any H with H'H = (K + delta I)^-1 is a valid H_sqrt_inv; the reference's own
+            # is fixed only up to LAPACK's eigenvector signs, and the shuffled vector lives in the basis of the H that is
+            # used): REML on the device without eigh(K), H X / H y by mmg_reml_linv_apply, the plan from the workspace in
+            # HBM.  MMG_PERM_H=eigen: the literal route below.
+            est = self._try_eigen_free_method(method)
+            if est is not None:
+                reml, delta = est['reml'], est['delta']
+                Zt = reml.linv_apply(delta, np.column_stack([self.X, y]))
+                h0_X, Yt = Zt[:, :-1], Zt[:, -1]
+        if reml is None:
+            if H_sqrt_inv is None:
+                K = self.random_effects[1][1]
+                eig_L = self._get_eigen_L_(K)
+                H_sqrt_inv = self.get_estimates(eig_L=eig_L, method=method)['H_sqrt_inv']   # :1184-1186
+            H = np.asarray(H_sqrt_inv, dtype=np.float64)
+            Yt = H @ y                                                   # :1195
+            h0_X = H @ self.X                                            # :1196
         (h0_betas, _r, _rank, _s) = linalg.lstsq(h0_X, Yt)               # :1197
         r = Yt - h0_X @ h0_betas                                         # :1198
         h0_rss = float(r @ r)
@@ -995,11 +1031,17 @@ class LinearMixedModel(object):
                 perm_idx.append(idx.copy())
         perm_idx = np.asarray(perm_idx)
         Ys = np.ascontiguousarray(r[perm_idx].T)                         # n x P
-        CH = H - H.mean(axis=0, keepdims=True)                           # C H: the transformed SNP minus its mean (:1211)
         own = not isinstance(snps, _lib.Geno)
         snp_mat = kinship._as_snp_matrix(snps) if own else None
         num_snps = len(snp_mat) if own else snps.M
-        plan = ctx.perm_plan(CH, Ys, h0_rss, centre_snps=False)
+        if reml is not None:
+            try:                                                         # C H: the transformed SNP minus its mean (:1211), on the device
+                plan = reml.perm_plan(delta, Ys, h0_rss, centre_snps=False, centre_H=True)
+            finally:
+                reml.close()
+        else:
+            CH = H - H.mean(axis=0, keepdims=True)                       # C H: the transformed SNP minus its mean (:1211)
+            plan = ctx.perm_plan(CH, Ys, h0_rss, centre_snps=False)
         try:
             if not reference_indexing:
                 g = ctx.geno(snp_mat) if own else snps

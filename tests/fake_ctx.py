@@ -123,6 +123,24 @@ class FakeReml(object):
         self.ctx.scan_set_model(P, Py)
         return s1, beta
 
+    def uses_band(self, route="auto"):
+        return False
+
+    def linv(self, delta):
+        """L^-1 of K + delta I = L L' (mmg_reml_linv_fetch)."""
+        L = np.linalg.cholesky(self.K + delta * np.eye(len(self.K)))
+        return np.linalg.inv(L)
+
+    def linv_apply(self, delta, V, trans=False):
+        H = self.linv(delta)
+        return (H.T if trans else H) @ np.asarray(V, dtype=np.float64)
+
+    def perm_plan(self, delta, Ys, h0_rss, centre_snps=True, centre_H=False):
+        H = self.linv(delta)
+        if centre_H:
+            H = H - H.mean(axis=0, keepdims=True)
+        return self.ctx.perm_plan(H, Ys, h0_rss, centre_snps=centre_snps)
+
     def close(self):
         pass
 
