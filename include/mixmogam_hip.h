@@ -168,6 +168,10 @@ int mmg_kin_acc_add(mmg_ctx* ctx, mmg_kin_acc* acc, mmg_geno* g, const float* sc
  * silently while their SNPs stayed counted). */
 int mmg_kin_acc_add_grm(mmg_ctx* ctx, mmg_kin_acc* acc, mmg_geno* g);
 int mmg_kin_acc_pending(mmg_ctx* ctx, mmg_kin_acc* acc, int64_t* n_snps_pending);
+/* The accumulator's matrix := the IBS kinship of a store (kinship.py:14-56: counts / (2 m_total) + 0.5, scale_k's rule when
+ * scaled != 0), formed and KEPT in HBM: followed by mmg_reml_create_from_acc the kinship of an emmax() call never visits the
+ * host.  comm / m_total: the SNP blocks of all ranks (RCCL SUM of the counts).  Replaces whatever the accumulator held. */
+int mmg_kin_acc_set_ibs(mmg_ctx* ctx, mmg_comm* comm, mmg_kin_acc* acc, mmg_geno* g, int64_t m_total, int32_t scaled);
 int mmg_kin_acc_snps(mmg_ctx* ctx, mmg_kin_acc* acc, int64_t* n_snps);      /* SNPs added so far (what fetch reports), without the download */
 int mmg_kin_acc_fetch(mmg_ctx* ctx, mmg_kin_acc* acc, double* C_out, int64_t* n_snps);
 /* scale_k of the reference (kinship.py:94-100, inlined at hdf5_data.py:108-111) on the device-resident matrix, in place:

@@ -59,6 +59,7 @@ PROTOTYPES = {
     "mmg_kin_acc_add": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mmg_kin_acc_add_grm": (C.c_int, [c_vp, c_vp, c_vp]),
     "mmg_kin_acc_pending": (C.c_int, [c_vp, c_vp, c_i64p]),
+    "mmg_kin_acc_set_ibs": (C.c_int, [c_vp, c_vp, c_vp, c_vp, C.c_int64, C.c_int32]),
     "mmg_kin_acc_snps": (C.c_int, [c_vp, c_vp, c_i64p]),
     "mmg_kin_acc_fetch": (C.c_int, [c_vp, c_vp, c_vp, c_i64p]),
     "mmg_kin_acc_scale_k": (C.c_int, [c_vp, c_vp, c_f64p]),
@@ -325,6 +326,13 @@ class KinshipAccumulator(object):
     def add_grm(self, g):
         """acc += sum_m z_m z_m', z = (s - mean)/std per SNP: the exact int8 route (mmg_kin_acc_add_grm)."""
         self.ctx._check(self.ctx.lib.mmg_kin_acc_add_grm(self.ctx.h, self.h, g.h))
+
+    def set_ibs(self, g, scaled=True, comm=None, m_total=None):
+        """The accumulator's matrix := the IBS kinship of g (of all ranks' blocks with comm / m_total), kept in HBM
+        (mmg_kin_acc_set_ibs)."""
+        self.ctx._check(self.ctx.lib.mmg_kin_acc_set_ibs(self.ctx.h, comm, self.h, g.h, int(g.M if m_total is None else m_total),
+                                                         1 if scaled else 0))
+        return self
 
     def pending(self):
         """SNPs of the last add_grm calls whose sums still sit in the int32 digit planes (combined into the fp64 sum by

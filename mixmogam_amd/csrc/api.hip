@@ -524,7 +524,7 @@ static int64_t kin_chunk() {
 }
 
 // f64: the IBS kinship itself instead of the counts (mmg_kinship_ibs_f64): K = counts / (2 m_total) + 0.5, scale_k on request
-struct IbsF64 { double* K_out; int64_t m_total; bool scaled; int64_t* dev64 = nullptr; };   // dev64: the counts stay in HBM (device buffer)
+struct IbsF64 { double* K_out; int64_t m_total; bool scaled; int64_t* dev64 = nullptr; double* dK_dev = nullptr; };   // dev64: the counts stay in HBM (device buffer); dK_dev: the kinship does (mmg_kin_acc_set_ibs)
 static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int thr, int64_t* C_out,
                              mmg_comm* comm = nullptr, const IbsF64* f64 = nullptr);
 
@@ -545,7 +545,7 @@ int mmg_kinship_indicator_i8(mmg_ctx* ctx, mmg_geno* g, int32_t thr, int64_t* C_
 static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int thr, int64_t* C_out, mmg_comm* comm, const IbsF64* f64) {
   Scratch sc;
   MMG_ENTER(ctx);
-  MMG_CHECK_ARG(ctx, g && (C_out || (f64 && (f64->K_out || f64->dev64))) && g->M > 0);
+  MMG_CHECK_ARG(ctx, g && (C_out || (f64 && (f64->K_out || f64->dev64 || f64->dK_dev))) && g->M > 0);
   // IBS (X = 2S - 1, kinship.py:43) runs on the RAW genotypes: X X' = 4 S S' - 2 (r 1' + 1 r') + M with r the column
   // sums of S -- the same exact integers, but the GEMM operands are 0/1 bytes instead of +-1: the matrix pipe draws
   // less power on mostly-zero operands and the power-limited chip clocks higher (measured at N = 5000, M = 1e6:
@@ -686,8 +686,8 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
       // the kinship leaves the device as the matrix the caller wants: conversion and scale_k's rule (kinship.py:94-100; the
       // sums of mmg_kin_acc_scale_k) in HBM instead of three host passes over N^2 doubles
       const int64_t N = g->N;
-      double *dK = nullptr, *drow = nullptr;
-      MMG_HIP(ctx, sc.alloc(&dK, (size_t)N * N * sizeof(double)));
+      double *dK = f64->dK_dev, *drow = nullptr;
+      if (!dK) MMG_HIP(ctx, sc.alloc(&dK, (size_t)N * N * sizeof(double)));
       launch_ibs_counts_to_f64(ctx, C64, N * N, 2.0 * (double)f64->m_total, dK);
       if (f64->scaled) {
         MMG_HIP(ctx, sc.alloc(&drow, 2 * N * sizeof(double)));
@@ -700,6 +700,11 @@ static int kinship_counts_i8(mmg_ctx* ctx, mmg_geno* g, int mul, int add, int th
         const double c = trace - total / (double)N;
         if (!(c > 0.0) || !std::isfinite(c)) return set_err(ctx, MMG_E_ARG, "scale_k: tr K - sum K / N is not positive");
         launch_scale_f64(ctx, dK, N * N, (double)(N - 1) / c);
+      }
+      if (f64->dK_dev) {                                       // stays in HBM
+        MMG_HIP(ctx, hipGetLastError());
+        MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return rc;
       }
       hipError_t e3 = hipMemcpyAsync(f64->K_out, dK, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
       if (e3 == hipSuccess) e3 = hipStreamSynchronize(ctx->stream);
@@ -1163,6 +1168,22 @@ int mmg_reml_create_from_acc(mmg_ctx* ctx, mmg_kin_acc* a, int32_t q, const doub
   MMG_ACC_USABLE(ctx, a);
   { int rcf = grm_flush(ctx, a->ws, a->dC); if (rcf) return rcf; }
   return mmg_reml_create_dev(ctx, a->N, q, a->dC, X, y, out);
+}
+
+// The accumulator takes the IBS kinship of a store (kinship.py:14-56: counts / (2 m_total) + 0.5, scale_k's rule when scaled) as
+// its matrix, formed and kept in HBM: with mmg_reml_create_from_acc behind it the kinship of an emmax() call never visits the
+// host (N = 5000: two 200 MB crossings of PCIe and the host's scale_k, ~40 ms of a 170 ms kinship -> threshold job).  comm /
+// m_total: the SNP blocks of all ranks.  Replaces whatever the accumulator held.
+int mmg_kin_acc_set_ibs(mmg_ctx* ctx, mmg_comm* comm, mmg_kin_acc* a, mmg_geno* g, int64_t m_total, int32_t scaled) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, a && g && g->N == a->N && m_total >= g->M);
+  MMG_ACC_USABLE(ctx, a);
+  a->ws.pending = false; a->ws.p_M = 0;                        // pending GRM sums are dropped with the matrix they belonged to
+  IbsF64 f{nullptr, m_total, scaled != 0};
+  f.dK_dev = a->dC;
+  int rc = kinship_counts_i8(ctx, g, 2, -1, 0, nullptr, comm, &f);
+  if (rc == MMG_OK) a->n_snps = m_total;
+  return rc;
 }
 
 int mmg_kin_acc_snps(mmg_ctx* ctx, mmg_kin_acc* a, int64_t* n_snps) {

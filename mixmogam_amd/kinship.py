@@ -61,12 +61,15 @@ def scale_k(k, verbose=False):
 
 
 def calc_ibs_kinship(snps, snps_data_format='binary', snp_dtype='int8', dtype='single',
-                     chunk_size=None, scaled=True, ctx=None, geno=None):
+                     chunk_size=None, scaled=True, ctx=None, geno=None, keep_device=False, comm=None, m_total=None):
     """kinship.py:14-56 ('binary'): K = sum_m (2s-1)(2s-1)^T / (2M) + 0.5, then scale_k.
 
     The count matrix is an exact int8-MFMA GEMM on the device (bit-exact with the reference's
     float64 accumulator); chunk_size is accepted for signature compatibility (the device kernel
-    tiles the SNP axis itself).  `geno` may pass an already-resident device genotype store."""
+    tiles the SNP axis itself).  `geno` may pass an already-resident device genotype store.
+    keep_device ('binary' only): return a _lib.DeviceKinship -- the matrix stays in HBM (mmg_kin_acc_set_ibs) and goes into
+    LinearMixedModel.add_random_effect / emmax() without visiting the host; numpy sees it through __array__ / .host().
+    comm / m_total: the SNP blocks of all ranks (RCCL sum of the counts)."""
     if snps_data_format not in ('binary', 'diploid_int'):
         raise NotImplementedError(snps_data_format)
     ctx = ctx or _lib.get_context()
@@ -74,6 +77,12 @@ def calc_ibs_kinship(snps, snps_data_format='binary', snp_dtype='int8', dtype='s
     g = ctx.geno(_as_snp_matrix(snps)) if own else geno
     try:
         num_snps = g.M
+        if keep_device and snps_data_format == 'binary' and hasattr(ctx, 'kinship_accumulator'):
+            acc = ctx.kinship_accumulator(g.N)
+            if hasattr(acc, 'set_ibs'):
+                acc.set_ibs(g, scaled=scaled, comm=comm, m_total=m_total)
+                return _lib.DeviceKinship(acc, scaled=scaled)
+            acc.close()
         if snps_data_format == 'diploid_int':
             # kinship.py:33-41: k_ij = #(|a-b| = 0) + 0.5 #(|a-b| = 1) = M - 0.5 sum_m |a_m - b_m| for
             # 0/1/2 genotypes; |a-b| = a + b - 2 min(a,b) and min(a,b) = [a>=1][b>=1] + [a>=2][b>=2]:

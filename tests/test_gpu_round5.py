@@ -54,7 +54,8 @@ def test_workspace_linv_is_a_square_root_of_the_inverse(ctx, n):
 @pytest.mark.parametrize("name", ["struct_n150_s0", "struct_n300_s2"])
 def test_permutation_thresholds_on_the_cholesky_root_vs_the_oracle(ctx, name):
     """_emmax_permutations_'s arithmetic (:1125-1175) with H_sqrt_inv := L^-1 from the device (perm_prepare(reml=...) +
-    mmg_perm_plan_create_from_reml) against oracle.perm_closed fed the same L^-1: max F per permutation to 1e-9."""
+    mmg_perm_plan_create_from_reml) against oracle.perm_closed fed the same L^-1: the null fit to 1e-10, max F per permutation to
+    1e-7 (the statistic's GEMM runs on four 7-bit digit planes of W' = Ys'H: ~1e-8)."""
     from mixmogam_amd import linear_models as lm
     from oracle import emmax_oracle as orc
     case = load_case(name)
@@ -84,7 +85,7 @@ def test_permutation_thresholds_on_the_cholesky_root_vs_the_oracle(ctx, name):
     ref = orc.perm_closed(case["snps"], opp)
     assert rel(pp["h0_rss"], opp["h0_rss"]) < 1e-10
     max_f = (pp["h0_rss"] / min_rss - 1.0) * pp["n_p"]
-    assert rel(max_f, ref["max_f_stats"]) < 1e-9
+    assert rel(max_f, ref["max_f_stats"]) < 1e-7
 
 
 def test_public_permutation_test_without_an_eigendecomposition(ctx):
@@ -108,7 +109,7 @@ def test_public_permutation_test_without_an_eigendecomposition(ctx):
     finally:
         est["reml"].close()
     want = orc.perm_public(snps, y, np.ones((n, 1)), H, idx, reference_indexing=False)
-    assert rel(res["max_f_stats"], want["max_f_stats"]) < 1e-8
+    assert rel(res["max_f_stats"], want["max_f_stats"]) < 1e-7
     assert "threshold_05" in res
     os.environ["MMG_PERM_H"] = "eigen"
     try:
@@ -169,3 +170,22 @@ def test_rejected_grm_call_leaves_the_accumulator_as_it_was(ctx):
         assert np.max(np.abs(K - 2 * z.T @ z)) / np.max(np.abs(K)) < 1e-8
     finally:
         acc.close(); g1.close(); g2.close()
+
+
+def test_ibs_kinship_kept_in_hbm_feeds_emmax_without_a_host_visit(ctx):
+    """kinship.calc_ibs_kinship(keep_device=True) (mmg_kin_acc_set_ibs): the same matrix as the host-returning call (bit for bit
+    above 2048 individuals, where both are formed on the device; to 1e-13 below), and emmax() on it equals emmax() on the array."""
+    from mixmogam_amd import kinship, linear_models as lm
+    for n, m in ((300, 1200), (2100, 900)):
+        snps, y, _rng = structured(n, m, 21)
+        Kh = kinship.calc_ibs_kinship(snps, ctx=ctx)
+        Kd = kinship.calc_ibs_kinship(snps, ctx=ctx, keep_device=True)
+        try:
+            got = np.asarray(Kd)
+            assert got.shape == (n, n)
+            assert np.max(np.abs(got - Kh)) <= (0.0 if n > 2048 else 1e-13)
+            a = lm.emmax(snps[:500], list(y), Kh, ctx=ctx)
+            b = lm.emmax(snps[:500], list(y), Kd, ctx=ctx)
+            assert rel(b["ps"], a["ps"]) < 1e-9 and abs(b["pseudo_heritability"] - a["pseudo_heritability"]) < 1e-10
+        finally:
+            Kd.close()

@@ -69,11 +69,18 @@ for c in range(cases):
             note("with_betas p", rel(wb["ps"][ok], ref["ps"][ok]), 1e-6, what)
         if rng.rand() < 0.5 and n <= 900 and kind != "few classes":   # (identical SNPs tie: which of them gets refined is arbitrary)
             en = int(rng.randint(1, 6))
+            # which SNPs get the exact test is decided by the order of the EMMAX p-values: two that differ by less than the
+            # parity bar (a SNP and its complement, duplicates up to rounding -- common at small n) may swap places between
+            # device and oracle, and then different SNPs are refined.  Such a near-tie AT the cutoff is not a parity question.
+            ps_sorted = np.sort(ref["ps"])
+            if len(ps_sorted) > en and ps_sorted[en] - ps_sorted[en - 1] <= 1e-5 * ps_sorted[en]:
+                en = 0
             os.environ.get("RP_VERBOSE") and print("   ->", 'lm.emmax', flush=True)
-            em = lm.emmax(snps, list(y), K, emma_num=en, ctx=ctx)
-            eo = orc.emmax_with_emma(snps, y, K, emma_num=en)
-            oke = eo["ps"] > 1e-290
-            note("emma_num p", rel(em["ps"][oke], eo["ps"][oke]), 2e-6, what + " emma_num=%d" % en)
+            if en:
+                em = lm.emmax(snps, list(y), K, emma_num=en, ctx=ctx)
+                eo = orc.emmax_with_emma(snps, y, K, emma_num=en)
+                oke = eo["ps"] > 1e-290
+                note("emma_num p", rel(em["ps"][oke], eo["ps"][oke]), 2e-6, what + " emma_num=%d" % en)
         if rng.rand() < 0.5 and n <= 900:
             P = int(rng.randint(2, 40))
             idx = np.array([rng.permutation(n) for _ in range(P)])
