@@ -1080,14 +1080,94 @@ def _cofactor_list(cofactors):
     return list(cofactors)
 
 
+class _LazyEstimates(dict):
+    """The result of get_emma_reml_estimates on the eigendecomposition-free route: the scalars are there; 'H_sqrt_inv', 'Y_t',
+    'X_t' (from the Cholesky square root L^-1 of (K + delta I)^-1 -- any H with H'H = (K + delta I)^-1 serves, linear_models.py
+    :898 is fixed only up to LAPACK's signs) and 'eig_L' (rocSOLVER's dsyevd, 0.27 s at N = 5000) are computed when first
+    asked for.  Iterating / items() / values() materialise everything."""
+    _LAZY = ('H_sqrt_inv', 'Y_t', 'X_t', 'eig_L')
+
+    def __init__(self, scalars, lmm, reml):
+        dict.__init__(self, scalars)
+        self._lmm, self._reml = lmm, reml
+
+    def _make(self, key):
+        if key == 'eig_L':
+            v = self._lmm._get_eigen_L_()
+        elif key == 'H_sqrt_inv':
+            v = self._reml.linv(dict.__getitem__(self, 'delta'))
+        else:
+            Zt = self._reml.linv_apply(dict.__getitem__(self, 'delta'), np.column_stack([self._lmm.X, self._lmm.Y.reshape(-1)]))
+            dict.__setitem__(self, 'X_t', Zt[:, :-1])
+            dict.__setitem__(self, 'Y_t', Zt[:, -1:])
+            return dict.__getitem__(self, key)
+        dict.__setitem__(self, key, v)
+        return v
+
+    def __getitem__(self, key):
+        if key in self._LAZY and not dict.__contains__(self, key):
+            return self._make(key)
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def __contains__(self, key):
+        return key in self._LAZY or dict.__contains__(self, key)
+
+    def _all(self):
+        for k in self._LAZY:
+            self[k]
+        return self
+
+    def keys(self):
+        return list(dict.keys(self)) + [k for k in self._LAZY if not dict.__contains__(self, k)]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
+
+    def items(self):
+        return dict.items(self._all())
+
+    def values(self):
+        return dict.values(self._all())
+
+    def close(self):
+        """Release the device workspace (after this the lazy entries that were not touched raise)."""
+        if self._reml is not None:
+            self._reml.close()
+            self._reml = None
+
+
 def get_emma_reml_estimates(y, K, K2=None, cofactors=None, include_intercept=True, ctx=None):
-    """:1690-1706."""
+    """:1690-1706.  Round 5: above EIGEN_FREE_MIN_N individuals the variance components come from the band reduction of K
+    (no eigendecomposition); beta / rss / mahalanobis_rss from two triangular products with the Cholesky factor; the matrices
+    the reference also returns ('H_sqrt_inv', 'Y_t', 'X_t', 'eig_L') are computed on first access (_LazyEstimates).
+    MMG_PERM_H=eigen: the eigendecomposition route with every entry filled."""
     if K2 is not None:
         raise NotImplementedError("two-kinship estimator (get_estimates_3) is outside the hot path (SURVEY 2)")
     lmm = LinearMixedModel(y, ctx=ctx)
     lmm.add_random_effect(K)
     if cofactors is not None:
         lmm.set_factors(cofactors, include_intercept=include_intercept)
+    if lmm.n > EIGEN_FREE_MIN_N and isinstance(lmm.ctx, _lib.Context) and perm_h_from_cholesky(lmm.ctx):
+        est = lmm._try_eigen_free_method('REML')
+        if est is not None:
+            reml = est.pop('reml')
+            Zt = reml.linv_apply(est['delta'], np.column_stack([lmm.X, lmm.Y.reshape(-1)]))
+            X_t, Y_t = Zt[:, :-1], Zt[:, -1]
+            (beta_est, _res, _rank, _sigma) = linalg.lstsq(X_t, Y_t)        # :902-907
+            resid = lmm.Y.reshape(-1) - lmm.X @ beta_est
+            est.pop('H_sqrt_inv', None)
+            est.update(beta=beta_est.reshape(-1, 1), mahalanobis_rss=np.array([float(np.sum((Y_t - X_t @ beta_est) ** 2))]),
+                       rss=float(resid @ resid), lmm=lmm)
+            out = _LazyEstimates(est, lmm, reml)
+            dict.__setitem__(out, 'X_t', X_t)
+            dict.__setitem__(out, 'Y_t', Y_t.reshape(-1, 1))
+            return out
     res = lmm.get_REML()
     res['Y_t'] = res['H_sqrt_inv'] @ lmm.Y
     res['X_t'] = res['H_sqrt_inv'] @ lmm.X

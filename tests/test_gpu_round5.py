@@ -189,3 +189,22 @@ def test_ibs_kinship_kept_in_hbm_feeds_emmax_without_a_host_visit(ctx):
             assert rel(b["ps"], a["ps"]) < 1e-9 and abs(b["pseudo_heritability"] - a["pseudo_heritability"]) < 1e-10
         finally:
             Kd.close()
+
+
+def test_get_emma_reml_estimates_is_lazy_about_the_matrices(ctx):
+    """get_emma_reml_estimates above EIGEN_FREE_MIN_N: scalars, beta and the transformed X / Y without an eigendecomposition
+    (golden values of the reference); H_sqrt_inv (the Cholesky root: H'H = (K + delta I)^-1) and eig_L only when asked for."""
+    from mixmogam_amd import linear_models as lm
+    case = load_case("struct_n300_s2")
+    res = lm.get_emma_reml_estimates(list(case["y"]), case["dbl_ibs_scaled"], cofactors=case["cof"], ctx=ctx)
+    assert isinstance(res, lm._LazyEstimates) and not dict.__contains__(res, "eig_L") and not dict.__contains__(res, "H_sqrt_inv")
+    for k in ("max_ll", "delta", "ve", "vg", "pseudo_heritability"):
+        assert rel(res[k], case["dbl_reml_" + k]) < 1e-7, k
+    assert rel(res["beta"], case["dbl_reml_beta"]) < 1e-6
+    H = res["H_sqrt_inv"]
+    assert np.allclose(H, np.tril(H))
+    probe = np.random.RandomState(99).randn(len(case["y"]), 3)
+    assert rel(H.T @ (H @ probe), case["dbl_HtH_probe"]) < 1e-6
+    assert rel(H @ res["lmm"].X, res["X_t"]) < 1e-9 and rel(H @ res["lmm"].Y.reshape(-1), res["Y_t"].reshape(-1)) < 1e-9
+    assert np.max(np.abs(res["eig_L"]["values"] - case["dbl_eig_L_values"])) < 1e-9
+    res.close()
