@@ -40,6 +40,10 @@ void launch_rows_gemm(hipStream_t st, const double* X, int64_t ldx, double* Y, i
 void launch_nt_update_lower(hipStream_t st, double* C, int64_t ldc, int64_t n, const double* A0, const double* B0,
                             const double* A1, const double* B1, int64_t lda, int64_t ldb);
 
+// ... the tiles (I, 0) of the first 64-column block column only
+void launch_nt_update_col0(hipStream_t st, double* C, int64_t ldc, int64_t n, const double* A0, const double* B0,
+                           const double* A1, const double* B1, int64_t lda, int64_t ldb);
+
 // First pass of Cholesky-QR: G = sum of the Gram slices -> R1 = chol(G)' and R1^-1 (64 x 64 column-major upper, ld 64)
 void launch_cholqr_head1(hipStream_t st, const double* part, int G, double* R1, double* R1inv, PanelFlags* flags);
 // Second pass + an orthogonal H with H'P = [R; 0] in basis-kernel form (Yamamoto 2012; signs as in Ballard et al., "Reconstructing

@@ -349,12 +349,13 @@ template <int NP>
 __global__ __launch_bounds__(256, 2) void nt_update_lower_kernel(double* __restrict__ C, int64_t ldc, int64_t n,
                                                                  const double* __restrict__ A0, const double* __restrict__ B0,
                                                                  const double* __restrict__ A1, const double* __restrict__ B1,
-                                                                 int64_t lda, int64_t ldb) {
+                                                                 int64_t lda, int64_t ldb, int col0) {
   const int64_t t = blockIdx.x;
   int64_t I = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while (I * (I + 1) / 2 > t) --I;
   while ((I + 1) * (I + 2) / 2 <= t) ++I;
-  const int64_t J = t - I * (I + 1) / 2;
+  int64_t J = t - I * (I + 1) / 2;
+  if (col0) { I = t; J = 0; }                                // only the first block column (launch_nt_update_col0)
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
   const int64_t I0 = I * 64, J0 = J * 64;
   const int64_t ci = I0 + 16 * w + lr;                       // this lane's row of C
@@ -519,8 +520,18 @@ void launch_nt_update_lower(hipStream_t st, double* C, int64_t ldc, int64_t n, c
   }
   const int64_t nt = (n + 63) / 64;
   const dim3 grid((unsigned)(nt * (nt + 1) / 2));
-  if (A1) hipLaunchKernelGGL(nt_update_lower_kernel<2>, grid, dim3(256), 0, st, C, ldc, n, A0, B0, A1, B1, lda, ldb);
-  else hipLaunchKernelGGL(nt_update_lower_kernel<1>, grid, dim3(256), 0, st, C, ldc, n, A0, B0, A0, B0, lda, ldb);
+  if (A1) hipLaunchKernelGGL(nt_update_lower_kernel<2>, grid, dim3(256), 0, st, C, ldc, n, A0, B0, A1, B1, lda, ldb, 0);
+  else hipLaunchKernelGGL(nt_update_lower_kernel<1>, grid, dim3(256), 0, st, C, ldc, n, A0, B0, A0, B0, lda, ldb, 0);
+}
+
+// the same update on the FIRST 64-column block column alone (tiles (I, 0), I = 0 ..): what the next panel of a blocked
+// factorisation needs before the rest of the trailing matrix is done (reml_band.hip: look-ahead)
+void launch_nt_update_col0(hipStream_t st, double* C, int64_t ldc, int64_t n, const double* A0, const double* B0,
+                           const double* A1, const double* B1, int64_t lda, int64_t ldb) {
+  if (n <= 0) return;
+  const dim3 grid((unsigned)((n + 63) / 64));
+  if (A1) hipLaunchKernelGGL(nt_update_lower_kernel<2>, grid, dim3(256), 0, st, C, ldc, n, A0, B0, A1, B1, lda, ldb, 1);
+  else hipLaunchKernelGGL(nt_update_lower_kernel<1>, grid, dim3(256), 0, st, C, ldc, n, A0, B0, A0, B0, lda, ldb, 1);
 }
 
 // ---- Cholesky-QR heads --------------------------------------------------------------------------------------------------

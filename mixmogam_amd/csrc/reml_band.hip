@@ -755,7 +755,7 @@ static int band_reduce_cqr(mmg_ctx* ctx, mmg_reml* r, bool* suspect) {
   Scratch sc;
   double *V = nullptr, *W = nullptr, *Wp = nullptr, *Y = nullptr, *small = nullptr, *part = nullptr, *part2 = nullptr;
   PanelFlags* flags = nullptr;
-  RC_HIP(ctx, sc.alloc(&V, (size_t)nmax * b * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&V, (size_t)2 * nmax * b * sizeof(double)));    // two panels' V: look-ahead (below)
   RC_HIP(ctx, sc.alloc(&W, (size_t)nmax * b * sizeof(double)));
   RC_HIP(ctx, sc.alloc(&Y, (size_t)nmax * b * sizeof(double)));
   if (smax > 1) RC_HIP(ctx, sc.alloc(&Wp, (size_t)smax * nmax * b * sizeof(double)));
@@ -775,12 +775,8 @@ static int band_reduce_cqr(mmg_ctx* ctx, mmg_reml* r, bool* suspect) {
     tsec[which] += std::chrono::duration<double>(now - tp).count();
     tp = now;
   };
-  // out (64 x 64) = A'B: Gram slices on the matrix pipe, summed by a second small launch (a head kernel that added 40
+  // (64 x 64 products A'B: Gram slices on the matrix pipe, summed by a second small launch -- a head kernel that added 40
   // slices itself spent 46 us reading 1.3 MB through one CU)
-  auto gram = [&](const double* Am, int64_t lda, const double* Bm, int64_t ldb, int kb, int64_t n, double* out) {
-    const int G = launch_gram_slices(st, Am, lda, Bm, ldb, kb, n, part2, 128);
-    launch_gram_reduce(st, part2, G, out, 64);
-  };
   // MMG_BAND_GRAPH=1 (A/B): the whole panel loop -- ~16 dependent launches per panel, 1200 at N = 5000, none of them a
   // library call -- captured into ONE hipGraph and replayed, instead of 1200 stream launches.  Measured at N = 5000
   // (tools/reml_time.py): the host enqueues a launch in ~4 us and the kernels average 23 us, so the stream never
@@ -789,12 +785,38 @@ static int band_reduce_cqr(mmg_ctx* ctx, mmg_reml* r, bool* suspect) {
   const bool capture = use_graph && !verbose;
   const auto t_cap0 = std::chrono::steady_clock::now();
   if (capture) RC_HIP(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  // Look-ahead (round 5; MMG_BAND_LOOKAHEAD=0: the single-stream order of round 4).  A panel's factorisation is a chain of
+  // two single-workgroup head kernels and four small launches (~200 us of which the chip works ~30) that needs only the FIRST
+  // block column of the trailing matrix of the panel before.  So the two-sided update of panel k is split: its first block
+  // column at once (launch_nt_update_col0, 77 tiles), then the rest on the compute stream while the factorisation of panel
+  // k + 1 runs beside it on the context's second stream; W = A22 V of panel k + 1 waits for both.  V is double-buffered
+  // (the rest of update k still reads V_k while the factorisation of k + 1 writes V_{k+1}); every other scratch buffer is
+  // used by one side at a time (the factorisation starts after band_y of the panel before and ends before sym_skinny of its own).
+  // Measured (tools/band_lookahead_ab.py, profiles/r5_band_lookahead_ab.txt): N = 12,000 118.7 -> 110.8 ms, but N = 5000 27.4 ->
+  // 30.6 and N = 1000 4.4 -> 5.7: there the rest of an update is ~70 us against ~300 us of dependent panel work, and the two
+  // event hops per panel cost more than the overlap returns.  On from N = 8192; MMG_BAND_LOOKAHEAD=1 / 0 force it.
+  static const int la_env = [] { const char* e = std::getenv("MMG_BAND_LOOKAHEAD"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+  const bool lookahead = (la_env == 1 || (la_env < 0 && N >= 8192)) && !verbose && !capture;
+  hipStream_t sf = lookahead ? ctx->stream2 : st;             // the stream of the panel factorisations
+  hipEvent_t ev_fact[2] = {nullptr, nullptr}, ev_col0[2] = {nullptr, nullptr};
+  struct EvGuard { hipEvent_t* e; int n; ~EvGuard() { for (int i = 0; i < n; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } g1{ev_fact, 2}, g2{ev_col0, 2};
+  if (lookahead) {
+    for (int i = 0; i < 2; ++i) {
+      RC_HIP(ctx, hipEventCreateWithFlags(&ev_fact[i], hipEventDisableTiming));
+      RC_HIP(ctx, hipEventCreateWithFlags(&ev_col0[i], hipEventDisableTiming));
+    }
+    RC_HIP(ctx, hipEventRecord(ev_col0[1], st));               // "panel -1": the copies of K and [X y] above
+    RC_HIP(ctx, hipStreamWaitEvent(sf, ev_col0[1], 0));
+  }
+  double* const Vbuf[2] = {V, V + (size_t)nmax * b};
   int64_t k0 = 0;
-  for (; N - k0 - b >= 2; k0 += b) {
+  int pk = 0;                                                 // panel counter (parity of the V buffer and the events)
+  for (; N - k0 - b >= 2; k0 += b, ++pk) {
     auto tp = std::chrono::steady_clock::now();
     if (verbose) { (void)hipStreamSynchronize(st); tp = std::chrono::steady_clock::now(); }
     const int64_t a0 = k0 + b, n = N - a0;
     if (n < b) {                                              // the last, short block column: one workgroup
+      if (lookahead) RC_HIP(ctx, hipStreamWaitEvent(st, ev_col0[(pk + 1) & 1], 0));   // (already ordered: same stream; kept for symmetry)
       hipLaunchKernelGGL(band_tail_kernel, dim3(1), dim3(256), 0, st, A, N, k0, r->dZr, q1);
       lap(0, tp);
       continue;
@@ -802,13 +824,23 @@ static int band_reduce_cqr(mmg_ctx* ctx, mmg_reml* r, bool* suspect) {
     double* P = A + a0 + k0 * N;
     double* A22 = A + a0 + a0 * N;
     double* Zs = r->dZr + a0;
-    // ---- panel: V, M, R
-    gram(P, N, P, N, b, n, part);
-    launch_cholqr_head1(st, part, 1, R1, R1inv, flags);
-    launch_rows_gemm(st, P, N, V, n, n, R1inv);               // Q1 = P R1^-1
-    gram(V, n, V, n, b, n, part);
-    launch_cholqr_head2(st, part, 1, R1, V, n, Mk, Cb, P, N, flags);
-    launch_rows_gemm(st, V + b, n, V + b, n, n - b, Cb);      // V[64:] = Q1[64:] (-R2^-1 S)
+    double* V = Vbuf[pk & 1];
+    // ---- panel: V, M, R  (stream sf; behind the first block column of the update before)
+    if (lookahead && pk > 0) RC_HIP(ctx, hipStreamWaitEvent(sf, ev_col0[(pk - 1) & 1], 0));
+    {
+      const int G1 = launch_gram_slices(sf, P, N, P, N, b, n, part2, 128);
+      launch_gram_reduce(sf, part2, G1, part, 64);
+      launch_cholqr_head1(sf, part, 1, R1, R1inv, flags);
+      launch_rows_gemm(sf, P, N, V, n, n, R1inv);             // Q1 = P R1^-1
+      const int G2 = launch_gram_slices(sf, V, n, V, n, b, n, part2, 128);
+      launch_gram_reduce(sf, part2, G2, part, 64);
+      launch_cholqr_head2(sf, part, 1, R1, V, n, Mk, Cb, P, N, flags);
+      launch_rows_gemm(sf, V + b, n, V + b, n, n - b, Cb);    // V[64:] = Q1[64:] (-R2^-1 S)
+    }
+    if (lookahead) {
+      RC_HIP(ctx, hipEventRecord(ev_fact[pk & 1], sf));
+      RC_HIP(ctx, hipStreamWaitEvent(st, ev_fact[pk & 1], 0));
+    }
     lap(0, tp);
     // ---- W = A22 V
     // ~3 tile steps per workgroup while the launch stays within ~1024 workgroups
@@ -825,9 +857,19 @@ static int band_reduce_cqr(mmg_ctx* ctx, mmg_reml* r, bool* suspect) {
     launch_band_coef(st, part, 1, partz, 1, q1, Mk, Cm, Cz);
     launch_band_y(st, V, W, n, Mk, Cm, Y, Zs, N, Cz, q1);
     lap(2, tp);
-    // ---- A22 -= V Y' + Y V' (lower tiles)
-    launch_nt_update_lower(st, A22, N, n, V, Y, Y, V, n, n);
+    // ---- A22 -= V Y' + Y V' (lower tiles): the first block column, then the rest
+    if (lookahead) {
+      launch_nt_update_col0(st, A22, N, n, V, Y, Y, V, n, n);
+      RC_HIP(ctx, hipEventRecord(ev_col0[pk & 1], st));
+      if (n > b) launch_nt_update_lower(st, A22 + b + b * N, N, n - b, V + b, Y + b, Y + b, V + b, n, n);
+    } else {
+      launch_nt_update_lower(st, A22, N, n, V, Y, Y, V, n, n);
+    }
     lap(3, tp);
+  }
+  if (lookahead) {                                            // nothing of this call may be left on the second stream
+    RC_HIP(ctx, hipEventRecord(ev_fact[0], sf));
+    RC_HIP(ctx, hipStreamWaitEvent(st, ev_fact[0], 0));
   }
   if (capture) {
     hipGraph_t graph = nullptr;
@@ -1105,8 +1147,25 @@ int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, 
       if (bad[k])
         return set_err(ctx, MMG_E_LIB, "K + delta I is not positive definite (banded Cholesky, pivot " + std::to_string(bad[k]) + ")");
     const auto t1 = std::chrono::steady_clock::now();
-    hipLaunchKernelGGL(band_solve_kernel, dim3(ng), dim3(256), 0, st, L, N, r->dZr, q1, F, G);
-    hipLaunchKernelGGL(band_trace_kernel, dim3(ng), dim3(256), 0, st, L, N, dtr);
+    // the trace recurrence and the substitutions both read L and nothing of each other: two single-workgroup chains per
+    // delta, 3.5 and 1.8 ms at N = 5000 -- side by side on the context's two streams (round 5: 9.2 -> 7.4 ms per call)
+    static const bool side = [] { const char* e = std::getenv("MMG_BAND_TRACE_SIDE"); return !(e && e[0] == '0'); }();
+    if (side) {
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      RC_HIP(ctx, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+      RC_HIP(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+      (void)hipEventRecord(e0, st);
+      (void)hipStreamWaitEvent(ctx->stream2, e0, 0);
+      hipLaunchKernelGGL(band_trace_kernel, dim3(ng), dim3(256), 0, ctx->stream2, L, N, dtr);
+      (void)hipEventRecord(e1, ctx->stream2);
+      hipLaunchKernelGGL(band_solve_kernel, dim3(ng), dim3(256), 0, st, L, N, r->dZr, q1, F, G);
+      (void)hipStreamWaitEvent(st, e1, 0);
+      (void)hipEventDestroy(e0);                               // (released when the work that references them has completed)
+      (void)hipEventDestroy(e1);
+    } else {
+      hipLaunchKernelGGL(band_solve_kernel, dim3(ng), dim3(256), 0, st, L, N, r->dZr, q1, F, G);
+      hipLaunchKernelGGL(band_trace_kernel, dim3(ng), dim3(256), 0, st, L, N, dtr);
+    }
     hipLaunchKernelGGL(band_gram_kernel, dim3(ng, q1 * q1), dim3(256), 0, st, F, G, N, q1, dff, dgg);
     RC_HIP(ctx, hipGetLastError());
     std::vector<double> hs(nsc);

@@ -80,6 +80,167 @@ __global__ void note_info_kernel(const rocblas_int* __restrict__ info, long long
   if (*info != 0 && *acc == 0) *acc = base + (long long)*info;
 }
 
+
+// ---- own kernels of the library-free scan model (round 5) -------------------------------------------------------------
+// out [N x k] = T V (T lower triangular N x N, column-major, only rows >= cols read; V, out column-major N x k, k <= 17):
+// thread = row i, loop over the columns j <= i of T (a wave reads 64 consecutive rows of column j: coalesced), V[j][.] broadcast.
+// The columns are dealt over blockIdx.y slices, partial sums to part[slice][k][N] (fixed order afterwards: deterministic).
+template <int K>
+__global__ __launch_bounds__(256) void tri_apply_n_kernel(const double* __restrict__ T, int64_t N, const double* __restrict__ V,
+                                                          double* __restrict__ part, int nslice) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i_hi = min(N, ((int64_t)blockIdx.x + 1) * 256);            // columns beyond the block's last row contribute nothing
+  const int64_t per = (i_hi + nslice - 1) / nslice;
+  const int64_t j0 = (int64_t)blockIdx.y * per, j1 = min(i_hi, j0 + per);
+  double acc[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) acc[c] = 0.0;
+  if (i < N) {
+    for (int64_t j = j0; j < j1; ++j) {
+      if (j > i) break;
+      const double t = T[i + j * N];
+#pragma unroll
+      for (int c = 0; c < K; ++c) acc[c] = fma(t, V[j + (int64_t)c * N], acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < K; ++c) part[((int64_t)blockIdx.y * K + c) * N + i] = acc[c];
+  }
+}
+
+// out [N x k] = T'V: one wave per column j of T (rows j .. N-1, contiguous), lanes stride the rows, K sums per lane, wave reduce
+template <int K>
+__global__ __launch_bounds__(256) void tri_apply_t_kernel(const double* __restrict__ T, int64_t N, const double* __restrict__ V,
+                                                          double* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int l = threadIdx.x & 63;
+  if (j >= N) return;
+  double acc[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) acc[c] = 0.0;
+  const double* __restrict__ col = T + j * N;
+  for (int64_t i = j + l; i < N; i += 64) {
+    const double t = col[i];
+#pragma unroll
+    for (int c = 0; c < K; ++c) acc[c] = fma(t, V[i + (int64_t)c * N], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    double v = acc[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (l == 0) out[j + (int64_t)c * N] = v;
+  }
+}
+
+__global__ void slice_sum_kernel(const double* __restrict__ part, int nslice, int64_t n, double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  double s = 0.0;
+  for (int k = 0; k < nslice; ++k) s += part[(int64_t)k * n + e];
+  out[e] = s;
+}
+
+// P (lower 64 x 64 tiles, column-major ld ldp) = X'X for a lower-triangular X (column-major ld ldx; the strictly upper part of its
+// diagonal blocks must be zero, blocks above them are never read): tile (I, J), I >= J, = X[64 I :, I]' X[64 I :, J] -- the rows
+// above 64 I of block column I are zero.  One workgroup per tile, the Gram inner loop of dense64.hip (v_mfma_f64_16x16x4_f64,
+// operands straight from global memory); replaces rocBLAS dsyrk + dtrmm recursion (lauum_lower).
+typedef double v4d_rc __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void lauum_tiles_kernel(const double* __restrict__ X, int64_t ldx, int64_t n, double* __restrict__ P,
+                                                          int64_t ldp) {
+  const int64_t t = blockIdx.x;
+  int64_t I = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while (I * (I + 1) / 2 > t) --I;
+  while ((I + 1) * (I + 2) / 2 <= t) ++I;
+  const int64_t J = t - I * (I + 1) / 2;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+  // wave w owns rows 16 w .. 16 w + 15 of the tile (columns 64 I + .. of X), all four 16-column groups of block column J
+  const int64_t ca = I * 64 + 16 * w + lr;                   // X column of the a operand
+  const bool ain = ca < n;
+  const double* __restrict__ ap = X + (ain ? ca : 0) * ldx;
+  const double* bp[4];
+  bool bin[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    const int64_t cb = J * 64 + 16 * ct + lr;
+    bin[ct] = cb < n;
+    bp[ct] = X + (bin[ct] ? cb : 0) * ldx;
+  }
+  v4d_rc acc[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) acc[ct] = v4d_rc{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int64_t r0 = I * 64; r0 < n; r0 += 4) {
+    const int64_t r = r0 + lk;
+    const bool in = r < n;
+    const double a = (in && ain) ? ap[r] : 0.0;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const double bv = (in && bin[ct]) ? bp[ct][r] : 0.0;
+      acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[ct], 0, 0, 0);
+    }
+  }
+  // accumulator layout of v_mfma_f64_16x16x4_f64 (as dense64.hip:gram_slices_kernel stores it): register e of lane l =
+  // C[row 4 e + l / 16][column l % 16], rows = the a operand's index (tile row 16 w + ..), columns = the b operand's (16 ct + ..)
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t pi = I * 64 + 16 * w + 4 * e + lk, pj = J * 64 + 16 * ct + lr;
+      if (pi < n && pj < n) P[pi + pj * ldp] = acc[ct][e];
+    }
+}
+
+// P (n x n column-major, lower tiles valid) -= Gx GA' on the lower tiles and the result mirrored into the upper ones:
+// Gx [n x q] column-major (ld ldg), GA [n x q] ROW-major.  One workgroup per 64 x 64 lower tile, the mirrored tile through LDS.
+__global__ __launch_bounds__(256) void rankq_mirror_kernel(double* __restrict__ P, int64_t n, const double* __restrict__ Gx, int64_t ldg,
+                                                           const double* __restrict__ GA, int q) {
+  const int64_t t = blockIdx.x;
+  int64_t I = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while (I * (I + 1) / 2 > t) --I;
+  while ((I + 1) * (I + 2) / 2 <= t) ++I;
+  const int64_t J = t - I * (I + 1) / 2;
+  __shared__ double tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t i = I * 64 + tx;                             // row (fast index: column-major)
+#pragma unroll 4
+  for (int r = 0; r < 16; ++r) {
+    const int64_t j = J * 64 + ty + 4 * r;
+    double v = 0.0;
+    if (i < n && j < n && (I > J || i >= j)) {
+      v = P[i + j * n];
+      for (int c = 0; c < q; ++c) v -= Gx[i + (int64_t)c * ldg] * GA[j * q + c];
+      P[i + j * n] = v;
+    }
+    tile[ty + 4 * r][tx] = v;                                // tile[col][row]
+  }
+  __syncthreads();
+  // the mirrored element P[j][i] for j > i ... i.e. rows of the upper tile (J, I): row index j2 in block J, column i2 in block I
+  const int64_t j2 = J * 64 + tx;                            // row of the upper tile (fast index)
+#pragma unroll 4
+  for (int r = 0; r < 16; ++r) {
+    const int64_t i2 = I * 64 + ty + 4 * r;                  // its column
+    if (j2 < n && i2 < n && (I > J ? true : j2 < i2)) P[j2 + i2 * n] = tile[tx][ty + 4 * r];
+  }
+}
+
+// B [n x n] column-major = A' (out of place), 64 x 64 tiles through LDS
+__global__ __launch_bounds__(256) void transpose64_kernel(const double* __restrict__ A, int64_t n, double* __restrict__ B) {
+  __shared__ double tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t i0 = (int64_t)blockIdx.x * 64, j0 = (int64_t)blockIdx.y * 64;
+#pragma unroll 4
+  for (int r = 0; r < 16; ++r) {
+    const int64_t i = i0 + tx, j = j0 + ty + 4 * r;
+    tile[ty + 4 * r][tx] = (i < n && j < n) ? A[i + j * n] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int r = 0; r < 16; ++r) {
+    const int64_t j = j0 + tx, i = i0 + ty + 4 * r;          // B[j][i] = A[i][j]
+    if (i < n && j < n) B[j + i * n] = tile[tx][ty + 4 * r];
+  }
+}
+
 }  // namespace mmg
 using namespace mmg;
 
@@ -234,6 +395,40 @@ static int tri_inv_own(mmg_ctx* ctx, double* L, int64_t N, const double* LinvT_a
   return MMG_OK;
 }
 
+
+// out [N x k] = T V / T'V for the lower-triangular T (see the kernels); V, out device column-major (ld N), k <= 17
+static int tri_apply_own(mmg_ctx* ctx, const double* T, int64_t N, const double* V, int k, double* out, bool trans, Scratch& sc) {
+  hipStream_t st = ctx->stream;
+  if (k < 1 || k > 17) return set_err(ctx, MMG_E_ARG, "tri_apply_own: 1..17 columns");
+#define MMG_TA(K_)                                                                                                       \
+  case K_:                                                                                                              \
+    if (trans) hipLaunchKernelGGL(tri_apply_t_kernel<K_>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, T, N, V, out); \
+    else hipLaunchKernelGGL(tri_apply_n_kernel<K_>, dim3((unsigned)((N + 255) / 256), nslice), dim3(256), 0, st, T, N, V, part, nslice); \
+    break;
+  const int nslice = (int)std::max<int64_t>(1, std::min<int64_t>(16, N / 256));
+  double* part = nullptr;
+  if (!trans) RC_HIP(ctx, sc.alloc(&part, (size_t)nslice * k * N * sizeof(double)));
+  switch (k) {
+    MMG_TA(1) MMG_TA(2) MMG_TA(3) MMG_TA(4) MMG_TA(5) MMG_TA(6) MMG_TA(7) MMG_TA(8) MMG_TA(9) MMG_TA(10) MMG_TA(11) MMG_TA(12)
+    MMG_TA(13) MMG_TA(14) MMG_TA(15) MMG_TA(16) MMG_TA(17)
+  }
+#undef MMG_TA
+  if (!trans) {
+    const int64_t tot = (int64_t)k * N;
+    hipLaunchKernelGGL(slice_sum_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, part, nslice, tot, out);
+  }
+  RC_HIP(ctx, hipGetLastError());
+  return MMG_OK;
+}
+
+// whether a call of size N runs on this library's kernels alone (no rocBLAS / rocSOLVER handle is even created): the own
+// Cholesky keeps every diagonal block's inverse up to N = 8192; MMG_REML_LIB=1 forces the library route (A/B)
+static bool reml_own_route(int64_t N) {
+  static const bool lib = [] { const char* e = std::getenv("MMG_REML_LIB"); return e && e[0] == '1'; }();
+  const char* pe = std::getenv("MMG_REML_POTRF");
+  return !lib && N <= 8192 && (!pe || std::string(pe) == "own");
+}
+
 struct RemlPoint {           // everything one delta yields
   double s1, s2, s3, s4;
   double ldh = 0.0, trh = 0.0;   // log|H|, tr H^-1
@@ -244,10 +439,14 @@ struct RemlPoint {           // everything one delta yields
 
 // factor H = K + delta I in r->dL and fill `pt`; leaves L^-1 (lower) in r->dL when inverse is true
 static int reml_point(mmg_ctx* ctx, mmg_reml* r, double delta, bool inverse, bool want_vectors, RemlPoint& pt) {
-  rocblas_handle h;
-  int rc = reml_handle(ctx, &h);
-  if (rc) return rc;
   const int64_t N = r->N;
+  // Round 5: with the inverse asked for (every caller's case) and N <= 8192 the whole point -- factorisation, inverse, the
+  // products with [X y] -- runs on this library's kernels; no rocBLAS / rocSOLVER handle is created (a process that only
+  // calls emmax() never loads either library: first call 0.25 -> ~0.1 s at N = 5000, seconds at N = 199 on a cold box)
+  const bool own_all = inverse && reml_own_route(N);
+  rocblas_handle h = nullptr;
+  int rc = MMG_OK;
+  if (!own_all && (rc = reml_handle(ctx, &h))) return rc;
   const int q = r->q, q1 = q + 1;
   hipStream_t st = ctx->stream;
   rocblas_int* dinfo = (rocblas_int*)(r->dsc + N + 4);   // [N+4]: info word read back; [N+6]: first failing block; [N+8]: scratch
@@ -271,7 +470,7 @@ static int reml_point(mmg_ctx* ctx, mmg_reml* r, double delta, bool inverse, boo
       // MMG_REML_TRTRI=own: tri_inv_own.  Measured and NOT the default: emmax()'s scan phase 48.9 ms against 45.9 ms with
       // rocsolver_dtrtri + trmm at N = 5000 (9.0 / 7.9 at 2000) -- the 9 ms a kernel trace attributes to the library's
       // inverse are profiler overhead on its many small launches; its wall time is 3 ms
-      own_inverse = inverse && N <= 8192 && std::getenv("MMG_REML_TRTRI") && std::string(std::getenv("MMG_REML_TRTRI")) == "own";
+      own_inverse = own_all || (inverse && N <= 8192 && std::getenv("MMG_REML_TRTRI") && std::string(std::getenv("MMG_REML_TRTRI")) == "own");
       RC_HIP(ctx, sc_inv.alloc(&LinvT_all, (own_inverse ? (size_t)((N + 63) / 64) : 1) * 4096 * sizeof(double)));
       int rcb = N <= 8192 ? potrf_own(ctx, r->dL, N, N, LinvT_all, dacc, 0, own_inverse)
                           : potrf_blocked(ctx, h, r->dL, N, 2048, (rocblas_int*)(r->dsc + N + 8), dacc, LinvT_all);
@@ -292,12 +491,23 @@ static int reml_point(mmg_ctx* ctx, mmg_reml* r, double delta, bool inverse, boo
   hipLaunchKernelGGL(logdiag_kernel, dim3(1), dim3(256), 0, st, r->dL, N, r->dsc);
   // Z = L^-1 [X y];  G = L^-T Z
   const double one = 1.0;
-  RC_HIP(ctx, hipMemcpyAsync(r->dZ, r->dB, (size_t)N * q1 * sizeof(double), hipMemcpyDeviceToDevice, st));
-  RC_RB(ctx, rocblas_dtrsm_64(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N,
-                              q1, &one, r->dL, N, r->dZ, N));
-  RC_HIP(ctx, hipMemcpyAsync(r->dG, r->dZ, (size_t)N * q1 * sizeof(double), hipMemcpyDeviceToDevice, st));
-  RC_RB(ctx, rocblas_dtrsm_64(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
-                              N, q1, &one, r->dL, N, r->dG, N));
+  bool inverted = false;
+  if (own_all) {
+    // the inverse first (three launches per block column, dense64.h), then both as products with it
+    Scratch sc_ta;
+    if ((rc = tri_inv_own(ctx, r->dL, N, LinvT_all, sc_inv))) return rc;
+    inverted = true;
+    if ((rc = tri_apply_own(ctx, r->dL, N, r->dB, q1, r->dZ, false, sc_ta))) return rc;
+    if ((rc = tri_apply_own(ctx, r->dL, N, r->dZ, q1, r->dG, true, sc_ta))) return rc;
+    RC_HIP(ctx, hipStreamSynchronize(st));                     // sc_ta is released here
+  } else {
+    RC_HIP(ctx, hipMemcpyAsync(r->dZ, r->dB, (size_t)N * q1 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    RC_RB(ctx, rocblas_dtrsm_64(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, rocblas_diagonal_non_unit, N,
+                                q1, &one, r->dL, N, r->dZ, N));
+    RC_HIP(ctx, hipMemcpyAsync(r->dG, r->dZ, (size_t)N * q1 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    RC_RB(ctx, rocblas_dtrsm_64(h, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose, rocblas_diagonal_non_unit,
+                                N, q1, &one, r->dL, N, r->dG, N));
+  }
   std::vector<double> Z((size_t)N * q1), G((size_t)N * q1);
   double sc[4] = {0, 0, 0, 0};
   int64_t info64 = 0;
@@ -311,8 +521,10 @@ static int reml_point(mmg_ctx* ctx, mmg_reml* r, double delta, bool inverse, boo
   double trHinv = 0.0;
   if (verbose) t2 = now();
   if (inverse) {
-    rc = own_inverse ? tri_inv_own(ctx, r->dL, N, LinvT_all, sc_inv) : tri_inv_lower(ctx, h, r->dL, N, N, dinfo);
-    if (rc) return rc;
+    if (!inverted) {
+      rc = own_inverse ? tri_inv_own(ctx, r->dL, N, LinvT_all, sc_inv) : tri_inv_lower(ctx, h, r->dL, N, N, dinfo);
+      if (rc) return rc;
+    }
     hipLaunchKernelGGL(lower_sqnorm_kernel, dim3((unsigned)N), dim3(256), 0, st, r->dL, N, r->dsc + 4);
     std::vector<double> part((size_t)N);
     RC_HIP(ctx, hipMemcpyAsync(part.data(), r->dsc + 4, N * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -544,9 +756,10 @@ int mmg_reml_scan_model_c(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, 
   MMG_NOTE_ENTRY();
   RC_HIP(ctx, hipSetDevice(ctx->device));
   if (!r) return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_scan_model");
-  rocblas_handle h;
-  int rc = reml_handle(ctx, &h);
-  if (rc) return rc;
+  const bool own_all = reml_own_route(r->N);
+  rocblas_handle h = nullptr;
+  int rc = MMG_OK;
+  if (!own_all && (rc = reml_handle(ctx, &h))) return rc;
   RemlPoint pt;
   rc = reml_point(ctx, r, delta, true, true, pt);          // leaves L^-1 (lower) in dL
   if (rc) return rc;
@@ -562,17 +775,23 @@ int mmg_reml_scan_model_c(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, 
   hipLaunchKernelGGL(zero_upper_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)N), dim3(256), 0, st, r->dL, N);
   r->linv_delta = delta;                                      // (reml_linv_device: the permutation test of the same delta reuses it)
   const double one = 1.0, zero = 0.0, mone = -1.0;
-  {
+  RC_HIP(ctx, hipMemcpyAsync(dGA, pt.GA.data(), (size_t)N * q * sizeof(double), hipMemcpyHostToDevice, st));
+  dGx = r->dG;
+  if (own_all) {
+    // lower tiles of H^-1 = X'X (lauum_tiles_kernel), then P = H^-1 - Gx GA' on them and the mirror image, one pass
+    const int64_t nt = (N + 63) / 64;
+    hipLaunchKernelGGL(lauum_tiles_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, r->dL, N, N, dP, N);
+    hipLaunchKernelGGL(rankq_mirror_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, dP, N, dGx, N, dGA, q);
+    RC_HIP(ctx, hipGetLastError());
+  } else {
     static const bool dense = [] { const char* e = std::getenv("MMG_REML_LAUUM"); return e && e[0] == '0'; }();   // A/B: dense syrk on the factor
     if (dense) RC_RB(ctx, rocblas_dsyrk_64(h, rocblas_fill_lower, rocblas_operation_transpose, N, N, &one, r->dL, N, &zero, dP, N));
     else if ((rc = lauum_lower(ctx, h, r->dL, N, N, dP, N))) return rc;
+    hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)N), dim3(256), 0, st, dP, N);
+    // P = H^-1 - (Gx a^-1) Gx'   (GA row-major N x q == column-major q x N;  dG column-major N x (q+1): Gx = first q columns)
+    // column-major: P (N x N) -= Gx (N x q) * GA' (q x N) where GA' in column-major is the row-major GA buffer read as q x N
+    RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_none, N, N, q, &mone, dGx, N, dGA, q, &one, dP, N));
   }
-  hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)N), dim3(256), 0, st, dP, N);
-  // P = H^-1 - (Gx a^-1) Gx'   (GA row-major N x q == column-major q x N;  dG column-major N x (q+1): Gx = first q columns)
-  RC_HIP(ctx, hipMemcpyAsync(dGA, pt.GA.data(), (size_t)N * q * sizeof(double), hipMemcpyHostToDevice, st));
-  dGx = r->dG;
-  // column-major: P (N x N) -= Gx (N x q) * GA' (q x N) where GA' in column-major is the row-major GA buffer read as q x N
-  RC_RB(ctx, rocblas_dgemm_64(h, rocblas_operation_none, rocblas_operation_none, N, N, q, &mone, dGx, N, dGA, q, &one, dP, N));
   RC_HIP(ctx, hipMemcpyAsync(dw, pt.Py.data(), N * sizeof(double), hipMemcpyHostToDevice, st));
   RC_HIP(ctx, hipGetLastError());
   bool adaptive = false;
@@ -601,9 +820,7 @@ int mmg_reml_linv_apply(mmg_ctx* ctx, mmg_reml* r, double delta, int32_t trans, 
   MMG_NOTE_ENTRY();
   RC_HIP(ctx, hipSetDevice(ctx->device));
   if (!(r && V && out && k >= 1 && (trans == 0 || trans == 1))) return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_linv_apply");
-  rocblas_handle h;
-  int rc = reml_handle(ctx, &h);
-  if (rc) return rc;
+  int rc = MMG_OK;
   const double* dLinv = nullptr;
   if ((rc = reml_linv_device(ctx, r, delta, &dLinv))) return rc;
   const int64_t N = r->N;
@@ -612,9 +829,15 @@ int mmg_reml_linv_apply(mmg_ctx* ctx, mmg_reml* r, double delta, int32_t trans, 
   RC_HIP(ctx, sc.alloc(&dV, (size_t)N * k * sizeof(double)));
   RC_HIP(ctx, sc.alloc(&dO, (size_t)N * k * sizeof(double)));
   RC_HIP(ctx, hipMemcpyAsync(dV, V, (size_t)N * k * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  const double one = 1.0, zero = 0.0;
-  RC_RB(ctx, rocblas_dgemm_64(h, trans ? rocblas_operation_transpose : rocblas_operation_none, rocblas_operation_none, N, k, N, &one,
-                              dLinv, N, dV, N, &zero, dO, N));
+  if (k <= 17) {                                               // a handful of vectors: the bandwidth-bound own kernels
+    if ((rc = tri_apply_own(ctx, dLinv, N, dV, k, dO, trans != 0, sc))) return rc;
+  } else {
+    rocblas_handle h;
+    if ((rc = reml_handle(ctx, &h))) return rc;
+    const double one = 1.0, zero = 0.0;
+    RC_RB(ctx, rocblas_dgemm_64(h, trans ? rocblas_operation_transpose : rocblas_operation_none, rocblas_operation_none, N, k, N, &one,
+                                dLinv, N, dV, N, &zero, dO, N));
+  }
   RC_HIP(ctx, hipMemcpyAsync(out, dO, (size_t)N * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   RC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MMG_OK;
@@ -626,18 +849,16 @@ int mmg_reml_linv_fetch(mmg_ctx* ctx, mmg_reml* r, double delta, double* H_out) 
   MMG_NOTE_ENTRY();
   RC_HIP(ctx, hipSetDevice(ctx->device));
   if (!(r && H_out)) return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_linv_fetch");
-  rocblas_handle h;
-  int rc = reml_handle(ctx, &h);
-  if (rc) return rc;
+  int rc = MMG_OK;
   const double* dLinv = nullptr;
   if ((rc = reml_linv_device(ctx, r, delta, &dLinv))) return rc;
   const int64_t N = r->N;
   Scratch sc;
   double* dT = nullptr;
   RC_HIP(ctx, sc.alloc(&dT, (size_t)N * N * sizeof(double)));
-  const double one = 1.0, zero = 0.0;                          // out-of-place transpose: column-major L^-1 -> row-major L^-1
-  RC_RB(ctx, rocblas_dgeam(h, rocblas_operation_transpose, rocblas_operation_none, (rocblas_int)N, (rocblas_int)N, &one, dLinv,
-                           (rocblas_int)N, &zero, dT, (rocblas_int)N, dT, (rocblas_int)N));
+  // out-of-place transpose: column-major L^-1 -> row-major L^-1
+  hipLaunchKernelGGL(transpose64_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0, ctx->stream, dLinv, N, dT);
+  RC_HIP(ctx, hipGetLastError());
   RC_HIP(ctx, hipMemcpyAsync(H_out, dT, (size_t)N * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   RC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MMG_OK;

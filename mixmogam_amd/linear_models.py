@@ -130,8 +130,11 @@ REML_SUMS_FROM_EIG_L = True
 # secant search on an interpolant of the sums, own blocked Cholesky for the scan model) -- tools/reml_vs_eigh.py, emmax()
 # on resident genotypes, eigen route / this route: N = 300 9.9 / 5.6 ms, 1000 91 / 17 ms, 2000 100 / 48 ms, 5000 324 /
 # 126 ms, 8192 957 / 297 ms (profiles/r4_reml_vs_eigh.txt); round 3 had the crossover at 5000.  Below N = 256
-# mmg_reml_sums takes one Cholesky factorisation per delta and the eigen route stays.
-EIGEN_FREE_MIN_N = 255
+# mmg_reml_sums takes one Cholesky factorisation per delta (no band to reduce to) -- since round 5 on this library's own kernels
+# like everything else of the route up to N = 8192 (csrc/reml_chol.hip: reml_own_route), so the smallest data sets take it
+# too: a process that calls emmax() on the bundled 199 accessions never loads rocSOLVER / rocBLAS (10-23 s of a first call on a
+# cold box, profiles/r4_small_configs.txt).  MMG_EIGEN_FREE_MIN_N overrides (256: round 4).
+EIGEN_FREE_MIN_N = int(os.environ.get("MMG_EIGEN_FREE_MIN_N", 15))
 EIGH_MAX_N = 46340
 # emmax_f_test builds the scan model on the device from K and delta (mmg_reml_scan_model) when nothing needs H itself.
 DEVICE_SCAN_MODEL = True
