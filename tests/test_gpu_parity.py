@@ -517,14 +517,27 @@ def test_chunked_run_emmax_perm(ctx):
     keep = [np.minimum(s.mean(1), 1 - s.mean(1)) > 0.05 for s in allsnps]
     # hdf5_data.py:294-311: the permutation test sees every chromosome but the LAST (`chr12_snps`)
     filt = np.vstack([s[k] for s, k in zip(allsnps, keep)][:-1])
-    lmm = lm.LinearMixedModel(y, ctx=ctx)
-    lmm.add_random_effect(a["kinship"])
-    eL, eR = lmm._get_eigen_L_(), lmm._get_eigen_R_(X=lmm.X)
-    H = lmm._get_estimates_with(eL, eR, "REML")["H_sqrt_inv"]    # the same (deterministic) device eigenbasis
+    # round 5: the driver's H_sqrt_inv is L^-1 of K + delta I = L L' (no eigendecomposition); the oracle on the same matrix
+    from mixmogam_amd import kinship
+    delta = 1.0 / a["pseudo_heritability"] - 1.0
+    H = np.linalg.inv(np.linalg.cholesky(kinship.scale_k(np.asarray(a["kinship"])) + delta * np.eye(n)))
     pp = orc.perm_prepare(y, np.ones((n, 1)), H, np.asarray(idx))
     ref = orc.perm_closed(filt, pp)
     assert rel(a["perm_max_f_stats"], ref["max_f_stats"]) < 1e-6
     assert a["threshold_05"][0] == np.sort(a["perm_min_ps"])[1]
+    # ... and MMG_PERM_H=eigen keeps the literal route: the eigendecomposition's matrix (the same deterministic device eigenbasis)
+    import os
+    os.environ["MMG_PERM_H"] = "eigen"
+    try:
+        c = hdf5_data.run_emmax_perm(src, y, min_maf=0.05, chunk_size=128, num_perm=30, perm_idx=idx, k=a["kinship"], ctx=ctx)
+    finally:
+        del os.environ["MMG_PERM_H"]
+    lmm = lm.LinearMixedModel(y, ctx=ctx)
+    lmm.add_random_effect(a["kinship"])
+    eL, eR = lmm._get_eigen_L_(), lmm._get_eigen_R_(X=lmm.X)
+    He = lmm._get_estimates_with(eL, eR, "REML")["H_sqrt_inv"]
+    refe = orc.perm_closed(filt, orc.perm_prepare(y, np.ones((n, 1)), He, np.asarray(idx)))
+    assert rel(c["perm_max_f_stats"], refe["max_f_stats"]) < 1e-6
 
 
 def test_mlmm_forward_backward_vs_golden(ctx):
