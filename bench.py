@@ -333,6 +333,30 @@ def main():
                 del r2, lmm2
         finally:
             lm.EIGEN_FREE_MIN_N = keep
+    # ---- the whole job as one clock (the timed region above leaves the replicated stages out): IBS kinship of
+    # every rank's SNP block (RCCL sum of the counts, scale_k on the device, kept in HBM) -> REML -> scan model -> scan of this
+    # rank's SNPs -> p-values on the host; max over the ranks
+    job_s = job_phases = None
+    if mode in ("weak", "strong"):
+        def whole_job():
+            t0 = time.time()
+            K2 = kinship.calc_ibs_kinship(None, geno=g, ctx=ctx, keep_device=True, comm=comm_h, m_total=Mtot)
+            tk = time.time()
+            lmm2 = lm.LinearMixedModel(y, ctx=ctx)
+            lmm2.add_random_effect(K2)
+            r2 = lmm2.emmax_f_test(g, emma_num=0)
+            K2.close()
+            t1 = time.time()
+            ph = {"kinship": tk - t0}
+            ph.update({k: v for k, v in r2.get("timings", {}).items() if v})
+            return t1 - t0, ph
+        whole_job()
+        barrier()
+        runs = [whole_job() for _ in range(2)]
+        barrier()
+        job_s, job_phases = min(runs, key=lambda v: v[0])
+        if coll is not None:
+            job_s = float(coll.allreduce(np.array([job_s]), "max")[0])
     setup_per_rank = [t_setup]
     e2e_per_rank = [e2e]
     if coll is not None:
@@ -347,6 +371,13 @@ def main():
                                   "model and the permutation plan are in model_and_plan_s (no eigendecomposition)"})
         if est is not None:
             res.update({"eigh_ms": eigh_ms, "delta": float(est["delta"])})
+        if job_s is not None:
+            res.update({"end_to_end_s": job_s, "end_to_end_phases_s": job_phases, "end_to_end_snps_per_s": Mtot / job_s,
+                        "end_to_end_s_note": "kinship (IBS counts of every rank's SNP block, RCCL sum, scale_k on the device, "
+                                           "kept in HBM) -> REML (band reduction, replicated) -> scan model (replicated) -> "
+                                           "EMMAX scan of this rank's SNPs -> p-values on the host; best of two warm runs, "
+                                           "max over the ranks.  This is the clock a scaling curve should be read against: "
+                                           "`value` times the scan alone"})
         if e2e is not None:
             res.update({"end_to_end_emmax_s": max(e2e_per_rank), "end_to_end_emmax_s_per_rank": e2e_per_rank,
                         "end_to_end_emmax_first_call_s": e2e_first, "end_to_end_emmax_phases_s": e2e_timings,
@@ -1035,11 +1066,43 @@ def bench_c5(args, ctx, coll, rank, world, info, rccl_nranks):
                         "achieved": None, "frac": grm_ops * n_snps / max(grm_s, 1e-9) / 1e12 / 5000.0,
                         "note": "executed int8 ops of the kinship pass (its GEMM kernels are the largest stage) over their "
                                 "summed kernel time on all ranks; the scan's kernel time is scan_kernel_s", "traffic": None},
-           "cpu_baseline": None,
+           "cpu_baseline": (cpu_baseline_c5(N) if (not args.no_cpu_baseline and world == 1) else None),
            "pseudo_heritability": float(out["pseudo_heritability"]), "min_p": float(ps.min()),
            "n_p_below_1e-8": int((ps < 1e-8).sum()), "device": info}
     rec["roofline"]["achieved"] = rec["roofline"]["frac"] * 5000.0
     print(json.dumps(rec))
+
+
+def cpu_baseline_c5(N, sample=1024):
+    """the CPU path on a SUBSAMPLE, extrapolated linearly in M.  At N = 50,000 the reference's two
+    per-SNP stages are timed on `sample` SNPs each, in the shapes and dtypes its loops use: the kinship chunk product
+    (2S - 1)(2S - 1)' in float64 (kinship.py:29-44) and the scan chunk -- float32 `chunk @ M` with an N x N matrix, one
+    scipy.linalg.lstsq per SNP, f.sf (linear_models.py:1315-1349).  The projection matrix is a constant-filled stand-in (BLAS
+    time does not depend on the values; the real one needs eigh(K) of a 50,000 x 50,000 matrix, ~1e15 flop, which is NOT
+    timed and NOT in the figure: the baseline is an upper bound of the CPU rate)."""
+    import scipy.linalg
+    import scipy.stats
+    rng = np.random.RandomState(5)
+    chunk = (rng.random_sample((sample, N)) < 0.5).astype(np.int8)
+    t0 = time.time()
+    x = (2.0 * chunk - 1.0)                                              # float64, as sp.mat(..., dtype='single') * 2 - 1 promotes
+    k_part = x.T @ x
+    t_kin = time.time() - t0
+    del k_part, x
+    Mp = np.full((N, N), 1e-3, dtype=np.float32)
+    r = rng.standard_normal(N).astype(np.float32)
+    t0 = time.time()
+    Xs = chunk.astype(np.float32) @ Mp                                   # :1317-1318
+    rss = np.empty(sample)
+    for j in range(sample):                                              # :1328
+        rss[j] = float(np.sum((r - Xs[j] * scipy.linalg.lstsq(Xs[j][:, None], r)[0][0]) ** 2))
+    scipy.stats.f.sf(np.maximum(rss, 1e-30), 1, N - 2)
+    t_scan = time.time() - t0
+    per_snp = (t_kin + t_scan) / sample
+    return {"value": 1.0 / per_snp, "unit": "SNPs/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d SNPs at N = %d through the reference's two per-SNP stages (kinship chunk product in float64 %.1f s, "
+                      "scan chunk float32 GEMM + one lstsq per SNP + f.sf %.1f s), extrapolated linearly in M; eigh(K) "
+                      "(~1e15 flop at this N) is not timed and not in the figure" % (sample, N, t_kin, t_scan)}
 
 
 def _device_rows(ctx, rows, n, seed):
