@@ -1001,7 +1001,11 @@ def bench_multi(args, ctx, coll, g, lmm, eig_L, N, M, Mtot, barrier, common):
                 "ms_per_step": 1e3 * elapsed / args.steps, "scaling": "weak", "dtype": "f64",
                 "config": {"workload": "N=%d x M=%d SNPs per GPU, %d phenotypes with their own delta, %d per pass" % (N, M, P, scan_multi_batch()),
                            "parallelism": "snp-block x%d" % common["n_gpus"]},
-                "roofline": multi_roofline(N, M, 1, min(P, scan_multi_batch()), pass_ms),
+                # (a pass moves the same bytes whatever the phenotype count of the run: the committed per-launch figure applies as
+                # long as the pass has the profile's batch -- round 4 shipped `traffic: null` for the 64-phenotype default)
+                "roofline": multi_roofline(N, M, 1, min(P, scan_multi_batch()), pass_ms,
+                                           _profiled_traffic(N, M, 0, True).get("scan_multi_mfma_kernel")
+                                           if min(P, scan_multi_batch()) == 16 else None),
                 "rotation_gemm_ms": rot_ms, "host_model_ms_per_phenotype": 1e3 * t_models / P,
                 "min_p": float(out["ps"].min())})
     return res
