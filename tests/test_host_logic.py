@@ -385,6 +385,24 @@ def test_real_hdf5_files_drive_the_same_driver(ctx, tmp_path):
     assert np.array_equal(kd["k"], ref["kinship"]) and kd["n_snps"] == 500
 
 
+def test_real_hdf5_branch_runs_under_an_interpreter_that_has_h5py():
+    """This image's main interpreter has no h5py (the test above is skipped there), but it ships a second one that has
+    (/opt/conda/bin/python3.9: h5py 3.3.0, numpy 1.26, scipy 1.7): the real-HDF5 branch -- h5py.File in, h5py.File out,
+    lzf-compressed raw_snps in the layout of plink2hdf5.py:111-118, copy_tree, the kinship file helpers -- runs there, on the
+    numpy stand-in context.  Skipped where neither interpreter has h5py."""
+    import importlib.util, os, subprocess, sys
+    if importlib.util.find_spec("h5py") is not None:
+        pytest.skip("h5py is importable here: test_real_hdf5_files_drive_the_same_driver ran in this interpreter")
+    alt = os.environ.get("MMG_H5PY_PYTHON", "/opt/conda/bin/python3.9")
+    probe = subprocess.run([alt, "-c", "import h5py, numpy, scipy, pytest"], capture_output=True) if os.path.exists(alt) else None
+    if probe is None or probe.returncode != 0:
+        pytest.skip("no interpreter with h5py on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([alt, "-m", "pytest", os.path.join(root, "tests", "test_host_logic.py"), "-q", "-p", "no:cacheprovider",
+                          "-k", "real_hdf5_files_drive", "-W", "ignore"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0 and "1 passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("bits,hi", [(1, 2), (2, 3)])
 def test_packed_genotype_containers_drive_the_same_driver(ctx, tmp_path, bits, hi):
     """`raw_snps_packed` (1 / 2 bits per genotype, low bits first) instead of `raw_snps`: pack / unpack round trip
