@@ -171,8 +171,13 @@ __device__ __forceinline__ void g4_slice(v16i (&acc)[4][2][2], const OpsG4& cur,
 // Runs one job; epi(acc): acc[d][m][n] = plane d, rows = P columns wm*64 + m*32 .., columns = Q columns wn*64 + n*32 ..
 // (C layout of gemm_i8_core.h inside a 32 x 32 tile).
 // ABL (timing ablations, WRONG results): 1 = no DMA in the loop, 2 = no LDS reads in the loop, 3 = no barrier in the loop
+// ABL 8 + k, k = 0..3 (round 5, `make EXPERIMENTS=1`): right results + s_memtime stamps (shader clock, SGPRs) at the start of a K
+// step, behind position k of it (0: slice 2, 1: slice 3, 2: the vmcnt / lgkmcnt wait + barrier, 3: slice 0 with its P pieces) and
+// at its end: stamps[k] += cycles start -> position, stamps[4] += position -> end, stamps[5] = K steps, stamps[6] = the loop;
+// lane 0 of every wave writes its row before the epilogue.  One position per variant: all five in one kernel cost 134 spilled
+// VGPRs (round 4 met the same wall), a single one none.
 template <int ABL = 0, class EpiFn>
-__device__ __forceinline__ void g4_stream(const G4Job& job, int64_t ld, char* lds, EpiFn&& epi) {
+__device__ __forceinline__ void g4_stream(const G4Job& job, int64_t ld, char* lds, EpiFn&& epi, unsigned long long* stamps = nullptr) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -245,24 +250,42 @@ __device__ __forceinline__ void g4_stream(const G4Job& job, int64_t ld, char* ld
   // k-slice s + 1 and reads those of k-slice s + 2 -- for s = 2, 3 that is k-slice 0, 1 of stage t + 1 in the other slot,
   // hence the barrier (and the vmcnt(0) for that stage) between slices 1 and 3.  Behind it every read of slot t & 1 has
   // been issued and waited for: stage t + 2 is issued into it during slices 2 and 3.
+  unsigned long long seg[5] = {0, 0, 0, 0, 0};
+  const unsigned long long T0 = ABL >= 8 ? __builtin_amdgcn_s_memtime() : 0;
+  unsigned long long tp = T0;
+#define MMG_G4_STAMP(K) do { if (ABL >= 8 && (K == 4 || K == ABL - 8)) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); seg[K] += now_ - tp; tp = now_; } } while (0)
   for (int t = 0; t < job.nks; ++t) {
     char* cur = lds + (t & 1) * G4_BUF;
     char* oth = lds + ((t + 1) & 1) * G4_BUF;
 #define MMG_G4_ARGS(SRC, SL) SRC, ab, bb, dgb, SL, sp, sq, rdig, dig_voff, dig_stride2, cur, wave
     if (t == 0) g4_slice<false, false, true, ABL>(acc, f0, f1, r1, r0, MMG_G4_ARGS(cur, 2));
     else g4_slice<false, false, false, ABL>(acc, f0, f1, r1, r0, MMG_G4_ARGS(cur, 2));
+    MMG_G4_STAMP(0);
     g4_slice<false, false, false, ABL>(acc, f1, f0, r0, r1, MMG_G4_ARGS(cur, 3));
+    MMG_G4_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (ABL != 3) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    MMG_G4_STAMP(2);
     g4_slice<true, false, false, ABL>(acc, f0, f1, r1, r0, MMG_G4_ARGS(oth, 0));
+    MMG_G4_STAMP(3);
     g4_slice<false, true, false, ABL>(acc, f1, f0, r0, r1, MMG_G4_ARGS(oth, 1));
+    MMG_G4_STAMP(4);
 #undef MMG_G4_ARGS
     advance();                                           // -> stage t+3
   }
+#undef MMG_G4_STAMP
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the re-issued tail stages must land before LDS is released
   wait_raw_g4(r0);                                       // ... and the raw fragments read for slices that do not exist stay
   wait_raw_g4(r1);                                       // live up to here (gemm_i8_w4tr.h: frag_drain)
+  if (ABL >= 8 && stamps != nullptr && lane == 0) {
+    const unsigned long long total = __builtin_amdgcn_s_memtime() - T0;
+    unsigned long long* o = stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) o[k] = seg[k];
+    o[5] = (unsigned long long)job.nks;
+    o[6] = total;
+  }
   epi(acc);
 }
 
@@ -441,6 +464,153 @@ __device__ __forceinline__ void g4r_stream(const G4Job& job, int64_t ld, char* l
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the re-issued tail stages must land before LDS is released
   wait_lds_g4r(r0, b0);                                  // ... and the registers of the reads for slices that do not exist
   wait_lds_g4r(r1, b1);                                  // stay live up to here (gemm_i8_w4tr.h: frag_drain)
+  epi(acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the quadrant kernel with the scaling where the compiler had put it anyway -- in the slice that CONSUMES it.
+// tools/grm4_stamps.py (s_memtime stamps, one position per variant) on g4_stream: the first slice of a K step took 1124
+// cycles, the other three 614-629, the wait + barrier 40.  The ISA shows why: `nxt.as[d] = mask & digit` is plain arithmetic,
+// sched_barrier orders a basic block only, the wave-0 digit pieces and the stage cursor split a slice into several blocks, and
+// machine sinking carried every scaled operand down to the block of the MFMA that uses it -- for slices 1-3 of a step into
+// the gap in front of that MFMA (fine), for the first slice into the LOOP LATCH (its operands are loop-carried, the header
+// has two predecessors): 8 v_add + 32 v_bitop3 in a row with the matrix pipe idle.  Pinning the operands where g4_slice computes
+// them (an empty volatile asm per result) restores the designed pipeline and spills 149 VGPRs: two scaled + two raw operand
+// sets never fitted beside the addresses; the "one slice ahead" scaling was never what ran.
+// Here a slice scales its own raw operands in the gaps in front of their first use (as[0] before MFMA 0, as[1..3] in gaps
+// 0-2, at[0..3] in gaps 3-6; MFMAs 8-15 reuse them), reads the raw fragments of the NEXT slice in gaps 7-9 into the other
+// raw set (one slice of lookahead: 6 MFMAs = 200 cycles for 12 LDS reads) and issues its DMA pieces in gaps 10-15.  Nothing
+// scaled is carried from slice to slice, so nothing can sink across a block boundary.  Slot use of a step t (stage t in
+// slot t & 1): slices 0-2 read k-slices 1-3 of the stage, the barrier, slice 3 reads k-slice 0 of stage t + 1 from the other
+// slot and issues the P pieces of stage t + 2 into the slot just retired; slice 0 of step t + 1 issues its Q pieces and digits.
+template <bool DMA_P, bool DMA_Q, bool ZERO>
+__device__ __forceinline__ void g4j_slice(v16i (&acc)[4][2][2], RawG4& cur, RawG4& nxt, const char* src, const int (&ab)[2],
+                                          const int (&bb)[2], int dgb, int slice, const StageG4& sp, const StageG4& sq,
+                                          const __amdgpu_buffer_rsrc_t& rdig, int dig_voff, int dig_stride2, char* dst, int wave) {
+  const uint32_t s32 = (uint32_t)(uintptr_t)src;
+  const v16i zero = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  wait_raw_g4(cur);                                      // the reads of `cur` were issued in gaps 7-9 of the slice before
+  v4i as[4], at[4];
+  const v4i m0 = byte_mask_g4(cur.a[0]);
+  v4i m1 = m0;
+  as[0] = m0 & cur.dg[0];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int m = (i >> 2) & 1, n = i >> 3, d = i & 3;    // (as, b0) x 4, (at, b0) x 4, (as, b1) x 4, (at, b1) x 4
+    acc[d][m][n] = mfma8(m ? at[d] : as[d], cur.b[n], ZERO ? zero : acc[d][m][n]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (i < 3) as[i + 1] = m0 & cur.dg[i + 1];
+    if (i == 3) { m1 = byte_mask_g4(cur.a[1]); at[0] = m1 & cur.dg[0]; }
+    if (i >= 4 && i <= 6) at[i - 3] = m1 & cur.dg[i - 3];
+    if (i == 7) lds_digits_g4(nxt.dg, s32 + (uint32_t)dgb, slice);
+    if (i == 8) { lds_frag_g4(nxt.a[0], s32 + (uint32_t)ab[0], slice); lds_frag_g4(nxt.a[1], s32 + (uint32_t)ab[1], slice); }
+    if (i == 9) { lds_frag_g4(nxt.b[0], s32 + (uint32_t)bb[0], slice); lds_frag_g4(nxt.b[1], s32 + (uint32_t)bb[1], slice); }
+    if (DMA_P && i >= 10 && i <= 13) stage_piece_g4(sp, dst, wave, i - 10);     // (four gaps apart instead -- 1, 5, 10, 13 -- no
+    if (DMA_Q && i >= 10 && i <= 13) stage_piece_g4(sq, dst + G4_TILE, wave, i - 10);   //  difference: 31.09 against 30.98 ms)
+    if (DMA_Q && wave == 0 && i >= 14)                    // digits: [plane 2 (i - 14) + (lane >> 5)][4 (lane & 31) ..]
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdig, (MMG_AS3 void*)(dst + G4_DIG + (i - 14) * 256), 4, dig_voff,
+                                               (i - 14) * dig_stride2, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// STAMP_AT in 0..3: s_memtime stamps (`make EXPERIMENTS=1`, tools/grm4_stamps.py) behind slice STAMP_AT and at the end of the step
+template <int STAMP_AT = -1, class EpiFn>
+__device__ __forceinline__ void g4j_stream(const G4Job& job, int64_t ld, char* lds, EpiFn&& epi, unsigned long long* stamps = nullptr) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int ab[2], bb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    ab[i] = frag_base_g4(wm * 64 + i * 32, lane);
+    bb[i] = frag_base_g4(wn * 64 + i * 32, lane) + G4_TILE;
+  }
+  const int dgb = (lane >> 5) * 16;
+  const int64_t kstep_bytes = (int64_t)BK * ld;
+  const int dig_voff = (lane >> 5) * job.dig_stride + (lane & 31) * 4, dig_stride2 = 2 * job.dig_stride;
+
+  int cks = 0;                                           // issue cursor (wave-uniform): the stage whose pieces go out next
+  StageG4 sp = make_stage_g4(job.P, ld, lane), sq = make_stage_g4(job.Q, ld, lane);
+  __amdgpu_buffer_rsrc_t rdig = __builtin_amdgcn_make_buffer_rsrc((void*)job.dig, 0, 0x7fffffff, 0x00020000);
+  auto rebase_p = [&](int st) { sp.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(job.P + st * kstep_bytes), 0, 0x7fffffff, 0x00020000); };
+  auto rebase_q = [&](int st) {
+    sq.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(job.Q + st * kstep_bytes), 0, 0x7fffffff, 0x00020000);
+    rdig = __builtin_amdgcn_make_buffer_rsrc((void*)(job.dig + (int64_t)st * BK), 0, 0x7fffffff, 0x00020000);
+  };
+  auto issue_stage = [&](char* slot) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_piece_g4(sp, slot, wave, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_piece_g4(sq, slot + G4_TILE, wave, i);
+    if (wave == 0) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdig, (MMG_AS3 void*)(slot + G4_DIG), 4, dig_voff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rdig, (MMG_AS3 void*)(slot + G4_DIG + 256), 4, dig_voff, dig_stride2, 0, 0);
+    }
+  };
+  const int last = job.nks - 1;                          // a stage beyond the job is the last one again (harmless re-issue)
+
+  // ---- prologue: stages 0 and 1 complete, raw fragments of step 0 slice 0
+  issue_stage(lds);
+  cks = 1 < last ? 1 : last;
+  rebase_p(cks); rebase_q(cks);
+  issue_stage(lds + G4_BUF);
+  cks = 2 < last ? 2 : last;                             // -> stage 2: its P pieces in slice 3 of step 0, its Q pieces in slice 0 of step 1
+  rebase_p(cks); rebase_q(cks);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  RawG4 r0, r1;
+  {
+    const uint32_t l32 = (uint32_t)(uintptr_t)lds;
+    lds_digits_g4(r0.dg, l32 + (uint32_t)dgb, 0);
+    lds_frag_g4(r0.a[0], l32 + (uint32_t)ab[0], 0);
+    lds_frag_g4(r0.a[1], l32 + (uint32_t)ab[1], 0);
+    lds_frag_g4(r0.b[0], l32 + (uint32_t)bb[0], 0);
+    lds_frag_g4(r0.b[1], l32 + (uint32_t)bb[1], 0);
+  }
+  v16i acc[4][2][2];                                     // written (not accumulated) by the first slice of the job
+
+  unsigned long long seg[5] = {0, 0, 0, 0, 0};
+  const unsigned long long T0 = STAMP_AT >= 0 ? __builtin_amdgcn_s_memtime() : 0;
+  unsigned long long tp = T0;
+#define MMG_G4J_STAMP(K) do { if (STAMP_AT >= 0 && (K == 4 || K == STAMP_AT)) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); seg[K] += now_ - tp; tp = now_; } } while (0)
+  for (int t = 0; t < job.nks; ++t) {
+    char* cur = lds + (t & 1) * G4_BUF;
+    char* oth = lds + ((t + 1) & 1) * G4_BUF;
+#define MMG_G4J_ARGS(SRC, SL, DST) SRC, ab, bb, dgb, SL, sp, sq, rdig, dig_voff, dig_stride2, DST, wave
+    if (t == 0) g4j_slice<false, false, true>(acc, r0, r1, MMG_G4J_ARGS(cur, 1, oth));
+    else {
+      g4j_slice<false, true, false>(acc, r0, r1, MMG_G4J_ARGS(cur, 1, oth));      // + Q pieces and digits of stage `cks`
+      cks = cks < last ? cks + 1 : last;
+      rebase_p(cks);
+    }
+    MMG_G4J_STAMP(0);
+    g4j_slice<false, false, false>(acc, r1, r0, MMG_G4J_ARGS(cur, 2, oth));
+    MMG_G4J_STAMP(1);
+    g4j_slice<false, false, false>(acc, r0, r1, MMG_G4J_ARGS(cur, 3, oth));
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    MMG_G4J_STAMP(2);
+    g4j_slice<true, false, false>(acc, r1, r0, MMG_G4J_ARGS(oth, 0, cur));         // + P pieces of stage `cks` into the slot just retired
+    rebase_q(cks);
+    MMG_G4J_STAMP(4);
+#undef MMG_G4J_ARGS
+  }
+#undef MMG_G4J_STAMP
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the re-issued tail stages must land before LDS is released
+  wait_raw_g4(r0);                                       // ... and the raw fragments read for a slice that does not exist stay
+  wait_raw_g4(r1);                                       // live up to here (gemm_i8_w4tr.h: frag_drain)
+  if (STAMP_AT >= 0 && stamps != nullptr && lane == 0) {
+    const unsigned long long total = __builtin_amdgcn_s_memtime() - T0;
+    unsigned long long* o = stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) o[k] = seg[k];
+    o[5] = (unsigned long long)job.nks;
+    o[6] = total;
+  }
   epi(acc);
 }
 

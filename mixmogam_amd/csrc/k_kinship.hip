@@ -125,7 +125,8 @@ __global__ __launch_bounds__(W4_THREADS) void kinship_i8_tr_kernel(const int8_t*
 template <int ABL>
 __global__ __launch_bounds__(W4_THREADS) void kinship_grm4_kernel(const int8_t* __restrict__ S, int64_t ld, int32_t Npad,
                                                                   const int8_t* __restrict__ dig, int dig_stride,
-                                                                  const KinJob* __restrict__ jobs, int* __restrict__ C32) {
+                                                                  const KinJob* __restrict__ jobs, int* __restrict__ C32,
+                                                                  unsigned long long* __restrict__ stamps = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const KinJob job = jobs[xcd_job_index(blockIdx.x)];
   if (job.ks1 <= job.ks0) return;
@@ -152,7 +153,42 @@ __global__ __launch_bounds__(W4_THREADS) void kinship_grm4_kernel(const int8_t* 
             atomicAdd(C32 + d * plane + (int64_t)row * Npad + col, acc[d][m][n][i]);
           }
         }
-  });
+  }, stamps);
+}
+
+// The quadrant layout with every slice scaling its own operands (gemm_i8_grm4.h, round 5: g4j_stream); STAMP_AT >= 0: + stamps.
+template <int STAMP_AT>
+__global__ __launch_bounds__(W4_THREADS) void kinship_grm4j_kernel(const int8_t* __restrict__ S, int64_t ld, int32_t Npad,
+                                                                   const int8_t* __restrict__ dig, int dig_stride,
+                                                                   const KinJob* __restrict__ jobs, int* __restrict__ C32,
+                                                                   unsigned long long* __restrict__ stamps = nullptr) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const KinJob job = jobs[xcd_job_index(blockIdx.x)];
+  if (job.ks1 <= job.ks0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, r = lane & 31;
+  G4Job gj;
+  gj.P = S + (int64_t)job.ks0 * BK * ld + (int64_t)job.I * G4_T;
+  gj.Q = S + (int64_t)job.ks0 * BK * ld + (int64_t)job.J * G4_T;
+  gj.dig = dig + (int64_t)job.ks0 * BK;
+  gj.dig_stride = dig_stride;
+  gj.nks = job.ks1 - job.ks0;
+  const int64_t plane = (int64_t)Npad * Npad;
+  g4j_stream<STAMP_AT>(gj, ld, lds, [&](v16i (&acc)[4][2][2]) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const int col = job.J * G4_T + wn * 64 + n * 32 + r;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = job.I * G4_T + wm * 64 + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            atomicAdd(C32 + d * plane + (int64_t)row * Npad + col, acc[d][m][n][i]);
+          }
+        }
+  }, stamps);
 }
 
 // The same product with the four waves as row strips of the tile (gemm_i8_grm4.h, round 4): half the digit-scaling VALU work.
@@ -575,8 +611,10 @@ int run_kinship_grm4(mmg_ctx* ctx, const int8_t* S, int64_t ld, int32_t Npad, in
   while (jobs.size() % 256) jobs.push_back(KinJob{0, 0, 0, 0, 0, 0, 0, 0});
   KinJob* djobs = nullptr;
   { int rcj = job_buffer(ctx, jobs, &djobs); if (rcj) return rcj; }
-  int abl = 0;                                            // MMG_GRM4_ABL=1..7: timing ablations (wrong results; tools/grm4_abl.py)
+  int abl = 0;                                            // MMG_GRM4_ABL=1..7: timing ablations (wrong results; tools/grm4_abl.py),
+#ifdef MMG_EXPERIMENTS                                    // 8..11: stamps -- in a `make EXPERIMENTS=1` library only
   if (const char* e = std::getenv("MMG_GRM4_ABL")) abl = std::atoi(e);
+#endif
 #define MMG_LAUNCH_G4(A)                                                                                                \
   do {                                                                                                                 \
     MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_grm4_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS)); \
@@ -584,19 +622,78 @@ int run_kinship_grm4(mmg_ctx* ctx, const int8_t* S, int64_t ld, int32_t Npad, in
     hipLaunchKernelGGL(kinship_grm4_kernel<A>, dim3((unsigned)jobs.size()), dim3(W4_THREADS), G4_LDS, ctx->stream, S, ld, \
                        Npad, dig, (int)dig_stride, djobs, C32);                                                        \
   } while (0)
-  static const bool quad = [] { const char* e = std::getenv("MMG_GRM4_LAYOUT"); return !(e && std::string(e) == "strips"); }();
+  static const std::string layout = [] { const char* e = std::getenv("MMG_GRM4_LAYOUT"); return std::string(e ? e : ""); }();
+  // default (round 5): kinship_grm4j_kernel, every slice scales its own operands; MMG_GRM4_LAYOUT=quad: the kernel of rounds
+  // 3-4 (scaling written one slice ahead), =strips: round 4's row strips -- all three bit-identical (tools/grm4_layouts.py)
+  const bool quad = layout != "strips";
+  if (layout != "quad" && layout != "strips" && abl == 0) {
+    MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_grm4j_kernel<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS));
+    EvScope ev(ctx, EV_KIN);
+    hipLaunchKernelGGL(kinship_grm4j_kernel<-1>, dim3((unsigned)jobs.size()), dim3(W4_THREADS), G4_LDS, ctx->stream, S, ld, Npad, dig,
+                       (int)dig_stride, djobs, C32, (unsigned long long*)nullptr);
+  } else
   if (!quad && abl == 0) {                                // MMG_GRM4_LAYOUT=strips: four row strips (round 4; not faster)
     MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_grm4r_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G4R_LDS));
     EvScope ev(ctx, EV_KIN);
     hipLaunchKernelGGL(kinship_grm4r_kernel<0>, dim3((unsigned)jobs.size()), dim3(W4_THREADS), G4R_LDS, ctx->stream, S, ld, Npad,
                        dig, (int)dig_stride, djobs, C32);
-  } else if (abl == 7) {                                  // strips without the digit reads (timing only)
+  } else
+#ifdef MMG_EXPERIMENTS
+  if (abl == 7) {                                         // strips without the digit reads (timing only)
     MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_grm4r_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, G4R_LDS));
     EvScope ev(ctx, EV_KIN);
     hipLaunchKernelGGL(kinship_grm4r_kernel<7>, dim3((unsigned)jobs.size()), dim3(W4_THREADS), G4R_LDS, ctx->stream, S, ld, Npad,
                        dig, (int)dig_stride, djobs, C32);
   } else
-  if (abl == 1) MMG_LAUNCH_G4(1); else if (abl == 2) MMG_LAUNCH_G4(2); else if (abl == 3) MMG_LAUNCH_G4(3); else if (abl == 4) MMG_LAUNCH_G4(4); else if (abl == 5) MMG_LAUNCH_G4(5); else if (abl == 6) MMG_LAUNCH_G4(6); else MMG_LAUNCH_G4(0);
+  if (abl == 1) MMG_LAUNCH_G4(1); else if (abl == 2) MMG_LAUNCH_G4(2); else if (abl == 3) MMG_LAUNCH_G4(3); else if (abl == 4) MMG_LAUNCH_G4(4); else if (abl == 5) MMG_LAUNCH_G4(5); else if (abl == 6) MMG_LAUNCH_G4(6);
+  else if (abl >= 8 && abl <= 15) {
+    // right results + s_memtime stamps: variant 8 + k stamps every K step behind position k (0: slice 2, 1: slice 3, 2: the
+    // vmcnt / lgkmcnt wait + barrier, 3: slice 0 with the P pieces) and at the end of the step (slice 1 with the Q pieces and
+    // the digits).  One position per variant: with all five in one kernel the allocator spills 134 VGPRs (the loop body sits at
+    // 254 + 256 registers).  tools/grm4_stamps.py runs the four and differences them.
+    static unsigned long long* dst = nullptr;
+    static size_t cap = 0;
+    const size_t n = jobs.size() * 4 * 8;
+    if (cap < n) { (void)hipFree(dst); dst = nullptr; cap = 0; MMG_HIP(ctx, hipMalloc(&dst, n * sizeof(unsigned long long))); cap = n; }
+    MMG_HIP(ctx, hipMemsetAsync(dst, 0, n * sizeof(unsigned long long), ctx->stream));
+#define MMG_LAUNCH_G4S(A)                                                                                              \
+  do {                                                                                                                 \
+    MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_grm4_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS)); \
+    EvScope ev(ctx, EV_KIN);                                                                                           \
+    hipLaunchKernelGGL(kinship_grm4_kernel<A>, dim3((unsigned)jobs.size()), dim3(W4_THREADS), G4_LDS, ctx->stream, S, ld, \
+                       Npad, dig, (int)dig_stride, djobs, C32, dst);                                                   \
+  } while (0)
+#define MMG_LAUNCH_G4JS(A)                                                                                             \
+  do {                                                                                                                 \
+    MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_grm4j_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS)); \
+    EvScope ev(ctx, EV_KIN);                                                                                           \
+    hipLaunchKernelGGL(kinship_grm4j_kernel<A>, dim3((unsigned)jobs.size()), dim3(W4_THREADS), G4_LDS, ctx->stream, S, ld, \
+                       Npad, dig, (int)dig_stride, djobs, C32, dst);                                                   \
+  } while (0)
+    // 12..15: the same four positions of kinship_grm4j_kernel (slices 0, 1, 2 + barrier, 3 in ITS order)
+    if (abl == 8) MMG_LAUNCH_G4S(8); else if (abl == 9) MMG_LAUNCH_G4S(9); else if (abl == 10) MMG_LAUNCH_G4S(10); else if (abl == 11) MMG_LAUNCH_G4S(11);
+    else if (abl == 12) MMG_LAUNCH_G4JS(0); else if (abl == 13) MMG_LAUNCH_G4JS(1); else if (abl == 14) MMG_LAUNCH_G4JS(2); else MMG_LAUNCH_G4JS(3);
+#undef MMG_LAUNCH_G4JS
+#undef MMG_LAUNCH_G4S
+    std::vector<unsigned long long> h(n);
+    MMG_HIP(ctx, hipMemcpyAsync(h.data(), dst, n * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double head = 0, tail = 0, steps = 0, total = 0, hw[4] = {0, 0, 0, 0}, sw[4] = {0, 0, 0, 0};
+    long cnt = 0;
+    for (size_t w = 0; w < jobs.size() * 4; ++w) {
+      if (h[w * 8 + 5] == 0) continue;
+      head += (double)h[w * 8 + ((abl - 8) & 3)]; tail += (double)h[w * 8 + 4]; steps += (double)h[w * 8 + 5]; total += (double)h[w * 8 + 6];
+      hw[w & 3] += (double)h[w * 8 + ((abl - 8) & 3)]; sw[w & 3] += (double)h[w * 8 + 5];
+      ++cnt;
+    }
+    if (cnt)
+      fprintf(stderr, "[grm4 stamps] position %d  waves %ld  K steps / wave %.0f  cycles per K step: start -> position %.1f  position -> end %.1f  "
+                      "whole loop %.1f   (start -> position by wave: %.1f %.1f %.1f %.1f)\n", (abl - 8) & 3, cnt, steps / cnt, head / steps,
+              tail / steps, total / steps, hw[0] / sw[0], hw[1] / sw[1], hw[2] / sw[2], hw[3] / sw[3]);
+  } else
+#endif
+  MMG_LAUNCH_G4(0);
+  (void)abl;
 #undef MMG_LAUNCH_G4
   MMG_HIP(ctx, hipGetLastError());
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -420,7 +420,9 @@ static void launch_multi(mmg_ctx* ctx, const double* T, int64_t nrows, int32_t N
   if constexpr (PB >= 8) if (PB == 16 || !valu_only || Q > 4) {
     const int64_t nb = (M + 255) / 256;
     int ab = 0;
-    if (const char* e = std::getenv("MMG_MULTI_ABL")) ab = std::atoi(e);
+#ifdef MMG_EXPERIMENTS
+    if (const char* e = std::getenv("MMG_MULTI_ABL")) ab = std::atoi(e);     // timing ablations (wrong results): `make EXPERIMENTS=1` only
+#endif
     constexpr int LB = MultiMfmaCfg<PB, Q>::LDS_BYTES;
 #define MMG_LAUNCH_MFMA(ABL_)                                                                                         \
   do {                                                                                                                \
@@ -443,7 +445,9 @@ static void launch_multi(mmg_ctx* ctx, const double* T, int64_t nrows, int32_t N
   if (const char* e = std::getenv("MMG_MULTI_R")) rsel = std::atoi(e) == 1 ? 1 : R;
   const int64_t nblk = (M + 255) / 256;
   int abl = 0;
+#ifdef MMG_EXPERIMENTS
   if (const char* e = std::getenv("MMG_MULTI_ABL")) abl = std::atoi(e);
+#endif
   if (abl == 1 && PB == 8 && Q == 1)
     hipLaunchKernelGGL((scan_multi_kernel<8, 1, 2, 1>), dim3((unsigned)((nblk + 1) / 2)), dim3(256), 0, ctx->stream, T,
                        nrows, N, M, coef, h0, (double)df2, lnbeta, rss, F, p, ldOut);

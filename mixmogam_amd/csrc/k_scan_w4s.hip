@@ -360,8 +360,12 @@ void launch_scan_quad_w4s(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model&
   const int64_t smax = g->smax;
   bool fast = smax * md.Npad < (1 << 16) && smax * smax * md.Npad < (1 << 18);
   if (std::getenv("MMG_W4S_SLOW_EPI")) fast = false;
+#ifdef MMG_EXPERIMENTS
+  // timing ablations (WRONG results) and the piece-distribution A/B: only in a `make EXPERIMENTS=1` library -- no environment
+  // variable can switch the shipped library to a kernel that does not compute the scan
   if (const char* e = std::getenv("MMG_W4S_ABL")) abl = std::atoi(e);
   if (const char* e = std::getenv("MMG_W4S_DIST")) dist = std::atoi(e);
+#endif
 #define MMG_LAUNCH_W4S(...)                                                                                             \
   do {                                                                                                                  \
     hipFuncSetAttribute((const void*)scan_quad_w4s_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
@@ -383,6 +387,8 @@ void launch_scan_quad_w4s(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model&
   const bool use_lin = lin != nullptr && lin->raw != nullptr && scan_lin_usable(g, md);
   if (use_lin) la = LinArgs{lin->raw, md.D - 1, md.Npad / TM - 1};
   static unsigned long long* dbg = nullptr;
+  (void)abl; (void)dist;
+#ifdef MMG_EXPERIMENTS
   if (abl == 4) {
     const size_t n = (size_t)16384 * 4 * 8;
     if (!dbg) hipMalloc(&dbg, n * sizeof(unsigned long long));
@@ -410,7 +416,9 @@ void launch_scan_quad_w4s(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model&
   else if (abl == 6) MMG_LAUNCH_W4S(6, 8, 8, 0, true);
   else if (abl == 7) MMG_LAUNCH_W4S(7, 8, 8, 0, true);
   else if (dist == 1 && fast) MMG_LAUNCH_W4S(0, 6, 5, 5, true);
-  else if (fast && use_lin) MMG_LAUNCH_W4S(0, 8, 8, 0, true, true);
+  else
+#endif
+  if (fast && use_lin) MMG_LAUNCH_W4S(0, 8, 8, 0, true, true);
   else if (fast) MMG_LAUNCH_W4S(0, 8, 8, 0, true);
   else if (use_lin) MMG_LAUNCH_W4S(0, 8, 8, 0, false, true);
   else MMG_LAUNCH_W4S(0, 8, 8, 0, false);

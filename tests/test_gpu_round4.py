@@ -310,17 +310,20 @@ def test_grm_of_a_diploid_store_through_the_centred_alphabet(ctx, m):
         assert np.abs(k - want).max() <= 2e-9 * np.abs(want).max(), packed
 
 
-def test_grm_row_strip_layout_equals_the_quadrant_layout_bit_for_bit():
-    """kinship_grm4r_kernel (MMG_GRM4_LAYOUT=strips: four row strips per tile, Q tiles in three LDS slots) against the shipped
-    quadrant layout: every plane is an exact integer sum, so the accumulated matrices must be identical.  The switch is read
-    once per process: tools/grm4_layouts.py runs each layout in a process of its own."""
+@pytest.mark.parametrize("n, m", [(1000, 140000), (300, 130), (300, 400), (640, 1300)])
+def test_grm_kernel_generations_are_bit_for_bit_identical(n, m):
+    """The shipped one-pass GRM kernel (round 5: kinship_grm4j_kernel, every slice scales its own operands) against round 3's
+    quadrant kernel (MMG_GRM4_LAYOUT=quad) and round 4's row strips (=strips: Q tiles in three LDS slots): every plane is an
+    exact integer sum, so the accumulated matrices must be identical -- at a size with padding individuals, and at jobs of one,
+    two and a few K steps (M = 130, 400, 1300), where the stage cursor of the pipeline is clamped from the first step on.  The
+    switch is read once per process: tools/grm4_layouts.py runs each layout in a process of its own."""
     import os, re, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "grm4_layouts.py"), "1000", "140000"], capture_output=True,
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "grm4_layouts.py"), str(n), str(m)], capture_output=True,
                          text=True, timeout=300, check=True).stdout
     digests = re.findall(r"layout (\w+)\s*:.*sha1 ([0-9a-f]+)", out)
-    assert [d[0] for d in digests] == ["quad", "strips"], out
-    assert digests[0][1] == digests[1][1], out
+    assert [d[0] for d in digests] == ["jit", "quad", "strips"], out
+    assert digests[0][1] == digests[1][1] == digests[2][1], out
 
 
 def test_grm_five_planes_one_pass_plus_one_image_equals_five_images_bit_for_bit():

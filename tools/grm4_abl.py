@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """kinship_grm4_kernel under its timing ablations (MMG_GRM4_ABL, WRONG results): what the DMA, the LDS reads and the digit
-scaling each cost.  One process per setting.   python tools/grm4_abl.py [N] [M]"""
+scaling each cost.  One process per setting, on the `make EXPERIMENTS=1` library (the shipped one ignores MMG_GRM4_ABL since
+round 5).   python tools/grm4_abl.py [N] [M]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
@@ -24,4 +25,4 @@ names = {"0": "as shipped", "1": "no DMA in the loop", "2": "no LDS reads, no sc
          "4": "half of the scaling VALU work (one A fragment instead of two)", "5": "no scaling VALU work (LDS reads kept)"}
 for abl in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("0", "6", "4", "5", "2", "1", "3")):
     print("%s:" % names[abl], flush=True)
-    subprocess.run([sys.executable, os.path.abspath(__file__), "--child", n, m], env=dict(os.environ, MMG_GRM4_ABL=abl), check=False)
+    subprocess.run([sys.executable, os.path.abspath(__file__), "--child", n, m], env=dict(os.environ, MMG_GRM4_ABL=abl, MMG_LIB=os.path.join(ROOT, "mixmogam_amd", "lib", "libmixmogam_hip_exp.so")), check=False)

@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.."
 for abl in 0 6 1; do
   echo "---- MMG_GRM4_ABL=$abl"
-  MMG_GRM4_ABL=$abl python3 - <<'PY' &
+  MMG_LIB="$(dirname "$0")/../mixmogam_amd/lib/libmixmogam_hip_exp.so" MMG_GRM4_ABL=$abl python3 - <<'PY' &
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 from mixmogam_amd import _lib
