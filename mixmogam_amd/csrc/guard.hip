@@ -31,6 +31,18 @@
 #include <unordered_map>
 #include <vector>
 
+// A HIP call of the guard's own whose failure does not change what the guard does next: say so, and take the error off the
+// runtime's sticky "last error" -- the library reads that after its launches (MMG_HIP(ctx, hipGetLastError())), and a failure
+// in here must not surface there as the library's.
+#define GUARD_IGN(call)                                                                                            \
+  do {                                                                                                             \
+    hipError_t e__ = (call);                                                                                       \
+    if (e__ != hipSuccess) {                                                                                       \
+      fprintf(stderr, "[mmg guard] %s -> %s (guard.hip:%d, ignored)\n", #call, hipGetErrorString(e__), __LINE__);  \
+      (void)hipGetLastError();                                                                                     \
+    }                                                                                                              \
+  } while (0)
+
 namespace {
 constexpr size_t GUARD_BYTES = 256 << 10;
 enum Mode { BANDS = 0, FENCE = 1, FENCE_LEFT = 2 };
@@ -116,12 +128,12 @@ int check_region(const unsigned char* p, size_t n, const char* when, const char*
   if (!damaged(h, &a, &b)) return 0;
   if (before) fprintf(stderr, "[mmg guard] %s: bytes %zu..%zu BEFORE the %zu-byte buffer of %s:%d were written\n", when, n - b, n - a, r.bytes, r.file, r.line);
   else fprintf(stderr, "[mmg guard] %s: bytes %zu..%zu %s of the %zu-byte buffer of %s:%d were written\n", when, a, b, side, r.bytes, r.file, r.line);
-  (void)hipMemset((void*)p, 0xA5, n);   // report an overrun once: restore the pattern
+  GUARD_IGN(hipMemset((void*)p, 0xA5, n));   // report an overrun once: restore the pattern
   return 1;
 }
 
 int check_one(void* user, const Rec& r, const char* when) {
-  (void)hipDeviceSynchronize();
+  GUARD_IGN(hipDeviceSynchronize());
   unsigned char* u = (unsigned char*)user;
   if (!r.va)
     return check_region(u - GUARD_BYTES, GUARD_BYTES, when, "", r, true) + check_region(u + r.bytes, GUARD_BYTES, when, "PAST the end", r, false);
@@ -161,15 +173,15 @@ hipError_t fence_malloc(void** p, size_t bytes, Rec& r) {
   if (e != hipSuccess) return e;
   hipMemGenericAllocationHandle_t h;
   e = hipMemCreate(&h, map_bytes, &prop, 0);
-  if (e != hipSuccess) { (void)hipMemAddressFree(va, span); return e; }
+  if (e != hipSuccess) { GUARD_IGN(hipMemAddressFree(va, span)); return e; }
   unsigned char* map = (unsigned char*)va + vg;
   e = hipMemMap(map, map_bytes, 0, h, 0);
-  if (e != hipSuccess) { (void)hipMemRelease(h); (void)hipMemAddressFree(va, span); return e; }
+  if (e != hipSuccess) { GUARD_IGN(hipMemRelease(h)); GUARD_IGN(hipMemAddressFree(va, span)); return e; }
   hipMemAccessDesc acc = {};
   acc.location = prop.location;
   acc.flags = hipMemAccessFlagsProtReadWrite;
   e = hipMemSetAccess(map, map_bytes, &acc, 1);
-  if (e != hipSuccess) { (void)hipMemUnmap(map, map_bytes); (void)hipMemRelease(h); (void)hipMemAddressFree(va, span); return e; }
+  if (e != hipSuccess) { GUARD_IGN(hipMemUnmap(map, map_bytes)); GUARD_IGN(hipMemRelease(h)); GUARD_IGN(hipMemAddressFree(va, span)); return e; }
   static const bool verbose = std::getenv("MMG_GUARD_TRACE") != nullptr;
   if (verbose) fprintf(stderr, "[mmg guard] fence_malloc %zu bytes: mapping %p .. %p, filling\n", bytes, (void*)map, (void*)(map + map_bytes));
   if (bytes >= ((size_t)1 << 30)) mmg_guard_note("(fence_malloc: filling a buffer >= 1 GiB)");
@@ -203,13 +215,13 @@ hipError_t mmg_guard_malloc(void** p, size_t bytes, const char* file, int line) 
       std::vector<Freed> q;
       { std::lock_guard<std::mutex> lk(g_mu); q.assign(g_quarantine.begin(), g_quarantine.end()); g_quarantine.clear(); g_quarantine_bytes = 0; }
       (void)hipGetLastError();
-      for (auto& f : q) (void)hipFree((unsigned char*)f.user - GUARD_BYTES);
+      for (auto& f : q) GUARD_IGN(hipFree((unsigned char*)f.user - GUARD_BYTES));
       e = hipMalloc(&raw, bytes + 2 * GUARD_BYTES);
     }
     if (e != hipSuccess) { *p = nullptr; return e; }
-    (void)hipMemset(raw, 0xA5, GUARD_BYTES);
-    (void)hipMemset((unsigned char*)raw + GUARD_BYTES + bytes, 0xA5, GUARD_BYTES);
-    (void)hipDeviceSynchronize();
+    GUARD_IGN(hipMemset(raw, 0xA5, GUARD_BYTES));
+    GUARD_IGN(hipMemset((unsigned char*)raw + GUARD_BYTES + bytes, 0xA5, GUARD_BYTES));
+    GUARD_IGN(hipDeviceSynchronize());
     *p = (unsigned char*)raw + GUARD_BYTES;
   }
   std::lock_guard<std::mutex> lk(g_mu);
@@ -235,19 +247,19 @@ hipError_t mmg_guard_free(void* p) {
   if (bad) { std::lock_guard<std::mutex> lk(g_mu); g_bad += bad; }
   if (r.va) {
     // unmapped and released, the addresses stay reserved: whatever still reads or writes the buffer faults from here on
-    (void)hipMemUnmap(r.map, r.map_bytes);
-    (void)hipMemRelease(r.h);
+    GUARD_IGN(hipMemUnmap(r.map, r.map_bytes));
+    GUARD_IGN(hipMemRelease(r.h));
     std::lock_guard<std::mutex> lk(g_mu);
     g_quarantine.push_back(Freed{p, r});
     // every reservation is a mapping of the host's address space too (vm.max_map_count, 65,530 by default): the oldest go
     while (g_quarantine.size() > 20000) {
-      (void)hipMemAddressFree(g_quarantine.front().r.va, g_quarantine.front().r.span);
+      GUARD_IGN(hipMemAddressFree(g_quarantine.front().r.va, g_quarantine.front().r.span));
       g_quarantine.pop_front();
     }
     return hipSuccess;
   }
-  (void)hipMemset(p, 0xA5, r.bytes);             // poison: a later read through a stale pointer does not see plausible data
-  (void)hipDeviceSynchronize();
+  GUARD_IGN(hipMemset(p, 0xA5, r.bytes));             // poison: a later read through a stale pointer does not see plausible data
+  GUARD_IGN(hipDeviceSynchronize());
   std::vector<Freed> out;
   {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -299,9 +311,22 @@ extern "C" __attribute__((visibility("default"))) void mmg_guard_note(const char
   if (live_trace) fprintf(stderr, "[mmg] %lx %s\n", (unsigned long)pthread_self(), fn);
 }
 
+hipError_t mmg_guard_func_attr(const char* what, int line, const void* f, hipFuncAttribute a, int v) {
+  const hipError_t e = hipFuncSetAttribute(f, a, v);
+  if (e != hipSuccess) fprintf(stderr, "[mmg guard] hipFuncSetAttribute(%s) at line %d -> %s\n", what, line, hipGetErrorString(e));
+  return e;
+}
+
+void mmg_guard_launch_check(const char* kernel, dim3 grid, dim3 block, size_t lds) {
+  const hipError_t e = hipPeekAtLastError();
+  if (e != hipSuccess)
+    fprintf(stderr, "[mmg guard] the launch of %s (grid %u x %u x %u, block %u x %u x %u, %zu bytes of dynamic LDS) left the runtime's last error at: %s\n",
+            kernel, grid.x, grid.y, grid.z, block.x, block.y, block.z, lds, hipGetErrorString(e));
+}
+
 extern "C" __attribute__((visibility("default"))) void mmg_guard_launched(hipStream_t s) {
   static const bool sync = [] { const char* e = std::getenv("MMG_GUARD_SYNC"); return e && e[0] == '1'; }();
-  if (sync) (void)hipStreamSynchronize(s);
+  if (sync) GUARD_IGN(hipStreamSynchronize(s));
 }
 
 // Proof that the bands work: one byte written past a 100-byte buffer and one before it must be reported (returns 2; 1 in the
@@ -311,8 +336,8 @@ extern "C" __attribute__((visibility("default"))) long mmg_guard_selftest(void) 
   if (mmg_guard_malloc(&p, 100, "guard.hip(selftest)", 0) != hipSuccess) return -1;
   long before;
   { std::lock_guard<std::mutex> lk(g_mu); before = g_bad; }
-  if (mode() != FENCE || fence_align() >= 128) (void)hipMemset((unsigned char*)p + 100, 0, 1);   // (fence: inside the alignment padding)
-  if (mode() != FENCE_LEFT) (void)hipMemset((unsigned char*)p - 1, 0, 1);
+  if (mode() != FENCE || fence_align() >= 128) GUARD_IGN(hipMemset((unsigned char*)p + 100, 0, 1));   // (fence: inside the alignment padding)
+  if (mode() != FENCE_LEFT) GUARD_IGN(hipMemset((unsigned char*)p - 1, 0, 1));
   (void)mmg_guard_free(p);
   std::lock_guard<std::mutex> lk(g_mu);
   const long found = g_bad - before;
@@ -332,7 +357,7 @@ extern "C" __attribute__((visibility("default"))) long mmg_guard_fault_selftest(
   if (which == 1) { target = (unsigned char*)p; (void)mmg_guard_free(p); }
   fprintf(stderr, "[mmg guard] fault self-test: reading %p\n", (const void*)target);
   guard_probe_kernel<<<1, 1>>>(target, (unsigned*)o);
-  (void)hipDeviceSynchronize();
+  GUARD_IGN(hipDeviceSynchronize());
   return 0;                             // reached only if the access did NOT fault
 }
 

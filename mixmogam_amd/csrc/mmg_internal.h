@@ -23,12 +23,16 @@ static inline hipError_t mmg_guard_malloc_t(T** p, size_t bytes, const char* fil
 #define hipFree(p) mmg_guard_free((void*)(p))
 extern "C" __attribute__((visibility("default"))) void mmg_guard_note(const char* fn);    // breadcrumb: the guard's abort handler prints the last entry points
 extern "C" __attribute__((visibility("default"))) void mmg_guard_launched(hipStream_t s); // MMG_GUARD_SYNC=1: wait for the kernel just launched (a fault then names it)
+void mmg_guard_launch_check(const char* kernel, dim3 grid, dim3 block, size_t lds);     // a launch the runtime refused: say which (the error stays for the caller)
+hipError_t mmg_guard_func_attr(const char* what, int line, const void* f, hipFuncAttribute a, int v);   // hipFuncSetAttribute; a refusal is reported
+#define hipFuncSetAttribute(...) mmg_guard_func_attr(#__VA_ARGS__, __LINE__, __VA_ARGS__)   // (kernel names carry template commas)
 #define MMG_NOTE_ENTRY() mmg_guard_note(__func__)
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                                   \
   do {                                                                                                                      \
     mmg_guard_note(#kernelName);                                                                                            \
     hipLaunchKernelGGLInternal((kernelName), numBlocks, numThreads, memPerBlock, streamId, ##__VA_ARGS__);                  \
+    mmg_guard_launch_check(#kernelName, dim3(numBlocks), dim3(numThreads), (size_t)(memPerBlock));                          \
     mmg_guard_launched(streamId);                                                                                           \
   } while (0)
 #else
@@ -154,7 +158,8 @@ int set_err(mmg_ctx* ctx, int code, const std::string& msg);
   do {                                                                                      \
     hipError_t e__ = (call);                                                                \
     if (e__ != hipSuccess)                                                                  \
-      return mmg::set_err(ctx, MMG_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+      return mmg::set_err(ctx, MMG_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__) + " (" + __FILE_NAME__ + ":" + \
+                                              std::to_string(__LINE__) + ")");               \
   } while (0)
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }

@@ -12,7 +12,7 @@ m = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
 ctx = _lib.get_context()
 g = ctx.geno(M=m, N=n).fill_structured(20250, npop=3)
 rng = np.random.RandomState(3)
-K = kinship.calc_ibs_kinship(g, ctx=ctx)
+K = kinship.calc_ibs_kinship(None, ctx=ctx, geno=g)
 y = rng.standard_normal(n) + np.asarray(g.download_rows(np.arange(5)), dtype=np.float64).sum(0)
 
 
