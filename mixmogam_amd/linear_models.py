@@ -215,6 +215,19 @@ class _SpectralSumsChol(object):
     # Chebyshev nodes of the local model of the sums over a bracket of the likelihood search (prepare_interval)
     INTERP_NODES = 16
     INTERP_MARGIN = 0.3                                                  # in log(delta), either side of the bracket
+    # Round 5: ONE device call per search.  The grid the search starts from (:814-830: 51 or 101 values equispaced in
+    # log(delta)) goes to the device refined to a spacing of ~0.1 with FINE_PAD extra nodes beyond either end -- up to
+    # FINE_MAX variance ratios, one workgroup each, the latency of one chain (tools/band_chain_width.py: 8.4 ms for 101, 8.5-9.5
+    # for 256 at N = 5000) -- and the model over the bracket is the polynomial through the FINE_STENCIL nearest nodes around the
+    # question, which therefore always sits in the central cell of its stencil.  The sums are analytic in u = log(delta) for
+    # |Im u| < pi: the error of that polynomial is at most M_r (h / r)^20 (0.5 * 1.5 * ... * 9.5)^2 = 1.2e-18 M_3 for
+    # h = 0.1, r = 3 (M_r: the sum's size on the circle of radius r) -- below the rounding of the evaluations (1e-13), as the
+    # 16 Chebyshev nodes were.  MMG_REML_FINE_GRID=0: the grid as it is asked for, then the 16 nodes (two device calls).
+    FINE_GRID = os.environ.get("MMG_REML_FINE_GRID", "1") != "0"
+    FINE_STEP = 0.1
+    FINE_STENCIL = 20
+    FINE_PAD = 13                                                        # >= FINE_STENCIL / 2 + INTERP_MARGIN / FINE_STEP
+    FINE_MAX = 256
 
     def __init__(self, reml, coll=None, route="auto"):
         self.reml, self.coll, self.route = reml, coll, route
@@ -224,6 +237,36 @@ class _SpectralSumsChol(object):
         self.n_calls = 0                                                 # device calls (each a latency chain of N steps)
         self._memo = {}
         self._interp = None
+        self._fine = None                                                # (u0, h, [4 arrays]) of the refined grid
+
+    def _fine_plan(self, deltas):
+        """(R, u0, h) when `deltas` is a grid equispaced in log(delta) that can be refined to ~FINE_STEP within FINE_MAX
+        variance ratios per call, else None."""
+        if not (self.FINE_GRID and self.band and len(deltas) >= 8 and np.all(deltas > 0)):
+            return None
+        u = np.log(deltas)
+        steps = np.diff(u)
+        h = float(steps.mean())
+        if not (h > 0 and np.max(np.abs(steps - h)) <= 1e-9 * max(1.0, abs(h))):
+            return None
+        R = max(1, int(round(h / self.FINE_STEP)))
+        while R > 1 and (len(deltas) - 1) * R + 1 + 2 * self.FINE_PAD > self.FINE_MAX:
+            R -= 1
+        if h / R > 1.5 * self.FINE_STEP or (len(deltas) - 1) * R + 1 + 2 * self.FINE_PAD > self.FINE_MAX:
+            return None
+        return R, float(u[0]), h / R
+
+    def _at_fine(self, deltas, plan):
+        """The grid of the search in one device call together with its refinement; returns the sums at `deltas`."""
+        R, u0, hf = plan
+        pad, m = self.FINE_PAD, len(deltas)
+        k = np.arange(-pad, (m - 1) * R + pad + 1)
+        fine = np.exp(u0 + hf * k)
+        own = pad + R * np.arange(m)                                     # the caller's values, bit for bit, at their places
+        fine[own] = deltas
+        vals = self._at(fine)
+        self._fine = (u0 - pad * hf, hf, [np.asarray(v, dtype=np.float64) for v in vals[:4]], np.log(fine))
+        return tuple(np.asarray(v)[own] for v in vals[:4])
 
     def prepare_interval(self, d_lo, d_hi):
         """The secant search of get_estimates (:847) asks for the sums at one delta after another inside the bracket
@@ -236,6 +279,13 @@ class _SpectralSumsChol(object):
         evaluation of the likelihood at the optimum (at_exact), go to the device."""
         if not self.band:
             return                                                       # the Cholesky route deals independent deltas over ranks
+        if self._fine is not None:
+            u_first, hf, vals, u = self._fine
+            lo, hi = np.log(d_lo) - self.INTERP_MARGIN, np.log(d_hi) + self.INTERP_MARGIN
+            half = self.FINE_STENCIL // 2
+            if lo >= u[half - 1] and hi <= u[len(u) - half]:             # every question in there has a full stencil around it
+                self._interp = (lo, hi, None, None, None)
+                return
         n = self.INTERP_NODES
         lo, hi = np.log(d_lo) - self.INTERP_MARGIN, np.log(d_hi) + self.INTERP_MARGIN
         k = np.arange(n)
@@ -245,8 +295,31 @@ class _SpectralSumsChol(object):
         vals = self._at(np.exp(u))
         self._interp = (lo, hi, u, w, [np.asarray(v, dtype=np.float64) for v in vals])
 
+    _FINE_W = None
+
+    def _from_fine(self, delta):
+        """The polynomial through the FINE_STENCIL nodes of the refined grid around log(delta), in barycentric form (equispaced
+        nodes: w_j = (-1)^j C(n - 1, j))."""
+        _u_first, hf, vals, u = self._fine
+        n = self.FINE_STENCIL
+        if _SpectralSumsChol._FINE_W is None or len(_SpectralSumsChol._FINE_W) != n:
+            from scipy.special import comb
+            _SpectralSumsChol._FINE_W = np.array([(-1.0) ** j * comb(n - 1, j, exact=True) for j in range(n)], dtype=np.float64)
+        w = _SpectralSumsChol._FINE_W
+        t = np.log(delta)
+        c = int(np.searchsorted(u, t, side='right')) - 1                 # u[c] <= t < u[c + 1]
+        a = min(max(c - (n // 2 - 1), 0), len(u) - n)
+        d = t - u[a:a + n]
+        hit = np.nonzero(d == 0.0)[0]
+        if len(hit):
+            return tuple(np.array([v[a + hit[0]]]) for v in vals)
+        cw = w / d
+        return tuple(np.array([float(cw @ v[a:a + n] / cw.sum())]) for v in vals)
+
     def _from_model(self, delta):
         lo, hi, u, w, vals = self._interp
+        if u is None:
+            return self._from_fine(delta)
         t = np.log(delta)
         d = t - u
         hit = np.nonzero(d == 0.0)[0]
@@ -265,6 +338,9 @@ class _SpectralSumsChol(object):
                 return self._from_model(key)
             self._at(deltas)
             return self._memo[key]
+        plan = self._fine_plan(deltas) if self._fine is None else None
+        if plan is not None:
+            return self._at_fine(deltas, plan)
         return self._at(deltas)
 
     def at_ml(self, deltas):

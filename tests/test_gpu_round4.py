@@ -98,8 +98,9 @@ def test_band_reduction_falls_back_on_duplicated_individuals(ctx):
 
 
 def test_reml_search_on_the_interpolant_vs_step_by_step_on_the_device(ctx, monkeypatch):
-    """get_estimates_eigen_free at N = 1,500: two device calls (grid, 16 Chebyshev nodes; the optimum's likelihood from the
-    model) against one call per secant step -- the variance ratio to 1e-10, likelihood and variance components to 1e-9."""
+    """get_estimates_eigen_free at N = 1,500: ONE device call (round 5: the grid refined to a spacing of 0.1, the search on
+    the polynomial through the 20 nodes around each question) and round 4's two (grid, 16 Chebyshev nodes) against one call per
+    secant step -- the variance ratio to 1e-10, likelihood and variance components to 1e-9."""
     from mixmogam_amd import linear_models as lm
     n, m = 1500, 4000
     g = ctx.geno(M=m, N=n).fill_structured(5, npop=3)
@@ -115,14 +116,19 @@ def test_reml_search_on_the_interpolant_vs_step_by_step_on_the_device(ctx, monke
     lmm.add_random_effect(K)
     a = lmm.get_estimates_eigen_free()
     a.pop("reml").close()
-    assert a["n_device_calls"] == 2
+    assert a["n_device_calls"] == 1 and a["n_factorisations"] == 50 * 4 + 1 + 2 * lm._SpectralSumsChol.FINE_PAD
+    monkeypatch.setattr(lm._SpectralSumsChol, "FINE_GRID", False)
+    a2 = lmm.get_estimates_eigen_free()
+    a2.pop("reml").close()
+    assert a2["n_device_calls"] == 2
     monkeypatch.setattr(lm._SpectralSumsChol, "prepare_interval", lambda self, lo, hi: None)
     b = lmm.get_estimates_eigen_free()
     b.pop("reml").close()
     assert b["n_device_calls"] > 4 and 1e-3 < b["delta"] < 1e3
-    assert abs(a["delta"] / b["delta"] - 1) < 1e-10
-    for k in ("max_ll", "ve", "vg"):
-        assert abs(a[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), k
+    for est in (a, a2):
+        assert abs(est["delta"] / b["delta"] - 1) < 1e-10
+        for k in ("max_ll", "ve", "vg"):
+            assert abs(est[k] - b[k]) <= 1e-9 * max(1.0, abs(b[k])), k
 
 
 def test_fp4_twin_of_the_store_follows_every_write_path(ctx, monkeypatch):

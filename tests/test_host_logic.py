@@ -549,18 +549,24 @@ def test_reml_search_on_the_interpolated_sums_matches_the_exact_search():
 
     model = lm.LinearMixedModel(list(y))
     model.add_factor(X[:, 1])
+
+    def two_calls(reml):                                                            # round 4's scheme: the grid, then 16 Chebyshev nodes
+        sm = lm._SpectralSumsChol(reml)
+        sm.FINE_GRID = False
+        return sm
+
     r1 = Reml(); r1.calls = []
-    a = model.get_estimates(None, method='REML', _sums=lm._SpectralSumsChol(r1))
+    a = model.get_estimates(None, method='REML', _sums=two_calls(r1))
     assert r1.calls == [51, lm._SpectralSumsChol.INTERP_NODES], r1.calls           # grid, nodes (the optimum: from the model)
     assert a['n_device_calls'] == 2
     r3 = Reml(); r3.calls = []
-    exact_final = lm._SpectralSumsChol(r3)
+    exact_final = two_calls(r3)
     exact_final.FINAL_FROM_MODEL = False                                           # the likelihood at the optimum from the workspace
     c = model.get_estimates(None, method='REML', _sums=exact_final)
     assert r3.calls == [51, lm._SpectralSumsChol.INTERP_NODES, 1]
     assert abs(a['max_ll'] - c['max_ll']) <= 1e-11 * abs(c['max_ll']) and abs(a['vg'] / c['vg'] - 1) < 1e-11
     r2 = Reml(); r2.calls = []
-    plain = lm._SpectralSumsChol(r2)
+    plain = two_calls(r2)
     plain.prepare_interval = lambda lo, hi: None                                    # every secant step asks the workspace
     b = model.get_estimates(None, method='REML', _sums=plain)
     assert len(r2.calls) > 4 and 1e-3 < b['delta'] < 1e3                            # an interior optimum, several steps
@@ -568,13 +574,44 @@ def test_reml_search_on_the_interpolated_sums_matches_the_exact_search():
     for k in ('max_ll', 've', 'vg', 'pseudo_heritability'):
         assert abs(a[k] - b[k]) <= 1e-10 * max(1.0, abs(b[k])), (k, a[k], b[k])
     # the model against exact evaluations across its interval
-    s = lm._SpectralSumsChol(Reml())
+    s = two_calls(Reml())
     s.prepare_interval(0.5 * b['delta'], 1.5 * b['delta'])
     for d in np.exp(np.linspace(s._interp[0], s._interp[1], 37)):
         want = exact.at(np.array([d]))
         got = s.at(np.array([d]))
         for i in range(4):
             assert abs(got[i][0] - want[i][0]) <= 1e-12 * max(1.0, abs(want[i][0])), (d, i)
+    # ---- round 5 (the default): ONE device call -- the grid refined to a spacing of 0.1 with 13 nodes beyond either end, the
+    # search on the polynomial through the 20 nodes around each question
+    assert lm._SpectralSumsChol.FINE_GRID
+    r4 = Reml(); r4.calls = []
+    one = lm._SpectralSumsChol(r4)
+    e = model.get_estimates(None, method='REML', _sums=one)
+    assert r4.calls == [50 * 4 + 1 + 2 * lm._SpectralSumsChol.FINE_PAD] and e['n_device_calls'] == 1, r4.calls
+    assert abs(e['delta'] / b['delta'] - 1) < 1e-11, (e['delta'], b['delta'])
+    for k in ('max_ll', 've', 'vg', 'pseudo_heritability'):
+        assert abs(e[k] - b[k]) <= 1e-10 * max(1.0, abs(b[k])), (k, e[k], b[k])
+    worst, worst_low = 0.0, 0.0
+    for d in np.exp(np.linspace(-10.3, 10.3, 997)):                                 # anywhere a bracket (+- its margin) can lie
+        dq = d * (1 + 1e-9)                                                         # (not a remembered node)
+        one._interp = (np.log(dq) - 1e-9, np.log(dq) + 1e-9, None, None, None)
+        want = exact.at(np.array([dq]))
+        got = one.at(np.array([dq]))
+        for i in range(4):
+            err = abs(got[i][0] - want[i][0]) / max(1.0, abs(want[i][0]))
+            if d > np.exp(-5.0):
+                worst = max(worst, err)
+            else:
+                worst_low = max(worst_low, err)
+    # (this K is singular: under delta = e^-5 the stand-in's own sums carry the rounding of a 1e5-conditioned H, and the
+    # polynomial through 20 noisy values repeats it; stencils of 16 / 24 nodes and half the spacing give the same figures)
+    assert worst <= 1e-12 and worst_low <= 1e-9, (worst, worst_low)
+    # the grid of mlmm (:1574: 100 intervals of 0.2): refined twice -- the same spacing, one call
+    r5 = Reml(); r5.calls = []
+    f = model.get_estimates(None, method='REML', ngrids=100, _sums=lm._SpectralSumsChol(r5))
+    assert r5.calls == [100 * 2 + 1 + 2 * lm._SpectralSumsChol.FINE_PAD]
+    g2 = model.get_estimates(None, method='REML', ngrids=100, _sums=two_calls(Reml()))
+    assert abs(f['delta'] / g2['delta'] - 1) < 1e-11 and abs(f['max_ll'] - g2['max_ll']) <= 1e-11 * abs(g2['max_ll'])
 
 
 # ---------------------------------------------------------------------- round 4: surface closures on the numpy stand-in
