@@ -217,8 +217,8 @@ class _SpectralSumsChol(object):
     INTERP_MARGIN = 0.3                                                  # in log(delta), either side of the bracket
     # Round 5: ONE device call per search.  The grid the search starts from (:814-830: 51 or 101 values equispaced in
     # log(delta)) goes to the device refined to a spacing of ~0.1 with FINE_PAD extra nodes beyond either end -- up to
-    # FINE_MAX variance ratios, one workgroup each, the latency of one chain (tools/band_chain_width.py: 8.4 ms for 101, 8.5-9.5
-    # for 256 at N = 5000) -- and the model over the bracket is the polynomial through the FINE_STENCIL nearest nodes around the
+    # FINE_MAX variance ratios, one workgroup each, one chain's latency plus what 227 of them contend for (tools/band_chain_width.py
+    # at N = 5000: 8.1 ms for 51 values, 11.1 for 221, against 8.1 + 7.8 for the two calls) -- and the model over the bracket is the polynomial through the FINE_STENCIL nearest nodes around the
     # question, which therefore always sits in the central cell of its stencil.  The sums are analytic in u = log(delta) for
     # |Im u| < pi: the error of that polynomial is at most M_r (h / r)^20 (0.5 * 1.5 * ... * 9.5)^2 = 1.2e-18 M_3 for
     # h = 0.1, r = 3 (M_r: the sum's size on the circle of radius r) -- below the rounding of the evaluations (1e-13), as the
@@ -237,7 +237,7 @@ class _SpectralSumsChol(object):
         self.n_calls = 0                                                 # device calls (each a latency chain of N steps)
         self._memo = {}
         self._interp = None
-        self._fine = None                                                # (u0, h, [4 arrays]) of the refined grid
+        self._fine = None                                                # refined grid: (first node, spacing, [4 arrays of sums], nodes) in log(delta)
 
     def _fine_plan(self, deltas):
         """(R, u0, h) when `deltas` is a grid equispaced in log(delta) that can be refined to ~FINE_STEP within FINE_MAX
