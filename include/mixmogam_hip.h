@@ -227,6 +227,15 @@ int mmg_reml_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, d
 #define MMG_REML_ROUTE_BAND 2
 int mmg_reml_sums_ex(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3,
                      double* s4, double* sum_sq_etas, int32_t route);
+/* Band route, round 5: factor B + delta I for nd variance ratios at once and KEEP the banded factors (at most 256 of them and
+ * 2 GB, in the context; beyond that the call keeps nothing and still succeeds).  A later mmg_reml_sums* call on the band route
+ * whose variance ratios are ALL among the kept ones (same bits) skips its factor sweep and costs the substitutions and the trace
+ * recurrence only.  What this serves: the likelihood search of get_estimates (linear_models.py:814-847) -- its grid is factored
+ * together with a four-fold refinement of itself (one workgroup per variance ratio: 4 ms at N = 5000 for 51 or for 227), the
+ * sums are taken on the grid, and once the grid has bracketed the optimum the nodes around the bracket are evaluated from the
+ * kept factors.  Kept factors belong to ONE workspace per context: the next mmg_reml_band_factor call replaces them.
+ * MMG_E_LIB "not positive definite" as mmg_reml_sums. */
+int mmg_reml_band_factor(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas);
 /* The maximum-likelihood variant (get_ML, linear_models.py:672-683; _ll_ / _dll_ :634-649) sums log(lambda_i + delta) and
  * 1 / (lambda_i + delta) over the spectrum of K itself: log|K + delta I| and tr (K + delta I)^-1, which the same
  * factorisations yield; s1 and s3 as above.  Round 4 (the eigendecomposition-free route evaluated REML only). */

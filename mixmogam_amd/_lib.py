@@ -88,6 +88,7 @@ PROTOTYPES = {
     "mmg_reml_destroy": (C.c_int, [c_vp, c_vp]),
     "mmg_reml_sums": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64p]),
     "mmg_reml_sums_ex": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f64p, C.c_int32]),
+    "mmg_reml_band_factor": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp]),
     "mmg_reml_sums_ml": (C.c_int, [c_vp, c_vp, C.c_int32, c_vp, c_vp, c_vp, c_vp, c_vp, C.c_int32]),
     "mmg_reml_band_info": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mmg_reml_scan_model": (C.c_int, [c_vp, c_vp, C.c_double, C.c_int, c_f64p, c_vp, c_f64p]),
@@ -531,6 +532,12 @@ class Reml(object):
         self.ctx._check(self.ctx.lib.mmg_reml_sums_ex(self.ctx.h, self.h, len(d), _ptr(d), *[_ptr(o) for o in out],
                                                       C.byref(sse), self.ROUTES[route]))
         return out[0], out[1], out[2], out[3], sse.value
+
+    def band_factor(self, deltas):
+        """mmg_reml_band_factor: factor B + delta I for all of `deltas` (<= 256) in one sweep and keep the factors; sums() calls
+        whose variance ratios are all among them then cost the substitutions and the trace recurrence only."""
+        d = _arr(np.asarray(deltas).reshape(-1), np.float64)
+        self.ctx._check(self.ctx.lib.mmg_reml_band_factor(self.ctx.h, self.h, len(d), _ptr(d)))
 
     def sums_ml(self, deltas, route="auto"):
         """s1, s3, log|K + delta I|, tr (K + delta I)^-1 for every delta: what the ML likelihood needs (mmg_reml_sums_ml)."""

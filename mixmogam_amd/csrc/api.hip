@@ -122,6 +122,8 @@ int mmg_ctx_destroy(mmg_ctx* ctx) {
   hipFree(ctx->jobs);
   hipFree(ctx->ingest);
   if (ctx->rocblas) rocblas_destroy_handle((rocblas_handle)ctx->rocblas);
+  (void)hipFree(ctx->band_ws);
+  (void)hipFree(ctx->band_keep);
   for (int i = 0; i < EV_COUNT; ++i) { hipEventDestroy(ctx->ev[i][0]); hipEventDestroy(ctx->ev[i][1]); }
   hipEventDestroy(ctx->ev_snap);
   hipEventDestroy(ctx->ev_deliver);

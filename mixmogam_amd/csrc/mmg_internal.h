@@ -147,6 +147,11 @@ struct mmg_ctx {
   std::vector<int2> grp_host;   // host image of grp_tab (source of the asynchronous upload: must outlive it)
   void* jobs = nullptr;         // device job lists of the kinship GEMM launches (k_kinship.hip:job_buffer), grown on demand:
   size_t jobs_cap = 0;          // a hipMalloc / hipFree per launch serialised the streams and leaked on an early return
+  void* band_keep = nullptr;    // banded factors kept by mmg_reml_band_factor (<= 2 GB) for the workspace band_keep_owner: the
+  size_t band_keep_cap = 0;     // sums at those variance ratios then cost the substitutions and the trace recurrence only
+  const void* band_keep_owner = nullptr;
+  void* band_ws = nullptr;      // per-delta factors / right-hand sides of reml_band_sums up to 2 GB (650 MB at N = 5000 for the 227
+  size_t band_ws_cap = 0;       // variance ratios of a search): a hipMalloc + hipFree per emmax() call was ~8 ms of a 90 ms call
   void* ingest = nullptr;       // device staging of the genotype ingest paths (packed rows, pageable int8 rows); kept:
   size_t ingest_cap = 0;        // hipMalloc / hipFree per chunk would serialise the upload stream with the compute stream
 };

@@ -182,12 +182,14 @@ __device__ __forceinline__ double wave_sum_fast(double v) {
 // ROW j of L -- entries of the 64 columns before j -- hence two 64-column chunks of L at a time.  Waves 1-3 fetch the
 // chunk needed next into the third buffer of a ring meanwhile (one wave loading 36 KB per 64 steps by itself spent
 // more time fetching than solving).
+// sel (or nullptr): workgroup g works on factor sel[g] of Lall (factors kept by mmg_reml_band_factor) and writes result g
 __global__ __launch_bounds__(256) void band_solve_kernel(const double* __restrict__ Lall, int N, const double* __restrict__ Zr,
-                                                         int q1, double* __restrict__ Fall, double* __restrict__ Gall) {
+                                                         int q1, double* __restrict__ Fall, double* __restrict__ Gall,
+                                                         const int* __restrict__ sel) {
   const int t = threadIdx.x & 63;
   const bool loader = threadIdx.x >= 64;
   const int lt = threadIdx.x - 64;
-  const double* Lc = Lall + (size_t)blockIdx.x * N * BAND_LD;
+  const double* Lc = Lall + (size_t)(sel ? sel[blockIdx.x] : (int)blockIdx.x) * N * BAND_LD;
   __shared__ __attribute__((aligned(16))) double ch[3][64 * BAND_LD];
   const int nchunk = (N + 63) / 64;
   auto ring = [](int cb) { return (cb + 3) % 3; };            // cb >= -2
@@ -260,9 +262,10 @@ __global__ __launch_bounds__(256) void band_solve_kernel(const double* __restric
 // trace of (L L')^-1 from the band of the inverse:  Z_ij = -(1/l_jj) sum_{k>j} Z_ik L_kj (i > j),
 // Z_jj = 1/l_jj^2 - (1/l_jj) sum_{k>j} L_kj Z_kj;  row / column i of the window lives at slot i mod 64.  Four waves: wave w
 // sums over the slots 16 w .. 16 w + 15 (L entries through v_readlane), the partial sums meet in LDS.
-__global__ __launch_bounds__(256) void band_trace_kernel(const double* __restrict__ Lall, int N, double* __restrict__ trace) {
+__global__ __launch_bounds__(256) void band_trace_kernel(const double* __restrict__ Lall, int N, double* __restrict__ trace,
+                                                         const int* __restrict__ sel) {
   const int t = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const double* Lc = Lall + (size_t)blockIdx.x * N * BAND_LD;
+  const double* Lc = Lall + (size_t)(sel ? sel[blockIdx.x] : (int)blockIdx.x) * N * BAND_LD;
   constexpr int ZS = 65;                                      // row stride of the window: column writes hit 64 banks
   __shared__ double Zw[64 * ZS];
   __shared__ double ch[64 * BAND_LD];
@@ -1103,8 +1106,9 @@ static int band_reduce_hh(mmg_ctx* ctx, mmg_reml* r) {
 }
 
 void reml_band_free(mmg_reml* r) {
-  hipFree(r->dBand); hipFree(r->dZr);
+  hipFree(r->dBand); hipFree(r->dZr); hipFree(r->dBandWs);
   r->dBand = r->dZr = nullptr;
+  r->dBandWs = nullptr; r->band_ws_bytes = 0;
   r->band_ready = false;
 }
 
@@ -1124,30 +1128,68 @@ int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, 
   const int group = (int)std::max<int64_t>(1, std::min<int64_t>(256, (int64_t(8) << 30) / per));
   for (int g0 = 0; g0 < nd; g0 += group) {
     const int ng = std::min(group, nd - g0);
-    Scratch sc;
     double *dd = nullptr, *L = nullptr, *F = nullptr, *G = nullptr, *sca = nullptr;
     int* dfail = nullptr;
     const size_t nsc = (size_t)ng * (2 + 2 * q1 * q1);
-    RC_HIP(ctx, sc.alloc(&dd, ng * sizeof(double)));
-    RC_HIP(ctx, sc.alloc(&L, (size_t)ng * per));
-    RC_HIP(ctx, sc.alloc(&F, (size_t)ng * q1 * N * sizeof(double)));
-    RC_HIP(ctx, sc.alloc(&G, (size_t)ng * q1 * N * sizeof(double)));
-    RC_HIP(ctx, sc.alloc(&sca, nsc * sizeof(double)));
-    RC_HIP(ctx, sc.alloc(&dfail, ng * sizeof(int)));
+    // factors kept by mmg_reml_band_factor: when EVERY variance ratio of the group is among them (same bits) the factor sweep is
+    // skipped and the chains below read the kept factors through an index list
+    std::vector<int> sel;
+    if (ctx->band_keep_owner == r && !r->keep_deltas.empty()) {
+      sel.resize(ng);
+      for (int k = 0; k < ng && !sel.empty(); ++k) {
+        const auto it = std::find(r->keep_deltas.begin(), r->keep_deltas.end(), deltas[g0 + k]);
+        if (it == r->keep_deltas.end()) sel.clear();
+        else sel[k] = (int)(it - r->keep_deltas.begin());
+      }
+    }
+    const bool kept = !sel.empty();
+    {
+      // one buffer kept with the workspace, carved at 256-byte boundaries
+      auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+      const size_t b_dd = up(ng * sizeof(double)), b_L = kept ? 0 : up((size_t)ng * per), b_F = up((size_t)ng * q1 * N * sizeof(double)),
+                   b_sca = up(nsc * sizeof(double)), b_fail = up(ng * sizeof(int));
+      const size_t need = b_dd + b_L + 2 * b_F + b_sca + b_fail;
+      // up to 2 GB the buffer belongs to the CONTEXT and outlives this workspace (a workspace lives for one emmax() call; entry
+      // points of a context do not overlap, and this one returns with its streams idle); larger ones stay with the workspace
+      const bool shared = need <= ((size_t)2 << 30);
+      void*& ws = shared ? ctx->band_ws : r->dBandWs;
+      size_t& cap = shared ? ctx->band_ws_cap : r->band_ws_bytes;
+      if (cap < need) {
+        RC_HIP(ctx, hipStreamSynchronize(st));
+        (void)hipFree(ws);
+        ws = nullptr; cap = 0;
+        RC_HIP(ctx, hipMalloc(&ws, need));
+        cap = need;
+      }
+      char* w = (char*)ws;
+      dd = (double*)w; w += b_dd;
+      L = (double*)w; w += b_L;
+      F = (double*)w; w += b_F;
+      G = (double*)w; w += b_F;
+      sca = (double*)w; w += b_sca;
+      dfail = (int*)w;
+    }
     double* dlog = sca;
     double* dtr = sca + ng;
     double* dff = sca + 2 * ng;
     double* dgg = dff + (size_t)ng * q1 * q1;
-    RC_HIP(ctx, hipMemcpyAsync(dd, deltas + g0, ng * sizeof(double), hipMemcpyHostToDevice, st));
     RC_HIP(ctx, hipMemsetAsync(sca, 0, nsc * sizeof(double), st));
     const auto t0 = std::chrono::steady_clock::now();
-    hipLaunchKernelGGL(band_factor_kernel, dim3(ng), dim3(256), 0, st, r->dBand, N, dd, L, dlog, dfail);
-    std::vector<int> bad(ng);
-    RC_HIP(ctx, hipMemcpyAsync(bad.data(), dfail, ng * sizeof(int), hipMemcpyDeviceToHost, st));
-    RC_HIP(ctx, hipStreamSynchronize(st));
-    for (int k = 0; k < ng; ++k)
-      if (bad[k])
-        return set_err(ctx, MMG_E_LIB, "K + delta I is not positive definite (banded Cholesky, pivot " + std::to_string(bad[k]) + ")");
+    const int* dsel = nullptr;
+    if (kept) {
+      L = (double*)ctx->band_keep;
+      RC_HIP(ctx, hipMemcpyAsync(dfail, sel.data(), ng * sizeof(int), hipMemcpyHostToDevice, st));    // (the failure flags' place)
+      dsel = dfail;
+    } else {
+      RC_HIP(ctx, hipMemcpyAsync(dd, deltas + g0, ng * sizeof(double), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(band_factor_kernel, dim3(ng), dim3(256), 0, st, r->dBand, N, dd, L, dlog, dfail);
+      std::vector<int> bad(ng);
+      RC_HIP(ctx, hipMemcpyAsync(bad.data(), dfail, ng * sizeof(int), hipMemcpyDeviceToHost, st));
+      RC_HIP(ctx, hipStreamSynchronize(st));
+      for (int k = 0; k < ng; ++k)
+        if (bad[k])
+          return set_err(ctx, MMG_E_LIB, "K + delta I is not positive definite (banded Cholesky, pivot " + std::to_string(bad[k]) + ")");
+    }
     const auto t1 = std::chrono::steady_clock::now();
     // the trace recurrence and the substitutions both read L and nothing of each other: two single-workgroup chains per
     // delta, 3.5 and 1.8 ms at N = 5000 -- side by side on the context's two streams (round 5: 9.2 -> 7.4 ms per call)
@@ -1158,25 +1200,27 @@ int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, 
       RC_HIP(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
       (void)hipEventRecord(e0, st);
       (void)hipStreamWaitEvent(ctx->stream2, e0, 0);
-      hipLaunchKernelGGL(band_trace_kernel, dim3(ng), dim3(256), 0, ctx->stream2, L, N, dtr);
+      hipLaunchKernelGGL(band_trace_kernel, dim3(ng), dim3(256), 0, ctx->stream2, L, N, dtr, dsel);
       (void)hipEventRecord(e1, ctx->stream2);
-      hipLaunchKernelGGL(band_solve_kernel, dim3(ng), dim3(256), 0, st, L, N, r->dZr, q1, F, G);
+      hipLaunchKernelGGL(band_solve_kernel, dim3(ng), dim3(256), 0, st, L, N, r->dZr, q1, F, G, dsel);
       (void)hipStreamWaitEvent(st, e1, 0);
       (void)hipEventDestroy(e0);                               // (released when the work that references them has completed)
       (void)hipEventDestroy(e1);
     } else {
-      hipLaunchKernelGGL(band_solve_kernel, dim3(ng), dim3(256), 0, st, L, N, r->dZr, q1, F, G);
-      hipLaunchKernelGGL(band_trace_kernel, dim3(ng), dim3(256), 0, st, L, N, dtr);
+      hipLaunchKernelGGL(band_solve_kernel, dim3(ng), dim3(256), 0, st, L, N, r->dZr, q1, F, G, dsel);
+      hipLaunchKernelGGL(band_trace_kernel, dim3(ng), dim3(256), 0, st, L, N, dtr, dsel);
     }
     hipLaunchKernelGGL(band_gram_kernel, dim3(ng, q1 * q1), dim3(256), 0, st, F, G, N, q1, dff, dgg);
     RC_HIP(ctx, hipGetLastError());
     std::vector<double> hs(nsc);
     RC_HIP(ctx, hipMemcpyAsync(hs.data(), sca, nsc * sizeof(double), hipMemcpyDeviceToHost, st));
     RC_HIP(ctx, hipStreamSynchronize(st));
+    if (kept)
+      for (int k = 0; k < ng; ++k) hs[k] = r->keep_logdet[sel[k]];            // log|B + delta I| came with the kept factor
     if (verbose) {
       const auto t2 = std::chrono::steady_clock::now();
-      fprintf(stderr, "[reml] N=%d: %d deltas through the band: factor %.1f ms, solves + trace %.1f ms\n", N, ng,
-              std::chrono::duration<double>(t1 - t0).count() * 1e3, std::chrono::duration<double>(t2 - t1).count() * 1e3);
+      fprintf(stderr, "[reml] N=%d: %d deltas through the band: factor %.1f ms%s, solves + trace %.1f ms\n", N, ng,
+              std::chrono::duration<double>(t1 - t0).count() * 1e3, kept ? " (kept factors)" : "", std::chrono::duration<double>(t2 - t1).count() * 1e3);
     }
     for (int k = 0; k < ng; ++k) {
       const double* ff = hs.data() + 2 * ng + (size_t)k * q1 * q1;
@@ -1207,6 +1251,51 @@ int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, 
       s4[g0 + k] = hs[ng + k] - tr_aB2;
     }
   }
+  return MMG_OK;
+}
+
+// mmg_reml_band_factor: the banded Cholesky factors of B + delta I for nd variance ratios, kept in the context (<= 256 of them and
+// <= 2 GB; more: nothing is kept and nothing fails) -- a later reml_band_sums whose variance ratios are ALL among them skips
+// its factor sweep.  One workgroup per variance ratio: the sweep costs for 227 what it costs for 51 (4.0 ms at N = 5000).
+int reml_band_factor_keep(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas) {
+  r->keep_deltas.clear(); r->keep_logdet.clear();
+  if (ctx->band_keep_owner == r) ctx->band_keep_owner = nullptr;
+  if (!r->band_ready) {
+    int rc = band_reduce(ctx, r);
+    if (rc) return rc;
+  }
+  const int N = r->N;
+  const size_t per = (size_t)N * BAND_LD * sizeof(double);
+  if (nd <= 0 || nd > 256 || (size_t)nd * per > ((size_t)2 << 30)) return MMG_OK;
+  hipStream_t st = ctx->stream;
+  if (ctx->band_keep_cap < (size_t)nd * per) {
+    RC_HIP(ctx, hipStreamSynchronize(st));
+    (void)hipFree(ctx->band_keep);
+    ctx->band_keep = nullptr; ctx->band_keep_cap = 0;
+    RC_HIP(ctx, hipMalloc(&ctx->band_keep, (size_t)nd * per));
+    ctx->band_keep_cap = (size_t)nd * per;
+  }
+  ctx->band_keep_owner = nullptr;                            // (whatever another workspace kept there is gone)
+  Scratch sc;
+  double *dd = nullptr, *dlog = nullptr;
+  int* dfail = nullptr;
+  RC_HIP(ctx, sc.alloc(&dd, nd * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&dlog, nd * sizeof(double)));
+  RC_HIP(ctx, sc.alloc(&dfail, nd * sizeof(int)));
+  RC_HIP(ctx, hipMemcpyAsync(dd, deltas, nd * sizeof(double), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(band_factor_kernel, dim3(nd), dim3(256), 0, st, r->dBand, N, dd, (double*)ctx->band_keep, dlog, dfail);
+  RC_HIP(ctx, hipGetLastError());
+  std::vector<int> bad(nd);
+  std::vector<double> ld(nd);
+  RC_HIP(ctx, hipMemcpyAsync(bad.data(), dfail, nd * sizeof(int), hipMemcpyDeviceToHost, st));
+  RC_HIP(ctx, hipMemcpyAsync(ld.data(), dlog, nd * sizeof(double), hipMemcpyDeviceToHost, st));
+  RC_HIP(ctx, hipStreamSynchronize(st));
+  for (int k = 0; k < nd; ++k)
+    if (bad[k])
+      return set_err(ctx, MMG_E_LIB, "K + delta I is not positive definite (banded Cholesky, pivot " + std::to_string(bad[k]) + ")");
+  r->keep_deltas.assign(deltas, deltas + nd);
+  r->keep_logdet = ld;
+  ctx->band_keep_owner = r;
   return MMG_OK;
 }
 

@@ -675,10 +675,21 @@ int mmg_reml_destroy(mmg_ctx* ctx, mmg_reml* r) {
   if (!r) return MMG_OK;
   MMG_NOTE_ENTRY();
   if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
+  if (ctx && ctx->band_keep_owner == r) ctx->band_keep_owner = nullptr;     // (the next workspace may get this address)
   hipFree(r->dK); hipFree(r->dL); hipFree(r->dB); hipFree(r->dZ); hipFree(r->dG); hipFree(r->dsc);
   reml_band_free(r);
   delete r;
   return MMG_OK;
+}
+
+int mmg_reml_band_factor(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas) {
+  if (!ctx) return MMG_E_ARG;
+  MMG_NOTE_ENTRY();
+  RC_HIP(ctx, hipSetDevice(ctx->device));
+  if (!(r && deltas && nd >= 0)) return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_band_factor");
+  for (int k = 0; k < nd; ++k)
+    if (!(deltas[k] > 0.0)) return set_err(ctx, MMG_E_ARG, "bad argument: mmg_reml_band_factor wants positive variance ratios");
+  return reml_band_factor_keep(ctx, r, nd, deltas);
 }
 
 int mmg_reml_sums_ex(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3,

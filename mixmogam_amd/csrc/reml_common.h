@@ -30,6 +30,10 @@ struct mmg_reml {
   double band_s = 0.0;      // seconds the reduction took
   int64_t band_k0 = 0;      // first column the Householder-panel path still has to do (reml_band.hip:band_reduce)
   bool band_fallback = false;   // a Cholesky-QR panel was rank deficient: the reduction was redone with Householder panels
+  std::vector<double> keep_deltas, keep_logdet;   // mmg_reml_band_factor: variance ratios whose banded factors lie in ctx->band_keep (while
+                                                  // ctx->band_keep_owner == this), and log|B + delta I| of each
+  void* dBandWs = nullptr;      // per-delta factors and right-hand sides of reml_band_sums: grows, freed with the workspace (a
+  size_t band_ws_bytes = 0;     // hipMalloc + hipFree of 650 MB per call was 3 ms of an 11 ms call of 227 variance ratios)
 };
 
 #define RC_HIP(ctx, call)                                                                     \
@@ -95,6 +99,7 @@ namespace mmg {
 int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, double* s1, double* s2, double* s3, double* s4,
                    double* ldh = nullptr, double* trh = nullptr);
 void reml_band_free(mmg_reml* r);
+int reml_band_factor_keep(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas);   // mmg_reml_band_factor
 // reml_chol.hip: makes r->dL hold L^-1 of K + delta I = L L' (column-major, upper triangle zero) and hands the pointer out
 int reml_linv_device(mmg_ctx* ctx, mmg_reml* r, double delta, const double** dLinv);
 // reml_band.hip: W [n x 64] (ld n) = A V on the fp64 matrix pipe for an n x n matrix A of which only the lower triangle is read

@@ -215,14 +215,15 @@ class _SpectralSumsChol(object):
     # Chebyshev nodes of the local model of the sums over a bracket of the likelihood search (prepare_interval)
     INTERP_NODES = 16
     INTERP_MARGIN = 0.3                                                  # in log(delta), either side of the bracket
-    # Round 5: ONE device call per search.  The grid the search starts from (:814-830: 51 or 101 values equispaced in
+    # Round 5: the search FACTORS once.  The grid the search starts from (:814-830: 51 or 101 values equispaced in
     # log(delta)) goes to the device refined to a spacing of ~0.1 with FINE_PAD extra nodes beyond either end -- up to
-    # FINE_MAX variance ratios, one workgroup each, one chain's latency plus what 227 of them contend for (tools/band_chain_width.py
-    # at N = 5000: 8.1 ms for 51 values, 11.1 for 221, against 8.1 + 7.8 for the two calls) -- and the model over the bracket is the polynomial through the FINE_STENCIL nearest nodes around the
+    # FINE_MAX variance ratios, one workgroup each: the factor sweep takes 4 ms at N = 5000 for 227 as for 51
+    # (mmg_reml_band_factor); the substitutions and the trace recurrence (3.6 ms) run on the grid, and on the ~40 refined nodes
+    # around the bracket if there is one -- and the model over the bracket is the polynomial through the FINE_STENCIL nearest nodes around the
     # question, which therefore always sits in the central cell of its stencil.  The sums are analytic in u = log(delta) for
     # |Im u| < pi: the error of that polynomial is at most M_r (h / r)^20 (0.5 * 1.5 * ... * 9.5)^2 = 1.2e-18 M_3 for
     # h = 0.1, r = 3 (M_r: the sum's size on the circle of radius r) -- below the rounding of the evaluations (1e-13), as the
-    # 16 Chebyshev nodes were.  MMG_REML_FINE_GRID=0: the grid as it is asked for, then the 16 nodes (two device calls).
+    # 16 Chebyshev nodes were.  MMG_REML_FINE_GRID=0: the grid as it is asked for, then the 16 nodes (two full device calls).
     FINE_GRID = os.environ.get("MMG_REML_FINE_GRID", "1") != "0"
     FINE_STEP = 0.1
     FINE_STENCIL = 20
@@ -237,7 +238,7 @@ class _SpectralSumsChol(object):
         self.n_calls = 0                                                 # device calls (each a latency chain of N steps)
         self._memo = {}
         self._interp = None
-        self._fine = None                                                # refined grid: (first node, spacing, [4 arrays of sums], nodes) in log(delta)
+        self._fine = None                                                # refined grid: (first node, spacing, [4 arrays of sums], log nodes, nodes, evaluated?)
 
     def _fine_plan(self, deltas):
         """(R, u0, h) when `deltas` is a grid equispaced in log(delta) that can be refined to ~FINE_STEP within FINE_MAX
@@ -257,16 +258,34 @@ class _SpectralSumsChol(object):
         return R, float(u[0]), h / R
 
     def _at_fine(self, deltas, plan):
-        """The grid of the search in one device call together with its refinement; returns the sums at `deltas`."""
+        """The grid of the search together with its refinement; returns the sums at `deltas`.  With mmg_reml_band_factor
+        (Reml.band_factor) the refined grid is FACTORED in one sweep -- as long for 227 variance ratios as for 51 -- and the sums
+        are taken on the caller's grid only (substitutions + trace recurrence from the kept factors); the refined nodes around
+        a bracket follow in prepare_interval, again from the kept factors.  A search whose optimum is a grid point thus costs
+        what it always did, one with a bracket 4.1 + 3.6 + 3.6 ms at N = 5000 instead of two full calls of 7.5.  Without the
+        entry point: every refined node in one call."""
         R, u0, hf = plan
         pad, m = self.FINE_PAD, len(deltas)
         k = np.arange(-pad, (m - 1) * R + pad + 1)
         fine = np.exp(u0 + hf * k)
         own = pad + R * np.arange(m)                                     # the caller's values, bit for bit, at their places
         fine[own] = deltas
-        vals = self._at(fine)
-        self._fine = (u0 - pad * hf, hf, [np.asarray(v, dtype=np.float64) for v in vals[:4]], np.log(fine))
-        return tuple(np.asarray(v)[own] for v in vals[:4])
+        have = np.zeros(len(fine), dtype=bool)
+        arrays = [np.full(len(fine), np.nan) for _ in range(4)]
+        if hasattr(self.reml, "band_factor"):
+            self.reml.band_factor(fine)
+            self.n_factorisations += len(fine) - m                       # (_at_device counts the m it is asked for)
+            vals = self._at(fine[own])
+            for a, v in zip(arrays, vals[:4]):
+                a[own] = v
+            have[own] = True
+        else:
+            vals = self._at(fine)
+            arrays = [np.asarray(v, dtype=np.float64) for v in vals[:4]]
+            have[:] = True
+            vals = tuple(a[own] for a in arrays)
+        self._fine = (u0 - pad * hf, hf, arrays, np.log(fine), fine, have)
+        return tuple(np.asarray(v) for v in vals[:4])
 
     def prepare_interval(self, d_lo, d_hi):
         """The secant search of get_estimates (:847) asks for the sums at one delta after another inside the bracket
@@ -280,10 +299,18 @@ class _SpectralSumsChol(object):
         if not self.band:
             return                                                       # the Cholesky route deals independent deltas over ranks
         if self._fine is not None:
-            u_first, hf, vals, u = self._fine
+            u_first, hf, vals, u, fine, have = self._fine
             lo, hi = np.log(d_lo) - self.INTERP_MARGIN, np.log(d_hi) + self.INTERP_MARGIN
             half = self.FINE_STENCIL // 2
             if lo >= u[half - 1] and hi <= u[len(u) - half]:             # every question in there has a full stencil around it
+                first = max(int(np.searchsorted(u, lo, side='right')) - 1 - (half - 1), 0)
+                last = min(int(np.searchsorted(u, hi, side='right')) - 1 + half, len(u) - 1)
+                missing = np.nonzero(~have[first:last + 1])[0] + first
+                if len(missing):                                         # the refined nodes around the bracket, from the kept factors
+                    got = self._at(fine[missing])
+                    for a, v in zip(vals, got[:4]):
+                        a[missing] = v
+                    have[missing] = True
                 self._interp = (lo, hi, None, None, None)
                 return
         n = self.INTERP_NODES
@@ -300,7 +327,7 @@ class _SpectralSumsChol(object):
     def _from_fine(self, delta):
         """The polynomial through the FINE_STENCIL nodes of the refined grid around log(delta), in barycentric form (equispaced
         nodes: w_j = (-1)^j C(n - 1, j))."""
-        _u_first, hf, vals, u = self._fine
+        _u_first, hf, vals, u, _fine, _have = self._fine
         n = self.FINE_STENCIL
         if _SpectralSumsChol._FINE_W is None or len(_SpectralSumsChol._FINE_W) != n:
             from scipy.special import comb

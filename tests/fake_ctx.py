@@ -106,6 +106,10 @@ class FakeReml(object):
         return (float(self.y @ Py), np.linalg.slogdet(H)[1] + np.linalg.slogdet(a)[1] - self.logdet_xtx,
                 float(Py @ Py), float(np.trace(P)), beta, Py, P)
 
+    def band_factor(self, deltas):
+        """mmg_reml_band_factor keeps factors; the stand-in has none to keep (its sums cost the same either way)."""
+        self.factored = [float(d) for d in np.asarray(deltas).reshape(-1)]
+
     def sums(self, deltas):
         pts = [self._point(d) for d in np.asarray(deltas).reshape(-1)]
         return tuple(np.array([p[k] for p in pts]) for k in range(4)) + (self.sse,)

@@ -98,9 +98,11 @@ def test_band_reduction_falls_back_on_duplicated_individuals(ctx):
 
 
 def test_reml_search_on_the_interpolant_vs_step_by_step_on_the_device(ctx, monkeypatch):
-    """get_estimates_eigen_free at N = 1,500: ONE device call (round 5: the grid refined to a spacing of 0.1, the search on
-    the polynomial through the 20 nodes around each question) and round 4's two (grid, 16 Chebyshev nodes) against one call per
-    secant step -- the variance ratio to 1e-10, likelihood and variance components to 1e-9."""
+    """get_estimates_eigen_free at N = 1,500: round 5's search (the grid and its refinement to a spacing of 0.1 factored in one
+    sweep, sums on the grid and then on the refined nodes around the bracket from the kept factors, the search on the polynomial
+    through the 20 nodes around each question) and round 4's two full calls (grid, 16 Chebyshev nodes) against one call per
+    secant step -- the variance ratio to 1e-10, likelihood and variance components to 1e-9; and sums from kept factors equal
+    sums that factor themselves, bit for bit."""
     from mixmogam_amd import linear_models as lm
     n, m = 1500, 4000
     g = ctx.geno(M=m, N=n).fill_structured(5, npop=3)
@@ -116,7 +118,23 @@ def test_reml_search_on_the_interpolant_vs_step_by_step_on_the_device(ctx, monke
     lmm.add_random_effect(K)
     a = lmm.get_estimates_eigen_free()
     a.pop("reml").close()
-    assert a["n_device_calls"] == 1 and a["n_factorisations"] == 50 * 4 + 1 + 2 * lm._SpectralSumsChol.FINE_PAD
+    n_fine = 50 * 4 + 1 + 2 * lm._SpectralSumsChol.FINE_PAD
+    assert a["n_device_calls"] == 2 and n_fine + 20 < a["n_factorisations"] < n_fine + 60
+    # the kept factors give the sums a self-factoring call gives
+    reml = ctx.reml(K, np.ones((n, 1)), y)
+    try:
+        d = np.exp(np.linspace(-3.0, 3.0, 31))
+        plain = reml.sums(d)
+        reml.band_factor(d)
+        kept = reml.sums(d[::3])
+        for i in range(4):
+            assert np.array_equal(kept[i], plain[i][::3]), i
+        mixed = reml.sums(np.r_[d[:2], 0.777])                 # one value that was not kept: the call factors for itself
+        assert np.array_equal(mixed[0][:2], plain[0][:2])
+        with pytest.raises(Exception):
+            reml.band_factor(np.array([1.0, -1.0]))
+    finally:
+        reml.close()
     monkeypatch.setattr(lm._SpectralSumsChol, "FINE_GRID", False)
     a2 = lmm.get_estimates_eigen_free()
     a2.pop("reml").close()

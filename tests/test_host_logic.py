@@ -581,13 +581,23 @@ def test_reml_search_on_the_interpolated_sums_matches_the_exact_search():
         got = s.at(np.array([d]))
         for i in range(4):
             assert abs(got[i][0] - want[i][0]) <= 1e-12 * max(1.0, abs(want[i][0])), (d, i)
-    # ---- round 5 (the default): ONE device call -- the grid refined to a spacing of 0.1 with 13 nodes beyond either end, the
-    # search on the polynomial through the 20 nodes around each question
+    # ---- round 5 (the default): the grid refined to a spacing of 0.1 with 13 nodes beyond either end, the search on the
+    # polynomial through the 20 nodes around each question.  Without mmg_reml_band_factor: every refined node in ONE call
     assert lm._SpectralSumsChol.FINE_GRID
+    n_fine = 50 * 4 + 1 + 2 * lm._SpectralSumsChol.FINE_PAD
     r4 = Reml(); r4.calls = []
     one = lm._SpectralSumsChol(r4)
     e = model.get_estimates(None, method='REML', _sums=one)
-    assert r4.calls == [50 * 4 + 1 + 2 * lm._SpectralSumsChol.FINE_PAD] and e['n_device_calls'] == 1, r4.calls
+    assert r4.calls == [n_fine] and e['n_device_calls'] == 1, r4.calls
+    # ... with it: all refined nodes factored in one sweep, sums on the grid, then on the refined nodes around the bracket
+    class RemlKeep(Reml):
+        def band_factor(self, deltas):
+            self.factored = np.array(deltas, dtype=np.float64)
+    r6 = RemlKeep(); r6.calls = []
+    e6 = model.get_estimates(None, method='REML', _sums=lm._SpectralSumsChol(r6))
+    assert len(r6.factored) == n_fine and r6.calls[0] == 51 and len(r6.calls) == 2 and 20 < r6.calls[1] < 60, r6.calls
+    assert e6['n_factorisations'] == n_fine + r6.calls[1] and e6['n_device_calls'] == 2
+    assert e6['delta'] == e['delta'] and e6['max_ll'] == e['max_ll'] and e6['vg'] == e['vg']     # the same nodes, the same polynomial
     assert abs(e['delta'] / b['delta'] - 1) < 1e-11, (e['delta'], b['delta'])
     for k in ('max_ll', 've', 'vg', 'pseudo_heritability'):
         assert abs(e[k] - b[k]) <= 1e-10 * max(1.0, abs(b[k])), (k, e[k], b[k])
