@@ -1123,8 +1123,8 @@ int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, 
   const bool verbose = std::getenv("MMG_REML_VERBOSE") != nullptr;
   // deltas in groups: L of a group is group x N x 72 doubles
   const int64_t per = (int64_t)N * BAND_LD * sizeof(double);
-  // (256 since round 5: the search sends its grid refined to ~227 values in ONE call, linear_models._SpectralSumsChol.FINE_GRID;
-  // with 128 a call of 129-256 values was two chains back to back, tools/band_chain_width.py: 8.4 -> 16.3 ms at N = 5000)
+  // (256 since round 5, as many as mmg_reml_band_factor keeps: with 128 a call of 129-256 values was two chains back to back,
+  // tools/band_chain_width.py: 8.4 -> 16.3 ms at N = 5000, now 9.7)
   const int group = (int)std::max<int64_t>(1, std::min<int64_t>(256, (int64_t(8) << 30) / per));
   for (int g0 = 0; g0 < nd; g0 += group) {
     const int ng = std::min(group, nd - g0);
