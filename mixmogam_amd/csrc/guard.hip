@@ -205,7 +205,39 @@ hipError_t mmg_guard_malloc(void** p, size_t bytes, const char* file, int line) 
   // without a pause after hipMemSetAccess.  Buffers beyond MMG_GUARD_FENCE_MAX_MB (default 1024) therefore get guard bands
   // around a hipMalloc instead of a mapping of their own; the kernels that index them run fenced at every smaller size.
   static const size_t fence_max = [] { const char* e = std::getenv("MMG_GUARD_FENCE_MAX_MB"); const long v = e ? std::atol(e) : 0; return (size_t)(v > 0 ? v : 1024) << 20; }();
-  if (mode() != BANDS && bytes <= fence_max) {
+  // Address space is never recycled.  Round 5: once freed reservations were handed back (hipMemAddressFree of the oldest beyond
+  // 20,000) two threads in the library saw wrong results and damaged slack within a few rounds -- at round 2,490 with that cap, at
+  // round 340 with a cap of 5,000, never (4,745 rounds) with 60,000 (profiles/r5e_guard_va_recycling.txt) -- and a long
+  // single-process run had the runtime refuse launches at the same point.  No access faulted before the recycling began, so
+  // these are not stale pointers of the library meeting new mappings; what the runtime does with a recycled range is its own.
+  // Nor can reservations pile up for ever: each leaves several mappings in the HOST's address space (a reserved range with a
+  // mapped stretch inside it is three; vm.max_map_count is 65,530 by default), and once those are used up the runtime refuses
+  // kernel launches with "invalid argument" -- right behind the 15,000th fenced buffer in a single-process run of the GPU suite,
+  // behind the 60,000th of a stress whose buffers are short-lived.  So the guard watches /proc/self/maps: beyond 60 % of the
+  // limit (or MMG_GUARD_MAX_RESERVATIONS fenced buffers, if set) the rest of the process gets guard bands.
+  static const long max_reservations = [] { const char* e = std::getenv("MMG_GUARD_MAX_RESERVATIONS"); const long v = e ? std::atol(e) : 0; return v > 0 ? v : 0L; }();
+  static std::atomic<long> reservations{0};
+  static std::atomic<bool> exhausted{false};
+  bool fenced = mode() != BANDS && bytes <= fence_max && !exhausted.load();
+  if (fenced) {
+    const long n = reservations.fetch_add(1);
+    bool stop = max_reservations > 0 && n >= max_reservations;
+    if (!stop && (n & 127) == 0) {
+      static const long limit = [] { long v = 65530; if (FILE* f = fopen("/proc/sys/vm/max_map_count", "r")) { if (fscanf(f, "%ld", &v) != 1) v = 65530; fclose(f); } return v; }();
+      long lines = 0;
+      if (FILE* f = fopen("/proc/self/maps", "r")) {
+        char buf[1 << 16];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof(buf), f)) > 0)
+          for (size_t i = 0; i < got; ++i) lines += buf[i] == '\n';
+        fclose(f);
+      }
+      stop = lines > limit * 6 / 10;
+      if (stop) fprintf(stderr, "[mmg guard] %ld fenced buffers so far, %ld of %ld host mappings in use: later buffers get guard bands\n", n, lines, limit);
+    }
+    if (stop) { exhausted.store(true); fenced = false; }
+  }
+  if (fenced) {
     hipError_t e = fence_malloc(p, bytes, r);
     if (e != hipSuccess) { *p = nullptr; return e == hipErrorOutOfMemory ? e : hipErrorOutOfMemory; }
   } else {
@@ -251,12 +283,7 @@ hipError_t mmg_guard_free(void* p) {
     GUARD_IGN(hipMemRelease(r.h));
     std::lock_guard<std::mutex> lk(g_mu);
     g_quarantine.push_back(Freed{p, r});
-    // every reservation is a mapping of the host's address space too (vm.max_map_count, 65,530 by default): the oldest go
-    while (g_quarantine.size() > 20000) {
-      GUARD_IGN(hipMemAddressFree(g_quarantine.front().r.va, g_quarantine.front().r.span));
-      g_quarantine.pop_front();
-    }
-    return hipSuccess;
+    return hipSuccess;                                        // (the reservation is never given back: see max_reservations)
   }
   GUARD_IGN(hipMemset(p, 0xA5, r.bytes));             // poison: a later read through a stale pointer does not see plausible data
   GUARD_IGN(hipDeviceSynchronize());
