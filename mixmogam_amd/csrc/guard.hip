@@ -54,7 +54,14 @@ struct Rec {
 struct Freed { void* user; Rec r; };
 std::mutex g_mu;
 std::unordered_map<void*, Rec> g_live;        // user pointer -> record
-std::deque<Freed> g_quarantine;               // bands: poisoned, not yet hipFree'd;  fence: unmapped for good (table only)
+std::deque<Freed> g_quarantine;               // band buffers: poisoned, not yet hipFree'd
+std::deque<Freed> g_fenced_freed;             // fenced buffers: unmapped for good (table only; never evicted).  One deque for both
+                                              // was a bug of its own in the fence modes: a freed 3 GB band buffer (above 1 GiB every
+                                              // buffer gets bands) pushed the quarantine over its cap, the eviction loop popped FENCE
+                                              // records and treated them as band buffers -- hipMemcpy from an unmapped address, hipFree
+                                              // of user - 256 KiB --, and the two hipErrorInvalidValue stayed in the runtime's last-error
+                                              // slot until the library read it behind its next launch ("the launch was refused":
+                                              // profiles/r5e_guard_va_recycling.txt; found with AMD_LOG_LEVEL=3)
 size_t g_quarantine_bytes = 0;
 long g_bad = 0;
 
@@ -98,9 +105,10 @@ void on_abort(int) {
   FILE* f = dump ? fopen(dump, "w") : stderr;
   if (!f) f = stderr;
   if (g_mu.try_lock()) {
-    fprintf(f, "[mmg guard] %zu live buffers, %zu freed ones on record:\n", g_live.size(), g_quarantine.size());
+    fprintf(f, "[mmg guard] %zu live buffers, %zu freed ones on record:\n", g_live.size(), g_quarantine.size() + g_fenced_freed.size());
     for (auto& kv : g_live) dump_record(f, "live", kv.first, kv.second);
     for (auto& q : g_quarantine) dump_record(f, "freed", q.user, q.r);
+    for (auto& q : g_fenced_freed) dump_record(f, "freed", q.user, q.r);
     g_mu.unlock();
   }
   if (f != stderr) fclose(f);
@@ -282,7 +290,7 @@ hipError_t mmg_guard_free(void* p) {
     GUARD_IGN(hipMemUnmap(r.map, r.map_bytes));
     GUARD_IGN(hipMemRelease(r.h));
     std::lock_guard<std::mutex> lk(g_mu);
-    g_quarantine.push_back(Freed{p, r});
+    g_fenced_freed.push_back(Freed{p, r});
     return hipSuccess;                                        // (the reservation is never given back: see max_reservations)
   }
   GUARD_IGN(hipMemset(p, 0xA5, r.bytes));             // poison: a later read through a stale pointer does not see plausible data
@@ -309,7 +317,7 @@ hipError_t mmg_guard_free(void* p) {
       ++g_bad;
     }
     hipError_t e1 = hipFree((unsigned char*)f.user - GUARD_BYTES);
-    if (e1 != hipSuccess) e = e1;
+    if (e1 != hipSuccess) { e = e1; fprintf(stderr, "[mmg guard] hipFree of a quarantined buffer -> %s\n", hipGetErrorString(e1)); (void)hipGetLastError(); }
   }
   return e;
 }
