@@ -215,14 +215,13 @@ hipError_t mmg_guard_malloc(void** p, size_t bytes, const char* file, int line) 
   static const size_t fence_max = [] { const char* e = std::getenv("MMG_GUARD_FENCE_MAX_MB"); const long v = e ? std::atol(e) : 0; return (size_t)(v > 0 ? v : 1024) << 20; }();
   // Address space is never recycled.  Round 5: once freed reservations were handed back (hipMemAddressFree of the oldest beyond
   // 20,000) two threads in the library saw wrong results and damaged slack within a few rounds -- at round 2,490 with that cap, at
-  // round 340 with a cap of 5,000, never (4,745 rounds) with 60,000 (profiles/r5e_guard_va_recycling.txt) -- and a long
-  // single-process run had the runtime refuse launches at the same point.  No access faulted before the recycling began, so
-  // these are not stale pointers of the library meeting new mappings; what the runtime does with a recycled range is its own.
-  // Nor can reservations pile up for ever: each leaves several mappings in the HOST's address space (a reserved range with a
-  // mapped stretch inside it is three; vm.max_map_count is 65,530 by default), and once those are used up the runtime refuses
-  // kernel launches with "invalid argument" -- right behind the 15,000th fenced buffer in a single-process run of the GPU suite,
-  // behind the 60,000th of a stress whose buffers are short-lived.  So the guard watches /proc/self/maps: beyond 60 % of the
-  // limit (or MMG_GUARD_MAX_RESERVATIONS fenced buffers, if set) the rest of the process gets guard bands.
+  // round 340 with a cap of 5,000, never (4,745 rounds) with 60,000 (profiles/r5e_guard_va_recycling.txt).  No access faulted before
+  // the recycling began, so these are not stale pointers of the library meeting new mappings; what the runtime does with a recycled
+  // range is its own.
+  // Nor should reservations pile up for ever: each leaves mappings in the HOST's address space (a reserved range with a mapped
+  // stretch inside it is three; vm.max_map_count is 65,530 by default).  A precaution, never reached in any run so far (the
+  // two-thread stress stays under 60 % of the limit through 40,000 fenced buffers): the guard watches /proc/self/maps, and beyond
+  // 60 % of the limit (or MMG_GUARD_MAX_RESERVATIONS fenced buffers, if set) the rest of the process gets guard bands.
   static const long max_reservations = [] { const char* e = std::getenv("MMG_GUARD_MAX_RESERVATIONS"); const long v = e ? std::atol(e) : 0; return v > 0 ? v : 0L; }();
   static std::atomic<long> reservations{0};
   static std::atomic<bool> exhausted{false};
