@@ -181,10 +181,11 @@ def copy_tree(src, dst):
             dst.create_dataset(name, data=np.asarray(item[...]))
 
 
-def write_genotype_container(path, chrom_snps, indiv_ids, phenotypes=None, positions=None, mode="w", packed_bits=0):
+def write_genotype_container(path, chrom_snps, indiv_ids, phenotypes=None, positions=None, mode="w", packed_bits=0,
+                             freqs=None):
     """Write a genotype file in the layout of plink2hdf5.py:27-28,111-118,226 from in-memory arrays:
-    chrom_snps {chrom: int8 [M_c x N]}; freqs = per-SNP mean of the 0/1 genotypes (the allele frequency that
-    hdf5_data.py:91-93 filters on).  packed_bits = 1 / 2: the rows are stored as `raw_snps_packed` (uint8, 1 or 2
+    chrom_snps {chrom: int8 [M_c x N]}; freqs {chrom: [M_c]} (the allele frequency hdf5_data.py:91-93 filters on), default
+    the parser's rule: mean / 2 for a chromosome with 0/1/2 codes (plink2hdf5.py:202), the carrier frequency for 0/1 codes.  packed_bits = 1 / 2: the rows are stored as `raw_snps_packed` (uint8, 1 or 2
     bits per genotype, low bits first) with `packed_bits` and `num_indivs` beside them instead of `raw_snps` -- an
     eighth / a quarter of the bytes for the streamed drivers to read and upload (hdf5_data._raw_dataset)."""
     st = Store(path, mode)
@@ -206,7 +207,10 @@ def write_genotype_container(path, chrom_snps, indiv_ids, phenotypes=None, posit
             cg.create_dataset("raw_snps", data=snps)
         cg.create_dataset("positions", data=np.asarray(positions[chrom]) if positions is not None
                           else np.arange(len(snps), dtype=np.int64))
-        cg.create_dataset("freqs", data=snps.mean(axis=1, dtype=np.float64))
+        if freqs is not None:
+            cg.create_dataset("freqs", data=np.asarray(freqs[chrom], dtype=np.float64))
+        else:
+            cg.create_dataset("freqs", data=snps.mean(axis=1, dtype=np.float64) / (2.0 if snps.size and snps.max() > 1 else 1.0))
         total += len(snps)
     st.create_dataset("num_snps", data=np.array(total))
     st.close()

@@ -426,7 +426,7 @@ def _gather_owned(parts, plan, coll):
 
 def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=True, chunk_size=100000, k=None,
               ctx=None, coll=None, num_perm=0, perm_idx=None, phenotypes=None, prefetch=True, fast_perm=True,
-              eigen_free=None, timings=None):
+              eigen_free=None, timings=None, perm_h=None):
     """hdf5_data.py:70-187 (and :191-351 when num_perm > 0).  fast_perm: the permutation test of a chunk reuses the
     quadratic forms of the scan that just ran over it (mmg_emmax_perm_after_scan) instead of recomputing them.
     eigen_free: REML and the scan model from Cholesky factorisations instead of eigh(K) (linear_models.
@@ -447,6 +447,11 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
     of HBM, and 2 x max(largest chunk, 6 GB) of pinned host memory whatever the MAF filter keeps (a chunk whose span of
     file rows exceeds that is read run by run: _read_chunk).  All chromosomes of a stream must hold the same individuals; the buffers
     are sized by the largest row (raw int8 or bit-packed) over the plan.
+
+    perm_idx / perm_h: replay of a recorded permutation test -- the [num_perm x N] shuffles and the H_sqrt_inv they were
+    applied in.  A permutation's outcome depends on the row signs of H_sqrt_inv (the ROTATED residuals are what
+    linear_models.py:1151-1154 shuffles) and those are the eigensolver's choice, so reproducing the numbers of a reference
+    run takes the reference's matrix; without perm_h the test runs in this model's own H (a draw from the same null).
 
     timings: a dict that receives the wall seconds of the stages (kinship_pass_s, reml_s, scan_model_s, scan_pass_s,
     gather_s) and the route taken -- what bench.py --mode c5 reports per rank."""
@@ -527,7 +532,17 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
     if num_perm:                                                         # :262-330: SNP-independent part, once
         lmm_p = lm.LinearMixedModel(phenotypes, ctx=ctx)                 # perm_prepare centres Y in place
         lmm_p.add_random_effect(k)
-        if reml_ws is not None:
+        if perm_h is not None:
+            if reml_ws is not None:
+                reml_ws.close()
+                reml_ws = None
+            if 'HtQ' not in prep:                                            # A = H'H - (H'Q)(H'Q)' does not depend on the signs
+                from scipy import linalg as _la
+                Hh = np.asarray(perm_h, dtype=np.float64)
+                prep['HtQ'] = np.ascontiguousarray((Hh.T @ _la.qr(Hh @ lmm.X, mode='economic')[0]).T)
+            pp = lmm_p.perm_prepare(perm_h, num_perm=num_perm, perm_idx=perm_idx)
+            plan_p = ctx.perm_plan(pp['H'], pp['Ys'], pp['h0_rss'])
+        elif reml_ws is not None:
             try:
                 # the scan model has left L^-1 of this delta in the workspace: H X, H y are two triangular products, the
                 # plan's operand images are built from the matrix where it lies, and the rows H'Q_c of the after-scan
@@ -566,6 +581,7 @@ def run_emmax(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=Tru
         d = out['chrom_results'].setdefault(chrom, {'ps': [np.zeros(0)], 'positions': [np.zeros(0, dtype=np.int64)]})
         d['ps'] = np.concatenate(d['ps'])
         d['positions'] = np.concatenate(d['positions'])
+    out['chrom_results'] = {chrom: out['chrom_results'][chrom] for chrom in chroms}      # the file's chromosome order
     if num_perm:                                                         # :339-347
         plan_p.close()
         if coll is not None and world > 1:
@@ -591,9 +607,14 @@ def _write_results(out_file, out, ih5f, num_perm):
     oh5f.create_dataset('ve', data=np.array(out['ve']))
     oh5f.create_dataset('vg', data=np.array(out['vg']))
     oh5f.create_dataset('max_ll', data=np.array(out['max_ll']))
-    # :150 copies the INPUT file's num_snps (all SNPs, before the MAF filter); :289 (perm) stores the filtered count
-    n_in = np.array(ih5f['num_snps'][...]) if (ih5f is not None and 'num_snps' in ih5f.keys() and not num_perm) \
-        else np.array(out['num_snps'])
+    # :150 copies the INPUT file's num_snps (all SNPs, before the MAF filter); the permutation driver stores `n_snps` (:289),
+    # a name its counting loop has reused (:253): the kept count of the LAST chromosome (pinned by tests/golden/hdf5_n200.npz)
+    if num_perm:
+        n_in = np.array(len(list(out['chrom_results'].values())[-1]['ps']) if out['chrom_results'] else 0)
+    elif ih5f is not None and 'num_snps' in ih5f.keys():
+        n_in = np.array(ih5f['num_snps'][...])
+    else:
+        n_in = np.array(out['num_snps'])
     oh5f.create_dataset('num_snps', data=n_in)
     crg = oh5f.create_group('chrom_results')
     for chrom, d in out['chrom_results'].items():
@@ -618,11 +639,11 @@ def _write_results(out_file, out, ih5f, num_perm):
 
 def run_emmax_perm(hdf5_filename, out_file=None, min_maf=0.1, recalculate_kinship=True, chunk_size=100000,
                    num_perm=500, perm_idx=None, k=None, ctx=None, coll=None, phenotypes=None, prefetch=True,
-                   fast_perm=True):
+                   fast_perm=True, perm_h=None):
     """hdf5_data.py:191-351 (the reference always recalculates the kinship here; pass k to skip that)."""
     return run_emmax(hdf5_filename, out_file, min_maf=min_maf, chunk_size=chunk_size, k=k, ctx=ctx, coll=coll,
                      num_perm=num_perm, perm_idx=perm_idx, phenotypes=phenotypes, prefetch=prefetch,
-                     fast_perm=fast_perm)
+                     fast_perm=fast_perm, perm_h=perm_h)
 
 
 def run_emmax_multi(hdf5_filename, out_file=None, phenotypes=None, min_maf=0.1, chunk_size=50000, k=None, ctx=None,

@@ -466,6 +466,76 @@ def perm_public(snps, y, X, H_sqrt_inv, perm_idx, reference_indexing=True):
     return {'min_rss': min_rss, 'max_f_stats': max_f, 'min_ps': f_sf(max_f, 1, n_p), 'h0_rss': h0_rss}
 
 
+# ----------------------------------------------------------------------------- HDF5 drivers (hdf5_data.py)
+def hdf5_maf_filter(freqs, min_maf):
+    """hdf5_data.py:91-93 (= :153-155, :213-215, :249-251, :301-303): keep where min(f, 1 - f) > min_maf, strictly."""
+    freqs = np.asarray(freqs, dtype=np.float64)
+    return np.minimum(freqs, 1 - freqs) > min_maf
+
+
+def hdf5_ibd_kinship(chroms, chunk_size=1000, min_maf=None, acc_dtype=np.float64):
+    """The kinship loop the three drivers share -- calculate_ibd_kinship hdf5_data.py:30-58 (no filter) and
+    run_emmax :84-111 / run_emmax_perm :205-232 (MAF-filtered rows): per chromosome in key order, chunks of
+    chunk_size rows WITHIN the chromosome (:99), each SNP standardised with the population std (:103),
+    k_mat += x'x in the accumulator's dtype ('single' as written, :84), / n_snps (:107), then scale_k's rule inline
+    (:108-111).  chroms: ordered [(raw_snps [M_c x N], freqs [M_c]), ...].  Returns (k, n_snps)."""
+    n = np.asarray(chroms[0][0]).shape[1]
+    k_mat = np.zeros((n, n), dtype=acc_dtype)
+    n_snps = 0
+    for snps, freqs in chroms:
+        snps = np.asarray(snps)
+        if min_maf is not None:
+            snps = snps[hdf5_maf_filter(freqs, min_maf)]
+        for i in range(0, len(snps), chunk_size):
+            x = snps[i:i + chunk_size].T.astype(np.float64)
+            x = ((x - x.mean(0)) / x.std(0)).T
+            n_snps += len(x)
+            k_mat += (x.T @ x).astype(acc_dtype)
+    k_mat = k_mat / float(n_snps)
+    c = np.sum((np.eye(n) - (1.0 / n) * np.ones(k_mat.shape)) * np.asarray(k_mat, dtype=np.float64))
+    return ((n - 1) / c) * k_mat, n_snps
+
+
+def hdf5_run_emmax(chroms, positions, y, min_maf=0.1, chunk_size=1000, k=None, perm_idx=None, perm_H=None):
+    """run_emmax hdf5_data.py:70-187 and, with perm_idx [P x N], run_emmax_perm :191-351.
+    Kinship from the MAF-filtered rows unless k is given (:113-115, recalculate_kinship=False reads the stored one);
+    LinearMixedModel(phenotypes) + add_random_effect(k) -- which scales k once more (linear_models.py:580);
+    eig_L, eig_R, REML once (:126-137); _emmax_f_test_(emma_num=0) per chromosome on its filtered rows (:157-176).
+    Permutation variant: the test runs on every chromosome but the LAST (`chr12_snps`, :294-311,330); both result
+    arrays are stored sorted ascending (:339-341, the `[::-1]` is a no-op expression), the 5 % entries are index
+    num_perm // 20 of each (:342-347); the stored `num_snps` is the LAST chromosome's filtered count (the counting loop
+    reuses the name, :253,289), where run_emmax copies the input file's unfiltered total (:150).
+    perm_H: the H_sqrt_inv to shuffle in (default: this model's own) -- a permutation's outcome depends on the signs of its
+    rows (the ROTATED residuals are shuffled, linear_models.py:1151-1154), which are LAPACK's choice, so replaying a recorded
+    reference run needs the reference's matrix."""
+    y = np.asarray(y, dtype=np.float64).reshape(-1)
+    n = len(y)
+    keep = [hdf5_maf_filter(f, min_maf) for _s, f in chroms]
+    if k is None:
+        k, _n = hdf5_ibd_kinship(chroms, chunk_size, min_maf)
+    X = np.ones((n, 1))
+    est = get_estimates(y, X, scale_k(np.asarray(k, dtype=np.float64)))
+    prep = scan_prepare(y, X, est['H_sqrt_inv'])
+    out = {'kinship': np.asarray(k), 'chrom_ps': [], 'chrom_positions': []}
+    for k_ in ('pseudo_heritability', 've', 'vg', 'max_ll', 'delta'):
+        out[k_] = est[k_]
+    for (snps, _f), kp, pos in zip(chroms, keep, positions):
+        out['chrom_ps'].append(scan_closed(np.asarray(snps)[kp], prep)['ps'])
+        out['chrom_positions'].append(np.asarray(pos)[kp])
+    out['num_snps'] = sum(len(np.asarray(s)) for s, _f in chroms)             # :150 (the input file's own dataset)
+    if perm_idx is not None:
+        chr12 = np.vstack([np.asarray(s)[kp] for (s, _f), kp in zip(chroms, keep)][:-1]).astype(np.float64)
+        out['H_sqrt_inv'] = est['H_sqrt_inv']
+        pr = perm_closed(chr12, perm_prepare(y, X, est['H_sqrt_inv'] if perm_H is None else perm_H, perm_idx))
+        five = len(perm_idx) // 20
+        out['perm_min_ps'] = np.sort(pr['min_ps'])
+        out['perm_max_f_stats'] = np.sort(pr['max_f_stats'])
+        out['five_perc_perm_min_ps'] = out['perm_min_ps'][five]
+        out['five_perc_perm_max_f_stats'] = out['perm_max_f_stats'][five]
+        out['num_snps'] = int(keep[-1].sum())                                 # :253,289
+    return out
+
+
 # ----------------------------------------------------------------------------- synthetic data
 def hash_genotypes(m0, m1, n, seed, maf_q16=None):
     """Counter-based Bernoulli genotypes shared by bench.py (device generator

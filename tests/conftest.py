@@ -54,3 +54,40 @@ def load_extras3():
     n = int(d["n"])
     d["snps"] = np.unpackbits(d["snps_packed"], axis=1)[:, :n].astype(np.int8)
     return d
+
+
+def load_hdf5_golden():
+    """tests/golden/hdf5_n200.npz (round 6): what the reference's own hdf5_data.calculate_ibd_kinship / run_emmax /
+    run_emmax_perm wrote for two 3-chromosome files (0/1 codes 'bin', 0/1/2 codes 'dip'), 'lit' and 'dbl' modes.
+    Adds d[variant + '_chroms'] = [(name, raw_snps int8, freqs, positions)] and full symmetric kinship matrices."""
+    d = dict(np.load(os.path.join(GOLDEN, "hdf5_n200.npz")))
+    n = int(d["n"])
+    iu = np.triu_indices(n)
+    for variant in ("bin", "dip"):
+        chroms = []
+        for c in (1, 2, 3):
+            name = "chrom_%d" % c
+            s = np.unpackbits(d["%s_%s_raw_snps_ge1" % (variant, name)], axis=1)[:, :n].astype(np.int8)
+            if variant == "dip":
+                s = s + np.unpackbits(d["%s_%s_raw_snps_eq2" % (variant, name)], axis=1)[:, :n].astype(np.int8)
+            chroms.append((name, s, d["%s_%s_freqs" % (variant, name)], d["%s_%s_positions" % (variant, name)]))
+        d[variant + "_chroms"] = chroms
+        for mode in ("lit", "dbl"):
+            for key in ("perm_kinship", "calc_kinship"):
+                full = np.zeros((n, n))
+                full[iu] = d["%s_%s_%s" % (variant, mode, key)]
+                d["%s_%s_%s" % (variant, mode, key)] = full + np.triu(full, 1).T
+    return d
+
+
+def reference_row_signs(d, tag, H):
+    """H (an H_sqrt_inv of the same K and delta, any LAPACK's row signs) with the row signs the REFERENCE run had
+    (fixture keys <tag>_perm_H_argmax / _sign), verified against the recorded products H v (<tag>_perm_H_probe)."""
+    H = np.array(H, dtype=np.float64)
+    n = len(H)
+    at = H[np.arange(n), d[tag + "_perm_H_argmax"]]
+    H *= (np.sign(at) * d[tag + "_perm_H_sign"])[:, None]
+    probe = H @ np.random.RandomState(99).randn(n, 3)
+    want = d[tag + "_perm_H_probe"]
+    assert np.abs(probe - want).max() < 1e-7 * np.abs(want).max(), "H_sqrt_inv does not reconstruct the reference's"
+    return H

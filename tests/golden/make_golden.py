@@ -317,6 +317,162 @@ def run_extras3(mods_by_mode):
     print('extras3_n150', snps.shape, '%.0f KB' % (os.path.getsize(path) / 1024.0))
 
 
+def hdf5_genotypes(rng, n, m, diploid):
+    """One chromosome of the HDF5 layout (plink2hdf5.py:111-118): int8 raw_snps [m x n], `freqs` as the parser writes
+    them for 0/1/2 codes (mean / 2, plink2hdf5.py:202) or the carrier frequency for 0/1 codes, sorted positions.
+    Allele frequencies span 0.02..0.98 so that `mafs > min_maf` (hdf5_data.py:91-93) removes a good share, plus two rows
+    ON the threshold of min_maf = 0.1 at n = 200 (freq 0.1 exactly, and 0.9 whose 1 - f is 0.0999...98)."""
+    npop, fst = 3, 0.12
+    anc = rng.uniform(0.02, 0.98, size=m)
+    a = anc * (1 - fst) / fst
+    b = (1 - anc) * (1 - fst) / fst
+    pop_p = rng.beta(a[:, None], b[:, None], size=(m, npop))
+    pops = rng.randint(0, npop, size=n)
+    snps = (rng.random_sample((m, n)) < pop_p[:, pops]).astype(np.int8)
+    if diploid:
+        snps = snps + (rng.random_sample((m, n)) < pop_p[:, pops]).astype(np.int8)
+    top = 2 if diploid else 1
+    for row, carriers in ((5, n // 10), (6, n - n // 10)):         # carrier frequency 0.1 and 0.9 on the binary file
+        snps[row] = 0
+        snps[row, rng.choice(n, carriers, replace=False)] = top
+    keep = snps.std(1) > 0                                            # monomorphic rows cannot be standardised (:103)
+    snps = snps[keep]
+    freqs = snps.mean(1) / float(top)
+    positions = np.sort(rng.choice(10 ** 6, len(snps), replace=False)).astype(np.int64)
+    return snps, freqs, positions
+
+
+def run_hdf5(mods_by_mode):
+    """Reference-run answers for the HDF5 DRIVERS (hdf5_data.py: calculate_ibd_kinship :17-62, run_emmax :70-187,
+    run_emmax_perm :191-351) -- needs a real h5py, i.e. `/opt/conda/bin/python3.9 tests/golden/make_golden.py` with
+    MMG_GOLDEN_ONLY=hdf5 in the build container.  Two 3-chromosome files in plink2hdf5's layout (0/1 codes and 0/1/2
+    codes), N = 200; the fixture keeps the INPUT arrays and what the reference wrote to its files, nothing else
+    (the tests rebuild the container from the arrays through chunkstore)."""
+    import tempfile
+    import h5py
+    n, nperm, chunk, min_maf = 200, 40, 150, 0.1
+    data = {'n': np.int64(n), 'num_perm': np.int64(nperm), 'chunk_size': np.int64(chunk), 'min_maf': np.float64(min_maf)}
+    for variant, seed in (('bin', 61), ('dip', 62)):
+        rng = np.random.RandomState(seed)
+        chroms = [hdf5_genotypes(rng, n, m, variant == 'dip') for m in (420, 380, 400)]
+        allsnps = np.vstack([c[0] for c in chroms])
+        y = phenotype(rng, allsnps, h2=0.6, ncausal=8)
+        ids = np.arange(1000, 1000 + n)
+        for ci, (snps, freqs, positions) in enumerate(chroms):
+            name = 'chrom_%d' % (ci + 1)
+            # 0/1 codes bit-packed, 0/1/2 codes as two bit planes ([s >= 1], [s == 2]) -- the tests unpack to int8
+            data['%s_%s_raw_snps_ge1' % (variant, name)] = np.packbits((snps >= 1).astype(np.uint8), axis=1)
+            if variant == 'dip':
+                data['%s_%s_raw_snps_eq2' % (variant, name)] = np.packbits((snps == 2).astype(np.uint8), axis=1)
+            data['%s_%s_freqs' % (variant, name)] = freqs
+            data['%s_%s_positions' % (variant, name)] = positions
+        data['%s_phenotypes' % variant] = y
+        data['%s_indiv_ids' % variant] = ids
+        for mode, mods in mods_by_mode.items():
+            hd = mods['hdf5_data']
+            tmp = tempfile.mkdtemp(prefix='mmg_h5_')
+            try:
+                fn = os.path.join(tmp, 'geno.hdf5')
+                f = h5py.File(fn, 'w')
+                gg, ig = f.create_group('genot_data'), f.create_group('indiv_data')
+                for ci, (snps, freqs, positions) in enumerate(chroms):
+                    cg = gg.create_group('chrom_%d' % (ci + 1))
+                    cg.create_dataset('raw_snps', compression='lzf', data=snps)
+                    cg.create_dataset('positions', compression='lzf', data=positions)
+                    cg.create_dataset('freqs', compression='lzf', data=freqs)
+                ig.create_dataset('indiv_ids', data=ids)
+                ig.create_dataset('phenotypes', data=y)
+                f.create_dataset('num_snps', data=np.array(len(allsnps)))
+                f.close()
+                tag = '%s_%s' % (variant, mode)
+                iu = np.triu_indices(n)
+
+                def keep32(v):                                          # exactly symmetric (asserted): upper triangle
+                    assert np.array_equal(v, v.T)
+                    return v[iu].astype(np.float32) if mode == 'lit' else v[iu]
+                # --- run_emmax, kinship recalculated from the MAF-filtered SNPs (:82-111)
+                out1 = os.path.join(tmp, 'res.hdf5')
+                quiet(hd.run_emmax, hdf5_filename=fn, out_file=out1, min_maf=min_maf, recalculate_kinship=True,
+                      chunk_size=chunk)
+                with h5py.File(out1, 'r') as o:
+                    for k in ('pseudo_heritability', 've', 'vg', 'max_ll', 'num_snps'):
+                        data['%s_emmax_%s' % (tag, k)] = np.asarray(o[k][...], dtype=np.float64)
+                    data['%s_emmax_chroms' % tag] = np.asarray(list(o['chrom_results'].keys()))
+                    for c in o['chrom_results'].keys():
+                        data['%s_emmax_%s_ps' % (tag, c)] = np.asarray(o['chrom_results'][c]['ps'][...], dtype=np.float64)
+                        data['%s_emmax_%s_positions' % (tag, c)] = np.asarray(o['chrom_results'][c]['positions'][...])
+                # --- run_emmax_perm with the shuffles recorded (sp.random.shuffle of an n x 1 matrix, linear_models.py:1153)
+                np.random.seed(777)
+                idx = np.asmatrix(np.arange(n).reshape(n, 1))
+                perm_idx = []
+                for _ in range(nperm):
+                    np.random.shuffle(idx)
+                    perm_idx.append(np.asarray(idx).reshape(-1).copy())
+                data['%s_perm_idx' % tag] = np.asarray(perm_idx, dtype=np.int32)
+                out2 = os.path.join(tmp, 'res_perm.hdf5')
+                # the outcome of a permutation depends on the SIGNS of H_sqrt_inv's rows (the rotated residuals are what is
+                # shuffled, linear_models.py:1151-1154) and those are LAPACK's choice: observe the matrix the driver hands
+                # to _emmax_permutations_ (:330) and keep, per row, where its largest entry sits and that entry's sign,
+                # plus three products H v to verify a reconstruction against
+                seen = {}
+                lmm_cls = mods['linear_models'].LinearMixedModel
+                orig = lmm_cls._emmax_permutations_
+
+                def spy(self, snps_, K_, H_, num_perm=100, _orig=orig, _seen=seen):
+                    _seen['H'] = np.array(H_, dtype=np.float64)
+                    _seen['num_rows'] = len(snps_)
+                    return _orig(self, snps_, K_, H_, num_perm=num_perm)
+                lmm_cls._emmax_permutations_ = spy
+                np.random.seed(777)
+                try:
+                    quiet(hd.run_emmax_perm, hdf5_filename=fn, out_file=out2, min_maf=min_maf, chunk_size=chunk,
+                          num_perm=nperm)
+                finally:
+                    lmm_cls._emmax_permutations_ = orig
+                H = seen['H']
+                jmax = np.abs(H).argmax(axis=1)
+                data['%s_perm_H_argmax' % tag] = jmax.astype(np.int32)
+                data['%s_perm_H_sign' % tag] = np.sign(H[np.arange(n), jmax]).astype(np.int8)
+                data['%s_perm_H_probe' % tag] = H @ np.random.RandomState(99).randn(n, 3)
+                data['%s_perm_num_rows' % tag] = np.int64(seen['num_rows'])
+                with h5py.File(out2, 'r') as o:
+                    for k in ('pseudo_heritability', 've', 'vg', 'max_ll', 'num_snps', 'perm_min_ps', 'perm_max_f_stats',
+                              'five_perc_perm_min_ps', 'five_perc_perm_max_f_stats'):
+                        data['%s_perm_%s' % (tag, k)] = np.asarray(o[k][...], dtype=np.float64)
+                    data['%s_perm_kinship' % tag] = keep32(np.asarray(o['kinship'][...]))
+                    for c in o['chrom_results'].keys():
+                        data['%s_perm_%s_ps' % (tag, c)] = np.asarray(o['chrom_results'][c]['ps'][...], dtype=np.float64)
+                # --- calculate_ibd_kinship: ALL SNPs (no MAF filter, :17-62), stored into the genotype file (:60)
+                quiet(hd.calculate_ibd_kinship, hdf5_filename=fn, chunk_size=chunk)
+                with h5py.File(fn, 'r') as o:
+                    data['%s_calc_kinship' % tag] = keep32(np.asarray(o['kinship'][...]))
+                # ... a second call finds it there and leaves it (:25,61-62); overwrite=True recomputes the same
+                quiet(hd.calculate_ibd_kinship, hdf5_filename=fn, chunk_size=400, overwrite=True)
+                with h5py.File(fn, 'r') as o:                           # (only how far a different chunking moves it is kept)
+                    data['%s_calc_kinship_chunk400_maxdiff' % tag] = np.float64(np.abs(
+                        keep32(np.asarray(o['kinship'][...])) - data['%s_calc_kinship' % tag]).max())
+                # --- run_emmax(recalculate_kinship=False) reads that stored (unfiltered) kinship (:113-115)
+                out3 = os.path.join(tmp, 'res_k.hdf5')
+                try:
+                    quiet(hd.run_emmax, hdf5_filename=fn, out_file=out3, min_maf=min_maf, recalculate_kinship=False,
+                          chunk_size=chunk)
+                    with h5py.File(out3, 'r') as o:
+                        data['%s_storedk_pseudo_heritability' % tag] = np.asarray(o['pseudo_heritability'][...], dtype=np.float64)
+                        for c in o['chrom_results'].keys():
+                            data['%s_storedk_%s_ps' % (tag, c)] = np.asarray(o['chrom_results'][c]['ps'][...], dtype=np.float64)
+                except Exception as e:                                  # recorded, not hidden: the tests assert on it
+                    data['%s_storedk_error' % tag] = np.asarray('%s: %s' % (type(e).__name__, e))
+            finally:
+                import shutil
+                shutil.rmtree(tmp, ignore_errors=True)
+    path = os.path.join(HERE, 'hdf5_n200.npz')
+    np.savez_compressed(path, **data)
+    print('hdf5_n200', '%.0f KB' % (os.path.getsize(path) / 1024.0))
+    for k in sorted(data):
+        if 'error' in k:
+            print(' ', k, data[k])
+
+
 CASES = [
     # name, kind, N, M, seed, n_cofactors, nperm
     ('struct_n150_s0', 'struct', 150, 600, 0, 0, 20),
@@ -330,6 +486,9 @@ CASES = [
 def main():
     if not refshim.available():
         print('reference not mounted; nothing to do')
+        return
+    if os.environ.get('MMG_GOLDEN_ONLY', '') == 'hdf5':           # under /opt/conda/bin/python3.9 (real h5py)
+        run_hdf5({'lit': refshim.load('literal', with_hdf5=True), 'dbl': refshim.load('double', with_hdf5=True)})
         return
     mods = {'lit': refshim.load('literal'), 'dbl': refshim.load('double')}
     if os.environ.get('MMG_GOLDEN_ONLY', '') in ('', 'extras'):

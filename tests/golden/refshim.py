@@ -20,6 +20,9 @@ import types
 REF = os.environ.get("MIXMOGAM_REFERENCE", "/root/reference")
 _MODS = ["kinship", "linear_models", "simulations", "snpsdata", "analyze_gwas_results",
          "phenotypeData", "gwaResults"]
+# hdf5_data.py needs a REAL h5py (load(with_hdf5=True)): in the build container that is /opt/conda/bin/python3.9
+# (h5py 3.3, numpy 1.26, scipy 1.7.1), not the python3.10 the tests run under.
+_HDF5_MODS = ["hdf5_data"]
 
 
 def available():
@@ -29,6 +32,9 @@ def available():
 def _install_aliases():
     import numpy
     import scipy
+    # under scipy < 1.9 the sub-packages are not lazy attributes: import them before the alias loop, or the loop would
+    # bind scipy.linalg to numpy.linalg (no lstsq(overwrite_a=), no qr(mode=) ...)
+    import scipy.linalg, scipy.stats, scipy.optimize, scipy.special  # noqa: E401,F401
     for name in dir(numpy):
         if name.startswith("_"):
             continue
@@ -57,11 +63,14 @@ def _install_aliases():
         pass
 
 
-def load(mode="double"):
-    """Return dict name->module of the translated reference.  mode in {'literal','double'}."""
+def load(mode="double", with_hdf5=False):
+    """Return dict name->module of the translated reference.  mode in {'literal','double'}.
+    with_hdf5: also hdf5_data.py (needs a real h5py); its `h5py.File(name)` calls get the mode 'a' that h5py 2 (the
+    reference's) defaulted to -- h5py 3 defaults to read-only."""
     assert mode in ("literal", "double")
     if not available():
         raise RuntimeError("reference not mounted at %s" % REF)
+    _MODS = globals()["_MODS"] + (_HDF5_MODS if with_hdf5 else [])
     tmp = tempfile.mkdtemp(prefix="mmg_ref_%s_" % mode)
     for m in _MODS:
         shutil.copy(os.path.join(REF, m + ".py"), os.path.join(tmp, m + ".py"))
@@ -76,7 +85,9 @@ def load(mode="double"):
             # sp.negative(bool) is rejected by numpy >= 1.13 (kinship.py:67)
             src = src.replace("sp.negative(sp.isnan(norm_snps_array))",
                               "~sp.isnan(norm_snps_array)")
-        if mode == "double" and m in ("kinship", "linear_models"):
+        if m == "hdf5_data":
+            src = re.sub(r"h5py\.File\((\w+)\)", r"h5py.File(\1, 'a')", src)
+        if mode == "double" and m in ("kinship", "linear_models", "hdf5_data"):
             src = src.replace("'single'", "'double'")
         open(p, "w").write(src)
     _install_aliases()

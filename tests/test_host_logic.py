@@ -649,3 +649,23 @@ def test_random_shapes_through_the_host_mirror():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "random_parity.py"), "40", "3"], capture_output=True, text=True,
                          timeout=600, env=dict(os.environ, MMG_PARITY_HOST="1"))
     assert out.returncode == 0 and "failures: 0" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+# ------------------------------------------------------------------ round 6: the HDF5 drivers' HOST logic vs the reference's own runs
+@pytest.mark.parametrize("variant", ["bin", "dip"])
+def test_hdf5_driver_host_logic_vs_the_reference_run(tmp_path, variant):
+    """The bodies of the -m gpu driver tests (tests/test_gpu_round6.py) with the numpy stand-in context: what is checked
+    here is the drivers' own reading of hdf5_data.py (MAF filter, chromosome order, `chr12_snps`, sorted outputs, the
+    5 % index, both num_snps conventions, file layout) against tests/golden/hdf5_n200.npz -- the reference's own files."""
+    import test_gpu_round6 as g
+    from conftest import load_hdf5_golden
+    from fake_ctx import FakeContext
+    d, ctx = load_hdf5_golden(), FakeContext()
+    for i, (fn, args) in enumerate(((g.test_calculate_ibd_kinship_driver_vs_the_reference_run, (variant,)),
+                                    (g.test_run_emmax_driver_vs_the_reference_run, (variant, 0)),
+                                    (g.test_run_emmax_driver_vs_the_reference_run, (variant, 1 if variant == "bin" else 2)),
+                                    (g.test_run_emmax_with_the_stored_kinship_vs_the_reference_run, (variant,)),
+                                    (g.test_run_emmax_perm_driver_vs_the_reference_run, (variant,)))):
+        sub = tmp_path / ("case%d" % i)
+        sub.mkdir()
+        fn(ctx, sub, d, *args)
