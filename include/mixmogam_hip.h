@@ -47,6 +47,10 @@ int mmg_has_experiments(void);
 int mmg_device_count(int* n);
 int mmg_ctx_create(int device, mmg_ctx** ctx);
 int mmg_ctx_destroy(mmg_ctx* ctx);
+/* Free the buffers the context keeps BETWEEN calls for speed (the band-route factor stores of the REML search, up to 2 GB each;
+ * ~650 MB each after an emmax() call at N = 5000).  They are re-allocated on demand; factors kept by mmg_reml_band_factor are
+ * forgotten (the next sums() call of their workspace factors again). */
+int mmg_ctx_trim(mmg_ctx* ctx);
 const char* mmg_last_error(mmg_ctx* ctx);    /* ctx may be NULL: last global error */
 int mmg_device_info(mmg_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
 /* milliseconds the dominant kernel of the last call took, from hipEvents recorded on the

@@ -32,6 +32,7 @@ PROTOTYPES = {
     "mmg_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "mmg_ctx_create": (C.c_int, [C.c_int, C.POINTER(c_vp)]),
     "mmg_ctx_destroy": (C.c_int, [c_vp]),
+    "mmg_ctx_trim": (C.c_int, [c_vp]),
     "mmg_last_error": (C.c_char_p, [c_vp]),
     "mmg_device_info": (C.c_int, [c_vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), c_i64p]),
     "mmg_last_kernel_ms": (C.c_int, [c_vp, C.c_int, c_f64p]),
@@ -812,6 +813,10 @@ class Context(object):
         self._check(self.lib.mmg_emmax_perm_sharded(self.h, comm, g.h, g.N, _ptr(H), _ptr(Ys), P, float(h0_rss),
                                                     int(ndigits), _ptr(out)))
         return out
+
+    def trim(self):
+        """Free what the context keeps between calls for speed (mmg_ctx_trim: the band-route factor stores, up to 2 x 2 GB)."""
+        self._check(self.lib.mmg_ctx_trim(self.h))
 
     def close(self):
         if getattr(self, "h", None) is not None:

@@ -71,6 +71,14 @@ int mmg_device_count(int* n) {
   return MMG_OK;
 }
 
+int mmg_ctx_trim(mmg_ctx* ctx) {
+  MMG_ENTER(ctx);
+  MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(ctx->band_ws);   ctx->band_ws = nullptr;   ctx->band_ws_cap = 0;
+  (void)hipFree(ctx->band_keep); ctx->band_keep = nullptr; ctx->band_keep_cap = 0; ctx->band_keep_owner = nullptr;
+  return MMG_OK;
+}
+
 const char* mmg_last_error(mmg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
 int mmg_ctx_create(int device, mmg_ctx** out) {
@@ -869,8 +877,8 @@ struct mmg_kin_acc {
 #define MMG_ACC_USABLE(ctx, a)                                                                                         \
   do {                                                                                                                 \
     if ((a)->broken)                                                                                                   \
-      return set_err(ctx, MMG_E_STATE, "the kinship accumulator is unusable: an earlier mmg_kin_acc_add_grm failed "    \
-                                       "part-way through (its SNPs are partly in the sum); create a new accumulator"); \
+      return set_err(ctx, MMG_E_STATE, "the kinship accumulator is unusable: an earlier mmg_kin_acc_add_grm / _set_ibs " \
+                                       "failed part-way through (its matrix is half built); create a new accumulator");   \
   } while (0)
 
 int mmg_kin_acc_create(mmg_ctx* ctx, int32_t N, mmg_kin_acc** out) {
@@ -1180,11 +1188,16 @@ int mmg_kin_acc_set_ibs(mmg_ctx* ctx, mmg_comm* comm, mmg_kin_acc* a, mmg_geno* 
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, a && g && g->N == a->N && m_total >= g->M);
   MMG_ACC_USABLE(ctx, a);
-  a->ws.pending = false; a->ws.p_M = 0;                        // pending GRM sums are dropped with the matrix they belonged to
+  // pending GRM sums are dropped with the matrix they belonged to, and the run state of the exact route starts over with it
+  a->ws.pending = false; a->ws.p_M = 0; a->ws.p_c0 = 0.0; a->ws.p_smax = 0.0; a->ws.stream_M = 0;
   IbsF64 f{nullptr, m_total, scaled != 0};
   f.dK_dev = a->dC;
   int rc = kinship_counts_i8(ctx, g, 2, -1, 0, nullptr, comm, &f);
-  if (rc == MMG_OK) a->n_snps = m_total;
+  if (rc == MMG_OK) { a->n_snps = m_total; return rc; }
+  // the counts are converted INTO dC and scaled there: a failure may have left it half built ('not positive' from scale_k's
+  // rule, a HIP error) with n_snps still describing what it replaced -- the accumulator says so from here on (advisor r5)
+  a->n_snps = 0;
+  a->broken = true;
   return rc;
 }
 

@@ -932,6 +932,7 @@ static int band_reduce_hh(mmg_ctx* ctx, mmg_reml* r) {
   if (!r->dBand) RC_HIP(ctx, hipMalloc(&r->dBand, (size_t)N * BAND_LD * sizeof(double)));
   if (!r->dZr) RC_HIP(ctx, hipMalloc(&r->dZr, (size_t)N * q1 * sizeof(double)));
   double* A = r->dL;                                          // work copy of K, reduced in place (lower triangle)
+  r->linv_delta = NAN;                                        // ... so whatever L^-1 it cached is gone (advisor r5)
   const int64_t k_first = r->band_k0;                         // > 0: band_reduce_cqr did the panels before this one
   if (k_first == 0) {
     RC_HIP(ctx, hipMemcpyAsync(A, r->dK, (size_t)N * N * sizeof(double), hipMemcpyDeviceToDevice, st));

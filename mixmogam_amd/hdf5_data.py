@@ -44,6 +44,8 @@ def release_pools():
         for g in stores:
             g.close()
     _POOLS.clear()
+    if _lib._default_ctx is not None:                                     # ... and what the default context keeps between calls
+        _lib._default_ctx.trim()
 
 # parallel readinto() streams per chunk (a single page-cache copy runs at 5-8 GB/s): a quarter of the host's cores, 4..16
 _READ_THREADS = int(os.environ.get('MMG_READ_THREADS', 0)) or max(4, min(16, (os.cpu_count() or 8) // 4))

@@ -854,10 +854,10 @@ class LinearMixedModel(object):
         """get_estimates on a PRECOMPUTED eig_R (the reference's own route, :787-799)."""
         return self.get_estimates(eig_L, method=method, eig_R=eig_R, ngrids=ngrids, use_eig_R=True)
 
-    def _try_eigen_free_method(self, method='REML'):
+    def _try_eigen_free_method(self, method='REML', ngrids=50):
         """get_estimates_eigen_free(method=...) or None (K + delta I not positive definite on the grid: eigen route)."""
         try:
-            return self.get_estimates_eigen_free(method=method)
+            return self.get_estimates_eigen_free(method=method, ngrids=ngrids)
         except _lib.MixmogamHipError as e:
             if "positive definite" not in str(e):
                 raise
@@ -1108,7 +1108,8 @@ class LinearMixedModel(object):
         n_p = n - (self.X.shape[1] + 1)                                  # :1190-1193
         y = self.Y.reshape(-1)
         reml = None
-        if H_sqrt_inv is None and perm_h_from_cholesky(ctx):
+        if (H_sqrt_inv is None and perm_h_from_cholesky(ctx) and n > EIGEN_FREE_MIN_N and isinstance(ctx, _lib.Context)):
+            # (the gate of emmax_f_test / get_emma_reml_estimates: a real device context and N past the eigen-free threshold)
             # H := L^-1 of K + delta I = L L' (any H with H'H = (K + delta I)^-1 is a valid H_sqrt_inv; the reference's own
             # is fixed only up to LAPACK's eigenvector signs, and the shuffled vector lives in the basis of the H that is
             # used): REML on the device without eigh(K), H X / H y by mmg_reml_linv_apply, the plan from the workspace in
@@ -1116,7 +1117,11 @@ class LinearMixedModel(object):
             est = self._try_eigen_free_method(method)
             if est is not None:
                 reml, delta = est['reml'], est['delta']
-                Zt = reml.linv_apply(delta, np.column_stack([self.X, y]))
+                try:
+                    Zt = reml.linv_apply(delta, np.column_stack([self.X, y]))
+                except Exception:
+                    reml.close()                                         # the workspace does not outlive a failed product
+                    raise
                 h0_X, Yt = Zt[:, :-1], Zt[:, -1]
         if reml is None:
             if H_sqrt_inv is None:
@@ -1193,20 +1198,32 @@ class _LazyEstimates(dict):
     asked for.  Iterating / items() / values() materialise everything."""
     _LAZY = ('H_sqrt_inv', 'Y_t', 'X_t', 'eig_L')
 
-    def __init__(self, scalars, lmm, reml):
+    def __init__(self, scalars, lmm):
         dict.__init__(self, scalars)
-        self._lmm, self._reml = lmm, reml
+        self._lmm = lmm
+
+    def _workspace(self):
+        """A fresh device workspace of this model (2 N^2 doubles + band buffers in HBM): the result does not hold one -- a caller
+        that keeps the results of a loop over phenotypes would pin 0.4 GB each at N = 5000, 40 GB at N = 50,000 (advisor r5)."""
+        lmm = self._lmm
+        return lmm.ctx.reml(lmm.random_effects[1][1], lmm.X, lmm.Y.reshape(-1))
 
     def _make(self, key):
         if key == 'eig_L':
             v = self._lmm._get_eigen_L_()
-        elif key == 'H_sqrt_inv':
-            v = self._reml.linv(dict.__getitem__(self, 'delta'))
         else:
-            Zt = self._reml.linv_apply(dict.__getitem__(self, 'delta'), np.column_stack([self._lmm.X, self._lmm.Y.reshape(-1)]))
-            dict.__setitem__(self, 'X_t', Zt[:, :-1])
-            dict.__setitem__(self, 'Y_t', Zt[:, -1:])
-            return dict.__getitem__(self, key)
+            reml = self._workspace()
+            try:
+                if key == 'H_sqrt_inv':
+                    v = reml.linv(dict.__getitem__(self, 'delta'))
+                else:
+                    Zt = reml.linv_apply(dict.__getitem__(self, 'delta'),
+                                         np.column_stack([self._lmm.X, self._lmm.Y.reshape(-1)]))
+                    dict.__setitem__(self, 'X_t', Zt[:, :-1])
+                    dict.__setitem__(self, 'Y_t', Zt[:, -1:])
+                    return dict.__getitem__(self, key)
+            finally:
+                reml.close()
         dict.__setitem__(self, key, v)
         return v
 
@@ -1242,10 +1259,7 @@ class _LazyEstimates(dict):
         return dict.values(self._all())
 
     def close(self):
-        """Release the device workspace (after this the lazy entries that were not touched raise)."""
-        if self._reml is not None:
-            self._reml.close()
-            self._reml = None
+        """Kept for callers of round 5: the result no longer owns a device workspace, there is nothing to release."""
 
 
 def get_emma_reml_estimates(y, K, K2=None, cofactors=None, include_intercept=True, ctx=None):
@@ -1260,17 +1274,20 @@ def get_emma_reml_estimates(y, K, K2=None, cofactors=None, include_intercept=Tru
     if cofactors is not None:
         lmm.set_factors(cofactors, include_intercept=include_intercept)
     if lmm.n > EIGEN_FREE_MIN_N and isinstance(lmm.ctx, _lib.Context) and perm_h_from_cholesky(lmm.ctx):
-        est = lmm._try_eigen_free_method('REML')
+        est = lmm._try_eigen_free_method('REML', ngrids=100)              # get_REML's grid (:653), as the eigen route below
         if est is not None:
             reml = est.pop('reml')
-            Zt = reml.linv_apply(est['delta'], np.column_stack([lmm.X, lmm.Y.reshape(-1)]))
+            try:
+                Zt = reml.linv_apply(est['delta'], np.column_stack([lmm.X, lmm.Y.reshape(-1)]))
+            finally:
+                reml.close()                                              # the result keeps no HBM (see _LazyEstimates)
             X_t, Y_t = Zt[:, :-1], Zt[:, -1]
             (beta_est, _res, _rank, _sigma) = linalg.lstsq(X_t, Y_t)        # :902-907
             resid = lmm.Y.reshape(-1) - lmm.X @ beta_est
             est.pop('H_sqrt_inv', None)
             est.update(beta=beta_est.reshape(-1, 1), mahalanobis_rss=np.array([float(np.sum((Y_t - X_t @ beta_est) ** 2))]),
                        rss=float(resid @ resid), lmm=lmm)
-            out = _LazyEstimates(est, lmm, reml)
+            out = _LazyEstimates(est, lmm)
             dict.__setitem__(out, 'X_t', X_t)
             dict.__setitem__(out, 'Y_t', Y_t.reshape(-1, 1))
             return out

@@ -14,7 +14,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+_BIG = {}
+
+
 def load_case(name):
+    if name == "struct_n1000_s7":
+        return dict(load_n1000())
+    if name == "ft10_config1":
+        return dict(load_config1())
     d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
     n = int(d["n"])
     d["snps"] = np.unpackbits(d["snps_packed"], axis=1)[:, :n].astype(np.int8)
@@ -23,11 +30,69 @@ def load_case(name):
 
 
 CASE_NAMES = ["struct_n150_s0", "struct_n150_s1", "struct_n300_s2", "struct_n300_s3", "bern_n200_s4"]
+# round 6: reference runs at a size that reaches the device code's tile structure (N = 1000: four tile rows, the tail launch,
+# >= 15 band-reduction panels) and in the shape of BASELINE config 1 (the 198 FT10 accessions through the reference's own
+# coordinate_w_phenotype_data); they carry the emmax / REML / permutation keys of the small cases, not the kernel-level ones
+BIG_CASE_NAMES = ["struct_n1000_s7", "ft10_config1"]
 
 
 @pytest.fixture(params=CASE_NAMES)
 def case(request):
     return load_case(request.param)
+
+
+@pytest.fixture(params=CASE_NAMES + BIG_CASE_NAMES)
+def case_emmax(request):
+    return load_case(request.param)
+
+
+@pytest.fixture(params=CASE_NAMES + BIG_CASE_NAMES[:1])
+def case_reml(request):
+    return load_case(request.param)
+
+
+def load_n1000():
+    """tests/golden/struct_n1000_s7.npz with the keys of load_case.  The 8 MB matrices are rebuilt, then VERIFIED against what
+    the reference run recorded: K = counts / 2M + 0.5 scaled (exact function of the genotypes; products K v and the diagonal
+    are in the fixture), H_sqrt_inv of the permutation run from its row signs (reference_row_signs checks products H v)."""
+    if "n1000" in _BIG:
+        return _BIG["n1000"]
+    from oracle import emmax_oracle as orc
+    d = dict(np.load(os.path.join(GOLDEN, "struct_n1000_s7.npz")))
+    n = int(d["n"])
+    d["snps"] = np.unpackbits(d["snps_packed"], axis=1)[:, :n].astype(np.int8)
+    d["cof"] = list(d["cofactors"])
+    K = orc.calc_ibs_kinship(d["snps"])
+    want = d["ibs_scaled_probe"]
+    assert np.abs(K @ np.random.RandomState(98).randn(n, 3) - want).max() < 1e-12 * np.abs(want).max()
+    assert np.abs(np.diag(K) - d["ibs_scaled_diag"]).max() < 1e-13
+    d["dbl_ibs_scaled"] = K
+    est0 = orc.get_estimates(d["y"], np.ones((n, 1)), orc.scale_k(K))
+    assert abs(est0["delta"] / float(d["dbl_reml0_delta"]) - 1) < 1e-6
+    d["dbl_perm_H"] = reference_row_signs(d, "dbl", est0["H_sqrt_inv"])
+    d["dbl_perm_idx"] = d["lit_perm_idx"] = d["perm_idx"].astype(np.int64)
+    _BIG["n1000"] = d
+    return d
+
+
+def load_config1():
+    """tests/golden/ft10_config1.npz: `snps`, `y`, K are the COORDINATED data the reference handed to calc_ibs_kinship / emmax
+    (examples.py:84-90); the raw inputs (`raw_snps`, accessions, chromosomes, positions) are what the plumbing test feeds the
+    build's own snpsdata / phenotypeData."""
+    if "config1" in _BIG:
+        return _BIG["config1"]
+    d = dict(np.load(os.path.join(GOLDEN, "ft10_config1.npz")))
+    d["raw_snps"] = np.unpackbits(d["snps_packed"], axis=1)[:, :int(d["n_genotyped"])].astype(np.int8)
+    n = len(d["coord_values"])
+    d["n"] = np.int64(n)
+    d["snps"] = np.unpackbits(d["coord_snps_packed"], axis=1)[:, :n].astype(np.int8)
+    d["y"] = d["coord_values"]
+    d["cof"] = None
+    K = np.zeros((n, n))
+    K[np.triu_indices(n)] = d["ibs_scaled_triu"]
+    d["dbl_ibs_scaled"] = K + np.triu(K, 1).T
+    _BIG["config1"] = d
+    return d
 
 
 def load_extras():

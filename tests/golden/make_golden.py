@@ -473,6 +473,152 @@ def run_hdf5(mods_by_mode):
             print(' ', k, data[k])
 
 
+def _row_signs(H):
+    """Per row of an H_sqrt_inv: where its largest entry sits and that entry's sign (LAPACK's choice), plus three products
+    H v -- enough to rebuild the matrix from the same K and delta elsewhere (conftest.reference_row_signs) at 1/1000 of its size."""
+    n = len(H)
+    jmax = np.abs(H).argmax(axis=1)
+    return (jmax.astype(np.int32), np.sign(H[np.arange(n), jmax]).astype(np.int8),
+            H @ np.random.RandomState(99).randn(n, 3))
+
+
+def run_n1000(mods_by_mode):
+    """Round-6 known answers at a size that reaches the device code's real tile structure (N = 1000 -> Npad 1024: four tile
+    rows of the triangular scan GEMM, its tail launch, >= 15 panels of the band reduction): structured N = 1000 x M = 4000,
+    two cofactors for emmax / REML / exact-EMMA refinement of the 10 top hits (emma_num=10), and 50 recorded permutations
+    of the intercept-only model (_emmax_permutations_ needs q == 1).  The 8 MB matrices are NOT stored: K is an exact
+    function of the genotypes (integer counts / 2M + 0.5, scale_k) -- the fixture carries products K v to verify a rebuilt K
+    against -- and H_sqrt_inv of the permutation run is kept as its row signs (_row_signs)."""
+    rng = np.random.RandomState(7)
+    n, m, nperm = 1000, 4000, 50
+    snps = structured_genotypes(rng, n, m, npop=4, fst=0.08)
+    y = phenotype(rng, snps, h2=0.6, ncausal=12)
+    cof = [rng.randn(n) + 0.5 * snps[7 + i] for i in range(2)]
+    data = {'snps_packed': np.packbits(snps.astype(np.uint8), axis=1), 'n': np.int64(n), 'y': y,
+            'cofactors': np.asarray(cof)}
+    np.random.seed(1007)
+    idx = np.asmatrix(np.arange(n).reshape(n, 1))
+    perm_idx = []
+    for _ in range(nperm):
+        np.random.shuffle(idx)
+        perm_idx.append(np.asarray(idx).reshape(-1).copy())
+    data['perm_idx'] = np.asarray(perm_idx, dtype=np.int16)
+    for mode, mods in mods_by_mode.items():
+        lm, kin = mods['linear_models'], mods['kinship']
+        f = (lambda v: np.asarray(v, dtype=np.float64)) if mode == 'dbl' else (lambda v: np.asarray(v, dtype=np.float32))
+        snp_list = list(snps)
+        k_ibs = np.asarray(quiet(kin.calc_ibs_kinship, snp_list))
+        if mode == 'dbl':
+            data['ibs_scaled_probe'] = k_ibs @ np.random.RandomState(98).randn(n, 3)
+            data['ibs_scaled_diag'] = np.diag(k_ibs).copy()
+        res = quiet(lm.emmax, snp_list, list(y), k_ibs, cofactors=cof)
+        for k in ('ps', 'f_stats', 'rss', 'var_perc'):
+            data['%s_emmax_%s' % (mode, k)] = f(res[k]).reshape(-1)
+        data['%s_emmax_h0_rss' % mode] = np.asarray(res['h0_rss'], dtype=np.float64).reshape(-1)
+        data['%s_emmax_h0_betas' % mode] = np.asarray(res['h0_betas'], dtype=np.float64).reshape(-1)
+        for k in ('pseudo_heritability', 've', 'vg', 'max_ll'):
+            data['%s_emmax_%s' % (mode, k)] = np.float64(res[k])
+        reml = quiet(lm.get_emma_reml_estimates, list(y), k_ibs, cofactors=cof)
+        for k in ('max_ll', 'delta', 've', 'vg', 'pseudo_heritability'):
+            data['%s_reml_%s' % (mode, k)] = np.float64(reml[k])
+        data['%s_reml_beta' % mode] = np.asarray(reml['beta'], dtype=np.float64).reshape(-1)
+        data['%s_reml_mahalanobis_rss' % mode] = np.asarray(reml['mahalanobis_rss'], dtype=np.float64).reshape(-1)
+        data['%s_eig_L_values' % mode] = f(reml['eig_L']['values'])
+        lmm = reml['lmm']
+        data['%s_eig_R_values' % mode] = f(lmm._get_eigen_R_(X=lmm.X)['values'])
+        H = np.asarray(reml['H_sqrt_inv'], dtype=np.float64)
+        data['%s_HtH_probe' % mode] = H.T @ (H @ np.random.RandomState(99).randn(n, 3))
+        if mode == 'dbl':
+            eres = quiet(lm.emmax, snp_list, list(y), k_ibs, cofactors=cof, emma_num=10)
+            for k in ('ps', 'f_stats', 'rss', 'var_perc'):
+                data['%s_emma10_%s' % (mode, k)] = f(eres[k]).reshape(-1)
+        # permutations: the intercept-only model
+        lmm3 = lm.LinearMixedModel(list(y))
+        lmm3.add_random_effect(k_ibs)
+        reml0 = quiet(lm.get_emma_reml_estimates, list(y), k_ibs)
+        data['%s_reml0_delta' % mode] = np.float64(reml0['delta'])
+        H0 = np.asarray(reml0['H_sqrt_inv'], dtype=np.float64)
+        (data['%s_perm_H_argmax' % mode], data['%s_perm_H_sign' % mode], data['%s_perm_H_probe' % mode]) = _row_signs(H0)
+        np.random.seed(1007)
+        pr = quiet(lmm3._emmax_permutations_, [s_.astype(np.float64) for s_ in snps], k_ibs, reml0['H_sqrt_inv'],
+                   num_perm=nperm)
+        data['%s_perm_min_ps' % mode] = np.asarray(pr['min_ps'], dtype=np.float64).reshape(-1)
+        data['%s_perm_max_f_stats' % mode] = np.asarray(pr['max_f_stats'], dtype=np.float64).reshape(-1)
+    path = os.path.join(HERE, 'struct_n1000_s7.npz')
+    np.savez_compressed(path, **data)
+    print('struct_n1000_s7', snps.shape, '%.0f KB' % (os.path.getsize(path) / 1024.0))
+
+
+def run_config1(mods_by_mode):
+    """Round-6 known answers in the shape of BASELINE config 1 (examples.py:72-96): the FT10 phenotype (phenotype_id 5) of
+    at_data/199_phenotypes.csv -- its 198 accessions and values, the rows tests/golden/at_phenotypes_ft10_ft16.csv excerpts --
+    against 3,000 synthetic SNPs on 5 chromosomes (the real genotype file is not mounted) for 210 genotyped accessions in a
+    shuffled order, 190 of them phenotyped, so that the reference's own coordinate_w_phenotype_data has accessions to drop on
+    both sides, an order to impose and non-binary SNPs to remove; then calc_ibs_kinship(sd.get_snps()) and
+    emmax(sd.get_snps(), phend.get_values(5), K), verbatim.  The sub-population of an accession follows its FT10 value
+    (flowering time is structured in the real data too), so the REML optimum is interior."""
+    import csv
+    rows = [r for r in csv.reader(open(os.path.join(refshim.REF, 'at_data', '199_phenotypes.csv'))) if r and r[0] == '5']
+    mine = [r for r in csv.reader(open(os.path.join(HERE, 'at_phenotypes_ft10_ft16.csv'))) if r and r[0] == '5']
+    assert [(r[2], float(r[3])) for r in rows] == [(r[2], float(r[3])) for r in mine], 'the committed excerpt is not FT10'
+    ets = [r[2] for r in rows]
+    vals = np.array([float(r[3]) for r in rows])
+    rng = np.random.RandomState(31)
+    order = np.argsort(np.argsort(vals + 25.0 * rng.randn(len(vals))))           # noisy rank of the FT10 value (sd 17.5)
+    pop_of = {e: int(3 * o // len(ets)) for e, o in zip(ets, order)}
+    genotyped = [ets[i] for i in rng.choice(len(ets), 190, replace=False)] + [str(990000 + i) for i in range(20)]
+    genotyped = [genotyped[i] for i in rng.permutation(len(genotyped))]
+    pops = np.array([pop_of.get(a, rng.randint(3)) for a in genotyped])
+    m, fst = 3000, 0.15
+    anc = rng.uniform(0.1, 0.9, size=m)
+    pop_p = rng.beta((anc * (1 - fst) / fst)[:, None], ((1 - anc) * (1 - fst) / fst)[:, None], size=(m, 3))
+    snps = (rng.random_sample((m, len(genotyped))) < pop_p[:, pops]).astype(np.int8)
+    unphen = np.array([a not in pop_of for a in genotyped])
+    for row in (11, 700, 1500, 2999):                                             # carried only by accessions that get dropped
+        snps[row] = 0
+        snps[row, np.nonzero(unphen)[0][:3]] = 1
+    chromosomes = np.repeat(np.arange(1, 6), m // 5)
+    positions = np.concatenate([np.sort(rng.choice(10 ** 7, m // 5, replace=False)) for _ in range(5)]).astype(np.int64)
+    data = {'snps_packed': np.packbits(snps.astype(np.uint8), axis=1), 'n_genotyped': np.int64(len(genotyped)),
+            'accessions': np.asarray(genotyped), 'chromosomes': chromosomes.astype(np.int8), 'positions': positions,
+            'phenotype_id': np.int64(5)}
+    for mode, mods in mods_by_mode.items():
+        sd_mod, pd_mod, kin, lm = mods['snpsdata'], mods['phenotypeData'], mods['kinship'], mods['linear_models']
+        f = (lambda v: np.asarray(v, dtype=np.float64)) if mode == 'dbl' else (lambda v: np.asarray(v, dtype=np.float32))
+        phend = quiet(pd_mod.parse_phenotype_file, os.path.join(refshim.REF, 'at_data', '199_phenotypes.csv'))
+        # construct_snps_data_set's own body (snpsdata.py:3307-3323) minus its dtype assert, with the rows as the LIST the
+        # parsers hand it (removeAccessionIndices :1229 assigns shorter rows in place, which a 2-D array refuses)
+        snpsds = [sd_mod.SNPsData(snps=[snps[i] for i in np.nonzero(chromosomes == c)[0]],
+                                  positions=list(positions[chromosomes == c]), chromosome=c, accessions=list(genotyped))
+                  for c in range(1, 6)]
+        sd = sd_mod.SNPsDataSet(snpsds, [1, 2, 3, 4, 5], data_format='binary')
+        quiet(sd.coordinate_w_phenotype_data, phend, 5)
+        s = sd.get_snps()
+        values = phend.get_values(5)
+        k_ibs = quiet(kin.calc_ibs_kinship, s)
+        res = quiet(lm.emmax, s, values, k_ibs)
+        if mode == 'dbl':
+            data['coord_accessions'] = np.asarray(sd.accessions)
+            data['coord_ecotypes'] = np.asarray(phend.phen_dict[5]['ecotypes'])
+            data['coord_values'] = np.asarray(values, dtype=np.float64)
+            data['coord_positions'] = np.asarray(sd.get_positions(), dtype=np.int64)
+            data['coord_chromosomes'] = np.asarray(sd.get_chr_list(), dtype=np.int8)
+            data['coord_snps_packed'] = np.packbits(np.asarray(s, dtype=np.uint8), axis=1)
+            kk = np.asarray(k_ibs)
+            assert np.array_equal(kk, kk.T)
+            data['ibs_scaled_triu'] = kk[np.triu_indices(len(kk))]
+        for k in ('ps', 'f_stats', 'rss', 'var_perc'):
+            data['%s_emmax_%s' % (mode, k)] = f(res[k]).reshape(-1)
+        data['%s_emmax_h0_rss' % mode] = np.asarray(res['h0_rss'], dtype=np.float64).reshape(-1)
+        data['%s_emmax_h0_betas' % mode] = np.asarray(res['h0_betas'], dtype=np.float64).reshape(-1)
+        for k in ('pseudo_heritability', 've', 'vg', 'max_ll'):
+            data['%s_emmax_%s' % (mode, k)] = np.float64(res[k])
+    path = os.path.join(HERE, 'ft10_config1.npz')
+    np.savez_compressed(path, **data)
+    print('ft10_config1', snps.shape, '->', len(s), 'x', len(s[0]), 'h2 %.3f' % data['dbl_emmax_pseudo_heritability'],
+          '%.0f KB' % (os.path.getsize(path) / 1024.0))
+
+
 CASES = [
     # name, kind, N, M, seed, n_cofactors, nperm
     ('struct_n150_s0', 'struct', 150, 600, 0, 0, 20),
@@ -497,7 +643,11 @@ def main():
         run_extras2(mods)
     if os.environ.get('MMG_GOLDEN_ONLY', '') in ('', 'extras3'):
         run_extras3(mods)
-    if os.environ.get('MMG_GOLDEN_ONLY', '') in ('extras', 'extras2', 'extras3'):
+    if os.environ.get('MMG_GOLDEN_ONLY', '') in ('', 'n1000'):
+        run_n1000(mods)
+    if os.environ.get('MMG_GOLDEN_ONLY', '') in ('', 'config1'):
+        run_config1(mods)
+    if os.environ.get('MMG_GOLDEN_ONLY', '') in ('extras', 'extras2', 'extras3', 'n1000', 'config1'):
         return
     for name, kind, n, m, seed, ncof, nperm in CASES:
         rng = np.random.RandomState(seed)

@@ -203,8 +203,10 @@ def test_scan_bitwise_reproducible_and_schedule_independent(ctx):
         assert np.array_equal(a[k], b[k])
 
 
-def test_emmax_python_surface_vs_golden(ctx, case):
+def test_emmax_python_surface_vs_golden(ctx, case_emmax):
+    """Every small case plus (round 6) the reference runs at N = 1000 (two cofactors) and in config 1's shape."""
     from mixmogam_amd import linear_models as lm
+    case = case_emmax
     res = lm.emmax(list(case["snps"]), list(case["y"]), case["dbl_ibs_scaled"], cofactors=case["cof"])
     assert rel(res["ps"], case["dbl_emmax_ps"]) < 1e-6          # the north-star tolerance
     assert rel(res["rss"], case["dbl_emmax_rss"]) < 1e-8
@@ -216,8 +218,9 @@ def test_emmax_python_surface_vs_golden(ctx, case):
     assert np.argmin(res["ps"]) == np.argmin(case["dbl_emmax_ps"])
 
 
-def test_reml_python_surface_vs_golden(ctx, case):
+def test_reml_python_surface_vs_golden(ctx, case_reml):
     from mixmogam_amd import linear_models as lm
+    case = case_reml
     res = lm.get_emma_reml_estimates(list(case["y"]), case["dbl_ibs_scaled"], cofactors=case["cof"])
     for k in ("max_ll", "delta", "ve", "vg", "pseudo_heritability"):
         assert rel(res[k], case["dbl_reml_" + k]) < 1e-7, k
@@ -333,7 +336,7 @@ def test_one_shot_c_abi(ctx):
 
 
 # ------------------------------------------------------------------ permutations
-@pytest.mark.parametrize("name", ["struct_n150_s0", "struct_n300_s2", "bern_n200_s4"])
+@pytest.mark.parametrize("name", ["struct_n150_s0", "struct_n300_s2", "bern_n200_s4", "struct_n1000_s7"])
 def test_permutations_vs_golden_and_oracle(ctx, name, monkeypatch):
     from mixmogam_amd import linear_models as lm
     case = load_case(name)

@@ -148,3 +148,114 @@ def test_run_emmax_perm_driver_vs_the_reference_run(ctx, tmp_path, h5gold, varia
                                    perm_idx=ref("perm_idx"), ctx=ctx)
     assert 1 / 30.0 < own["threshold_05"][0] / float(ref("perm_five_perc_perm_min_ps")) < 30.0
     assert rel(own["chrom_results"]["chrom_1"]["ps"], ref("perm_chrom_1_ps")) < 1e-6
+
+
+# ------------------------------------------------------------------ N = 1000 and config-1 reference runs
+def test_exact_emma_refinement_vs_the_n1000_reference_run(ctx):
+    """emma_num=10 at N = 1000 with two cofactors (linear_models.py:1365-1377): the ten top hits re-estimated exactly, the
+    rest untouched -- against the reference's own run."""
+    from conftest import load_case
+    from mixmogam_amd import linear_models as lm
+    case = load_case("struct_n1000_s7")
+    res = lm.emmax(case["snps"], list(case["y"]), case["dbl_ibs_scaled"], cofactors=case["cof"], emma_num=10)
+    assert rel(res["ps"], case["dbl_emma10_ps"]) < 1e-5
+    top = np.argsort(case["dbl_emmax_ps"], kind="stable")[:10]
+    assert rel(res["rss"][top], case["dbl_emma10_rss"][top]) < 1e-6
+    assert rel(res["f_stats"][top], case["dbl_emma10_f_stats"][top]) < 1e-5
+
+
+def test_config1_call_sequence_vs_the_reference_run(ctx):
+    """examples.py:72-96 verbatim against the build's modules on config 1's shape -- parse the phenotype file, construct the
+    SNP data set, coordinate, calc_ibs_kinship(sd.get_snps()), emmax(sd.get_snps(), phend.get_values(5), K) -- and every
+    number against the reference's own run of the same sequence (tests/golden/ft10_config1.npz)."""
+    from conftest import GOLDEN, load_case
+    from mixmogam_amd import kinship, linear_models as lm, phenotypeData as pd, snpsdata
+    c = load_case("ft10_config1")
+    phend = pd.parse_phenotype_file(os.path.join(GOLDEN, "at_phenotypes_ft10_ft16.csv"))
+    sd = snpsdata.construct_snps_data_set(c["raw_snps"], list(c["positions"]), list(c["chromosomes"]), list(c["accessions"]))
+    sd.coordinate_w_phenotype_data(phend, 5)
+    K = kinship.calc_ibs_kinship(sd.get_snps())
+    assert np.abs(np.asarray(K) - c["dbl_ibs_scaled"]).max() < 1e-13
+    res = lm.emmax(sd.get_snps(), phend.get_values(5), K)
+    assert rel(res["ps"], c["dbl_emmax_ps"]) < 1e-6
+    assert rel(res["rss"], c["dbl_emmax_rss"]) < 1e-8
+    for k in ("pseudo_heritability", "ve", "vg", "max_ll"):
+        assert rel(res[k], c["dbl_emmax_" + k]) < 1e-7, k
+    assert np.argmin(res["ps"]) == np.argmin(c["dbl_emmax_ps"])
+    lit = c["lit_emmax_ps"].astype(np.float64)
+    ok = lit > 1e-30
+    assert np.median(np.abs(res["ps"][ok] / lit[ok] - 1)) < 1e-3          # the literal fp32 run: its own noise
+
+
+# ------------------------------------------------------------------ small N, not multiples of 64 (advisor r5)
+def _small(n, m, seed):
+    rng = np.random.RandomState(seed)
+    pops = rng.randint(0, 2, size=n)
+    freqs = rng.uniform(0.15, 0.85, size=(m, 2))
+    snps = (rng.random_sample((m, n)) < freqs[:, pops]).astype(np.int8)
+    snps = snps[snps.std(1) > 0]
+    y = snps[:3].astype(float).sum(0) + rng.randn(n)
+    return snps, y, rng
+
+
+@pytest.mark.parametrize("n", [16, 17, 63, 65, 100])
+def test_small_n_routes_vs_the_oracle(ctx, n):
+    """EIGEN_FREE_MIN_N = 15 sends N = 16..255 down the per-delta Cholesky route: REML scalars and the scan through emmax(), the
+    L^-1 primitives, the device scan model and the permutation test on L^-1, at sizes that are not multiples of 64."""
+    from mixmogam_amd import kinship, linear_models as lm
+    snps, y, rng = _small(n, 400, n)
+    K = kinship.calc_ibs_kinship(snps, ctx=ctx)
+    assert np.array_equal(np.rint((kinship.calc_ibs_kinship(snps, scaled=False, ctx=ctx) - 0.5) * 2 * len(snps)).astype(np.int64),
+                          orc.ibs_counts(snps))
+    ref = orc.emmax(snps, y, K)
+    res = lm.emmax(snps, y, K, ctx=ctx)
+    flat = abs(np.log10(ref["delta"])) > 9.5                       # an optimum on the grid's edge: both sit there
+    assert rel(res["ps"], ref["ps"]) < (1e-6 if not flat else 1e-5)
+    assert rel(res["pseudo_heritability"], ref["pseudo_heritability"]) < 1e-6 or flat
+    X = np.ones((n, 1))
+    reml = ctx.reml(kinship.scale_k(K), X, y)
+    try:
+        delta = float(ref["delta"]) if not flat else 0.7
+        H = reml.linv(delta)
+        V = kinship.scale_k(K) + delta * np.eye(n)
+        assert np.allclose(H, np.tril(H)) and np.max(np.abs(H.T @ H @ V - np.eye(n))) < 1e-9
+        W = rng.randn(n, 2)
+        assert rel(reml.linv_apply(delta, W), H @ W) < 1e-10
+        h0_rss, beta = reml.scan_model(delta)
+        prep = orc.scan_prepare(y, X, H)
+        assert rel(h0_rss, prep["h0_rss"]) < 1e-9
+        got = ctx.scan(ctx.geno(snps), h0_rss, n - 2)
+        assert rel(got["ps"], orc.scan_closed(snps, prep)["ps"]) < 1e-6
+        idx = np.array([np.random.RandomState(50 + p).permutation(n) for p in range(21)])
+        lmm = lm.LinearMixedModel(list(y), ctx=ctx)
+        lmm.add_random_effect(K)
+        pp = lmm.perm_prepare(None, num_perm=len(idx), perm_idx=idx, reml=reml, delta=delta)
+        plan = reml.perm_plan(delta, pp["Ys"], pp["h0_rss"])
+        try:
+            min_rss = plan.run(ctx.geno(snps))
+        finally:
+            plan.close()
+        want = orc.perm_closed(snps, orc.perm_prepare(y, X, H, idx))
+        assert rel(min_rss, want["min_rss"]) < 1e-7
+    finally:
+        reml.close()
+
+
+def test_reml_estimates_result_holds_no_device_workspace(ctx):
+    """get_emma_reml_estimates on the eigendecomposition-free route (advisor r5): the 100-point grid of get_REML (:653), and a
+    result that keeps no HBM -- the matrices the reference also returns are rebuilt from the model when first asked for."""
+    from conftest import load_case
+    from mixmogam_amd import linear_models as lm
+    case = load_case("struct_n300_s2")
+    out = [lm.get_emma_reml_estimates(list(case["y"]), case["dbl_ibs_scaled"], ctx=ctx) for _ in range(4)]
+    for res in out:
+        assert isinstance(res, lm._LazyEstimates) and not hasattr(res, "_reml")
+        assert rel(res["delta"], case["dbl_reml_delta"]) < 1e-7
+    H = out[0]["H_sqrt_inv"]                                          # built now, from a workspace that is closed again
+    n = len(case["y"])
+    probe = np.random.RandomState(99).randn(n, 3)
+    assert rel(H.T @ (H @ probe), case["dbl_HtH_probe"]) < 1e-6
+    assert rel(out[1]["X_t"], H @ np.ones((n, 1))) < 1e-9
+    lmm = lm.LinearMixedModel(list(case["y"]), ctx=ctx)
+    lmm.add_random_effect(case["dbl_ibs_scaled"])
+    assert rel(lmm.get_REML()["delta"], case["dbl_reml_delta"]) < 1e-7     # the eigen route's 100-point search agrees

@@ -269,6 +269,26 @@ def test_config1_plumbing_phenotypes_and_coordination():
     assert Z.shape == (198, 198) and Z.sum() == 198
 
 
+def test_config1_coordination_vs_the_reference_run():
+    """The same step against what the REFERENCE's coordinate_w_phenotype_data produced (tests/golden/ft10_config1.npz,
+    examples.py:84): 210 genotyped accessions in a shuffled order, 190 of them phenotyped, 8 phenotyped ones without
+    genotypes, rows that stop being binary once accessions go -- kept accessions and their order on both sides, the
+    phenotype values in that order, the surviving SNPs with their positions and chromosomes."""
+    from conftest import load_case
+    from mixmogam_amd import phenotypeData as pd, snpsdata
+    c = load_case("ft10_config1")
+    phend = pd.parse_phenotype_file(os.path.join(ROOT, "tests", "golden", "at_phenotypes_ft10_ft16.csv"))
+    sd = snpsdata.construct_snps_data_set(c["raw_snps"], list(c["positions"]), list(c["chromosomes"]), list(c["accessions"]))
+    info = sd.coordinate_w_phenotype_data(phend, int(c["phenotype_id"]))
+    assert sd.accessions == [str(a) for a in c["coord_accessions"]]
+    assert [str(e) for e in phend.get_ecotypes(5)] == [str(e) for e in c["coord_ecotypes"]]
+    assert np.array_equal(np.asarray(phend.get_values(5)), c["coord_values"])
+    assert info["n_filtered_snps"] == len(c["raw_snps"]) - len(c["snps"]) > 0
+    assert np.array_equal(np.asarray(sd.get_snps()), c["snps"])
+    assert np.array_equal(np.asarray(sd.get_positions()), c["coord_positions"])
+    assert np.array_equal(np.asarray(sd.get_chr_list()), c["coord_chromosomes"])
+
+
 def test_bench_self_launch_dry(built):
     """`python bench.py --gpus 2` without a launcher environment starts two ranks itself: the parent
     never touches the GPU; --dry-launch makes the ranks report their rendezvous environment and exit."""
