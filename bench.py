@@ -51,7 +51,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default 3 (c5 mode: 1)")
     ap.add_argument("--warmup", type=int, default=None, help="default 1 (c5 mode: 0)")
-    ap.add_argument("--mode", choices=("weak", "strong", "perm", "multi", "c5"), default="weak")
+    ap.add_argument("--mode", choices=("weak", "strong", "perm", "multi", "c5"), default="weak",
+                    help="weak (default, the driver's contract): --m SNPs PER GPU; strong: --m SNPs in total split over the ranks "
+                         "-- the curve to read for BASELINE config 3 (independent SNP blocks scale weakly by construction: "
+                         "a healthy strong curve has the scan ~1/N and end_to_end_s flat at the replicated REML + scan model)")
     ap.add_argument("--c5-n", type=int, default=50000, help="c5 mode: individuals")
     ap.add_argument("--c5-m", type=int, default=10000000, help="c5 mode: SNPs in total, dealt chunk-wise over the ranks")
     ap.add_argument("--c5-chunk", type=int, default=50000, help="c5 mode: SNPs per chunk")
@@ -140,6 +143,60 @@ def self_launch(args):
     return rc
 
 
+def _check_distinct_devices(coll, rank, world, local_rank, info):
+    """[{rank, device, pci_bus_id}] of every rank (all-gathered over RCCL as numbers); exits non-zero on every rank when two
+    ranks report the same PCI bus id."""
+    def code(bus):                                         # "0000:c1:00.0" -> an exact integer in a double
+        try:
+            dom, b, rest = bus.split(":")
+            dev, fn = rest.split(".")
+            return float((int(dom, 16) << 24) | (int(b, 16) << 16) | (int(dev, 16) << 8) | int(fn, 16))
+        except Exception:
+            return -1.0 - rank
+    mine = np.array([float(rank), float(local_rank), code(info["pci_bus_id"])])
+    rows = np.asarray(coll.allgather(mine)).reshape(world, 3) if coll is not None else mine.reshape(1, 3)
+    ident = [{"rank": int(r), "device": int(d), "pci_code": int(c)} for r, d, c in rows]
+    ident[rank]["pci_bus_id"] = info["pci_bus_id"]
+    codes = [i["pci_code"] for i in ident]
+    if len(set(codes)) != len(codes):
+        raise SystemExit("bench.py: two ranks sit on the same GPU (PCI codes %s): refusing to time anything" % codes)
+    return ident
+
+
+def rccl_probe(ctx, coll, comm_h, N, m_block, repeats=3):
+    """The two exchange steps of the sharded hot path, timed on their own before the bench (first contact with RCCL over
+    xGMI): the all-reduce SUM of the N x N fp64 kinship accumulator in HBM (mmg_kin_acc_allreduce; 200 MB at C3 -- what
+    mmg_kinship_ibs_i8_sharded does after its GEMM) and the all-gather of one rank's (rss, F, p) block (mmg_comm_allgather_f64,
+    host-staged like mmg_comm_allgather_scan's delivery).  busbw = algbw x 2 (w - 1) / w (ring convention), 0 for one rank."""
+    w = coll.world
+    acc = ctx.kinship_accumulator(N)
+    t = []
+    for _ in range(repeats + 1):                           # the first call builds RCCL's channels
+        coll.barrier()
+        t0 = time.time()
+        acc.allreduce(comm_h)
+        coll.barrier()
+        t.append(time.time() - t0)
+    acc.close()
+    ar = min(t[1:])
+    nbytes = 8.0 * N * N
+    blk = np.zeros(3 * min(int(m_block), 1 << 22))
+    tg = []
+    for _ in range(repeats + 1):
+        coll.barrier()
+        t0 = time.time()
+        coll.allgather(blk)
+        coll.barrier()
+        tg.append(time.time() - t0)
+    ag = min(tg[1:])
+    return {"nranks": w, "allreduce_bytes": nbytes, "allreduce_ms": 1e3 * ar, "allreduce_first_call_ms": 1e3 * t[0],
+            "allreduce_algbw_gbps": nbytes / ar / 1e9, "allreduce_busbw_gbps": nbytes / ar / 1e9 * 2.0 * (w - 1) / w,
+            "allgather_bytes_per_rank": 8.0 * blk.size, "allgather_ms": 1e3 * ag, "allgather_first_call_ms": 1e3 * tg[0],
+            "allgather_algbw_gbps": 8.0 * blk.size * w / ag / 1e9,
+            "note": "N x N fp64 accumulator summed in HBM (RCCL over xGMI) and one (rss, F, p) block gathered through the "
+                    "host-staged path, each with a barrier on both sides; per-link xGMI ~153 GB/s"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -174,9 +231,17 @@ def main():
         if rccl_nranks != world:
             raise SystemExit("RCCL reports %d ranks, launcher %d" % (rccl_nranks, world))
     comm_h = coll.device_comm if coll is not None else None
+    # first contact with a multi-GPU node: say where this rank sits BEFORE anything is timed, and refuse to go on when two ranks
+    # share a GPU (LOCAL_RANK not honoured, a visibility mask ...): a scaling curve measured that way is worse than none
+    sys.stderr.write("[bench rank %d/%d] device %d  pci %s  %s  %d CUs  %.0f GB\n"
+                     % (rank, world, local_rank, info["pci_bus_id"], info["arch"], info["n_cu"], info["hbm_bytes"] / 2.0 ** 30))
+    sys.stderr.flush()
+    identity = _check_distinct_devices(coll, rank, world, local_rank, info)
+    rccl = rccl_probe(ctx, coll, comm_h, args.n if args.mode != "c5" else args.c5_n,
+                      args.m if args.mode != "c5" else args.c5_chunk) if coll is not None else None
 
     if args.mode == "c5":
-        return bench_c5(args, ctx, coll, rank, world, info, rccl_nranks)
+        return bench_c5(args, ctx, coll, rank, world, info, rccl_nranks, identity, rccl)
     N, D, mode = args.n, args.digits, args.mode
     if mode in ("weak", "multi"):
         M, Mtot, m_global0 = args.m, args.m * world, rank * args.m
@@ -270,7 +335,9 @@ def main():
             coll.barrier()
 
     common = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
-              "vs_baseline": None, "data": "synthetic", "rccl_nranks": rccl_nranks, "mode": mode}
+              "vs_baseline": None, "data": "synthetic", "rccl_nranks": rccl_nranks, "mode": mode,
+              "devices": identity, "rccl": rccl,
+              "rccl_allreduce_gbps": rccl["allreduce_busbw_gbps"] if rccl else None}
 
     if mode == "perm":
         res = bench_perm(args, ctx, coll, comm_h, g, lmm, y, N, M, Mtot, barrier, common)
@@ -469,7 +536,16 @@ def bench_scan(args, ctx, coll, comm_h, g, lmm, est, prep, N, M, Mtot, D, barrie
 
     traffic = _profiled_traffic(N, M, D, scan_stats["adaptive"])
     roof = roofline_of(per_rank_quad[0], M, scan_stats)
-    roof.update({"traffic": traffic.get(QUAD_KERNEL), "traffic_from_profiles": True,
+    tq = traffic.get(QUAD_KERNEL)
+    # what north_star asks to see beside the MFMA fraction: HBM-side GB/s of the dominant kernel (counter bytes of the committed
+    # --pmc passes over THIS run's hipEvent time) and how much of that traffic the algorithm did not ask for
+    roof.update({"hbm_gbps_achieved": (tq / (roof["ms"] * 1e-3) / 1e9) if tq else None,
+                 "hbm_frac_of_peak": (tq / (roof["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if tq else None,
+                 "wasted_traffic_ratio": (tq / roof["algorithmic_bytes"]) if tq else None,
+                 "ms_rocprof_first_pass_mean": traffic.get(QUAD_KERNEL + ":first_pass_ms_mean"),
+                 "ms_rocprof_source": "profiles/r6_bench_c3_scan_launches.txt (per-launch --kernel-trace durations of this "
+                                      "command; first passes = the timed kernel)"})
+    roof.update({"traffic": tq, "traffic_from_profiles": True,
                  "traffic_unit": "HBM-side bytes per launch from committed rocprofv3 --pmc passes of this command "
                                  "(profiles/traffic_c3.json: FETCH_SIZE, WRITE_SIZE in separate passes, gfx950 "
                                  "corrections) -- NOT measured in this run; null when the config differs"})
@@ -577,7 +653,11 @@ def _profiled_traffic(N, M, D, adaptive):
         # loads the committed file with the default arguments)
         cfg = tj["config"]
         if (cfg["n"], cfg["m"], cfg.get("digits", 4)) == (N, M, D or 4) and tj.get("adaptive", False) == adaptive:
-            return {k: v.get("hbm_bytes_corrected") for k, v in tj["kernels"].items()}
+            out = {k: v.get("hbm_bytes_corrected") for k, v in tj["kernels"].items()}
+            for k, v in tj["kernels"].items():                 # tools/scan_launch_list.py: mean --kernel-trace duration of the first passes
+                if v.get("first_pass_ms_mean") is not None:
+                    out[k + ":first_pass_ms_mean"] = v["first_pass_ms_mean"]
+            return out
     except Exception:
         pass
     return {}
@@ -928,6 +1008,7 @@ def bench_perm(args, ctx, coll, comm_h, g, lmm, y, N, M, Mtot, barrier, common):
                                       if tt_ms else None),
                 "perm_gemm_ms_per_rank": per_rank, "model_and_plan_s": plan_s,
                 "end_to_end_perm_s": e2e_s, "end_to_end_perm_phases_s": e2e_phases, "end_to_end_threshold_05_min_p": e2e_thr,
+                "end_to_end_s": e2e_s, "end_to_end_phases_s": e2e_phases,          # the keys every mode carries
                 "end_to_end_note": "kinship (IBS counts of the resident SNPs, RCCL sum, scale_k on the device, kept in HBM) -> REML "
                                    "(band reduction) -> scan model + permutation plan from the Cholesky factor in HBM "
                                    "(H_sqrt_inv := L^-1, no eigendecomposition) -> EMMAX scan + after-scan permutation test "
@@ -990,6 +1071,24 @@ def bench_multi(args, ctx, coll, g, lmm, eig_L, N, M, Mtot, barrier, common):
     if coll is not None:
         elapsed = float(coll.allreduce(np.array([elapsed]), "max")[0])
     rot.close()
+    # the whole multi-phenotype job on this rank as one clock: null models of all phenotypes (host), rotation of the resident
+    # SNPs into the eigenbasis, every phenotype's pass, p-values on the host; max over the ranks
+    def whole_job():
+        t0 = time.time()
+        mo, d2, om2, G2 = lm._multi_models(ys, lmm.X, eig_L)
+        t1 = time.time()
+        r2 = ctx.rot(eig_L["vectors"], M)
+        r2.load(g)
+        t2 = time.time()
+        ctx.scan_multi(r2, d2, om2, G2, np.array([m["h0_rss"] for m in mo]), N - 2, want=("ps",), out=pinned)
+        t3 = time.time()
+        r2.close()
+        return t3 - t0, {"null_models_host": t1 - t0, "rotation": t2 - t1, "scan_passes": t3 - t2}
+    barrier()
+    job_s, job_ph = min((whole_job() for _ in range(2)), key=lambda v: v[0])
+    barrier()
+    if coll is not None:
+        job_s = float(coll.allreduce(np.array([job_s]), "max")[0])
     if (coll.rank if coll is not None else 0) != 0:
         return None
     from mixmogam_amd._lib import scan_multi_batch
@@ -1007,11 +1106,12 @@ def bench_multi(args, ctx, coll, g, lmm, eig_L, N, M, Mtot, barrier, common):
                                            _profiled_traffic(N, M, 0, True).get("scan_multi_mfma_kernel")
                                            if min(P, scan_multi_batch()) == 16 else None),
                 "rotation_gemm_ms": rot_ms, "host_model_ms_per_phenotype": 1e3 * t_models / P,
+                "end_to_end_s": job_s, "end_to_end_phases_s": job_ph,
                 "min_p": float(out["ps"].min())})
     return res
 
 
-def bench_c5(args, ctx, coll, rank, world, info, rccl_nranks):
+def bench_c5(args, ctx, coll, rank, world, info, rccl_nranks, identity=None, rccl=None):
     """BASELINE config 5 as a job: N = 50,000 individuals x M = 10,000,000 SNPs streamed chunk-wise, the chunks dealt
     round-robin over the ranks -- hdf5_data.run_emmax (hdf5_data.py:70-187 of the reference) on a lazily generated,
     1-bit packed genotype tree (simulations.lazy_synthetic_source: every chunk is regenerated on each read, the 500 GB
@@ -1058,7 +1158,12 @@ def bench_c5(args, ctx, coll, rank, world, info, rccl_nranks):
     rec = {"metric": "SNPs/sec EMMAX end to end (kinship + REML + scan, streamed)", "unit": "SNPs/s",
            "value": n_snps * args.steps / dt_max, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-           "dtype": "i8", "data": "synthetic", "rccl_nranks": rccl_nranks, "mode": "c5",
+           "dtype": "i8", "data": "synthetic", "rccl_nranks": rccl_nranks, "mode": "c5", "devices": identity, "rccl": rccl,
+           "rccl_allreduce_gbps": rccl["allreduce_busbw_gbps"] if rccl else None,
+           # the step IS the whole job here: the same keys the other modes carry
+           "end_to_end_s": dt_max / args.steps,
+           "end_to_end_phases_s": {k: float(allv[:, 1 + i].max()) for i, k in enumerate(stage_keys)},
+           "setup_s_per_rank": [0.0] * world,
            "config": {"workload": "BASELINE configs[4]: N=%d individuals x M=%d SNPs streamed in chunks of %d from a lazily "
                                   "generated 1-bit packed source%s" % (N, Mtot, args.c5_chunk,
                                   " -- the share of ONE rank of %d, timed alone on one GPU" % share_of if share_of else ""),

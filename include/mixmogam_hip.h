@@ -53,6 +53,9 @@ int mmg_ctx_destroy(mmg_ctx* ctx);
 int mmg_ctx_trim(mmg_ctx* ctx);
 const char* mmg_last_error(mmg_ctx* ctx);    /* ctx may be NULL: last global error */
 int mmg_device_info(mmg_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
+/* PCI bus id of the context's device ("0000:c1:00.0"): what a multi-process launcher compares across ranks to be sure that no
+ * two of them sit on the same GPU. */
+int mmg_device_pci_bus_id(mmg_ctx* ctx, char* buf, int buf_len);
 /* milliseconds the dominant kernel of the last call took, from hipEvents recorded on the
  * ctx stream around it.  which: 0 = kinship GEMM, 1 = scan quadratic-form GEMM,
  * 2 = scan finalize (per-SNP dot + F + p), 3 = permutation GEMM, 4 = eigh, 5 = transpose/pack,

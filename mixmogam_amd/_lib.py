@@ -35,6 +35,7 @@ PROTOTYPES = {
     "mmg_ctx_trim": (C.c_int, [c_vp]),
     "mmg_last_error": (C.c_char_p, [c_vp]),
     "mmg_device_info": (C.c_int, [c_vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), c_i64p]),
+    "mmg_device_pci_bus_id": (C.c_int, [c_vp, C.c_char_p, C.c_int]),
     "mmg_last_kernel_ms": (C.c_int, [c_vp, C.c_int, c_f64p]),
     "mmg_host_pin": (C.c_int, [c_vp, c_vp, C.c_int64]),
     "mmg_host_unpin": (C.c_int, [c_vp, c_vp]),
@@ -630,7 +631,9 @@ class Context(object):
         ncu = C.c_int(0)
         mem = C.c_int64(0)
         self._check(self.lib.mmg_device_info(self.h, name, 64, C.byref(ncu), C.byref(mem)))
-        return {"arch": name.value.decode(), "n_cu": ncu.value, "hbm_bytes": mem.value}
+        bus = C.create_string_buffer(32)
+        self._check(self.lib.mmg_device_pci_bus_id(self.h, bus, 32))
+        return {"arch": name.value.decode(), "n_cu": ncu.value, "hbm_bytes": mem.value, "pci_bus_id": bus.value.decode()}
 
     def kernel_ms(self, which):
         ms = C.c_double(0.0)

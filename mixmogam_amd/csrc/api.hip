@@ -151,6 +151,13 @@ int mmg_device_info(mmg_ctx* ctx, char* name, int name_len, int* n_cu, int64_t* 
   return MMG_OK;
 }
 
+int mmg_device_pci_bus_id(mmg_ctx* ctx, char* buf, int buf_len) {
+  MMG_ENTER(ctx);
+  MMG_CHECK_ARG(ctx, buf != nullptr && buf_len >= 16);
+  MMG_HIP(ctx, hipDeviceGetPCIBusId(buf, buf_len, ctx->device));
+  return MMG_OK;
+}
+
 int mmg_last_kernel_ms(mmg_ctx* ctx, int which, double* ms) {
   MMG_ENTER(ctx);
   MMG_CHECK_ARG(ctx, which >= 0 && which < EV_COUNT && ms != nullptr);

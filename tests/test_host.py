@@ -312,6 +312,75 @@ def test_bench_self_launch_dry(built):
     assert out.returncode == 0 and json.loads(out.stdout)["RANK"] == "1"
 
 
+def test_bench_self_launch_dry_world8_and_first_contact_checks(built, monkeypatch):
+    """The 8-rank launch the driver's scaling run is (dry: nobody touches a GPU), and the checks every rank runs before anything
+    is timed: device identities all-gathered and asserted distinct (two ranks on one GPU -> every rank exits non-zero), the
+    RCCL probe's record, and the keys every mode's ONE JSON line carries."""
+    import importlib
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MMG_RUN_ID")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--mode", "strong", "--dry-launch"],
+                         capture_output=True, text=True, env=env, timeout=180)
+    assert out.returncode == 0, out.stderr
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["world"] == 8 and sorted(int(r["RANK"]) for r in rec["ranks"]) == list(range(8))
+    assert all(r["LOCAL_RANK"] == r["RANK"] and r["WORLD_SIZE"] == "8" and r["MASTER_ADDR"] == "127.0.0.1" for r in rec["ranks"])
+    assert len({r["MASTER_PORT"] for r in rec["ranks"]}) == 1 and len({r["MMG_RUN_ID"] for r in rec["ranks"]}) == 1
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    bench = importlib.import_module("bench")
+
+    class Coll(object):                                     # 8 ranks' worth of an all-gather, seen from rank 3
+        rank, world = 3, 8
+
+        def __init__(self, buses):
+            self.buses = buses
+
+        def allgather(self, mine):
+            if len(mine) != 3:                              # the probe's (rss, F, p) block
+                return np.tile(mine, 8)
+            rows = []
+            for r in range(8):
+                dom, b, rest = self.buses[r].split(":")
+                dev, fn = rest.split(".")
+                rows.append([r, r, (int(dom, 16) << 24) | (int(b, 16) << 16) | (int(dev, 16) << 8) | int(fn, 16)])
+            assert list(mine[:2]) == [3.0, 3.0] and mine[2] == rows[3][2]
+            return np.asarray(rows, dtype=np.float64).reshape(-1)
+
+        def barrier(self):
+            pass
+
+    buses = ["0000:%02x:00.0" % (0x05 + 0x10 * r) for r in range(8)]
+    ident = bench._check_distinct_devices(Coll(buses), 3, 8, 3, {"pci_bus_id": buses[3]})
+    assert [i["rank"] for i in ident] == list(range(8)) and ident[3]["pci_bus_id"] == buses[3]
+    assert len({i["pci_code"] for i in ident}) == 8
+    dup = list(buses)
+    dup[6] = dup[3]
+    with pytest.raises(SystemExit) as e:
+        bench._check_distinct_devices(Coll(dup), 3, 8, 3, {"pci_bus_id": dup[3]})
+    assert "same GPU" in str(e.value)
+
+    class Acc(object):
+        def allreduce(self, comm):
+            pass
+
+        def close(self):
+            pass
+
+    class Ctx(object):
+        def kinship_accumulator(self, n):
+            return Acc()
+    probe = bench.rccl_probe(Ctx(), Coll(buses), None, 5000, 125000)
+    assert probe["nranks"] == 8 and probe["allreduce_bytes"] == 8.0 * 5000 * 5000
+    assert probe["allreduce_busbw_gbps"] == pytest.approx(probe["allreduce_algbw_gbps"] * 2 * 7 / 8)
+    for k in ("allreduce_ms", "allreduce_first_call_ms", "allgather_ms", "allgather_algbw_gbps"):
+        assert probe[k] >= 0
+    # every mode's line carries these (main() / bench_c5 put them there; grep the source so a rename cannot drop one silently)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ('"rccl_allreduce_gbps"', '"rccl_nranks"', '"end_to_end_s"', '"end_to_end_phases_s"', '"setup_s_per_rank"',
+                '"devices"'):
+        assert src.count(key) >= 2, key
+
+
 def test_bench_self_launch_fails_cleanly_without_devices(built):
     """On a box with fewer devices than ranks the children say so and the parent exits non-zero -- no hang in the
     RCCL rendezvous, no partial JSON line."""

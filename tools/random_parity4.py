@@ -53,8 +53,10 @@ try:
             path = os.path.join(tmp, "g%d" % c)
             chunkstore.write_genotype_container(path, chroms, np.arange(n), phenotypes=y, packed_bits=bits)
             out = hdf5_data.run_emmax(path, None, min_maf=maf, chunk_size=chunk, ctx=ctx)
-            # the reference's MAF filter on `freqs` (the mean genotype), hdf5_data.py:91-96
-            keep = {k: np.minimum(v.mean(1), 1 - v.mean(1)) > maf for k, v in chroms.items()}
+            # the reference's MAF filter on `freqs` (hdf5_data.py:91-96) -- the allele frequency as its parser writes it: mean / 2 for
+            # 0/1/2 codes (plink2hdf5.py:202), the carrier frequency for 0/1 codes (chunkstore.write_genotype_container's default)
+            fr = {k: v.mean(1) / (2.0 if v.max() > 1 else 1.0) for k, v in chroms.items()}
+            keep = {k: np.minimum(fr[k], 1 - fr[k]) > maf for k in chroms}
             kept = np.vstack([chroms[k][keep[k]] for k in chroms])
             poly = kept.std(1) > 0
             if not poly.all() or len(kept) < 3 or n - 2 < 3:
@@ -66,7 +68,7 @@ try:
             ok = ref["ps"] > 1e-290
             note("file run_emmax p", rel(got[ok], ref["ps"][ok]), 1e-6, what)
             note("file h2", abs(out["pseudo_heritability"] - ref["pseudo_heritability"]), 1e-6, what)
-            mem = {k: {"raw_snps": v, "freqs": v.mean(1), "positions": np.arange(len(v))} for k, v in chroms.items()}
+            mem = {k: {"raw_snps": v, "freqs": fr[k], "positions": np.arange(len(v))} for k, v in chroms.items()}
             out2 = hdf5_data.run_emmax(mem, y, min_maf=maf, chunk_size=int(rng.choice([50, 100000])), ctx=ctx)
             got2 = np.concatenate([out2["chrom_results"][k]["ps"] for k in chroms])
             note("file vs memory p", rel(got, got2), 1e-7, what)
