@@ -18,7 +18,8 @@ constexpr int D64_MAX_SLICES = 40;         // partial Gram matrices a head kerne
 // Device scalars of a panel factorisation: flags[0] != 0 when a Cholesky-QR pass met a non-positive pivot or a first-pass Q
 // that is far from orthonormal (the panel is numerically rank deficient: the caller redoes the reduction with
 // Householder panels); flags[1] counts the panels done.
-struct PanelFlags { int bad; int panels; };
+// flags[2] counts the panels whose second Cholesky factor came from the series around the identity (cholqr_head2_kernel).
+struct PanelFlags { int bad; int panels; int series; };
 
 // part[g] (64 x 64 column-major each) = A[rows of slice g]' B[rows of slice g], g < *G_out slices of `rows_per` rows;
 // A [n x 64] (ld lda), B [n x kb] (ld ldb), kb <= 64.  Returns the slice count the launch used.

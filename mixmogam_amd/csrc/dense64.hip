@@ -257,6 +257,251 @@ __device__ __forceinline__ void mm64_store(int tid, const v4d (&acc)[4], FC fc) 
     for (int rr = 0; rr < 4; ++rr) fc(16 * w + 4 * rr + lk, 16 * jt + lr, acc[jt][rr]);
 }
 
+// ---- 64 x 64 Cholesky + inverse, blocked: panels inside ONE wave, the rest on the matrix pipe ------------------------------------
+// The chains above pay an LDS write -> barrier -> read round trip (195 cycles) and a Newton reciprocal (dependent v_fma_f64 of 40
+// cycles each) per column with four waves in lock step: 650 ns per column, 35 us per factorisation.  Here a 64 x 16 block column
+// is factored by wave 0 alone with the matrix row-per-lane in registers: what a column step needs from other rows comes over
+// v_readlane (no LDS, no barrier), and the NEXT pivot and its reciprocal are computed one step ahead from three readlanes
+// (d - (u rp) u, the very operations the owning lane performs), so the dependent chain of a step is multiply, multiply-add,
+// reciprocal -- the 15 row updates run in its shadow.  The trailing 16 x 16 blocks are updated by all four waves with
+// v_mfma_f64_16x16x4 between two barriers per block column (8 barriers in all instead of 64).  Nothing is scaled inside the chain:
+// the factor is kept as G = Lu D Lu' (Lu = I + F unit lower, D the pivots), L = Lu D^1/2 is formed by the caller's write-out.
+// The inverse of Lu: its four diagonal blocks by forward substitution (wave w: block w, one lane per column, no division: unit
+// diagonal), then with N[bi][bc] = Dinv[bi] F[bi][bc] (block-strictly lower, nilpotent) T = (I + N)^-1 by block rows of distance
+// 1, 2, 3 (T[bi][bc] = -sum_k N[bi][k] T[k][bc]) and Lu^-1 = T blockdiag(Dinv): 6 + 2 + 1 + 6 block products of 16^3 on the matrix
+// pipe in four barrier-separated stages.
+// As: the matrix (row-major, stride LD; lower triangle + diagonal read) -> unscaled columns u_ik (i > k), the pivots p_k on the
+//     diagonal, zeros above;   Fs -> F = u_ik / p_k (strictly lower; everything else zero);   T1 -> Lu^-1 (unit lower, row-major);
+// Xs: scratch;  rs[64] -> 1 / sqrt(p_k);  sh: >= 2 ints.   L_ik = u_ik rs_k,  L_kk = p_k rs_k,  (L^-1)_ik = rs_i Lu^-1_ik.
+// Returns 0, or 1 + the index of the first non-positive / non-finite pivot (replaced by 1: everything stays finite), uniform.
+__device__ __forceinline__ double lane_val64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+// one Newton step on v_rcp_f64 (its seed carries ~26 bits: LLVM's own f64 division takes two steps and a residual fix-up to round
+// correctly; one leaves <= ~2 ulp, measured by tools/probe/head_probe.hip) -- the reciprocal sits on the dependent chain of a panel
+__device__ __forceinline__ double rcp1_f64(double p) {
+  const double r = __builtin_amdgcn_rcp(p);
+  return fma(r, fma(-p, r, 1.0), r);
+}
+__device__ __forceinline__ v4d blk_load(const double* __restrict__ Cm, int r0, int c0, int lr, int lk) {
+  v4d acc;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) acc[rr] = Cm[(r0 + 4 * rr + lk) * LD + c0 + lr];
+  return acc;
+}
+__device__ __forceinline__ void blk_store(double* __restrict__ Cm, int r0, int c0, int lr, int lk, v4d acc) {
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) Cm[(r0 + 4 * rr + lk) * LD + c0 + lr] = acc[rr];
+}
+// acc += sgn * A[ar.., ac..] B[br.., bc..] (16 x 16 blocks of row-major LDS images)
+__device__ __forceinline__ v4d blk_mma(v4d acc, const double* __restrict__ Am, int ar, int ac, const double* __restrict__ Bm, int br,
+                                       int bc, int lr, int lk, double sgn) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sgn * Am[(ar + lr) * LD + ac + 4 * ks + lk], Bm[(br + 4 * ks + lk) * LD + bc + lr], acc, 0, 0, 0);
+  return acc;
+}
+// ... with the B operand transposed: acc += sgn * A[ar.., ac..] (B[br.., bc..])'
+__device__ __forceinline__ v4d blk_mma_nt(v4d acc, const double* __restrict__ Am, int ar, int ac, const double* __restrict__ Bm, int br,
+                                          int bc, int lr, int lk, double sgn) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sgn * Am[(ar + lr) * LD + ac + 4 * ks + lk], Bm[(br + lr) * LD + bc + 4 * ks + lk], acc, 0, 0, 0);
+  return acc;
+}
+// t -> (r, c), r > c: the six strictly-lower blocks of a 4 x 4 block matrix
+__device__ __forceinline__ void lower_block(int t, int& r, int& c) {
+  r = t >= 3 ? 3 : (t >= 1 ? 2 : 1);
+  c = t - r * (r - 1) / 2;
+}
+// Lu^-1 -> T1 for Lu = I + Fs (unit lower); Xs scratch (N is kept in T1's strictly-lower blocks until the last stage overwrites them).
+// Ends with a barrier.
+__device__ __forceinline__ void unit_lower_inverse64(const double* __restrict__ Fs, double* __restrict__ Xs, double* __restrict__ T1,
+                                                     int tid) {
+  double* const T2 = T1;
+  const int w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+  const v4d zero = {0.0, 0.0, 0.0, 0.0};
+  if (l < 16) {                                                // Dinv[w] = (I + F_ww)^-1: lane = column
+    const int b0 = 16 * w;
+    double t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = k == l ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+#pragma unroll
+      for (int i = k + 1; i < 16; ++i) t[i] = fma(-Fs[(b0 + i) * LD + b0 + k], t[k], t[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { Xs[(b0 + i) * LD + b0 + l] = t[i]; T1[(b0 + i) * LD + b0 + l] = t[i]; }
+  }
+  __syncthreads();
+  for (int t = w; t < 6; t += 4) {                             // N[r][c] = Dinv[r] F[r][c] -> T2 (N lives in T2's strictly-lower blocks)
+    int r, c;
+    lower_block(t, r, c);
+    blk_store(T2, 16 * r, 16 * c, lr, lk, blk_mma(zero, Xs, 16 * r, 16 * r, Fs, 16 * r, 16 * c, lr, lk, 1.0));
+  }
+  __syncthreads();
+  // T = (I + N)^-1 into the strictly-lower blocks of Xs (its diagonal blocks keep Dinv): distance 1 and 2 now, (3, 0) after them
+  for (int t = w; t < 5; t += 4) {
+    const int r = t < 3 ? t + 1 : t - 1, c = t < 3 ? t : t - 3;   // (1,0) (2,1) (3,2) | (2,0) (3,1)
+    v4d acc = blk_load(T2, 16 * r, 16 * c, lr, lk);
+    acc = -acc;
+    if (r - c == 2) acc = blk_mma(acc, T2, 16 * r, 16 * (c + 1), T2, 16 * (c + 1), 16 * c, lr, lk, 1.0);   // + N[r][c+1] N[c+1][c]
+    blk_store(Xs, 16 * r, 16 * c, lr, lk, acc);
+  }
+  __syncthreads();
+  if (w == 0) {                                                // T30 = -N30 - N31 T10 - N32 T20
+    v4d acc = blk_load(T2, 48, 0, lr, lk);
+    acc = -acc;
+    acc = blk_mma(acc, T2, 48, 16, Xs, 16, 0, lr, lk, -1.0);
+    acc = blk_mma(acc, T2, 48, 32, Xs, 32, 0, lr, lk, -1.0);
+    blk_store(Xs, 48, 0, lr, lk, acc);
+  }
+  __syncthreads();
+  for (int t = w; t < 6; t += 4) {                             // Lu^-1[r][c] = T[r][c] Dinv[c]
+    int r, c;
+    lower_block(t, r, c);
+    blk_store(T1, 16 * r, 16 * c, lr, lk, blk_mma(zero, Xs, 16 * r, 16 * c, Xs, 16 * c, 16 * c, lr, lk, 1.0));
+  }
+  for (int t = w; t < 6; t += 4) {                             // zeros above the block diagonal
+    int r, c;
+    lower_block(t, r, c);
+    blk_store(T1, 16 * c, 16 * r, lr, lk, zero);
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ int chol64_lds(double* __restrict__ As, double* __restrict__ Fs, double* __restrict__ Xs,
+                                          double* __restrict__ T1, double* __restrict__ rs, int* __restrict__ sh, int tid) {
+  const int w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+  if (tid == 0) sh[0] = 0;
+  for (int e = tid; e < 64 * LD; e += 256) Fs[e] = 0.0;
+#pragma unroll 1
+  for (int kb = 0; kb < 4; ++kb) {
+    const int c0 = 16 * kb;
+    __syncthreads();
+    if (w == 0) {
+      double a[16], pv[16], rpv[16];
+      int bad = 0;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) a[m] = As[l * LD + c0 + m];
+      double p = lane_val64(a[0], c0);
+      if (!(p > 0.0 && p < 1e300)) { bad = c0 + 1; p = 1.0; }
+      double rp = rcp1_f64(p);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int jg = c0 + j;
+        pv[j] = p;
+        rpv[j] = rp;
+        double pn = 1.0, rpn = 1.0;
+        if (j < 15) {                                          // the next pivot, one step ahead: exactly lane jg + 1's own arithmetic
+          const double u = lane_val64(a[j], jg + 1);
+          pn = fma(-(u * rp), u, lane_val64(a[j + 1], jg + 1));
+          if (!(pn > 0.0 && pn < 1e300)) { if (!bad) bad = jg + 2; pn = 1.0; }
+          rpn = rcp1_f64(pn);
+        }
+        const double f = l > jg ? a[j] * rp : 0.0;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) a[k] = fma(-f, lane_val64(a[j], c0 + k), a[k]);   // u of row c0 + k, column j
+        p = pn;
+        rp = rpn;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        As[l * LD + c0 + j] = l > c0 + j ? a[j] : (l == c0 + j ? pv[j] : 0.0);
+        if (l > c0 + j) Fs[l * LD + c0 + j] = a[j] * rpv[j];
+      }
+      if (l == 0 && bad && sh[0] == 0) sh[0] = bad;
+    }
+    __syncthreads();
+    const int nb = 3 - kb;
+    for (int t = w; t < nb * (nb + 1) / 2; t += 4) {           // trailing blocks (bi >= bc > kb): C -= F U'
+      const int r = t >= 3 ? 2 : (t >= 1 ? 1 : 0), c = t - r * (r + 1) / 2;
+      const int i0 = 16 * (kb + 1 + r), j0 = 16 * (kb + 1 + c);
+      blk_store(As, i0, j0, lr, lk, blk_mma_nt(blk_load(As, i0, j0, lr, lk), Fs, i0, c0, As, j0, c0, lr, lk, -1.0));
+    }
+  }
+  __syncthreads();
+  D64_STAMP(20);
+  if (tid < 64) rs[tid] = 1.0 / sqrt(As[tid * LD + tid]);
+  unit_lower_inverse64(Fs, Xs, T1, tid);                        // (ends with a barrier: rs is visible too)
+  D64_STAMP(21);
+  return sh[0];
+}
+
+// LU factorisation without pivoting of Q - S, S_jj = -sgn(current diagonal entry) chosen at step j so that |pivot| >= 1 (the rule
+// of gj64_signed_reg), blocked like chol64_lds: wave 0 eliminates the 64 x 16 block column (lane = row: the multipliers), wave 1
+// -- at the same time, on its own SIMD -- the 16-row block row (lane = column: the rows of U to the right of the diagonal block);
+// both walk the same pivots with the same arithmetic, so they need nothing from each other; then C -= F U on the matrix pipe.
+// Bq: Q (row-major, stride LD) -> U on and above the diagonal (the modified pivots on it; what is below is scratch);
+// Fq -> the multipliers (strictly lower, zeros elsewhere);  pv[64], sg[64] -> pivots and signs.  Ends with a barrier.
+__device__ __forceinline__ void lu64_signed_lds(double* __restrict__ Bq, double* __restrict__ Fq, double* __restrict__ pv,
+                                                double* __restrict__ sg, int tid) {
+  const int w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+  for (int e = tid; e < 64 * LD; e += 256) Fq[e] = 0.0;
+#pragma unroll 1
+  for (int kb = 0; kb < 4; ++kb) {
+    const int c0 = 16 * kb;
+    __syncthreads();
+    if (w == 0) {
+      double a[16], pvv[16], rpv[16], sgv[16];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) a[m] = Bq[l * LD + c0 + m];
+      double d = lane_val64(a[0], c0);
+      double sn = d >= 0.0 ? -1.0 : 1.0, p = d - sn, rp = rcp1_f64(p);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int jg = c0 + j;
+        pvv[j] = p; rpv[j] = rp; sgv[j] = sn;
+        double pn = 1.0, rpn = 1.0, snn = 1.0;
+        if (j < 15) {                                          // the next pivot one step ahead, with row jg + 1's own arithmetic
+          const double dn = fma(-(lane_val64(a[j], jg + 1) * rp), lane_val64(a[j + 1], jg), lane_val64(a[j + 1], jg + 1));
+          snn = dn >= 0.0 ? -1.0 : 1.0;
+          pn = dn - snn;
+          rpn = rcp1_f64(pn);
+        }
+        const double f = l > jg ? a[j] * rp : 0.0;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) a[k] = fma(-f, lane_val64(a[k], jg), a[k]);   // the pivot row's entry of column c0 + k
+        p = pn; rp = rpn; sn = snn;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (l > c0 + j) Fq[l * LD + c0 + j] = a[j] * rpv[j];
+        else if (l >= c0) Bq[l * LD + c0 + j] = l == c0 + j ? pvv[j] : a[j];
+        if (l == 0) { pv[c0 + j] = pvv[j]; sg[c0 + j] = sgv[j]; }
+      }
+    } else if (w == 1 && kb < 3) {
+      double t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = Bq[(c0 + r) * LD + l];
+      double d = lane_val64(t[0], c0);
+      double sn = d >= 0.0 ? -1.0 : 1.0, p = d - sn, rp = rcp1_f64(p);
+#pragma unroll
+      for (int j = 0; j < 15; ++j) {
+        const int jg = c0 + j;
+        const double dn = fma(-(lane_val64(t[j + 1], jg) * rp), lane_val64(t[j], jg + 1), lane_val64(t[j + 1], jg + 1));
+        const double snn = dn >= 0.0 ? -1.0 : 1.0, pn = dn - snn, rpn = rcp1_f64(pn);
+#pragma unroll
+        for (int r = j + 1; r < 16; ++r) t[r] = fma(-(lane_val64(t[r], jg) * rp), t[j], t[r]);   // multiplier of row c0 + r, uniform
+        p = pn; rp = rpn; sn = snn;
+      }
+      if (l >= c0 + 16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Bq[(c0 + r) * LD + l] = t[r];
+      }
+    }
+    __syncthreads();
+    const int nb = 3 - kb;
+    for (int t = w; t < nb * nb; t += 4) {                     // C -= F[.., kb] U[kb, ..] on the trailing blocks
+      const int i0 = 16 * (kb + 1 + t / nb), j0 = 16 * (kb + 1 + t % nb);
+      blk_store(Bq, i0, j0, lr, lk, blk_mma(blk_load(Bq, i0, j0, lr, lk), Fq, i0, c0, Bq, c0, j0, lr, lk, -1.0));
+    }
+  }
+  __syncthreads();
+}
+
 // ---- Y = X0 C0 (+ X1 C1) for tall X and 64 x 64 coefficients, on the matrix pipe ----------------------------------------------
 // One workgroup per 64 rows (wave w: rows 16 w .. 16 w + 15, all 64 columns; the transposed tile is computed so that a
 // register holds 16 consecutive rows of one column of Y: 128-byte stores).  The coefficient matrices sit in LDS transposed
@@ -565,8 +810,52 @@ __global__ __launch_bounds__(256) void cholqr_head1_kernel(const double* __restr
   D64_STAMP(3);
 }
 
+// the same on the blocked factorisation (chol64_lds): 4 LDS images
+constexpr int CHOL_LDS = (4 * 64 * LD + 64 + 8) * (int)sizeof(double);
+__global__ __launch_bounds__(256) void cholqr_head1_blk_kernel(const double* __restrict__ part, int G, double* __restrict__ R1,
+                                                               double* __restrict__ R1inv, PanelFlags* __restrict__ flags) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double *As = sm, *Fs = sm + 64 * LD, *Xs = sm + 2 * 64 * LD, *T1 = sm + 3 * 64 * LD, *rs = sm + 4 * 64 * LD;
+  int* sh = (int*)(rs + 64);
+  const int tid = threadIdx.x, i = tid & 63, kq = tid >> 6;
+  D64_STAMP(0);
+  {
+    double a[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) a[m] = 0.0;
+#pragma unroll 4
+    for (int g = 0; g < G; ++g) {
+      const double* __restrict__ pg = part + (size_t)g * 4096 + i + 64 * 16 * kq;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) a[m] += pg[64 * m];
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) As[i * LD + 16 * kq + m] = a[m];
+  }
+  __syncthreads();
+  D64_STAMP(1);
+  const int bad = chol64_lds(As, Fs, Xs, T1, rs, sh, tid);
+  D64_STAMP(2);
+  // R1 = L' and its inverse, both column-major upper: R1[k + 64 i] = L_ik = u_ik rs_k, R1inv[k + 64 i] = (L^-1)_ik = rs_i Lu^-1_ik
+  const double rsi = rs[i];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int k = 16 * kq + m;
+    R1[k + 64 * i] = As[i * LD + k] * rs[k];
+    R1inv[k + 64 * i] = T1[i * LD + k] * rsi;
+  }
+  if (tid == 0 && bad) flags->bad = 1;
+  D64_STAMP(3);
+}
+
+static bool head_blocked() {
+  static const bool on = [] { const char* e = std::getenv("MMG_HEAD_CHAIN"); return !(e && e[0] == '1'); }();   // MMG_HEAD_CHAIN=1: round 5's chains (A/B)
+  return on;
+}
+
 void launch_cholqr_head1(hipStream_t st, const double* part, int G, double* R1, double* R1inv, PanelFlags* flags) {
-  hipLaunchKernelGGL(cholqr_head1_kernel, dim3(1), dim3(256), 0, st, part, G, R1, R1inv, flags);
+  if (head_blocked()) hipLaunchKernelGGL(cholqr_head1_blk_kernel, dim3(1), dim3(256), CHOL_LDS, st, part, G, R1, R1inv, flags);
+  else hipLaunchKernelGGL(cholqr_head1_kernel, dim3(1), dim3(256), 0, st, part, G, R1, R1inv, flags);
 }
 
 // Second pass + the Householder-like representation of Q = Q1 R2^-1 in Yamamoto's basis-kernel form with the adaptive signs
@@ -576,6 +865,7 @@ void launch_cholqr_head1(hipStream_t st, const double* part, int G, double* R1, 
 // -(Qtop - S) S is inverted by Gauss-Jordan elimination of Qtop - S with S_jj chosen at step j so that |pivot| >= 1.
 // The rows below the top block need no solve at all:  V[64:] = Q1[64:] Cb,  Cb = -R2^-1 S.
 constexpr int HEAD2_LDS = (4 * 64 * LD + 2 * 64 + 2 * 128 + 3 * 64 + 8) * (int)sizeof(double);
+template <bool BLK>
 __global__ __launch_bounds__(256) void cholqr_head2_kernel(const double* __restrict__ part, int G, const double* __restrict__ R1,
                                                            double* __restrict__ V, int64_t ldv, double* __restrict__ M,
                                                            double* __restrict__ Cb, double* __restrict__ Rtop, int64_t ldr,
@@ -611,9 +901,52 @@ __global__ __launch_bounds__(256) void cholqr_head2_kernel(const double* __restr
     B3[(e & 63) * LD + (e >> 6)] = V[(e & 63) + (int64_t)(e >> 6) * ldv];
   }
   D64_STAMP(8);
-  const int bad = chol64_inv_reg(a, b, cb, rab, pb, piv, tid);
-  D64_STAMP(9);
-  {
+  // The second Gram matrix is I + E with |E| ~ eps cond(P)^2: when every entry of E is below 2^-24 the factor and its inverse
+  // come from the series around the identity -- four 64^3 products on the matrix pipe instead of a 64-step dependent chain
+  // (40 of this kernel's 100 us).  R2 = I + U, U upper triangular:  U + U' = E - U'U,  solved by  U <- Phi(E - U'U)  from
+  // U = Phi(E)  (Phi: strict upper triangle + half the diagonal); two sweeps leave |E|^3 <= (64 * 2^-24)^3 = 6e-17.
+  // R2^-1 = (I - U)(I + U^2) = I - U + U^2 - U^3  (the next term is |U|^4 ~ 2e-22).  Anything larger takes the chain below.
+  int big = 0;
+#pragma unroll
+  for (int m = 0; m < 16; ++m)
+    if (!(fabs(a[m] - (16 * kq + m == i ? 1.0 : 0.0)) <= 0x1p-24)) big = 1;
+#ifdef MMG_HEAD2_NO_SERIES
+  big = 1;                                                     // (A/B builds of tools/probe/head_probe.hip)
+#endif
+  big = __syncthreads_or(big);                                 // (also orders the B2 / B3 fills above before their readers)
+  int bad = 0;
+  static_assert(sizeof(v4d) == 32, "v4d");
+  if (!big) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int k = 16 * kq + m;
+      const double e = a[m] - (k == i ? 1.0 : 0.0);
+      B1[i * LD + k] = e;
+      B0[i * LD + k] = k > i ? e : (k == i ? 0.5 * e : 0.0);
+    }
+    __syncthreads();
+    v4d t[4];
+#pragma unroll 1
+    for (int it = 0; it < 2; ++it) {
+      mm64_mfma(tid, [&](int r, int k) { return B0[k * LD + r]; }, [&](int k, int c) { return B0[k * LD + c]; }, t);   // U'U
+      __syncthreads();
+      mm64_store(tid, t, [&](int r, int c, double v) {
+        const double x = B1[r * LD + c] - v;
+        B0[r * LD + c] = c > r ? x : (c == r ? 0.5 * x : 0.0);
+      });
+      __syncthreads();
+    }
+    mm64_mfma(tid, [&](int r, int k) { return B0[r * LD + k]; }, [&](int k, int c) { return B0[k * LD + c]; }, t);     // U^2
+    mm64_store(tid, t, [&](int r, int c, double v) { B1[r * LD + c] = v; });                                           // (E is dead)
+    __syncthreads();
+    mm64_mfma(tid, [&](int r, int k) { return (r == k ? 1.0 : 0.0) - B0[r * LD + k]; },
+              [&](int k, int c) { return (k == c ? 1.0 : 0.0) + B1[k * LD + c]; }, t);
+    __syncthreads();
+    mm64_store(tid, t, [&](int r, int c, double v) { B1[r * LD + c] = c >= r ? v : 0.0; });                           // R2^-1 (upper)
+    if ((i >> 4) == kq) B0[i * LD + i] += 1.0;                                                                         // R2 = I + U
+    if (tid == 0) flags->series += 1;
+  } else {
+    bad = chol64_inv_reg(a, b, cb, rab, pb, piv, tid);
     const double rsi = 1.0 / sqrt(piv[i]);
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
@@ -622,6 +955,7 @@ __global__ __launch_bounds__(256) void cholqr_head2_kernel(const double* __restr
       B1[k * LD + i] = k <= i ? b[m] * rsi : 0.0;
     }
   }
+  D64_STAMP(9);
   far = __syncthreads_or(far);
   v4d rr[4], qt[4];
   mm64_mfma(tid, [&](int r, int k) { return B0[r * LD + k]; }, [&](int k, int c) { return B2[k * LD + c]; }, rr);   // R2 R1
@@ -631,6 +965,55 @@ __global__ __launch_bounds__(256) void cholqr_head2_kernel(const double* __restr
   mm64_store(tid, qt, [&](int r, int c, double v) { B3[r * LD + c] = v; });
   __syncthreads();
   D64_STAMP(10);
+  if constexpr (BLK) {
+    // (Qtop - S)^-1 through the blocked LU: the three matrices the outputs need wait in registers while the LDS images are reused
+    double q[16], r2i[16], rr1[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int k = 16 * kq + m;
+      q[m] = B3[i * LD + k]; r2i[m] = B1[i * LD + k]; rr1[m] = B2[i * LD + k];
+    }
+    __syncthreads();
+    double *Bq = B3, *Fq = B0, *Xs = B1, *Li = B2;
+    lu64_signed_lds(Bq, Fq, pv, sg, tid);                       // Qtop - S = Lq Uq
+    unit_lower_inverse64(Fq, Xs, Li, tid);                      // Li = Lq^-1
+    // Uq = Dp (I + G): Gt = G' (strictly lower) -> Fq, W = (I + Gt)^-1 -> Bq;  Uq^-1[r][c] = W[c][r] / p_c
+    if (tid < 64) cb[tid] = 1.0 / pv[tid];                      // (cb: 128 doubles of chain scratch, free here)
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int k = 16 * kq + m;
+      Fq[i * LD + k] = i > k ? Bq[k * LD + i] * cb[k] : 0.0;
+    }
+    __syncthreads();
+    unit_lower_inverse64(Fq, Xs, Bq, tid);
+    D64_STAMP(11);
+    // M[k][i] = -N[i][k] s_i,  N = Uq^-1 Lq^-1:  M[k][i] = -s_i sum_m Li[m][k] W[m][i] / p_m  (m >= max(k, i))
+    {
+      const int w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+      for (int t = w; t < 16; t += 4) {
+        const int kb_ = t >> 2, ib = t & 3;
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        for (int mb = kb_ > ib ? kb_ : ib; mb < 4; ++mb)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const int mm = 16 * mb + 4 * ks + lk;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[mm * LD + 16 * kb_ + lr], Bq[mm * LD + 16 * ib + lr] * cb[mm], acc, 0, 0, 0);
+          }
+        const double si = -sg[16 * ib + lr];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) M[(16 * kb_ + 4 * rr + lk) + 64 * (16 * ib + lr)] = acc[rr] * si;
+      }
+    }
+    if (!(fabs(pv[i]) >= 1.0)) far = 1;                          // (NaN-aware: a panel that lost its numbers is flagged below)
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int k = 16 * kq + m;
+      V[i + (int64_t)k * ldv] = (k == i ? 1.0 : 0.0) - q[m] * sg[k];             // V[0:64] = I - Qtop S
+      Cb[i + 64 * k] = -r2i[m] * sg[k];                                          // Cb = -R2^-1 S
+      if (i <= k) Rtop[i + (int64_t)k * ldr] = sg[i] * rr1[m];                  // upper triangle of S R2 R1
+    }
+  } else {
 #pragma unroll
   for (int m = 0; m < 16; ++m) a[m] = B3[i * LD + 16 * kq + m];
   gj64_signed_reg(a, b, cb, rab, pb, pv, sg, tid);
@@ -649,6 +1032,7 @@ __global__ __launch_bounds__(256) void cholqr_head2_kernel(const double* __restr
       if (i <= k) Rtop[i + (int64_t)k * ldr] = sg[i] * B2[i * LD + k];          // upper triangle of S R2 R1
     }
   }
+  }
   far = __syncthreads_or(far);
   if (tid == 0) {
     if (bad || far) flags->bad = 1;
@@ -659,7 +1043,8 @@ __global__ __launch_bounds__(256) void cholqr_head2_kernel(const double* __restr
 
 void launch_cholqr_head2(hipStream_t st, const double* part, int G, const double* R1, double* V, int64_t ldv, double* M, double* Cb,
                          double* Rtop, int64_t ldr, PanelFlags* flags) {
-  hipLaunchKernelGGL(cholqr_head2_kernel, dim3(1), dim3(256), HEAD2_LDS, st, part, G, R1, V, ldv, M, Cb, Rtop, ldr, flags);
+  if (head_blocked()) hipLaunchKernelGGL(cholqr_head2_kernel<true>, dim3(1), dim3(256), HEAD2_LDS, st, part, G, R1, V, ldv, M, Cb, Rtop, ldr, flags);
+  else hipLaunchKernelGGL(cholqr_head2_kernel<false>, dim3(1), dim3(256), HEAD2_LDS, st, part, G, R1, V, ldv, M, Cb, Rtop, ldr, flags);
 }
 
 // ---- coefficients of the two-sided update ------------------------------------------------------------------------------------
@@ -742,13 +1127,40 @@ __global__ __launch_bounds__(256) void potrf_head_kernel(double* __restrict__ A,
   if (tid == 0 && bad && *info == 0) *info = base + bad;
 }
 
+__global__ __launch_bounds__(256) void potrf_head_blk_kernel(double* __restrict__ A, int64_t lda, int kb, double* __restrict__ LinvT,
+                                                             long long* __restrict__ info, long long base) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double *As = sm, *Fs = sm + 64 * LD, *Xs = sm + 2 * 64 * LD, *T1 = sm + 3 * 64 * LD, *rs = sm + 4 * 64 * LD;
+  int* sh = (int*)(rs + 64);
+  const int tid = threadIdx.x, i = tid & 63, kq = tid >> 6;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int k = 16 * kq + m;
+    As[i * LD + k] = (i < kb && k < kb) ? (i >= k ? A[i + (int64_t)k * lda] : 0.0) : (i == k ? 1.0 : 0.0);
+  }
+  __syncthreads();
+  const int bad = chol64_lds(As, Fs, Xs, T1, rs, sh, tid);
+  const double rsi = rs[i];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int k = 16 * kq + m;                                 // L[i][k], i >= k
+    if (i >= k && i < kb) A[i + (int64_t)k * lda] = As[i * LD + k] * rs[k];
+    LinvT[k + 64 * i] = T1[i * LD + k] * rsi;                  // (L^-T)[k][i] = (L^-1)[i][k]
+  }
+  if (tid == 0 && bad && *info == 0) *info = base + bad;
+}
+
 void launch_potrf_head(hipStream_t st, double* A, int64_t lda, int kb, double* LinvT, long long* info, long long base) {
-  hipLaunchKernelGGL(potrf_head_kernel, dim3(1), dim3(256), 0, st, A, lda, kb, LinvT, info, base);
+  if (head_blocked()) hipLaunchKernelGGL(potrf_head_blk_kernel, dim3(1), dim3(256), CHOL_LDS, st, A, lda, kb, LinvT, info, base);
+  else hipLaunchKernelGGL(potrf_head_kernel, dim3(1), dim3(256), 0, st, A, lda, kb, LinvT, info, base);
 }
 
 int dense64_init() {
   static int rc = [] {
-    hipError_t e = hipFuncSetAttribute((const void*)cholqr_head2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, HEAD2_LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)cholqr_head2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HEAD2_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cholqr_head2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HEAD2_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cholqr_head1_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHOL_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)potrf_head_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHOL_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)band_coef_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, COEF_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rows_gemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_LDS2);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rows_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_LDS1);

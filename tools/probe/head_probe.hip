@@ -8,7 +8,27 @@
 #include <algorithm>
 #include <cmath>
 using namespace mmg;
+// worst relative error of one / two Newton steps on v_rcp_f64 against IEEE division
+__global__ void rcp_err_kernel(double* out) {
+  double e1 = 0, e2 = 0;
+  unsigned long long x = 0x9E3779B97F4A7C15ull * (threadIdx.x + 1);
+  for (int it = 0; it < 20000; ++it) {
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    const double p = ldexp(1.0 + (double)(x >> 12) * 0x1p-52, (int)(x & 63) - 32);
+    const double q = 1.0 / p;
+    e1 = fmax(e1, fabs(rcp1_f64(p) - q) / q);
+    e2 = fmax(e2, fabs(rcp_f64(p) - q) / q);
+  }
+  out[2 * threadIdx.x] = e1; out[2 * threadIdx.x + 1] = e2;
+}
 int main(int argc, char** argv) {
+  {
+    double* d; hipMalloc(&d, 128 * 8);
+    hipLaunchKernelGGL(rcp_err_kernel, dim3(1), dim3(64), 0, 0, d);
+    double h[128]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    double e1 = 0, e2 = 0; for (int i = 0; i < 64; ++i) { e1 = std::max(e1, h[2 * i]); e2 = std::max(e2, h[2 * i + 1]); }
+    printf("v_rcp_f64 + 1 Newton step: max rel err %.3e (%.2f ulp);  + 2 steps: %.3e\n", e1, e1 / 1.11e-16, e2);
+  }
   const int64_t n = argc > 1 ? atoll(argv[1]) : 5000;
   std::mt19937_64 rng(1);
   std::normal_distribution<double> nd;
@@ -48,6 +68,7 @@ int main(int argc, char** argv) {
     unsigned long long hs[64];
     hipMemcpyFromSymbol(hs, HIP_SYMBOL(d64_stamps), sizeof(hs));
     printf("\n  head1 phases (us): load %.1f  chol+inv %.1f  write %.1f\n", (hs[1] - hs[0]) / 100.0, (hs[2] - hs[1]) / 100.0, (hs[3] - hs[2]) / 100.0);
+    printf("  chol64_lds inside head1 (us): panels + updates %.1f  inverse %.1f\n", (hs[20] - hs[1]) / 100.0, (hs[21] - hs[20]) / 100.0);
     printf("  head2 phases (us): load %.1f  chol+inv %.1f  products %.1f  gauss-jordan %.1f  write %.1f\n", (hs[8] - hs[7]) / 100.0,
            (hs[9] - hs[8]) / 100.0, (hs[10] - hs[9]) / 100.0, (hs[11] - hs[10]) / 100.0, (hs[12] - hs[11]) / 100.0);
   }
@@ -76,7 +97,27 @@ int main(int argc, char** argv) {
     }
     printf("checks: |M + M' - M'(V'V)M| %.2e   |H'P below the triangle| %.2e   |top - R| %.2e\n", err, below, top);
   }
+  {
+    // head1 on its own: R1'R1 = P'P and R1inv R1 = I
+    int G = launch_gram_slices(st, P, n, P, n, 64, n, part2, 128);
+    launch_gram_reduce(st, part2, G, G1, 64);
+    launch_cholqr_head1(st, G1, 1, R1, R1inv, flags);
+    hipStreamSynchronize(st);
+    std::vector<double> g(4096), r1(4096), ri(4096);
+    hipMemcpy(g.data(), G1, 4096 * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(r1.data(), R1, 4096 * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(ri.data(), R1inv, 4096 * 8, hipMemcpyDeviceToHost);
+    double e1 = 0, e2 = 0, gmax = 0, low = 0;
+    for (int a = 0; a < 64; ++a) for (int b2 = 0; b2 < 64; ++b2) {
+      double s1 = 0, s2 = 0;
+      for (int k = 0; k < 64; ++k) { s1 += r1[k + 64 * a] * r1[k + 64 * b2]; s2 += ri[a + 64 * k] * r1[k + 64 * b2]; }
+      e1 = std::max(e1, std::abs(s1 - g[a + 64 * b2])); gmax = std::max(gmax, std::abs(g[a + 64 * b2]));
+      e2 = std::max(e2, std::abs(s2 - (a == b2 ? 1.0 : 0.0)));
+      if (a > b2) low = std::max(low, std::max(std::abs(r1[a + 64 * b2]), std::abs(ri[a + 64 * b2])));
+    }
+    printf("head1: |R1'R1 - G| / |G| %.2e   |R1inv R1 - I| %.2e   below the diagonal %.2e\n", e1 / gmax, e2, low);
+  }
   PanelFlags hf; hipMemcpy(&hf, flags, sizeof(hf), hipMemcpyDeviceToHost);
-  printf("flags: bad %d panels %d\n", hf.bad, hf.panels);
+  printf("flags: bad %d panels %d series %d\n", hf.bad, hf.panels, hf.series);
   return 0;
 }
