@@ -19,7 +19,8 @@ constexpr int D64_MAX_SLICES = 40;         // partial Gram matrices a head kerne
 // that is far from orthonormal (the panel is numerically rank deficient: the caller redoes the reduction with
 // Householder panels); flags[1] counts the panels done.
 // flags[2] counts the panels whose second Cholesky factor came from the series around the identity (cholqr_head2_kernel).
-struct PanelFlags { int bad; int panels; int series; };
+// flags[3]: ... of those, the panels whose |E| was so small (<= 2^-33) that R2 = I + Phi(E), R2^-1 = I - Phi(E) needed no product.
+struct PanelFlags { int bad; int panels; int series; int tiny; };
 
 // part[g] (64 x 64 column-major each) = A[rows of slice g]' B[rows of slice g], g < *G_out slices of `rows_per` rows;
 // A [n x 64] (ld lda), B [n x kb] (ld ldb), kb <= 64.  Returns the slice count the launch used.

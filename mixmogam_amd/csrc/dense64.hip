@@ -279,8 +279,8 @@ __device__ __forceinline__ double lane_val64(double v, int lane) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
 }
-// one Newton step on v_rcp_f64 (its seed carries ~26 bits: LLVM's own f64 division takes two steps and a residual fix-up to round
-// correctly; one leaves <= ~2 ulp, measured by tools/probe/head_probe.hip) -- the reciprocal sits on the dependent chain of a panel
+// one Newton step on v_rcp_f64: up to 20 ulp off (2.2e-15, measured by tools/probe/head_probe.hip) -- NOT used by the panels: with
+// the two-step rcp_f64 they take the same 13 us (a panel step is bound by its ~45 v_readlane / v_fma issues, not by the chain)
 __device__ __forceinline__ double rcp1_f64(double p) {
   const double r = __builtin_amdgcn_rcp(p);
   return fma(r, fma(-p, r, 1.0), r);
@@ -388,7 +388,7 @@ __device__ __forceinline__ int chol64_lds(double* __restrict__ As, double* __res
       for (int m = 0; m < 16; ++m) a[m] = As[l * LD + c0 + m];
       double p = lane_val64(a[0], c0);
       if (!(p > 0.0 && p < 1e300)) { bad = c0 + 1; p = 1.0; }
-      double rp = rcp1_f64(p);
+      double rp = rcp_f64(p);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int jg = c0 + j;
@@ -399,7 +399,7 @@ __device__ __forceinline__ int chol64_lds(double* __restrict__ As, double* __res
           const double u = lane_val64(a[j], jg + 1);
           pn = fma(-(u * rp), u, lane_val64(a[j + 1], jg + 1));
           if (!(pn > 0.0 && pn < 1e300)) { if (!bad) bad = jg + 2; pn = 1.0; }
-          rpn = rcp1_f64(pn);
+          rpn = rcp_f64(pn);
         }
         const double f = l > jg ? a[j] * rp : 0.0;
 #pragma unroll
@@ -449,7 +449,7 @@ __device__ __forceinline__ void lu64_signed_lds(double* __restrict__ Bq, double*
 #pragma unroll
       for (int m = 0; m < 16; ++m) a[m] = Bq[l * LD + c0 + m];
       double d = lane_val64(a[0], c0);
-      double sn = d >= 0.0 ? -1.0 : 1.0, p = d - sn, rp = rcp1_f64(p);
+      double sn = d >= 0.0 ? -1.0 : 1.0, p = d - sn, rp = rcp_f64(p);
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int jg = c0 + j;
@@ -459,7 +459,7 @@ __device__ __forceinline__ void lu64_signed_lds(double* __restrict__ Bq, double*
           const double dn = fma(-(lane_val64(a[j], jg + 1) * rp), lane_val64(a[j + 1], jg), lane_val64(a[j + 1], jg + 1));
           snn = dn >= 0.0 ? -1.0 : 1.0;
           pn = dn - snn;
-          rpn = rcp1_f64(pn);
+          rpn = rcp_f64(pn);
         }
         const double f = l > jg ? a[j] * rp : 0.0;
 #pragma unroll
@@ -477,12 +477,12 @@ __device__ __forceinline__ void lu64_signed_lds(double* __restrict__ Bq, double*
 #pragma unroll
       for (int r = 0; r < 16; ++r) t[r] = Bq[(c0 + r) * LD + l];
       double d = lane_val64(t[0], c0);
-      double sn = d >= 0.0 ? -1.0 : 1.0, p = d - sn, rp = rcp1_f64(p);
+      double sn = d >= 0.0 ? -1.0 : 1.0, p = d - sn, rp = rcp_f64(p);
 #pragma unroll
       for (int j = 0; j < 15; ++j) {
         const int jg = c0 + j;
         const double dn = fma(-(lane_val64(t[j + 1], jg) * rp), lane_val64(t[j], jg + 1), lane_val64(t[j + 1], jg + 1));
-        const double snn = dn >= 0.0 ? -1.0 : 1.0, pn = dn - snn, rpn = rcp1_f64(pn);
+        const double snn = dn >= 0.0 ? -1.0 : 1.0, pn = dn - snn, rpn = rcp_f64(pn);
 #pragma unroll
         for (int r = j + 1; r < 16; ++r) t[r] = fma(-(lane_val64(t[r], jg) * rp), t[j], t[r]);   // multiplier of row c0 + r, uniform
         p = pn; rp = rpn; sn = snn;
@@ -578,6 +578,7 @@ void launch_rows_gemm(hipStream_t st, const double* X, int64_t ldx, double* Y, i
                      (const double*)nullptr, (int64_t)0, (const double*)nullptr, Y, ldy, n, (double*)nullptr, (int64_t)0,
                      (const double*)nullptr, 0, cf_transposed ? 1 : 0);
 }
+
 
 void launch_band_y(hipStream_t st, const double* V, const double* W, int64_t n, const double* T, const double* C, double* Y,
                    double* Z, int64_t ldz, const double* Cz, int q1) {
@@ -916,7 +917,25 @@ __global__ __launch_bounds__(256) void cholqr_head2_kernel(const double* __restr
   big = __syncthreads_or(big);                                 // (also orders the B2 / B3 fills above before their readers)
   int bad = 0;
   static_assert(sizeof(v4d) == 32, "v4d");
-  if (!big) {
+  int nottiny = 0;                                             // |E| <= 2^-33: |E|_2^2 <= (64 * 2^-33)^2 = 6e-17 -- the first-order factor is exact
+#pragma unroll
+  for (int m = 0; m < 16; ++m)
+    if (!(fabs(a[m] - (16 * kq + m == i ? 1.0 : 0.0)) <= 0x1p-33)) nottiny = 1;
+#ifdef MMG_HEAD2_NO_SERIES
+  nottiny = 1;
+#endif
+  nottiny = __syncthreads_or(nottiny);
+  if (!nottiny) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int k = 16 * kq + m;
+      const double e = a[m] - (k == i ? 1.0 : 0.0);
+      const double u = k > i ? e : (k == i ? 0.5 * e : 0.0);
+      B0[i * LD + k] = (k == i ? 1.0 : 0.0) + u;               // R2 = I + Phi(E)
+      B1[i * LD + k] = (k == i ? 1.0 : 0.0) - u;               // R2^-1 = I - Phi(E)  (+ O(|E|^2))
+    }
+    if (tid == 0) { flags->series += 1; flags->tiny += 1; }
+  } else if (!big) {
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
       const int k = 16 * kq + m;

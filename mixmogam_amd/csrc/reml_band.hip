@@ -896,8 +896,8 @@ static int band_reduce_cqr(mmg_ctx* ctx, mmg_reml* r, bool* suspect) {
   RC_HIP(ctx, hipMemcpyAsync(&hf, flags, sizeof(hf), hipMemcpyDeviceToHost, st));
   RC_HIP(ctx, hipStreamSynchronize(st));
   if (verbose)
-    fprintf(stderr, "[reml] N=%lld: band reduction (Cholesky-QR panels, %d of them%s) %.3f s: panel %.3f, A22 V %.3f, coefficients + Y %.3f, rank-2b update %.3f\n",
-            (long long)N, hf.panels, hf.bad ? "; a panel was rank deficient -> Householder panels" : "",
+    fprintf(stderr, "[reml] N=%lld: band reduction (Cholesky-QR panels, %d of them, second factor by series %d, first order %d%s) %.3f s: panel %.3f, A22 V %.3f, coefficients + Y %.3f, rank-2b update %.3f\n",
+            (long long)N, hf.panels, hf.series, hf.tiny, hf.bad ? "; a panel was rank deficient -> Householder panels" : "",
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(), tsec[0], tsec[1], tsec[2], tsec[3]);
   *suspect = hf.bad != 0;
   r->band_k0 = k0;                                            // band_reduce_hh finishes the short panels from here

@@ -118,6 +118,6 @@ int main(int argc, char** argv) {
     printf("head1: |R1'R1 - G| / |G| %.2e   |R1inv R1 - I| %.2e   below the diagonal %.2e\n", e1 / gmax, e2, low);
   }
   PanelFlags hf; hipMemcpy(&hf, flags, sizeof(hf), hipMemcpyDeviceToHost);
-  printf("flags: bad %d panels %d series %d\n", hf.bad, hf.panels, hf.series);
+  printf("flags: bad %d panels %d series %d tiny %d\n", hf.bad, hf.panels, hf.series, hf.tiny);
   return 0;
 }
