@@ -766,6 +766,41 @@ int mmg_kinship_ibs_diploid_f64(mmg_ctx* ctx, mmg_geno* g, int32_t scaled, doubl
   const int64_t N = g->N;
   int64_t *c1 = nullptr, *c2 = nullptr;
   double* dK = nullptr;
+  // Round 6: both indicator images from one read of the store, stacked into ONE 2 M-row FP4 image, so that c12 = u'u + v'v is a
+  // single launch of the FP4 kinship GEMM (twice the contraction length of a binary store's) instead of two image passes, two
+  // GEMMs, two mirrors and two N^2 copies.  MMG_IBS_DIPLOID_FUSED=0 / a range the fp32 accumulators cannot hold: the two calls.
+  static const bool fused_off = [] { const char* e = std::getenv("MMG_IBS_DIPLOID_FUSED"); return e && e[0] == '0'; }();
+  static const bool fp4_off_d = [] { const char* e = std::getenv("MMG_KIN_FP4"); return e && e[0] == '0'; }();
+  if (!fused_off && !fp4_off_d && g->sneg == 0 && g->smax <= 2) {
+    Scratch sf;                                               // (freed when this attempt ends, whichever way)
+    uint8_t* X4 = nullptr;
+    int* C32 = nullptr;
+    const int64_t ld4 = g->Npad / 2;
+    if (sf.alloc(&X4, (size_t)2 * g->Mpad * ld4) == hipSuccess && sf.alloc(&C32, (size_t)g->Npad * g->Npad * sizeof(int)) == hipSuccess &&
+        sf.alloc(&c1, (size_t)N * N * sizeof(int64_t)) == hipSuccess && sf.alloc(&dK, (size_t)N * N * sizeof(double)) == hipSuccess) {
+      MMG_HIP(ctx, hipMemsetAsync(C32, 0, (size_t)g->Npad * g->Npad * sizeof(int), ctx->stream));
+      {
+        EvScope ev(ctx, EV_PACK);
+        launch_pack_fp4_two(ctx, g->d, g->Mpad, g->Npad, X4, X4 + g->Mpad * ld4);
+      }
+      int rc = MMG_OK;
+      {
+        EvScope ev(ctx, EV_KIN);
+        rc = run_kinship_f4_tr(ctx, sf, X4, g->Npad, 2 * g->Mpad / 256, C32);
+      }
+      if (rc == MMG_OK) {
+        launch_mirror_i32_to_i64(ctx, C32, g->Npad, g->N, c1);
+        launch_ibs_diploid_combine(ctx, c1, nullptr, N, (double)g->M, dK);
+        MMG_HIP(ctx, hipGetLastError());
+        return scale_and_fetch(ctx, dK, N, scaled != 0, K_out);
+      }
+      if (rc != MMG_E_STATE) return rc;
+      MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+      (void)hipGetLastError();
+    }
+    c1 = nullptr; dK = nullptr;
+  }
   MMG_HIP(ctx, sc.alloc(&c1, (size_t)N * N * sizeof(int64_t)));
   MMG_HIP(ctx, sc.alloc(&c2, (size_t)N * N * sizeof(int64_t)));
   MMG_HIP(ctx, sc.alloc(&dK, (size_t)N * N * sizeof(double)));

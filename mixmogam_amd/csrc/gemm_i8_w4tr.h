@@ -163,7 +163,9 @@ struct W4JobTr {
 // first use of positions 0..7 is at MFMA index 0, 0, 1, 2, 4, 6, 9, 12 with r = 0, 0, 2, 2, 4, 6, 10, 12:
 // lgkmcnt(12), (12), (10), (10), (10), (12), (12).  No other lgkm operation may be issued inside the stream (scalar
 // loads return out of order): job descriptors are held in registers.
-template <class Fmt, int P0, int P1, bool ZERO>
+// ABL (timing ablations, WRONG results, instantiated by `make EXPERIMENTS=1` builds only): 1 = no LDS-DMA inside the loop, 2 = no
+// fragment reads inside the loop, 3 = neither (the MFMAs, the barrier and the waits alone).
+template <class Fmt, int P0, int P1, bool ZERO, int ABL = 0>
 __device__ __forceinline__ void w4tr_slice(typename Fmt::Acc (&acc)[4][4], Frag4& cur, Frag4& nxt, const char* src,
                                            const int (&ab)[4], const int (&bb)[4], int slice,
                                            const typename Fmt::Stage& sp, const typename Fmt::Stage& sq, char* dst,
@@ -184,8 +186,10 @@ __device__ __forceinline__ void w4tr_slice(typename Fmt::Acc (&acc)[4][4], Frag4
     // the asm statements keep their order among themselves, but the MFMAs (no side effects) are free to sink below
     // them -- the scheduler bunched all 16 at the end of the slice: pin the source order MFMA / reads / MFMA / DMA
     __builtin_amdgcn_sched_barrier(0);
-    if ((i & 1) == 0) Fmt::frag(nxt.a[i >> 1], s32 + (uint32_t)ab[i >> 1], slice);
-    else Fmt::frag(nxt.b[i >> 1], s32 + (uint32_t)bb[i >> 1], slice);
+    if (ABL != 2 && ABL != 3) {
+      if ((i & 1) == 0) Fmt::frag(nxt.a[i >> 1], s32 + (uint32_t)ab[i >> 1], slice);
+      else Fmt::frag(nxt.b[i >> 1], s32 + (uint32_t)bb[i >> 1], slice);
+    }
     if (i == 0) frag_wait<12>(cur.a[1]);                 // MFMA 1: a1 b0
     if (i == 4) frag_wait<12>(cur.a[3]);                 // MFMA 9: a3 b0
     if (ZERO) acc[m1][n1] = Fmt::mma(cur.a[m1], cur.b[n1], Fmt::zero());
@@ -194,7 +198,7 @@ __device__ __forceinline__ void w4tr_slice(typename Fmt::Acc (&acc)[4][4], Frag4
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int pc = P0 + PER * i + u;
-      if (pc < P1) {
+      if (pc < P1 && ABL != 1 && ABL != 3) {
         if (pc < 8) Fmt::piece(sp, dst, wave, pc);
         else Fmt::piece(sq, dst + TILE_BYTES, wave, pc - 8);
       }
@@ -216,7 +220,7 @@ __device__ __forceinline__ void w4tr_slice(typename Fmt::Acc (&acc)[4][4], Frag4
 // DMA of that stage is issued, so the DMA finds its lines in L2.  Same-job stages only.
 constexpr int W4TR_PF_LDS = 1024;
 
-template <int N3 = 8, int PFD = 0, class Fmt = FmtI8, class JobFn, class PreFn, class EpiFn>
+template <int N3 = 8, int PFD = 0, class Fmt = FmtI8, int ABL = 0, class JobFn, class PreFn, class EpiFn>
 __device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* lds, JobFn&& job, PreFn&& pre, EpiFn&& epi) {
   static_assert(N3 >= 8 && N3 <= 16, "N3");
   static_assert(PFD == 0 || Fmt::KROWS == 128, "the L2 prefetch is written for the int8 image");
@@ -298,16 +302,16 @@ __device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* ld
   auto step = [&](bool first) {
     char* cur = lds + (t & 1) * BUF_BYTES;
     char* oth = lds + ((t + 1) & 1) * BUF_BYTES;
-    if (first) w4tr_slice<Fmt, N3, 16, true>(acc, f0, f1, cur, ab, bb, 1, sp, sq, oth, wave);
-    else w4tr_slice<Fmt, N3, 16, false>(acc, f0, f1, cur, ab, bb, 1, sp, sq, oth, wave);
-    w4tr_slice<Fmt, 16, 16, false>(acc, f1, f0, cur, ab, bb, 2, sp, sq, oth, wave);
-    w4tr_slice<Fmt, 16, 16, false>(acc, f0, f1, cur, ab, bb, 3, sp, sq, oth, wave);
+    if (first) w4tr_slice<Fmt, N3, 16, true, ABL>(acc, f0, f1, cur, ab, bb, 1, sp, sq, oth, wave);
+    else w4tr_slice<Fmt, N3, 16, false, ABL>(acc, f0, f1, cur, ab, bb, 1, sp, sq, oth, wave);
+    w4tr_slice<Fmt, 16, 16, false, ABL>(acc, f1, f0, cur, ab, bb, 2, sp, sq, oth, wave);
+    w4tr_slice<Fmt, 16, 16, false, ABL>(acc, f0, f1, cur, ab, bb, 3, sp, sq, oth, wave);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     advance();                                           // -> stage t+2
     prefetch();                                          // lines of stage t+2+PFD -> L2
-    w4tr_slice<Fmt, 0, N3, false>(acc, f1, f0, oth, ab, bb, 0, sp, sq, cur, wave);
+    w4tr_slice<Fmt, 0, N3, false, ABL>(acc, f1, f0, oth, ab, bb, 0, sp, sq, cur, wave);
     ++t;
   };
   for (int jj = j0; jj < j1; ++jj) {

@@ -228,6 +228,9 @@ __global__ __launch_bounds__(W4_THREADS) void kinship_grm4r_kernel(const int8_t*
 // every LDS fill carries half the bytes -- both bounds of the int8 kernel move.  X4: the FP4 image
 // (pack_fp4_kernel), row stride ld4 = Npad / 2; a K step is 256 SNP rows.  The fp32 accumulators of a job hold exact
 // counts (< 2^24: the host bounds the K range per job).
+// ABL: 0 = production; 1-3: the stream's timing ablations (gemm_i8_w4tr.h), 4 = the epilogue writes nothing -- WRONG results, `make
+// EXPERIMENTS=1` builds only (MMG_F4_ABL; tools/kin_sweep.py --abl).
+template <int ABL = 0>
 __global__ __launch_bounds__(W4_THREADS) void kinship_f4_tr_kernel(const int8_t* __restrict__ X4, int64_t ld4,
                                                                    int32_t Npad, const KinJob* __restrict__ jobs,
                                                                    int* __restrict__ C32) {
@@ -239,9 +242,20 @@ __global__ __launch_bounds__(W4_THREADS) void kinship_f4_tr_kernel(const int8_t*
   const int8_t* P = X4 + (int64_t)job.ks0 * FmtF4::KROWS * ld4 + (int64_t)job.I * (TM / 2);
   const int8_t* Q = X4 + (int64_t)job.ks0 * FmtF4::KROWS * ld4 + (int64_t)job.J * (TN / 2);
   const int nks = job.ks1 - job.ks0;
-  w4tr_stream<8, 0, FmtF4>(
+  w4tr_stream<8, 0, FmtF4, (ABL >= 1 && ABL <= 3) ? ABL : 0>(
       0, 1, ld4, lds, [&](int) { return W4JobTr{P, Q, nks}; }, [](int) {},
       [&](int, v16f (&acc)[4][4]) {
+        if (ABL == 4) {                                        // one atomic per lane instead of 256: the accumulators stay live
+          float t = 0.f;
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+              for (int i = 0; i < 16; ++i) t += acc[m][n][i];
+          atomicAdd(C32 + (int64_t)(job.I * TM + wm * 128 + r) * Npad + job.J * TN + wn * 128 + h, (int)t);
+          return;
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -406,8 +420,8 @@ __global__ void ibs_diploid_combine_kernel(const int64_t* __restrict__ c1, const
   if (e >= N * N) return;
   const int64_t i = e / N, j = e - i * N;
   if (i == j) { K[e] = 1.0; return; }
-  const double c12 = (double)(c1[e] + c2[e]);
-  const double ri = (double)(c1[i * N + i] + c2[i * N + i]), rj = (double)(c1[j * N + j] + c2[j * N + j]);
+  const double c12 = (double)(c1[e] + (c2 ? c2[e] : 0));
+  const double ri = (double)(c1[i * N + i] + (c2 ? c2[i * N + i] : 0)), rj = (double)(c1[j * N + j] + (c2 ? c2[j * N + j] : 0));
   const double absdiff = ri + rj - 2.0 * c12;
   K[e] = (M - 0.5 * absdiff) / M;
 }
@@ -576,15 +590,27 @@ int run_kinship_i8_tr(mmg_ctx* ctx, const int8_t* Sp, const int8_t* Sq, int64_t 
 // fp32 accumulators (caller takes the int8 kernel).
 int run_kinship_f4_tr(mmg_ctx* ctx, Scratch& sc, const uint8_t* X4, int32_t Npad, int64_t nk4, int* C32) {
   const int nT = Npad / TM;
-  const int ksplit = choose_ksplit(nT * (nT + 1) / 2, (int)nk4, 4, 64);
+  int ksplit = choose_ksplit(nT * (nT + 1) / 2, (int)nk4, 4, 64);
+  if (const char* e = std::getenv("MMG_KIN_KSPLIT")) ksplit = std::max(1, std::min((int)nk4, std::atoi(e)));   // A/B runs (tools/kin_sweep.sh)
   if ((nk4 + ksplit - 1) / ksplit * FmtF4::KROWS >= (int64_t(1) << 24)) return MMG_E_STATE;
   std::vector<KinJob> jobs = build_jobs(nT, (int)nk4, ksplit);
   KinJob* djobs = nullptr;
   MMG_HIP(ctx, sc.alloc(&djobs, jobs.size() * sizeof(KinJob)));
   MMG_HIP(ctx, hipMemcpy(djobs, jobs.data(), jobs.size() * sizeof(KinJob), hipMemcpyHostToDevice));   // `jobs` dies with this call
-  MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_f4_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-  hipLaunchKernelGGL(kinship_f4_tr_kernel, dim3((unsigned)jobs.size()), dim3(W4_THREADS), LDS_BYTES, ctx->stream,
-                     (const int8_t*)X4, (int64_t)(Npad / 2), Npad, djobs, C32);
+#define MMG_LAUNCH_F4(ABL_)                                                                                                              \
+  do {                                                                                                                                   \
+    MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_f4_tr_kernel<ABL_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); \
+    hipLaunchKernelGGL(kinship_f4_tr_kernel<ABL_>, dim3((unsigned)jobs.size()), dim3(W4_THREADS), LDS_BYTES, ctx->stream,              \
+                       (const int8_t*)X4, (int64_t)(Npad / 2), Npad, djobs, C32);                                                       \
+  } while (0)
+  int abl = 0;
+#ifdef MMG_EXPERIMENTS
+  if (const char* e = std::getenv("MMG_F4_ABL")) abl = std::atoi(e);
+  if (abl == 1) MMG_LAUNCH_F4(1); else if (abl == 2) MMG_LAUNCH_F4(2); else if (abl == 3) MMG_LAUNCH_F4(3); else if (abl == 4) MMG_LAUNCH_F4(4); else
+#endif
+  MMG_LAUNCH_F4(0);
+  (void)abl;
+#undef MMG_LAUNCH_F4
   MMG_HIP(ctx, hipGetLastError());
   return MMG_OK;
 }

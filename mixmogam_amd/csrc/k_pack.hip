@@ -337,6 +337,45 @@ __global__ __launch_bounds__(256) void pack_fp4_kernel(const int8_t* __restrict_
   *(uint4*)(X4 + r * (int64_t)(Npad >> 1) + c * 16) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// Both indicator images of a 0/1/2 store from ONE read of it (round 6): X4a = [s >= 1], X4b = [s >= 2] -- the two operands of the
+// 'diploid_int' IBS kinship (kinship.py:33-41), stacked by the caller into one 2 M-row image so that u'u + v'v is ONE GEMM.
+__global__ __launch_bounds__(256) void pack_fp4_two_kernel(const int8_t* __restrict__ S, int64_t rows, int32_t Npad,
+                                                           uint8_t* __restrict__ X4a, uint8_t* __restrict__ X4b) {
+  const int nchunk = Npad >> 5;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= rows * nchunk) return;
+  const int64_t r = gid / nchunk;
+  const int c = (int)(gid % nchunk);
+  const uint4* src = (const uint4*)(S + r * (int64_t)Npad + c * 32);
+  const uint4 a = src[0], b = src[1];
+  const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int img = 0; img < 2; ++img) {
+    uint32_t x[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v |= ((int)(int8_t)((w[q] >> (8 * j)) & 0xff) >= 1 + img ? 1u : 0u) << (8 * j);
+      x[q] = v;
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t lo = x[2 * q], hi = x[2 * q + 1];
+      const uint32_t l4 = (lo | (lo >> 4)) & 0x00110011u, h4 = (hi | (hi >> 4)) & 0x00110011u;
+      const uint32_t l2 = (l4 | (l4 >> 8)) & 0x0000ffffu, h2 = (h4 | (h4 >> 8)) & 0x0000ffffu;
+      o[q] = ((l2 & 0x1111u) | ((h2 & 0x1111u) << 16)) << 1;
+    }
+    *(uint4*)((img ? X4b : X4a) + r * (int64_t)(Npad >> 1) + c * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+void launch_pack_fp4_two(mmg_ctx* ctx, const int8_t* S, int64_t rows, int32_t Npad, uint8_t* X4a, uint8_t* X4b) {
+  const int64_t total = rows * (Npad >> 5);
+  if (total <= 0) return;
+  hipLaunchKernelGGL(pack_fp4_two_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, S, rows, Npad, X4a, X4b);
+}
+
 // binary: every stored value is 0 or 1 and thr == 1 (the bytes are the indicator already)
 void launch_pack_fp4_on(mmg_ctx* ctx, hipStream_t stream, const int8_t* S, int64_t rows, int32_t Npad, uint8_t* X4,
                         int thr, bool binary) {

@@ -247,7 +247,8 @@ int run_kinship_f32(mmg_ctx*, const int8_t* Xt, int32_t Npad, int64_t Mk, const 
 void launch_reduce_slabs(mmg_ctx*, const float* slabs, int ksplit, int32_t Npad, int32_t N, double* C, int accumulate);
 void launch_mirror_i32_to_i64(mmg_ctx*, const int* C32, int32_t Npad, int32_t N, int64_t* C);
 void launch_ibs_counts_to_f64(mmg_ctx*, const int64_t* C, int64_t n, double two_m, double* K);
-void launch_ibs_diploid_combine(mmg_ctx*, const int64_t* c1, const int64_t* c2, int64_t N, double M, double* K);
+void launch_ibs_diploid_combine(mmg_ctx*, const int64_t* c1, const int64_t* c2, int64_t N, double M, double* K);   // c2 may be nullptr: c1 is the sum
+void launch_pack_fp4_two(mmg_ctx*, const int8_t* S, int64_t rows, int32_t Npad, uint8_t* X4a, uint8_t* X4b);
 
 // ---- k_scan.hip
 void launch_absmax_offdiag(mmg_ctx*, const double* A, int32_t N, unsigned long long* out_bits);

@@ -259,3 +259,29 @@ def test_reml_estimates_result_holds_no_device_workspace(ctx):
     lmm = lm.LinearMixedModel(list(case["y"]), ctx=ctx)
     lmm.add_random_effect(case["dbl_ibs_scaled"])
     assert rel(lmm.get_REML()["delta"], case["dbl_reml_delta"]) < 1e-7     # the eigen route's 100-point search agrees
+
+
+# ------------------------------------------------------------------ 0/1/2 stores: the stacked single-GEMM IBS route
+@pytest.mark.parametrize("n,m", [(2100, 3000), (2305, 1111)])
+def test_diploid_ibs_device_route_is_one_stacked_gemm_and_bit_exact(ctx, n, m):
+    """calc_ibs_kinship('diploid_int') above 2048 individuals runs in HBM (mmg_kinship_ibs_diploid_f64); round 6: both indicator
+    images [s >= 1], [s >= 2] from one read of the store, stacked into one 2 M-row FP4 image, ONE GEMM.  Exact counts, so the
+    unscaled kinship equals kinship.py:33-41's expression bit for bit (integers / M); the scaled one follows scale_k's rule."""
+    from mixmogam_amd import kinship
+    rng = np.random.RandomState(n + m)
+    f = rng.uniform(0.05, 0.95, size=(m, 1))
+    dip = ((rng.random_sample((m, n)) < f).astype(np.int8) + (rng.random_sample((m, n)) < f).astype(np.int8))
+    dip[7] = 2
+    dip[8] = 0
+    u1, u2 = (dip >= 1).astype(np.float64), (dip >= 2).astype(np.float64)
+    c12 = u1.T @ u1 + u2.T @ u2                                       # exact in float64 (counts <= 2 M)
+    r = np.diag(c12)
+    want = (m - 0.5 * (r[:, None] + r[None, :] - 2.0 * c12)) / m
+    np.fill_diagonal(want, 1.0)
+    g = ctx.geno(dip)
+    got = kinship.calc_ibs_kinship(None, snps_data_format='diploid_int', scaled=False, ctx=ctx, geno=g)
+    assert np.array_equal(np.asarray(got), want)
+    assert ctx.kernel_ms("kinship") > 0 and ctx.kernel_ms("pack") > 0   # one GEMM launch, one image pass were timed
+    got_s = kinship.calc_ibs_kinship(None, snps_data_format='diploid_int', scaled=True, ctx=ctx, geno=g)
+    assert np.abs(np.asarray(got_s) - orc.scale_k(want)).max() < 1e-12
+    g.close()

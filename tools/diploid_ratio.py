@@ -36,9 +36,11 @@ for name, g in stores.items():
     grm_ms = ctx.kernel_ms("grm")
     acc.close()
     if name == "binary":
-        t_ibs = timed(lambda: ctx.kinship_ibs_counts(g))
+        t_ibs = timed(lambda: kinship.calc_ibs_kinship(None, ctx=ctx, geno=g, scaled=False))
     else:
-        t_ibs = timed(lambda: (ctx.kinship_indicator_counts(g, 1), ctx.kinship_indicator_counts(g, 2)))
+        # the device route of calc_ibs_kinship('diploid_int') (mmg_kinship_ibs_diploid_f64; round 6: one stacked FP4 GEMM) against
+        # the binary store's counts call; MMG_IBS_DIPLOID_FUSED=0: the two indicator products of round 5
+        t_ibs = timed(lambda: kinship.calc_ibs_kinship(None, snps_data_format='diploid_int', ctx=ctx, geno=g, scaled=False))
     K = kinship.calc_ibs_kinship(None, ctx=ctx, geno=g) if name == "binary" else kinship.calc_ibs_kinship(None, snps_data_format='diploid_int', ctx=ctx, geno=g)
     lmm = lm.LinearMixedModel(list(y), ctx=ctx)
     lmm.add_random_effect(K)
