@@ -223,7 +223,7 @@ constexpr int W4TR_PF_LDS = 1024;
 template <int N3 = 8, int PFD = 0, class Fmt = FmtI8, int ABL = 0, class JobFn, class PreFn, class EpiFn>
 __device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* lds, JobFn&& job, PreFn&& pre, EpiFn&& epi) {
   static_assert(N3 >= 8 && N3 <= 16, "N3");
-  static_assert(PFD == 0 || Fmt::KROWS == 128, "the L2 prefetch is written for the int8 image");
+  static_assert(PFD == 0 || Fmt::KROWS == 128 || Fmt::KROWS == 256, "the L2 prefetch knows the int8 and the FP4 stage shapes");
   if (j1 <= j0) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -248,7 +248,8 @@ __device__ __forceinline__ void w4tr_stream(int j0, int j1, int64_t ld, char* ld
     sq.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(cjb.Q + cks * kstep_bytes), 0, 0x7fffffff, 0x00020000);
   };
   // one 128-byte line per lane: lane l -> k row wave*32 + (l >> 1) of the stage, line (l & 1) of the 256-byte window
-  const int pf_off = (wave * 32 + (lane >> 1)) * (int)ld + (lane & 1) * 128;
+  // (FP4 image: a stage is 256 k rows of one 128-byte line each: lane l -> k row wave * 64 + l)
+  const int pf_off = Fmt::KROWS == 128 ? (wave * 32 + (lane >> 1)) * (int)ld + (lane & 1) * 128 : (wave * 64 + lane) * (int)ld;
   auto prefetch = [&]() {
     if (PFD > 0 && cks + PFD < cnks) {
       char* scratch = lds + LDS_BYTES + wave * 256;

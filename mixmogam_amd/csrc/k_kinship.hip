@@ -230,7 +230,7 @@ __global__ __launch_bounds__(W4_THREADS) void kinship_grm4r_kernel(const int8_t*
 // counts (< 2^24: the host bounds the K range per job).
 // ABL: 0 = production; 1-3: the stream's timing ablations (gemm_i8_w4tr.h), 4 = the epilogue writes nothing -- WRONG results, `make
 // EXPERIMENTS=1` builds only (MMG_F4_ABL; tools/kin_sweep.py --abl).
-template <int ABL = 0>
+template <int ABL = 0, int N3 = 8, int PFD = 0>
 __global__ __launch_bounds__(W4_THREADS) void kinship_f4_tr_kernel(const int8_t* __restrict__ X4, int64_t ld4,
                                                                    int32_t Npad, const KinJob* __restrict__ jobs,
                                                                    int* __restrict__ C32) {
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(W4_THREADS) void kinship_f4_tr_kernel(const int8_t*
   const int8_t* P = X4 + (int64_t)job.ks0 * FmtF4::KROWS * ld4 + (int64_t)job.I * (TM / 2);
   const int8_t* Q = X4 + (int64_t)job.ks0 * FmtF4::KROWS * ld4 + (int64_t)job.J * (TN / 2);
   const int nks = job.ks1 - job.ks0;
-  w4tr_stream<8, 0, FmtF4, (ABL >= 1 && ABL <= 3) ? ABL : 0>(
+  w4tr_stream<N3, PFD, FmtF4, (ABL >= 1 && ABL <= 3) ? ABL : 0>(
       0, 1, ld4, lds, [&](int) { return W4JobTr{P, Q, nks}; }, [](int) {},
       [&](int, v16f (&acc)[4][4]) {
         if (ABL == 4) {                                        // one atomic per lane instead of 256: the accumulators stay live
@@ -597,16 +597,19 @@ int run_kinship_f4_tr(mmg_ctx* ctx, Scratch& sc, const uint8_t* X4, int32_t Npad
   KinJob* djobs = nullptr;
   MMG_HIP(ctx, sc.alloc(&djobs, jobs.size() * sizeof(KinJob)));
   MMG_HIP(ctx, hipMemcpy(djobs, jobs.data(), jobs.size() * sizeof(KinJob), hipMemcpyHostToDevice));   // `jobs` dies with this call
-#define MMG_LAUNCH_F4(ABL_)                                                                                                              \
-  do {                                                                                                                                   \
-    MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_f4_tr_kernel<ABL_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); \
-    hipLaunchKernelGGL(kinship_f4_tr_kernel<ABL_>, dim3((unsigned)jobs.size()), dim3(W4_THREADS), LDS_BYTES, ctx->stream,              \
-                       (const int8_t*)X4, (int64_t)(Npad / 2), Npad, djobs, C32);                                                       \
+#define MMG_LAUNCH_F4(...)                                                                                                                      \
+  do {                                                                                                                                          \
+    const size_t lb = LDS_BYTES + W4TR_PF_LDS;                                                                                                  \
+    MMG_HIP(ctx, hipFuncSetAttribute((const void*)kinship_f4_tr_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb)); \
+    hipLaunchKernelGGL((kinship_f4_tr_kernel<__VA_ARGS__>), dim3((unsigned)jobs.size()), dim3(W4_THREADS), lb, ctx->stream,                   \
+                       (const int8_t*)X4, (int64_t)(Npad / 2), Npad, djobs, C32);                                                              \
   } while (0)
   int abl = 0;
 #ifdef MMG_EXPERIMENTS
-  if (const char* e = std::getenv("MMG_F4_ABL")) abl = std::atoi(e);
-  if (abl == 1) MMG_LAUNCH_F4(1); else if (abl == 2) MMG_LAUNCH_F4(2); else if (abl == 3) MMG_LAUNCH_F4(3); else if (abl == 4) MMG_LAUNCH_F4(4); else
+  if (const char* e = std::getenv("MMG_F4_ABL")) abl = std::atoi(e);                    // 1-4: timing ablations; 12 / 16: N3; 101 / 102: L2 prefetch distance
+  if (abl == 1) MMG_LAUNCH_F4(1); else if (abl == 2) MMG_LAUNCH_F4(2); else if (abl == 3) MMG_LAUNCH_F4(3); else if (abl == 4) MMG_LAUNCH_F4(4);
+  else if (abl == 12) MMG_LAUNCH_F4(0, 12); else if (abl == 16) MMG_LAUNCH_F4(0, 16);
+  else if (abl == 101) MMG_LAUNCH_F4(0, 8, 1); else if (abl == 102) MMG_LAUNCH_F4(0, 8, 2); else if (abl == 113) MMG_LAUNCH_F4(0, 12, 1); else
 #endif
   MMG_LAUNCH_F4(0);
   (void)abl;
