@@ -371,18 +371,22 @@ def main():
         band_rec = None
         try:
             rw = ctx.reml(K, np.ones((N, 1)), y)
-            for _ in range(2):                                 # (a second workspace: the first reduction of a process loads code)
-                rw.close()
+            runs = []
+            for _ in range(6):                                 # (the first reduction of a process loads code; best of the other five:
+                rw.close()                                     # a single reduction varies by +-0.5 ms with the clock the box holds)
                 rw = ctx.reml(K, np.ones((N, 1)), y)
                 rw.sums(np.array([1.0]), route="band")
-            bi = rw.band_info()
+                runs.append(rw.band_info())
+            bi = min(runs[1:], key=lambda v: v["seconds"])
+            bi = dict(bi, seconds_median=sorted(v["seconds"] for v in runs[1:])[2])
             rw.close()
             flop = 4.0 * N ** 3 / 3.0
             band_rec = {"kernel": "band_reduce_cqr (gram_slices / cholqr_head1|2 / rows_gemm / sym_skinny / nt_update_lower kernels)",
-                        "n": N, "seconds": bi["seconds"], "householder_fallback": bi["householder_fallback"],
+                        "n": N, "seconds": bi["seconds"], "seconds_median_of_5": bi["seconds_median"],
+                        "householder_fallback": bi["householder_fallback"],
                         "algorithmic_flop": flop, "achieved": flop / bi["seconds"] / 1e12, "peak": 78.6, "unit": "TFLOP/s",
-                        "frac": flop / bi["seconds"] / 1e12 / 78.6, "bound": "launch latency at this N (77 panels x 16 dependent "
-                        "launches; 30-33 TFLOP/s at N = 50,000, DESIGN 4.6c)"}
+                        "frac": flop / bi["seconds"] / 1e12 / 78.6, "bound": "latency at this N (77 panels x 13 dependent launches whose work is "
+                        "microseconds; 30-33 TFLOP/s at N = 50,000, DESIGN 4.4)"}
         except Exception as e:                                 # never let an extra break the line
             band_rec = {"error": str(e)}
         # the same call on the eigendecomposition route (rocSOLVER dsyevd + REML from eig_L): what round 3's default was

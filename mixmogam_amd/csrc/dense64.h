@@ -37,10 +37,20 @@ void launch_gram_reduce(hipStream_t st, const double* part, int G, double* out, 
 void launch_rows_gemm(hipStream_t st, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t n, const double* Cf,
                       bool cf_transposed = false);    // cf_transposed: Y = X Cf' 
 
+// ... and, in the same launch, the Gram matrix of every workgroup's 64 rows of Y as slice g of `gram` (ceil(n / 64) slices of 4096
+// doubles, the layout launch_gram_slices writes; their count is returned): Y'Y without a second pass over Y
+int launch_rows_gemm_gram(hipStream_t st, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t n, const double* Cf,
+                          double* gram);
+// two reductions (ld 64 outputs) in one launch
+void launch_gram_reduce2(hipStream_t st, const double* part0, const double* part1, int G, double* out0, double* out1);
+
 // Lower 64 x 64 tiles (I >= J) of the n x n matrix C (column-major, ld ldc):
 //   C[I][J] -= A0[I] B0[J]' (+ A1[I] B1[J]' when A1 != nullptr),   A*, B*: [n x 64] column-major (ld lda / ldb)
-void launch_nt_update_lower(hipStream_t st, double* C, int64_t ldc, int64_t n, const double* A0, const double* B0,
-                            const double* A1, const double* B1, int64_t lda, int64_t ldb);
+// gram_col0 != nullptr: the 64-row tiles (I >= 1, 0) also leave the Gram matrix of their updated tile as slice I - 1 there (the
+// next panel's P'P for a blocked factorisation); returns the slice count written -- 0 when the launch took the 128 x 128 tiles
+// (n >= 4096), which do not do this.
+int launch_nt_update_lower(hipStream_t st, double* C, int64_t ldc, int64_t n, const double* A0, const double* B0,
+                           const double* A1, const double* B1, int64_t lda, int64_t ldb, double* gram_col0 = nullptr);
 
 // ... the tiles (I, 0) of the first 64-column block column only
 void launch_nt_update_col0(hipStream_t st, double* C, int64_t ldc, int64_t n, const double* A0, const double* B0,

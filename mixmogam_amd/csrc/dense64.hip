@@ -509,11 +509,14 @@ __device__ __forceinline__ void lu64_signed_lds(double* __restrict__ Bq, double*
 // wave reads its 16 rows of X completely before it stores: Y may be X0.  WITHZ: the same workgroup rotates its rows of
 // [X y]:  Z[r][c] -= sum_k X0[r][k] Cz[k][c].
 constexpr int YLD = 68;
+// gram != nullptr (round 6): the workgroup also leaves the Gram matrix of ITS 64 rows of Y, Y[rows]'Y[rows], as slice blockIdx.x of
+// `gram` (the layout of gram_slices_kernel): the second pass of Cholesky-QR needs Q1'Q1 of the Q1 this kernel has just produced.
 template <bool TWO>
 __global__ __launch_bounds__(256) void rows_gemm_kernel(const double* __restrict__ X0, int64_t ld0, const double* __restrict__ C0,
                                                         const double* __restrict__ X1, int64_t ld1, const double* __restrict__ C1,
                                                         double* __restrict__ Y, int64_t ldy, int64_t n, double* __restrict__ Z,
-                                                        int64_t ldz, const double* __restrict__ Cz, int q1, int c0_transposed) {
+                                                        int64_t ldz, const double* __restrict__ Cz, int q1, int c0_transposed,
+                                                        double* __restrict__ gram) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* Cs = sm;                         // [j][k] = C0[k][j]
   double* Ts = sm + 64 * YLD;              // [j][k] = C1[k][j]
@@ -551,6 +554,29 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const double* __restrict
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) Y[r + (int64_t)(16 * jt + 4 * rr + lk) * ldy] = acc[jt][rr];
   }
+  if (!TWO && gram) {
+    __syncthreads();                                           // the coefficient image has been read by every wave
+    double* Ys = sm;                                           // [row][col] of this workgroup's 64 x 64 tile of Y, zero rows beyond n
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) Ys[(16 * w + lr) * YLD + 16 * jt + 4 * rr + lk] = rin ? acc[jt][rr] : 0.0;
+    __syncthreads();
+    v4d g[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) g[ct] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+      const double av = Ys[(4 * ks + lk) * YLD + 16 * w + lr];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) g[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Ys[(4 * ks + lk) * YLD + 16 * ct + lr], g[ct], 0, 0, 0);
+    }
+    double* o = gram + (size_t)blockIdx.x * 4096;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) o[(16 * w + 4 * rr + lk) + 64 * (16 * ct + lr)] = g[ct][rr];
+  }
   if (Z) {
     // rows of [X y]: thread (row l, columns w, w + 4, ..); X0 is not the output here
     const int64_t rz = R0 + l;
@@ -576,14 +602,37 @@ void launch_rows_gemm(hipStream_t st, const double* X, int64_t ldx, double* Y, i
   if (n <= 0) return;
   hipLaunchKernelGGL(rows_gemm_kernel<false>, dim3((unsigned)((n + 63) / 64)), dim3(256), ROWS_LDS1, st, X, ldx, Cf,
                      (const double*)nullptr, (int64_t)0, (const double*)nullptr, Y, ldy, n, (double*)nullptr, (int64_t)0,
-                     (const double*)nullptr, 0, cf_transposed ? 1 : 0);
+                     (const double*)nullptr, 0, cf_transposed ? 1 : 0, (double*)nullptr);
+}
+
+int launch_rows_gemm_gram(hipStream_t st, const double* X, int64_t ldx, double* Y, int64_t ldy, int64_t n, const double* Cf,
+                          double* gram) {
+  const int G = (int)((n + 63) / 64);
+  hipLaunchKernelGGL(rows_gemm_kernel<false>, dim3((unsigned)G), dim3(256), ROWS_LDS1, st, X, ldx, Cf, (const double*)nullptr,
+                     (int64_t)0, (const double*)nullptr, Y, ldy, n, (double*)nullptr, (int64_t)0, (const double*)nullptr, 0, 0, gram);
+  return G;
+}
+
+// out0 = sum of the G slices of part0, out1 likewise of part1 (two reductions of launch_gram_slices2's pair in one launch)
+__global__ __launch_bounds__(256) void gram_reduce2_kernel(const double* __restrict__ part0, const double* __restrict__ part1, int G,
+                                                           double* __restrict__ out0, double* __restrict__ out1) {
+  const double* __restrict__ part = blockIdx.y ? part1 : part0;
+  double* __restrict__ out = blockIdx.y ? out1 : out0;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  double s = 0.0;
+#pragma unroll 8
+  for (int g = 0; g < G; ++g) s += part[(size_t)g * 4096 + e];
+  out[e] = s;
+}
+void launch_gram_reduce2(hipStream_t st, const double* part0, const double* part1, int G, double* out0, double* out1) {
+  hipLaunchKernelGGL(gram_reduce2_kernel, dim3(16, 2), dim3(256), 0, st, part0, part1, G, out0, out1);
 }
 
 
 void launch_band_y(hipStream_t st, const double* V, const double* W, int64_t n, const double* T, const double* C, double* Y,
                    double* Z, int64_t ldz, const double* Cz, int q1) {
   hipLaunchKernelGGL(rows_gemm_kernel<true>, dim3((unsigned)((n + 63) / 64)), dim3(256), ROWS_LDS2, st, V, n, C, W, n, T, Y, n, n, Z,
-                     ldz, Cz, q1, 0);
+                     ldz, Cz, q1, 0, (double*)nullptr);
 }
 
 // ---- C[I][J] -= A0[I] B0[J]' + A1[I] B1[J]' on the lower 64 x 64 tiles ---------------------------------------------------
@@ -592,10 +641,13 @@ void launch_band_y(hipStream_t st, const double* V, const double* W, int64_t n, 
 // consecutive rows of one column of C: 128-byte segments on the only traffic that matters here (C is read and written once
 // per call; the operands are 64 KB per tile side and come out of L2).
 template <int NP>
+// gram != nullptr (round 6): the tiles (I >= 1, J = 0) -- the block column the NEXT panel of a blocked factorisation starts from --
+// also leave the Gram matrix of their updated 64 x 64 tile as slice I - 1 of `gram` (gram_slices_kernel's layout): the next
+// panel's P'P without a pass of its own over P.
 __global__ __launch_bounds__(256, 2) void nt_update_lower_kernel(double* __restrict__ C, int64_t ldc, int64_t n,
                                                                  const double* __restrict__ A0, const double* __restrict__ B0,
                                                                  const double* __restrict__ A1, const double* __restrict__ B1,
-                                                                 int64_t lda, int64_t ldb, int col0) {
+                                                                 int64_t lda, int64_t ldb, int col0, double* __restrict__ gram) {
   const int64_t t = blockIdx.x;
   int64_t I = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
   while (I * (I + 1) / 2 > t) --I;
@@ -662,6 +714,28 @@ __global__ __launch_bounds__(256, 2) void nt_update_lower_kernel(double* __restr
         const int64_t cj = J0 + 16 * jt + 4 * r + lk;
         if (cj < n) C[ci + cj * ldc] = acc[jt][r];
       }
+  }
+  if (gram && J == 0 && I >= 1) {                               // (workgroup-uniform)
+    __shared__ double Ts[64 * YLD];                            // [row][col] of the updated tile, zero rows beyond n
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ts[(16 * w + lr) * YLD + 16 * jt + 4 * r + lk] = iin ? acc[jt][r] : 0.0;
+    __syncthreads();
+    v4d g[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) g[ct] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+      const double av = Ts[(4 * ks + lk) * YLD + 16 * w + lr];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) g[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Ts[(4 * ks + lk) * YLD + 16 * ct + lr], g[ct], 0, 0, 0);
+    }
+    double* o = gram + (size_t)(I - 1) * 4096;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[(16 * w + 4 * r + lk) + 64 * (16 * ct + lr)] = g[ct][r];
   }
 }
 
@@ -751,9 +825,9 @@ __global__ __launch_bounds__(512, 1) void nt_update_lower128_kernel(double* __re
       }
 }
 
-void launch_nt_update_lower(hipStream_t st, double* C, int64_t ldc, int64_t n, const double* A0, const double* B0,
-                            const double* A1, const double* B1, int64_t lda, int64_t ldb) {
-  if (n <= 0) return;
+int launch_nt_update_lower(hipStream_t st, double* C, int64_t ldc, int64_t n, const double* A0, const double* B0,
+                           const double* A1, const double* B1, int64_t lda, int64_t ldb, double* gram_col0) {
+  if (n <= 0) return 0;
   // large trailing matrices: 128 x 128 tiles (MMG_NT_TILE=64 | 128 overrides; default 128 from n = 4096, where a launch
   // still has >= 528 workgroups)
   static const int forced = [] { const char* e = std::getenv("MMG_NT_TILE"); return e ? std::atoi(e) : 0; }();
@@ -762,12 +836,13 @@ void launch_nt_update_lower(hipStream_t st, double* C, int64_t ldc, int64_t n, c
     const dim3 grid((unsigned)(nt * (nt + 1) / 2));
     if (A1) hipLaunchKernelGGL(nt_update_lower128_kernel<2>, grid, dim3(512), 0, st, C, ldc, n, A0, B0, A1, B1, lda, ldb);
     else hipLaunchKernelGGL(nt_update_lower128_kernel<1>, grid, dim3(512), 0, st, C, ldc, n, A0, B0, A0, B0, lda, ldb);
-    return;
+    return 0;
   }
   const int64_t nt = (n + 63) / 64;
   const dim3 grid((unsigned)(nt * (nt + 1) / 2));
-  if (A1) hipLaunchKernelGGL(nt_update_lower_kernel<2>, grid, dim3(256), 0, st, C, ldc, n, A0, B0, A1, B1, lda, ldb, 0);
-  else hipLaunchKernelGGL(nt_update_lower_kernel<1>, grid, dim3(256), 0, st, C, ldc, n, A0, B0, A0, B0, lda, ldb, 0);
+  if (A1) hipLaunchKernelGGL(nt_update_lower_kernel<2>, grid, dim3(256), 0, st, C, ldc, n, A0, B0, A1, B1, lda, ldb, 0, gram_col0);
+  else hipLaunchKernelGGL(nt_update_lower_kernel<1>, grid, dim3(256), 0, st, C, ldc, n, A0, B0, A0, B0, lda, ldb, 0, gram_col0);
+  return gram_col0 ? (int)(nt - 1) : 0;                       // slices written: the 64-row tiles below the first
 }
 
 // the same update on the FIRST 64-column block column alone (tiles (I, 0), I = 0 ..): what the next panel of a blocked
@@ -776,8 +851,8 @@ void launch_nt_update_col0(hipStream_t st, double* C, int64_t ldc, int64_t n, co
                            const double* A1, const double* B1, int64_t lda, int64_t ldb) {
   if (n <= 0) return;
   const dim3 grid((unsigned)((n + 63) / 64));
-  if (A1) hipLaunchKernelGGL(nt_update_lower_kernel<2>, grid, dim3(256), 0, st, C, ldc, n, A0, B0, A1, B1, lda, ldb, 1);
-  else hipLaunchKernelGGL(nt_update_lower_kernel<1>, grid, dim3(256), 0, st, C, ldc, n, A0, B0, A0, B0, lda, ldb, 1);
+  if (A1) hipLaunchKernelGGL(nt_update_lower_kernel<2>, grid, dim3(256), 0, st, C, ldc, n, A0, B0, A1, B1, lda, ldb, 1, (double*)nullptr);
+  else hipLaunchKernelGGL(nt_update_lower_kernel<1>, grid, dim3(256), 0, st, C, ldc, n, A0, B0, A0, B0, lda, ldb, 1, (double*)nullptr);
 }
 
 // ---- Cholesky-QR heads --------------------------------------------------------------------------------------------------

@@ -811,6 +811,11 @@ static int band_reduce_cqr(mmg_ctx* ctx, mmg_reml* r, bool* suspect) {
     RC_HIP(ctx, hipEventRecord(ev_col0[1], st));               // "panel -1": the copies of K and [X y] above
     RC_HIP(ctx, hipStreamWaitEvent(sf, ev_col0[1], 0));
   }
+  // round-6 fusions, each switchable for A/B runs (tools/band_prof.py): MMG_BAND_FUSE=<bits>: 1 = Q1'Q1 slices inside rows_gemm,
+  // 2 = the two reductions of (V'W, V'Z) in one launch, 4 = the next panel's P'P slices inside the rank-2b update's first block column
+  static const int fuse_bits = [] { const char* e = std::getenv("MMG_BAND_FUSE"); return e ? std::atoi(e) : 7; }();
+  const bool fuse_gram = (fuse_bits & 1) != 0, fuse_red2 = (fuse_bits & 2) != 0, fuse_g1 = (fuse_bits & 4) != 0;
+  int g1_ready = 0;                                           // slices of the NEXT panel's P'P already in part2
   double* const Vbuf[2] = {V, V + (size_t)nmax * b};
   int64_t k0 = 0;
   int pk = 0;                                                 // panel counter (parity of the V buffer and the events)
@@ -831,11 +836,18 @@ static int band_reduce_cqr(mmg_ctx* ctx, mmg_reml* r, bool* suspect) {
     // ---- panel: V, M, R  (stream sf; behind the first block column of the update before)
     if (lookahead && pk > 0) RC_HIP(ctx, hipStreamWaitEvent(sf, ev_col0[(pk - 1) & 1], 0));
     {
-      const int G1 = launch_gram_slices(sf, P, N, P, N, b, n, part2, 128);
+      // P'P: the slices the update of the panel before left behind (g1_ready), or a pass over P
+      const int G1 = g1_ready > 0 ? g1_ready : launch_gram_slices(sf, P, N, P, N, b, n, part2, 128);
+      g1_ready = 0;
       launch_gram_reduce(sf, part2, G1, part, 64);
       launch_cholqr_head1(sf, part, 1, R1, R1inv, flags);
-      launch_rows_gemm(sf, P, N, V, n, n, R1inv);             // Q1 = P R1^-1
-      const int G2 = launch_gram_slices(sf, V, n, V, n, b, n, part2, 128);
+      // Q1 = P R1^-1 and the slices of Q1'Q1 -- in one launch while a slice per 64 rows fits the buffer (n <= 8192)
+      int G2;
+      if (fuse_gram && (n + 63) / 64 <= 128) G2 = launch_rows_gemm_gram(sf, P, N, V, n, n, R1inv, part2);
+      else {
+        launch_rows_gemm(sf, P, N, V, n, n, R1inv);
+        G2 = launch_gram_slices(sf, V, n, V, n, b, n, part2, 128);
+      }
       launch_gram_reduce(sf, part2, G2, part, 64);
       launch_cholqr_head2(sf, part, 1, R1, V, n, Mk, Cb, P, N, flags);
       launch_rows_gemm(sf, V + b, n, V + b, n, n - b, Cb);    // V[64:] = Q1[64:] (-R2^-1 S)
@@ -854,8 +866,11 @@ static int band_reduce_cqr(mmg_ctx* ctx, mmg_reml* r, bool* suspect) {
     // ---- Y = W M - 1/2 V M'(V'W) M and the rotated columns of [X y]
     {
       const int G = launch_gram_slices2(st, V, n, n, W, n, b, part2, Zs, N, q1, part2 + (size_t)128 * 4096, 128);
-      launch_gram_reduce(st, part2, G, part, 64);
-      launch_gram_reduce(st, part2 + (size_t)128 * 4096, G, partz, 64);
+      if (fuse_red2) launch_gram_reduce2(st, part2, part2 + (size_t)128 * 4096, G, part, partz);
+      else {
+        launch_gram_reduce(st, part2, G, part, 64);
+        launch_gram_reduce(st, part2 + (size_t)128 * 4096, G, partz, 64);
+      }
     }
     launch_band_coef(st, part, 1, partz, 1, q1, Mk, Cm, Cz);
     launch_band_y(st, V, W, n, Mk, Cm, Y, Zs, N, Cz, q1);
@@ -866,7 +881,10 @@ static int band_reduce_cqr(mmg_ctx* ctx, mmg_reml* r, bool* suspect) {
       RC_HIP(ctx, hipEventRecord(ev_col0[pk & 1], st));
       if (n > b) launch_nt_update_lower(st, A22 + b + b * N, N, n - b, V + b, Y + b, Y + b, V + b, n, n);
     } else {
-      launch_nt_update_lower(st, A22, N, n, V, Y, Y, V, n, n);
+      // the tiles of the first block column also write the next panel's Gram slices (part2 is free: its last readers, the
+      // reductions in front of band_coef, are behind us on this stream) -- when there is a next full panel
+      const bool next_full = n - b >= b && N - (k0 + b) - b >= 2;
+      g1_ready = launch_nt_update_lower(st, A22, N, n, V, Y, Y, V, n, n, (fuse_g1 && next_full) ? part2 : nullptr);
     }
     lap(3, tp);
   }

@@ -10,8 +10,14 @@ g = ctx.geno(M=200000, N=N)
 g.fill_hash(20240, m_global0=0, thr16=32768)
 K = kinship.scale_k(ctx.kinship_ibs_counts(g).astype(np.float64) / (2.0 * 200000) + 0.5)
 y = np.random.RandomState(1).standard_normal(N)
-for rep in range(6):
+REPS = int(os.environ.get("BAND_PROF_REPS", 6))
+ms = []
+for rep in range(REPS):
     rw = ctx.reml(K, np.ones((N, 1)), y)
     rw.sums(np.array([1.0]), route="band")
-    print("run %d: band reduction %.3f ms" % (rep, 1e3 * rw.band_info()["seconds"]), flush=True)
+    ms.append(1e3 * rw.band_info()["seconds"])
+    if REPS <= 6:
+        print("run %d: band reduction %.3f ms" % (rep, ms[-1]), flush=True)
     rw.close()
+print("N=%d, %d runs: min %.3f ms  median %.3f ms  (%s)" % (N, REPS, min(ms[1:]), sorted(ms[1:])[len(ms[1:]) // 2],
+      " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith(("MMG_BAND", "MMG_HEAD")))), flush=True)
