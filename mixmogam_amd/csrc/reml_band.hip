@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "dense64.h"
+#include "dense64_dev.h"
 #include "reml_common.h"
 
 namespace mmg {
@@ -158,6 +159,123 @@ __global__ __launch_bounds__(256) void band_factor_kernel(const double* __restri
     }
   }
   if (threadIdx.x == 0) { logdet[blockIdx.x] = log(mant) + (double)expo * 0.6931471805599453094; fail[blockIdx.x] = bad; }
+}
+
+// The same factor in 64-column BLOCKS (round 6).  With bandwidth 64 the matrix is block tridiagonal in 64 x 64 blocks whose
+// sub-diagonal blocks C_k are upper triangular, so the factorisation is
+//     L_kk = chol(S_k),   L_{k+1,k} = C_k L_kk^-T  (upper triangular again),   S_{k+1} = A_{k+1} + delta I - L_{k+1,k} L_{k+1,k}',
+// i.e. per 64 columns one blocked 64 x 64 Cholesky with its inverse (dense64_dev.h:chol64_lds: 8 barriers) and two
+// triangular 64^3 products as 16 x 16 block products on the matrix pipe -- against 64 steps of LDS write -> barrier -> read.
+// Same output layout (band of L per column, 1 / l_jj at d = 65, log-determinant, first bad pivot).
+constexpr int BFAC_LDS = (4 * 64 * LD + 64 + 8) * (int)sizeof(double);
+__global__ __launch_bounds__(256) void band_factor_blk_kernel(const double* __restrict__ Bc, int N, const double* __restrict__ deltas,
+                                                              double* __restrict__ Lall, double* __restrict__ logdet,
+                                                              int* __restrict__ fail) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double *As = sm, *Fs = sm + 64 * LD, *Xs = sm + 2 * 64 * LD, *T1 = sm + 3 * 64 * LD, *rs = sm + 4 * 64 * LD;
+  int* sh = (int*)(rs + 64);
+  const int tid = threadIdx.x, i = tid & 63, kq = tid >> 6;
+  const int w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+  const double delta = deltas[blockIdx.x];
+  double* Lc = Lall + (size_t)blockIdx.x * N * BAND_LD;
+  const v4d zero = {0.0, 0.0, 0.0, 0.0};
+  // thread (i, kq): entries (row i, columns 16 kq + m) of a block.  Diagonal block k: A[64k + i][64k + c] for i >= c (identity
+  // beyond N); sub-diagonal block k: C[i][c] = A[64(k+1) + i][64k + c] for c >= i.
+  auto diag_at = [&](int k, int c) -> double {
+    const int col = 64 * k + c, d = i - c;
+    if (d < 0) return 0.0;
+    if (64 * k + i >= N) return d == 0 ? 1.0 : 0.0;
+    return Bc[(size_t)col * BAND_LD + d] + (d == 0 ? delta : 0.0);
+  };
+  auto sub_at = [&](int k, int c) -> double {
+    const int col = 64 * k + c, d = 64 + i - c;
+    return (c >= i && 64 * (k + 1) + i < N) ? Bc[(size_t)col * BAND_LD + d] : 0.0;
+  };
+  const int nblk = (N + 63) / 64;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) As[i * LD + 16 * kq + m] = diag_at(0, 16 * kq + m);
+  double lsum = 0.0;                                           // threads < 64: sum of log pivots of their column index
+  int bad = 0;
+  __syncthreads();
+  for (int k = 0; k < nblk; ++k) {
+    double cpre[16], apre[16];                                 // the next blocks' band entries travel while this one is factored
+    const bool more = k + 1 < nblk;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      cpre[m] = more ? sub_at(k, 16 * kq + m) : 0.0;
+      apre[m] = more ? diag_at(k + 1, 16 * kq + m) : 0.0;
+    }
+    const int b = chol64_lds(As, Fs, Xs, T1, rs, sh, tid);
+    if (b) { bad = 64 * k + b; break; }                        // uniform
+    // columns 64k .. 64k + 63 of L inside the diagonal block: L[r][c] = u_rc rs_c (r > c), p_c rs_c on the diagonal; 1 / l_cc
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int c = 16 * kq + m, col = 64 * k + c;
+      // (rows beyond N are the identity padding: their entries in the columns < N are exact zeros, written like the rest)
+      if (i >= c && col < N) Lc[(size_t)col * BAND_LD + (i - c)] = As[i * LD + c] * rs[c];
+      if (!more && c >= i && col < N) Lc[(size_t)col * BAND_LD + (64 + i - c)] = 0.0;   // last block: nothing below it
+    }
+    if (tid < 64 && 64 * k + tid < N) {
+      Lc[(size_t)(64 * k + tid) * BAND_LD + BAND_B + 1] = rs[tid];
+      lsum += log(As[tid * LD + tid]);
+    }
+    if (!more) break;
+    // X = C L_kk^-T: X[a][j] = rs_j sum_m C[a][m] Lu^-1[j][m]  (C upper, Lu^-1 lower: X upper triangular) -> Fs
+    __syncthreads();                                           // (everybody has read As / rs for the write-out above)
+#pragma unroll
+    for (int m = 0; m < 16; ++m) Xs[i * LD + 16 * kq + m] = cpre[m];
+    __syncthreads();
+    for (int t = w; t < 16; t += 4) {
+      const int ib = t >> 2, jb = t & 3;
+      v4d acc = zero;
+      for (int mb = ib; mb <= jb; ++mb) acc = blk_mma_nt(acc, Xs, 16 * ib, 16 * mb, T1, 16 * jb, 16 * mb, lr, lk, 1.0);
+      const double sc = rs[16 * jb + lr];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) acc[rr] *= sc;
+      blk_store(Fs, 16 * ib, 16 * jb, lr, lk, acc);            // (zeros for jb < ib: the loop above is empty)
+    }
+    __syncthreads();
+    // rows 64(k+1) + a of columns 64k + j (a <= j): d = 64 + a - j; and S_{k+1} = A_{k+1} + delta I - X X' (lower blocks) -> As
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int c = 16 * kq + m;
+      if (c >= i) Lc[(size_t)(64 * k + c) * BAND_LD + (64 + i - c)] = Fs[i * LD + c];   // (column < N: there is a next block)
+      As[i * LD + c] = apre[m];
+    }
+    __syncthreads();
+    for (int t = w; t < 10; t += 4) {                          // lower blocks (r >= c) of the 4 x 4 block matrix
+      const int r = t >= 6 ? 3 : (t >= 3 ? 2 : (t >= 1 ? 1 : 0)), c = t - r * (r + 1) / 2;
+      v4d acc = blk_load(As, 16 * r, 16 * c, lr, lk);
+      for (int jb = r; jb < 4; ++jb) acc = blk_mma_nt(acc, Fs, 16 * r, 16 * jb, Fs, 16 * c, 16 * jb, lr, lk, -1.0);
+      blk_store(As, 16 * r, 16 * c, lr, lk, acc);
+    }
+    __syncthreads();
+  }
+  // log-determinant: the 64 partial sums through LDS (rs is free now)
+  __syncthreads();
+  if (tid < 64) rs[tid] = lsum;
+  __syncthreads();
+  if (tid == 0) {
+    double sum = 0.0;
+    for (int c = 0; c < 64; ++c) sum += rs[c];
+    logdet[blockIdx.x] = sum;
+    fail[blockIdx.x] = bad;
+  }
+}
+
+static bool band_factor_blocked() {
+  static const bool on = [] { const char* e = std::getenv("MMG_BAND_FACTOR"); return !(e && std::string(e) == "chain"); }();   // chain: round 5's kernel (A/B)
+  return on;
+}
+static int launch_band_factor(hipStream_t st, int ng, const double* dBand, int N, const double* dd, double* L, double* dlog, int* dfail) {
+  if (band_factor_blocked()) {
+    static const hipError_t attr = hipFuncSetAttribute((const void*)band_factor_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BFAC_LDS);
+    if (attr != hipSuccess) return 1;
+    hipLaunchKernelGGL(band_factor_blk_kernel, dim3(ng), dim3(256), BFAC_LDS, st, dBand, N, dd, L, dlog, dfail);
+  } else {
+    hipLaunchKernelGGL(band_factor_kernel, dim3(ng), dim3(256), 0, st, dBand, N, dd, L, dlog, dfail);
+  }
+  return 0;
 }
 
 // sum over the wave, the same value in every lane: butterflies inside the 16-lane rows by DPP, the four row sums through
@@ -1201,7 +1319,7 @@ int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, 
       dsel = dfail;
     } else {
       RC_HIP(ctx, hipMemcpyAsync(dd, deltas + g0, ng * sizeof(double), hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(band_factor_kernel, dim3(ng), dim3(256), 0, st, r->dBand, N, dd, L, dlog, dfail);
+      if (launch_band_factor(st, ng, r->dBand, N, dd, L, dlog, dfail)) return set_err(ctx, MMG_E_HIP, "hipFuncSetAttribute (band_factor_blk_kernel)");
       std::vector<int> bad(ng);
       RC_HIP(ctx, hipMemcpyAsync(bad.data(), dfail, ng * sizeof(int), hipMemcpyDeviceToHost, st));
       RC_HIP(ctx, hipStreamSynchronize(st));
@@ -1302,7 +1420,7 @@ int reml_band_factor_keep(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* d
   RC_HIP(ctx, sc.alloc(&dlog, nd * sizeof(double)));
   RC_HIP(ctx, sc.alloc(&dfail, nd * sizeof(int)));
   RC_HIP(ctx, hipMemcpyAsync(dd, deltas, nd * sizeof(double), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(band_factor_kernel, dim3(nd), dim3(256), 0, st, r->dBand, N, dd, (double*)ctx->band_keep, dlog, dfail);
+  if (launch_band_factor(st, nd, r->dBand, N, dd, (double*)ctx->band_keep, dlog, dfail)) return set_err(ctx, MMG_E_HIP, "hipFuncSetAttribute (band_factor_blk_kernel)");
   RC_HIP(ctx, hipGetLastError());
   std::vector<int> bad(nd);
   std::vector<double> ld(nd);

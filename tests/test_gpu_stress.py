@@ -24,7 +24,7 @@ def run_tool(name, *args, env=None, timeout=900):
     return out.stdout
 
 
-@pytest.mark.parametrize("tool, cases", [("random_parity2.py", 16), ("random_parity3.py", 12), ("random_parity4.py", 12),
+@pytest.mark.parametrize("tool, cases", [("random_parity2.py", 10), ("random_parity3.py", 8), ("random_parity4.py", 12),
                                          ("random_parity5.py", 10)])
 def test_randomised_sweeps_against_the_oracle(tool, cases):
     """tools/random_parity2..5.py: larger N on the band route with duplicated / related individuals, the public permutation
@@ -46,5 +46,6 @@ def test_two_threads_in_the_library_at_once(n, parts, binary):
     """tools/stress_two_threads.py: an uploader thread on its own context beside GRM / IBS kinship / scan calls on the default
     one -- the library of round 4 faulted within 2 s of this (write to a wild address from kinship_i8_tr_kernel /
     kinship_grm4_kernel); results must not change from round to round and nothing may fault."""
-    out = run_tool("stress_two_threads.py", 8, n, 1, env={"MMG_STRESS_PARTS": parts, "MMG_STRESS_BINARY": binary})
+    # (5 s per variant: the library of round 4 faulted within 2-3 s; 8 s until round 5 -- the suite's time)
+    out = run_tool("stress_two_threads.py", 5, n, 1, env={"MMG_STRESS_PARTS": parts, "MMG_STRESS_BINARY": binary})
     assert "compute rounds" in out
