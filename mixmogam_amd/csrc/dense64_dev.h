@@ -74,6 +74,14 @@ __device__ __forceinline__ v4d blk_mma_nt(v4d acc, const double* __restrict__ Am
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sgn * Am[(ar + lr) * LD + ac + 4 * ks + lk], Bm[(br + lr) * LD + bc + 4 * ks + lk], acc, 0, 0, 0);
   return acc;
 }
+// ... with the A operand transposed: acc += sgn * (A[ak.., ai..])' B[bk.., bj..]  (the contraction runs over the ROWS of both)
+__device__ __forceinline__ v4d blk_mma_tn(v4d acc, const double* __restrict__ Am, int ak, int ai, const double* __restrict__ Bm, int bk,
+                                          int bj, int lr, int lk, double sgn) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sgn * Am[(ak + 4 * ks + lk) * LD + ai + lr], Bm[(bk + 4 * ks + lk) * LD + bj + lr], acc, 0, 0, 0);
+  return acc;
+}
 // t -> (r, c), r > c: the six strictly-lower blocks of a 4 x 4 block matrix
 __device__ __forceinline__ void lower_block(int t, int& r, int& c) {
   r = t >= 3 ? 3 : (t >= 1 ? 2 : 1);

@@ -423,6 +423,100 @@ __global__ __launch_bounds__(256) void band_trace_kernel(const double* __restric
 }
 
 // out[blk][a][b] = <F_a, F_b>, out2 likewise for G: one block per (delta, a, b), fixed summation order
+// The trace in 64-column blocks (round 6).  L is block bidiagonal (diagonal blocks L_k lower, sub-diagonal blocks M_k upper
+// triangular), and Z = (L L')^-1 restricted to the block pattern obeys, from the last block up,
+//     G_k = M_k L_k^-1,     Z_kk = L_k^-T L_k^-1 + G_k' Z_{k+1,k+1} G_k,
+// so a block costs one inverse of a 64 x 64 triangle (unit_lower_inverse64) and ~190 block products of 16^3 on the matrix pipe
+// instead of 64 steps of (16 readlanes + LDS round trip + two barriers).  tr (B + delta I)^-1 = sum_k tr Z_kk.
+constexpr int BTR_LDS = (4 * 64 * LD + 64 + 8) * (int)sizeof(double);
+__global__ __launch_bounds__(256) void band_trace_blk_kernel(const double* __restrict__ Lall, int N, double* __restrict__ trace,
+                                                             const int* __restrict__ sel) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double *Fs = sm, *Xs = sm + 64 * LD, *T1 = sm + 2 * 64 * LD, *Zs = sm + 3 * 64 * LD, *rs = sm + 4 * 64 * LD;
+  const int tid = threadIdx.x, i = tid & 63, kq = tid >> 6;
+  const int w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+  const double* Lc = Lall + (size_t)(sel ? sel[blockIdx.x] : (int)blockIdx.x) * N * BAND_LD;
+  const v4d zero = {0.0, 0.0, 0.0, 0.0};
+  const int nblk = (N + 63) / 64;
+  for (int e = tid; e < 64 * LD; e += 256) Zs[e] = 0.0;
+  double tr = 0.0;
+  for (int k = nblk - 1; k >= 0; --k) {
+    // F = strict lower triangle of Lu = L_k diag(1 / l_jj); rows / columns beyond N: the identity
+    double mpre[16];
+    if (tid < 64) rs[tid] = 64 * k + tid < N ? Lc[(size_t)(64 * k + tid) * BAND_LD + BAND_B + 1] : 1.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int c = 16 * kq + m, col = 64 * k + c;
+      const bool in = col < N && 64 * k + i < N;
+      Fs[i * LD + c] = (i > c && in) ? Lc[(size_t)col * BAND_LD + (i - c)] * Lc[(size_t)col * BAND_LD + BAND_B + 1] : 0.0;
+      // M_k[a = i][c] = L[64(k+1) + i][64k + c], c >= i (zero for the last block and beyond N)
+      mpre[m] = (c >= i && k + 1 < nblk && col < N && 64 * (k + 1) + i < N) ? Lc[(size_t)col * BAND_LD + (64 + i - c)] : 0.0;
+    }
+    __syncthreads();
+    unit_lower_inverse64(Fs, Xs, T1, tid);                      // T1 = Lu^-1 (ends with a barrier)
+    {
+      const double ri = rs[i];                                 // L_k^-1 = diag(1 / l_ii) Lu^-1
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        T1[i * LD + 16 * kq + m] *= ri;
+        Fs[i * LD + 16 * kq + m] = mpre[m];                    // M (F is dead)
+      }
+    }
+    __syncthreads();
+    for (int t = w; t < 16; t += 4) {                          // G = M L^-1 -> Xs: blocks (a, j), contraction blocks >= max(a, j)
+      const int ab = t >> 2, jb = t & 3;
+      v4d acc = zero;
+      for (int mb = ab > jb ? ab : jb; mb < 4; ++mb) acc = blk_mma(acc, Fs, 16 * ab, 16 * mb, T1, 16 * mb, 16 * jb, lr, lk, 1.0);
+      blk_store(Xs, 16 * ab, 16 * jb, lr, lk, acc);
+    }
+    __syncthreads();
+    for (int t = w; t < 16; t += 4) {                          // W = Z G -> Fs (M is dead)
+      const int ab = t >> 2, jb = t & 3;
+      v4d acc = zero;
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) acc = blk_mma(acc, Zs, 16 * ab, 16 * mb, Xs, 16 * mb, 16 * jb, lr, lk, 1.0);
+      blk_store(Fs, 16 * ab, 16 * jb, lr, lk, acc);
+    }
+    __syncthreads();
+    v4d zk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                              // Z_kk = L^-T L^-1 + G' W: block (ib, jb) = (u, w) per wave
+      const int ib = u, jb = w;
+      v4d acc = zero;
+      for (int mb = ib > jb ? ib : jb; mb < 4; ++mb) acc = blk_mma_tn(acc, T1, 16 * mb, 16 * ib, T1, 16 * mb, 16 * jb, lr, lk, 1.0);
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) acc = blk_mma_tn(acc, Xs, 16 * mb, 16 * ib, Fs, 16 * mb, 16 * jb, lr, lk, 1.0);
+      zk[u] = acc;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) blk_store(Zs, 16 * u, 16 * w, lr, lk, zk[u]);   // (Z's last readers passed the barrier above)
+    __syncthreads();
+    if (tid < 64 && 64 * k + tid < N) tr += Zs[tid * LD + tid];
+  }
+  __syncthreads();
+  if (tid < 64) rs[tid] = tr;
+  __syncthreads();
+  if (tid == 0) {
+    double sum = 0.0;
+    for (int c = 0; c < 64; ++c) sum += rs[c];
+    trace[blockIdx.x] = sum;
+  }
+}
+static bool band_trace_blocked() {
+  static const bool on = [] { const char* e = std::getenv("MMG_BAND_TRACE"); return !(e && std::string(e) == "chain"); }();   // chain: round 5's kernel (A/B)
+  return on;
+}
+static int launch_band_trace(hipStream_t st, int ng, const double* L, int N, double* dtr, const int* dsel) {
+  if (band_trace_blocked()) {
+    static const hipError_t attr = hipFuncSetAttribute((const void*)band_trace_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BTR_LDS);
+    if (attr != hipSuccess) return 1;
+    hipLaunchKernelGGL(band_trace_blk_kernel, dim3(ng), dim3(256), BTR_LDS, st, L, N, dtr, dsel);
+  } else {
+    hipLaunchKernelGGL(band_trace_kernel, dim3(ng), dim3(256), 0, st, L, N, dtr, dsel);
+  }
+  return 0;
+}
+
 __global__ __launch_bounds__(256) void band_gram_kernel(const double* __restrict__ Fall, const double* __restrict__ Gall, int N,
                                                         int q1, double* __restrict__ ff, double* __restrict__ gg) {
   const int blk = blockIdx.x, a = blockIdx.y / q1, b = blockIdx.y % q1;
@@ -1337,7 +1431,7 @@ int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, 
       RC_HIP(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
       (void)hipEventRecord(e0, st);
       (void)hipStreamWaitEvent(ctx->stream2, e0, 0);
-      hipLaunchKernelGGL(band_trace_kernel, dim3(ng), dim3(256), 0, ctx->stream2, L, N, dtr, dsel);
+      if (launch_band_trace(ctx->stream2, ng, L, N, dtr, dsel)) return set_err(ctx, MMG_E_HIP, "hipFuncSetAttribute (band_trace_blk_kernel)");
       (void)hipEventRecord(e1, ctx->stream2);
       hipLaunchKernelGGL(band_solve_kernel, dim3(ng), dim3(256), 0, st, L, N, r->dZr, q1, F, G, dsel);
       (void)hipStreamWaitEvent(st, e1, 0);
@@ -1345,7 +1439,7 @@ int reml_band_sums(mmg_ctx* ctx, mmg_reml* r, int32_t nd, const double* deltas, 
       (void)hipEventDestroy(e1);
     } else {
       hipLaunchKernelGGL(band_solve_kernel, dim3(ng), dim3(256), 0, st, L, N, r->dZr, q1, F, G, dsel);
-      hipLaunchKernelGGL(band_trace_kernel, dim3(ng), dim3(256), 0, st, L, N, dtr, dsel);
+      if (launch_band_trace(st, ng, L, N, dtr, dsel)) return set_err(ctx, MMG_E_HIP, "hipFuncSetAttribute (band_trace_blk_kernel)");
     }
     hipLaunchKernelGGL(band_gram_kernel, dim3(ng, q1 * q1), dim3(256), 0, st, F, G, N, q1, dff, dgg);
     RC_HIP(ctx, hipGetLastError());
