@@ -1071,7 +1071,12 @@ void launch_potrf_head(hipStream_t st, double* A, int64_t lda, int kb, double* L
 }
 
 int dense64_init() {
-  static int rc = [] {
+  // once per DEVICE (the attribute belongs to the device the calling context is bound to; a process may hold contexts on several)
+  static int done[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (done[dev]) return done[dev] - 1;
+  const int rc = [] {
     hipError_t e = hipFuncSetAttribute((const void*)cholqr_head2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, HEAD2_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cholqr_head2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, HEAD2_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)cholqr_head1_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHOL_LDS);
@@ -1081,6 +1086,7 @@ int dense64_init() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)rows_gemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_LDS1);
     return e == hipSuccess ? 0 : 1;
   }();
+  done[dev] = rc + 1;
   return rc;
 }
 

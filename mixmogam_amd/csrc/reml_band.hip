@@ -269,8 +269,8 @@ static bool band_factor_blocked() {
 }
 static int launch_band_factor(hipStream_t st, int ng, const double* dBand, int N, const double* dd, double* L, double* dlog, int* dfail) {
   if (band_factor_blocked()) {
-    static const hipError_t attr = hipFuncSetAttribute((const void*)band_factor_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BFAC_LDS);
-    if (attr != hipSuccess) return 1;
+    // (per call, not once per process: the attribute belongs to the device the calling context is bound to)
+    if (hipFuncSetAttribute((const void*)band_factor_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BFAC_LDS) != hipSuccess) return 1;
     hipLaunchKernelGGL(band_factor_blk_kernel, dim3(ng), dim3(256), BFAC_LDS, st, dBand, N, dd, L, dlog, dfail);
   } else {
     hipLaunchKernelGGL(band_factor_kernel, dim3(ng), dim3(256), 0, st, dBand, N, dd, L, dlog, dfail);
@@ -508,8 +508,7 @@ static bool band_trace_blocked() {
 }
 static int launch_band_trace(hipStream_t st, int ng, const double* L, int N, double* dtr, const int* dsel) {
   if (band_trace_blocked()) {
-    static const hipError_t attr = hipFuncSetAttribute((const void*)band_trace_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BTR_LDS);
-    if (attr != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)band_trace_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BTR_LDS) != hipSuccess) return 1;
     hipLaunchKernelGGL(band_trace_blk_kernel, dim3(ng), dim3(256), BTR_LDS, st, L, N, dtr, dsel);
   } else {
     hipLaunchKernelGGL(band_trace_kernel, dim3(ng), dim3(256), 0, st, L, N, dtr, dsel);
