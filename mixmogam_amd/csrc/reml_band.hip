@@ -304,9 +304,11 @@ __device__ __forceinline__ double wave_sum_fast(double v) {
 __global__ __launch_bounds__(256) void band_solve_kernel(const double* __restrict__ Lall, int N, const double* __restrict__ Zr,
                                                          int q1, double* __restrict__ Fall, double* __restrict__ Gall,
                                                          const int* __restrict__ sel) {
-  const int t = threadIdx.x & 63;
-  const bool loader = threadIdx.x >= 64;
-  const int lt = threadIdx.x - 64;
+  // Round 6: two right-hand sides at a time, one per wave (waves 0 and 1 walk the same chunks in lock step; q1 = 2 for the
+  // intercept-only model: one round instead of two, 1.8 -> ~1.0 ms at N = 5000); waves 2 and 3 fetch.
+  const int t = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+  const bool loader = wv_ >= 2;
+  const int lt = threadIdx.x - 128;
   const double* Lc = Lall + (size_t)(sel ? sel[blockIdx.x] : (int)blockIdx.x) * N * BAND_LD;
   __shared__ __attribute__((aligned(16))) double ch[3][64 * BAND_LD];
   const int nchunk = (N + 63) / 64;
@@ -315,21 +317,24 @@ __global__ __launch_bounds__(256) void band_solve_kernel(const double* __restric
     double2* dst = (double2*)ch[ring(cb)];
     const int nj = (cb < 0 || cb >= nchunk) ? 0 : min(64, N - cb * 64);
     const double2* src = (const double2*)(Lc + (size_t)(cb < 0 ? 0 : cb) * 64 * BAND_LD);
-    for (int i = lt; i < 32 * BAND_LD; i += 192) dst[i] = 2 * i < nj * BAND_LD ? src[i] : double2{0.0, 0.0};
+    for (int i = lt; i < 32 * BAND_LD; i += 128) dst[i] = 2 * i < nj * BAND_LD ? src[i] : double2{0.0, 0.0};
   };
-  for (int r = 0; r < q1; ++r) {
-    const double* z0 = Zr + (size_t)r * N;
-    double* f = Fall + ((size_t)blockIdx.x * q1 + r) * N;
-    double* g = Gall + ((size_t)blockIdx.x * q1 + r) * N;
+  for (int r0 = 0; r0 < q1; r0 += 2) {
+    const int r = r0 + wv_;                                    // this wave's right-hand side (compute waves)
+    const bool solver = !loader && r < q1;                     // (a compute wave without one only keeps the barriers)
+    const int rr_ = r < q1 ? r : 0;
+    const double* z0 = Zr + (size_t)rr_ * N;
+    double* f = Fall + ((size_t)blockIdx.x * q1 + rr_) * N;
+    double* g = Gall + ((size_t)blockIdx.x * q1 + rr_) * N;
     // ---- forward: lane t holds the running right-hand side of unknown i = t (mod 64) of the current window
     __syncthreads();
     if (loader) load_chunk(0);
     __syncthreads();
-    double z = t < N ? z0[t] : 0.0;
+    double z = (solver && t < N) ? z0[t] : 0.0;
     for (int cb = 0; cb < nchunk; ++cb) {
       if (loader) {
         load_chunk(cb + 1);
-      } else {
+      } else if (solver) {
         const int j0 = cb * 64, nj = min(64, N - j0);
         const double* cur = ch[ring(cb)];
         const double znext = (j0 + 64 + t < N) ? z0[j0 + 64 + t] : 0.0;
@@ -352,11 +357,11 @@ __global__ __launch_bounds__(256) void band_solve_kernel(const double* __restric
     if (loader) { load_chunk(top); load_chunk(top - 1); }
     __syncthreads();
     double x = 0.0;
-    if (!loader) x = t < ntop ? f[top0 + t] : (top0 + t - 64 >= 0 ? f[top0 + t - 64] : 0.0);
+    if (solver) x = t < ntop ? f[top0 + t] : (top0 + t - 64 >= 0 ? f[top0 + t - 64] : 0.0);
     for (int cb = top; cb >= 0; --cb) {
       if (loader) {
         load_chunk(cb - 2);
-      } else {
+      } else if (solver) {
         const int j0 = cb * 64, nj = min(64, N - j0);
         const double* cur = ch[ring(cb)];
         const double* low = ch[ring(cb - 1)];
