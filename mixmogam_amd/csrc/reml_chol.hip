@@ -190,6 +190,76 @@ __global__ __launch_bounds__(256) void lauum_tiles_kernel(const double* __restri
     }
 }
 
+// The same tiles with the operand panels staged through LDS (round 6).  The contraction of X'X runs over the ROWS of X, its
+// contiguous dimension, while a 16x16x4 MFMA operand wants 16 different columns per 4 rows: read straight from global memory
+// (kernel above) every wave load touches 16 cache lines for 32 bytes each.  Here a chunk of 32 rows x 64 columns is loaded with
+// 64 contiguous bytes per lane (lane = column, wave = 8-row group), written to LDS as [row][column] and read from there in the
+// operand layout; the next chunk travels in registers while the current one is multiplied.  2.5 -> ~1.3 ms at N = 5000.
+constexpr int LAU_LD = 80;                                    // doubles per staged row: 64 columns + 16 (row stride = 32 banks mod 64: the two
+                                                              // k rows a 32-lane half reads fall into disjoint bank halves)
+__global__ __launch_bounds__(256) void lauum_tiles_lds_kernel(const double* __restrict__ X, int64_t ldx, int64_t n,
+                                                              double* __restrict__ P, int64_t ldp) {
+  const int64_t t = blockIdx.x;
+  int64_t I = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while (I * (I + 1) / 2 > t) --I;
+  while ((I + 1) * (I + 2) / 2 <= t) ++I;
+  const int64_t J = t - I * (I + 1) / 2;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, lr = l & 15, lk = l >> 4;
+  __shared__ __attribute__((aligned(16))) double As[2][32 * LAU_LD], Bs[2][32 * LAU_LD];
+  const bool same = I == J;
+  const int64_t ca = I * 64 + l, cb = J * 64 + l;             // this lane's column of the two panels
+  const bool ain = ca < n, bin = cb < n;
+  const double* __restrict__ ap = X + (ain ? ca : 0) * ldx;
+  const double* __restrict__ bp = X + (bin ? cb : 0) * ldx;
+  double ra[8], rb[8];
+  auto fetch = [&](int64_t r0) {                              // rows r0 + 8 w .. + 7 of this lane's columns
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t r = r0 + 8 * w + k;
+      ra[k] = (ain && r < n) ? ap[r] : 0.0;
+      rb[k] = (!same && bin && r < n) ? bp[r] : 0.0;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      As[buf][(8 * w + k) * LAU_LD + l] = ra[k];
+      if (!same) Bs[buf][(8 * w + k) * LAU_LD + l] = rb[k];
+    }
+  };
+  v4d_rc acc[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) acc[ct] = v4d_rc{0.0, 0.0, 0.0, 0.0};
+  const int64_t rbeg = I * 64;
+  fetch(rbeg);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t r0 = rbeg; r0 < n; r0 += 32) {
+    const bool more = r0 + 32 < n;
+    if (more) fetch(r0 + 32);
+    const double* __restrict__ a_s = As[buf];
+    const double* __restrict__ b_s = same ? As[buf] : Bs[buf];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const double a = a_s[(4 * ks + lk) * LAU_LD + 16 * w + lr];
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+        acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b_s[(4 * ks + lk) * LAU_LD + 16 * ct + lr], acc[ct], 0, 0, 0);
+    }
+    if (more) stash(buf ^ 1);                                 // (the other buffer's readers passed the barrier below one chunk ago)
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t pi = I * 64 + 16 * w + 4 * e + lk, pj = J * 64 + 16 * ct + lr;
+      if (pi < n && pj < n) P[pi + pj * ldp] = acc[ct][e];
+    }
+}
+
 // P (n x n column-major, lower tiles valid) -= Gx GA' on the lower tiles and the result mirrored into the upper ones:
 // Gx [n x q] column-major (ld ldg), GA [n x q] ROW-major.  One workgroup per 64 x 64 lower tile, the mirrored tile through LDS.
 __global__ __launch_bounds__(256) void rankq_mirror_kernel(double* __restrict__ P, int64_t n, const double* __restrict__ Gx, int64_t ldg,
@@ -791,7 +861,9 @@ int mmg_reml_scan_model_c(mmg_ctx* ctx, mmg_reml* r, double delta, int ndigits, 
   if (own_all) {
     // lower tiles of H^-1 = X'X (lauum_tiles_kernel), then P = H^-1 - Gx GA' on them and the mirror image, one pass
     const int64_t nt = (N + 63) / 64;
-    hipLaunchKernelGGL(lauum_tiles_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, r->dL, N, N, dP, N);
+    static const bool lauum_direct = [] { const char* e = std::getenv("MMG_LAUUM_TILES"); return e && std::string(e) == "direct"; }();   // round 5's kernel (A/B)
+    if (lauum_direct) hipLaunchKernelGGL(lauum_tiles_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, r->dL, N, N, dP, N);
+    else hipLaunchKernelGGL(lauum_tiles_lds_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, r->dL, N, N, dP, N);
     hipLaunchKernelGGL(rankq_mirror_kernel, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, st, dP, N, dGx, N, dGA, q);
     RC_HIP(ctx, hipGetLastError());
   } else {
