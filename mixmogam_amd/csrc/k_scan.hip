@@ -91,8 +91,17 @@ __global__ void quantize_kernel(const double* __restrict__ A, int32_t N, int32_t
   for (int d = 0; d < D; ++d)
     *(uint4*)(Bq + ((int64_t)d * Npad + j) * Npad + c * 16) = make_uint4(out[d][0], out[d][1], out[d][2], out[d][3]);
   if (c == 0) diag[j] = (j < N) ? A[(int64_t)j * N + j] : 0.0;
-  if (z0_tile && z0acc != 0)
-    atomicAdd((unsigned long long*)(z0_tile + (int64_t)(j >> 8) * (Npad >> 8) + (c >> 4)), (unsigned long long)z0acc);
+  }
+  if (z0_tile) {
+    // one atomic per 16 lanes (= the 16 chunks of one row inside one 256-column tile; Npad is a multiple of 256, so a group of 16
+    // consecutive lanes never straddles a row or a tile) instead of one per lane: 1.6 M atomics on 400 addresses were most of
+    // this kernel's 1.0 ms at N = 5000
+    long long v = z0acc;
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+    if ((threadIdx.x & 15) == 0 && v != 0 && gid < (int64_t)Npad * chunks) {
+      const int j = (int)(gid / chunks), c = (int)(gid % chunks);
+      atomicAdd((unsigned long long*)(z0_tile + (int64_t)(j >> 8) * (Npad >> 8) + (c >> 4)), (unsigned long long)v);
+    }
   }
   if (z0_sum) {
 #pragma unroll
