@@ -434,7 +434,13 @@ static int potrf_own(mmg_ctx* ctx, double* A, int64_t N, int64_t lda, double* Li
 // i.e. a tall x 64x64 product on the matrix pipe and one lower-triangular x tall product (sym_skinny_kernel<TRI>, contraction
 // slices summed by wsum_into_kernel with the sign) per block column -- three launches, no library call.  N = 5000: 4 ms,
 // against 3 ms for rocsolver_dtrtri + rocblas_dtrmm (see reml_point): kept behind MMG_REML_TRTRI=own, tested, not the default.
-__global__ void put_diag_inverse_kernel(double* __restrict__ A, int64_t lda, int kb, const double* __restrict__ LinvT) {
+// (one launch for ALL diagonal blocks -- blockIdx.y = block column -- in front of the loop below: nothing in it reads a diagonal
+// block of L before it has been replaced; round 5 launched this once per block column, 79 x 5 us at N = 5000)
+__global__ void put_diag_inverse_kernel(double* __restrict__ L, int64_t lda, int64_t N, const double* __restrict__ LinvT_all) {
+  const int64_t k0 = (int64_t)blockIdx.y * 64;
+  const int kb = (int)min((int64_t)64, N - k0);
+  double* A = L + k0 + k0 * lda;
+  const double* LinvT = LinvT_all + (size_t)blockIdx.y * 4096;
   const int e = blockIdx.x * 256 + threadIdx.x;               // element (i, j) of the block: A[i][j] = (L^-1)[i][j] = LinvT[j][i]
   const int i = e & 63, j = e >> 6;
   if (i < kb && j < kb) A[i + (int64_t)j * lda] = i >= j ? LinvT[j + 64 * i] : 0.0;
@@ -447,9 +453,9 @@ static int tri_inv_own(mmg_ctx* ctx, double* L, int64_t N, const double* LinvT_a
   const int smax = 8;
   RC_HIP(ctx, sc.alloc(&T, (size_t)N * 64 * sizeof(double)));
   RC_HIP(ctx, sc.alloc(&Wp, (size_t)smax * N * 64 * sizeof(double)));
+  hipLaunchKernelGGL(put_diag_inverse_kernel, dim3(16, (unsigned)nb), dim3(256), 0, st, L, N, N, LinvT_all);
   for (int64_t k = nb - 1; k >= 0; --k) {
     const int64_t k0 = k * 64, a0 = k0 + 64;
-    const int kb = (int)std::min<int64_t>(64, N - k0);
     const int64_t n = N - a0;                                 // rows below the block
     double* panel = L + a0 + k0 * N;
     if (n > 0) {
@@ -459,7 +465,6 @@ static int tri_inv_own(mmg_ctx* ctx, double* L, int64_t N, const double* LinvT_a
       launch_tall_product(st, L + a0 + a0 * N, N, n, T, Wp, S, true);
       launch_slice_sum_into(st, Wp, S, n, panel, N, -1.0);
     }
-    hipLaunchKernelGGL(put_diag_inverse_kernel, dim3(16), dim3(256), 0, st, L + k0 + k0 * N, N, kb, LinvT_all + k * 4096);
   }
   RC_HIP(ctx, hipGetLastError());
   return MMG_OK;
