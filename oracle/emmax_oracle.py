@@ -473,22 +473,28 @@ def hdf5_maf_filter(freqs, min_maf):
     return np.minimum(freqs, 1 - freqs) > min_maf
 
 
-def hdf5_ibd_kinship(chroms, chunk_size=1000, min_maf=None, acc_dtype=np.float64):
+def hdf5_ibd_kinship(chroms, chunk_size=1000, min_maf=None, acc_dtype=np.float64, normalised=None):
     """The kinship loop the three drivers share -- calculate_ibd_kinship hdf5_data.py:30-58 (no filter) and
     run_emmax :84-111 / run_emmax_perm :205-232 (MAF-filtered rows): per chromosome in key order, chunks of
     chunk_size rows WITHIN the chromosome (:99), each SNP standardised with the population std (:103),
     k_mat += x'x in the accumulator's dtype ('single' as written, :84), / n_snps (:107), then scale_k's rule inline
-    (:108-111).  chroms: ordered [(raw_snps [M_c x N], freqs [M_c]), ...].  Returns (k, n_snps)."""
+    (:108-111).  chroms: ordered [(raw_snps [M_c x N], freqs [M_c]), ...].  normalised: per chromosome None or the file's
+    pre-normalised `snps` dataset, which calculate_ibd_kinship takes as it is (:36-38; the loop bound stays len(raw_snps)).
+    Returns (k, n_snps)."""
     n = np.asarray(chroms[0][0]).shape[1]
     k_mat = np.zeros((n, n), dtype=acc_dtype)
     n_snps = 0
-    for snps, freqs in chroms:
+    for ci, (snps, freqs) in enumerate(chroms):
         snps = np.asarray(snps)
+        pre = None if normalised is None else normalised[ci]
         if min_maf is not None:
             snps = snps[hdf5_maf_filter(freqs, min_maf)]
         for i in range(0, len(snps), chunk_size):
-            x = snps[i:i + chunk_size].T.astype(np.float64)
-            x = ((x - x.mean(0)) / x.std(0)).T
+            if pre is not None:
+                x = np.asarray(pre[i:i + chunk_size], dtype=np.float64)          # :38
+            else:
+                x = snps[i:i + chunk_size].T.astype(np.float64)
+                x = ((x - x.mean(0)) / x.std(0)).T
             n_snps += len(x)
             k_mat += (x.T @ x).astype(acc_dtype)
     k_mat = k_mat / float(n_snps)

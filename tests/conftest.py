@@ -138,7 +138,7 @@ def load_hdf5_golden():
             chroms.append((name, s, d["%s_%s_freqs" % (variant, name)], d["%s_%s_positions" % (variant, name)]))
         d[variant + "_chroms"] = chroms
         for mode in ("lit", "dbl"):
-            for key in ("perm_kinship", "calc_kinship"):
+            for key in ("perm_kinship", "calc_kinship") + (("calcnorm_kinship",) if variant == "bin" else ()):
                 full = np.zeros((n, n))
                 full[iu] = d["%s_%s_%s" % (variant, mode, key)]
                 d["%s_%s_%s" % (variant, mode, key)] = full + np.triu(full, 1).T

@@ -451,6 +451,25 @@ def run_hdf5(mods_by_mode):
                 with h5py.File(fn, 'r') as o:                           # (only how far a different chunking moves it is kept)
                     data['%s_calc_kinship_chunk400_maxdiff' % tag] = np.float64(np.abs(
                         keep32(np.asarray(o['kinship'][...])) - data['%s_calc_kinship' % tag]).max())
+                # --- calculate_ibd_kinship on a file that carries pre-normalised `snps` datasets (:36-38: taken as they are, no
+                # standardisation; the loop bound is still len(raw_snps)) -- the 0/1 file's rows standardised in float64
+                if variant == 'bin':
+                    fn2 = os.path.join(tmp, 'geno_norm.hdf5')
+                    f2 = h5py.File(fn2, 'w')
+                    gg2, ig2 = f2.create_group('genot_data'), f2.create_group('indiv_data')
+                    for ci, (snps, freqs, positions) in enumerate(chroms):
+                        cg2 = gg2.create_group('chrom_%d' % (ci + 1))
+                        x = snps.astype(np.float64)
+                        cg2.create_dataset('raw_snps', compression='lzf', data=snps)
+                        cg2.create_dataset('snps', data=(x - x.mean(1, keepdims=True)) / x.std(1, keepdims=True))
+                        cg2.create_dataset('positions', data=positions)
+                        cg2.create_dataset('freqs', data=freqs)
+                    ig2.create_dataset('indiv_ids', data=ids)
+                    ig2.create_dataset('phenotypes', data=y)
+                    f2.close()
+                    quiet(hd.calculate_ibd_kinship, hdf5_filename=fn2, chunk_size=chunk)
+                    with h5py.File(fn2, 'r') as o:
+                        data['%s_calcnorm_kinship' % tag] = keep32(np.asarray(o['kinship'][...]))
                 # --- run_emmax(recalculate_kinship=False) reads that stored (unfiltered) kinship (:113-115)
                 out3 = os.path.join(tmp, 'res_k.hdf5')
                 try:

@@ -63,6 +63,20 @@ def test_calculate_ibd_kinship_driver_vs_the_reference_run(ctx, tmp_path, h5gold
     assert none is None and np.array_equal(again, k)
     k2, _ = hdf5_data.calculate_ibd_kinship(path, chunk_size=400, overwrite=True, ctx=ctx)
     assert np.abs(k2 - k).max() < 1e-12                                                 # chunking is invisible
+    if variant == "bin":
+        # a file that carries pre-normalised `snps` datasets: taken as they are (:36-38), against the reference's run on such a file
+        from mixmogam_amd import chunkstore
+        path_n = _container(tmp_path, d, variant, name="geno_norm.mmg")
+        st = chunkstore.open_container(path_n, "a")
+        for c, s, _f, _p in d[variant + "_chroms"]:
+            x = s.astype(np.float64)
+            st["genot_data"][c].create_dataset("snps", data=(x - x.mean(1, keepdims=True)) / x.std(1, keepdims=True))
+        st.flush()
+        st.close()
+        kn, n_n = hdf5_data.calculate_ibd_kinship(path_n, chunk_size=chunk, ctx=ctx)
+        assert n_n == n_snps
+        assert np.abs(kn - d["bin_dbl_calcnorm_kinship"]).max() < 1e-9
+        assert np.abs(kn - d["bin_lit_calcnorm_kinship"]).max() < 2e-5
 
 
 @pytest.mark.parametrize("variant,packed_bits", [("bin", 0), ("dip", 0), ("bin", 1), ("dip", 2)])
