@@ -551,6 +551,24 @@ def run_n1000(mods_by_mode):
             eres = quiet(lm.emmax, snp_list, list(y), k_ibs, cofactors=cof, emma_num=10)
             for k in ('ps', 'f_stats', 'rss', 'var_perc'):
                 data['%s_emma10_%s' % (mode, k)] = f(eres[k]).reshape(-1)
+        if mode == 'dbl':
+            # MLMM forward / backward at this size (linear_models.py:2543-2923): every step a full scan with one more cofactor
+            import sys as _sys
+            _sys.modules['gwaResults'] = mods['gwaResults']
+            lm.agr.calc_median = lambda ps, exp_median=0.5: float(np.median(ps) - exp_median)   # py2 int division inside
+            lm.agr.calc_ks_stats = lambda ps, exp_dist=None: {'D': 0.0, 'p_val': 1.0}
+            mres = quiet(lm.mlmm, list(y), k_ibs, num_steps=3, forward_backwards=True, file_prefix=None, snps=list(snp_list),
+                         positions=list(range(m)), chromosomes=[1] * m, mafs=[0.3] * m, macs=[30] * m)
+            keys = ('pseudo_heritability', 'll', 'bic', 'e_bic', 'm_bic', 'mbonf', 'min_pval', 'rss', 'reml_mahalanobis_rss',
+                    'mahalanobis_rss')
+            data['dbl_mlmm_steps'] = np.asarray([[np.nan if si[k] is None else float(np.asarray(si[k]).reshape(-1)[0]) for k in keys]
+                                                 for si in mres['step_info_list']])
+            data['dbl_mlmm_cof_pos'] = np.asarray([[c[1] for c in si['cofactors']] + [-1] * (3 - len(si['cofactors']))
+                                                   for si in mres['step_info_list']])
+            data['dbl_mlmm_cof_mlogp'] = np.asarray([[c[2] for c in si['cofactors']] + [np.nan] * (3 - len(si['cofactors']))
+                                                     for si in mres['step_info_list']])
+            for c in ('ebics', 'mbics', 'bonf', 'mbonf', 'min_cof_ppa'):
+                data['dbl_mlmm_opt_' + c] = np.int64(mres['opt_dict'][c])
         # permutations: the intercept-only model
         lmm3 = lm.LinearMixedModel(list(y))
         lmm3.add_random_effect(k_ibs)
