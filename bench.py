@@ -178,7 +178,7 @@ def rccl_probe(ctx, coll, comm_h, N, m_block, repeats=3):
         coll.barrier()
         t.append(time.time() - t0)
     acc.close()
-    ar = min(t[1:])
+    ar = max(min(t[1:]), 1e-9)                                 # (a stand-in collective in the tests can take no measurable time)
     nbytes = 8.0 * N * N
     blk = np.zeros(3 * min(int(m_block), 1 << 22))
     tg = []
@@ -188,7 +188,7 @@ def rccl_probe(ctx, coll, comm_h, N, m_block, repeats=3):
         coll.allgather(blk)
         coll.barrier()
         tg.append(time.time() - t0)
-    ag = min(tg[1:])
+    ag = max(min(tg[1:]), 1e-9)
     return {"nranks": w, "allreduce_bytes": nbytes, "allreduce_ms": 1e3 * ar, "allreduce_first_call_ms": 1e3 * t[0],
             "allreduce_algbw_gbps": nbytes / ar / 1e9, "allreduce_busbw_gbps": nbytes / ar / 1e9 * 2.0 * (w - 1) / w,
             "allgather_bytes_per_rank": 8.0 * blk.size, "allgather_ms": 1e3 * ag, "allgather_first_call_ms": 1e3 * tg[0],
