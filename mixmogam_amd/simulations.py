@@ -65,6 +65,29 @@ def packed_chunk(chunk_id, rows, num_indivs, seed=20240):
     return raw
 
 
+def packed2_chunk(chunk_id, rows, num_indivs, seed=20240):
+    """packed_chunk's twin for 0/1/2 codes (the plink2hdf5.py:171-179 coding) in 2-bit storage: uint8 [rows x ceil(N/4)],
+    individual i in bits 2(i mod 4) .. 2(i mod 4)+1 of byte i // 4 (_lib.pack_genotypes(bits=2), a PLINK .bed row's order).
+    Every code is the sum of two Bernoulli(0.5) alleles u + v (Hardy-Weinberg at allele frequency 0.5: 1/4, 1/2, 1/4), both
+    bits of the code from the two bits of the generator's word it replaces: low = u xor v, high = u and v; never 3."""
+    rb = (int(num_indivs) + 3) // 4
+    nbytes = int(rows) * rb
+    gen = np.random.Generator(np.random.SFC64(int(seed) * 1000003 + int(chunk_id)))
+    w = gen.integers(0, 2 ** 64, size=(nbytes + 7) // 8, dtype=np.uint64, endpoint=False)
+    lo_mask = np.uint64(0x5555555555555555)
+    u = w & lo_mask
+    w >>= np.uint64(1)
+    w &= lo_mask                                              # v
+    hi = u & w
+    hi <<= np.uint64(1)
+    u ^= w
+    u |= hi
+    raw = u.view(np.uint8)[:nbytes].reshape(int(rows), rb)
+    if num_indivs % 4:
+        raw[:, -1] &= np.uint8((1 << (2 * (num_indivs % 4))) - 1)
+    return raw
+
+
 def _fill_rows(args):
     """Worker of write_synthetic_container: rows [r0, r0 + rows) of one chromosome's raw_snps <- synthetic_chunk."""
     npy_path, r0, rows, num_indivs, chunk_id, seed = args
@@ -136,9 +159,10 @@ class LazySyntheticGenotypes(object):
         """packed: 1-bit rows (`raw_snps_packed`, LSB first: uint8 [M x ceil(N/8)]) that never exist expanded on the
         host -- the generator's 64-bit words ARE the rows (numpy's SFC64, one stream per generation chunk: 2 GB/s of
         packed bytes = 16 G genotypes/s per thread, where MT19937 `bytes` + unpackbits delivers 0.5 GB/s of int8).  A
-        different, equally distributed matrix than the int8 form (`packed_chunk` regenerates any part of it)."""
-        self.num_indivs, self.packed = int(num_indivs), bool(packed)
-        self.shape = (int(num_snps), (self.num_indivs + 7) // 8 if packed else self.num_indivs)
+        different, equally distributed matrix than the int8 form (`packed_chunk` regenerates any part of it).
+        packed=2: 2-bit rows of 0/1/2 codes (`packed2_chunk`)."""
+        self.num_indivs, self.packed = int(num_indivs), int(packed)        # 0: int8 rows, 1: 1-bit rows, 2: 2-bit 0/1/2 rows
+        self.shape = (int(num_snps), (self.num_indivs * self.packed + 7) // 8 if packed else self.num_indivs)
         if packed:
             self.dtype = np.dtype(np.uint8)
         self.gen_rows, self.seed, self.chunk_id0, self.threads = int(gen_rows), int(seed), int(chunk_id0), int(threads)
@@ -149,6 +173,8 @@ class LazySyntheticGenotypes(object):
 
     def _gen(self, k):
         rows = min(self.gen_rows, self.shape[0] - k * self.gen_rows)
+        if self.packed == 2:
+            return packed2_chunk(self.chunk_id0 + k, rows, self.num_indivs, self.seed)
         if self.packed:
             return packed_chunk(self.chunk_id0 + k, rows, self.num_indivs, self.seed)
         return synthetic_chunk(self.chunk_id0 + k, rows, self.num_indivs, self.seed)
@@ -192,14 +218,16 @@ def lazy_synthetic_source(num_indivs, num_snps, num_chroms=5, gen_rows=6250, see
         ds = LazySyntheticGenotypes(num_indivs, m_c, gen_rows, seed, chunk_id0=k0, threads=threads, packed=packed)
         tree["chrom_%d" % (c + 1)] = {"freqs": np.full(m_c, 0.5), "positions": np.arange(1, m_c + 1, dtype=np.int64)}
         if packed:                                            # hdf5_data._raw_dataset's packed layout
-            tree["chrom_%d" % (c + 1)].update(raw_snps_packed=ds, packed_bits=np.array(1), num_indivs=np.array(num_indivs))
+            tree["chrom_%d" % (c + 1)].update(raw_snps_packed=ds, packed_bits=np.array(int(packed)),
+                                              num_indivs=np.array(num_indivs))
         else:
             tree["chrom_%d" % (c + 1)]["raw_snps"] = ds
         done += m_c
         k0 += -(-m_c // gen_rows)
     if packed:
         from ._lib import unpack_genotypes
-        first = unpack_genotypes(packed_chunk(0, min(gen_rows, num_snps), num_indivs, seed), num_indivs, 1)
+        first = unpack_genotypes((packed2_chunk if int(packed) == 2 else packed_chunk)(0, min(gen_rows, num_snps), num_indivs, seed),
+                                 num_indivs, int(packed))
     else:
         first = synthetic_chunk(0, min(gen_rows, num_snps), num_indivs, seed)
     y = simulate_phenotype(first, h2=h2, num_causals=min(num_causals, len(first)), seed=pheno_seed)

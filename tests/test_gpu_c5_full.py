@@ -36,3 +36,28 @@ def test_config5_stated_size_one_gpu_streamed_pipeline_vs_float64_cg(capsys):
     assert "band reduction" in rec["route"]
     assert not rec["adaptive_last_chunk"]["fell_back"]
     assert rec["pipeline_s"] < 150.0                          # 76 s in round 3; 345 s in round 2
+
+
+def test_config5_individuals_two_bit_rows_of_diploid_codes_streamed(capsys):
+    """The same pipeline at config 5's N = 50,000 on a 0/1/2 store (the coding of /root/reference/plink2hdf5.py:171-179; the
+    `diploid_int` kind of kinship.py:33-41), streamed as 2-bit packed rows and expanded on the device: M = 1,000,000 SNPs
+    (12.5 GB of rows per read instead of 50 GB; not 10^7 -- suite time), codes u + v of two Bernoulli(0.5) alleles.  Exact
+    GRM of the 0/1/2 codes (four digit planes per weight), band-reduction REML, Cholesky scan model, the scan with its
+    sum_i A_ii s_i^2 term; same float64 CG checker on rows regenerated and unpacked on the host."""
+    from mixmogam_amd import hdf5_data
+    hdf5_data.release_pools()
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "c5_stream.py"), "--world", "1", "--lazy", "--packed", "--packed-bits", "2",
+           "--m-total", "1000000", "--samples", "8"]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, MMG_REML_VERBOSE="1"), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    with capsys.disabled():
+        print("\n---- N = 50,000 x M = 1,000,000, 0/1/2 codes in 2-bit rows, one GPU (tools/c5_stream.py --packed-bits 2) ----")
+        print(r.stdout[-4000:])
+    assert r.returncode == 0, r.stdout[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["N"] == 50000 and rec["M_share"] == 1000000 and rec["codes"].startswith("0/1/2")
+    assert rec["n_sampled"] >= 8
+    assert rec["max_rel_p_err_vs_host_f64"] < 1e-6
+    assert rec["h0_rss_rel_err_vs_host_f64"] < 1e-9
+    assert "band reduction" in rec["route"]
+    assert not rec["adaptive_last_chunk"]["fell_back"]

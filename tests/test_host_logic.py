@@ -281,6 +281,27 @@ def test_run_emmax_over_a_never_resident_packed_source(ctx):
         assert rel(a["chrom_results"][c]["ps"], b["chrom_results"][c]["ps"]) < 1e-9
 
 
+def test_run_emmax_over_a_never_resident_two_bit_source_of_diploid_codes(ctx):
+    """lazy_synthetic_source(packed=2): 0/1/2 codes (plink2hdf5.py:171-179) as 2-bit rows, each the sum of two Bernoulli(0.5)
+    alleles, never a 3; == the run over the expanded int8 arrays; N not a multiple of 4."""
+    from mixmogam_amd import simulations, _lib
+    tree, y = simulations.lazy_synthetic_source(53, 900, num_chroms=3, gen_rows=64, num_causals=5, threads=3, packed=2)
+    ds = tree["chrom_2"]["raw_snps_packed"]
+    assert int(tree["chrom_2"]["packed_bits"]) == 2
+    assert ds.shape == (len(ds), 14) and ds[:].dtype == np.uint8 and np.array_equal(ds[70:200], ds[:][70:200])
+    assert not np.any(ds[:][:, -1] >> 2)                                                   # 53 = 13 * 4 + 1: pad fields are zero
+    mem = {c: {"raw_snps": _lib.unpack_genotypes(v["raw_snps_packed"][:], 53, 2), "freqs": v["freqs"],
+               "positions": v["positions"]} for c, v in tree.items()}
+    codes = np.concatenate([m["raw_snps"] for m in mem.values()])
+    assert codes.max() == 2 and np.abs(np.bincount(codes.ravel(), minlength=3) / codes.size - [0.25, 0.5, 0.25]).max() < 0.01
+    assert np.array_equal(_lib.pack_genotypes(mem["chrom_2"]["raw_snps"], 2), ds[:])
+    a = hdf5_data.run_emmax(tree, y, min_maf=0.1, chunk_size=100, ctx=ctx)
+    b = hdf5_data.run_emmax(mem, y, min_maf=0.1, chunk_size=10 ** 6, ctx=ctx)
+    assert a["num_snps"] == b["num_snps"] == 900
+    for c in mem:
+        assert rel(a["chrom_results"][c]["ps"], b["chrom_results"][c]["ps"]) < 1e-9
+
+
 def test_run_emmax_multi_equals_run_emmax_per_phenotype(ctx, tmp_path):
     """hdf5_data.run_emmax_multi (one pass over the chunks for all phenotypes) == run_emmax once per phenotype."""
     from mixmogam_amd import chunkstore, simulations

@@ -32,6 +32,8 @@ ap.add_argument("--lazy", action="store_true",
                      "nothing but the current chunks is ever in host memory -- the whole 10 M SNPs on one GPU")
 ap.add_argument("--packed", action="store_true",
                 help="with --lazy: the same genotypes as 1-bit packed rows (raw_snps_packed), expanded on the device")
+ap.add_argument("--packed-bits", type=int, default=1, choices=(1, 2),
+                help="with --packed: 1 = 0/1 genotypes, one bit each; 2 = 0/1/2 codes (plink2hdf5.py:171-179), two bits each")
 ap.add_argument("--max-gb", type=float, default=80.0, help="largest container this run may put into the scratch directory")
 ap.add_argument("--writers", type=int, default=8, help="processes generating / writing the container")
 ap.add_argument("--eig", action="store_true", help="take the eigendecomposition route (eigh of K) even beyond N = 46,340")
@@ -66,7 +68,8 @@ try:
     GEN = 6250                                               # generation chunk of the lazy source (8 per 50,000-SNP read)
     if a.lazy:
         tree, y_lazy = simulations.lazy_synthetic_source(N, M, num_chroms=5, gen_rows=GEN, seed=20240, pheno_seed=20241,
-                                                         num_causals=100, threads=a.writers, packed=a.packed)
+                                                         num_causals=100, threads=a.writers,
+                                                         packed=a.packed_bits if a.packed else 0)
     t0 = time.time()
     path = None if a.lazy else simulations.write_synthetic_container(os.path.join(root, "geno.mmg"), N, M, chunk_rows=CH, num_chroms=5,
                                                  seed=20240, pheno_seed=20241, num_causals=100, workers=a.writers)
@@ -82,7 +85,7 @@ try:
         for chrom in tree:
             ds = tree[chrom]["raw_snps_packed" if a.packed else "raw_snps"]
             if gi < len(ds):
-                return _lib.unpack_genotypes(ds[int(gi)][None, :], N, 1)[0] if a.packed else ds[int(gi)]
+                return _lib.unpack_genotypes(ds[int(gi)][None, :], N, a.packed_bits)[0] if a.packed else ds[int(gi)]
             gi -= len(ds)
         raise IndexError(gi)
     plan = hdf5_data._chunk_plan(src["genot_data"], 0.1, CH)
@@ -183,6 +186,7 @@ try:
             worst = max(worst, abs(ps[gi] / p - 1))
     total = sum(v for k, v in T.items() if k.endswith("_s") and k not in ("write_container_s", "scan_quad_kernel_s"))
     print(json.dumps({"config": ("C5 share of rank 0 of %d" % a.world) + (", lazily generated" if a.lazy else ""), "N": N, "M_share": M, "M_total": a.m_total,
+                      "codes": "0/1/2, 2-bit rows" if a.packed and a.packed_bits == 2 else "0/1",
                       "chunks": len(plan), "timings": T, "pipeline_s": round(total, 1),
                       "snps_per_s_end_to_end": M / total, "min_p": float(ps.min()),
                       "route": "eigendecomposition-free (REML through %s)" % ("one band reduction" if eigen_free and _band else "Cholesky factorisations") if eigen_free else "eigh",
