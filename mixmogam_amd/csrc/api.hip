@@ -105,7 +105,7 @@ int mmg_ctx_create(int device, mmg_ctx** out) {
 }
 
 static void free_model(mmg_scan_model& m) {
-  hipFree(m.Bq); hipFree(m.A64); hipFree(m.diag); hipFree(m.w); hipFree(m.job_off); hipFree(m.jobs);
+  hipFree(m.Bq); hipFree(m.A64); hipFree(m.diag); hipFree(m.w); hipFree(m.job_off); hipFree(m.jobs); hipFree(m.lin_tab);
   hipFree(m.job_off_hi); hipFree(m.jobs_hi); hipFree(m.job_off_lo); hipFree(m.jobs_lo);
   for (int r = 0; r < 3; ++r)
     for (int k = 0; k < 2; ++k) { hipFree(m.tail_off[r][k]); hipFree(m.tail_jobs[r][k]); }
@@ -113,7 +113,7 @@ static void free_model(mmg_scan_model& m) {
 }
 static void free_result(mmg_scan_result& r) {
   hipFree(r.q); hipFree(r.rss); hipFree(r.F); hipFree(r.p); hipFree(r.dot); hipFree(r.den); hipFree(r.sum);
-  hipFree(r.dd); hipFree(r.ssq); hipFree(r.idx); hipFree(r.scal); hipFree(r.q2); hipFree(r.linraw);
+  hipFree(r.dd); hipFree(r.ssq); hipFree(r.idx); hipFree(r.scal); hipFree(r.q2); hipFree(r.linraw); hipFree(r.linraw2);
   r = mmg_scan_result();
 }
 
@@ -124,7 +124,7 @@ int mmg_ctx_destroy(mmg_ctx* ctx) {
   hipStreamSynchronize(ctx->stream2);
   free_model(ctx->model);
   free_result(ctx->res);
-  if (ctx->sel_geno) { hipFree(ctx->sel_geno->d); hipFree(ctx->sel_geno->bits); hipFree(ctx->sel_geno->fp4); hipFree(ctx->sel_geno->d_smax); delete ctx->sel_geno; }
+  if (ctx->sel_geno) { hipFree(ctx->sel_geno->d); hipFree(ctx->sel_geno->bits); hipFree(ctx->sel_geno->hi2); hipFree(ctx->sel_geno->fp4); hipFree(ctx->sel_geno->d_smax); delete ctx->sel_geno; }
   hipFree(ctx->dstage);
   hipFree(ctx->grp_tab);
   hipFree(ctx->jobs);
@@ -268,6 +268,7 @@ int mmg_geno_destroy(mmg_ctx* ctx, mmg_geno* g) {
   if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
   hipFree(g->d);
   hipFree(g->bits);
+  hipFree(g->hi2);
   hipFree(g->fp4);
   hipFree(g->d_smax);
   delete g;
@@ -1522,6 +1523,7 @@ static int build_schedule(mmg_ctx* ctx, mmg_scan_model& md) {
 // are in double precision.  Needs 16 free rows; otherwise the scan keeps the separate finalize pass over the store.
 static int add_linear_rows(mmg_ctx* ctx, mmg_scan_model& md) {
   md.lin_rows = false;
+  (void)hipFree(md.lin_tab); md.lin_tab = nullptr;
   if (md.Npad - md.N < 16 || md.D < 2) return MMG_OK;
   const int N = md.N, Npad = md.Npad;
   std::vector<double> w((size_t)N), dg((size_t)N);
@@ -1547,6 +1549,14 @@ static int add_linear_rows(mmg_ctx* ctx, mmg_scan_model& md) {
   }
   int8_t* dst = md.Bq + (size_t)(md.D - 1) * Npad * Npad + (size_t)(Npad - 16) * Npad;
   MMG_HIP(ctx, hipMemcpyAsync(dst, rows.data(), rows.size(), hipMemcpyHostToDevice, ctx->stream));
+  // stores of 0/1/2 codes (k_scan.hip:lin_hi_bits_kernel): the digit rows of diag(A) and the ones once more, as an [8 x Npad]
+  // table of their own.  Not fatal if it cannot be had: such stores then keep the finalize pass over their bytes.
+  std::vector<int8_t> tab((size_t)8 * Npad, 0);
+  for (int d = 0; d < 7; ++d) std::memcpy(&tab[(size_t)d * Npad], &rows[(size_t)row_d[d] * Npad], (size_t)Npad);
+  std::memcpy(&tab[(size_t)7 * Npad], &rows[(size_t)11 * Npad], (size_t)Npad);
+  if (hipMalloc(&md.lin_tab, tab.size()) == hipSuccess)
+    MMG_HIP(ctx, hipMemcpyAsync(md.lin_tab, tab.data(), tab.size(), hipMemcpyHostToDevice, ctx->stream));
+  else { md.lin_tab = nullptr; (void)hipGetLastError(); }
   MMG_HIP(ctx, hipStreamSynchronize(ctx->stream));
   md.lin_rows = true;
   return MMG_OK;
@@ -1747,6 +1757,28 @@ static int exact_tier(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, mmg_s
   return MMG_OK;
 }
 
+// Stores of 0/1/2 codes: make the [s = 2] bit image (mmg_internal.h:mmg_geno::hi2) available if this is at least the second
+// scan of the store's present content (MMG_SCAN_HI2=1: already on the first, =0: never), and the [Mpad][8] result rows of
+// lin_hi_bits_kernel.  Nothing here is fatal: without the image the scan keeps the finalize pass over the store's bytes.
+static int hi2_prepare(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, mmg_scan_result& res) {
+  if (g->smax != 2 || g->sneg != 0 || !md.lin_rows || !md.lin_tab) return MMG_OK;
+  const char* e = std::getenv("MMG_SCAN_HI2");
+  if (e && e[0] == '0') { g->hi2_version = ~0ull; return MMG_OK; }
+  if (g->scanned_version != g->version) { g->scanned_version = g->version; g->scans_of_version = 0; }
+  const int seen = g->scans_of_version++;
+  if (!res.linraw2) {
+    if (hipMalloc(&res.linraw2, (size_t)res.cap * 8 * sizeof(int)) != hipSuccess) { res.linraw2 = nullptr; (void)hipGetLastError(); }
+  }
+  if (!res.linraw2) { g->hi2_version = ~0ull; return MMG_OK; }
+  if (geno_hi2_ready(g)) return MMG_OK;
+  if (seen < 1 && !(e && e[0] == '1')) return MMG_OK;
+  if (!g->hi2 && hipMalloc(&g->hi2, (size_t)g->Mcap * (g->Npad >> 3)) != hipSuccess) { g->hi2 = nullptr; (void)hipGetLastError(); return MMG_OK; }
+  launch_pack_hi_bits(ctx, g);
+  MMG_HIP(ctx, hipGetLastError());
+  g->hi2_version = g->version;
+  return MMG_OK;
+}
+
 // The scan of g against model md into res: all planes for an explicit digit count, else the adaptive schedule.
 // f_free: the refinement criterion ignores F (a quadratic form wanted for its own sake -- the permutation test's t.t --
 // is refined wherever six sigma of the first pass exceed `target` of the form itself); with_p: p-values at the end.
@@ -1759,11 +1791,15 @@ static int scan_into(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, mmg_sc
   MMG_HIP(ctx, hipMemsetAsync(res.q, 0, g->Mpad * sizeof(unsigned long long), ctx->stream));
   // by-products of the GEMM (s.w, sum A_ii s_i, sum s_i; binary stores, k_scan_w4s.hip LIN) replace the finalize
   // pass's second sweep over the genotype store
+  if ((rc = hi2_prepare(ctx, g, md, res))) return rc;       // stores of 0/1/2 codes: the [s = 2] bit image, from their second scan on
   const LinOut lin_out{res.linraw};
   const bool lin = scan_lin_usable(g, md);
   const LinOut* linp = lin ? &lin_out : nullptr;
+  const bool lin2 = lin && g->smax == 2;                    // s^2 = s + 2 [s = 2]: the correction terms from the image
+  bool lin2_done = false;
   auto finalize = [&](bool with_p, double bias) {
-    if (lin) launch_scan_finalize_lin(ctx, g, md, res, h0_rss, df2, lnb, with_p, bias);
+    if (lin2 && !lin2_done) { launch_lin_hi_bits(ctx, g, md, res.linraw2); lin2_done = true; }
+    if (lin) launch_scan_finalize_lin(ctx, g, md, res, h0_rss, df2, lnb, with_p, bias, lin2 ? res.linraw2 : nullptr);
     else launch_scan_finalize(ctx, g, md, res, h0_rss, df2, lnb, with_p, bias);
   };
   double target = 2.5e-7;                                  // a quarter of the 1e-6 bar on p
@@ -1823,7 +1859,7 @@ static int scan_into(mmg_ctx* ctx, mmg_geno* g, const mmg_scan_model& md, mmg_sc
       res.q2_cap = ctx->sel_geno->Mpad;
     }
     mmg_geno view = *ctx->sel_geno;                        // a cpad-row window of the compact store
-    view.M = cnt; view.Mpad = cpad; view.smax = g->smax; view.sneg = g->sneg; view.bits = nullptr; view.bits_valid = false;
+    view.M = cnt; view.Mpad = cpad; view.smax = g->smax; view.sneg = g->sneg; view.bits = nullptr; view.bits_valid = false; view.hi2 = nullptr;
     launch_gather_rows(ctx, g, res.idx, cnt, view.d);
     MMG_HIP(ctx, hipMemsetAsync(res.q2, 0, cpad * sizeof(unsigned long long), ctx->stream));
     rc = run_scan_quad(ctx, &view, lo, res.q2, EV_QUAD2);

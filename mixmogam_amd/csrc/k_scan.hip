@@ -521,7 +521,8 @@ void launch_snp_dot_raw(mmg_ctx* ctx, const int8_t* S, int64_t ldS, int64_t rows
 
 // The same arithmetic from the by-products of the quadratic-form GEMM (k_scan_w4s.hip, LIN): the raw accumulators of the
 // model's linear rows, raw[m][h][i] -- h = 0: digits 0..6 of s.w (i = 0..6) and sum s (i = 7); h = 1: digits 0..6 of
-// sum_i A_ii s_i.  Binary store (sum s^2 = sum s).  72 bytes per SNP instead of Npad.  Digits 0-3 and 4-6 are combined
+// sum_i A_ii s_i.  Binary store (sum s^2 = sum s); raw2 (store of 0/1/2 codes): [m][8] = digits 0..6 of sum_i A_ii [s_i = 2]
+// and the number of 2s from lin_hi_bits_kernel below -- s^2 = s + 2 [s = 2].  72 (104) bytes per SNP instead of Npad.  Digits 0-3 and 4-6 are combined
 // as two exact integers (below 2^52 and 2^44) and added in double precision.
 __device__ __forceinline__ double digits7_to_f64(int4 lo4, int d4, int d5, int d6) {
   const long long lo = (long long)lo4.x + ((long long)lo4.y << 8) + ((long long)lo4.z << 16) + ((long long)lo4.w << 24);
@@ -531,7 +532,7 @@ __device__ __forceinline__ double digits7_to_f64(int4 lo4, int d4, int d5, int d
 
 __global__ void scan_finalize_lin_kernel(int64_t M, const unsigned long long* __restrict__ q, const int* __restrict__ raw,
                                          double step, unsigned long long offset, double step_w, double step_d, double bias,
-                                         double h0_rss, double nu,
+                                         double h0_rss, double nu, const int* __restrict__ raw2,
                                          double* __restrict__ rss, double* __restrict__ Fst, double* __restrict__ dotv,
                                          double* __restrict__ denv, double* __restrict__ sumv, double* __restrict__ ddv,
                                          double* __restrict__ ssqv) {
@@ -540,10 +541,16 @@ __global__ void scan_finalize_lin_kernel(int64_t M, const unsigned long long* __
   const int4* rw = (const int4*)(raw + m * 16);
   const int4 a0 = rw[0], a1 = rw[1], b0 = rw[2], b1 = rw[3];
   const double my_dw = digits7_to_f64(a0, a1.x, a1.y, a1.z) * step_w;
-  const double my_dd = digits7_to_f64(b0, b1.x, b1.y, b1.z) * step_d;
+  double my_dd = digits7_to_f64(b0, b1.x, b1.y, b1.z) * step_d;
+  long long ssq_i = a1.w;
+  if (raw2) {
+    const int4 c0 = ((const int4*)(raw2 + m * 8))[0], c1 = ((const int4*)(raw2 + m * 8))[1];
+    my_dd = fma(2.0 * step_d, digits7_to_f64(c0, c1.x, c1.y, c1.z), my_dd);
+    ssq_i += 2 * (long long)c1.w;
+  }
   const double sm = (double)a1.w;
-  const double qd = quad_without_offset(q[m], offset, (long long)a1.w, (long long)a1.w);
-  const double den = fma(step, qd, my_dd) + bias * (0.5 * (sm * sm - sm));
+  const double qd = quad_without_offset(q[m], offset, (long long)a1.w, ssq_i);
+  const double den = fma(step, qd, my_dd) + bias * (0.5 * (sm * sm - (double)ssq_i));
   const double num = my_dw * my_dw;
   double r = h0_rss;
   if (den > 1e-7 * my_dd && den > 0.0) r = h0_rss - num / den;
@@ -554,16 +561,106 @@ __global__ void scan_finalize_lin_kernel(int64_t M, const unsigned long long* __
   if (denv) denv[m] = den;
   if (sumv) sumv[m] = sm;
   if (ddv) ddv[m] = my_dd;
-  if (ssqv) ssqv[m] = sm;
+  if (ssqv) ssqv[m] = (double)ssq_i;
 }
 
 void launch_scan_finalize_lin(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, mmg_scan_result& res,
-                              double h0_rss, int32_t df2, double lnbeta, bool with_p, double bias) {
+                              double h0_rss, int32_t df2, double lnbeta, bool with_p, double bias, const int* raw2) {
   hipLaunchKernelGGL(scan_finalize_lin_kernel, dim3((unsigned)((g->M + 255) / 256)), dim3(256), 0, ctx->stream, g->M, res.q,
                      res.linraw, md.step, (unsigned long long)md.offset, md.lin_step_w, md.lin_step_d, bias, h0_rss, (double)df2,
+                     raw2,
                      res.rss, res.F, res.dot,
                      res.den, res.sum, res.dd, res.ssq);
   if (with_p && res.p && g->M > 0) launch_f_sf(ctx, res.F, g->M, df2, lnbeta, res.p);
+}
+
+// ------------------------------------------------------------------ stores of 0/1/2 codes: the [s = 2] bit image
+// HBM-bound, once per store content: 16 genotype bytes -> 16 bits (bit 1 of every byte, LSB first).
+__global__ __launch_bounds__(256) void pack_hi_bits_kernel(const int8_t* __restrict__ S, int64_t units, uint16_t* __restrict__ out) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= units) return;
+  const uint4 v = ((const uint4*)S)[u];
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+  unsigned bits = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) bits |= ((((w[d] >> 1) & 0x01010101u) * 0x01020408u) >> 24) << (4 * d);   // byte i -> bit i
+  out[u] = (uint16_t)bits;
+}
+
+void launch_pack_hi_bits(mmg_ctx* ctx, const mmg_geno* g) {
+  const int64_t units = g->Mpad * (int64_t)(g->Npad >> 4);
+  hipLaunchKernelGGL(pack_hi_bits_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, ctx->stream, g->d, units,
+                     (uint16_t*)g->hi2);
+}
+
+// raw2[m][0..6] = sum_k digit_d(diag_k) [s_mk = 2], raw2[m][7] = sum_k [s_mk = 2]: a [8 x N] x [N x M] integer product on the
+// matrix cores with the SNP operand expanded from the bit image in registers -- 0.6 GB of HBM at N = 5000 x M = 1e6 where
+// the finalize pass over the store reads 5 GB.  A wave owns 64 SNPs (two 32-column tiles that share every table fragment,
+// read from a chunk of the table in LDS); per block of 1024 individuals a lane loads up to 64 contiguous image bytes per
+// tile (its SNP's bits of half h of the block) and runs v_mfma_i32_32x32x32_i8 on 16 bits at a time: slot (h, i) of the K
+// dimension of MFMA t is individual k0 + h * half + 16 t + i for both operands.  A = the table (rows 0..7, lanes of rows
+// 8..31 hold zeros), B = the SNPs; in the result lane (snp, h) holds digits 4 h .. 4 h + 3 of its SNP in registers 0..3.
+__device__ __forceinline__ v4i expand16_bits(unsigned x16) {
+  v4i o;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) o[d] = (int)((((x16 >> (4 * d)) & 0xFu) * 0x00204081u) & 0x01010101u);   // bit i -> byte i
+  return o;
+}
+
+constexpr int HB_KC = 4096;                 // individuals per table chunk in LDS
+constexpr int HB_LD = HB_KC + 16;           // row stride of the chunk: the eight rows start four banks apart
+__global__ __launch_bounds__(256) void lin_hi_bits_kernel(const uint8_t* __restrict__ img, int64_t ld_img, int64_t Mpad,
+                                                          int32_t Npad, const int8_t* __restrict__ tab,
+                                                          int* __restrict__ raw2) {
+  extern __shared__ __attribute__((aligned(16))) char hb_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t m0 = ((int64_t)blockIdx.x * 4 + wave) * 64;        // grid = Mpad / 256 blocks: every wave has its 64 SNPs
+  const uint8_t* p0 = img + (m0 + r) * ld_img;
+  const uint8_t* p1 = p0 + 32 * ld_img;
+  const bool row = r < 8;
+  v16i acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc1 = acc0;
+  for (int c0 = 0; c0 < Npad; c0 += HB_KC) {
+    const int kc = min(HB_KC, Npad - c0);
+    __syncthreads();
+    for (int u = threadIdx.x; u < 8 * (kc >> 4); u += 256) {       // the chunk of the table: 16-byte units, row-major
+      const int rr = u / (kc >> 4), cc = u % (kc >> 4);
+      *(v4i*)(hb_lds + rr * HB_LD + cc * 16) = *(const v4i*)(tab + (int64_t)rr * Npad + c0 + cc * 16);
+    }
+    __syncthreads();
+    // K blocks of 1024 individuals (768 / 512 / 256 at the end): lane (., h) takes the block's half h, i.e. up to 64
+    // contiguous image bytes of its SNP -- a whole 128-byte line per SNP and block between the two halves
+    for (int k0 = 0; k0 < kc; k0 += 1024) {
+      const int half = min(1024, kc - k0) >> 1;                    // 512, 384, 256 or 128 individuals
+      const int nq = half >> 7;                                    // 16-byte pieces per lane: 4, 3, 2, 1
+      const int kb = c0 + k0 + h * half;
+      uint4 x0[4], x1[4];
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+        if (qd < nq) { x0[qd] = *(const uint4*)(p0 + (kb >> 3) + qd * 16); x1[qd] = *(const uint4*)(p1 + (kb >> 3) + qd * 16); }
+      const char* tl = hb_lds + (r & 7) * HB_LD + (k0 + h * half);
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        if (qd >= nq) break;
+        const unsigned w0[4] = {x0[qd].x, x0[qd].y, x0[qd].z, x0[qd].w}, w1[4] = {x1[qd].x, x1[qd].y, x1[qd].z, x1[qd].w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          v4i a = v4i{0, 0, 0, 0};
+          if (row) a = *(const v4i*)(tl + qd * 128 + 16 * t);
+          acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, expand16_bits((w0[t >> 1] >> (16 * (t & 1))) & 0xffffu), acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, expand16_bits((w1[t >> 1] >> (16 * (t & 1))) & 0xffffu), acc1, 0, 0, 0);
+        }
+      }
+    }
+  }
+  *(v4i*)(raw2 + (m0 + r) * 8 + h * 4) = v4i{acc0[0], acc0[1], acc0[2], acc0[3]};
+  *(v4i*)(raw2 + (m0 + 32 + r) * 8 + h * 4) = v4i{acc1[0], acc1[1], acc1[2], acc1[3]};
+}
+
+void launch_lin_hi_bits(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, int* raw2) {
+  const int lds = 8 * HB_LD;
+  hipFuncSetAttribute((const void*)lin_hi_bits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(lin_hi_bits_kernel, dim3((unsigned)(g->Mpad / 256)), dim3(256), lds, ctx->stream, g->hi2,
+                     (int64_t)(g->Npad >> 3), g->Mpad, g->Npad, md.lin_tab, raw2);
 }
 
 void launch_scan_finalize(mmg_ctx* ctx, const mmg_geno* g, const mmg_scan_model& md, mmg_scan_result& res,

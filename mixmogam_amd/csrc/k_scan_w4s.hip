@@ -328,7 +328,11 @@ bool scan_lin_usable(const mmg_geno* g, const mmg_scan_model& md) {
   const char* e = std::getenv("MMG_SCAN_FUSED_LINEAR");     // =0: keep the separate finalize pass over the store (A/B, tests)
   const bool off = e && e[0] == '0';
   // (diagnostic builds: only the production kernel writes the by-products)
-  return !off && md.lin_rows && g->smax <= 1 && g->sneg == 0 && std::getenv("MMG_W4S_ABL") == nullptr &&
+  // the by-products are linear in s: valid for any store; what a binary store adds is s^2 = s.  A store of 0/1/2 codes takes
+  // them once its [s = 2] bit image exists (mmg_internal.h:mmg_geno::hi2, api.hip:hi2_prepare) -- the finalize step then
+  // corrects sum A_ii s_i^2 and sum s_i^2 from the image
+  const bool values_ok = g->sneg == 0 && (g->smax <= 1 || (g->smax == 2 && md.lin_tab != nullptr && geno_hi2_ready(g)));
+  return !off && md.lin_rows && values_ok && std::getenv("MMG_W4S_ABL") == nullptr &&
          std::getenv("MMG_SCAN_KERNEL") == nullptr && std::getenv("MMG_ABLATE") == nullptr &&
          std::getenv("MMG_W4S_DIST") == nullptr;
 }

@@ -59,6 +59,15 @@ struct mmg_geno {
   // as long as the store is binary (smax <= 1, sneg == 0).  nullptr: MMG_FP4_TWIN=0, or the allocation failed (then the
   // kinship call writes a scratch image itself, as in round 3: 1.3 ms of a 6.6 ms call at N = 5000 x M = 1e6).
   uint8_t* fp4 = nullptr;
+  // [s = 2] bit image of a store of 0/1/2 codes (/root/reference/plink2hdf5.py:171-179), for the scan's finalize step
+  // (k_scan.hip:lin_hi_bits_kernel): [Mcap x Npad / 8], bit k of a row (LSB first) = bit 1 of genotype byte k.  With it
+  // sum_i A_ii s_i^2 = sum_i A_ii s_i + 2 sum_i A_ii [s_i = 2] needs 1/8 of the store's bytes instead of all of them.
+  // Built on the SECOND scan of the same content (hi2_version == version): a store that is scanned once -- a streamed chunk --
+  // keeps the finalize pass over its bytes, which costs what building the image would.
+  uint8_t* hi2 = nullptr;
+  uint64_t hi2_version = ~0ull;       // the write version the image was built from
+  uint64_t scanned_version = ~0ull;   // the write version the scans below saw
+  int scans_of_version = 0;
 };
 
 enum { EV_KIN = 0, EV_QUAD = 1, EV_FIN = 2, EV_PERM = 3, EV_EIGH = 4, EV_PACK = 5, EV_QUAD2 = 6, EV_ROT = 7, EV_MULTI = 8, EV_GRM = 9, EV_COUNT = 10 };
@@ -94,6 +103,7 @@ struct mmg_scan_model {
   // diag(A) and a row of ones, so that the quadratic-form GEMM yields s.w, sum diag_i s_i and sum s_i of every SNP as
   // a by-product (binary stores) and the finalize pass need not read the genotype store a second time
   bool lin_rows = false;
+  int8_t* lin_tab = nullptr;     // [8][Npad]: the seven digit rows of diag(A) and a row of ones once more, for lin_hi_bits_kernel
   double lin_step_w = 0.0, lin_step_d = 0.0;
 };
 
@@ -114,6 +124,7 @@ struct mmg_scan_result {
   unsigned long long* q2 = nullptr;
   int64_t q2_cap = 0;
   int* linraw = nullptr;         // [cap][16] raw accumulators of the model's linear rows (k_scan_w4s.hip LIN)
+  int* linraw2 = nullptr;        // [cap][8] stores of 0/1/2 codes: digits of sum_i A_ii [s_i = 2] and the count of 2s (lazily)
   const void* geno = nullptr;    // the store the last scan ran on and its write version (mmg_emmax_perm_after_scan)
   uint64_t geno_version = 0;
   // what the last scan did (mmg_scan_last_stats)
@@ -270,7 +281,10 @@ bool scan_lin_usable(const mmg_geno* g, const mmg_scan_model& md);   // by-produ
 void launch_scan_finalize(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, mmg_scan_result&,
                           double h0_rss, int32_t df2, double lnbeta, bool with_p = true, double bias = 0.0);
 void launch_scan_finalize_lin(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, mmg_scan_result&, double h0_rss,
-                              int32_t df2, double lnbeta, bool with_p = true, double bias = 0.0);
+                              int32_t df2, double lnbeta, bool with_p = true, double bias = 0.0, const int* raw2 = nullptr);
+void launch_pack_hi_bits(mmg_ctx*, const mmg_geno*);                                   // g->d -> g->hi2
+void launch_lin_hi_bits(mmg_ctx*, const mmg_geno*, const mmg_scan_model&, int* raw2);  // g->hi2 x md.lin_tab -> raw2 [Mpad][8]
+inline bool geno_hi2_ready(const mmg_geno* g) { return g->hi2 != nullptr && g->hi2_version == g->version; }
 void launch_scan_select(mmg_ctx*, const mmg_scan_result&, int64_t M, double sig_unit, double target, unsigned long long* cnt,
                         bool use_F = true);
 void launch_gather_rows(mmg_ctx*, const mmg_geno*, const int64_t* idx, int64_t cnt, int8_t* Sc);

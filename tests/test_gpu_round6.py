@@ -354,3 +354,65 @@ def test_streamed_two_bit_container_of_diploid_codes(ctx, tmp_path):
         if p > 1e-290:
             worst = max(worst, abs(ps[gi] / p - 1))
     assert worst < 1e-6
+
+
+@pytest.mark.parametrize("n,m,adaptive,rows", [(150, 900, 0, True), (700, 2600, 4, True), (1100, 2000, 4, True),
+                                                (240, 700, 4, True), (241, 700, 4, False), (256, 500, 0, False)])
+def test_diploid_store_scan_takes_its_square_terms_from_the_bit_image(ctx, monkeypatch, n, m, adaptive, rows):
+    """Stores of 0/1/2 codes (plink2hdf5.py:171-179), where s^2 != s.  The linear by-products of the scan GEMM (s.w, sum s,
+    sum A_ii s_i) hold for any store; sum A_ii s_i^2 = sum A_ii s_i + 2 sum A_ii [s_i = 2] and sum s^2 = sum s + 2 #[s = 2]
+    take their second terms from a bit image of the store (1/8 of its bytes; lin_hi_bits_kernel), built on the SECOND scan of
+    the same content -- the first scan, and every scan when the model has no free rows for the linear terms (N mod 256 >
+    240), is the finalize pass over the store's bytes, bit-identical to MMG_SCAN_FUSED_LINEAR=0.  Both against float64
+    numpy; a write to the store invalidates the image."""
+    rng = np.random.RandomState(1000 + n)
+    f = rng.uniform(0.05, 0.95, size=(m, 1))
+    snps = ((rng.random_sample((m, n)) < f).astype(np.int8) + (rng.random_sample((m, n)) < f).astype(np.int8))
+    snps[3] = 0
+    snps[4] = 2
+    snps[5] = 1
+    B = rng.standard_normal((n, 20)) / 4
+    A = np.eye(n) * rng.uniform(0.5, 3.0, size=n) + B @ B.T / n
+    A = 0.5 * (A + A.T)
+    w = rng.standard_normal(n) * np.exp(rng.uniform(-6, 2, size=n))
+    g = ctx.geno(snps)
+    ctx.scan_set_model(A, w, adaptive)
+
+    def check(out, S):
+        scale = np.maximum(np.abs(S) @ np.abs(w), 1e-300)
+        den = np.einsum("ij,ij->i", S @ A, S)
+        assert np.max(np.abs(out["dot"] - S @ w) / scale) < 1e-13
+        assert np.array_equal(out["sum"], S.sum(1))
+        ok = den > 1e-6 * np.abs(den).max()
+        assert rel(out["den"][ok], den[ok]) < 1e-7
+
+    monkeypatch.setenv("MMG_SCAN_FUSED_LINEAR", "0")
+    plain = ctx.scan(g, 5e6, n - 2, stats=True)
+    monkeypatch.delenv("MMG_SCAN_FUSED_LINEAR")
+    S = snps.astype(np.float64)
+    check(plain, S)
+    g2 = ctx.geno(snps)                                                      # a fresh store: scan count 0
+    first = ctx.scan(g2, 5e6, n - 2, stats=True)
+    for k in ("dot", "den", "ps", "rss"):
+        assert np.array_equal(first[k], plain[k]), k                         # first scan: the same route
+    second = ctx.scan(g2, 5e6, n - 2, stats=True)
+    check(second, S)
+    assert rel(second["den"], plain["den"]) < 1e-13
+    keep = plain["ps"] > 1e-280
+    assert rel(second["ps"][keep], plain["ps"][keep]) < 1e-11
+    assert np.array_equal(second["rss"][3], plain["rss"][3])                 # monomorphic 0: rss = h0_rss either way
+    same = all(np.array_equal(second[k], plain[k]) for k in ("dot", "den", "ps"))
+    assert same != rows, "the image route was %staken" % ("not " if rows else "")
+    third = ctx.scan(g2, 5e6, n - 2, stats=True)
+    for k in ("dot", "den", "ps", "rss"):
+        assert np.array_equal(third[k], second[k]), k                        # reproducible
+    # a write invalidates the image: new rows, two more scans, both right
+    snps2 = snps.copy()
+    snps2[10:60] = snps[200:250]
+    snps2[7] = 2 - snps[7]
+    g2.upload(snps2[:64], 0)
+    S2 = snps2.astype(np.float64)
+    check(ctx.scan(g2, 5e6, n - 2, stats=True), S2)
+    check(ctx.scan(g2, 5e6, n - 2, stats=True), S2)
+    g.close()
+    g2.close()
