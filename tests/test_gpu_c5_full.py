@@ -47,7 +47,7 @@ def test_config5_individuals_two_bit_rows_of_diploid_codes_streamed(capsys):
     from mixmogam_amd import hdf5_data
     hdf5_data.release_pools()
     cmd = [sys.executable, os.path.join(ROOT, "tools", "c5_stream.py"), "--world", "1", "--lazy", "--packed", "--packed-bits", "2",
-           "--m-total", "1000000", "--samples", "8"]
+           "--m-total", "1000000", "--samples", "5"]
     r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, MMG_REML_VERBOSE="1"), stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=600)
     with capsys.disabled():
@@ -56,7 +56,7 @@ def test_config5_individuals_two_bit_rows_of_diploid_codes_streamed(capsys):
     assert r.returncode == 0, r.stdout[-3000:]
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert rec["N"] == 50000 and rec["M_share"] == 1000000 and rec["codes"].startswith("0/1/2")
-    assert rec["n_sampled"] >= 8
+    assert rec["n_sampled"] >= 5
     assert rec["max_rel_p_err_vs_host_f64"] < 1e-6
     assert rec["h0_rss_rel_err_vs_host_f64"] < 1e-9
     assert "band reduction" in rec["route"]
