@@ -416,3 +416,41 @@ def test_diploid_store_scan_takes_its_square_terms_from_the_bit_image(ctx, monke
     check(ctx.scan(g2, 5e6, n - 2, stats=True), S2)
     g.close()
     g2.close()
+
+
+def test_mlmm_on_a_store_of_diploid_codes_with_and_without_the_bit_image(ctx, monkeypatch):
+    """MLMM scans ONE resident store once per step (linear_models.py:2543-2923): on 0/1/2 codes the first scan takes the
+    finalize pass over the store, every later one the [s = 2] bit image.  Same step statistics, cofactors and p-values as
+    with the image switched off (MMG_SCAN_HI2=0), and the first step's p-values against the oracle's emmax."""
+    from mixmogam_amd import linear_models as lm, kinship
+    from oracle import emmax_oracle as orc
+    rng = np.random.RandomState(61)
+    n, m = 300, 2500
+    f = rng.uniform(0.1, 0.9, size=(m, 1))
+    snps = ((rng.random_sample((m, n)) < f).astype(np.int8) + (rng.random_sample((m, n)) < f).astype(np.int8))
+    snps = snps[(snps.std(1) > 0)]
+    m = len(snps)
+    K = orc.calc_ibd_kinship(snps)
+    y = 0.9 * snps[100] - 0.7 * snps[900] + 0.5 * snps[1700] + rng.standard_normal(n)
+    kw = dict(num_steps=4, forward_backwards=True, snps=snps, positions=list(range(m)), chromosomes=[1] * m, ctx=ctx,
+              save_pvals=True)
+    a = lm.mlmm(list(y), K, **kw)
+    monkeypatch.setenv("MMG_SCAN_HI2", "0")
+    b = lm.mlmm(list(y), K, **kw)
+    monkeypatch.delenv("MMG_SCAN_HI2")
+    assert len(a["step_info_list"]) == len(b["step_info_list"]) >= 5
+    for sa, sb in zip(a["step_info_list"], b["step_info_list"]):
+        assert [c[1] for c in sa["cofactors"]] == [c[1] for c in sb["cofactors"]]
+        for k in ("pseudo_heritability", "bic", "e_bic", "m_bic", "min_pval", "rss", "mahalanobis_rss"):
+            if sa[k] is None:
+                assert sb[k] is None
+            else:
+                assert rel(np.asarray(sa[k], dtype=np.float64), np.asarray(sb[k], dtype=np.float64)) < 1e-9, k
+        if "ps" in sa and sa["ps"] is not None:
+            pa, pb = np.asarray(sa["ps"]), np.asarray(sb["ps"])
+            ok = pb > 1e-280
+            assert rel(pa[ok], pb[ok]) < 1e-9
+    assert a["opt_dict"] == b["opt_dict"]
+    first = np.asarray(a["step_info_list"][0]["ps"])
+    want = orc.emmax(snps, y, K)["ps"]
+    assert rel(first, want) < 1e-6
