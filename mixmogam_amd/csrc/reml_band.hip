@@ -735,7 +735,13 @@ constexpr int SY_SA = 80, SY_ST = 66;
 // one workgroup per 64 output rows is 40-78 workgroups on 256 CUs, each a chain of ~40 tile steps
 // TRI: A is LOWER TRIANGULAR instead of symmetric (the triangular inverse of reml_chol.hip: X21 = -X22 (L21 X11)): the tiles
 // right of the diagonal are skipped and the diagonal tile is its lower half alone.
-template <bool TRI>
+// Round 6: interior tiles (all 64 rows and all 64 k inside the matrix -- every tile but those of the last block row / column)
+// are fetched by 32 unconditional loads per thread and multiplied from LDS with the fragments of step ks + 1 read while the
+// MFMAs of step ks run.  Before, every load carried its own bounds predicate: the compiler turned the 32 loads of a tile into
+// as many exec-mask branches with a vmcnt(0) wait each, and the kernel ran its memory phase and its MFMA phase one after the
+// other (timing ablations at n = 4936: 95 us as it was, 59 without MFMAs, 82 without loads; the MFMAs alone take 41).
+// ABL (make EXPERIMENTS=1, MMG_SYM_ABL; WRONG results): 1 = no MFMAs, 2 = no global loads after the first tile.
+template <bool TRI, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void sym_skinny_kernel(const double* __restrict__ A, int64_t lda, int n,
                                                             const double* __restrict__ V, double* __restrict__ Wout) {
   __shared__ double As[64 * SY_SA];
@@ -754,9 +760,20 @@ __global__ __launch_bounds__(256, 2) void sym_skinny_kernel(const double* __rest
   // 32-bit element offsets from wave-uniform tile bases (scalar base + one VGPR per address)
   const int lo = tid & 63, h0 = tid >> 6;
   const int ldi = (int)lda;
+  const bool rows_full = I0 + 64 <= n;
   auto fetch = [&](int kt) {
     const int K0 = kt * 64;
     const double* vb = V + K0;
+    if (rows_full && K0 + 64 <= n) {
+      // interior tile: stored tile (k <= own rows; the diagonal tile whole -- its upper half is masked on the way into LDS)
+      // or the mirrored one, both as they lie in memory
+      const double* ab = K0 <= I0 ? A + (int64_t)K0 * lda + I0 : A + (int64_t)I0 * lda + K0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) rv[i] = vb[lo + (h0 + 4 * i) * n];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ra[i] = ab[lo + (h0 + 4 * i) * ldi];
+      return;
+    }
     const bool vin = K0 + lo < n;
 #pragma unroll
     for (int i = 0; i < 16; ++i) rv[i] = vin ? vb[lo + (h0 + 4 * i) * n] : 0.0;                            // k = lo, col = hi
@@ -782,31 +799,66 @@ __global__ __launch_bounds__(256, 2) void sym_skinny_kernel(const double* __rest
     const int K0 = kt * 64;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int hi = h0 + 4 * i;
-      Vt[hi * SY_ST + lo] = rv[i];
-      if (K0 < I0) As[hi * SY_SA + lo] = ra[i];
-      else if (K0 > I0) As[hi * SY_ST + lo] = ra[i];
-      else if (TRI) As[hi * SY_SA + lo] = ra[i];               // (zero above the diagonal: fetch() loaded the lower half only)
-      else if (lo >= hi) { As[hi * SY_SA + lo] = ra[i]; As[lo * SY_SA + hi] = ra[i]; }
+    for (int i = 0; i < 16; ++i) Vt[(h0 + 4 * i) * SY_ST + lo] = rv[i];
+    if (K0 < I0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) As[(h0 + 4 * i) * SY_SA + lo] = ra[i];
+    } else if (K0 > I0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) As[(h0 + 4 * i) * SY_ST + lo] = ra[i];
+    } else if (TRI) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) As[(h0 + 4 * i) * SY_SA + lo] = lo >= h0 + 4 * i ? ra[i] : 0.0;          // zero above the diagonal
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int hi = h0 + 4 * i;
+        if (lo >= hi) { As[hi * SY_SA + lo] = ra[i]; As[lo * SY_SA + hi] = ra[i]; }
+      }
     }
     __syncthreads();
-    if (kt + 1 < kt1) fetch(kt + 1);
-    if (K0 <= I0) {
-#pragma unroll 4
-      for (int ks = 0; ks < 16; ++ks) {
-        const double bv = Vt[(16 * w + lr) * SY_ST + 4 * ks + lk];
+    if (kt + 1 < kt1 && ABL != 2) fetch(kt + 1);
+    if (ABL == 1) {
+      acc[0][0] += As[tid] + Vt[tid];
+    } else if (K0 <= I0) {
+      const double* ap = As + lk * SY_SA + lr;                 // + 4 ks SY_SA + 16 rt
+      const double* bp = Vt + (16 * w + lr) * SY_ST + lk;      // + 4 ks
+      double a_cur[4], b_cur = bp[0];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-          acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(4 * ks + lk) * SY_SA + 16 * rt + lr], bv, acc[rt], 0, 0, 0);
+      for (int rt = 0; rt < 4; ++rt) a_cur[rt] = ap[16 * rt];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        double a_nxt[4] = {0.0, 0.0, 0.0, 0.0}, b_nxt = 0.0;
+        if (ks < 15) {
+          b_nxt = bp[4 * (ks + 1)];
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) a_nxt[rt] = ap[4 * (ks + 1) * SY_SA + 16 * rt];
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[rt], b_cur, acc[rt], 0, 0, 0);
+        b_cur = b_nxt;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) a_cur[rt] = a_nxt[rt];
       }
     } else {
-#pragma unroll 4
-      for (int ks = 0; ks < 16; ++ks) {
-        const double bv = Vt[(16 * w + lr) * SY_ST + 4 * ks + lk];
+      const double* ap = As + lr * SY_ST + lk;                 // + 16 rt SY_ST + 4 ks
+      const double* bp = Vt + (16 * w + lr) * SY_ST + lk;
+      double a_cur[4], b_cur = bp[0];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-          acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(As[(16 * rt + lr) * SY_ST + 4 * ks + lk], bv, acc[rt], 0, 0, 0);
+      for (int rt = 0; rt < 4; ++rt) a_cur[rt] = ap[16 * rt * SY_ST];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        double a_nxt[4] = {0.0, 0.0, 0.0, 0.0}, b_nxt = 0.0;
+        if (ks < 15) {
+          b_nxt = bp[4 * (ks + 1)];
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) a_nxt[rt] = ap[16 * rt * SY_ST + 4 * (ks + 1)];
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_cur[rt], b_cur, acc[rt], 0, 0, 0);
+        b_cur = b_nxt;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) a_cur[rt] = a_nxt[rt];
       }
     }
   }
@@ -1076,6 +1128,12 @@ static int band_reduce_cqr(mmg_ctx* ctx, mmg_reml* r, bool* suspect) {
     // ---- W = A22 V
     // ~3 tile steps per workgroup while the launch stays within ~1024 workgroups
     const int S = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)smax, 1024 / ((n + 63) / 64), (n + 63) / 64 / 3}));
+#ifdef MMG_EXPERIMENTS
+    static const int sym_abl = [] { const char* e = std::getenv("MMG_SYM_ABL"); return e ? std::atoi(e) : 0; }();
+    if (sym_abl == 1) hipLaunchKernelGGL((sym_skinny_kernel<false, 1>), dim3((unsigned)((n + 63) / 64), S), dim3(256), 0, st, A22, N, (int)n, V, S > 1 ? Wp : W);
+    else if (sym_abl == 2) hipLaunchKernelGGL((sym_skinny_kernel<false, 2>), dim3((unsigned)((n + 63) / 64), S), dim3(256), 0, st, A22, N, (int)n, V, S > 1 ? Wp : W);
+    else
+#endif
     hipLaunchKernelGGL(sym_skinny_kernel<false>, dim3((unsigned)((n + 63) / 64), S), dim3(256), 0, st, A22, N, (int)n, V, S > 1 ? Wp : W);
     if (S > 1) hipLaunchKernelGGL(wsum_kernel, dim3((unsigned)((n * b + 255) / 256)), dim3(256), 0, st, Wp, S, n * b, W);
     lap(1, tp);
