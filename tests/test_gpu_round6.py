@@ -416,6 +416,14 @@ def test_diploid_store_scan_takes_its_square_terms_from_the_bit_image(ctx, monke
     check(ctx.scan(g2, 5e6, n - 2, stats=True), S2)
     g.close()
     g2.close()
+    if rows:                                                                 # MMG_SCAN_HI2=1: the image already on the first scan
+        monkeypatch.setenv("MMG_SCAN_HI2", "1")
+        g3 = ctx.geno(snps)
+        forced = ctx.scan(g3, 5e6, n - 2, stats=True)
+        monkeypatch.delenv("MMG_SCAN_HI2")
+        g3.close()
+        for k in ("dot", "den", "ps", "rss"):
+            assert np.array_equal(forced[k], second[k]), k
 
 
 def test_mlmm_on_a_store_of_diploid_codes_with_and_without_the_bit_image(ctx, monkeypatch):
